@@ -1,0 +1,810 @@
+// Batched 1-D spectral transforms along one axis of [outer][n][inner] float64 arrays, gfx950.
+//
+// One workgroup transforms B "line pairs" held in LDS.  Two real lines are packed into one
+// complex FFT (real part = line a, imaginary part = line b) so no flop or LDS byte is wasted on
+// Hermitian redundancy.  When the transformed axis is strided (inner > 1) the two lines of a pair
+// are neighbours along the contiguous inner axis, i.e. one 16-byte load; when the axis is the
+// contiguous one (inner == 1) the two lines are neighbours along the outer axis.
+//
+// The FFT itself is a mixed-radix (2,3,4,5,7) Stockham autosort in LDS, in place with register
+// staging (each thread holds <= 16 complex values per pass), twiddles from an exact table.
+// All of the reference's separate pack / scale / pad / truncate NumPy passes
+// (core/transforms.py:469-509, 726-746, 844-890) are fused into the load and store phases, so each
+// transform is exactly one HBM read of its input and one HBM write of its output.
+#include "ddh_common.h"
+
+#include <cmath>
+
+namespace ddh {
+
+enum FftKind { K_RFFT = 0, K_CHEB = 1, K_CFFT = 2 };
+enum FftMode { RFFT_FWD = 0, RFFT_BWD, CHEB_FWD, CHEB_BWD, CFFT_FWD, CFFT_BWD };
+
+constexpr int MAX_RADIX_PASSES = 16;
+constexpr int MAX_BANDS = 4;
+
+struct FftDev {
+    int N;       // grid size = FFT length
+    int M;       // coefficient size
+    int K;       // Fourier: largest retained wavenumber
+    int nradix;
+    int radix[MAX_RADIX_PASSES];
+    const double2 *tw;     // exp(-2 pi i q / N)
+    const double2 *half;   // exp(-i pi k / (2N))
+    const double *fscale;  // Chebyshev forward scale per k (includes (-1)^k)
+    const double *bscale;  // Chebyshev backward scale per k
+    int nbands;
+    int gcd_off;           // gcd of the non-zero band offsets (independent back-substitution chains)
+    int boff[MAX_BANDS];
+    const double *bands;   // [nbands][M]
+    int B;                 // line pairs per workgroup
+    int ld;                // LDS leading dimension of the FFT buffer (>= N)
+};
+
+struct FftPlan : HandleBase {
+    FftDev dev;
+    int tkind;
+    void *d_tw = nullptr, *d_half = nullptr, *d_fscale = nullptr, *d_bscale = nullptr, *d_bands = nullptr;
+    ~FftPlan() override {
+        (void)hipFree(d_tw);
+        (void)hipFree(d_half);
+        (void)hipFree(d_fscale);
+        (void)hipFree(d_bscale);
+        (void)hipFree(d_bands);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// complex helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// multiply by (sign * i)
+__device__ __forceinline__ double2 muli(double2 a, int sign) {
+    return sign > 0 ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+}
+
+template <int R>
+__device__ __forceinline__ void butterfly(double2 *v, int sign);
+
+template <>
+__device__ __forceinline__ void butterfly<2>(double2 *v, int) {
+    double2 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+}
+template <>
+__device__ __forceinline__ void butterfly<3>(double2 *v, int sign) {
+    const double s = 0.86602540378443864676372317075294;  // sqrt(3)/2
+    double2 t = cadd(v[1], v[2]);
+    double2 d = csub(v[1], v[2]);
+    double2 m = make_double2(v[0].x - 0.5 * t.x, v[0].y - 0.5 * t.y);
+    double2 r = muli(make_double2(s * d.x, s * d.y), sign);
+    v[0] = cadd(v[0], t);
+    v[1] = cadd(m, r);
+    v[2] = csub(m, r);
+}
+template <>
+__device__ __forceinline__ void butterfly<4>(double2 *v, int sign) {
+    double2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]);
+    double2 c = cadd(v[1], v[3]), d = muli(csub(v[1], v[3]), sign);
+    v[0] = cadd(a, c);
+    v[1] = cadd(b, d);
+    v[2] = csub(a, c);
+    v[3] = csub(b, d);
+}
+template <>
+__device__ __forceinline__ void butterfly<5>(double2 *v, int sign) {
+    const double c1 = 0.30901699437494742410229341718282;   // cos(2pi/5)
+    const double c2 = -0.80901699437494742410229341718282;  // cos(4pi/5)
+    const double s1 = 0.95105651629515357211643933337938;   // sin(2pi/5)
+    const double s2 = 0.58778525229247312916870595463907;   // sin(4pi/5)
+    double2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
+    double2 d1 = csub(v[1], v[4]), d2 = csub(v[2], v[3]);
+    double2 m1 = make_double2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+    double2 m2 = make_double2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+    double2 r1 = muli(make_double2(s1 * d1.x + s2 * d2.x, s1 * d1.y + s2 * d2.y), sign);
+    double2 r2 = muli(make_double2(s2 * d1.x - s1 * d2.x, s2 * d1.y - s1 * d2.y), sign);
+    v[0] = cadd(v[0], cadd(t1, t2));
+    v[1] = cadd(m1, r1);
+    v[4] = csub(m1, r1);
+    v[2] = cadd(m2, r2);
+    v[3] = csub(m2, r2);
+}
+template <>
+__device__ __forceinline__ void butterfly<7>(double2 *v, int sign) {
+    // direct 7-point DFT (rare size): X_u = sum_t v_t exp(sign 2 pi i t u / 7)
+    const double c[7] = {1.0, 0.62348980185873353052500488400424, -0.22252093395631440428890256449679,
+                         -0.90096886790241912623610231950745, -0.90096886790241912623610231950745,
+                         -0.22252093395631440428890256449679, 0.62348980185873353052500488400424};
+    const double s[7] = {0.0, 0.78183148246802980870844452667406, 0.97492791218182360701813168299393,
+                         0.43388373911755812047576833284836, -0.43388373911755812047576833284836,
+                         -0.97492791218182360701813168299393, -0.78183148246802980870844452667406};
+    double2 x[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) x[t] = v[t];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+        double2 acc = x[0];
+#pragma unroll
+        for (int t = 1; t < 7; ++t) {
+            const int q = (t * u) % 7;
+            double2 w = make_double2(c[q], sign > 0 ? s[q] : -s[q]);
+            acc = cadd(acc, cmul(x[t], w));
+        }
+        v[u] = acc;
+    }
+}
+
+// One Stockham pass of radix R over B lines of length N held in buf[line*ld + j].
+template <int R>
+__device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int Ns,
+                                         const double2 *__restrict__ tw, int sign, int tid, int T) {
+    constexpr int MAXI = 16 / R;
+    const int nb = N / R;
+    const int total = nb * B;
+    const int twstep = nb / Ns;  // N / (Ns*R)
+    double2 v[MAXI][R];
+    int jsave[MAXI], ksave[MAXI], lsave[MAXI];
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+        const int w = tid + it * T;
+        if (w < total) {
+            const int line = w / nb;
+            const int j = w - line * nb;
+            const int k = j % Ns;
+            const double2 *x = buf + line * ld;
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[it][t] = x[j + t * nb];
+            if (Ns > 1) {
+#pragma unroll
+                for (int t = 1; t < R; ++t) {
+                    double2 wq = tw[t * k * twstep];
+                    if (sign > 0) wq.y = -wq.y;
+                    v[it][t] = cmul(v[it][t], wq);
+                }
+            }
+            butterfly<R>(v[it], sign);
+            jsave[it] = j;
+            ksave[it] = k;
+            lsave[it] = line;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+        const int w = tid + it * T;
+        if (w < total) {
+            double2 *x = buf + lsave[it] * ld;
+            const int j0 = (jsave[it] - ksave[it]) * R + ksave[it];
+#pragma unroll
+            for (int u = 0; u < R; ++u) x[j0 + u * Ns] = v[it][u];
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void lds_fft(double2 *buf, const FftDev &p, int sign, int tid, int T) {
+    int Ns = 1;
+    for (int i = 0; i < p.nradix; ++i) {
+        const int R = p.radix[i];
+        switch (R) {
+            case 2: fft_pass<2>(buf, p.ld, p.B, p.N, Ns, p.tw, sign, tid, T); break;
+            case 3: fft_pass<3>(buf, p.ld, p.B, p.N, Ns, p.tw, sign, tid, T); break;
+            case 4: fft_pass<4>(buf, p.ld, p.B, p.N, Ns, p.tw, sign, tid, T); break;
+            case 5: fft_pass<5>(buf, p.ld, p.B, p.N, Ns, p.tw, sign, tid, T); break;
+            default: fft_pass<7>(buf, p.ld, p.B, p.N, Ns, p.tw, sign, tid, T); break;
+        }
+        Ns *= R;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pair addressing.  INNER: pairs along the contiguous inner axis; otherwise (inner == 1) pairs of
+// adjacent outer lines.
+// ------------------------------------------------------------------------------------------------
+template <bool INNER>
+struct PairIO {
+    long outer_idx;  // INNER only
+    long inner;      // INNER only
+    long nlines;     // !INNER: number of real lines (= outer)
+    bool vec;        // INNER: inner even -> aligned double2 access
+
+    __device__ __forceinline__ double2 load(const double *base, long n_axis, long j, long q) const {
+        if (INNER) {
+            const double *p = base + ((outer_idx * n_axis + j) * inner + 2 * q);
+            if (vec) return *reinterpret_cast<const double2 *>(p);
+            double a = p[0];
+            double b = (2 * q + 1 < inner) ? p[1] : 0.0;
+            return make_double2(a, b);
+        } else {
+            const double *p = base + (2 * q) * n_axis + j;
+            double a = p[0];
+            double b = (2 * q + 1 < nlines) ? p[n_axis] : 0.0;
+            return make_double2(a, b);
+        }
+    }
+    __device__ __forceinline__ void store(double *base, long n_axis, long j, long q, double2 v) const {
+        if (INNER) {
+            double *p = base + ((outer_idx * n_axis + j) * inner + 2 * q);
+            if (vec) {
+                *reinterpret_cast<double2 *>(p) = v;
+            } else {
+                p[0] = v.x;
+                if (2 * q + 1 < inner) p[1] = v.y;
+            }
+        } else {
+            double *p = base + (2 * q) * n_axis + j;
+            p[0] = v.x;
+            if (2 * q + 1 < nlines) p[n_axis] = v.y;
+        }
+    }
+};
+
+// item -> (axis index j, pair slot b) so that global accesses coalesce
+template <bool INNER>
+__device__ __forceinline__ void split_item(int w, int B, int n, int &j, int &b) {
+    if (INNER) {
+        b = w % B;
+        j = w / B;
+    } else {
+        j = w % n;
+        b = w / n;
+    }
+}
+
+__device__ __forceinline__ int dct_perm(int j, int N) { return (j & 1) ? (N - 1 - (j >> 1)) : (j >> 1); }
+
+template <int MODE, bool INNER>
+__global__ void __launch_bounds__(1024)
+fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ dst, long outer, long inner,
+                long npairs, unsigned blocks_per_outer) {
+    extern __shared__ double2 lds[];
+    double2 *buf = lds;                 // [B][ld]
+    double2 *cbuf = lds + p.B * p.ld;   // [B][M]   (Chebyshev coefficient staging only)
+    const int tid = threadIdx.x, T = blockDim.x;
+    const unsigned bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    PairIO<INNER> io;
+    long q0;
+    if (INNER) {
+        io.outer_idx = bid / blocks_per_outer;
+        io.inner = inner;
+        io.vec = (inner % 2 == 0);
+        q0 = (long)(bid % blocks_per_outer) * p.B;
+    } else {
+        io.nlines = outer;
+        q0 = (long)bid * p.B;
+    }
+    const int N = p.N, M = p.M, B = p.B, ld = p.ld;
+    const double invN = 1.0 / (double)N;
+
+    // ---------------------------------------------------------------- load + pre-process
+    if (MODE == RFFT_FWD) {
+        for (int w = tid; w < N * B; w += T) {
+            int j, b;
+            split_item<INNER>(w, B, N, j, b);
+            double2 v = make_double2(0.0, 0.0);
+            if (q0 + b < npairs) v = io.load(src, N, j, q0 + b);
+            buf[b * ld + j] = v;
+        }
+    } else if (MODE == RFFT_BWD) {
+        const int K = p.K;
+        // zero the dealiased band K < k < N-K
+        const int nzero = N - 2 * K - 1;
+        for (int w = tid; w < nzero * B; w += T) {
+            int b = w % B, j = w / B;
+            buf[b * ld + K + 1 + j] = make_double2(0.0, 0.0);
+        }
+        if (INNER) {
+            for (int w = tid; w < (K + 1) * B; w += T) {
+                int b = w % B, k = w / B;
+                double2 c = make_double2(0.0, 0.0), s = c;
+                if (q0 + b < npairs) {
+                    c = io.load(src, M, 2 * k, q0 + b);
+                    s = io.load(src, M, 2 * k + 1, q0 + b);
+                }
+                if (k == 0) {
+                    buf[b * ld] = c;  // a0 of line a + i a0 of line b
+                } else {
+                    buf[b * ld + k] = make_double2(0.5 * (c.x - s.y), 0.5 * (s.x + c.y));
+                    buf[b * ld + N - k] = make_double2(0.5 * (c.x + s.y), 0.5 * (c.y - s.x));
+                }
+            }
+        } else {
+            // contiguous lines: element 2k, 2k+1 of each line
+            for (int w = tid; w < (K + 1) * B; w += T) {
+                int k = w % (K + 1), b = w / (K + 1);
+                double2 c = make_double2(0.0, 0.0), s = c;
+                if (q0 + b < npairs) {
+                    c = io.load(src, M, 2 * k, q0 + b);
+                    s = io.load(src, M, 2 * k + 1, q0 + b);
+                }
+                if (k == 0) {
+                    buf[b * ld] = c;
+                } else {
+                    buf[b * ld + k] = make_double2(0.5 * (c.x - s.y), 0.5 * (s.x + c.y));
+                    buf[b * ld + N - k] = make_double2(0.5 * (c.x + s.y), 0.5 * (c.y - s.x));
+                }
+            }
+        }
+    } else if (MODE == CHEB_FWD) {
+        for (int w = tid; w < N * B; w += T) {
+            int j, b;
+            split_item<INNER>(w, B, N, j, b);
+            double2 v = make_double2(0.0, 0.0);
+            if (q0 + b < npairs) v = io.load(src, N, j, q0 + b);
+            buf[b * ld + dct_perm(j, N)] = v;
+        }
+    } else if (MODE == CHEB_BWD) {
+        for (int w = tid; w < M * B; w += T) {
+            int k, b;
+            split_item<INNER>(w, B, M, k, b);
+            double2 v = make_double2(0.0, 0.0);
+            // coefficients beyond the grid size are dropped BEFORE the conversion solve
+            // (transforms.py:878-881)
+            if (q0 + b < npairs && k < N) v = io.load(src, M, k, q0 + b);
+            cbuf[b * M + k] = v;
+        }
+        __syncthreads();
+        if (p.nbands > 0) {
+            // upper-banded back substitution (solve_upper_sparse, transforms.py:876-890):
+            // independent chains k == r (mod gcd_off), both lines of a pair at once.
+            const int g = p.gcd_off;
+            for (int w = tid; w < g * B; w += T) {
+                const int r = w % g, b = w / g;
+                double2 *c = cbuf + b * M;
+                int kstart = M - 1 - ((M - 1 - r) % g);  // largest k < M with k % g == r
+                for (int k = kstart; k >= 0; k -= g) {
+                    double2 acc = c[k];
+                    for (int d = 1; d < p.nbands; ++d) {
+                        const int kk = k + p.boff[d];
+                        if (kk < M) {
+                            const double a = p.bands[d * M + k];
+                            acc.x -= a * c[kk].x;
+                            acc.y -= a * c[kk].y;
+                        }
+                    }
+                    const double inv = 1.0 / p.bands[k];
+                    c[k] = make_double2(acc.x * inv, acc.y * inv);
+                }
+            }
+            __syncthreads();
+        }
+        const int Mk = (M < N) ? M : N;
+        for (int w = tid; w < N * B; w += T) {
+            const int k = w % N, b = w / N;
+            const double2 *c = cbuf + b * M;
+            double2 e = make_double2(0.0, 0.0), f = e;
+            if (k < Mk) {
+                const double s = p.bscale[k];
+                e = make_double2(s * c[k].x, s * c[k].y);
+            }
+            const int kr = N - k;
+            if (k > 0 && kr < Mk) {
+                const double s = p.bscale[kr];
+                f = make_double2(s * c[kr].x, s * c[kr].y);
+            }
+            const double2 h = p.half[k];  // exp(-i pi k / 2N); we need its conjugate
+            const double cr = h.x, ci = -h.y;
+            // V^a = (e.x - i f.x)(cr + i ci), V^b likewise with .y ; Z = V^a + i V^b
+            const double var = e.x * cr + f.x * ci, vai = e.x * ci - f.x * cr;
+            const double vbr = e.y * cr + f.y * ci, vbi = e.y * ci - f.y * cr;
+            buf[b * ld + k] = make_double2(var - vbi, vai + vbr);
+        }
+    } else if (MODE == CFFT_FWD) {
+        // complex lines, no pairing: "pair" slot = one complex line; load() returns (re, im)
+        for (int w = tid; w < N * B; w += T) {
+            int j, b;
+            split_item<INNER>(w, B, N, j, b);
+            double2 v = make_double2(0.0, 0.0);
+            if (q0 + b < npairs) {
+                const long line = q0 + b;
+                const double *ptr = INNER ? src + 2 * ((io.outer_idx * N + j) * inner + line)
+                                          : src + 2 * (line * N + j);
+                v = *reinterpret_cast<const double2 *>(ptr);
+            }
+            buf[b * ld + j] = v;
+        }
+    } else if (MODE == CFFT_BWD) {
+        const int K = p.K;
+        for (int w = tid; w < N * B; w += T) {
+            int j, b;
+            split_item<INNER>(w, B, N, j, b);
+            // fft position j -> wavenumber k in (-N/2, N/2]; keep |k| <= K
+            int k = (j <= N / 2) ? j : j - N;
+            double2 v = make_double2(0.0, 0.0);
+            if (k >= -K && k <= K && q0 + b < npairs) {
+                const long line = q0 + b;
+                const int m = (k >= 0) ? k : M + k;
+                const double *ptr = INNER ? src + 2 * ((io.outer_idx * M + m) * inner + line)
+                                          : src + 2 * (line * M + m);
+                v = *reinterpret_cast<const double2 *>(ptr);
+            }
+            buf[b * ld + j] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- FFT in LDS
+    const int sign = (MODE == RFFT_FWD || MODE == CHEB_FWD || MODE == CFFT_FWD) ? -1 : +1;
+    lds_fft(buf, p, sign, tid, T);
+
+    // ---------------------------------------------------------------- post-process + store
+    if (MODE == RFFT_BWD || MODE == CHEB_BWD) {
+        for (int w = tid; w < N * B; w += T) {
+            int j, b;
+            split_item<INNER>(w, B, N, j, b);
+            if (q0 + b < npairs) {
+                const int pos = (MODE == CHEB_BWD) ? dct_perm(j, N) : j;
+                io.store(dst, N, j, q0 + b, buf[b * ld + pos]);
+            }
+        }
+    } else if (MODE == RFFT_FWD) {
+        const int K = p.K;
+        const int Mh = M / 2;
+        for (int w = tid; w < Mh * B; w += T) {
+            int k, b;
+            split_item<INNER>(w, B, Mh, k, b);
+            if (q0 + b >= npairs) continue;
+            double2 c = make_double2(0.0, 0.0), s = c;
+            if (k == 0) {
+                const double2 z = buf[b * ld];
+                c = make_double2(z.x * invN, z.y * invN);
+            } else if (k <= K) {
+                const double2 z1 = buf[b * ld + k], z2 = buf[b * ld + N - k];
+                c = make_double2((z1.x + z2.x) * invN, (z1.y + z2.y) * invN);
+                s = make_double2((z1.y - z2.y) * invN, (z2.x - z1.x) * invN);
+            }
+            io.store(dst, M, 2 * k, q0 + b, c);
+            io.store(dst, M, 2 * k + 1, q0 + b, s);
+        }
+    } else if (MODE == CHEB_FWD) {
+        const int Mk = (M < N) ? M : N;
+        if (p.nbands == 0) {
+            for (int w = tid; w < M * B; w += T) {
+                int k, b;
+                split_item<INNER>(w, B, M, k, b);
+                if (q0 + b >= npairs) continue;
+                double2 c = make_double2(0.0, 0.0);
+                if (k < Mk) {
+                    const double2 z1 = buf[b * ld + k], z2 = buf[b * ld + ((k == 0) ? 0 : N - k)];
+                    const double2 h = p.half[k];
+                    const double s = p.fscale[k];
+                    c.x = s * ((z1.x + z2.x) * h.x - (z1.y - z2.y) * h.y);
+                    c.y = s * ((z1.y + z2.y) * h.x - (z2.x - z1.x) * h.y);
+                }
+                io.store(dst, M, k, q0 + b, c);
+            }
+        } else {
+            for (int w = tid; w < M * B; w += T) {
+                const int k = w % M, b = w / M;
+                double2 c = make_double2(0.0, 0.0);
+                if (k < Mk) {
+                    const double2 z1 = buf[b * ld + k], z2 = buf[b * ld + ((k == 0) ? 0 : N - k)];
+                    const double2 h = p.half[k];
+                    const double s = p.fscale[k];
+                    c.x = s * ((z1.x + z2.x) * h.x - (z1.y - z2.y) * h.y);
+                    c.y = s * ((z1.y + z2.y) * h.x - (z2.x - z1.x) * h.y);
+                }
+                cbuf[b * M + k] = c;
+            }
+            __syncthreads();
+            // forward_conversion apply (transforms.py:862-874): c'_k = sum_d C[k,k+off_d] c_{k+off_d}
+            for (int w = tid; w < M * B; w += T) {
+                int k, b;
+                split_item<INNER>(w, B, M, k, b);
+                if (q0 + b >= npairs) continue;
+                const double2 *c = cbuf + b * M;
+                double2 acc = make_double2(0.0, 0.0);
+                for (int d = 0; d < p.nbands; ++d) {
+                    const int kk = k + p.boff[d];
+                    if (kk < M) {
+                        const double a = p.bands[d * M + k];
+                        acc.x += a * c[kk].x;
+                        acc.y += a * c[kk].y;
+                    }
+                }
+                io.store(dst, M, k, q0 + b, acc);
+            }
+        }
+    } else if (MODE == CFFT_FWD) {
+        const int K = p.K;
+        for (int w = tid; w < M * B; w += T) {
+            int m, b;
+            split_item<INNER>(w, B, M, m, b);
+            if (q0 + b >= npairs) continue;
+            // coefficient slot m -> wavenumber (transforms.py:201-208): k = m for m <= KM else m - M
+            const int KM = (M - 1) / 2;
+            const int k = (m <= KM) ? m : m - M;
+            double2 v = make_double2(0.0, 0.0);
+            if (k >= -K && k <= K && !(2 * m == M)) {
+                const double2 z = buf[b * ld + ((k >= 0) ? k : N + k)];
+                v = make_double2(z.x * invN, z.y * invN);
+            }
+            const long line = q0 + b;
+            double *ptr = INNER ? dst + 2 * ((io.outer_idx * M + m) * inner + line) : dst + 2 * (line * M + m);
+            *reinterpret_cast<double2 *>(ptr) = v;
+        }
+    } else if (MODE == CFFT_BWD) {
+        for (int w = tid; w < N * B; w += T) {
+            int j, b;
+            split_item<INNER>(w, B, N, j, b);
+            if (q0 + b >= npairs) continue;
+            const long line = q0 + b;
+            double *ptr = INNER ? dst + 2 * ((io.outer_idx * N + j) * inner + line) : dst + 2 * (line * N + j);
+            *reinterpret_cast<double2 *>(ptr) = buf[b * ld + j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static bool factorize(int n, int *radix, int &nradix) {
+    nradix = 0;
+    while (n % 4 == 0) { radix[nradix++] = 4; n /= 4; }
+    while (n % 2 == 0) { radix[nradix++] = 2; n /= 2; }
+    while (n % 3 == 0) { radix[nradix++] = 3; n /= 3; }
+    while (n % 5 == 0) { radix[nradix++] = 5; n /= 5; }
+    while (n % 7 == 0) { radix[nradix++] = 7; n /= 7; }
+    if (nradix == 0 && n == 1) return true;  // N == 1
+    return n == 1 && nradix <= MAX_RADIX_PASSES;
+}
+
+template <typename T>
+static int upload(void **dptr, const std::vector<T> &v) {
+    DDH_HIP(hipMalloc(dptr, v.size() * sizeof(T) + 16));
+    DDH_HIP(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nbands, const int *boff,
+                     const double *bands) {
+    if (n_grid < 1 || n_coeff < 1) return fail("plan: sizes must be positive");
+    FftPlan *pl = new FftPlan();
+    pl->kind = H_FFT;
+    pl->tkind = kind;
+    FftDev &d = pl->dev;
+    memset(&d, 0, sizeof(d));
+    d.N = n_grid;
+    d.M = n_coeff;
+    if (!factorize(n_grid, d.radix, d.nradix)) {
+        delete pl;
+        return fail("plan: grid size must factor into 2,3,5,7 (got " + std::to_string(n_grid) + ")");
+    }
+    if (kind == K_RFFT) {
+        if (n_coeff % 2) {
+            delete pl;
+            return fail("plan_rfft: n_coeff must be even");
+        }
+        int KN = (n_grid - 1) / 2, KM = (n_coeff - 1) / 2;
+        d.K = KN < KM ? KN : KM;
+    } else if (kind == K_CFFT) {
+        int KN = (n_grid - 1) / 2, KM = (n_coeff - 1) / 2;
+        d.K = KN < KM ? KN : KM;
+    }
+    const int N = n_grid, M = n_coeff;
+    std::vector<double2> tw(N), half(N);
+    for (int q = 0; q < N; ++q) {
+        long double a = -2.0L * M_PIl * (long double)q / (long double)N;
+        tw[q] = make_double2((double)cosl(a), (double)sinl(a));
+        long double h = -M_PIl * (long double)q / (2.0L * (long double)N);
+        half[q] = make_double2((double)cosl(h), (double)sinl(h));
+    }
+    int st = upload(&pl->d_tw, tw);
+    if (!st) st = upload(&pl->d_half, half);
+    d.tw = (const double2 *)pl->d_tw;
+    d.half = (const double2 *)pl->d_half;
+    if (!st && kind == K_CHEB) {
+        // Appendix A of SURVEY.md / transforms.py:720-724, 737-746, 823-826, 844-860
+        const int L = N > M ? N : M;
+        std::vector<double> fs(L, 0.0), bs(L, 0.0);
+        const long double sqpi = sqrtl(M_PIl), sqpi2 = sqrtl(M_PIl / 2.0L);
+        for (int k = 0; k < L; ++k) {
+            long double sgn = (k % 2) ? -1.0L : 1.0L;
+            if (k == 0) {
+                fs[k] = (double)(sqpi / (2.0L * N));
+                bs[k] = (double)(1.0L / sqpi);
+            } else {
+                fs[k] = (double)(sgn * sqpi2 / (long double)N);
+                bs[k] = (double)(sgn / (2.0L * sqpi2));
+            }
+        }
+        st = upload(&pl->d_fscale, fs);
+        if (!st) st = upload(&pl->d_bscale, bs);
+        d.fscale = (const double *)pl->d_fscale;
+        d.bscale = (const double *)pl->d_bscale;
+        if (nbands > MAX_BANDS) {
+            delete pl;
+            return fail("plan_cheb: at most 4 conversion bands supported");
+        }
+        d.nbands = nbands;
+        d.gcd_off = 1;
+        if (!st && nbands > 0) {
+            if (boff[0] != 0) {
+                delete pl;
+                return fail("plan_cheb: first band must be the diagonal");
+            }
+            int g = 0;
+            for (int i = 0; i < nbands; ++i) {
+                d.boff[i] = boff[i];
+                int a = boff[i], b = g;
+                while (b) { int t = a % b; a = b; b = t; }
+                g = a;
+            }
+            d.gcd_off = g > 0 ? g : 1;
+            std::vector<double> bv(bands, bands + (size_t)nbands * M);
+            st = upload(&pl->d_bands, bv);
+            d.bands = (const double *)pl->d_bands;
+        }
+    }
+    if (st) {
+        delete pl;
+        return st;
+    }
+    d.ld = N;
+    *out = register_handle(pl);
+    return 0;
+}
+
+template <int MODE>
+static int launch(FftPlan *pl, const double *src, double *dst, long outer, long inner, void *stream) {
+    if (outer <= 0 || inner <= 0) return 0;
+    FftDev d = pl->dev;
+    const bool is_cfft = (MODE == CFFT_FWD || MODE == CFFT_BWD);
+    const bool inner_mode = inner > 1;
+    long npairs;
+    if (is_cfft)
+        npairs = inner_mode ? inner : outer;
+    else
+        npairs = inner_mode ? (inner + 1) / 2 : (outer + 1) / 2;
+    // lines per workgroup: 64 B of contiguous data per row when strided; bounded by LDS (<= 64 KiB
+    // so that at least two workgroups share a CU) and by 16 staged values per thread.
+    const int N = d.N, M = d.M;
+    const bool cheb = (MODE == CHEB_FWD || MODE == CHEB_BWD);
+    const size_t per_line = (size_t)(N + (cheb ? M : 0)) * sizeof(double2);
+    int B = inner_mode ? 4 : 2;
+    while (B > 1 && per_line * B > 64 * 1024) B /= 2;
+    if ((long)B > npairs) B = (int)npairs;
+    if (per_line * B > 160 * 1024) return fail("transform: axis too long for the LDS kernel");
+    int T = 256;
+    while ((long)N * B > 16L * T && T < 1024) T *= 2;
+    if ((long)N * B > 16L * T) return fail("transform: axis too long for the LDS kernel (registers)");
+    d.B = B;
+    const unsigned bpo = (unsigned)((npairs + B - 1) / B);
+    const unsigned long nblocks = inner_mode ? (unsigned long)bpo * (unsigned long)outer : bpo;
+    if (nblocks > 0x7fffffffUL) return fail("transform: grid too large");
+    const size_t lds = per_line * B;
+    hipStream_t s = as_stream(stream);
+    if (inner_mode) {
+        auto kern = fft_axis_kernel<MODE, true>;
+        if (lds > 64 * 1024)
+            DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(T), lds, s, d, src, dst, outer, inner, npairs, bpo);
+    } else {
+        auto kern = fft_axis_kernel<MODE, false>;
+        if (lds > 64 * 1024)
+            DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(T), lds, s, d, src, dst, outer, inner, npairs, bpo);
+    }
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense matrix transform along an axis: out[o,i,x] = sum_j mat[i,j] in[o,j,x]
+// ------------------------------------------------------------------------------------------------
+struct MmtPlan : HandleBase {
+    int n_out, n_in;
+    double *d_mat = nullptr;
+    ~MmtPlan() override { (void)hipFree(d_mat); }
+};
+
+constexpr int MT_I = 32, MT_X = 64, MT_J = 16;
+
+__global__ void __launch_bounds__(256)
+mmt_kernel(const double *__restrict__ mat, const double *__restrict__ in, double *__restrict__ out, int n_out,
+           int n_in, long inner) {
+    // tile: MT_I output rows x MT_X inner columns; threads: 256 = 64 (x) * 4 (i groups of 8)
+    __shared__ double sA[MT_I][MT_J + 1];
+    __shared__ double sB[MT_J][MT_X];
+    const long o = blockIdx.z;
+    const int i0 = blockIdx.y * MT_I;
+    const long x0 = (long)blockIdx.x * MT_X;
+    const int tx = threadIdx.x % MT_X, ty = threadIdx.x / MT_X;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double *inb = in + o * (long)n_in * inner;
+    for (int j0 = 0; j0 < n_in; j0 += MT_J) {
+        for (int w = threadIdx.x; w < MT_I * MT_J; w += 256) {
+            int jj = w % MT_J, ii = w / MT_J;
+            sA[ii][jj] = (i0 + ii < n_out && j0 + jj < n_in) ? mat[(long)(i0 + ii) * n_in + j0 + jj] : 0.0;
+        }
+        for (int w = threadIdx.x; w < MT_J * MT_X; w += 256) {
+            int xx = w % MT_X, jj = w / MT_X;
+            sB[jj][xx] = (j0 + jj < n_in && x0 + xx < inner) ? inb[(long)(j0 + jj) * inner + x0 + xx] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < MT_J; ++jj) {
+            const double bv = sB[jj][tx];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] += sA[ty * 8 + r][jj] * bv;
+        }
+        __syncthreads();
+    }
+    if (x0 + tx < inner) {
+        double *ob = out + o * (long)n_out * inner;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = i0 + ty * 8 + r;
+            if (i < n_out) ob[(long)i * inner + x0 + tx] = acc[r];
+        }
+    }
+}
+
+}  // namespace ddh
+
+using namespace ddh;
+
+extern "C" {
+
+int ddh_plan_rfft(ddh_handle *plan, int n_grid, int n_coeff) {
+    return make_plan(plan, K_RFFT, n_grid, n_coeff, 0, nullptr, nullptr);
+}
+int ddh_plan_cfft(ddh_handle *plan, int n_grid, int n_coeff) {
+    return make_plan(plan, K_CFFT, n_grid, n_coeff, 0, nullptr, nullptr);
+}
+int ddh_plan_cheb(ddh_handle *plan, int n_grid, int n_coeff, int nbands, const int *band_offsets_h,
+                  const double *bands_h) {
+    return make_plan(plan, K_CHEB, n_grid, n_coeff, nbands, band_offsets_h, bands_h);
+}
+
+#define DDH_FFT_ENTRY(name, KIND, MODE)                                                               \
+    int name(ddh_handle plan, const double *a, double *b, long outer, long inner, void *stream) {     \
+        FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);                                          \
+        if (!pl) return -1;                                                                           \
+        if (pl->tkind != KIND) return fail(#name ": plan is of a different transform kind");           \
+        if ((const void *)a == (const void *)b) return fail(#name ": in-place transforms unsupported"); \
+        return launch<MODE>(pl, a, b, outer, inner, stream);                                          \
+    }
+
+DDH_FFT_ENTRY(ddh_rfft_forward, K_RFFT, RFFT_FWD)
+DDH_FFT_ENTRY(ddh_rfft_backward, K_RFFT, RFFT_BWD)
+DDH_FFT_ENTRY(ddh_cheb_forward, K_CHEB, CHEB_FWD)
+DDH_FFT_ENTRY(ddh_cheb_backward, K_CHEB, CHEB_BWD)
+DDH_FFT_ENTRY(ddh_cfft_forward, K_CFFT, CFFT_FWD)
+DDH_FFT_ENTRY(ddh_cfft_backward, K_CFFT, CFFT_BWD)
+
+int ddh_plan_mmt(ddh_handle *plan, int n_out, int n_in, const double *mat_h) {
+    if (n_out < 1 || n_in < 1) return fail("plan_mmt: sizes must be positive");
+    MmtPlan *pl = new MmtPlan();
+    pl->kind = H_MMT;
+    pl->n_out = n_out;
+    pl->n_in = n_in;
+    size_t bytes = (size_t)n_out * n_in * sizeof(double);
+    if (check_hip(hipMalloc((void **)&pl->d_mat, bytes), "hipMalloc") ||
+        check_hip(hipMemcpy(pl->d_mat, mat_h, bytes, hipMemcpyHostToDevice), "hipMemcpy")) {
+        delete pl;
+        return -2;
+    }
+    *plan = register_handle(pl);
+    return 0;
+}
+
+int ddh_mmt_apply(ddh_handle plan, const double *in, double *out, long outer, long inner, void *stream) {
+    MmtPlan *pl = (MmtPlan *)lookup_handle(plan, H_MMT);
+    if (!pl) return -1;
+    if (in == out) return fail("ddh_mmt_apply: in-place unsupported");
+    if (outer <= 0 || inner <= 0) return 0;
+    dim3 grid((unsigned)((inner + MT_X - 1) / MT_X), (unsigned)((pl->n_out + MT_I - 1) / MT_I), (unsigned)outer);
+    if (outer > 65535) return fail("ddh_mmt_apply: outer too large");
+    hipLaunchKernelGGL(mmt_kernel, grid, dim3(256), 0, as_stream(stream), pl->d_mat, in, out, pl->n_out, pl->n_in,
+                       inner);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

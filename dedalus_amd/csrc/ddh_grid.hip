@@ -1,0 +1,245 @@
+// Streaming (HBM-bound) vector and grid-space kernels, gfx950.
+//  - ddh_lincomb:        RHS assembly  y = sum_t alpha_t x_t   (timesteppers.py:617-623, 156-166)
+//  - ddh_grid_bilinear:  out[c] = sum_t coef_t a[ia_t] b[ib_t] (arithmetic.py:666-674, 708-728, 855-866)
+//  - ddh_grid_cfl:       max_x sum_c |u_c| / dx_c              (operators.py:4342-4419, basis.py:6078-6113)
+//  - ddh_a2a_pack/unpack: block re-ordering around the RCCL all-to-all (transposes.pyx:359-445)
+// All are one read of each input and one write of the output with 16-byte accesses.
+#include "ddh_common.h"
+
+namespace ddh {
+
+constexpr int MAX_TERMS = 16;
+constexpr int MAX_BIL = 32;
+
+struct LincombArgs {
+    const double *x[MAX_TERMS];
+    double alpha[MAX_TERMS];
+    int nterms;
+};
+
+__global__ void __launch_bounds__(256) lincomb_kernel(double *__restrict__ y, LincombArgs a, long n2, long n) {
+    // n2 = number of double2 elements; tail handled by the last thread block
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 acc = make_double2(0.0, 0.0);
+#pragma unroll 4
+        for (int t = 0; t < a.nterms; ++t) {
+            const double2 v = reinterpret_cast<const double2 *>(a.x[t])[i];
+            acc.x += a.alpha[t] * v.x;
+            acc.y += a.alpha[t] * v.y;
+        }
+        reinterpret_cast<double2 *>(y)[i] = acc;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double acc = 0.0;
+        for (int t = 0; t < a.nterms; ++t) acc += a.alpha[t] * a.x[t][n - 1];
+        y[n - 1] = acc;
+    }
+}
+
+struct BilArgs {
+    int nterms;
+    int ncomp_out;
+    int ic[MAX_BIL], ia[MAX_BIL], ib[MAX_BIL];
+    double coef[MAX_BIL];
+};
+
+__global__ void __launch_bounds__(256)
+bilinear_kernel(double *__restrict__ out, const double *__restrict__ a, const double *__restrict__ b, long n,
+                BilArgs args) {
+    const long n2 = n >> 1;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        for (int c = 0; c < args.ncomp_out; ++c) {
+            double2 acc = make_double2(0.0, 0.0);
+            for (int t = 0; t < args.nterms; ++t) {
+                if (args.ic[t] != c) continue;
+                const double2 av = reinterpret_cast<const double2 *>(a + (long)args.ia[t] * n)[i];
+                const double2 bv = reinterpret_cast<const double2 *>(b + (long)args.ib[t] * n)[i];
+                acc.x += args.coef[t] * av.x * bv.x;
+                acc.y += args.coef[t] * av.y * bv.y;
+            }
+            reinterpret_cast<double2 *>(out + (long)c * n)[i] = acc;
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int c = 0; c < args.ncomp_out; ++c) {
+            double acc = 0.0;
+            for (int t = 0; t < args.nterms; ++t)
+                if (args.ic[t] == c) acc += args.coef[t] * a[(long)args.ia[t] * n + n - 1] * b[(long)args.ib[t] * n + n - 1];
+            out[(long)c * n + n - 1] = acc;
+        }
+    }
+}
+
+constexpr int MAX_AXES = 3;
+struct CflArgs {
+    const double *inv[MAX_AXES];
+    long len[MAX_AXES];
+    int naxes;
+    int ncomp;
+};
+
+__device__ __forceinline__ void atomic_max_double(double *addr, double v) {
+    // values are non-negative: integer ordering == floating ordering
+    atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+__global__ void __launch_bounds__(256) cfl_kernel(double *result, const double *__restrict__ u, long n, CflArgs a) {
+    __shared__ double red[256];
+    double m = 0.0;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        // decompose i into axis indices (last axis fastest)
+        long rem = i;
+        long idx[MAX_AXES];
+        for (int ax = a.naxes - 1; ax >= 0; --ax) {
+            idx[ax] = rem % a.len[ax];
+            rem /= a.len[ax];
+        }
+        double f = 0.0;
+        for (int c = 0; c < a.ncomp; ++c) f += fabs(u[(long)c * n + i]) * a.inv[c][idx[c]];
+        m = fmax(m, f);
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomic_max_double(result, red[0]);
+}
+
+// [outer][na][nb*inner]  ->  [P][outer][na/P][nb*inner]   (split axis a into P blocks)
+__global__ void __launch_bounds__(256)
+a2a_pack_kernel(const double *__restrict__ src, double *__restrict__ dst, long outer, long na, long row, int P) {
+    // one block row = `row` contiguous doubles; grid-stride over (o, ia) rows, 16-byte copies
+    const long blk = na / P;
+    const long nrows = outer * na;
+    const long row2 = row >> 1;
+    for (long r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const long o = r / na, ia = r % na;
+        const long p = ia / blk, il = ia % blk;
+        const double *s = src + r * row;
+        double *d = dst + ((p * outer + o) * blk + il) * row;
+        for (long i = threadIdx.x; i < row2; i += blockDim.x)
+            reinterpret_cast<double2 *>(d)[i] = reinterpret_cast<const double2 *>(s)[i];
+        if ((row & 1) && threadIdx.x == 0) d[row - 1] = s[row - 1];
+    }
+}
+
+// [P][outer][na][nb/P][inner]  ->  [outer][na][nb][inner]   (gather axis b from P blocks)
+__global__ void __launch_bounds__(256)
+a2a_unpack_kernel(const double *__restrict__ src, double *__restrict__ dst, long outer, long na, long nb, long inner,
+                  int P) {
+    const long blk = nb / P;
+    const long seg = blk * inner;  // contiguous doubles per (p, o, ia)
+    const long nseg = (long)P * outer * na;
+    const long seg2 = seg >> 1;
+    for (long r = blockIdx.x; r < nseg; r += gridDim.x) {
+        const long p = r / (outer * na);
+        const long oi = r % (outer * na);
+        const double *s = src + r * seg;
+        double *d = dst + (oi * nb + p * blk) * inner;
+        for (long i = threadIdx.x; i < seg2; i += blockDim.x)
+            reinterpret_cast<double2 *>(d)[i] = reinterpret_cast<const double2 *>(s)[i];
+        if ((seg & 1) && threadIdx.x == 0) d[seg - 1] = s[seg - 1];
+    }
+}
+
+static unsigned stream_grid(long work_items) {
+    long blocks = (work_items + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace ddh
+
+using namespace ddh;
+
+extern "C" {
+
+int ddh_lincomb(double *y, int nterms, const double *const *xs_h, const double *alpha_h, long n, void *stream) {
+    if (nterms < 1 || nterms > MAX_TERMS) return fail("ddh_lincomb: 1..16 terms supported");
+    if (n <= 0) return 0;
+    LincombArgs a;
+    a.nterms = nterms;
+    for (int t = 0; t < nterms; ++t) {
+        a.x[t] = xs_h[t];
+        a.alpha[t] = alpha_h[t];
+        if (((uintptr_t)xs_h[t]) & 15) return fail("ddh_lincomb: operands must be 16-byte aligned");
+    }
+    if (((uintptr_t)y) & 15) return fail("ddh_lincomb: output must be 16-byte aligned");
+    hipLaunchKernelGGL(lincomb_kernel, dim3(stream_grid(n / 2)), dim3(256), 0, as_stream(stream), y, a, n / 2, n);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_grid_bilinear(double *out, int ncomp_out, const double *a, const double *b, long n, int nterms,
+                      const int *ic_h, const int *ia_h, const int *ib_h, const double *coef_h, void *stream) {
+    if (nterms < 1 || nterms > MAX_BIL) return fail("ddh_grid_bilinear: 1..32 terms supported");
+    if (n <= 0) return 0;
+    if (n & 1) {
+        // component offsets c*n must stay 16-byte aligned for the vector path
+        if (ncomp_out > 1) return fail("ddh_grid_bilinear: odd point count with several components unsupported");
+    }
+    BilArgs args;
+    args.nterms = nterms;
+    args.ncomp_out = ncomp_out;
+    for (int t = 0; t < nterms; ++t) {
+        args.ic[t] = ic_h[t];
+        args.ia[t] = ia_h[t];
+        args.ib[t] = ib_h[t];
+        args.coef[t] = coef_h[t];
+        if ((n & 1) && (ia_h[t] || ib_h[t])) return fail("ddh_grid_bilinear: odd point count with several components unsupported");
+    }
+    hipLaunchKernelGGL(bilinear_kernel, dim3(stream_grid(n / 2)), dim3(256), 0, as_stream(stream), out, a, b, n, args);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_grid_cfl(double *result_d, const double *u, int ncomp, long n, const double *const *inv_spacing_axes,
+                 const long *axis_len_h, int naxes, void *stream) {
+    if (naxes < 1 || naxes > MAX_AXES || ncomp != naxes) return fail("ddh_grid_cfl: ncomp must equal naxes <= 3");
+    CflArgs a;
+    a.naxes = naxes;
+    a.ncomp = ncomp;
+    long tot = 1;
+    for (int i = 0; i < naxes; ++i) {
+        a.inv[i] = inv_spacing_axes[i];
+        a.len[i] = axis_len_h[i];
+        tot *= axis_len_h[i];
+    }
+    if (tot != n) return fail("ddh_grid_cfl: axis lengths do not multiply to n");
+    DDH_HIP(hipMemsetAsync(result_d, 0, sizeof(double), as_stream(stream)));
+    hipLaunchKernelGGL(cfl_kernel, dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), result_d, u, n, a);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_a2a_pack(const double *src, double *dst, long outer, long na, long nb, long inner, int nparts, void *stream) {
+    if (nparts < 1 || na % nparts) return fail("ddh_a2a_pack: axis length must be divisible by nparts");
+    const long row = nb * inner;
+    if (row & 1) return fail("ddh_a2a_pack: row length must be even");
+    long nrows = outer * na;
+    unsigned grid = (unsigned)(nrows < 8192 ? nrows : 8192);
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL(a2a_pack_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, dst, outer, na, row, nparts);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_a2a_unpack(const double *src, double *dst, long outer, long na, long nb, long inner, int nparts, void *stream) {
+    if (nparts < 1 || nb % nparts) return fail("ddh_a2a_unpack: axis length must be divisible by nparts");
+    if (((nb / nparts) * inner) & 1) return fail("ddh_a2a_unpack: segment length must be even");
+    long nseg = (long)nparts * outer * na;
+    unsigned grid = (unsigned)(nseg < 8192 ? nseg : 8192);
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL(a2a_unpack_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, dst, outer, na, nb, inner,
+                       nparts);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

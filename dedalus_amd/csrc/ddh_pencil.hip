@@ -1,0 +1,941 @@
+// Batched pencil linear algebra for ALL pencils of a problem at once, gfx950.
+//
+// Layout.  A system vector is a real array [nrows][nx][ny]; a "cell" is one
+// group of separable real-Fourier modes (mx, my) holding 2^nfourier real parts (cos/msin
+// combinations).  Every translation-invariant real operator acts on the complex combinations
+//     nfourier = 1:  P = a + i b                                         symbol lambda( kx)
+//     nfourier = 2:  P = (cc - ss) + i (cs + sc)                          symbol lambda( kx, ky)
+//                    Q = (cc + ss) + i (cs - sc)                          symbol lambda(-kx, ky)
+// as an independent complex linear system, so one cell = S (1 or 2) complex "systems".  The cell
+// index is the fastest-varying index of every array: thread g works on system g, all memory
+// accesses of a wave are contiguous, and no gather/scatter pass exists at all (the reference's
+// gather_inputs / scatter_inputs, core/subsystems.py:340-380, are the identity here).
+//
+// Matrices are term lists  A[row, col] += coef * kx^ex * ky^ey * [mx==0]^dx * [my==0]^dy  shared by
+// all pencils (no per-pencil matrix values are ever stored or read for mat-vecs).
+//
+// The implicit solve is a bordered band LU with partial pivoting inside the band
+// (replaces SuperLU, libraries/matsolvers.py:126-149):
+//     columns = [interior variables, coupled-axis index outermost | border variables (taus)]
+//     rows    = [interior equations, coupled-axis index outermost | border equations (BCs)]
+// rows < n form a band (kl, ku); the nb border rows are dense and are eliminated without taking
+// part in pivoting; systems whose band block is singular are flagged and solved through an
+// explicit dense inverse supplied by the host (ddh_pencil_set_dense_inverse).
+#include "ddh_common.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace ddh {
+
+constexpr int KLMAX = 12;
+constexpr int NBMAX = 16;
+
+struct PencilDev {
+    int nf;      // separable real-Fourier axes: 0, 1, 2
+    int S;       // complex systems per cell
+    int nrows;   // rows of the system vector
+    long nx, ny; // real storage extents of a row
+    long ncx, ncy;  // cells per axis
+    long ncells;
+    long G;         // systems = ncells * S
+    const double *kx, *ky;
+};
+
+struct MatDev {
+    int nrows_out;
+    int nterms;
+    const int *rowptr;   // [nrows_out+1]  (terms sorted by row)
+    const int *col;
+    const double2 *coef;
+    const unsigned *expo;  // ex | ey<<8 | dx<<16 | dy<<24
+};
+
+struct Matrix {
+    MatDev dev;
+    std::vector<int> row_h, col_h;
+    std::vector<double2> coef_h;
+    std::vector<unsigned> expo_h;
+    void *d_rowptr = nullptr, *d_col = nullptr, *d_coef = nullptr, *d_expo = nullptr;
+};
+
+struct LuDev {
+    int n, nb, N, kl, ku, W, BW;   // BW = kl + W + 1, W = ku + kl
+    double2 *Aw;                   // [n][BW][G]   band rows, LAPACK-style fill space
+    double2 *Ab;                   // [N][nb][G]   border rows (multipliers | Schur block inverse)
+    unsigned char *piv;            // [n][G]
+    unsigned char *flag;           // [G]
+    double2 *scratch;              // [n][G]
+    const int *rowperm, *colperm;  // logical -> physical
+    const unsigned char *row_axes, *col_axes;   // per logical border row / col: validity bits
+};
+
+struct LuFactor {
+    LuDev dev;
+    size_t bytes = 0;
+    void *d_rowperm = nullptr, *d_colperm = nullptr, *d_raxes = nullptr, *d_caxes = nullptr;
+    // dense fallback
+    int nflag = 0;
+    std::vector<long> flag_cells;   // flagged cell ids
+    void *d_flag_cells = nullptr;   // long[nflagcells]
+    void *d_inv = nullptr;          // double2 [nflagcells*S][N][N]
+    void *d_dense_rhs = nullptr;    // double2 [nflagcells*S][N]
+};
+
+struct PencilPack : HandleBase {
+    PencilDev dev;
+    void *d_kx = nullptr, *d_ky = nullptr;
+    std::vector<Matrix *> mats;
+    std::vector<LuFactor *> lus;
+    ~PencilPack() override;
+};
+
+static void free_lu(LuFactor *lu) {
+    if (!lu) return;
+    (void)hipFree(lu->dev.Aw);
+    (void)hipFree(lu->dev.Ab);
+    (void)hipFree(lu->dev.piv);
+    (void)hipFree(lu->dev.flag);
+    (void)hipFree(lu->dev.scratch);
+    (void)hipFree(lu->d_rowperm);
+    (void)hipFree(lu->d_colperm);
+    (void)hipFree(lu->d_raxes);
+    (void)hipFree(lu->d_caxes);
+    (void)hipFree(lu->d_flag_cells);
+    (void)hipFree(lu->d_inv);
+    (void)hipFree(lu->d_dense_rhs);
+    delete lu;
+}
+
+PencilPack::~PencilPack() {
+    (void)hipFree(d_kx);
+    (void)hipFree(d_ky);
+    for (auto m : mats) {
+        (void)hipFree(m->d_rowptr);
+        (void)hipFree(m->d_col);
+        (void)hipFree(m->d_coef);
+        (void)hipFree(m->d_expo);
+        delete m;
+    }
+    for (auto l : lus) free_lu(l);
+}
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ void cfma(double2 &acc, double2 a, double2 b) {   // acc += a*b
+    acc.x += a.x * b.x - a.y * b.y;
+    acc.y += a.x * b.y + a.y * b.x;
+}
+__device__ __forceinline__ void cfms(double2 &acc, double2 a, double2 b) {   // acc -= a*b
+    acc.x -= a.x * b.x - a.y * b.y;
+    acc.y -= a.x * b.y + a.y * b.x;
+}
+__device__ __forceinline__ double cabs2(double2 a) { return a.x * a.x + a.y * a.y; }
+__device__ __forceinline__ double2 cinv(double2 a) {
+    const double d = 1.0 / (a.x * a.x + a.y * a.y);
+    return make_double2(a.x * d, -a.y * d);
+}
+__device__ __forceinline__ double ipow(double k, unsigned e) {
+    double r = 1.0, b = k;
+    if (e & 1u) r *= b;
+    b *= b;
+    if (e & 2u) r *= b;
+    b *= b;
+    if (e & 4u) r *= b;
+    return r;
+}
+
+struct CellCtx {
+    long mx, my;
+    double kx, ky;
+};
+
+__device__ __forceinline__ CellCtx cell_ctx(const PencilDev &P, long cell) {
+    CellCtx c;
+    if (P.nf == 2) {
+        c.mx = cell / P.ncy;
+        c.my = cell % P.ncy;
+    } else {
+        c.mx = cell;
+        c.my = 0;
+    }
+    c.kx = (P.nf >= 1) ? P.kx[c.mx] : 0.0;
+    c.ky = (P.nf == 2) ? P.ky[c.my] : 0.0;
+    return c;
+}
+
+// real factor of a term for the +kx system; the -kx system multiplies by (-1)^ex
+__device__ __forceinline__ double term_factor(unsigned e, const CellCtx &c) {
+    const unsigned ex = e & 0xffu, ey = (e >> 8) & 0xffu, dx = (e >> 16) & 0xffu, dy = (e >> 24) & 0xffu;
+    double f = ipow(c.kx, ex) * ipow(c.ky, ey);
+    if (dx && c.mx != 0) f = 0.0;
+    if (dy && c.my != 0) f = 0.0;
+    return f;
+}
+
+// validity of a border row/col for a cell: bit0 set -> exists for mx>0, bit1 set -> exists for my>0
+__device__ __forceinline__ bool axes_valid(unsigned char bits, const CellCtx &c, int nf) {
+    if (nf >= 1 && c.mx != 0 && !(bits & 1)) return false;
+    if (nf == 2 && c.my != 0 && !(bits & 2)) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = A x for every cell (apply_sparse over all pencils; M.X and L.X of timesteppers.py:588-604)
+// ------------------------------------------------------------------------------------------------
+template <int NF>
+__global__ void __launch_bounds__(256)
+matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *__restrict__ y) {
+    const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= P.ncells) return;
+    const CellCtx c = cell_ctx(P, cell);
+    const long plane = P.nx * P.ny;
+    long off0, off1 = 0;
+    if (NF == 2) {
+        off0 = (2 * c.mx) * P.ny + 2 * c.my;
+        off1 = off0 + P.ny;
+    } else if (NF == 1) {
+        off0 = 2 * c.mx;
+    } else {
+        off0 = 0;
+    }
+    for (int r = 0; r < A.nrows_out; ++r) {
+        double2 accP = make_double2(0.0, 0.0), accQ = accP;
+        const int t1 = A.rowptr[r + 1];
+        for (int t = A.rowptr[r]; t < t1; ++t) {
+            const unsigned e = A.expo[t];
+            const double f = term_factor(e, c);
+            const double2 cf = A.coef[t];
+            const double2 v = make_double2(cf.x * f, cf.y * f);
+            const double *xr = x + (long)A.col[t] * plane;
+            if (NF == 2) {
+                const double2 a = *reinterpret_cast<const double2 *>(xr + off0);   // cc, cs
+                const double2 b = *reinterpret_cast<const double2 *>(xr + off1);   // sc, ss
+                const double2 xP = make_double2(a.x - b.y, a.y + b.x);
+                const double2 xQ = make_double2(a.x + b.y, a.y - b.x);
+                cfma(accP, v, xP);
+                const double sg = (e & 1u) ? -1.0 : 1.0;
+                cfma(accQ, make_double2(v.x * sg, v.y * sg), xQ);
+            } else if (NF == 1) {
+                const double2 xP = *reinterpret_cast<const double2 *>(xr + off0);
+                cfma(accP, v, xP);
+            } else {
+                accP.x += v.x * xr[0];
+            }
+        }
+        double *yr = y + (long)r * plane;
+        if (NF == 2) {
+            *reinterpret_cast<double2 *>(yr + off0) =
+                make_double2(0.5 * (accP.x + accQ.x), 0.5 * (accP.y + accQ.y));
+            *reinterpret_cast<double2 *>(yr + off1) =
+                make_double2(0.5 * (accP.y - accQ.y), 0.5 * (accQ.x - accP.x));
+        } else if (NF == 1) {
+            *reinterpret_cast<double2 *>(yr + off0) = accP;
+        } else {
+            yr[0] = accP.x;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// system <-> real storage (used by factor's nothing, solve's RHS load and solution store)
+// thread g = cell*S + s.  For NF == 2 lanes (2i, 2i+1) hold the P and Q systems of one cell.
+// ------------------------------------------------------------------------------------------------
+template <int NF>
+__device__ __forceinline__ double2 load_sys(const double *__restrict__ v, long plane, int row, const PencilDev &P,
+                                            const CellCtx &c, int s) {
+    const double *vr = v + (long)row * plane;
+    if (NF == 2) {
+        const double2 mine = *reinterpret_cast<const double2 *>(vr + (2 * c.mx + s) * P.ny + 2 * c.my);
+        double2 other;
+        other.x = __shfl_xor(mine.x, 1);
+        other.y = __shfl_xor(mine.y, 1);
+        // s==0: mine=(cc,cs), other=(sc,ss) -> P ; s==1: mine=(sc,ss), other=(cc,cs) -> Q
+        return s == 0 ? make_double2(mine.x - other.y, mine.y + other.x)
+                      : make_double2(other.x + mine.y, other.y - mine.x);
+    } else if (NF == 1) {
+        return *reinterpret_cast<const double2 *>(vr + 2 * c.mx);
+    } else {
+        return make_double2(vr[0], 0.0);
+    }
+}
+
+template <int NF>
+__device__ __forceinline__ void store_sys(double *__restrict__ v, long plane, int row, const PencilDev &P,
+                                          const CellCtx &c, int s, double2 val) {
+    double *vr = v + (long)row * plane;
+    if (NF == 2) {
+        double2 other;
+        other.x = __shfl_xor(val.x, 1);
+        other.y = __shfl_xor(val.y, 1);
+        const double2 out = (s == 0) ? make_double2(0.5 * (val.x + other.x), 0.5 * (val.y + other.y))    // cc, cs
+                                     : make_double2(0.5 * (other.y - val.y), 0.5 * (val.x - other.x));  // sc, ss
+        *reinterpret_cast<double2 *>(vr + (2 * c.mx + s) * P.ny + 2 * c.my) = out;
+    } else if (NF == 1) {
+        *reinterpret_cast<double2 *>(vr + 2 * c.mx) = val;
+    } else {
+        vr[0] = val.x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// assemble a*M + b*L into band + border storage and factor it, one thread per system
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void scatter_terms(const PencilDev &P, const LuDev &L, const MatDev &A, double scale,
+                                              const int *__restrict__ rowinv, const int *__restrict__ colinv,
+                                              const CellCtx &c, int s, long g, double &anorm, bool &bad) {
+    if (scale == 0.0) return;
+    for (int r = 0; r < A.nrows_out; ++r) {
+        const int i = rowinv[r];
+        const int t1 = A.rowptr[r + 1];
+        for (int t = A.rowptr[r]; t < t1; ++t) {
+            const unsigned e = A.expo[t];
+            double f = term_factor(e, c) * scale;
+            if (s == 1 && (e & 1u)) f = -f;
+            if (f == 0.0) continue;
+            const double2 cf = A.coef[t];
+            const double2 v = make_double2(cf.x * f, cf.y * f);
+            const int cc = colinv[A.col[t]];
+            anorm = fmax(anorm, fabs(v.x) + fabs(v.y));
+            if (i < L.n) {
+                const int d = cc - i + L.kl;
+                if (d < 0 || cc - i > L.ku) {
+                    // entry outside the band (e.g. a k=0-only gauge column): this pencil goes to
+                    // the dense fallback
+                    bad = true;
+                    continue;
+                }
+                double2 *p = L.Aw + ((long)i * L.BW + d) * P.G + g;
+                double2 o = *p;
+                o.x += v.x;
+                o.y += v.y;
+                *p = o;
+            } else {
+                double2 *p = L.Ab + ((long)cc * L.nb + (i - L.n)) * P.G + g;
+                double2 o = *p;
+                o.x += v.x;
+                o.y += v.y;
+                *p = o;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64)
+factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, const int *__restrict__ rowinv,
+              const int *__restrict__ colinv) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P.G) return;
+    const long cell = g / P.S;
+    const int s = (int)(g % P.S);
+    const CellCtx c = cell_ctx(P, cell);
+    const long G = P.G;
+    const int n = L.n, nb = L.nb, N = L.N, kl = L.kl, W = L.W, BW = L.BW;
+    double anorm = 0.0;
+    bool bad = false;
+    scatter_terms(P, L, M, a, rowinv, colinv, c, s, g, anorm, bad);
+    scatter_terms(P, L, Lm, b, rowinv, colinv, c, s, g, anorm, bad);
+    // border rows / columns that do not exist for this cell are paired into identity entries
+    {
+        int cb = 0;
+        for (int rb = 0; rb < nb; ++rb) {
+            if (axes_valid(L.row_axes[rb], c, P.nf)) continue;
+            while (cb < nb && axes_valid(L.col_axes[cb], c, P.nf)) ++cb;
+            if (cb < nb) {
+                L.Ab[((long)(n + cb) * nb + rb) * G + g] = make_double2(1.0, 0.0);
+                ++cb;
+            }
+        }
+    }
+    const double tiny = 1e-13 * anorm;
+    bad = bad || (anorm == 0.0);
+    // ---- band elimination with partial pivoting among rows j..j+kl (border rows never pivot)
+    for (int j = 0; j < n; ++j) {
+        int p = 0;
+        double best = -1.0;
+        const int imax = (j + kl < n) ? kl : (n - 1 - j);
+        for (int i = 0; i <= imax; ++i) {
+            const double2 v = L.Aw[((long)(j + i) * BW + (kl - i)) * G + g];
+            const double m = cabs2(v);
+            if (m > best) {
+                best = m;
+                p = i;
+            }
+        }
+        L.piv[(long)j * G + g] = (unsigned char)p;
+        const int wmax = (j + W < N) ? W : (N - 1 - j);   // columns j .. j+wmax
+        if (p != 0) {
+            for (int d = 0; d <= wmax; ++d) {
+                double2 *pa = L.Aw + ((long)j * BW + kl + d) * G + g;
+                double2 *pb = L.Aw + ((long)(j + p) * BW + (kl - p) + d) * G + g;
+                const double2 t = *pa;
+                *pa = *pb;
+                *pb = t;
+            }
+        }
+        double2 piv = L.Aw[((long)j * BW + kl) * G + g];
+        if (!(cabs2(piv) > tiny * tiny)) {
+            bad = true;
+            piv = make_double2(1.0, 0.0);
+            L.Aw[((long)j * BW + kl) * G + g] = piv;
+        }
+        const double2 ip = cinv(piv);
+        for (int i = 1; i <= imax; ++i) {
+            double2 *pm = L.Aw + ((long)(j + i) * BW + (kl - i)) * G + g;
+            const double2 m = cmul(*pm, ip);
+            *pm = m;
+            if (m.x == 0.0 && m.y == 0.0) continue;
+            for (int d = 1; d <= wmax; ++d) {
+                double2 *pt = L.Aw + ((long)(j + i) * BW + (kl - i) + d) * G + g;
+                double2 t = *pt;
+                cfms(t, m, L.Aw[((long)j * BW + kl + d) * G + g]);
+                *pt = t;
+            }
+        }
+        for (int rb = 0; rb < nb; ++rb) {
+            double2 *pm = L.Ab + ((long)j * nb + rb) * G + g;
+            const double2 m = cmul(*pm, ip);
+            *pm = m;
+            if (m.x == 0.0 && m.y == 0.0) continue;
+            for (int d = 1; d <= wmax; ++d) {
+                double2 *pt = L.Ab + ((long)(j + d) * nb + rb) * G + g;
+                double2 t = *pt;
+                cfms(t, m, L.Aw[((long)j * BW + kl + d) * G + g]);
+                *pt = t;
+            }
+        }
+        // store the reciprocal pivot: the solve multiplies instead of dividing
+        L.Aw[((long)j * BW + kl) * G + g] = ip;
+    }
+    // ---- Schur block (nb x nb) at Ab[n + c][r]: invert in place by Gauss-Jordan with pivoting.
+    //      scratch rows [0, nb) x [0, nb) of L.scratch hold the inverse being built.
+    if (nb > 0) {
+        double2 *Sinv = L.scratch;   // [nb*nb][G] (n >= nb*nb is checked on the host)
+        for (int r = 0; r < nb; ++r)
+            for (int cidx = 0; cidx < nb; ++cidx)
+                Sinv[((long)r * nb + cidx) * G + g] = make_double2(r == cidx ? 1.0 : 0.0, 0.0);
+        for (int k = 0; k < nb; ++k) {
+            int p = k;
+            double best = -1.0;
+            for (int r = k; r < nb; ++r) {
+                const double m = cabs2(L.Ab[((long)(n + k) * nb + r) * G + g]);
+                if (m > best) {
+                    best = m;
+                    p = r;
+                }
+            }
+            if (p != k) {
+                for (int cidx = 0; cidx < nb; ++cidx) {
+                    double2 *pa = L.Ab + ((long)(n + cidx) * nb + k) * G + g, *pb = L.Ab + ((long)(n + cidx) * nb + p) * G + g;
+                    double2 t = *pa;
+                    *pa = *pb;
+                    *pb = t;
+                    pa = Sinv + ((long)k * nb + cidx) * G + g;
+                    pb = Sinv + ((long)p * nb + cidx) * G + g;
+                    t = *pa;
+                    *pa = *pb;
+                    *pb = t;
+                }
+            }
+            double2 piv = L.Ab[((long)(n + k) * nb + k) * G + g];
+            if (!(cabs2(piv) > tiny * tiny)) {
+                bad = true;
+                piv = make_double2(1.0, 0.0);
+            }
+            const double2 ip = cinv(piv);
+            for (int cidx = 0; cidx < nb; ++cidx) {
+                double2 *pa = L.Ab + ((long)(n + cidx) * nb + k) * G + g;
+                *pa = cmul(*pa, ip);
+                pa = Sinv + ((long)k * nb + cidx) * G + g;
+                *pa = cmul(*pa, ip);
+            }
+            for (int r = 0; r < nb; ++r) {
+                if (r == k) continue;
+                const double2 m = L.Ab[((long)(n + k) * nb + r) * G + g];
+                if (m.x == 0.0 && m.y == 0.0) continue;
+                for (int cidx = 0; cidx < nb; ++cidx) {
+                    double2 *pt = L.Ab + ((long)(n + cidx) * nb + r) * G + g;
+                    double2 t = *pt;
+                    cfms(t, m, L.Ab[((long)(n + cidx) * nb + k) * G + g]);
+                    *pt = t;
+                    pt = Sinv + ((long)r * nb + cidx) * G + g;
+                    t = *pt;
+                    cfms(t, m, Sinv[((long)k * nb + cidx) * G + g]);
+                    *pt = t;
+                }
+            }
+        }
+        // copy inverse into the Schur slot: Ab[n + c][r] = Sinv[r][c]
+        for (int r = 0; r < nb; ++r)
+            for (int cidx = 0; cidx < nb; ++cidx)
+                L.Ab[((long)(n + cidx) * nb + r) * G + g] = Sinv[((long)r * nb + cidx) * G + g];
+    }
+    L.flag[g] = bad ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// solve: forward sweep (row interchanges, band multipliers, border multipliers), Schur block,
+// backward sweep with a register window of the last W solution entries.
+// ------------------------------------------------------------------------------------------------
+template <int NF, int WT>
+__global__ void __launch_bounds__(256)
+solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__restrict__ xout) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P.G) return;   // G is a multiple of S, pairs never straddle the guard
+    const long cell = g / P.S;
+    const int s = (int)(g % P.S);
+    const CellCtx c = cell_ctx(P, cell);
+    const long G = P.G;
+    const long plane = P.nx * P.ny;
+    const int n = L.n, nb = L.nb, kl = L.kl, W = L.W, BW = L.BW;
+
+    // ---- forward
+    double2 w[KLMAX + 1];
+#pragma unroll
+    for (int d = 0; d <= KLMAX; ++d) {
+        w[d] = make_double2(0.0, 0.0);
+        if (d <= kl && d < n) w[d] = load_sys<NF>(rhs, plane, L.rowperm[d], P, c, s);
+    }
+    double2 gb[NBMAX];
+#pragma unroll
+    for (int rb = 0; rb < NBMAX; ++rb) {
+        gb[rb] = make_double2(0.0, 0.0);
+        if (rb < nb) gb[rb] = load_sys<NF>(rhs, plane, L.rowperm[n + rb], P, c, s);
+    }
+    for (int j = 0; j < n; ++j) {
+        const int p = L.piv[(long)j * G + g];
+        double2 yj = w[0];
+#pragma unroll
+        for (int d = 1; d <= KLMAX; ++d) {
+            if (d == p) {
+                yj = w[d];
+                w[d] = w[0];
+            }
+        }
+        L.scratch[(long)j * G + g] = yj;
+#pragma unroll
+        for (int i = 1; i <= KLMAX; ++i) {
+            if (i <= kl && j + i < n) {
+                const double2 m = L.Aw[((long)(j + i) * BW + (kl - i)) * G + g];
+                cfms(w[i], m, yj);
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < NBMAX; ++rb) {
+            if (rb < nb) {
+                const double2 m = L.Ab[((long)j * nb + rb) * G + g];
+                cfms(gb[rb], m, yj);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < KLMAX; ++d) w[d] = w[d + 1];
+        w[KLMAX] = make_double2(0.0, 0.0);
+        const int nxt = j + kl + 1;
+        if (nxt < n) {
+            const double2 v = load_sys<NF>(rhs, plane, L.rowperm[nxt], P, c, s);
+#pragma unroll
+            for (int d = 0; d <= KLMAX; ++d)
+                if (d == kl) w[d] = v;
+        }
+    }
+    // ---- Schur block: z = Sinv * gb
+    double2 win[WT];
+#pragma unroll
+    for (int d = 0; d < WT; ++d) win[d] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int r = 0; r < NBMAX; ++r) {
+        if (r < nb) {
+            double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int cidx = 0; cidx < NBMAX; ++cidx) {
+                if (cidx < nb) cfma(acc, L.Ab[((long)(n + cidx) * nb + r) * G + g], gb[cidx]);
+            }
+            // border unknown r is logical column n + r
+#pragma unroll
+            for (int d = 0; d < WT; ++d)
+                if (d == r) win[d] = acc;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NBMAX; ++r) {
+        if (r < nb) {
+            double2 z = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int d = 0; d < WT; ++d)
+                if (d == r) z = win[d];
+            store_sys<NF>(xout, plane, L.colperm[n + r], P, c, s, z);
+        }
+    }
+    // ---- backward: win[d] = x[j+1+d]
+    for (int j = n - 1; j >= 0; --j) {
+        double2 acc = L.scratch[(long)j * G + g];
+        const double2 *Ur = L.Aw + ((long)j * BW + kl) * G + g;
+#pragma unroll
+        for (int d = 0; d < WT; ++d) {
+            if (d < W) cfms(acc, Ur[(long)(d + 1) * G], win[d]);
+        }
+        const double2 xj = cmul(acc, Ur[0]);   // reciprocal pivot stored on the diagonal
+#pragma unroll
+        for (int d = WT - 1; d > 0; --d) win[d] = win[d - 1];
+        win[0] = xj;
+        store_sys<NF>(xout, plane, L.colperm[j], P, c, s, xj);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense fallback for flagged cells: x = Inv * rhs (explicit inverse built on the host)
+// ------------------------------------------------------------------------------------------------
+template <int NF>
+__global__ void __launch_bounds__(256)
+dense_gather_kernel(PencilDev P, LuDev L, const long *__restrict__ cells, int ncellsf,
+                    const double *__restrict__ rhs, double2 *__restrict__ out) {
+    // thread -> (flagged cell f, system s, logical row i); pairs (s=0,1) adjacent lanes for NF == 2
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)L.N * P.S;
+    if (t >= per * ncellsf) return;
+    const long f = t / per;
+    const int i = (int)((t % per) / P.S);
+    const int s = (int)(t % P.S);
+    const CellCtx c = cell_ctx(P, cells[f]);
+    const double2 v = load_sys<NF>(rhs, P.nx * P.ny, L.rowperm[i], P, c, s);
+    out[(f * P.S + s) * L.N + i] = v;
+}
+
+__global__ void __launch_bounds__(256)
+dense_apply_kernel(int N, const double2 *__restrict__ inv, const double2 *__restrict__ rhs, double2 *__restrict__ x) {
+    // one wave per output row: blockIdx.y = system, 4 rows per block
+    const int sys = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const double2 *a = inv + ((long)sys * N + row) * N;
+    const double2 *b = rhs + (long)sys * N;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int k = lane; k < N; k += 64) cfma(acc, a[k], b[k]);
+    for (int off = 32; off > 0; off >>= 1) {
+        acc.x += __shfl_down(acc.x, off);
+        acc.y += __shfl_down(acc.y, off);
+    }
+    if (lane == 0) x[(long)sys * N + row] = acc;
+}
+
+template <int NF>
+__global__ void __launch_bounds__(256)
+dense_scatter_kernel(PencilDev P, LuDev L, const long *__restrict__ cells, int ncellsf,
+                     const double2 *__restrict__ xin, double *__restrict__ xout) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)L.N * P.S;
+    if (t >= per * ncellsf) return;
+    const long f = t / per;
+    const int i = (int)((t % per) / P.S);
+    const int s = (int)(t % P.S);
+    const CellCtx c = cell_ctx(P, cells[f]);
+    store_sys<NF>(xout, P.nx * P.ny, L.colperm[i], P, c, s, xin[(f * P.S + s) * L.N + i]);
+}
+
+template <typename T>
+static int upload_vec(void **dptr, const T *src, size_t count) {
+    DDH_HIP(hipMalloc(dptr, count * sizeof(T) + 16));
+    if (count) DDH_HIP(hipMemcpy(*dptr, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <int NF>
+static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double *x, hipStream_t s) {
+    const PencilDev &P = pp->dev;
+    const LuDev &d = lu->dev;
+    const unsigned blocks = (unsigned)((P.G + 255) / 256);
+    const int W = d.W;
+    if (W <= 8)
+        hipLaunchKernelGGL((solve_kernel<NF, 8>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
+    else if (W <= 16)
+        hipLaunchKernelGGL((solve_kernel<NF, 16>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
+    else if (W <= 24)
+        hipLaunchKernelGGL((solve_kernel<NF, 24>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
+    else if (W <= 32)
+        hipLaunchKernelGGL((solve_kernel<NF, 32>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
+    else if (W <= 48)
+        hipLaunchKernelGGL((solve_kernel<NF, 48>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
+    else
+        hipLaunchKernelGGL((solve_kernel<NF, 64>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
+    DDH_HIP(hipGetLastError());
+    if (lu->nflag) {
+        if (!lu->d_inv) return fail("pencil_solve: flagged pencils need ddh_pencil_set_dense_inverse first");
+        const int nsys = lu->nflag * P.S;
+        double2 *drhs = (double2 *)lu->d_dense_rhs;
+        double2 *dx = drhs + (size_t)nsys * d.N;
+        const long work = (long)lu->nflag * d.N * P.S;
+        const unsigned gb = (unsigned)((work + 255) / 256);
+        hipLaunchKernelGGL(dense_gather_kernel<NF>, dim3(gb), dim3(256), 0, s, P, d, (const long *)lu->d_flag_cells,
+                           lu->nflag, rhs, drhs);
+        hipLaunchKernelGGL(dense_apply_kernel, dim3((unsigned)((d.N + 3) / 4), (unsigned)nsys), dim3(256), 0, s, d.N,
+                           (const double2 *)lu->d_inv, (const double2 *)drhs, dx);
+        hipLaunchKernelGGL(dense_scatter_kernel<NF>, dim3(gb), dim3(256), 0, s, P, d, (const long *)lu->d_flag_cells,
+                           lu->nflag, (const double2 *)dx, x);
+        DDH_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+
+}  // namespace ddh
+
+using namespace ddh;
+
+extern "C" {
+
+int ddh_pencil_create(ddh_handle *pack, const ddh_pencil_geom *geom) {
+    if (!geom || geom->nfourier < 0 || geom->nfourier > 2) return fail("pencil_create: nfourier must be 0, 1 or 2");
+    PencilPack *pp = new PencilPack();
+    pp->kind = H_PENCIL;
+    PencilDev &d = pp->dev;
+    d.nf = geom->nfourier;
+    d.S = (d.nf == 2) ? 2 : 1;
+    d.nrows = geom->nrows;
+    d.nx = geom->nx;
+    d.ny = geom->ny;
+    if (d.nf == 0) {
+        d.ncx = d.ncy = 1;
+        if (d.nx != 1 || d.ny != 1) { delete pp; return fail("pencil_create: nfourier=0 needs nx=ny=1"); }
+    } else if (d.nf == 1) {
+        if (d.nx % 2 || d.ny != 1) { delete pp; return fail("pencil_create: nfourier=1 needs even nx and ny=1"); }
+        d.ncx = d.nx / 2;
+        d.ncy = 1;
+    } else {
+        if (d.nx % 2 || d.ny % 2) { delete pp; return fail("pencil_create: nfourier=2 needs even nx, ny"); }
+        d.ncx = d.nx / 2;
+        d.ncy = d.ny / 2;
+    }
+    d.ncells = d.ncx * d.ncy;
+    d.G = d.ncells * d.S;
+    int st = 0;
+    if (d.nf >= 1) st = upload_vec(&pp->d_kx, geom->kx_h, (size_t)d.ncx);
+    if (!st && d.nf == 2) st = upload_vec(&pp->d_ky, geom->ky_h, (size_t)d.ncy);
+    if (st) { delete pp; return st; }
+    d.kx = (const double *)pp->d_kx;
+    d.ky = (const double *)pp->d_ky;
+    *pack = register_handle(pp);
+    return 0;
+}
+
+int ddh_pencil_add_matrix(ddh_handle pack, const ddh_polymat *mat, int nrows_out, int *mat_id) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    const int nt = mat->nterms;
+    std::vector<int> order(nt);
+    for (int i = 0; i < nt; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return mat->row_h[a] < mat->row_h[b]; });
+    Matrix *m = new Matrix();
+    std::vector<int> rowptr(nrows_out + 1, 0);
+    m->col_h.resize(nt);
+    m->coef_h.resize(nt);
+    m->expo_h.resize(nt);
+    m->row_h.resize(nt);
+    for (int k = 0; k < nt; ++k) {
+        const int t = order[k];
+        const int r = mat->row_h[t];
+        if (r < 0 || r >= nrows_out || mat->col_h[t] < 0 || mat->col_h[t] >= pp->dev.nrows) {
+            delete m;
+            return fail("pencil_add_matrix: term index out of range");
+        }
+        if (mat->ex_h[t] < 0 || mat->ex_h[t] > 7 || mat->ey_h[t] < 0 || mat->ey_h[t] > 7) {
+            delete m;
+            return fail("pencil_add_matrix: exponents must be in 0..7");
+        }
+        rowptr[r + 1]++;
+        m->row_h[k] = r;
+        m->col_h[k] = mat->col_h[t];
+        m->coef_h[k] = make_double2(mat->coef_re_h[t], mat->coef_im_h[t]);
+        m->expo_h[k] = (unsigned)mat->ex_h[t] | ((unsigned)mat->ey_h[t] << 8) |
+                       ((unsigned)(mat->dx_h[t] ? 1 : 0) << 16) | ((unsigned)(mat->dy_h[t] ? 1 : 0) << 24);
+    }
+    for (int r = 0; r < nrows_out; ++r) rowptr[r + 1] += rowptr[r];
+    int st = upload_vec(&m->d_rowptr, rowptr.data(), rowptr.size());
+    if (!st) st = upload_vec(&m->d_col, m->col_h.data(), (size_t)nt);
+    if (!st) st = upload_vec(&m->d_coef, m->coef_h.data(), (size_t)nt);
+    if (!st) st = upload_vec(&m->d_expo, m->expo_h.data(), (size_t)nt);
+    if (st) { delete m; return st; }
+    m->dev.nrows_out = nrows_out;
+    m->dev.nterms = nt;
+    m->dev.rowptr = (const int *)m->d_rowptr;
+    m->dev.col = (const int *)m->d_col;
+    m->dev.coef = (const double2 *)m->d_coef;
+    m->dev.expo = (const unsigned *)m->d_expo;
+    pp->mats.push_back(m);
+    *mat_id = (int)pp->mats.size() - 1;
+    return 0;
+}
+
+int ddh_pencil_matvec(ddh_handle pack, int mat_id, const double *x, double *y, void *stream) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (mat_id < 0 || mat_id >= (int)pp->mats.size()) return fail("pencil_matvec: bad matrix id");
+    if (x == y) return fail("pencil_matvec: in-place unsupported");
+    const PencilDev &P = pp->dev;
+    const MatDev &A = pp->mats[mat_id]->dev;
+    const unsigned blocks = (unsigned)((P.ncells + 255) / 256);
+    hipStream_t s = as_stream(stream);
+    if (P.nf == 2)
+        hipLaunchKernelGGL(matvec_kernel<2>, dim3(blocks), dim3(256), 0, s, P, A, x, y);
+    else if (P.nf == 1)
+        hipLaunchKernelGGL(matvec_kernel<1>, dim3(blocks), dim3(256), 0, s, P, A, x, y);
+    else
+        hipLaunchKernelGGL(matvec_kernel<0>, dim3(blocks), dim3(256), 0, s, P, A, x, y);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_pencil_factor(ddh_handle pack, int matM_id, int matL_id, double a, double b, const int *row_perm_h,
+                      const int *col_perm_h, int n_interior, int kl, int ku, const unsigned char *row_axes_h,
+                      const unsigned char *col_axes_h, int reuse_lu_id, int *lu_id, void *stream) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    const PencilDev &P = pp->dev;
+    const int nm = (int)pp->mats.size();
+    if (matM_id < 0 || matM_id >= nm || matL_id < 0 || matL_id >= nm) return fail("pencil_factor: bad matrix id");
+    const int N = P.nrows, n = n_interior, nb = N - n;
+    if (n < 0 || nb < 0) return fail("pencil_factor: bad interior size");
+    if (kl > KLMAX) return fail("pencil_factor: lower bandwidth " + std::to_string(kl) + " exceeds KLMAX=12");
+    if (nb > NBMAX) return fail("pencil_factor: border size " + std::to_string(nb) + " exceeds NBMAX=16");
+    const int W = ku + kl;
+    if (W > 64) return fail("pencil_factor: band too wide (ku+kl=" + std::to_string(W) + " > 64)");
+    if (nb > W && n > 0) return fail("pencil_factor: border wider than the band window");
+    if (pp->mats[matM_id]->dev.nrows_out != N || pp->mats[matL_id]->dev.nrows_out != N)
+        return fail("pencil_factor: matrices must be square (nrows x nrows)");
+    LuFactor *lu = nullptr;
+    const bool reuse = reuse_lu_id >= 0 && reuse_lu_id < (int)pp->lus.size() && pp->lus[reuse_lu_id] &&
+                       pp->lus[reuse_lu_id]->dev.n == n && pp->lus[reuse_lu_id]->dev.kl == kl &&
+                       pp->lus[reuse_lu_id]->dev.ku == ku;
+    hipStream_t s = as_stream(stream);
+    if (reuse) {
+        lu = pp->lus[reuse_lu_id];
+    } else {
+        lu = new LuFactor();
+        LuDev &d = lu->dev;
+        d.n = n; d.nb = nb; d.N = N; d.kl = kl; d.ku = ku; d.W = W; d.BW = kl + W + 1;
+        const size_t G = (size_t)P.G;
+        const size_t szAw = sizeof(double2) * (size_t)(n > 0 ? n : 1) * d.BW * G;
+        const size_t szAb = sizeof(double2) * (size_t)N * (nb > 0 ? nb : 1) * G;
+        const size_t szScr = sizeof(double2) * (size_t)std::max(n, nb * nb) * G;
+        int st = check_hip(hipMalloc((void **)&d.Aw, szAw), "hipMalloc(band LU)");
+        if (!st) st = check_hip(hipMalloc((void **)&d.Ab, szAb), "hipMalloc(border LU)");
+        if (!st) st = check_hip(hipMalloc((void **)&d.piv, (size_t)(n > 0 ? n : 1) * G), "hipMalloc(piv)");
+        if (!st) st = check_hip(hipMalloc((void **)&d.flag, G), "hipMalloc(flag)");
+        if (!st) st = check_hip(hipMalloc((void **)&d.scratch, szScr), "hipMalloc(scratch)");
+        if (!st) st = upload_vec(&lu->d_rowperm, row_perm_h, (size_t)N);
+        if (!st) st = upload_vec(&lu->d_colperm, col_perm_h, (size_t)N);
+        if (!st) st = upload_vec(&lu->d_raxes, row_axes_h + n, (size_t)nb);
+        if (!st) st = upload_vec(&lu->d_caxes, col_axes_h + n, (size_t)nb);
+        if (st) { free_lu(lu); return st; }
+        d.rowperm = (const int *)lu->d_rowperm;
+        d.colperm = (const int *)lu->d_colperm;
+        d.row_axes = (const unsigned char *)lu->d_raxes;
+        d.col_axes = (const unsigned char *)lu->d_caxes;
+        lu->bytes = szAw + szAb + szScr + (size_t)n * G + G;
+        // interior rows / columns must exist for every cell
+        for (int i = 0; i < n; ++i)
+            if ((row_axes_h[i] & 3) != 3 || (col_axes_h[i] & 3) != 3) {
+                free_lu(lu);
+                return fail("pencil_factor: interior rows/columns must be valid for all pencils");
+            }
+    }
+    LuDev &d = lu->dev;
+    const size_t G = (size_t)P.G;
+    DDH_HIP(hipMemsetAsync(d.Aw, 0, sizeof(double2) * (size_t)(n > 0 ? n : 1) * d.BW * G, s));
+    DDH_HIP(hipMemsetAsync(d.Ab, 0, sizeof(double2) * (size_t)N * (nb > 0 ? nb : 1) * G, s));
+    // inverse permutations (physical -> logical) on the device
+    std::vector<int> rowinv(N), colinv(N);
+    for (int i = 0; i < N; ++i) {
+        rowinv[row_perm_h[i]] = i;
+        colinv[col_perm_h[i]] = i;
+    }
+    void *d_rowinv = nullptr, *d_colinv = nullptr;
+    int st = upload_vec(&d_rowinv, rowinv.data(), (size_t)N);
+    if (!st) st = upload_vec(&d_colinv, colinv.data(), (size_t)N);
+    if (st) { if (!reuse) free_lu(lu); return st; }
+    const unsigned blocks = (unsigned)((P.G + 63) / 64);
+    hipLaunchKernelGGL(factor_kernel, dim3(blocks), dim3(64), 0, s, P, d, pp->mats[matM_id]->dev,
+                       pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
+    DDH_HIP(hipGetLastError());
+    DDH_HIP(hipStreamSynchronize(s));
+    (void)hipFree(d_rowinv);
+    (void)hipFree(d_colinv);
+    // flagged systems -> flagged cells
+    std::vector<unsigned char> flags(G);
+    DDH_HIP(hipMemcpy(flags.data(), d.flag, G, hipMemcpyDeviceToHost));
+    lu->flag_cells.clear();
+    for (long cidx = 0; cidx < P.ncells; ++cidx) {
+        bool f = false;
+        for (int sidx = 0; sidx < P.S; ++sidx) f = f || flags[cidx * P.S + sidx];
+        if (f) lu->flag_cells.push_back(cidx);
+    }
+    lu->nflag = (int)lu->flag_cells.size();
+    (void)hipFree(lu->d_flag_cells); lu->d_flag_cells = nullptr;
+    (void)hipFree(lu->d_inv); lu->d_inv = nullptr;
+    (void)hipFree(lu->d_dense_rhs); lu->d_dense_rhs = nullptr;
+    if (lu->nflag) {
+        st = upload_vec(&lu->d_flag_cells, lu->flag_cells.data(), lu->flag_cells.size());
+        if (st) return st;
+    }
+    if (reuse) {
+        *lu_id = reuse_lu_id;
+    } else {
+        pp->lus.push_back(lu);
+        *lu_id = (int)pp->lus.size() - 1;
+    }
+    return 0;
+}
+
+/* number of flagged cells of a factorization and their ids (host array of *count longs) */
+int ddh_pencil_flagged(ddh_handle pack, int lu_id, int *count, long *cells_h, int max_cells) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_flagged: bad LU id");
+    LuFactor *lu = pp->lus[lu_id];
+    *count = lu->nflag;
+    for (int i = 0; i < lu->nflag && i < max_cells; ++i) cells_h[i] = lu->flag_cells[i];
+    return 0;
+}
+
+/* explicit inverses (logical ordering, row-major N x N complex) for every system of every flagged
+ * cell, in the order of ddh_pencil_flagged: inv_h[(f*S + s)*N*N + i*N + j] as interleaved re/im */
+int ddh_pencil_set_dense_inverse(ddh_handle pack, int lu_id, const double *inv_h) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_set_dense_inverse: bad LU id");
+    LuFactor *lu = pp->lus[lu_id];
+    if (!lu->nflag) return 0;
+    const size_t N = (size_t)lu->dev.N, nsys = (size_t)lu->nflag * pp->dev.S;
+    (void)hipFree(lu->d_inv);
+    (void)hipFree(lu->d_dense_rhs);
+    DDH_HIP(hipMalloc(&lu->d_inv, nsys * N * N * sizeof(double2)));
+    DDH_HIP(hipMalloc(&lu->d_dense_rhs, 2 * nsys * N * sizeof(double2)));
+    DDH_HIP(hipMemcpy(lu->d_inv, inv_h, nsys * N * N * sizeof(double2), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ddh_pencil_solve(ddh_handle pack, int lu_id, const double *rhs, double *x, void *stream) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_solve: bad LU id");
+    if (rhs == x) return fail("pencil_solve: in-place unsupported");
+    LuFactor *lu = pp->lus[lu_id];
+    hipStream_t s = as_stream(stream);
+    if (pp->dev.nf == 2) return launch_solve<2>(pp, lu, rhs, x, s);
+    if (pp->dev.nf == 1) return launch_solve<1>(pp, lu, rhs, x, s);
+    return launch_solve<0>(pp, lu, rhs, x, s);
+}
+
+int ddh_pencil_lu_bytes(ddh_handle pack, int lu_id, size_t *bytes) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_lu_bytes: bad LU id");
+    *bytes = pp->lus[lu_id]->bytes;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+"""
+ctypes binding of libdedalus_hip.so (the C ABI declared in include/dedalus_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing, or no gfx950 device is
+visible when a device operation is requested, this module raises.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdedalus_hip.so")
+
+_lib = None
+
+
+class DdhError(RuntimeError):
+    pass
+
+
+class PencilGeom(C.Structure):
+    _fields_ = [("nfourier", C.c_int), ("nrows", C.c_int), ("nx", C.c_long), ("ny", C.c_long),
+                ("kx_h", C.POINTER(C.c_double)), ("ky_h", C.POINTER(C.c_double))]
+
+
+class PolyMat(C.Structure):
+    _fields_ = [("nterms", C.c_int),
+                ("row_h", C.POINTER(C.c_int)), ("col_h", C.POINTER(C.c_int)),
+                ("coef_re_h", C.POINTER(C.c_double)), ("coef_im_h", C.POINTER(C.c_double)),
+                ("ex_h", C.POINTER(C.c_byte)), ("ey_h", C.POINTER(C.c_byte)),
+                ("dx_h", C.POINTER(C.c_byte)), ("dy_h", C.POINTER(C.c_byte))]
+
+
+_vp, _h, _hp = C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)
+_dp, _ip, _l, _i, _d = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_long, C.c_int, C.c_double
+
+# name -> argtypes; every function returns int status (except ddh_last_error)
+SIGNATURES = {
+    "ddh_init": [_i],
+    "ddh_device_count": [_ip],
+    "ddh_alloc": [C.POINTER(_vp), C.c_size_t],
+    "ddh_free": [_vp],
+    "ddh_memset": [_vp, _i, C.c_size_t, _vp],
+    "ddh_memcpy_h2d": [_vp, _vp, C.c_size_t, _vp],
+    "ddh_memcpy_d2h": [_vp, _vp, C.c_size_t, _vp],
+    "ddh_memcpy_d2d": [_vp, _vp, C.c_size_t, _vp],
+    "ddh_stream_sync": [_vp],
+    "ddh_destroy": [_h],
+    "ddh_plan_rfft": [_hp, _i, _i],
+    "ddh_rfft_forward": [_h, _vp, _vp, _l, _l, _vp],
+    "ddh_rfft_backward": [_h, _vp, _vp, _l, _l, _vp],
+    "ddh_plan_cfft": [_hp, _i, _i],
+    "ddh_cfft_forward": [_h, _vp, _vp, _l, _l, _vp],
+    "ddh_cfft_backward": [_h, _vp, _vp, _l, _l, _vp],
+    "ddh_plan_cheb": [_hp, _i, _i, _i, _ip, _dp],
+    "ddh_cheb_forward": [_h, _vp, _vp, _l, _l, _vp],
+    "ddh_cheb_backward": [_h, _vp, _vp, _l, _l, _vp],
+    "ddh_plan_mmt": [_hp, _i, _i, _dp],
+    "ddh_mmt_apply": [_h, _vp, _vp, _l, _l, _vp],
+    "ddh_lincomb": [_vp, _i, C.POINTER(_vp), _dp, _l, _vp],
+    "ddh_grid_bilinear": [_vp, _i, _vp, _vp, _l, _i, _ip, _ip, _ip, _dp, _vp],
+    "ddh_grid_cfl": [_vp, _vp, _i, _l, C.POINTER(_vp), C.POINTER(_l), _i, _vp],
+    "ddh_pencil_create": [_hp, C.POINTER(PencilGeom)],
+    "ddh_pencil_add_matrix": [_h, C.POINTER(PolyMat), _i, _ip],
+    "ddh_pencil_matvec": [_h, _i, _vp, _vp, _vp],
+    "ddh_pencil_factor": [_h, _i, _i, _d, _d, _ip, _ip, _i, _i, _i,
+                          C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte), _i, _ip, _vp],
+    "ddh_pencil_solve": [_h, _i, _vp, _vp, _vp],
+    "ddh_pencil_flagged": [_h, _i, _ip, C.POINTER(_l), _i],
+    "ddh_pencil_set_dense_inverse": [_h, _i, _dp],
+    "ddh_pencil_lu_bytes": [_h, _i, C.POINTER(C.c_size_t)],
+    "ddh_a2a_pack": [_vp, _vp, _l, _l, _l, _l, _i, _vp],
+    "ddh_a2a_unpack": [_vp, _vp, _l, _l, _l, _l, _i, _vp],
+}
+
+
+def load(build_if_missing=False):
+    """Load the shared library (no device needed). Raises if it cannot be found."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if build_if_missing:
+            from . import build
+            build.build_library()
+        else:
+            raise DdhError("libdedalus_hip.so not found at %s -- run `python -m dedalus_amd.build` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.ddh_last_error.argtypes = []
+    lib.ddh_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().ddh_last_error().decode("utf-8", "replace")
+        raise DdhError("%s failed (status %d): %s" % (what or "libdedalus_hip call", status, msg))
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)
+
+
+def as_dp(a):
+    return a.ctypes.data_as(_dp)
+
+
+def as_ip(a):
+    return a.ctypes.data_as(_ip)
+
+
+def as_bp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_byte))
+
+
+def as_ubp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_ubyte))

@@ -1,0 +1,156 @@
+"""
+Host wrapper of the batched pencil engine in libdedalus_hip.so (ddh_pencil_*).
+
+A PencilPack owns, for ALL pencils of a problem at once: the cell geometry, the matrices as
+polynomial term lists, and the bordered-band LU factorizations.  It replaces the reference's
+per-subproblem Python loops (core/timesteppers.py:588-591, 611-614, 630-643) and per-pencil
+scipy/SuperLU objects (core/subsystems.py:497-596, libraries/matsolvers.py:126-149).
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import libhip
+from .device import ptr
+
+
+class TermList:
+    """Sparse matrix whose entries are polynomials in the pencil wavenumbers:
+        A[row, col] += coef * kx^ex * ky^ey * [mx==0]^dx * [my==0]^dy
+    """
+
+    __slots__ = ("nrows", "ncols", "row", "col", "coef", "ex", "ey", "dx", "dy")
+
+    def __init__(self, nrows, ncols, row=(), col=(), coef=(), ex=(), ey=(), dx=(), dy=()):
+        self.nrows, self.ncols = int(nrows), int(ncols)
+        self.row = np.asarray(row, dtype=np.int32).ravel()
+        self.col = np.asarray(col, dtype=np.int32).ravel()
+        self.coef = np.asarray(coef, dtype=np.complex128).ravel()
+        n = self.row.size
+        self.ex = np.asarray(ex, dtype=np.int8).ravel() if np.size(ex) else np.zeros(n, np.int8)
+        self.ey = np.asarray(ey, dtype=np.int8).ravel() if np.size(ey) else np.zeros(n, np.int8)
+        self.dx = np.asarray(dx, dtype=np.int8).ravel() if np.size(dx) else np.zeros(n, np.int8)
+        self.dy = np.asarray(dy, dtype=np.int8).ravel() if np.size(dy) else np.zeros(n, np.int8)
+
+    @property
+    def nterms(self):
+        return self.row.size
+
+    def consolidated(self, cutoff=0.0):
+        """Merge duplicate (row, col, monomial) terms and drop |coef| <= cutoff."""
+        if self.nterms == 0:
+            return self
+        key = np.stack([self.row.astype(np.int64), self.col.astype(np.int64), self.ex.astype(np.int64),
+                        self.ey.astype(np.int64), self.dx.astype(np.int64), self.dy.astype(np.int64)], axis=1)
+        uniq, inv = np.unique(key, axis=0, return_inverse=True)
+        coef = np.zeros(len(uniq), dtype=np.complex128)
+        np.add.at(coef, inv.ravel(), self.coef)
+        keep = np.abs(coef) > cutoff
+        u = uniq[keep]
+        return TermList(self.nrows, self.ncols, u[:, 0], u[:, 1], coef[keep], u[:, 2], u[:, 3], u[:, 4], u[:, 5])
+
+    def dense(self, kx, ky, mx, my, sign=1):
+        """Dense complex matrix of one system (host-side; used for the few flagged pencils)."""
+        val = self.coef * (sign * kx) ** self.ex.astype(float) * ky ** self.ey.astype(float)
+        if mx != 0:
+            val = np.where(self.dx != 0, 0.0, val)
+        if my != 0:
+            val = np.where(self.dy != 0, 0.0, val)
+        A = np.zeros((self.nrows, self.ncols), dtype=np.complex128)
+        np.add.at(A, (self.row, self.col), val)
+        return A
+
+
+class PencilPack:
+    def __init__(self, dev, nfourier, nrows, nx, ny, kx, ky):
+        self.dev = dev
+        self.nf, self.nrows, self.nx, self.ny = int(nfourier), int(nrows), int(nx), int(ny)
+        self.kx = np.ascontiguousarray(kx, dtype=np.float64)
+        self.ky = np.ascontiguousarray(ky, dtype=np.float64)
+        geom = libhip.PencilGeom(self.nf, self.nrows, self.nx, self.ny, libhip.as_dp(self.kx), libhip.as_dp(self.ky))
+        self.handle = C.c_uint64(0)
+        libhip.call("ddh_pencil_create", C.byref(self.handle), C.byref(geom))
+        self.S = 2 if self.nf == 2 else 1
+        self.ncx = self.nx // 2 if self.nf >= 1 else 1
+        self.ncy = self.ny // 2 if self.nf == 2 else 1
+        self.matrices = []
+        self.lu_meta = {}
+
+    def add_matrix(self, tl):
+        row = np.ascontiguousarray(tl.row)
+        col = np.ascontiguousarray(tl.col)
+        cre = np.ascontiguousarray(tl.coef.real)
+        cim = np.ascontiguousarray(tl.coef.imag)
+        ex, ey, dx, dy = (np.ascontiguousarray(a) for a in (tl.ex, tl.ey, tl.dx, tl.dy))
+        pm = libhip.PolyMat(tl.nterms, libhip.as_ip(row), libhip.as_ip(col), libhip.as_dp(cre), libhip.as_dp(cim),
+                            libhip.as_bp(ex), libhip.as_bp(ey), libhip.as_bp(dx), libhip.as_bp(dy))
+        mid = C.c_int(-1)
+        libhip.call("ddh_pencil_add_matrix", self.handle, C.byref(pm), tl.nrows, C.byref(mid))
+        self.matrices.append(tl)
+        return mid.value
+
+    def matvec(self, mat_id, x, y):
+        libhip.call("ddh_pencil_matvec", self.handle, mat_id, ptr(x), ptr(y), self.dev.stream)
+
+    def factor(self, matM, matL, a, b, row_perm, col_perm, n_interior, kl, ku, row_axes, col_axes, reuse=-1):
+        """Factor a*M + b*L for every pencil; returns the LU id."""
+        row_perm = np.ascontiguousarray(row_perm, dtype=np.int32)
+        col_perm = np.ascontiguousarray(col_perm, dtype=np.int32)
+        # masks are passed in LOGICAL order
+        ra = np.ascontiguousarray(np.asarray(row_axes, dtype=np.uint8)[row_perm])
+        ca = np.ascontiguousarray(np.asarray(col_axes, dtype=np.uint8)[col_perm])
+        lu = C.c_int(-1)
+        libhip.call("ddh_pencil_factor", self.handle, matM, matL, float(a), float(b), libhip.as_ip(row_perm),
+                    libhip.as_ip(col_perm), int(n_interior), int(kl), int(ku), libhip.as_ubp(ra), libhip.as_ubp(ca),
+                    int(reuse), C.byref(lu), self.dev.stream)
+        lu_id = lu.value
+        # pencils whose band block is singular: explicit dense inverse built here on the host
+        count = C.c_int(0)
+        cells = np.zeros(4096, dtype=np.int64)
+        libhip.call("ddh_pencil_flagged", self.handle, lu_id, C.byref(count),
+                    cells.ctypes.data_as(C.POINTER(C.c_long)), cells.size)
+        nflag = count.value
+        if nflag > cells.size or nflag * self.S * self.nrows ** 2 * 16 > 8e9:
+            raise libhip.DdhError("%d pencils have a singular band block: problem structure unsupported by the "
+                                  "bordered-band solver" % nflag)
+        if nflag:
+            N = self.nrows
+            inv = np.zeros((nflag * self.S, N, N), dtype=np.complex128)
+            M, L = self.matrices[matM], self.matrices[matL]
+            for f in range(nflag):
+                cell = int(cells[f])
+                mx, my = (cell // self.ncy, cell % self.ncy) if self.nf == 2 else (cell, 0)
+                kxv = self.kx[mx] if self.nf >= 1 else 0.0
+                kyv = self.ky[my] if self.nf == 2 else 0.0
+                for s in range(self.S):
+                    sign = 1 if s == 0 else -1
+                    A = a * M.dense(kxv, kyv, mx, my, sign) + b * L.dense(kxv, kyv, mx, my, sign)
+                    A = A[np.ix_(row_perm, col_perm)]
+                    # identity pairing of rows/columns that do not exist for this pencil
+                    bad_r = [i for i in range(N) if not _valid(ra[i], mx, my, self.nf)]
+                    bad_c = [i for i in range(N) if not _valid(ca[i], mx, my, self.nf)]
+                    for i, j in zip(bad_r, bad_c):
+                        A[i, j] = 1.0
+                    inv[f * self.S + s] = np.linalg.inv(A)
+            inv = np.ascontiguousarray(inv)
+            libhip.call("ddh_pencil_set_dense_inverse", self.handle, lu_id,
+                        inv.view(np.float64).ctypes.data_as(C.POINTER(C.c_double)))
+        self.lu_meta[lu_id] = dict(nflag=nflag, a=a, b=b)
+        return lu_id
+
+    def solve(self, lu_id, rhs, x):
+        libhip.call("ddh_pencil_solve", self.handle, lu_id, ptr(rhs), ptr(x), self.dev.stream)
+
+    def lu_bytes(self, lu_id):
+        n = C.c_size_t(0)
+        libhip.call("ddh_pencil_lu_bytes", self.handle, lu_id, C.byref(n))
+        return n.value
+
+
+def _valid(bits, mx, my, nf):
+    if nf >= 1 and mx != 0 and not (bits & 1):
+        return False
+    if nf == 2 and my != 0 and not (bits & 2):
+        return False
+    return True

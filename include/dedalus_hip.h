@@ -1,0 +1,155 @@
+/*
+ * libdedalus_hip.so -- C ABI of the MI355X (gfx950) implementation of the Dedalus v3 IMEX hot path.
+ *
+ * Conventions:
+ *   - plain C symbols, int status return: 0 = ok, negative = error; ddh_last_error() gives the text
+ *   - every pointer is a DEVICE pointer unless its name ends in _h (host)
+ *   - opaque uint64_t handles; the library owns plan/workspace memory, the caller owns field buffers
+ *   - asynchronous on the caller-supplied hipStream_t (passed as void*; NULL = default stream)
+ *   - thread-compatible, not thread-safe: one host thread per GPU
+ *   - all floating point data is IEEE double (the reference computes in float64 throughout)
+ *
+ * Each entry point names the reference interface it replaces (file:line under /root/reference).
+ *
+ * Data layout ("z-major pencil layout"): a field's coefficient array is
+ *   [component][coupled axis (Chebyshev) index][separable axis 0][separable axis 1]
+ * with the last axis contiguous.  A transform acts on one axis of the 3-index view
+ *   [outer][n][inner]            (n = axis length, inner = product of the faster axes).
+ */
+#ifndef DEDALUS_HIP_H
+#define DEDALUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t ddh_handle;
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+int ddh_init(int device);                       /* replaces fftw_mpi_init, libraries/fftw/fftw_wrappers.pyx:23-25 */
+const char *ddh_last_error(void);
+int ddh_device_count(int *count);
+int ddh_alloc(void **ptr, size_t bytes);        /* replaces create_buffer, fftw_wrappers.pyx:28-58 (Field._create_buffer core/field.py:476-485) */
+int ddh_free(void *ptr);
+int ddh_memset(void *ptr, int value, size_t bytes, void *stream);
+int ddh_memcpy_h2d(void *dst, const void *src_h, size_t bytes, void *stream);
+int ddh_memcpy_d2h(void *dst_h, const void *src, size_t bytes, void *stream);
+int ddh_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int ddh_stream_sync(void *stream);
+int ddh_destroy(ddh_handle h);                  /* any plan / pack handle */
+
+/* ---- spectral transforms -------------------------------------------- */
+/* RealFourier: replaces FFTWRealFFT.forward/backward core/transforms.py:537-565 with the
+ * unpack_rescale / repack_rescale passes (:469-509) fused into the FFT's load/store.
+ * Coefficient axis is interleaved [a0,b0,a1,b1,...] (cos, -sin); n_coeff must be even.        */
+int ddh_plan_rfft(ddh_handle *plan, int n_grid, int n_coeff);
+int ddh_rfft_forward(ddh_handle plan, const double *g, double *c, long outer, long inner, void *stream);
+int ddh_rfft_backward(ddh_handle plan, const double *c, double *g, long outer, long inner, void *stream);
+
+/* ComplexFourier: replaces FFTWComplexFFT core/transforms.py:292-330 (resize_coeffs :243-267 fused).
+ * Arrays are complex128 stored as interleaved doubles; `inner` counts complex elements.        */
+int ddh_plan_cfft(ddh_handle *plan, int n_grid, int n_coeff);
+int ddh_cfft_forward(ddh_handle plan, const double *g, double *c, long outer, long inner, void *stream);
+int ddh_cfft_backward(ddh_handle plan, const double *c, double *g, long outer, long inner, void *stream);
+
+/* Chebyshev-T grid (a0=b0=-1/2) with optional ultraspherical output basis: replaces
+ * FFTWFastChebyshevTransform core/transforms.py:801-902 (FastCosineTransform :715-746, FFTWDCT
+ * :771-798, conversion apply :862-874, solve_upper_sparse :876-890).
+ * The conversion matrix (n_coeff x n_coeff, upper banded) is passed as `nbands` diagonals with
+ * offsets band_offsets_h[d] >= 0 (offset 0 first): bands_h[d*n_coeff + k] = C[k, k+offset_d].
+ * nbands = 0 means output basis == grid basis (no conversion).
+ * Only dealias_before_converting = True (the reference default, dedalus.cfg:41) is implemented. */
+int ddh_plan_cheb(ddh_handle *plan, int n_grid, int n_coeff, int nbands,
+                  const int *band_offsets_h, const double *bands_h);
+int ddh_cheb_forward(ddh_handle plan, const double *g, double *c, long outer, long inner, void *stream);
+int ddh_cheb_backward(ddh_handle plan, const double *c, double *g, long outer, long inner, void *stream);
+
+/* Dense matrix-multiply transform along an axis (JacobiMMT core/transforms.py:114-158 via
+ * apply_dense tools/array.py:104-129): out[o, i, :] = sum_j mat[i, j] * in[o, j, :].
+ * mat_h is row-major (n_out x n_in) float64 on the host; copied to the device by the plan.     */
+int ddh_plan_mmt(ddh_handle *plan, int n_out, int n_in, const double *mat_h);
+int ddh_mmt_apply(ddh_handle plan, const double *in, double *out, long outer, long inner, void *stream);
+
+/* ---- grid-space and vector kernels -------------------------------- */
+/* y = sum_t alpha[t] * x_t  (RHS assembly timesteppers.py:617-623 / :156-166; BLAS axpy chain).
+ * xs_h: host array of nterms device pointers; y may alias one of them only if it is xs_h[0].   */
+int ddh_lincomb(double *y, int nterms, const double *const *xs_h, const double *alpha_h,
+                long n, void *stream);
+/* out[c] = sum_t coef[t] * a[ia[t]] * b[ib[t]] over `n` grid points per component: covers
+ * MultiplyFields / DotProduct / CrossProduct operate() (core/arithmetic.py:666-674,708-728,855-866). */
+int ddh_grid_bilinear(double *out, int ncomp_out, const double *a, const double *b, long n,
+                      int nterms, const int *ic_h, const int *ia_h, const int *ib_h,
+                      const double *coef_h, void *stream);
+/* max over points of sum_c |u_c| * inv_spacing_c  (AdvectiveCFL, core/operators.py:4342-4419) */
+int ddh_grid_cfl(double *result_d, const double *u, int ncomp, long n,
+                 const double *const *inv_spacing_axes, const long *axis_len_h, int naxes, void *stream);
+
+/* ---- pencil systems ------------------------------------------ */
+/* A "pencil pack" describes all pencils of a problem at once.  System vectors are real arrays
+ * [nrows][nx][ny] (cell index fastest).  With nfourier real-Fourier separable axes a cell holds
+ * 2^nfourier real parts which are combined on the fly into complex systems.
+ *
+ * Matrices are "polynomial term lists": entry (row,col) += coef * kx^ex * ky^ey * [mx==0]^dx * [my==0]^dy.
+ * This replaces the per-pencil scipy CSR matrices of Subproblem.build_matrices
+ * (core/subsystems.py:497-596) and the per-pencil Python loops of timesteppers.py:588-591,630-643. */
+typedef struct {
+    int nfourier;          /* 0, 1 or 2 separable real-Fourier axes                                */
+    int nrows;             /* rows of the system vector (all variables x coupled-axis modes)       */
+    long nx, ny;           /* real storage extents of the two cell axes (ny = 1 ... if unused)     */
+    const double *kx_h;    /* physical wavenumber per x mode index (nx/2 entries), host            */
+    const double *ky_h;    /* physical wavenumber per y mode index (ny/2 entries), host            */
+} ddh_pencil_geom;
+
+typedef struct {
+    int nterms;
+    const int *row_h, *col_h;       /* nterms each                                                  */
+    const double *coef_re_h, *coef_im_h;
+    const signed char *ex_h, *ey_h; /* monomial exponents                                           */
+    const signed char *dx_h, *dy_h; /* 1 -> term only present where mx==0 / my==0                   */
+} ddh_polymat;
+
+int ddh_pencil_create(ddh_handle *pack, const ddh_pencil_geom *geom);
+/* register a matrix; returns its id in *mat_id */
+int ddh_pencil_add_matrix(ddh_handle pack, const ddh_polymat *mat, int nrows_out, int *mat_id);
+/* y[nrows_out][cells] = A x  (apply_sparse tools/array.py:171-203 over all pencils at once;
+ * gather/scatter subsystems.py:340-380 are the identity in this layout)                           */
+int ddh_pencil_matvec(ddh_handle pack, int mat_id, const double *x, double *y, void *stream);
+/* Bordered-banded LU of (a*M + b*L) for every pencil (matsolvers.py:126-149 SuperLU replaced;
+ * LHS formation timesteppers.py:172-181, 630-640).
+ * perm_h: logical->physical row/col permutations, n_interior leading logical rows/cols form the
+ * banded block with lower/upper bandwidth kl/ku, the remaining nrows-n_interior are the border.
+ * valid masks: row_axes_h/col_axes_h[r] bit0: row exists for mx>0, bit1: exists for my>0.
+ * Entries outside the declared band send the affected pencil to the dense fallback below.
+ * reuse_lu_id >= 0 re-factors into the storage of an existing LU (dt change), -1 allocates.
+ * Returns an LU id in *lu_id.                                                                      */
+int ddh_pencil_factor(ddh_handle pack, int matM_id, int matL_id, double a, double b,
+                      const int *row_perm_h, const int *col_perm_h, int n_interior, int kl, int ku,
+                      const unsigned char *row_axes_h, const unsigned char *col_axes_h,
+                      int reuse_lu_id, int *lu_id, void *stream);
+int ddh_pencil_solve(ddh_handle pack, int lu_id, const double *rhs, double *x, void *stream);
+/* Pencils whose band block is singular (e.g. the kx=ky=0 pressure-gauge pencil) are flagged by
+ * ddh_pencil_factor and solved with an explicit dense inverse the host supplies: query the flagged
+ * cell ids, then upload inverses in logical (permuted) ordering, complex row-major N x N per
+ * system, systems ordered (flagged cell, s).                                                      */
+int ddh_pencil_flagged(ddh_handle pack, int lu_id, int *count, long *cells_h, int max_cells);
+int ddh_pencil_set_dense_inverse(ddh_handle pack, int lu_id, const double *inv_h);
+int ddh_pencil_lu_bytes(ddh_handle pack, int lu_id, size_t *bytes);
+
+/* ---- distributed transposes ----------------------------------------------- */
+/* Local pack / unpack for the all-to-all that replaces FFTWTranspose / AlltoallvTranspose
+ * (core/transposes.pyx:22-445).  The exchange itself is issued by the host through RCCL
+ * (torch.distributed all_to_all_single on the packed buffers).
+ * Splits axis `a` (length na) of [outer][na][nb][inner] into P blocks of `blk` and writes
+ * [P][outer][blk][nb][inner] (pack) or the inverse gathers along nb (unpack).                     */
+int ddh_a2a_pack(const double *src, double *dst, long outer, long na, long nb, long inner,
+                 int nparts, void *stream);
+int ddh_a2a_unpack(const double *src, double *dst, long outer, long na, long nb, long inner,
+                   int nparts, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

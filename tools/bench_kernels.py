@@ -1,0 +1,66 @@
+"""Micro-benchmark of the transform kernels at the 3-D Rayleigh-Benard line sizes (one component).
+Prints achieved algorithmic GB/s = (bytes read + bytes written) / time, measured with HIP events
+on the launch stream."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dedalus_amd import libhip  # noqa: E402
+from dedalus_amd.device import Device, ptr  # noqa: E402
+
+
+def plan(name, *args):
+    h = C.c_uint64(0)
+    libhip.call(name, C.byref(h), *args)
+    return h
+
+
+def timeit(dev, fn, reps=5):
+    t = dev.torch
+    fn()
+    dev.sync()
+    e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    dev.sync()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def main():
+    dev = Device.get()
+    t = dev.torch
+    Nx = Ny = int(os.environ.get("NXY", "512"))
+    Nz = int(os.environ.get("NZ", "256"))
+    Gx, Gy, Gz = 3 * Nx // 2, 3 * Ny // 2, 3 * Nz // 2
+    cases = [
+        # name, kind, N, M, coeff shape [outer, M, inner], as seen by the kernel
+        ("z  cheb  bwd/fwd  [kz,kx*ky]", "cheb", Gz, Nz, (1, Nz, Nx * Ny)),
+        ("y  rfft  bwd/fwd  contiguous", "rfft", Gy, Ny, (Gz * Nx, Ny, 1)),
+        ("x  rfft  bwd/fwd  inner=Gy  ", "rfft", Gx, Nx, (Gz, Nx, Gy)),
+    ]
+    for name, kind, N, M, cs in cases:
+        p = plan("ddh_plan_cheb", N, M, 0, None, None) if kind == "cheb" else plan("ddh_plan_rfft", N, M)
+        c = t.randn(cs, dtype=t.float64, device=dev.tdev)
+        gs = (cs[0], N, cs[2])
+        g = dev.empty(gs)
+        c2 = dev.empty(cs)
+        bytes_ = (c.numel() + g.numel()) * 8
+        tb = timeit(dev, lambda: libhip.call("ddh_%s_backward" % kind, p, ptr(c), ptr(g), cs[0], cs[2], dev.stream))
+        tf = timeit(dev, lambda: libhip.call("ddh_%s_forward" % kind, p, ptr(g), ptr(c2), cs[0], cs[2], dev.stream))
+        print("%s  bwd %.3f ms %.0f GB/s | fwd %.3f ms %.0f GB/s   (%.2f GB/pass)" %
+              (name, tb * 1e3, bytes_ / tb / 1e9, tf * 1e3, bytes_ / tf / 1e9, bytes_ / 1e9), flush=True)
+        del c, g, c2
+    # plain copy for reference
+    a = t.randn(2 ** 27, dtype=t.float64, device=dev.tdev)
+    b = t.empty_like(a)
+    tc = timeit(dev, lambda: b.copy_(a))
+    print("torch copy 1 GiB: %.0f GB/s" % (2 * a.numel() * 8 / tc / 1e9))
+
+
+if __name__ == "__main__":
+    main()
