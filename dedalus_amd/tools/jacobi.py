@@ -73,7 +73,12 @@ def conversion_matrix(N, a0, b0, a1, b1, dtype=np.float64):
     for _ in range(int(da)):
         C = _conv_a(N, a, b) @ C
         a += 1
-    return sparse.csr_matrix(C.astype(dtype))
+    C = sparse.csr_matrix(C.astype(dtype))
+    # products of the symmetric (a == b) steps cancel on the odd diagonals only up to long-double
+    # round-off (~1e-20): remove that noise so the band structure is exact
+    C.data[np.abs(C.data) < 1e-17] = 0.0
+    C.eliminate_zeros()
+    return C
 
 
 def differentiation_matrix(N, a, b, dtype=np.float64):

@@ -142,7 +142,7 @@ def test_matvec_factor_solve_vs_oracle(nf, ncx, ncy, gauge):
     assert rel(dev.to_host(dy), y_ref) < 1e-13
     # factor + solve
     a, b = 1.0, 0.37
-    kl, ku = bandwidth([M, L], pb["perm"], n) if nf > 0 else (0, 0)   # single pencil -> dense path
+    kl, ku = bandwidth([M, L], pb["perm"], n) if nf > 0 else (0, pb["nb"])   # single pencil -> dense path
     lu = pack.factor(idM, idL, a, b, pb["perm"], pb["perm"], n, kl, ku, pb["row_axes"], pb["col_axes"])
     if gauge and nf > 0:
         assert pack.lu_meta[lu]["nflag"] >= 1      # the k=0 pencil has a singular band block
@@ -208,7 +208,8 @@ def test_lincomb_bilinear_cfl_a2a():
     out = dev.empty((1, npts))
     ic = np.zeros(3, np.int32); ia = np.arange(3, dtype=np.int32); ib = np.arange(3, dtype=np.int32)
     cf = -np.ones(3)
-    libhip.call("ddh_grid_bilinear", ptr(out), 1, ptr(dev.from_host(u)), ptr(dev.from_host(g)), npts, 3,
+    d_u, d_g = dev.from_host(u), dev.from_host(g)
+    libhip.call("ddh_grid_bilinear", ptr(out), 1, ptr(d_u), ptr(d_g), npts, 3,
                 libhip.as_ip(ic), libhip.as_ip(ia), libhip.as_ip(ib), libhip.as_dp(cf), dev.stream)
     dev.sync()
     assert rel(dev.to_host(out)[0], -(u * g).sum(0)) < 1e-14
@@ -224,7 +225,8 @@ def test_lincomb_bilinear_cfl_a2a():
         assert np.array_equal(pk[p], src[:, p * (na // P):(p + 1) * (na // P)])
     blocks = rng.standard_normal((P, outer, na, nb_ // P, inner))
     d_un = dev.empty((outer, na, nb_, inner))
-    libhip.call("ddh_a2a_unpack", ptr(dev.from_host(blocks)), ptr(d_un), outer, na, nb_, inner, P, dev.stream)
+    d_blocks = dev.from_host(blocks)
+    libhip.call("ddh_a2a_unpack", ptr(d_blocks), ptr(d_un), outer, na, nb_, inner, P, dev.stream)
     dev.sync()
     un = dev.to_host(d_un)
     for p in range(P):

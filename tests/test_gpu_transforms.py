@@ -55,9 +55,9 @@ def _cheb_plan(N, M, alpha):
     if alpha == 0:
         return _plan("ddh_plan_cheb", N, M, 0, None, None), None
     conv = jacobi.conversion_matrix(M, -0.5, -0.5, alpha - 0.5, alpha - 0.5)
-    offs = np.array(sorted(set((conv.tocoo().col - conv.tocoo().row).tolist())), dtype=np.int32)
-    bands = np.zeros((len(offs), M))
     dense = conv.toarray()
+    offs = np.array([o for o in range(M) if np.any(np.diagonal(dense, o) != 0)], dtype=np.int32)
+    bands = np.zeros((len(offs), M))
     for d, o in enumerate(offs):
         bands[d, :M - o] = np.diagonal(dense, o)
     return _plan("ddh_plan_cheb", N, M, len(offs), libhip.as_ip(offs), libhip.as_dp(bands)), conv
