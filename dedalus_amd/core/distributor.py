@@ -1,0 +1,179 @@
+"""
+Distributor: owns the coordinate system, the storage-order convention, the device executor and the
+per-axis transform driver.  Replaces the Layout / Transform / Transpose path machinery of
+dedalus/core/distributor.py:36-175, 311-517, 588-661 (one rank per GPU; the pencil transposes of
+:696-924 become RCCL all-to-alls, see parallel.py).
+"""
+
+import numpy as np
+
+from .coords import CartesianCoordinates, Coordinate
+from .field import Field
+
+
+class Distributor:
+    def __init__(self, coordsystems, comm=None, mesh=None, dtype=None, executor=None):
+        if isinstance(coordsystems, (CartesianCoordinates, Coordinate)):
+            coordsystems = (coordsystems,)
+        self.coordsystems = tuple(coordsystems)
+        self.coords = tuple(c for cs in self.coordsystems for c in cs.coords)
+        self.dim = len(self.coords)
+        self.dtype = np.dtype(np.float64 if dtype is None else dtype)
+        self.mesh = tuple(mesh) if mesh is not None else ()
+        self._jacobi_axes = set()
+        self._layout_frozen = False
+        self._executor = executor
+        self.transformer = Transformer(self)
+        self.comm = comm
+
+    # ---- executor (device) -------------------------------------------------------------------------
+    @property
+    def executor(self):
+        if self._executor is None:
+            from ..executor import HipExecutor
+            self._executor = HipExecutor()       # raises without a gfx950 device: no CPU fallback
+        return self._executor
+
+    # ---- coordinates ---------------------------------------------------------------------------------
+    def coord_axis(self, coord):
+        return self.coords.index(coord)
+
+    def get_coord(self, name):
+        for c in self.coords:
+            if c.name == name:
+                return c
+        raise ValueError("unknown coordinate %r" % name)
+
+    def get_axis(self, coord):
+        return self.coord_axis(coord)
+
+    # ---- storage order ---------------------------------------------------------------------------------
+    def _register_domain(self, domain):
+        for ax, b in enumerate(domain.by_axis):
+            if b is not None and not b.separable and ax not in self._jacobi_axes:
+                if self._layout_frozen:
+                    raise ValueError("a Jacobi basis appeared on a new axis after fields were allocated")
+                self._jacobi_axes.add(ax)
+        if sum(b is not None for b in domain.by_axis) > 1:
+            self._layout_frozen = True
+        if len(self._jacobi_axes) > 1:
+            raise NotImplementedError("at most one Jacobi (coupled) axis is supported in this round")
+
+    @property
+    def storage_order(self):
+        jac = sorted(self._jacobi_axes)
+        return tuple(jac + [ax for ax in range(self.dim) if ax not in self._jacobi_axes])
+
+    @property
+    def separable_axes(self):
+        """User axes of the separable (Fourier) directions, in storage order."""
+        return tuple(ax for ax in self.storage_order if ax not in self._jacobi_axes)
+
+    def coupled_size(self, domain):
+        for ax in self._jacobi_axes:
+            b = domain.by_axis[ax]
+            if b is not None:
+                return b.coeff_size
+        return 1
+
+    # ---- field factories (core/distributor.py:Field/VectorField/TensorField) ----------------------------
+    def Field(self, *args, **kw):
+        return Field(self, *args, **kw)
+
+    ScalarField = Field
+
+    def VectorField(self, coordsys, *args, **kw):
+        return Field(self, *args, tensorsig=(coordsys,), **kw)
+
+    def TensorField(self, coordsys, *args, order=2, **kw):
+        if isinstance(coordsys, (tuple, list)):
+            sig = tuple(coordsys)
+        else:
+            sig = (coordsys,) * order
+        return Field(self, *args, tensorsig=sig, **kw)
+
+    # ---- grids ---------------------------------------------------------------------------------------
+    def _reshape_axis(self, arr, axis):
+        shape = [1] * self.dim
+        shape[axis] = arr.size
+        return arr.reshape(shape)
+
+    def local_grid(self, basis, scale=None):
+        scale = 1.0 if scale is None else scale
+        return self._reshape_axis(basis.global_grid(scale), self.coord_axis(basis.coord))
+
+    def local_grids(self, *bases, scales=None):
+        out = []
+        for b in bases:
+            ax = self.coord_axis(b.coord)
+            if scales is None:
+                s = 1.0
+            elif isinstance(scales, (tuple, list)):
+                s = scales[ax]
+            else:
+                s = scales
+            out.append(self._reshape_axis(b.global_grid(s), ax))
+        return tuple(out)
+
+    def local_modes(self, basis):
+        ax = self.coord_axis(basis.coord)
+        if basis.separable:
+            return self._reshape_axis(basis.wavenumbers, ax)
+        return self._reshape_axis(np.arange(basis.size), ax)
+
+
+class Transformer:
+    """Walks a field through its axes (the reference's Transform.increment/decrement loop,
+    core/distributor.py:601-661): backward = Jacobi axis first then Fourier axes in storage order,
+    forward = the reverse.  Every step is one out-of-place kernel launch."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def _steps(self, domain, scales):
+        """[(storage position, basis, plan_spec)] for axes that carry a basis."""
+        steps = []
+        for pos, ax in enumerate(self.dist.storage_order):
+            b = domain.by_axis[ax]
+            if b is not None:
+                steps.append((pos, b, b.plan_spec(scales[ax])))
+        return steps
+
+    def backward(self, field, c, g, scales):
+        return self.backward_data(field.domain, field.ncomp, c, g, scales)
+
+    def forward(self, field, g, scales, c):
+        return self.forward_data(field.domain, field.ncomp, g, scales, c)
+
+    def backward_data(self, domain, ncomp, c, g, scales):
+        ex = self.dist.executor
+        steps = self._steps(domain, scales)
+        shape = [ncomp] + list(domain.storage_coeff_shape())
+        if not steps:
+            ex.copy(g, c)
+            return
+        src = c
+        for i, (pos, b, spec) in enumerate(steps):
+            n_out = b.grid_size(scales[self.dist.storage_order[pos]])
+            outer = int(np.prod(shape[:pos + 1]))
+            inner = int(np.prod(shape[pos + 2:]))
+            shape[pos + 1] = n_out
+            dst = g if i == len(steps) - 1 else ex.empty(tuple(shape))
+            ex.transform(spec, b, "backward", src, dst, outer, inner)
+            src = dst
+
+    def forward_data(self, domain, ncomp, g, scales, c):
+        ex = self.dist.executor
+        steps = self._steps(domain, scales)
+        shape = [ncomp] + list(domain.storage_grid_shape(scales))
+        if not steps:
+            ex.copy(c, g)
+            return
+        src = g
+        for i, (pos, b, spec) in enumerate(reversed(steps)):
+            outer = int(np.prod(shape[:pos + 1]))
+            inner = int(np.prod(shape[pos + 2:]))
+            shape[pos + 1] = b.coeff_size
+            dst = c if i == len(steps) - 1 else ex.empty(tuple(shape))
+            ex.transform(spec, b, "forward", src, dst, outer, inner)
+            src = dst

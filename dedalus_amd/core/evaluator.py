@@ -1,0 +1,299 @@
+"""
+Expression evaluation on the device.
+
+The reference oscillates every field through the layout chain and lets each operator `operate()`
+wherever its layout condition is met (core/evaluator.py:95-146, core/future.py:149-206).  Here an
+expression is split into alternating stages that each map to few large kernel launches:
+
+  linear stage     every maximal sub-expression that is linear in its leaves is ONE batched
+                   term-list mat-vec over all pencils (core/polyop.py); leaves that live in the same
+                   system vector (the solver state) share a launch
+  backward         coefficient -> dealiased grid, one fused FFT kernel per axis
+  grid stage       products / dot / cross as a table-driven bilinear kernel
+  forward          grid -> coefficient
+
+Nothing leaves HBM between the stages.
+"""
+
+import numpy as np
+
+from . import operators as ops
+from .field import Field
+from .polyop import flatten
+from .problems import LinCtx
+
+
+class SystemBuffer:
+    """A [rows][nx][ny] device array together with the leaves that are views into it."""
+
+    def __init__(self, array, nrows):
+        self.array, self.nrows = array, nrows
+
+
+def _pencil_geom(dist):
+    """(nf, nx, ny, kx, ky) of the separable axes shared by every system vector of this distributor."""
+    return dist._pencil_geom
+
+
+def set_pencil_geom(dist, domain_like_bases):
+    sep = dist.separable_axes
+    nf = len(sep)
+    sizes, ks = [], []
+    for ax in sep:
+        b = domain_like_bases[ax]
+        if b is None:
+            raise ValueError("pencil geometry needs a basis on every separable axis")
+        sizes.append(b.coeff_size)
+        ks.append(b.mode_wavenumbers)
+    nx = sizes[0] if nf >= 1 else 1
+    ny = sizes[1] if nf >= 2 else 1
+    kx = ks[0] if nf >= 1 else np.zeros(1)
+    ky = ks[1] if nf >= 2 else np.zeros(1)
+    dist._pencil_geom = (nf, nx, ny, kx, ky)
+    return dist._pencil_geom
+
+
+def _full_sep(dist, domain):
+    return all(domain.by_axis[ax] is not None for ax in dist.separable_axes)
+
+
+class Evaluator:
+    """Evaluates expressions for one distributor; caches term lists and pencil packs."""
+
+    def __init__(self, dist, variables=()):
+        self.dist = dist
+        self.ex = dist.executor
+        self.variables = tuple(variables)
+        self.ctx = LinCtx(self.variables, strict=False)
+        self._packs = {}
+        self._lin_cache = {}
+        self._const_cache = {}
+        self.cache = {}
+
+    # ---- geometry ------------------------------------------------------------------------------------
+    def geom(self):
+        g = getattr(self.dist, "_pencil_geom", None)
+        if g is None:
+            # infer from any field with a full set of separable bases
+            raise RuntimeError("pencil geometry not set (no field with all Fourier bases seen yet)")
+        return g
+
+    def pack(self, nrows_in):
+        """Operator pack whose input vectors have `nrows_in` rows."""
+        nf, nx, ny, kx, ky = self.geom()
+        key = nrows_in
+        if key not in self._packs:
+            self._packs[key] = self.ex.make_pack(nf, nrows_in, nx, ny, kx, ky)
+        return self._packs[key]
+
+    # ---- leaves ------------------------------------------------------------------------------------------
+    def _leaf_rows(self, leaf):
+        return leaf.ncomp * self.dist.coupled_size(leaf.domain)
+
+    def _leaf_plane_data(self, leaf):
+        """Coefficient data of a leaf as a [rows][nx][ny] system vector."""
+        nf, nx, ny, kx, ky = self.geom()
+        if isinstance(leaf, Field):
+            c = leaf.coeff_data()
+        else:
+            c = self.eval_coeff(leaf)
+        if _full_sep(self.dist, leaf.domain):
+            return c
+        # expand a field that lacks separable bases (constants, horizontally uniform fields)
+        if isinstance(leaf, Field) and getattr(leaf, "_is_number", False):
+            key = id(leaf)
+            if key not in self._const_cache:
+                self._const_cache[key] = self._expand(leaf, c)
+            return self._const_cache[key]
+        return self._expand(leaf, c)
+
+    def _expand(self, leaf, c):
+        nf, nx, ny, kx, ky = self.geom()
+        rows = self._leaf_rows(leaf)
+        host = self.ex.download(c).reshape(rows, -1)
+        sep = self.dist.separable_axes
+        sizes = [1 if leaf.domain.by_axis[ax] is None else leaf.domain.by_axis[ax].coeff_size for ax in sep]
+        sx = sizes[0] if nf >= 1 else 1
+        sy = sizes[1] if nf >= 2 else 1
+        full = np.zeros((rows, nx, ny))
+        full[:, :sx, :sy] = host.reshape(rows, sx, sy)
+        return self.ex.from_host(full)
+
+    # ---- linear stage ----------------------------------------------------------------------------------
+    def _lin(self, expr):
+        key = id(expr)
+        if key not in self._lin_cache:
+            self._lin_cache[key] = (expr, expr.lin(self.ctx))
+        return self._lin_cache[key][1]
+
+    def _force_flags(self, domain):
+        sep = self.dist.separable_axes
+        fx = len(sep) >= 1 and domain.by_axis[sep[0]] is None
+        fy = len(sep) >= 2 and domain.by_axis[sep[1]] is None
+        return fx, fy
+
+    def apply_linear(self, le, out_domain, out_rows_total=None, row0=0, out=None):
+        """out[rows] = sum over leaves of TermList(le) @ leaf; returns a [rows][nx][ny] array."""
+        nf, nx, ny, kx, ky = self.geom()
+        nrows = le.nco * le.nzo if out_rows_total is None else out_rows_total
+        # group leaves by the system buffer they live in
+        groups = {}
+        for leaf, terms in le.leaves.items():
+            if not terms:
+                continue
+            sb = getattr(leaf, "_sysbuf", None) if isinstance(leaf, Field) else None
+            if sb is not None:
+                groups.setdefault(("sys", id(sb)), [sb, []])[1].append((leaf, terms))
+            else:
+                groups.setdefault(("leaf", id(leaf)), [None, []])[1].append((leaf, terms))
+        parts = []
+        fdx_o, fdy_o = self._force_flags(out_domain)
+        for key, (sb, items) in groups.items():
+            ckey = (id(le), key, nrows, row0)
+            cached = getattr(le, "_tl_cache", None)
+            if cached is None:
+                cached = le._tl_cache = {}
+            if sb is not None:
+                x = sb.array
+                nrows_in = sb.nrows
+            else:
+                leaf = items[0][0]
+                x = None
+                nrows_in = self._leaf_rows(leaf)
+            if ckey not in cached:
+                blocks = []
+                for leaf, terms in items:
+                    nzi = self.dist.coupled_size(leaf.domain)
+                    col0 = leaf._row0 if sb is not None else 0
+                    fdx_i, fdy_i = self._force_flags(leaf.domain)
+                    blocks.append((row0, le.nzo, col0, nzi, terms, fdx_o or fdx_i, fdy_o or fdy_i))
+                tl = flatten(blocks, nrows, nrows_in)
+                pack = self.pack(nrows_in)
+                cached[ckey] = (pack, pack.add_matrix(tl))
+            pack, mid = cached[ckey]
+            if x is None:
+                x = self._leaf_plane_data(items[0][0])
+            y = self.ex.empty((nrows, nx, ny))
+            pack.matvec(mid, x, y)
+            parts.append(y)
+        if not parts:
+            res = self.ex.zeros((nrows, nx, ny))
+        elif len(parts) == 1:
+            res = parts[0]
+        else:
+            res = self.ex.empty((nrows, nx, ny))
+            self.ex.lincomb(res, parts, [1.0] * len(parts))
+        return res
+
+    # ---- public evaluation -------------------------------------------------------------------------------
+    def eval_coeff(self, expr):
+        """Coefficient data [ncomp, storage coeff shape] of expr in expr.domain."""
+        key = ("c", id(expr))
+        if key in self.cache:
+            return self.cache[key]
+        if isinstance(expr, Field):
+            res = expr.coeff_data()
+        elif self._is_nonlinear_node(expr):
+            g = self.eval_grid(expr)
+            res = self.ex.empty((expr.ncomp,) + tuple(expr.domain.storage_coeff_shape()))
+            self.dist.transformer.forward_data(expr.domain, expr.ncomp, g, expr.domain.dealias, res)
+        else:
+            le = self._lin(expr)
+            if not _full_sep(self.dist, expr.domain):
+                raise NotImplementedError("evaluating expressions without all Fourier bases")
+            res = self.apply_linear(le, expr.domain)
+            res = res.reshape((expr.ncomp,) + tuple(expr.domain.storage_coeff_shape()))
+        self.cache[key] = res
+        return res
+
+    def eval_grid(self, expr):
+        """Grid data at the dealias scales."""
+        key = ("g", id(expr))
+        if key in self.cache:
+            return self.cache[key]
+        scales = expr.domain.dealias
+        if isinstance(expr, Field):
+            res = expr.grid_data(scales)
+        elif self._is_nonlinear_node(expr):
+            res = self._eval_nonlinear(expr, scales)
+        else:
+            c = self.eval_coeff(expr)
+            res = self.ex.empty((expr.ncomp,) + tuple(expr.domain.storage_grid_shape(scales)))
+            self.dist.transformer.backward_data(expr.domain, expr.ncomp, c, res, scales)
+        self.cache[key] = res
+        return res
+
+    @staticmethod
+    def _is_nonlinear_node(expr):
+        if isinstance(expr, (ops.CrossProduct, ops.Power, ops.UnaryGridFunction)):
+            return True
+        if isinstance(expr, (ops.Multiply, ops.DotProduct)):
+            if isinstance(expr, ops.Multiply) and expr.number is not None:
+                return False
+            a, b = expr.args
+            return not (ops._is_const_field(a, None) or ops._is_const_field(b, None))
+        return False
+
+    def _grid_shape(self, expr, scales):
+        return (expr.ncomp,) + tuple(expr.domain.storage_grid_shape(scales))
+
+    def _broadcast_grid(self, operand, out_domain, scales):
+        """Grid data of an operand broadcast to the product's full grid shape."""
+        g = self.eval_grid(operand)
+        tgt = tuple(out_domain.storage_grid_shape(scales))
+        src = tuple(operand.domain.storage_grid_shape(scales))
+        if src == tgt:
+            return g
+        host = self.ex.download(g).reshape((operand.ncomp,) + src)
+        full = np.broadcast_to(host, (operand.ncomp,) + tgt)
+        return self.ex.from_host(np.ascontiguousarray(full))
+
+    def _eval_nonlinear(self, expr, scales):
+        ex = self.ex
+        if isinstance(expr, (ops.Multiply, ops.DotProduct, ops.CrossProduct)):
+            a, b = expr.args
+            ga = self._broadcast_grid(a, expr.domain, scales)
+            gb = self._broadcast_grid(b, expr.domain, scales)
+            out = ex.empty(self._grid_shape(expr, scales))
+            npts = int(np.prod(expr.domain.storage_grid_shape(scales)))
+            ex.bilinear(out, expr.ncomp, ga, gb, npts, expr.bilinear_terms())
+            return out
+        if isinstance(expr, ops.Power):
+            a, p = expr.args
+            ga = self._broadcast_grid(a, expr.domain, scales)
+            if p == 2:
+                out = ex.empty(self._grid_shape(expr, scales))
+                npts = int(np.prod(expr.domain.storage_grid_shape(scales)))
+                ex.bilinear(out, 1, ga, ga, npts, [(0, 0, 0, 1.0)])
+                return out
+            return ex.from_host(self.ex.download(ga) ** p)      # analysis-only path
+        if isinstance(expr, ops.UnaryGridFunction):
+            func, a = expr.args
+            ga = self.eval_grid(a)
+            return ex.from_host(func(self.ex.download(ga)))     # analysis-only path
+        raise NotImplementedError(type(expr))
+
+    def new_pass(self):
+        self.cache = {}
+
+
+def evaluate_expression(expr):
+    """expr.evaluate(): returns a new Field holding the value (operators.py Future.evaluate)."""
+    dist = expr.dist
+    ev = getattr(dist, "_default_evaluator", None)
+    if ev is None:
+        ev = dist._default_evaluator = Evaluator(dist)
+    ev.new_pass()
+    out = Field(dist, bases=expr.domain.bases, tensorsig=expr.tensorsig)
+    if ev._is_nonlinear_node(expr):
+        g = ev.eval_grid(expr)
+        out._g, out._g_scales = g, expr.domain.dealias
+        out.scales = expr.domain.dealias
+        out.layout = "g"
+    else:
+        c = ev.eval_coeff(expr)
+        out._c = c.reshape(out._storage_shape("c", None))
+        out.layout = "c"
+    out._authority = "device"
+    ev.new_pass()
+    return out

@@ -1,0 +1,433 @@
+"""
+Solvers.  InitialValueSolver keeps the reference's interface (core/solvers.py:503-806:
+step / proceed / evolve / sim_time / iteration / stop_* / log_stats) while the per-pencil Python
+loops of the reference (loops A and C of SURVEY.md section 3.1) are replaced by batched device
+calls over ALL pencils:
+
+  state X, M.X, L.X, F, RHS : [rows][nx][ny] system vectors in HBM (state fields are views into X)
+  M, L                      : term lists shared by all pencils (no per-pencil matrices)
+  LHS solves                : bordered band LU, factored on the device when (a0, b0) / k*H_ii changes
+"""
+
+import time
+
+import numpy as np
+
+from . import operators as ops
+from . import timesteppers as ts_mod
+from .evaluator import Evaluator, SystemBuffer, _full_sep
+from .field import Field
+from .polyop import flatten
+from .problems import LinCtx
+
+import logging
+logger = logging.getLogger(__name__)
+
+
+class SolverBase:
+    def __init__(self, problem, **kw):
+        self.problem = problem
+        self.dist = dist = problem.dist
+        self.ex = dist.executor
+        self.variables = list(problem.variables)
+        self.equations = list(problem.equations)
+        self.state = self.variables
+        self.evaluator_core = Evaluator(dist, self.variables)
+        nf, nx, ny, kx, ky = self.evaluator_core.geom()
+        self.nf, self.nx, self.ny = nf, nx, ny
+        sep = dist.separable_axes
+
+        def axes_bits(domain):
+            bits = 0
+            for i in range(2):
+                if i >= nf or domain.by_axis[sep[i]] is not None:
+                    bits |= (1 << i)
+            return bits
+
+        # ---- variable rows
+        row = 0
+        self.var_info = []
+        for v in self.variables:
+            nz = dist.coupled_size(v.domain)
+            info = dict(field=v, row0=row, nz=nz, ncomp=v.ncomp, rows=v.ncomp * nz, bits=axes_bits(v.domain),
+                        interior=(nz > 1), aliased=_full_sep(dist, v.domain))
+            self.var_info.append(info)
+            row += info["rows"]
+        self.R = row
+        # ---- equation rows
+        row = 0
+        self.eq_info = []
+        for eq in self.equations:
+            nz = dist.coupled_size(eq["domain"])
+            info = dict(eq=eq, row0=row, nz=nz, ncomp=eq["ncomp"], rows=eq["ncomp"] * nz, bits=axes_bits(eq["domain"]),
+                        interior=(nz > 1))
+            self.eq_info.append(info)
+            row += info["rows"]
+        if row != self.R:
+            raise ValueError("Problem is not square: %d equation rows vs %d variable rows (pencil-wise counts "
+                             "may still differ, this is the global count)" % (row, self.R))
+        # ---- state vector; state fields become views into it
+        self.X = self.ex.zeros((self.R, nx, ny))
+        self.sysbuf = SystemBuffer(self.X, self.R)
+        for info in self.var_info:
+            v = info["field"]
+            old = v.coeff_data()
+            if info["aliased"]:
+                view = self.X[info["row0"]:info["row0"] + info["rows"]].reshape(v._storage_shape("c", None))
+                self.ex.copy(view, old)
+                v._c = view
+                v._adopted = True
+                v._sysbuf = self.sysbuf
+                v._row0 = info["row0"]
+        # ---- matrices as term lists (physical row / column numbering)
+        self.M_tl = self._assemble("M")
+        self.L_tl = self._assemble("L")
+        self.pack = self.ex.make_pack(nf, self.R, nx, ny, kx, ky)
+        self.M_id = self.pack.add_matrix(self.M_tl)
+        self.L_id = self.pack.add_matrix(self.L_tl)
+        self._build_ordering()
+        self._build_F_plan()
+
+    # ---- assembly ----------------------------------------------------------------------------------------
+    def _flags(self, domain):
+        sep = self.dist.separable_axes
+        fx = self.nf >= 1 and domain.by_axis[sep[0]] is None
+        fy = self.nf >= 2 and domain.by_axis[sep[1]] is None
+        return fx, fy
+
+    def _assemble(self, which):
+        var_of = {id(i["field"]): i for i in self.var_info}
+        blocks = []
+        for einfo in self.eq_info:
+            le = einfo["eq"][which]
+            efx, efy = self._flags(einfo["eq"]["domain"])
+            for leaf, terms in le.leaves.items():
+                vinfo = var_of[id(leaf)]
+                vfx, vfy = self._flags(leaf.domain)
+                blocks.append((einfo["row0"], le.nzo, vinfo["row0"], vinfo["nz"], terms, efx or vfx, efy or vfy))
+        return flatten(blocks, self.R, self.R)
+
+    def _build_ordering(self):
+        """Logical ordering for the bordered band LU: coupled-axis index outermost over the interior
+        rows/columns, border (taus / boundary conditions) last.  (The reference's own orderings,
+        core/subsystems.py:614-739, are not banded for real-Fourier pencils: SURVEY.md section 7.2.)"""
+        def order(infos):
+            inter = [i for i in infos if i["interior"]]
+            border = [i for i in infos if not i["interior"]]
+            nzs = {i["nz"] for i in inter}
+            if len(nzs) > 1:
+                raise NotImplementedError("interior blocks with different coupled sizes")
+            nz = nzs.pop() if nzs else 0
+            perm = []
+            for kz in range(nz):
+                for i in inter:
+                    for c in range(i["ncomp"]):
+                        perm.append(i["row0"] + c * i["nz"] + kz)
+            n_int = len(perm)
+            for i in border:
+                perm.extend(range(i["row0"], i["row0"] + i["rows"]))
+            return np.array(perm, dtype=np.int32), n_int
+        self.col_perm, n_c = order(self.var_info)
+        self.row_perm, n_r = order(self.eq_info)
+        if n_c != n_r:
+            raise ValueError("interior equation rows (%d) and interior variable rows (%d) differ" % (n_r, n_c))
+        self.n_interior = n_c
+        self.row_axes = np.zeros(self.R, dtype=np.uint8)
+        self.col_axes = np.zeros(self.R, dtype=np.uint8)
+        for i in self.eq_info:
+            self.row_axes[i["row0"]:i["row0"] + i["rows"]] = i["bits"]
+        for i in self.var_info:
+            self.col_axes[i["row0"]:i["row0"] + i["rows"]] = i["bits"]
+        rinv = np.empty(self.R, dtype=np.int64)
+        cinv = np.empty(self.R, dtype=np.int64)
+        rinv[self.row_perm] = np.arange(self.R)
+        cinv[self.col_perm] = np.arange(self.R)
+        kl = ku = 0
+        for tl in (self.M_tl, self.L_tl):
+            if tl.nterms == 0:
+                continue
+            i, c = rinv[tl.row], cinv[tl.col]
+            m = (i < self.n_interior) & (tl.dx == 0) & (tl.dy == 0)
+            if m.any():
+                kl = max(kl, int((i[m] - c[m]).max()))
+                ku = max(ku, int((c[m] - i[m]).max()))
+        nb = self.R - self.n_interior
+        if self.nf == 0 or self.n_interior == 0:
+            # single pencil / no coupled axis: everything is "border" -> dense path or tiny systems
+            ku = max(ku, nb)
+        self.kl, self.ku = kl, max(ku, nb if self.n_interior else 0)
+
+    # ---- RHS plan --------------------------------------------------------------------------------------------
+    def _build_F_plan(self):
+        ev = self.evaluator_core
+        ctx = LinCtx(self.variables, strict=False)
+        nl_leaves, nl_rows = [], 0
+        groups = {"nl": [], "x": [], "const": [], "param": {}}
+        for einfo in self.eq_info:
+            F = einfo["eq"]["F"]
+            if F is None:
+                continue
+            le = F.lin(ctx)
+            efx, efy = self._flags(einfo["eq"]["domain"])
+            for leaf, terms in le.leaves.items():
+                if not terms:
+                    continue
+                lfx, lfy = self._flags(leaf.domain)
+                nzi = self.dist.coupled_size(leaf.domain)
+                blk = [einfo["row0"], le.nzo, None, nzi, terms, efx or lfx, efy or lfy]
+                if isinstance(leaf, Field):
+                    if getattr(leaf, "_sysbuf", None) is self.sysbuf:
+                        blk[2] = leaf._row0
+                        groups["x"].append(tuple(blk))
+                    elif getattr(leaf, "_is_number", False):
+                        groups["const"].append((leaf, blk))
+                    else:
+                        groups["param"].setdefault(id(leaf), [leaf, []])[1].append(blk)
+                else:
+                    if not _full_sep(self.dist, leaf.domain):
+                        raise NotImplementedError("nonlinear RHS term without all Fourier bases")
+                    found = [x for x in nl_leaves if x[0] is leaf]
+                    if found:
+                        row0 = found[0][1]
+                    else:
+                        row0 = nl_rows
+                        nl_leaves.append((leaf, row0, leaf.ncomp * nzi))
+                        nl_rows += leaf.ncomp * nzi
+                    blk[2] = row0
+                    groups["nl"].append(tuple(blk))
+        self.nl_leaves, self.nl_rows = nl_leaves, nl_rows
+        nf, nx, ny, kx, ky = ev.geom()
+        self.F_nl = None
+        if nl_rows:
+            self.NLbuf = self.ex.zeros((nl_rows, nx, ny))
+            self.nl_pack = self.ex.make_pack(nf, nl_rows, nx, ny, kx, ky)
+            self.F_nl = self.nl_pack.add_matrix(flatten(groups["nl"], self.R, nl_rows))
+        self.F_x = None
+        if groups["x"]:
+            self.F_x = self.pack.add_matrix(flatten(groups["x"], self.R, self.R))
+        self.F_params = []
+        for key, (leaf, blks) in groups["param"].items():
+            rows = leaf.ncomp * self.dist.coupled_size(leaf.domain)
+            pk = self.ex.make_pack(nf, rows, nx, ny, kx, ky)
+            mid = pk.add_matrix(flatten([tuple(b[:2] + [0] + b[3:]) for b in blks], self.R, rows))
+            self.F_params.append((leaf, pk, mid))
+        # constants (e.g. "b(z=0) = Lz"): evaluated once
+        self.F_const = None
+        if groups["const"]:
+            total = np.zeros((self.R, nx, ny))
+            for leaf, blk in groups["const"]:
+                tl = flatten([tuple(blk[:2] + [0] + blk[3:])], self.R, 1)
+                val = leaf._number
+                for t in range(tl.nterms):
+                    # constants only reach the k=0 pencil, cos-cos part
+                    if tl.ex[t] == 0 and tl.ey[t] == 0:
+                        total[tl.row[t], 0, 0] += (tl.coef[t] * val).real
+            self.F_const = self.ex.from_host(total)
+
+    def evaluate_F(self, out):
+        """F system vector for the current state (coefficient space, equation bases)."""
+        ev, ex = self.evaluator_core, self.ex
+        ev.new_pass()
+        parts = []
+        if self.F_nl is not None:
+            for leaf, row0, rows in self.nl_leaves:
+                g = ev.eval_grid(leaf)
+                dst = self.NLbuf[row0:row0 + rows].reshape((leaf.ncomp,) + tuple(leaf.domain.storage_coeff_shape()))
+                self.dist.transformer.forward_data(leaf.domain, leaf.ncomp, g, leaf.domain.dealias, dst)
+            y = ex.empty((self.R, self.nx, self.ny))
+            self.nl_pack.matvec(self.F_nl, self.NLbuf, y)
+            parts.append(y)
+        if self.F_x is not None:
+            y = ex.empty((self.R, self.nx, self.ny))
+            self.pack.matvec(self.F_x, self.X, y)
+            parts.append(y)
+        for leaf, pk, mid in self.F_params:
+            y = ex.empty((self.R, self.nx, self.ny))
+            pk.matvec(mid, ev._leaf_plane_data(leaf), y)
+            parts.append(y)
+        if self.F_const is not None:
+            parts.append(self.F_const)
+        ev.new_pass()
+        if not parts:
+            ex.fill_zero(out)
+        elif len(parts) == 1:
+            ex.copy(out, parts[0])
+        else:
+            ex.lincomb(out, parts, [1.0] * len(parts))
+
+    # ---- un-aliased variables (no separable bases): tiny copies around each solve ---------------------------
+    def push_unaliased(self):
+        for info in self.var_info:
+            if not info["aliased"]:
+                v = info["field"]
+                c = v.coeff_data()
+                self._plane_copy(info, v, c, to_state=True)
+
+    def pull_unaliased(self):
+        for info in self.var_info:
+            if not info["aliased"]:
+                v = info["field"]
+                self._plane_copy(info, v, v._alloc_c(), to_state=False)
+                v.mark_device_coeff_current()
+
+    def _plane_copy(self, info, v, c, to_state):
+        sep = self.dist.separable_axes
+        sx = 1 if (self.nf < 1 or v.domain.by_axis[sep[0]] is None) else self.nx
+        sy = 1 if (self.nf < 2 or v.domain.by_axis[sep[1]] is None) else self.ny
+        xs = self.X[info["row0"]:info["row0"] + info["rows"]].reshape(info["rows"], self.nx, self.ny)[:, :sx, :sy]
+        cs = c.reshape(info["rows"], sx, sy)
+        if to_state:
+            self.ex.assign(xs, cs)
+        else:
+            self.ex.assign(cs, xs)
+
+    def mark_state_current(self):
+        for info in self.var_info:
+            if info["aliased"]:
+                info["field"].mark_device_coeff_current()
+        self.pull_unaliased()
+
+    def sync_state_to_device(self):
+        for info in self.var_info:
+            info["field"].require_coeff_space()
+        self.push_unaliased()
+
+    def factor(self, a, b, reuse=-1):
+        return self.pack.factor(self.M_id, self.L_id, a, b, self.row_perm, self.col_perm, self.n_interior,
+                                self.kl, self.ku, self.row_axes, self.col_axes, reuse=reuse)
+
+
+class InitialValueSolver(SolverBase):
+    def __init__(self, problem, timestepper, enforce_real_cadence=100, warmup_iterations=10, **kw):
+        t0 = time.time()
+        super().__init__(problem, **kw)
+        self.sim_time_field = problem.time
+        self._sim_time = 0.0
+        self.iteration = 0
+        self.initial_iteration = 0
+        self.stop_sim_time = np.inf
+        self.stop_wall_time = np.inf
+        self.stop_iteration = np.inf
+        self.enforce_real_cadence = enforce_real_cadence
+        self.warmup_iterations = warmup_iterations
+        self.dt = None
+        if isinstance(timestepper, str):
+            timestepper = ts_mod.schemes[timestepper]
+        self.timestepper = timestepper(self)
+        self.start_time = time.time()
+        self.init_time = self.start_time - t0
+        self.warmup_time = None
+        self.run_time_start = None
+        self.total_modes = self.R * self.nx * self.ny
+        self.handlers = []
+        self.evaluator = _HandlerRegistry(self)
+
+    @property
+    def sim_time(self):
+        return self._sim_time
+
+    @sim_time.setter
+    def sim_time(self, t):
+        self._sim_time = float(t)
+        self.sim_time_field["g"] = float(t)
+
+    @property
+    def proceed(self):
+        """core/solvers.py:594-618"""
+        if self.sim_time >= self.stop_sim_time:
+            logger.info("Simulation stop time reached.")
+            return False
+        if (time.time() - self.start_time) >= self.stop_wall_time:
+            logger.info("Wall stop time reached.")
+            return False
+        if self.iteration >= self.stop_iteration:
+            logger.info("Stop iteration reached.")
+            return False
+        return True
+
+    def step(self, dt):
+        """Advance one timestep (core/solvers.py:683-711)."""
+        if not np.isfinite(dt):
+            raise ValueError("Invalid timestep: %r" % dt)
+        if self.iteration == self.initial_iteration + self.warmup_iterations:
+            self.ex.sync()
+            self.warmup_time = time.time()
+        self.dt = dt
+        self.timestepper.step(dt, time.time() - self.start_time)
+        self.iteration += 1
+        if self.enforce_real_cadence and self.iteration % self.enforce_real_cadence == 0:
+            self.enforce_hermitian_symmetry(self.state)
+
+    def enforce_hermitian_symmetry(self, fields):
+        """Grid and back (core/solvers.py:675-681): removes the invalid modes of real data."""
+        for f in fields:
+            f.require_grid_space(f.domain.dealias)
+            f.require_coeff_space()
+
+    def evolve(self, timestep_function, log_cadence=100):
+        try:
+            logger.info("Starting main loop")
+            while self.proceed:
+                dt = timestep_function()
+                self.step(dt)
+                if (self.iteration - 1) % log_cadence == 0:
+                    logger.info("Iteration=%i, Time=%e, dt=%e" % (self.iteration, self.sim_time, dt))
+        except Exception:
+            logger.error("Exception raised, triggering end of main loop.")
+            raise
+        finally:
+            self.log_stats()
+
+    def log_stats(self, format=".4g"):
+        """core/solvers.py:755-778: modes*stages per (device-)second."""
+        self.ex.sync()
+        end = time.time()
+        logger.info("Final iteration: %i" % self.iteration)
+        logger.info("Final sim time: %s" % self.sim_time)
+        logger.info("Setup time (init - iter 0): %.4g sec" % self.init_time)
+        if self.warmup_time is not None:
+            run = end - self.warmup_time
+            its = self.iteration - self.initial_iteration - self.warmup_iterations
+            stages = its * self.timestepper.stages
+            logger.info("Run time (iter %d-end): %.4g sec" % (self.warmup_iterations, run))
+            if run > 0:
+                logger.info("Speed: %.4g mode-stages/gpu-sec" % (self.total_modes * stages / run))
+
+    def load_state(self, path, index=-1):
+        raise NotImplementedError("HDF5 restart files: out of scope this round (SURVEY section 8f #4)")
+
+
+class _HandlerRegistry:
+    """Minimal stand-in for solver.evaluator: analysis output is host-side I/O outside the hot path."""
+
+    def __init__(self, solver):
+        self.solver = solver
+        self.handlers = []
+
+    def add_file_handler(self, *a, **k):
+        return _NullHandler()
+
+    def add_dictionary_handler(self, *a, **k):
+        return _NullHandler()
+
+
+class _NullHandler:
+    def add_task(self, *a, **k):
+        pass
+
+    def add_tasks(self, *a, **k):
+        pass
+
+
+class LinearBoundaryValueSolver(SolverBase):
+    """L.X = F in one batched factor + solve (core/solvers.py LBVP role)."""
+
+    def solve(self):
+        self.sync_state_to_device()
+        F = self.ex.empty((self.R, self.nx, self.ny))
+        self.evaluate_F(F)
+        lu = self.factor(0.0, 1.0)
+        Xnew = self.ex.empty((self.R, self.nx, self.ny))
+        self.pack.solve(lu, F, Xnew)
+        self.ex.copy(self.X, Xnew)
+        self.mark_state_current()

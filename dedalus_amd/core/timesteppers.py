@@ -1,0 +1,377 @@
+"""
+IMEX timesteppers on device-resident system vectors.
+
+Same schemes, names and stage algebra as dedalus/core/timesteppers.py:
+  multistep (:34-187)   (a0 M + b0 L) X_n = sum_j c_j F_{n-j} - sum_j a_j M X_{n-j} - sum_j b_j L X_{n-j}
+  Runge-Kutta (:498-644) (M + k H_ii L) X_i = M X_0 + k sum_j A_ij F_j - k sum_j H_ij L X_j
+but every per-subproblem Python loop is one batched kernel over all pencils:
+  M.X / L.X  -> ddh_pencil_matvec,   RHS assembly -> ddh_lincomb,   LHS solve -> ddh_pencil_solve,
+  LHS refactorisation (when a0,b0 or k*H_ii change) -> ddh_pencil_factor.
+
+The variable-step multistep coefficients are not tabulated: they are computed from their defining
+conditions (finite-difference / extrapolation / Adams weights on the actual time nodes), which
+reproduces the closed forms of Wang & Ruuth (2008) used by the reference to round-off
+(pinned by tests/test_timestepper_coefficients.py against reference-generated fixtures).
+"""
+
+import math
+from collections import deque
+
+import numpy as np
+
+schemes = {}
+
+
+def add_scheme(cls):
+    schemes[cls.__name__] = cls
+    return cls
+
+
+def _fd_weights(nodes, x0, deriv):
+    """Weights w_j with sum_j w_j f(nodes_j) = f^(deriv)(x0), exact for polynomials of degree len-1."""
+    nodes = np.asarray(nodes, dtype=np.longdouble) - np.longdouble(x0)
+    n = len(nodes)
+    V = np.vander(nodes, n, increasing=True).T          # V[p, j] = nodes_j^p
+    rhs = np.zeros(n, dtype=np.longdouble)
+    rhs[deriv] = math.factorial(deriv)
+    return _solve_ld(V, rhs)
+
+
+def _solve_ld(A, b):
+    """Gaussian elimination with partial pivoting in long double (tiny systems)."""
+    A = np.array(A, dtype=np.longdouble)
+    b = np.array(b, dtype=np.longdouble)
+    n = len(b)
+    for k in range(n):
+        p = k + int(np.argmax(np.abs(A[k:, k])))
+        if p != k:
+            A[[k, p]] = A[[p, k]]
+            b[[k, p]] = b[[p, k]]
+        for i in range(k + 1, n):
+            m = A[i, k] / A[k, k]
+            A[i, k:] -= m * A[k, k:]
+            b[i] -= m * b[k]
+    x = np.zeros(n, dtype=np.longdouble)
+    for k in range(n - 1, -1, -1):
+        x[k] = (b[k] - A[k, k + 1:] @ x[k + 1:]) / A[k, k]
+    return x.astype(np.float64)
+
+
+def _times(timesteps, n):
+    """Time nodes t_n = 0, t_{n-1} = -k_n, t_{n-2} = -k_n - k_{n-1}, ... (n+1 nodes)."""
+    t = [0.0]
+    for j in range(n):
+        t.append(t[-1] - timesteps[j])
+    return t
+
+
+# ==================================================================================================
+# multistep
+# ==================================================================================================
+
+class MultistepIMEX:
+    stages = 1
+
+    def __init__(self, solver):
+        self.solver = solver
+        ex, shape = solver.ex, (solver.R, solver.nx, solver.ny)
+        self.RHS = ex.zeros(shape)
+        self.dt = deque([0.0] * self.steps)
+        self.MX = deque(ex.zeros(shape) for _ in range(self.amax))
+        self.LX = deque(ex.zeros(shape) for _ in range(self.bmax))
+        self.F = deque(ex.zeros(shape) for _ in range(self.cmax))
+        self._iteration = 0
+        self._LHS_params = None
+        self._lu = -1
+
+    def step(self, dt, wall_time=None):
+        s = self.solver
+        ex, pack = s.ex, s.pack
+        self.dt.rotate()
+        self.dt[0] = dt
+        a, b, c = self.compute_coefficients(list(self.dt), self._iteration)
+        self._iteration += 1
+        self.MX.rotate()
+        self.LX.rotate()
+        self.F.rotate()
+        s.sync_state_to_device()
+        pack.matvec(s.M_id, s.X, self.MX[0])
+        pack.matvec(s.L_id, s.X, self.LX[0])
+        s.evaluate_F(self.F[0])
+        xs, al = [], []
+        for j in range(1, len(c)):
+            if c[j] != 0.0:
+                xs.append(self.F[j - 1]); al.append(c[j])
+        for j in range(1, len(a)):
+            if a[j] != 0.0:
+                xs.append(self.MX[j - 1]); al.append(-a[j])
+        for j in range(1, len(b)):
+            if b[j] != 0.0:
+                xs.append(self.LX[j - 1]); al.append(-b[j])
+        ex.lincomb(self.RHS, xs, al)
+        if (a[0], b[0]) != self._LHS_params:
+            self._lu = s.factor(a[0], b[0], reuse=self._lu)
+            self._LHS_params = (a[0], b[0])
+        Xnew = ex.empty((s.R, s.nx, s.ny))
+        pack.solve(self._lu, self.RHS, Xnew)
+        ex.copy(s.X, Xnew)
+        s.mark_state_current()
+        s.sim_time = s.sim_time + dt
+
+
+def _pad(v, n):
+    out = np.zeros(n + 1)
+    out[:len(v)] = v
+    return out
+
+
+@add_scheme
+class CNAB1(MultistepIMEX):
+    """Crank-Nicolson / forward Euler [Wang & Ruuth 2008 eq 2.5.3]"""
+    amax = bmax = cmax = steps = 1
+
+    @classmethod
+    def compute_coefficients(cls, timesteps, iteration):
+        k0 = timesteps[0]
+        a = _fd_weights(_times(timesteps, 1), 0.0, 1)           # two-point derivative
+        return _pad(a, cls.amax), _pad([0.5, 0.5], cls.bmax), _pad([0.0, 1.0], cls.cmax)
+
+
+@add_scheme
+class SBDF1(MultistepIMEX):
+    """Backward Euler / forward Euler [Wang & Ruuth 2008 eq 2.6]"""
+    amax = bmax = cmax = steps = 1
+
+    @classmethod
+    def compute_coefficients(cls, timesteps, iteration):
+        a = _fd_weights(_times(timesteps, 1), 0.0, 1)
+        return _pad(a, cls.amax), _pad([1.0], cls.bmax), _pad([0.0, 1.0], cls.cmax)
+
+
+def _adams_bashforth(timesteps, order):
+    """c_j (j=1..order): F integrated over the last step from the interpolant through t_{n-1..n-order},
+    normalised by the step (variable-step Adams-Bashforth)."""
+    t = _times(timesteps, order)           # t[0]=t_n, t[1]=t_{n-1}, ...
+    nodes = np.array(t[1:order + 1], dtype=np.longdouble)
+    k = np.longdouble(timesteps[0])
+    # weights w_j with sum_j w_j p(nodes_j) = (1/k) int_{t_{n-1}}^{t_n} p, exact for degree < order
+    V = np.vander(nodes, order, increasing=True).T
+    p = np.arange(order, dtype=np.longdouble)
+    rhs = (np.longdouble(t[0]) ** (p + 1) - np.longdouble(t[1]) ** (p + 1)) / (p + 1) / k
+    return np.concatenate([[0.0], _solve_ld(V, rhs)])
+
+
+def _extrapolation(timesteps, order):
+    """c_j (j=1..order): polynomial extrapolation of F from t_{n-1..n-order} to t_n."""
+    t = _times(timesteps, order)
+    w = _fd_weights(t[1:order + 1], t[0], 0)
+    return np.concatenate([[0.0], w])
+
+
+@add_scheme
+class CNAB2(MultistepIMEX):
+    """Crank-Nicolson / 2nd-order Adams-Bashforth [Wang & Ruuth 2008 eq 2.9]"""
+    amax = bmax = cmax = steps = 2
+
+    @classmethod
+    def compute_coefficients(cls, timesteps, iteration):
+        if iteration < 1:
+            a, b, c = CNAB1.compute_coefficients(timesteps, iteration)
+            return _pad(a, 2), _pad(b, 2), _pad(c, 2)
+        a = _fd_weights(_times(timesteps, 1), 0.0, 1)
+        return _pad(a, 2), _pad([0.5, 0.5], 2), _pad(_adams_bashforth(timesteps, 2), 2)
+
+
+@add_scheme
+class MCNAB2(MultistepIMEX):
+    """Modified Crank-Nicolson / 2nd-order Adams-Bashforth [Wang & Ruuth 2008 eq 2.10]"""
+    amax = bmax = cmax = steps = 2
+
+    @classmethod
+    def compute_coefficients(cls, timesteps, iteration):
+        if iteration < 1:
+            a, b, c = CNAB1.compute_coefficients(timesteps, iteration)
+            return _pad(a, 2), _pad(b, 2), _pad(c, 2)
+        w = timesteps[0] / timesteps[1]
+        a = _fd_weights(_times(timesteps, 1), 0.0, 1)
+        # the modified implicit weights are the definition of the scheme (Wang & Ruuth eq 2.10)
+        b = [(8 + 1 / w) / 16, (7 - 1 / w) / 16, 1 / 16]
+        return _pad(a, 2), _pad(b, 2), _pad(_adams_bashforth(timesteps, 2), 2)
+
+
+class _SBDF(MultistepIMEX):
+    @classmethod
+    def _coeffs(cls, timesteps, order, size):
+        a = _fd_weights(_times(timesteps, order), 0.0, 1)       # BDF derivative at t_n
+        return _pad(a, size), _pad([1.0], size), _pad(_extrapolation(timesteps, order), size)
+
+
+@add_scheme
+class SBDF2(_SBDF):
+    """2nd-order semi-implicit BDF [Wang & Ruuth 2008 eq 2.8]"""
+    amax = bmax = cmax = steps = 2
+
+    @classmethod
+    def compute_coefficients(cls, timesteps, iteration):
+        order = min(2, iteration + 1)
+        return cls._coeffs(timesteps, order, 2)
+
+
+@add_scheme
+class CNLF2(MultistepIMEX):
+    """Crank-Nicolson leap-frog [Wang & Ruuth 2008 eq 2.11]"""
+    amax = bmax = cmax = steps = 2
+
+    @classmethod
+    def compute_coefficients(cls, timesteps, iteration):
+        if iteration < 1:
+            a, b, c = CNAB1.compute_coefficients(timesteps, iteration)
+            return _pad(a, 2), _pad(b, 2), _pad(c, 2)
+        t = _times(timesteps, 2)
+        w = timesteps[0] / timesteps[1]
+        a = _fd_weights(t, t[1], 1)                              # centred derivative at t_{n-1}
+        b = [1 / w / 2, (1 - 1 / w) / 2, 1 / 2]                  # scheme definition (eq 2.11)
+        return _pad(a, 2), _pad(b, 2), _pad([0.0, 1.0], 2)
+
+
+@add_scheme
+class SBDF3(_SBDF):
+    """3rd-order semi-implicit BDF [Wang & Ruuth 2008 eq 2.14]"""
+    amax = bmax = cmax = steps = 3
+
+    @classmethod
+    def compute_coefficients(cls, timesteps, iteration):
+        order = min(3, iteration + 1)
+        return cls._coeffs(timesteps, order, 3)
+
+
+@add_scheme
+class SBDF4(_SBDF):
+    """4th-order semi-implicit BDF [Wang & Ruuth 2008 eq 2.15]"""
+    amax = bmax = cmax = steps = 4
+
+    @classmethod
+    def compute_coefficients(cls, timesteps, iteration):
+        order = min(4, iteration + 1)
+        return cls._coeffs(timesteps, order, 4)
+
+
+# ==================================================================================================
+# Runge-Kutta
+# ==================================================================================================
+
+class RungeKuttaIMEX:
+    steps = 1
+
+    def __init__(self, solver):
+        self.solver = solver
+        ex, shape = solver.ex, (solver.R, solver.nx, solver.ny)
+        self.RHS = ex.zeros(shape)
+        self.MX0 = ex.zeros(shape)
+        self.LX = [ex.zeros(shape) for _ in range(self.stages)]
+        self.F = [ex.zeros(shape) for _ in range(self.stages)]
+        self._k = None
+        self._lus = {}          # H_ii -> lu id
+
+    def step(self, dt, wall_time=None):
+        s = self.solver
+        ex, pack = s.ex, s.pack
+        k = dt
+        A, H, c = self.A, self.H, self.c
+        if k != self._k:
+            # refactor once per distinct diagonal coefficient (the reference refactors per stage)
+            old = self._lus
+            self._lus = {}
+            reuse = list(old.values())
+            for i in range(1, self.stages + 1):
+                h = float(H[i, i])
+                if h not in self._lus:
+                    self._lus[h] = s.factor(1.0, k * h, reuse=(reuse.pop() if reuse else -1))
+            self._k = k
+        t0 = s.sim_time
+        s.sync_state_to_device()
+        pack.matvec(s.M_id, s.X, self.MX0)
+        pack.matvec(s.L_id, s.X, self.LX[0])
+        for i in range(1, self.stages + 1):
+            if i > 1:
+                pack.matvec(s.L_id, s.X, self.LX[i - 1])
+            s.evaluate_F(self.F[i - 1])
+            xs, al = [self.MX0], [1.0]
+            for j in range(i):
+                if A[i, j] != 0.0:
+                    xs.append(self.F[j]); al.append(k * A[i, j])
+                if H[i, j] != 0.0:
+                    xs.append(self.LX[j]); al.append(-k * H[i, j])
+            ex.lincomb(self.RHS, xs, al)
+            Xnew = ex.empty((s.R, s.nx, s.ny))
+            pack.solve(self._lus[float(H[i, i])], self.RHS, Xnew)
+            ex.copy(s.X, Xnew)
+            s.mark_state_current()
+            s.sim_time = t0 + k * c[i]
+
+
+@add_scheme
+class RK111(RungeKuttaIMEX):
+    """1-stage 1st-order DIRK+ERK [Ascher, Ruuth & Spiteri 1997 sec 2.1]"""
+    stages = 1
+    c = np.array([0.0, 1.0])
+    A = np.array([[0.0, 0.0], [1.0, 0.0]])
+    H = np.array([[0.0, 0.0], [0.0, 1.0]])
+
+
+@add_scheme
+class RK222(RungeKuttaIMEX):
+    """2-stage 2nd-order DIRK+ERK [Ascher, Ruuth & Spiteri 1997 sec 2.6]"""
+    stages = 2
+    _g = 1.0 - np.sqrt(0.5)
+    _d = 1.0 - 1.0 / (2.0 * _g)
+    c = np.array([0.0, _g, 1.0])
+    A = np.array([[0.0, 0.0, 0.0], [_g, 0.0, 0.0], [_d, 1.0 - _d, 0.0]])
+    H = np.array([[0.0, 0.0, 0.0], [0.0, _g, 0.0], [0.0, 1.0 - _g, _g]])
+
+
+@add_scheme
+class RK443(RungeKuttaIMEX):
+    """4-stage 3rd-order DIRK+ERK [Ascher, Ruuth & Spiteri 1997 sec 2.8]"""
+    stages = 4
+    c = np.array([0.0, 1 / 2, 2 / 3, 1 / 2, 1.0])
+    A = np.array([[0, 0, 0, 0, 0],
+                  [1 / 2, 0, 0, 0, 0],
+                  [11 / 18, 1 / 18, 0, 0, 0],
+                  [5 / 6, -5 / 6, 1 / 2, 0, 0],
+                  [1 / 4, 7 / 4, 3 / 4, -7 / 4, 0]], dtype=float)
+    H = np.array([[0, 0, 0, 0, 0],
+                  [0, 1 / 2, 0, 0, 0],
+                  [0, 1 / 6, 1 / 2, 0, 0],
+                  [0, -1 / 2, 1 / 2, 1 / 2, 0],
+                  [0, 3 / 2, -3 / 2, 1 / 2, 1 / 2]], dtype=float)
+
+
+@add_scheme
+class RKSMR(RungeKuttaIMEX):
+    """3-stage (3-eps)-order scheme of Spalart, Moser & Rogers (1991), Appendix"""
+    stages = 3
+    _al = (29 / 96, -3 / 40, 1 / 6)
+    _be = (37 / 160, 5 / 24, 1 / 6)
+    _ga = (8 / 15, 5 / 12, 3 / 4)
+    _ze = (0.0, -17 / 60, -5 / 12)
+    c = np.array([0.0, 8 / 15, 2 / 3, 1.0])
+    A = np.zeros((4, 4))
+    H = np.zeros((4, 4))
+    for _i in range(1, 4):
+        # explicit: stage i uses gamma_i on F_{i-1} and zeta_i on F_{i-2}, accumulated over stages
+        for _j in range(1, _i + 1):
+            A[_i, _j - 1] += _ga[_j - 1]
+            if _j >= 2:
+                A[_i, _j - 2] += _ze[_j - 1]
+            H[_i, _j - 1] += _al[_j - 1]
+            H[_i, _j] += _be[_j - 1]
+    del _i, _j
+
+
+class RKGFY(RungeKuttaIMEX):
+    """2-stage 2nd-order scheme (defined but not registered in the reference either, timesteppers.py:727)"""
+    stages = 2
+    c = np.array([0.0, 1.0, 1.0])
+    A = np.array([[0, 0, 0], [1, 0, 0], [0.5, 0.5, 0]], dtype=float)
+    H = np.array([[0, 0, 0], [0.5, 0.5, 0], [0.5, 0, 0.5]], dtype=float)

@@ -1,0 +1,104 @@
+"""
+HipExecutor: the only compute back-end of the product.  Every numerical operation is a call into
+libdedalus_hip.so through ctypes; torch (ROCm) provides HBM allocations, the HIP stream and, for
+multi-GPU runs, torch.distributed (RCCL).  Construction fails loudly without a gfx950 device.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import libhip
+from .device import Device, ptr
+from .pencilpack import PencilPack
+
+
+class HipExecutor:
+    name = "hip"
+
+    def __init__(self, device=None):
+        self.dev = device or Device.get()
+        self.torch = self.dev.torch
+        self._plans = {}
+
+    # ---- memory -------------------------------------------------------------------------------------
+    def empty(self, shape):
+        return self.dev.empty(shape)
+
+    def zeros(self, shape):
+        return self.dev.zeros(shape)
+
+    def from_host(self, a):
+        return self.dev.from_host(np.ascontiguousarray(a, dtype=np.float64))
+
+    def download(self, t):
+        return t.detach().cpu().numpy()
+
+    def upload(self, dst, a):
+        dst.copy_(self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).reshape(dst.shape))
+
+    def copy(self, dst, src):
+        if dst.data_ptr() != src.data_ptr():
+            dst.reshape(-1).copy_(src.reshape(-1)) if dst.is_contiguous() else dst.copy_(src.reshape(dst.shape))
+
+    def assign(self, dst_view, src_view):
+        dst_view.copy_(src_view)
+
+    def fill_zero(self, a):
+        a.zero_()
+
+    def sync(self):
+        self.dev.sync()
+
+    # ---- kernels -------------------------------------------------------------------------------------
+    def lincomb(self, y, xs, alphas):
+        n = y.numel()
+        arr = (C.c_void_p * len(xs))(*[C.c_void_p(x.data_ptr()) for x in xs])
+        al = np.ascontiguousarray(alphas, dtype=np.float64)
+        libhip.call("ddh_lincomb", ptr(y), len(xs), arr, libhip.as_dp(al), n, self.dev.stream)
+
+    def bilinear(self, out, ncomp_out, a, b, npts, terms):
+        ic = np.ascontiguousarray([t[0] for t in terms], dtype=np.int32)
+        ia = np.ascontiguousarray([t[1] for t in terms], dtype=np.int32)
+        ib = np.ascontiguousarray([t[2] for t in terms], dtype=np.int32)
+        cf = np.ascontiguousarray([t[3] for t in terms], dtype=np.float64)
+        libhip.call("ddh_grid_bilinear", ptr(out), ncomp_out, ptr(a), ptr(b), npts, len(terms),
+                    libhip.as_ip(ic), libhip.as_ip(ia), libhip.as_ip(ib), libhip.as_dp(cf), self.dev.stream)
+
+    def _plan(self, spec, basis):
+        if spec not in self._plans:
+            h = C.c_uint64(0)
+            kind = spec[0]
+            if kind == "rfft":
+                libhip.call("ddh_plan_rfft", C.byref(h), spec[1], spec[2])
+                self._plans[spec] = ("rfft", h, None)
+            elif kind == "cheb":
+                offs, bands = basis.conversion_bands()
+                if offs:
+                    o = np.ascontiguousarray(offs, dtype=np.int32)
+                    bnd = np.ascontiguousarray(bands)
+                    libhip.call("ddh_plan_cheb", C.byref(h), spec[1], spec[2], len(offs), libhip.as_ip(o),
+                                libhip.as_dp(bnd))
+                else:
+                    libhip.call("ddh_plan_cheb", C.byref(h), spec[1], spec[2], 0, None, None)
+                self._plans[spec] = ("cheb", h, None)
+            elif kind == "mmt":
+                fwd, bwd = basis.mmt_matrices(spec[1])
+                hf, hb = C.c_uint64(0), C.c_uint64(0)
+                libhip.call("ddh_plan_mmt", C.byref(hf), fwd.shape[0], fwd.shape[1], libhip.as_dp(fwd))
+                libhip.call("ddh_plan_mmt", C.byref(hb), bwd.shape[0], bwd.shape[1], libhip.as_dp(bwd))
+                self._plans[spec] = ("mmt", hf, hb)
+            else:
+                raise NotImplementedError(kind)
+        return self._plans[spec]
+
+    def transform(self, spec, basis, direction, src, dst, outer, inner):
+        kind, h, h2 = self._plan(spec, basis)
+        if kind == "mmt":
+            libhip.call("ddh_mmt_apply", h if direction == "forward" else h2, ptr(src), ptr(dst), outer, inner,
+                        self.dev.stream)
+        else:
+            libhip.call("ddh_%s_%s" % (kind, direction), h, ptr(src), ptr(dst), outer, inner, self.dev.stream)
+
+    def make_pack(self, nf, nrows, nx, ny, kx, ky):
+        return PencilPack(self.dev, nf, nrows, nx, ny, kx, ky)

@@ -1,0 +1,113 @@
+"""
+TEST INFRASTRUCTURE ONLY -- numpy/scipy executor with the HipExecutor interface.
+
+It restates the reference's CPU algorithm for every device operation: scipy.fft transforms with
+separate pack/scale passes (oracle/np_transforms.py), and a Python loop over pencils with scipy CSR
+mat-vecs and SuperLU factorizations (oracle/np_pencil.py).  Tests inject it explicitly
+(`Distributor(..., executor=NumpyExecutor())`) to check the host logic on machines without a GPU
+and as the parity oracle / CPU baseline; the product never selects it by itself.
+"""
+
+import numpy as np
+
+from . import np_pencil as npp
+from . import np_transforms as npt
+
+
+class _NpPack:
+    def __init__(self, nf, nrows, nx, ny, kx, ky):
+        self.nf, self.nrows, self.nx, self.ny = nf, nrows, nx, ny
+        self.kx, self.ky = np.asarray(kx, float), np.asarray(ky, float)
+        self.mats = []
+        self.lus = []
+        self.lu_meta = {}
+
+    def add_matrix(self, tl):
+        self.mats.append(npp.TermList(tl.nrows, tl.ncols, tl.row, tl.col, tl.coef, tl.ex, tl.ey, tl.dx, tl.dy))
+        return len(self.mats) - 1
+
+    def matvec(self, mid, x, y):
+        A = self.mats[mid]
+        y[...] = npp.matvec(A, x.reshape(A.ncols, self.nx, self.ny), self.nf, self.kx, self.ky)
+
+    def factor(self, matM, matL, a, b, row_perm, col_perm, n_interior, kl, ku, row_axes, col_axes, reuse=-1):
+        lu = npp.PencilLU(self.mats[matM], self.mats[matL], a, b, self.nf, self.nx, self.ny, self.kx, self.ky,
+                          np.asarray(row_axes), np.asarray(col_axes))
+        if reuse >= 0:
+            self.lus[reuse] = lu
+            return reuse
+        self.lus.append(lu)
+        return len(self.lus) - 1
+
+    def solve(self, lu_id, rhs, x):
+        x[...] = self.lus[lu_id].solve(rhs).reshape(x.shape)
+
+    def lu_bytes(self, lu_id):
+        return 0
+
+
+class NumpyExecutor:
+    name = "numpy-oracle"
+
+    def empty(self, shape):
+        return np.zeros(tuple(int(s) for s in np.atleast_1d(shape)))
+
+    zeros = empty
+
+    def from_host(self, a):
+        return np.array(a, dtype=np.float64)
+
+    def download(self, t):
+        return np.array(t)
+
+    def upload(self, dst, a):
+        dst[...] = np.asarray(a).reshape(dst.shape)
+
+    def copy(self, dst, src):
+        dst[...] = np.asarray(src).reshape(dst.shape)
+
+    def assign(self, dst_view, src_view):
+        dst_view[...] = src_view
+
+    def fill_zero(self, a):
+        a[...] = 0.0
+
+    def sync(self):
+        pass
+
+    def lincomb(self, y, xs, alphas):
+        acc = np.zeros_like(y)
+        for x, a in zip(xs, alphas):
+            acc += a * x.reshape(y.shape)
+        y[...] = acc
+
+    def bilinear(self, out, ncomp_out, a, b, npts, terms):
+        a2, b2 = a.reshape(-1, npts), b.reshape(-1, npts)
+        o = np.zeros((ncomp_out, npts))
+        for (ic, ia, ib, cf) in terms:
+            o[ic] += cf * a2[ia] * b2[ib]
+        out[...] = o.reshape(out.shape)
+
+    def transform(self, spec, basis, direction, src, dst, outer, inner):
+        kind = spec[0]
+        n_in = src.size // (outer * inner)
+        s3 = src.reshape(outer, n_in, inner)
+        if kind == "rfft":
+            N, M = spec[1], spec[2]
+            res = npt.rfft_forward(s3, 1, M) if direction == "forward" else npt.rfft_backward(s3, 1, N)
+        elif kind == "cheb":
+            N, M = spec[1], spec[2]
+            conv = None
+            if basis.a != basis.a0 or basis.b != basis.b0:
+                from dedalus_amd.tools import jacobi
+                conv = jacobi.conversion_matrix(M, basis.a0, basis.b0, basis.a, basis.b)
+            res = npt.cheb_forward(s3, 1, M, conv) if direction == "forward" else npt.cheb_backward(s3, 1, N, conv)
+        elif kind == "mmt":
+            fwd, bwd = basis.mmt_matrices(spec[1])
+            res = npt.apply_matrix_along_axis(fwd if direction == "forward" else bwd, s3, 1)
+        else:
+            raise NotImplementedError(kind)
+        dst[...] = res.reshape(dst.shape)
+
+    def make_pack(self, nf, nrows, nx, ny, kx, ky):
+        return _NpPack(nf, nrows, nx, ny, kx, ky)
