@@ -3,7 +3,7 @@ TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz by running the UNMODIFIE
 (through oracle/refshim) on seeded inputs.  Works only where /root/reference exists; the
 fixtures it writes are committed so the GPU box (no reference there) can use them.
 
-    python oracle/make_golden.py [transforms] [matrices] [ivp]
+    python oracle/make_golden.py [transforms] [timesteppers] [ivp]
 """
 
 import os
@@ -96,9 +96,46 @@ def golden_transforms():
     print("wrote transforms.npz with", len(out), "arrays")
 
 
+def golden_ivp():
+    """End states of the reference itself on the shared problem scripts (tests/problems.py)."""
+    d3 = refshim.load_reference()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import problems
+    out = {}
+    for name in problems.IVP_CASES:
+        solver, res = problems.run_case(d3, name)
+        for k, v in res.items():
+            out[name + "__" + k] = v
+        print(name, {k: float(np.linalg.norm(v)) for k, v in res.items()})
+    np.savez_compressed(os.path.join(GOLD, "ivp.npz"), **out)
+    print("wrote ivp.npz")
+
+
+def golden_timesteppers():
+    """Multistep coefficients of the reference for random step sequences (timesteppers.py:190-495)."""
+    refshim.load_reference()
+    from dedalus.core import timesteppers as T
+    rng = np.random.default_rng(7)
+    out = {}
+    seqs = [list(1e-3 * (0.5 + rng.random(4))) for _ in range(6)]
+    out["timesteps"] = np.array(seqs)
+    for name in ("CNAB1", "SBDF1", "CNAB2", "MCNAB2", "SBDF2", "CNLF2", "SBDF3", "SBDF4"):
+        cls = T.schemes[name]
+        for si, seq in enumerate(seqs):
+            for it in range(5):
+                a, b, c = cls.compute_coefficients(seq[:cls.steps] if False else seq, it)
+                for lab, v in (("a", a), ("b", b), ("c", c)):
+                    out["%s_%d_%d_%s" % (name, si, it, lab)] = np.asarray(v, dtype=float)
+    for name in ("RK111", "RK222", "RK443", "RKSMR"):
+        cls = T.schemes[name]
+        out[name + "_A"], out[name + "_H"], out[name + "_c"] = np.array(cls.A, float), np.array(cls.H, float), np.array(cls.c, float)
+    np.savez_compressed(os.path.join(GOLD, "timesteppers.npz"), **out)
+    print("wrote timesteppers.npz")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["transforms", "matrices", "ivp"]
+    what = sys.argv[1:] or ["transforms", "timesteppers", "ivp"]
     for w in what:
         fn = globals().get("golden_" + w)
         if fn is None:

@@ -1,0 +1,73 @@
+"""CPU: the host layer (equation parsing, term-list assembly, IMEX stepping) driven by the numpy
+oracle executor reproduces the end states of the reference itself (tests/golden/ivp.npz, generated
+by oracle/make_golden.py through oracle/refshim).  This pins oracle + host logic; the GPU tests
+then compare the HIP path with the same fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import problems
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+TOL = {"p": 1e-10, "b": 1e-10, "u": 1e-9, "tau_b1": 1e-5, "tau_b2": 1e-5, "tau_u1": 1e-8, "tau_u2": 1e-8}
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "ivp.npz"))
+
+
+@pytest.mark.parametrize("name", ["kdv64_sbdf2", "kdv64_rk443", "rb2d_32x16_rk222", "rb2d_32x16_sbdf2",
+                                  "rb3d_8x12x8_rk222"])
+def test_oracle_executor_matches_reference(gold, name):
+    import dedalus_amd.public as d3
+    from oracle.np_executor import NumpyExecutor
+    solver, res = problems.run_case(d3, name, dist_kw=dict(executor=NumpyExecutor()))
+    for k, v in res.items():
+        ref = gold[name + "__" + k]
+        assert v.shape == ref.shape
+        assert rel(v, ref) < TOL.get(k, 1e-10), (name, k, rel(v, ref))
+
+
+def test_timestepper_coefficients_match_reference(golden_dir):
+    from dedalus_amd.core import timesteppers as T
+    g = np.load(os.path.join(golden_dir, "timesteppers.npz"))
+    seqs = g["timesteps"]
+    for name in ("CNAB1", "SBDF1", "CNAB2", "MCNAB2", "SBDF2", "CNLF2", "SBDF3", "SBDF4"):
+        cls = T.schemes[name]
+        for si, seq in enumerate(seqs):
+            for it in range(5):
+                a, b, c = cls.compute_coefficients(list(seq), it)
+                for lab, v in (("a", a), ("b", b), ("c", c)):
+                    ref = g["%s_%d_%d_%s" % (name, si, it, lab)]
+                    n = min(len(ref), len(v))
+                    assert np.allclose(v[:n], ref[:n], rtol=1e-12, atol=1e-12 * np.abs(ref).max()), (name, it, lab)
+                    assert np.all(v[n:] == 0) and np.all(ref[n:] == 0)
+    for name in ("RK111", "RK222", "RK443", "RKSMR"):
+        cls = T.schemes[name]
+        assert np.allclose(cls.A, g[name + "_A"], rtol=0, atol=1e-15)
+        assert np.allclose(cls.H, g[name + "_H"], rtol=0, atol=1e-15)
+        assert np.allclose(cls.c, g[name + "_c"], rtol=0, atol=1e-15)
+    assert set(T.schemes) == {"CNAB1", "SBDF1", "CNAB2", "MCNAB2", "SBDF2", "CNLF2", "SBDF3", "SBDF4",
+                              "RK111", "RK222", "RK443", "RKSMR"}
+
+
+def test_product_has_no_cpu_fallback():
+    """Without an explicit (test-only) executor the product insists on the HIP device."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import dedalus_amd.public as d3
+    from dedalus_amd.libhip import DdhError
+    xcoord = d3.Coordinate('x')
+    dist = d3.Distributor(xcoord, dtype=np.float64)
+    xb = d3.RealFourier(xcoord, size=8, bounds=(0, 1))
+    u = dist.Field(name='u', bases=xb)
+    u['g'] = 1.0
+    with pytest.raises(DdhError):
+        u['c']
