@@ -85,6 +85,7 @@ class SolverBase:
         self.pack = self.ex.make_pack(nf, self.R, nx, ny, kx, ky)
         self.M_id = self.pack.add_matrix(self.M_tl)
         self.L_id = self.pack.add_matrix(self.L_tl)
+        self._build_recombination()
         self._build_ordering()
         self._build_F_plan()
 
@@ -107,55 +108,132 @@ class SolverBase:
                 blocks.append((einfo["row0"], le.nzo, vinfo["row0"], vinfo["nz"], terms, efx or vfx, efy or vfy))
         return flatten(blocks, self.R, self.R)
 
-    def _build_ordering(self):
-        """Logical ordering for the bordered band LU: coupled-axis index outermost over the interior
-        rows/columns, border (taus / boundary conditions) last.  (The reference's own orderings,
-        core/subsystems.py:614-739, are not banded for real-Fourier pencils: SURVEY.md section 7.2.)"""
-        def order(infos):
+    def _classify(self):
+        full = 3 if self.nf >= 2 else (1 if self.nf == 1 else 0)
+        def split(infos):
             inter = [i for i in infos if i["interior"]]
-            border = [i for i in infos if not i["interior"]]
-            nzs = {i["nz"] for i in inter}
+            edge = [i for i in infos if not i["interior"] and (i["bits"] & full) == full]
+            special = [i for i in infos if not i["interior"] and (i["bits"] & full) != full]
+            return inter, edge, special
+        return split(self.eq_info), split(self.var_info)
+
+    def _build_recombination(self):
+        """Column recombination X = P Y that makes the boundary-condition rows sparse.
+
+        The tau-bordered pencil matrices are only well conditioned as a whole: their banded interior
+        block alone is exponentially ill conditioned (it is a spectral-space shooting problem), so the
+        dense boundary rows must be available as pivots.  Instead of carrying dense rows through the
+        factorization we change the basis of every interior variable so that all but its first m modes
+        satisfy its m boundary conditions identically,
+            phi_n = p_n + sum_{s=1..m} c_{n,s} p_{n-s},    R_r[n] + sum_s c_{n,s} R_r[n-s] = 0   (r = 1..m)
+        (for Dirichlet data at both ends this is the classical p_n - p_n(1)/p_{n-2}(1) p_{n-2} basis).
+        The rows R.P then only touch modes < m, sit at the top of the matrix, and (a M + b L) P is a
+        plain band matrix on which standard partial pivoting (LAPACK gbtrf-style) is backward stable.
+        The reference reaches the same goal with SuperLU + COLAMD on each pencil
+        (libraries/matsolvers.py:126-149); its `Woodbury` solver (:285-321) is the dense-border
+        alternative that this replaces."""
+        from scipy import sparse
+        (eq_int, eq_bc, eq_sp), (var_int, var_tau, var_sp) = self._classify()
+        self.P_tl = None
+        self.P_id = None
+        self.MP_id, self.LP_id = self.M_id, self.L_id
+        self.MP_tl, self.LP_tl = self.M_tl, self.L_tl
+        bc_rows = [r for i in eq_bc for r in range(i["row0"], i["row0"] + i["rows"])]
+        if not bc_rows or not var_int:
+            return
+        R = np.zeros((len(bc_rows), self.R))
+        rowpos = {r: k for k, r in enumerate(bc_rows)}
+        for tl in (self.M_tl, self.L_tl):
+            for t in range(tl.nterms):
+                r = int(tl.row[t])
+                if r in rowpos:
+                    if tl.ex[t] or tl.ey[t] or tl.dx[t] or tl.dy[t] or abs(tl.coef[t].imag) > 0:
+                        raise NotImplementedError("boundary conditions that depend on the wavenumber")
+                    R[rowpos[r], tl.col[t]] += tl.coef[t].real
+        P = sparse.identity(self.R, format="lil")
+        used = np.zeros(len(bc_rows), dtype=bool)
+        for vi in var_int:
+            for c in range(vi["ncomp"]):
+                cols = vi["row0"] + c * vi["nz"] + np.arange(vi["nz"])
+                touching = [k for k in range(len(bc_rows)) if np.any(R[k, cols] != 0)]
+                m = len(touching)
+                if m == 0:
+                    continue
+                for k in touching:
+                    others = np.delete(np.arange(self.R), cols)
+                    if np.any(R[k, others] != 0):
+                        raise NotImplementedError("boundary condition coupling several variables")
+                    used[k] = True
+                Rv = R[np.ix_(touching, cols)]
+                for n in range(m, vi["nz"]):
+                    G = np.array([[Rv[r, n - s1] for s1 in range(1, m + 1)] for r in range(m)])
+                    cvec = np.linalg.solve(G, -Rv[:, n])
+                    for s1 in range(1, m + 1):
+                        if cvec[s1 - 1] != 0.0:
+                            P[cols[n - s1], cols[n]] = cvec[s1 - 1]
+        if not used.all():
+            raise NotImplementedError("boundary condition row without interior variable")
+        P = sparse.csr_matrix(P)
+        coo = P.tocoo()
+        from ..pencilpack import TermList
+        self.P_tl = TermList(self.R, self.R, coo.row, coo.col, coo.data.astype(complex))
+        self.MP_tl = _termlist_times_matrix(self.M_tl, P)
+        self.LP_tl = _termlist_times_matrix(self.L_tl, P)
+        self.P_id = self.pack.add_matrix(self.P_tl)
+        self.MP_id = self.pack.add_matrix(self.MP_tl)
+        self.LP_id = self.pack.add_matrix(self.LP_tl)
+
+    def _build_ordering(self):
+        """Logical ordering for the band LU: boundary-condition rows first, then the interior equations
+        with the coupled-axis index outermost; columns: interior variables (coupled index outermost),
+        then the tau columns.  Rows / columns that only exist in the k=0 pencil (gauge conditions) form a
+        small border.  (The reference's own orderings, core/subsystems.py:614-739, are not banded for
+        real-Fourier pencils: SURVEY.md section 7.2.)"""
+        (eq_int, eq_bc, eq_sp), (var_int, var_tau, var_sp) = self._classify()
+
+        def kz_major(infos):
+            nzs = {i["nz"] for i in infos}
             if len(nzs) > 1:
                 raise NotImplementedError("interior blocks with different coupled sizes")
             nz = nzs.pop() if nzs else 0
-            perm = []
-            for kz in range(nz):
-                for i in inter:
-                    for c in range(i["ncomp"]):
-                        perm.append(i["row0"] + c * i["nz"] + kz)
-            n_int = len(perm)
-            for i in border:
-                perm.extend(range(i["row0"], i["row0"] + i["rows"]))
-            return np.array(perm, dtype=np.int32), n_int
-        self.col_perm, n_c = order(self.var_info)
-        self.row_perm, n_r = order(self.eq_info)
-        if n_c != n_r:
-            raise ValueError("interior equation rows (%d) and interior variable rows (%d) differ" % (n_r, n_c))
-        self.n_interior = n_c
+            return [i["row0"] + c * i["nz"] + kz for kz in range(nz) for i in infos for c in range(i["ncomp"])]
+
+        def flat(infos):
+            return [r for i in infos for r in range(i["row0"], i["row0"] + i["rows"])]
+
+        rows = flat(eq_bc) + kz_major(eq_int)
+        cols = kz_major(var_int) + flat(var_tau)
+        if len(rows) != len(cols):
+            raise ValueError("band block is not square: %d equation rows vs %d variable columns "
+                             "(boundary conditions and tau variables must balance)" % (len(rows), len(cols)))
+        self.n_interior = len(rows)
+        rows += flat(eq_sp)
+        cols += flat(var_sp)
+        if len(rows) != self.R or len(cols) != self.R:
+            raise ValueError("gauge rows and columns do not balance")
+        self.row_perm = np.array(rows, dtype=np.int32)
+        self.col_perm = np.array(cols, dtype=np.int32)
         self.row_axes = np.zeros(self.R, dtype=np.uint8)
         self.col_axes = np.zeros(self.R, dtype=np.uint8)
         for i in self.eq_info:
-            self.row_axes[i["row0"]:i["row0"] + i["rows"]] = i["bits"]
+            self.row_axes[i["row0"]:i["row0"] + i["rows"]] = i["bits"] | (0 if self.nf >= 2 else (2 if self.nf == 1 else 3))
         for i in self.var_info:
-            self.col_axes[i["row0"]:i["row0"] + i["rows"]] = i["bits"]
+            self.col_axes[i["row0"]:i["row0"] + i["rows"]] = i["bits"] | (0 if self.nf >= 2 else (2 if self.nf == 1 else 3))
         rinv = np.empty(self.R, dtype=np.int64)
         cinv = np.empty(self.R, dtype=np.int64)
         rinv[self.row_perm] = np.arange(self.R)
         cinv[self.col_perm] = np.arange(self.R)
         kl = ku = 0
-        for tl in (self.M_tl, self.L_tl):
+        for tl in (self.MP_tl, self.LP_tl):
             if tl.nterms == 0:
                 continue
             i, c = rinv[tl.row], cinv[tl.col]
-            m = (i < self.n_interior) & (tl.dx == 0) & (tl.dy == 0)
+            m = (i < self.n_interior) & (c < self.n_interior) & (tl.dx == 0) & (tl.dy == 0)
             if m.any():
                 kl = max(kl, int((i[m] - c[m]).max()))
                 ku = max(ku, int((c[m] - i[m]).max()))
         nb = self.R - self.n_interior
-        if self.nf == 0 or self.n_interior == 0:
-            # single pencil / no coupled axis: everything is "border" -> dense path or tiny systems
-            ku = max(ku, nb)
-        self.kl, self.ku = kl, max(ku, nb if self.n_interior else 0)
+        self.kl, self.ku = kl, max(ku, nb)
 
     # ---- RHS plan --------------------------------------------------------------------------------------------
     def _build_F_plan(self):
@@ -292,9 +370,40 @@ class SolverBase:
             info["field"].require_coeff_space()
         self.push_unaliased()
 
+    def solve(self, lu, rhs, out):
+        """out = (a M + b L)^-1 rhs  through the recombined band factorization: X = P Y."""
+        if self.P_id is None:
+            self.pack.solve(lu, rhs, out)
+        else:
+            Y = self.ex.empty((self.R, self.nx, self.ny))
+            self.pack.solve(lu, rhs, Y)
+            self.pack.matvec(self.P_id, Y, out)
+
     def factor(self, a, b, reuse=-1):
-        return self.pack.factor(self.M_id, self.L_id, a, b, self.row_perm, self.col_perm, self.n_interior,
+        return self.pack.factor(self.MP_id, self.LP_id, a, b, self.row_perm, self.col_perm, self.n_interior,
                                 self.kl, self.ku, self.row_axes, self.col_axes, reuse=reuse)
+
+
+def _termlist_times_matrix(tl, P, cutoff=1e-12):
+    """(term list) @ (constant sparse matrix): same monomials, columns mixed by P."""
+    from scipy import sparse
+    from ..pencilpack import TermList
+    if tl.nterms == 0:
+        return tl
+    key = np.stack([tl.ex, tl.ey, tl.dx, tl.dy], axis=1).astype(np.int64)
+    uniq, inv = np.unique(key, axis=0, return_inverse=True)
+    inv = inv.ravel()
+    rows, cols, coefs, exs = [], [], [], []
+    for u in range(len(uniq)):
+        sel = inv == u
+        A = sparse.coo_matrix((tl.coef[sel], (tl.row[sel], tl.col[sel])), shape=(tl.nrows, tl.ncols)).tocsr()
+        AP = (A @ P).tocoo()
+        keep = np.abs(AP.data) > cutoff
+        rows.append(AP.row[keep]); cols.append(AP.col[keep]); coefs.append(AP.data[keep])
+        exs.append(np.tile(uniq[u], (int(keep.sum()), 1)))
+    e = np.concatenate(exs)
+    return TermList(tl.nrows, tl.ncols, np.concatenate(rows), np.concatenate(cols), np.concatenate(coefs),
+                    e[:, 0], e[:, 1], e[:, 2], e[:, 3])
 
 
 class InitialValueSolver(SolverBase):
@@ -427,7 +536,5 @@ class LinearBoundaryValueSolver(SolverBase):
         F = self.ex.empty((self.R, self.nx, self.ny))
         self.evaluate_F(F)
         lu = self.factor(0.0, 1.0)
-        Xnew = self.ex.empty((self.R, self.nx, self.ny))
-        self.pack.solve(lu, F, Xnew)
-        self.ex.copy(self.X, Xnew)
+        self.solve(lu, F, self.X)
         self.mark_state_current()

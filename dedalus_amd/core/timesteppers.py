@@ -112,9 +112,7 @@ class MultistepIMEX:
         if (a[0], b[0]) != self._LHS_params:
             self._lu = s.factor(a[0], b[0], reuse=self._lu)
             self._LHS_params = (a[0], b[0])
-        Xnew = ex.empty((s.R, s.nx, s.ny))
-        pack.solve(self._lu, self.RHS, Xnew)
-        ex.copy(s.X, Xnew)
+        s.solve(self._lu, self.RHS, s.X)
         s.mark_state_current()
         s.sim_time = s.sim_time + dt
 
@@ -303,9 +301,7 @@ class RungeKuttaIMEX:
                 if H[i, j] != 0.0:
                     xs.append(self.LX[j]); al.append(-k * H[i, j])
             ex.lincomb(self.RHS, xs, al)
-            Xnew = ex.empty((s.R, s.nx, s.ny))
-            pack.solve(self._lus[float(H[i, i])], self.RHS, Xnew)
-            ex.copy(s.X, Xnew)
+            s.solve(self._lus[float(H[i, i])], self.RHS, s.X)
             s.mark_state_current()
             s.sim_time = t0 + k * c[i]
 

@@ -28,7 +28,7 @@
 
 namespace ddh {
 
-constexpr int KLMAX = 12;
+constexpr int KLMAX = 16;
 constexpr int NBMAX = 16;
 
 struct PencilDev {
@@ -658,6 +658,8 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
         hipLaunchKernelGGL((solve_kernel<NF, 24>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
     else if (W <= 32)
         hipLaunchKernelGGL((solve_kernel<NF, 32>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
+    else if (W <= 40)
+        hipLaunchKernelGGL((solve_kernel<NF, 40>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
     else if (W <= 48)
         hipLaunchKernelGGL((solve_kernel<NF, 48>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
     else
@@ -799,7 +801,7 @@ int ddh_pencil_factor(ddh_handle pack, int matM_id, int matL_id, double a, doubl
     if (matM_id < 0 || matM_id >= nm || matL_id < 0 || matL_id >= nm) return fail("pencil_factor: bad matrix id");
     const int N = P.nrows, n = n_interior, nb = N - n;
     if (n < 0 || nb < 0) return fail("pencil_factor: bad interior size");
-    if (kl > KLMAX) return fail("pencil_factor: lower bandwidth " + std::to_string(kl) + " exceeds KLMAX=12");
+    if (kl > KLMAX) return fail("pencil_factor: lower bandwidth " + std::to_string(kl) + " exceeds KLMAX=16");
     if (nb > NBMAX) return fail("pencil_factor: border size " + std::to_string(nb) + " exceeds NBMAX=16");
     const int W = ku + kl;
     if (W > 64) return fail("pencil_factor: band too wide (ku+kl=" + std::to_string(W) + " > 64)");
