@@ -20,6 +20,7 @@ class HipExecutor:
         self.dev = device or Device.get()
         self.torch = self.dev.torch
         self._plans = {}
+        self.timer = None            # KernelTimer while bench.py measures, else None
 
     # ---- memory -------------------------------------------------------------------------------------
     def empty(self, shape):
@@ -52,12 +53,23 @@ class HipExecutor:
 
     # ---- kernels -------------------------------------------------------------------------------------
     def lincomb(self, y, xs, alphas):
+        if self.timer is not None:
+            return self.timer.run("lincomb", (len(xs) + 1) * y.numel() * 8, self._lincomb, y, xs, alphas)
+        return self._lincomb(y, xs, alphas)
+
+    def _lincomb(self, y, xs, alphas):
         n = y.numel()
         arr = (C.c_void_p * len(xs))(*[C.c_void_p(x.data_ptr()) for x in xs])
         al = np.ascontiguousarray(alphas, dtype=np.float64)
         libhip.call("ddh_lincomb", ptr(y), len(xs), arr, libhip.as_dp(al), n, self.dev.stream)
 
     def bilinear(self, out, ncomp_out, a, b, npts, terms):
+        if self.timer is not None:
+            na = len({t[1] for t in terms}) + len({t[2] for t in terms}) + ncomp_out
+            return self.timer.run("grid_bilinear", na * npts * 8, self._bilinear, out, ncomp_out, a, b, npts, terms)
+        return self._bilinear(out, ncomp_out, a, b, npts, terms)
+
+    def _bilinear(self, out, ncomp_out, a, b, npts, terms):
         ic = np.ascontiguousarray([t[0] for t in terms], dtype=np.int32)
         ia = np.ascontiguousarray([t[1] for t in terms], dtype=np.int32)
         ib = np.ascontiguousarray([t[2] for t in terms], dtype=np.int32)
@@ -93,6 +105,13 @@ class HipExecutor:
         return self._plans[spec]
 
     def transform(self, spec, basis, direction, src, dst, outer, inner):
+        if self.timer is not None:
+            name = "%s_%s_%s" % (spec[0], direction, "strided" if inner > 1 else "contig")
+            return self.timer.run(name, (src.numel() + dst.numel()) * 8, self._transform, spec, basis, direction,
+                                  src, dst, outer, inner)
+        return self._transform(spec, basis, direction, src, dst, outer, inner)
+
+    def _transform(self, spec, basis, direction, src, dst, outer, inner):
         kind, h, h2 = self._plan(spec, basis)
         if kind == "mmt":
             libhip.call("ddh_mmt_apply", h if direction == "forward" else h2, ptr(src), ptr(dst), outer, inner,
@@ -101,4 +120,34 @@ class HipExecutor:
             libhip.call("ddh_%s_%s" % (kind, direction), h, ptr(src), ptr(dst), outer, inner, self.dev.stream)
 
     def make_pack(self, nf, nrows, nx, ny, kx, ky):
-        return PencilPack(self.dev, nf, nrows, nx, ny, kx, ky)
+        pk = PencilPack(self.dev, nf, nrows, nx, ny, kx, ky)
+        pk.executor = self
+        return pk
+
+
+class KernelTimer:
+    """HIP-event timing of every kernel family on the launch stream (bench.py roofline numbers)."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.records = {}            # name -> [bytes_total, [(e0, e1), ...]]
+
+    def run(self, name, nbytes, fn, *args):
+        e0 = self.torch.cuda.Event(enable_timing=True)
+        e1 = self.torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*args)
+        e1.record()
+        rec = self.records.setdefault(name, [0, []])
+        rec[0] += nbytes
+        rec[1].append((e0, e1))
+        return out
+
+    def summary(self):
+        self.torch.cuda.synchronize()
+        out = {}
+        for name, (nbytes, evs) in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b in evs)
+            out[name] = dict(launches=len(evs), total_ms=ms, avg_ms=ms / len(evs), bytes_per_launch=nbytes / len(evs),
+                             gbps=(nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0)
+        return out

@@ -76,6 +76,7 @@ class PencilPack:
         self.ncy = self.ny // 2 if self.nf == 2 else 1
         self.matrices = []
         self.lu_meta = {}
+        self.executor = None
 
     def add_matrix(self, tl):
         row = np.ascontiguousarray(tl.row)
@@ -90,7 +91,16 @@ class PencilPack:
         self.matrices.append(tl)
         return mid.value
 
+    def _timer(self):
+        return getattr(self.executor, "timer", None) if self.executor is not None else None
+
     def matvec(self, mat_id, x, y):
+        t = self._timer()
+        if t is not None:
+            return t.run("pencil_matvec", (x.numel() + y.numel()) * 8, self._matvec, mat_id, x, y)
+        return self._matvec(mat_id, x, y)
+
+    def _matvec(self, mat_id, x, y):
         libhip.call("ddh_pencil_matvec", self.handle, mat_id, ptr(x), ptr(y), self.dev.stream)
 
     def factor(self, matM, matL, a, b, row_perm, col_perm, n_interior, kl, ku, row_axes, col_axes, reuse=-1):
@@ -140,6 +150,13 @@ class PencilPack:
         return lu_id
 
     def solve(self, lu_id, rhs, x):
+        t = self._timer()
+        if t is not None:
+            nb = self.lu_bytes(lu_id) + (rhs.numel() + x.numel()) * 8
+            return t.run("pencil_solve", nb, self._solve, lu_id, rhs, x)
+        return self._solve(lu_id, rhs, x)
+
+    def _solve(self, lu_id, rhs, x):
         libhip.call("ddh_pencil_solve", self.handle, lu_id, ptr(rhs), ptr(x), self.dev.stream)
 
     def lu_bytes(self, lu_id):
