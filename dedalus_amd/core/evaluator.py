@@ -68,6 +68,7 @@ class Evaluator:
         self._packs = {}
         self._lin_cache = {}
         self._const_cache = {}
+        self._canon = {}
         self.cache = {}
 
     # ---- geometry ------------------------------------------------------------------------------------
@@ -185,9 +186,48 @@ class Evaluator:
             self.ex.lincomb(res, parts, [1.0] * len(parts))
         return res
 
+    # ---- structural de-duplication ------------------------------------------------------------------------
+    def _skey(self, x):
+        import numbers
+        from .field import Operand
+        if isinstance(x, Field):
+            return ("F", id(x))
+        if isinstance(x, Operand):
+            k = getattr(x, "_skey_cache", None)
+            if k is None:
+                k = (type(x).__name__,) + tuple(self._skey(a) for a in x.args)
+                x._skey_cache = k
+            return k
+        if isinstance(x, (numbers.Number, str, type(None))):
+            return x
+        if isinstance(x, (tuple, list)):
+            return tuple(self._skey(a) for a in x)
+        try:
+            hash(x)
+            return x
+        except TypeError:
+            return ("id", id(x))
+
+    def canon(self, expr):
+        """Structurally identical sub-expressions (e.g. `-u` written in two equations) share results."""
+        if isinstance(expr, Field):
+            return expr
+        k = self._skey(expr)
+        return self._canon.setdefault(k, expr)
+
+    @staticmethod
+    def _strip_scalar(expr):
+        """(c, X) with expr == c * X: numeric factors are folded into the product kernels."""
+        c = 1.0
+        while isinstance(expr, ops.Multiply) and expr.number is not None:
+            c *= expr.number
+            expr = expr.args[1]
+        return c, expr
+
     # ---- public evaluation -------------------------------------------------------------------------------
     def eval_coeff(self, expr):
         """Coefficient data [ncomp, storage coeff shape] of expr in expr.domain."""
+        expr = self.canon(expr)
         key = ("c", id(expr))
         if key in self.cache:
             return self.cache[key]
@@ -208,6 +248,7 @@ class Evaluator:
 
     def eval_grid(self, expr):
         """Grid data at the dealias scales."""
+        expr = self.canon(expr)
         key = ("g", id(expr))
         if key in self.cache:
             return self.cache[key]
@@ -252,11 +293,16 @@ class Evaluator:
         ex = self.ex
         if isinstance(expr, (ops.Multiply, ops.DotProduct, ops.CrossProduct)):
             a, b = expr.args
-            ga = self._broadcast_grid(a, expr.domain, scales)
-            gb = self._broadcast_grid(b, expr.domain, scales)
+            sa, a0 = self._strip_scalar(a)
+            sb, b0 = self._strip_scalar(b)
+            ga = self._broadcast_grid(a0, expr.domain, scales)
+            gb = self._broadcast_grid(b0, expr.domain, scales)
             out = ex.empty(self._grid_shape(expr, scales))
             npts = int(np.prod(expr.domain.storage_grid_shape(scales)))
-            ex.bilinear(out, expr.ncomp, ga, gb, npts, expr.bilinear_terms())
+            terms = expr.bilinear_terms()
+            if sa * sb != 1.0:
+                terms = [(ic, ia, ib, cf * sa * sb) for (ic, ia, ib, cf) in terms]
+            ex.bilinear(out, expr.ncomp, ga, gb, npts, terms)
             return out
         if isinstance(expr, ops.Power):
             a, p = expr.args

@@ -23,7 +23,27 @@ enum FftMode { RFFT_FWD = 0, RFFT_BWD, CHEB_FWD, CHEB_BWD, CFFT_FWD, CFFT_BWD };
 constexpr int MAX_RADIX_PASSES = 16;
 constexpr int MAX_BANDS = 4;
 
+// division by a runtime constant without the ~40-instruction software divide
+struct FastDiv {
+    unsigned d, m, s;
+    __host__ void set(unsigned dd) {
+        d = dd ? dd : 1;
+        if (d == 1) { m = 0; s = 0; return; }
+        s = 0;
+        while ((1ull << s) < d) ++s;
+        m = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+    }
+    __device__ __forceinline__ unsigned div(unsigned n) const {
+        return d == 1 ? n : (unsigned)(((unsigned long long)__umulhi(n, m) + n) >> s);
+    }
+    __device__ __forceinline__ void divmod(unsigned n, unsigned &q, unsigned &r) const {
+        q = div(n);
+        r = n - q * d;
+    }
+};
+
 struct FftDev {
+    FastDiv fdN, fdM, fdMh, fdK1, fdB, fd_nb[MAX_RADIX_PASSES], fd_ns[MAX_RADIX_PASSES];
     int N;       // grid size = FFT length
     int M;       // coefficient size
     int K;       // Fourier: largest retained wavenumber
@@ -141,8 +161,9 @@ __device__ __forceinline__ void butterfly<7>(double2 *v, int sign) {
 
 // One Stockham pass of radix R over B lines of length N held in buf[line*ld + j].
 template <int R>
-__device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int Ns,
-                                         const double2 *__restrict__ tw, int sign, int tid, int T) {
+__device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int Ns, const FastDiv &fd_nb,
+                                         const FastDiv &fd_ns, const double2 *__restrict__ tw, int sign, int tid,
+                                         int T) {
     constexpr int MAXI = 16 / R;
     const int nb = N / R;
     const int total = nb * B;
@@ -153,9 +174,10 @@ __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int
     for (int it = 0; it < MAXI; ++it) {
         const int w = tid + it * T;
         if (w < total) {
-            const int line = w / nb;
-            const int j = w - line * nb;
-            const int k = j % Ns;
+            unsigned uline, uj, uq, uk;
+            fd_nb.divmod((unsigned)w, uline, uj);
+            fd_ns.divmod(uj, uq, uk);
+            const int line = (int)uline, j = (int)uj, k = (int)uk;
             const double2 *x = buf + line * ld;
 #pragma unroll
             for (int t = 0; t < R; ++t) v[it][t] = x[j + t * nb];
@@ -192,11 +214,11 @@ __device__ __forceinline__ void lds_fft(double2 *buf, const FftDev &p, int sign,
     for (int i = 0; i < p.nradix; ++i) {
         const int R = p.radix[i];
         switch (R) {
-            case 2: fft_pass<2>(buf, p.ld, p.B, p.N, Ns, p.tw, sign, tid, T); break;
-            case 3: fft_pass<3>(buf, p.ld, p.B, p.N, Ns, p.tw, sign, tid, T); break;
-            case 4: fft_pass<4>(buf, p.ld, p.B, p.N, Ns, p.tw, sign, tid, T); break;
-            case 5: fft_pass<5>(buf, p.ld, p.B, p.N, Ns, p.tw, sign, tid, T); break;
-            default: fft_pass<7>(buf, p.ld, p.B, p.N, Ns, p.tw, sign, tid, T); break;
+            case 2: fft_pass<2>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
+            case 3: fft_pass<3>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
+            case 4: fft_pass<4>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
+            case 5: fft_pass<5>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
+            default: fft_pass<7>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
         }
         Ns *= R;
     }
@@ -246,13 +268,16 @@ struct PairIO {
 
 // item -> (axis index j, pair slot b) so that global accesses coalesce
 template <bool INNER>
-__device__ __forceinline__ void split_item(int w, int B, int n, int &j, int &b) {
+__device__ __forceinline__ void split_item(int w, const FastDiv &fdB, const FastDiv &fdn, int &j, int &b) {
+    unsigned q, r;
     if (INNER) {
-        b = w % B;
-        j = w / B;
+        fdB.divmod((unsigned)w, q, r);
+        b = (int)r;
+        j = (int)q;
     } else {
-        j = w % n;
-        b = w / n;
+        fdn.divmod((unsigned)w, q, r);
+        j = (int)r;
+        b = (int)q;
     }
 }
 
@@ -285,7 +310,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     if (MODE == RFFT_FWD) {
         for (int w = tid; w < N * B; w += T) {
             int j, b;
-            split_item<INNER>(w, B, N, j, b);
+            split_item<INNER>(w, p.fdB, p.fdN, j, b);
             double2 v = make_double2(0.0, 0.0);
             if (q0 + b < npairs) v = io.load(src, N, j, q0 + b);
             buf[b * ld + j] = v;
@@ -295,12 +320,16 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
         // zero the dealiased band K < k < N-K
         const int nzero = N - 2 * K - 1;
         for (int w = tid; w < nzero * B; w += T) {
-            int b = w % B, j = w / B;
+            unsigned q, r;
+            p.fdB.divmod((unsigned)w, q, r);
+            const int b = (int)r, j = (int)q;
             buf[b * ld + K + 1 + j] = make_double2(0.0, 0.0);
         }
         if (INNER) {
             for (int w = tid; w < (K + 1) * B; w += T) {
-                int b = w % B, k = w / B;
+                unsigned q, r;
+                p.fdB.divmod((unsigned)w, q, r);
+                const int b = (int)r, k = (int)q;
                 double2 c = make_double2(0.0, 0.0), s = c;
                 if (q0 + b < npairs) {
                     c = io.load(src, M, 2 * k, q0 + b);
@@ -316,7 +345,9 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
         } else {
             // contiguous lines: element 2k, 2k+1 of each line
             for (int w = tid; w < (K + 1) * B; w += T) {
-                int k = w % (K + 1), b = w / (K + 1);
+                unsigned q, r;
+                p.fdK1.divmod((unsigned)w, q, r);
+                const int k = (int)r, b = (int)q;
                 double2 c = make_double2(0.0, 0.0), s = c;
                 if (q0 + b < npairs) {
                     c = io.load(src, M, 2 * k, q0 + b);
@@ -333,7 +364,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     } else if (MODE == CHEB_FWD) {
         for (int w = tid; w < N * B; w += T) {
             int j, b;
-            split_item<INNER>(w, B, N, j, b);
+            split_item<INNER>(w, p.fdB, p.fdN, j, b);
             double2 v = make_double2(0.0, 0.0);
             if (q0 + b < npairs) v = io.load(src, N, j, q0 + b);
             buf[b * ld + dct_perm(j, N)] = v;
@@ -341,7 +372,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     } else if (MODE == CHEB_BWD) {
         for (int w = tid; w < M * B; w += T) {
             int k, b;
-            split_item<INNER>(w, B, M, k, b);
+            split_item<INNER>(w, p.fdB, p.fdM, k, b);
             double2 v = make_double2(0.0, 0.0);
             // coefficients beyond the grid size are dropped BEFORE the conversion solve
             // (transforms.py:878-881)
@@ -375,7 +406,9 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
         }
         const int Mk = (M < N) ? M : N;
         for (int w = tid; w < N * B; w += T) {
-            const int k = w % N, b = w / N;
+            unsigned q, r;
+            p.fdN.divmod((unsigned)w, q, r);
+            const int k = (int)r, b = (int)q;
             const double2 *c = cbuf + b * M;
             double2 e = make_double2(0.0, 0.0), f = e;
             if (k < Mk) {
@@ -398,7 +431,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
         // complex lines, no pairing: "pair" slot = one complex line; load() returns (re, im)
         for (int w = tid; w < N * B; w += T) {
             int j, b;
-            split_item<INNER>(w, B, N, j, b);
+            split_item<INNER>(w, p.fdB, p.fdN, j, b);
             double2 v = make_double2(0.0, 0.0);
             if (q0 + b < npairs) {
                 const long line = q0 + b;
@@ -412,7 +445,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
         const int K = p.K;
         for (int w = tid; w < N * B; w += T) {
             int j, b;
-            split_item<INNER>(w, B, N, j, b);
+            split_item<INNER>(w, p.fdB, p.fdN, j, b);
             // fft position j -> wavenumber k in (-N/2, N/2]; keep |k| <= K
             int k = (j <= N / 2) ? j : j - N;
             double2 v = make_double2(0.0, 0.0);
@@ -436,7 +469,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     if (MODE == RFFT_BWD || MODE == CHEB_BWD) {
         for (int w = tid; w < N * B; w += T) {
             int j, b;
-            split_item<INNER>(w, B, N, j, b);
+            split_item<INNER>(w, p.fdB, p.fdN, j, b);
             if (q0 + b < npairs) {
                 const int pos = (MODE == CHEB_BWD) ? dct_perm(j, N) : j;
                 io.store(dst, N, j, q0 + b, buf[b * ld + pos]);
@@ -447,7 +480,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
         const int Mh = M / 2;
         for (int w = tid; w < Mh * B; w += T) {
             int k, b;
-            split_item<INNER>(w, B, Mh, k, b);
+            split_item<INNER>(w, p.fdB, p.fdMh, k, b);
             if (q0 + b >= npairs) continue;
             double2 c = make_double2(0.0, 0.0), s = c;
             if (k == 0) {
@@ -466,7 +499,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
         if (p.nbands == 0) {
             for (int w = tid; w < M * B; w += T) {
                 int k, b;
-                split_item<INNER>(w, B, M, k, b);
+                split_item<INNER>(w, p.fdB, p.fdM, k, b);
                 if (q0 + b >= npairs) continue;
                 double2 c = make_double2(0.0, 0.0);
                 if (k < Mk) {
@@ -480,7 +513,9 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             }
         } else {
             for (int w = tid; w < M * B; w += T) {
-                const int k = w % M, b = w / M;
+                unsigned q, r;
+                p.fdM.divmod((unsigned)w, q, r);
+                const int k = (int)r, b = (int)q;
                 double2 c = make_double2(0.0, 0.0);
                 if (k < Mk) {
                     const double2 z1 = buf[b * ld + k], z2 = buf[b * ld + ((k == 0) ? 0 : N - k)];
@@ -495,7 +530,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             // forward_conversion apply (transforms.py:862-874): c'_k = sum_d C[k,k+off_d] c_{k+off_d}
             for (int w = tid; w < M * B; w += T) {
                 int k, b;
-                split_item<INNER>(w, B, M, k, b);
+                split_item<INNER>(w, p.fdB, p.fdM, k, b);
                 if (q0 + b >= npairs) continue;
                 const double2 *c = cbuf + b * M;
                 double2 acc = make_double2(0.0, 0.0);
@@ -514,7 +549,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
         const int K = p.K;
         for (int w = tid; w < M * B; w += T) {
             int m, b;
-            split_item<INNER>(w, B, M, m, b);
+            split_item<INNER>(w, p.fdB, p.fdM, m, b);
             if (q0 + b >= npairs) continue;
             // coefficient slot m -> wavenumber (transforms.py:201-208): k = m for m <= KM else m - M
             const int KM = (M - 1) / 2;
@@ -531,7 +566,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     } else if (MODE == CFFT_BWD) {
         for (int w = tid; w < N * B; w += T) {
             int j, b;
-            split_item<INNER>(w, B, N, j, b);
+            split_item<INNER>(w, p.fdB, p.fdN, j, b);
             if (q0 + b >= npairs) continue;
             const long line = q0 + b;
             double *ptr = INNER ? dst + 2 * ((io.outer_idx * N + j) * inner + line) : dst + 2 * (line * N + j);
@@ -646,6 +681,18 @@ static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nba
         return st;
     }
     d.ld = N;
+    d.fdN.set((unsigned)N);
+    d.fdM.set((unsigned)M);
+    d.fdMh.set((unsigned)(M / 2 > 0 ? M / 2 : 1));
+    d.fdK1.set((unsigned)(d.K + 1));
+    {
+        int Ns = 1;
+        for (int i = 0; i < d.nradix; ++i) {
+            d.fd_nb[i].set((unsigned)(N / d.radix[i]));
+            d.fd_ns[i].set((unsigned)Ns);
+            Ns *= d.radix[i];
+        }
+    }
     *out = register_handle(pl);
     return 0;
 }
@@ -674,6 +721,7 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     while ((long)N * B > 16L * T && T < 1024) T *= 2;
     if ((long)N * B > 16L * T) return fail("transform: axis too long for the LDS kernel (registers)");
     d.B = B;
+    d.fdB.set((unsigned)B);
     const unsigned bpo = (unsigned)((npairs + B - 1) / B);
     const unsigned long nblocks = inner_mode ? (unsigned long)bpo * (unsigned long)outer : bpo;
     if (nblocks > 0x7fffffffUL) return fail("transform: grid too large");

@@ -81,6 +81,12 @@ def load(build_if_missing=False):
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch ships its own libamdhip64: it must be the HIP runtime this library binds to, so that
+        # device pointers and streams are shared (loading ours first would create a second runtime)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         if build_if_missing:
             from . import build
