@@ -133,8 +133,11 @@ class Evaluator:
         fy = len(sep) >= 2 and domain.by_axis[sep[1]] is None
         return fx, fy
 
-    def apply_linear(self, le, out_domain, out_rows_total=None, row0=0, out=None):
-        """out[rows] = sum over leaves of TermList(le) @ leaf; returns a [rows][nx][ny] array."""
+    def apply_linear(self, le, out_domain, out_rows_total=None, row0=0, out=None, post_basis=None):
+        """out[rows] = sum over leaves of TermList(le) @ leaf; returns a [rows][nx][ny] array.
+        With post_basis (a Jacobi basis whose (a, b) differ from its grid parameters) the result is
+        delivered in the grid basis instead: the ultraspherical back-substitution is fused into the
+        mat-vec kernel (only possible when a single launch produces the result; else returns None)."""
         nf, nx, ny, kx, ky = self.geom()
         nrows = le.nco * le.nzo if out_rows_total is None else out_rows_total
         # group leaves by the system buffer they live in
@@ -149,6 +152,8 @@ class Evaluator:
                 groups.setdefault(("leaf", id(leaf)), [None, []])[1].append((leaf, terms))
         parts = []
         fdx_o, fdy_o = self._force_flags(out_domain)
+        if post_basis is not None and len(groups) != 1:
+            return None
         for key, (sb, items) in groups.items():
             ckey = (id(le), key, nrows, row0)
             cached = getattr(le, "_tl_cache", None)
@@ -175,7 +180,17 @@ class Evaluator:
             if x is None:
                 x = self._leaf_plane_data(items[0][0])
             y = self.ex.empty((nrows, nx, ny))
-            pack.matvec(mid, x, y)
+            if post_basis is not None:
+                offs, bands = post_basis.conversion_bands()
+                bkey = (post_basis.size, offs, bands.tobytes())
+                ids = getattr(pack, "_bands_ids", None)
+                if ids is None:
+                    ids = pack._bands_ids = {}
+                if bkey not in ids:
+                    ids[bkey] = pack.add_upper_bands(post_basis.size, offs, bands)
+                pack.matvec_solve(mid, ids[bkey], x, y)
+            else:
+                pack.matvec(mid, x, y)
             parts.append(y)
         if not parts:
             res = self.ex.zeros((nrows, nx, ny))
@@ -258,10 +273,32 @@ class Evaluator:
         elif self._is_nonlinear_node(expr):
             res = self._eval_nonlinear(expr, scales)
         else:
-            c = self.eval_coeff(expr)
-            res = self.ex.empty((expr.ncomp,) + tuple(expr.domain.storage_grid_shape(scales)))
-            self.dist.transformer.backward_data(expr.domain, expr.ncomp, c, res, scales)
+            res = self._linear_to_grid_fused(expr, scales)
+            if res is None:
+                c = self.eval_coeff(expr)
+                res = self.ex.empty((expr.ncomp,) + tuple(expr.domain.storage_grid_shape(scales)))
+                self.dist.transformer.backward_data(expr.domain, expr.ncomp, c, res, scales)
         self.cache[key] = res
+        return res
+
+    def _linear_to_grid_fused(self, expr, scales):
+        """Linear expression -> grid with the ultraspherical conversion solve fused into the mat-vec."""
+        if ("c", id(expr)) in self.cache or not _full_sep(self.dist, expr.domain):
+            return None
+        jac = [ax for ax in self.dist._jacobi_axes if expr.domain.by_axis[ax] is not None]
+        if len(jac) != 1:
+            return None
+        b = expr.domain.by_axis[jac[0]]
+        if (b.a, b.b) == (b.a0, b.b0) or not (b.a0 == b.b0 == -0.5):
+            return None
+        le = self._lin(expr)
+        c = self.apply_linear(le, expr.domain, post_basis=b)
+        if c is None:
+            return None
+        gdom = expr.domain.replace(jac[0], b.clone_with(a=b.a0, b=b.b0))
+        c = c.reshape((expr.ncomp,) + tuple(gdom.storage_coeff_shape()))
+        res = self.ex.empty((expr.ncomp,) + tuple(gdom.storage_grid_shape(scales)))
+        self.dist.transformer.backward_data(gdom, expr.ncomp, c, res, scales)
         return res
 
     @staticmethod

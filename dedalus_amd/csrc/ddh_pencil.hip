@@ -51,6 +51,15 @@ struct MatDev {
     const unsigned *expo;  // ex | ey<<8 | dx<<16 | dy<<24
 };
 
+// optional upper-banded back-substitution along the coupled index fused into a mat-vec:
+// rows are (component, kz); y[comp, kz] = (A x)[comp, kz] - sum_{d>=1} band[d][kz] y[comp, kz+off_d]) / band[0][kz]
+struct PostSolve {
+    int nz;          // 0 -> disabled
+    int nbands;
+    int off[4];
+    const double *bands;   // [nbands][nz]
+};
+
 struct Matrix {
     MatDev dev;
     std::vector<int> row_h, col_h;
@@ -87,6 +96,8 @@ struct PencilPack : HandleBase {
     void *d_kx = nullptr, *d_ky = nullptr;
     std::vector<Matrix *> mats;
     std::vector<LuFactor *> lus;
+    std::vector<PostSolve> posts;
+    std::vector<void *> post_mem;
     ~PencilPack() override;
 };
 
@@ -118,6 +129,7 @@ PencilPack::~PencilPack() {
         delete m;
     }
     for (auto l : lus) free_lu(l);
+    for (auto m : post_mem) (void)hipFree(m);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -189,7 +201,7 @@ __device__ __forceinline__ bool axes_valid(unsigned char bits, const CellCtx &c,
 // ------------------------------------------------------------------------------------------------
 template <int NF>
 __global__ void __launch_bounds__(256)
-matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *__restrict__ y) {
+matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, PostSolve ps) {
     const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= P.ncells) return;
     const CellCtx c = cell_ctx(P, cell);
@@ -203,7 +215,15 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *__res
     } else {
         off0 = 0;
     }
-    for (int r = 0; r < A.nrows_out; ++r) {
+    for (int rr = 0; rr < A.nrows_out; ++rr) {
+        int r = rr, kz = 0, comp0 = 0;
+        if (ps.nz > 0) {
+            // descending coupled index inside each component so that y[kz + off] is already final
+            const int comp = rr / ps.nz;
+            kz = ps.nz - 1 - (rr - comp * ps.nz);
+            comp0 = comp * ps.nz;
+            r = comp0 + kz;
+        }
         double2 accP = make_double2(0.0, 0.0), accQ = accP;
         const int t1 = A.rowptr[r + 1];
         for (int t = A.rowptr[r]; t < t1; ++t) {
@@ -228,15 +248,44 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *__res
             }
         }
         double *yr = y + (long)r * plane;
+        // stored real parts: v0 = (cc, cs) [or (a, b)], v1 = (sc, ss)
+        double2 v0, v1 = make_double2(0.0, 0.0);
         if (NF == 2) {
-            *reinterpret_cast<double2 *>(yr + off0) =
-                make_double2(0.5 * (accP.x + accQ.x), 0.5 * (accP.y + accQ.y));
-            *reinterpret_cast<double2 *>(yr + off1) =
-                make_double2(0.5 * (accP.y - accQ.y), 0.5 * (accQ.x - accP.x));
-        } else if (NF == 1) {
-            *reinterpret_cast<double2 *>(yr + off0) = accP;
+            v0 = make_double2(0.5 * (accP.x + accQ.x), 0.5 * (accP.y + accQ.y));
+            v1 = make_double2(0.5 * (accP.y - accQ.y), 0.5 * (accQ.x - accP.x));
         } else {
-            yr[0] = accP.x;
+            v0 = accP;
+        }
+        if (ps.nz > 0) {
+            // the conversion is real and wavenumber-independent: it acts on each real part alike
+            for (int d = 1; d < ps.nbands; ++d) {
+                const int kk = kz + ps.off[d];
+                if (kk < ps.nz) {
+                    const double bnd = ps.bands[d * ps.nz + kz];
+                    const double *yp = y + (long)(comp0 + kk) * plane;
+                    if (NF == 2) {
+                        const double2 p0 = *reinterpret_cast<const double2 *>(yp + off0);
+                        const double2 p1 = *reinterpret_cast<const double2 *>(yp + off1);
+                        v0.x -= bnd * p0.x; v0.y -= bnd * p0.y;
+                        v1.x -= bnd * p1.x; v1.y -= bnd * p1.y;
+                    } else if (NF == 1) {
+                        const double2 p0 = *reinterpret_cast<const double2 *>(yp + off0);
+                        v0.x -= bnd * p0.x; v0.y -= bnd * p0.y;
+                    } else {
+                        v0.x -= bnd * yp[0];
+                    }
+                }
+            }
+            const double inv = 1.0 / ps.bands[kz];
+            v0.x *= inv; v0.y *= inv; v1.x *= inv; v1.y *= inv;
+        }
+        if (NF == 2) {
+            *reinterpret_cast<double2 *>(yr + off0) = v0;
+            *reinterpret_cast<double2 *>(yr + off1) = v1;
+        } else if (NF == 1) {
+            *reinterpret_cast<double2 *>(yr + off0) = v0;
+        } else {
+            yr[0] = v0.x;
         }
     }
 }
@@ -772,23 +821,57 @@ int ddh_pencil_add_matrix(ddh_handle pack, const ddh_polymat *mat, int nrows_out
     return 0;
 }
 
-int ddh_pencil_matvec(ddh_handle pack, int mat_id, const double *x, double *y, void *stream) {
-    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
-    if (!pp) return -1;
+static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y, const PostSolve &ps, void *stream) {
     if (mat_id < 0 || mat_id >= (int)pp->mats.size()) return fail("pencil_matvec: bad matrix id");
     if (x == y) return fail("pencil_matvec: in-place unsupported");
     const PencilDev &P = pp->dev;
     const MatDev &A = pp->mats[mat_id]->dev;
+    if (ps.nz > 0 && A.nrows_out % ps.nz) return fail("pencil_matvec_solve: rows are not a multiple of nz");
     const unsigned blocks = (unsigned)((P.ncells + 255) / 256);
     hipStream_t s = as_stream(stream);
     if (P.nf == 2)
-        hipLaunchKernelGGL(matvec_kernel<2>, dim3(blocks), dim3(256), 0, s, P, A, x, y);
+        hipLaunchKernelGGL(matvec_kernel<2>, dim3(blocks), dim3(256), 0, s, P, A, x, y, ps);
     else if (P.nf == 1)
-        hipLaunchKernelGGL(matvec_kernel<1>, dim3(blocks), dim3(256), 0, s, P, A, x, y);
+        hipLaunchKernelGGL(matvec_kernel<1>, dim3(blocks), dim3(256), 0, s, P, A, x, y, ps);
     else
-        hipLaunchKernelGGL(matvec_kernel<0>, dim3(blocks), dim3(256), 0, s, P, A, x, y);
+        hipLaunchKernelGGL(matvec_kernel<0>, dim3(blocks), dim3(256), 0, s, P, A, x, y, ps);
     DDH_HIP(hipGetLastError());
     return 0;
+}
+
+int ddh_pencil_matvec(ddh_handle pack, int mat_id, const double *x, double *y, void *stream) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    PostSolve ps;
+    memset(&ps, 0, sizeof(ps));
+    return launch_matvec(pp, mat_id, x, y, ps, stream);
+}
+
+int ddh_pencil_add_upper_bands(ddh_handle pack, int nz, int nbands, const int *offsets_h, const double *bands_h,
+                               int *bands_id) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (nz < 1 || nbands < 1 || nbands > 4 || offsets_h[0] != 0) return fail("pencil_add_upper_bands: bad band description");
+    PostSolve ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.nz = nz;
+    ps.nbands = nbands;
+    for (int d = 0; d < nbands; ++d) ps.off[d] = offsets_h[d];
+    void *mem = nullptr;
+    int st = upload_vec(&mem, bands_h, (size_t)nbands * nz);
+    if (st) return st;
+    ps.bands = (const double *)mem;
+    pp->post_mem.push_back(mem);
+    pp->posts.push_back(ps);
+    *bands_id = (int)pp->posts.size() - 1;
+    return 0;
+}
+
+int ddh_pencil_matvec_solve(ddh_handle pack, int mat_id, int bands_id, const double *x, double *y, void *stream) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (bands_id < 0 || bands_id >= (int)pp->posts.size()) return fail("pencil_matvec_solve: bad bands id");
+    return launch_matvec(pp, mat_id, x, y, pp->posts[bands_id], stream);
 }
 
 int ddh_pencil_factor(ddh_handle pack, int matM_id, int matL_id, double a, double b, const int *row_perm_h,

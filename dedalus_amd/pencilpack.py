@@ -103,6 +103,23 @@ class PencilPack:
     def _matvec(self, mat_id, x, y):
         libhip.call("ddh_pencil_matvec", self.handle, mat_id, ptr(x), ptr(y), self.dev.stream)
 
+    def add_upper_bands(self, nz, offsets, bands):
+        offs = np.ascontiguousarray(offsets, dtype=np.int32)
+        b = np.ascontiguousarray(bands, dtype=np.float64)
+        bid = C.c_int(-1)
+        libhip.call("ddh_pencil_add_upper_bands", self.handle, int(nz), len(offs), libhip.as_ip(offs), libhip.as_dp(b),
+                    C.byref(bid))
+        return bid.value
+
+    def matvec_solve(self, mat_id, bands_id, x, y):
+        t = self._timer()
+        if t is not None:
+            return t.run("pencil_matvec", (x.numel() + y.numel()) * 8, self._matvec_solve, mat_id, bands_id, x, y)
+        return self._matvec_solve(mat_id, bands_id, x, y)
+
+    def _matvec_solve(self, mat_id, bands_id, x, y):
+        libhip.call("ddh_pencil_matvec_solve", self.handle, mat_id, bands_id, ptr(x), ptr(y), self.dev.stream)
+
     def factor(self, matM, matL, a, b, row_perm, col_perm, n_interior, kl, ku, row_axes, col_axes, reuse=-1):
         """Factor a*M + b*L for every pencil; returns the LU id."""
         row_perm = np.ascontiguousarray(row_perm, dtype=np.int32)

@@ -117,6 +117,15 @@ int ddh_pencil_add_matrix(ddh_handle pack, const ddh_polymat *mat, int nrows_out
 /* y[nrows_out][cells] = A x  (apply_sparse tools/array.py:171-203 over all pencils at once;
  * gather/scatter subsystems.py:340-380 are the identity in this layout)                           */
 int ddh_pencil_matvec(ddh_handle pack, int mat_id, const double *x, double *y, void *stream);
+/* Mat-vec fused with an upper-banded back-substitution along the coupled index of every output
+ * component (rows = (component, kz), nz per component): y <- C^-1 (A x).  With C the ultraspherical
+ * conversion matrix this yields the coefficients directly in the grid (Chebyshev-T) basis, i.e. the
+ * solve_upper_sparse step of FastChebyshevTransform.backward (core/transforms.py:876-890) is done
+ * here, per pencil thread, instead of inside the transform.  Bands as in ddh_plan_cheb.           */
+int ddh_pencil_add_upper_bands(ddh_handle pack, int nz, int nbands, const int *offsets_h,
+                               const double *bands_h, int *bands_id);
+int ddh_pencil_matvec_solve(ddh_handle pack, int mat_id, int bands_id, const double *x, double *y,
+                            void *stream);
 /* Bordered-banded LU of (a*M + b*L) for every pencil (matsolvers.py:126-149 SuperLU replaced;
  * LHS formation timesteppers.py:172-181, 630-640).
  * perm_h: logical->physical row/col permutations, n_interior leading logical rows/cols form the

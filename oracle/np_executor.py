@@ -30,6 +30,23 @@ class _NpPack:
         A = self.mats[mid]
         y[...] = npp.matvec(A, x.reshape(A.ncols, self.nx, self.ny), self.nf, self.kx, self.ky)
 
+    def add_upper_bands(self, nz, offsets, bands):
+        from scipy import sparse
+        bands = np.asarray(bands, float).reshape(len(offsets), nz)
+        C = sparse.diags([bands[d, :nz - o] for d, o in enumerate(offsets)], list(offsets), shape=(nz, nz)).tocsr()
+        self.posts = getattr(self, "posts", [])
+        self.posts.append((nz, C))
+        return len(self.posts) - 1
+
+    def matvec_solve(self, mid, bid, x, y):
+        """solve_upper_sparse (tools/array.py:206-232) applied to every output component."""
+        from scipy.sparse.linalg import spsolve_triangular
+        self.matvec(mid, x, y)
+        nz, C = self.posts[bid]
+        yy = y.reshape(-1, nz, self.nx * self.ny)
+        for c in range(yy.shape[0]):
+            yy[c] = spsolve_triangular(C, yy[c].copy(), lower=False)
+
     def factor(self, matM, matL, a, b, row_perm, col_perm, n_interior, kl, ku, row_axes, col_axes, reuse=-1):
         lu = npp.PencilLU(self.mats[matM], self.mats[matL], a, b, self.nf, self.nx, self.ny, self.kx, self.ky,
                           np.asarray(row_axes), np.asarray(col_axes))
