@@ -6,7 +6,7 @@ RK222, fixed dt) -- BASELINE.json's metric.
 
 N=1 runs the largest configuration that fits one MI355X (the metric's 512x512x256 by default).
 For N>1 (launched by torch.distributed.run, one rank per GPU) the pencils are sharded across ranks
-(weak scaling is NOT used: the metric's problem size is fixed -> "strong").
+(the metric's problem size is fixed, so this is "strong" scaling: total work constant).
 
 Rank 0 prints ONE JSON line with the timing, the roofline of the dominant kernel (algorithmic bytes
 per launch / HIP-event time, measured inside the timed region) and a CPU baseline (the numpy/scipy
@@ -110,7 +110,12 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
     summ = timer.summary()
-    chk = float(np.sqrt(np.sum(np.asarray(fields["b"]["c"]) ** 2)))
+    chk2 = float(np.sum(np.asarray(fields["b"]["c"]) ** 2))
+    if world > 1:
+        t = torch.tensor([chk2], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t)
+        chk2 = float(t.item())
+    chk = float(np.sqrt(chk2))
 
     if rank == 0:
         steps_per_s = args.steps / el

@@ -19,7 +19,17 @@ class Distributor:
         self.coords = tuple(c for cs in self.coordsystems for c in cs.coords)
         self.dim = len(self.coords)
         self.dtype = np.dtype(np.float64 if dtype is None else dtype)
-        self.mesh = tuple(mesh) if mesh is not None else ()
+        self.mesh = tuple(int(m) for m in mesh) if mesh is not None else ()
+        self.size = int(np.prod(self.mesh)) if self.mesh else 1
+        self.rank = 0
+        if self.size > 1:
+            if len(self.mesh) != 1:
+                raise NotImplementedError("only 1-D process meshes are implemented in this round")
+            from ..parallel import Comm
+            self.pcomm = Comm(self.size)
+            self.rank = self.pcomm.rank
+        else:
+            self.pcomm = None
         self._jacobi_axes = set()
         self._layout_frozen = False
         self._executor = executor
@@ -69,6 +79,25 @@ class Distributor:
         """User axes of the separable (Fourier) directions, in storage order."""
         return tuple(ax for ax in self.storage_order if ax not in self._jacobi_axes)
 
+    # ---- sharding (1-D mesh): coefficient space along the first separable axis, grid space along the
+    #      Jacobi axis; everything else is local
+    @property
+    def shard_coeff_axis(self):
+        sep = self.separable_axes
+        return sep[0] if (self.size > 1 and sep) else None
+
+    @property
+    def shard_grid_axis(self):
+        jac = sorted(self._jacobi_axes)
+        return jac[0] if (self.size > 1 and jac) else None
+
+    def local_block(self, n):
+        """(start, stop) of this rank's block of an axis of length n."""
+        if n % self.size:
+            raise ValueError("axis of length %d is not divisible by the %d ranks" % (n, self.size))
+        blk = n // self.size
+        return self.rank * blk, (self.rank + 1) * blk
+
     def coupled_size(self, domain):
         for ax in self._jacobi_axes:
             b = domain.by_axis[ax]
@@ -100,7 +129,7 @@ class Distributor:
 
     def local_grid(self, basis, scale=None):
         scale = 1.0 if scale is None else scale
-        return self._reshape_axis(basis.global_grid(scale), self.coord_axis(basis.coord))
+        return self.local_grids(basis, scales=scale)[0]
 
     def local_grids(self, *bases, scales=None):
         out = []
@@ -112,7 +141,11 @@ class Distributor:
                 s = scales[ax]
             else:
                 s = scales
-            out.append(self._reshape_axis(b.global_grid(s), ax))
+            g = b.global_grid(s)
+            if ax == self.shard_grid_axis:
+                lo, hi = self.local_block(g.size)
+                g = g[lo:hi]
+            out.append(self._reshape_axis(g, ax))
         return tuple(out)
 
     def local_modes(self, basis):
@@ -145,22 +178,53 @@ class Transformer:
     def forward(self, field, g, scales, c):
         return self.forward_data(field.domain, field.ncomp, g, scales, c)
 
+    def _needs_exchange(self, domain):
+        d = self.dist
+        if d.size == 1:
+            return False
+        a, z = d.shard_coeff_axis, d.shard_grid_axis
+        has_x = a is not None and domain.by_axis[a] is not None
+        has_z = z is not None and domain.by_axis[z] is not None
+        if has_x and has_z:
+            return True
+        if has_x != has_z:
+            raise NotImplementedError("grid-space data of a field that lacks the x or z basis on several ranks")
+        return False
+
     def backward_data(self, domain, ncomp, c, g, scales):
+        """coefficient -> grid: z transform (local, kx-sharded), all-to-all (-> z-sharded, kx local),
+        then the Fourier transforms."""
         ex = self.dist.executor
         steps = self._steps(domain, scales)
         shape = [ncomp] + list(domain.storage_coeff_shape())
         if not steps:
             ex.copy(g, c)
             return
+        exchange = self._needs_exchange(domain)
         src = c
         for i, (pos, b, spec) in enumerate(steps):
-            n_out = b.grid_size(scales[self.dist.storage_order[pos]])
+            ax = self.dist.storage_order[pos]
+            n_out = b.grid_size(scales[ax])
             outer = int(np.prod(shape[:pos + 1]))
             inner = int(np.prod(shape[pos + 2:]))
             shape[pos + 1] = n_out
-            dst = g if i == len(steps) - 1 else ex.empty(tuple(shape))
+            last = (i == len(steps) - 1)
+            dst = g if (last and not (exchange and pos == 0)) else ex.empty(tuple(shape))
             ex.transform(spec, b, "backward", src, dst, outer, inner)
             src = dst
+            if exchange and pos == 0:
+                # [comp, Gz, nx_loc, ny] -> [comp, Gz/P, nx, ny]
+                P = self.dist.size
+                nc, Gz, nxl = shape[0], shape[1], shape[2]
+                rest = int(np.prod(shape[3:]))
+                send = ex.empty((int(nc * Gz * nxl * rest),))
+                ex.a2a_pack(src, send, nc, Gz, nxl, rest, P)
+                recv = ex.empty(send.shape)
+                self.dist.pcomm.all_to_all(recv, send)
+                shape[1], shape[2] = Gz // P, nxl * P
+                dst2 = g if last else ex.empty(tuple(shape))
+                ex.a2a_unpack(recv, dst2, nc, Gz // P, nxl * P, rest, P)
+                src = dst2
 
     def forward_data(self, domain, ncomp, g, scales, c):
         ex = self.dist.executor
@@ -169,11 +233,27 @@ class Transformer:
         if not steps:
             ex.copy(c, g)
             return
+        exchange = self._needs_exchange(domain)
         src = g
-        for i, (pos, b, spec) in enumerate(reversed(steps)):
+        rsteps = list(reversed(steps))
+        for i, (pos, b, spec) in enumerate(rsteps):
+            if exchange and pos == 0:
+                # [comp, Gz/P, nx, ny] -> [comp, Gz, nx_loc, ny]
+                P = self.dist.size
+                nc, Gzl, nx = shape[0], shape[1], shape[2]
+                rest = int(np.prod(shape[3:]))
+                n_el = nc * Gzl * nx * rest
+                send = ex.empty((n_el,))
+                ex.a2a_pack(src, send, nc * Gzl, nx, 1, rest, P)
+                recv = ex.empty((n_el,))
+                self.dist.pcomm.all_to_all(recv, send)
+                shape[1], shape[2] = Gzl * P, nx // P
+                tmp = ex.empty(tuple(shape))
+                ex.a2a_unpack(recv, tmp, nc, 1, Gzl * P, (nx // P) * rest, P)
+                src = tmp
             outer = int(np.prod(shape[:pos + 1]))
             inner = int(np.prod(shape[pos + 2:]))
             shape[pos + 1] = b.coeff_size
-            dst = c if i == len(steps) - 1 else ex.empty(tuple(shape))
+            dst = c if i == len(rsteps) - 1 else ex.empty(tuple(shape))
             ex.transform(spec, b, "forward", src, dst, outer, inner)
             src = dst

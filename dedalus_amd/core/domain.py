@@ -49,12 +49,44 @@ class Domain:
     def dealias(self):
         return tuple(1.0 if b is None else b.dealias for b in self.by_axis)
 
-    def coeff_shape(self):
-        """User-axis-order coefficient shape."""
+    def global_coeff_shape(self):
         return tuple(1 if b is None else b.coeff_size for b in self.by_axis)
 
-    def grid_shape(self, scales):
+    def global_grid_shape(self, scales):
         return tuple(1 if b is None else b.grid_size(s) for b, s in zip(self.by_axis, scales))
+
+    def coeff_shape(self):
+        """LOCAL user-axis-order coefficient shape (kx-sharded on several ranks)."""
+        shape = list(self.global_coeff_shape())
+        ax = self.dist.shard_coeff_axis
+        if ax is not None and self.by_axis[ax] is not None:
+            lo, hi = self.dist.local_block(shape[ax] // 2)      # blocks of whole (cos, msin) pairs
+            shape[ax] = 2 * (hi - lo)
+        return tuple(shape)
+
+    def grid_shape(self, scales):
+        """LOCAL grid shape (sharded along the Jacobi axis on several ranks)."""
+        shape = list(self.global_grid_shape(scales))
+        ax = self.dist.shard_grid_axis
+        if ax is not None and self.by_axis[ax] is not None:
+            lo, hi = self.dist.local_block(shape[ax])
+            shape[ax] = hi - lo
+        return tuple(shape)
+
+    def local_slices(self, layout, scales=None):
+        """Slices of the global array (user axis order) owned by this rank."""
+        sl = [slice(None)] * self.dist.dim
+        if layout == "c":
+            ax = self.dist.shard_coeff_axis
+            if ax is not None and self.by_axis[ax] is not None:
+                lo, hi = self.dist.local_block(self.by_axis[ax].coeff_size // 2)
+                sl[ax] = slice(2 * lo, 2 * hi)
+        else:
+            ax = self.dist.shard_grid_axis
+            if ax is not None and self.by_axis[ax] is not None:
+                lo, hi = self.dist.local_block(self.by_axis[ax].grid_size(scales[ax]))
+                sl[ax] = slice(lo, hi)
+        return tuple(sl)
 
     # ---- internal ("z-major") storage order -----------------------------------------------------
     def storage_coeff_shape(self):

@@ -49,7 +49,16 @@ def set_pencil_geom(dist, domain_like_bases):
     ny = sizes[1] if nf >= 2 else 1
     kx = ks[0] if nf >= 1 else np.zeros(1)
     ky = ks[1] if nf >= 2 else np.zeros(1)
+    mx_offset = 0
+    if dist.size > 1:
+        if nf < 1:
+            raise NotImplementedError("several ranks need a separable axis to shard")
+        lo, hi = dist.local_block(nx // 2)
+        kx = kx[lo:hi]
+        nx = 2 * (hi - lo)
+        mx_offset = lo
     dist._pencil_geom = (nf, nx, ny, kx, ky)
+    dist._mx_offset = mx_offset
     return dist._pencil_geom
 
 
@@ -84,7 +93,7 @@ class Evaluator:
         nf, nx, ny, kx, ky = self.geom()
         key = nrows_in
         if key not in self._packs:
-            self._packs[key] = self.ex.make_pack(nf, nrows_in, nx, ny, kx, ky)
+            self._packs[key] = self.ex.make_pack(nf, nrows_in, nx, ny, kx, ky, self.dist._mx_offset)
         return self._packs[key]
 
     # ---- leaves ------------------------------------------------------------------------------------------
@@ -117,7 +126,8 @@ class Evaluator:
         sx = sizes[0] if nf >= 1 else 1
         sy = sizes[1] if nf >= 2 else 1
         full = np.zeros((rows, nx, ny))
-        full[:, :sx, :sy] = host.reshape(rows, sx, sy)
+        if sx == nx or self.dist._mx_offset == 0:        # the kx = 0 pencil lives on the first rank
+            full[:, :sx, :sy] = host.reshape(rows, sx, sy)
         return self.ex.from_host(full)
 
     # ---- linear stage ----------------------------------------------------------------------------------

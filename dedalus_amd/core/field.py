@@ -330,7 +330,8 @@ class Field(Operand):
             self.change_scales(scales)
         layout = layout or self.layout
         layout = "c" if layout in ("c", "coeff") else "g"
-        shape = self._user_shape(layout, self.scales)
+        gsp = self.domain.global_coeff_shape() if layout == "c" else self.domain.global_grid_shape(self.scales)
+        shape = self.tshape + tuple(gsp)
         n = int(np.prod(shape))
         cs = min(n, chunk_size)
         rng = np.random.default_rng(seed)
@@ -342,7 +343,8 @@ class Field(Operand):
             m = min(cs, n - pos)
             out[pos:pos + m] = chunk[:m]
             pos += m
-        self[layout] = out.reshape(shape)
+        sl = (slice(None),) * len(self.tshape) + self.domain.local_slices(layout, self.scales)
+        self[layout] = out.reshape(shape)[sl]
 
     def allgather_data(self, layout=None):
         return self[layout or "g"].copy()

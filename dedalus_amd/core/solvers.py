@@ -82,7 +82,7 @@ class SolverBase:
         # ---- matrices as term lists (physical row / column numbering)
         self.M_tl = self._assemble("M")
         self.L_tl = self._assemble("L")
-        self.pack = self.ex.make_pack(nf, self.R, nx, ny, kx, ky)
+        self.pack = self.ex.make_pack(nf, self.R, nx, ny, kx, ky, dist._mx_offset)
         self.M_id = self.pack.add_matrix(self.M_tl)
         self.L_id = self.pack.add_matrix(self.L_tl)
         self._build_recombination()
@@ -278,7 +278,7 @@ class SolverBase:
         self.F_nl = None
         if nl_rows:
             self.NLbuf = self.ex.zeros((nl_rows, nx, ny))
-            self.nl_pack = self.ex.make_pack(nf, nl_rows, nx, ny, kx, ky)
+            self.nl_pack = self.ex.make_pack(nf, nl_rows, nx, ny, kx, ky, self.dist._mx_offset)
             self.F_nl = self.nl_pack.add_matrix(flatten(groups["nl"], self.R, nl_rows))
         self.F_x = None
         if groups["x"]:
@@ -286,7 +286,7 @@ class SolverBase:
         self.F_params = []
         for key, (leaf, blks) in groups["param"].items():
             rows = leaf.ncomp * self.dist.coupled_size(leaf.domain)
-            pk = self.ex.make_pack(nf, rows, nx, ny, kx, ky)
+            pk = self.ex.make_pack(nf, rows, nx, ny, kx, ky, self.dist._mx_offset)
             mid = pk.add_matrix(flatten([tuple(b[:2] + [0] + b[3:]) for b in blks], self.R, rows))
             self.F_params.append((leaf, pk, mid))
         # constants (e.g. "b(z=0) = Lz"): evaluated once
@@ -298,7 +298,7 @@ class SolverBase:
                 val = leaf._number
                 for t in range(tl.nterms):
                     # constants only reach the k=0 pencil, cos-cos part
-                    if tl.ex[t] == 0 and tl.ey[t] == 0:
+                    if tl.ex[t] == 0 and tl.ey[t] == 0 and self.dist._mx_offset == 0:
                         total[tl.row[t], 0, 0] += (tl.coef[t] * val).real
             self.F_const = self.ex.from_host(total)
 
@@ -352,6 +352,8 @@ class SolverBase:
         sep = self.dist.separable_axes
         sx = 1 if (self.nf < 1 or v.domain.by_axis[sep[0]] is None) else self.nx
         sy = 1 if (self.nf < 2 or v.domain.by_axis[sep[1]] is None) else self.ny
+        if sx == 1 and self.nf >= 1 and self.dist._mx_offset != 0:
+            return          # data without x dependence belongs to the kx = 0 pencils of the first rank
         xs = self.X[info["row0"]:info["row0"] + info["rows"]].reshape(info["rows"], self.nx, self.ny)[:, :sx, :sy]
         cs = c.reshape(info["rows"], sx, sy)
         if to_state:

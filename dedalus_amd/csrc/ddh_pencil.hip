@@ -39,6 +39,7 @@ struct PencilDev {
     long ncx, ncy;  // cells per axis
     long ncells;
     long G;         // systems = ncells * S
+    long mx_offset; // global x mode index of the first local cell (pencils sharded over ranks)
     const double *kx, *ky;
 };
 
@@ -162,7 +163,8 @@ __device__ __forceinline__ double ipow(double k, unsigned e) {
 }
 
 struct CellCtx {
-    long mx, my;
+    long mx, my;   // local cell indices (addressing)
+    long gmx;      // global x mode index (k = 0 tests)
     double kx, ky;
 };
 
@@ -175,6 +177,7 @@ __device__ __forceinline__ CellCtx cell_ctx(const PencilDev &P, long cell) {
         c.mx = cell;
         c.my = 0;
     }
+    c.gmx = c.mx + P.mx_offset;
     c.kx = (P.nf >= 1) ? P.kx[c.mx] : 0.0;
     c.ky = (P.nf == 2) ? P.ky[c.my] : 0.0;
     return c;
@@ -184,14 +187,14 @@ __device__ __forceinline__ CellCtx cell_ctx(const PencilDev &P, long cell) {
 __device__ __forceinline__ double term_factor(unsigned e, const CellCtx &c) {
     const unsigned ex = e & 0xffu, ey = (e >> 8) & 0xffu, dx = (e >> 16) & 0xffu, dy = (e >> 24) & 0xffu;
     double f = ipow(c.kx, ex) * ipow(c.ky, ey);
-    if (dx && c.mx != 0) f = 0.0;
+    if (dx && c.gmx != 0) f = 0.0;
     if (dy && c.my != 0) f = 0.0;
     return f;
 }
 
 // validity of a border row/col for a cell: bit0 set -> exists for mx>0, bit1 set -> exists for my>0
 __device__ __forceinline__ bool axes_valid(unsigned char bits, const CellCtx &c, int nf) {
-    if (nf >= 1 && c.mx != 0 && !(bits & 1)) return false;
+    if (nf >= 1 && c.gmx != 0 && !(bits & 1)) return false;
     if (nf == 2 && c.my != 0 && !(bits & 2)) return false;
     return true;
 }
@@ -215,6 +218,9 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
     } else {
         off0 = 0;
     }
+    double2 h0[4], h1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h0[j] = h1[j] = make_double2(0.0, 0.0);
     for (int rr = 0; rr < A.nrows_out; ++rr) {
         int r = rr, kz = 0, comp0 = 0;
         if (ps.nz > 0) {
@@ -257,27 +263,30 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
             v0 = accP;
         }
         if (ps.nz > 0) {
-            // the conversion is real and wavenumber-independent: it acts on each real part alike
+            // the conversion is real and wavenumber-independent: it acts on each real part alike.
+            // h0/h1[j] hold the finished outputs at kz+1+j (register window, reset per component).
+            if (kz == ps.nz - 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h0[j] = h1[j] = make_double2(0.0, 0.0);
+            }
             for (int d = 1; d < ps.nbands; ++d) {
-                const int kk = kz + ps.off[d];
-                if (kk < ps.nz) {
+                const int o = ps.off[d];
+                if (kz + o < ps.nz) {
                     const double bnd = ps.bands[d * ps.nz + kz];
-                    const double *yp = y + (long)(comp0 + kk) * plane;
-                    if (NF == 2) {
-                        const double2 p0 = *reinterpret_cast<const double2 *>(yp + off0);
-                        const double2 p1 = *reinterpret_cast<const double2 *>(yp + off1);
-                        v0.x -= bnd * p0.x; v0.y -= bnd * p0.y;
-                        v1.x -= bnd * p1.x; v1.y -= bnd * p1.y;
-                    } else if (NF == 1) {
-                        const double2 p0 = *reinterpret_cast<const double2 *>(yp + off0);
-                        v0.x -= bnd * p0.x; v0.y -= bnd * p0.y;
-                    } else {
-                        v0.x -= bnd * yp[0];
-                    }
+                    double2 p0 = make_double2(0.0, 0.0), p1 = p0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (o - 1 == j) { p0 = h0[j]; p1 = h1[j]; }
+                    v0.x -= bnd * p0.x; v0.y -= bnd * p0.y;
+                    v1.x -= bnd * p1.x; v1.y -= bnd * p1.y;
                 }
             }
             const double inv = 1.0 / ps.bands[kz];
             v0.x *= inv; v0.y *= inv; v1.x *= inv; v1.y *= inv;
+#pragma unroll
+            for (int j = 3; j > 0; --j) { h0[j] = h0[j - 1]; h1[j] = h1[j - 1]; }
+            h0[0] = v0;
+            h1[0] = v1;
         }
         if (NF == 2) {
             *reinterpret_cast<double2 *>(yr + off0) = v0;
@@ -763,6 +772,7 @@ int ddh_pencil_create(ddh_handle *pack, const ddh_pencil_geom *geom) {
     }
     d.ncells = d.ncx * d.ncy;
     d.G = d.ncells * d.S;
+    d.mx_offset = geom->mx_offset;
     int st = 0;
     if (d.nf >= 1) st = upload_vec(&pp->d_kx, geom->kx_h, (size_t)d.ncx);
     if (!st && d.nf == 2) st = upload_vec(&pp->d_ky, geom->ky_h, (size_t)d.ncy);
@@ -852,6 +862,8 @@ int ddh_pencil_add_upper_bands(ddh_handle pack, int nz, int nbands, const int *o
     PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
     if (!pp) return -1;
     if (nz < 1 || nbands < 1 || nbands > 4 || offsets_h[0] != 0) return fail("pencil_add_upper_bands: bad band description");
+    for (int d = 1; d < nbands; ++d)
+        if (offsets_h[d] < 1 || offsets_h[d] > 4) return fail("pencil_add_upper_bands: band offsets must be 1..4");
     PostSolve ps;
     memset(&ps, 0, sizeof(ps));
     ps.nz = nz;

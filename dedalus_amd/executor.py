@@ -119,8 +119,14 @@ class HipExecutor:
         else:
             libhip.call("ddh_%s_%s" % (kind, direction), h, ptr(src), ptr(dst), outer, inner, self.dev.stream)
 
-    def make_pack(self, nf, nrows, nx, ny, kx, ky):
-        pk = PencilPack(self.dev, nf, nrows, nx, ny, kx, ky)
+    def a2a_pack(self, src, dst, outer, na, nb, inner, P):
+        libhip.call("ddh_a2a_pack", ptr(src), ptr(dst), outer, na, nb, inner, P, self.dev.stream)
+
+    def a2a_unpack(self, src, dst, outer, na, nb, inner, P):
+        libhip.call("ddh_a2a_unpack", ptr(src), ptr(dst), outer, na, nb, inner, P, self.dev.stream)
+
+    def make_pack(self, nf, nrows, nx, ny, kx, ky, mx_offset=0):
+        pk = PencilPack(self.dev, nf, nrows, nx, ny, kx, ky, mx_offset)
         pk.executor = self
         return pk
 

@@ -22,7 +22,7 @@ class DdhError(RuntimeError):
 
 class PencilGeom(C.Structure):
     _fields_ = [("nfourier", C.c_int), ("nrows", C.c_int), ("nx", C.c_long), ("ny", C.c_long),
-                ("kx_h", C.POINTER(C.c_double)), ("ky_h", C.POINTER(C.c_double))]
+                ("kx_h", C.POINTER(C.c_double)), ("ky_h", C.POINTER(C.c_double)), ("mx_offset", C.c_long)]
 
 
 class PolyMat(C.Structure):

@@ -1,0 +1,62 @@
+"""
+One process per GPU; pencils sharded over the ranks of a 1-D mesh.
+
+Coefficient space is block-distributed along the first separable (Fourier) axis, exactly like the
+reference's Layout.local_chunks (core/distributor.py:357-385), so every pencil is wholly owned by
+one rank and all pencil linear algebra is communication-free.  The only exchange on the hot path is
+the all-to-all between "kx-sharded, z local" and "z-sharded, kx local", which replaces the MPI
+pencil transposes (core/transposes.pyx:22-445, core/distributor.py:770-924).  It is issued through
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests) on buffers
+packed / unpacked by ddh_a2a_pack / ddh_a2a_unpack.
+
+The exchange is placed right after the z transform, i.e. BEFORE the 3/2 padding of x and y: the
+reference transposes padded data (core/distributor.py:58-75 order); moving it earlier sends 4/9 of
+the bytes and changes no result.
+"""
+
+import os
+
+import numpy as np
+
+
+class Comm:
+    def __init__(self, size):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        if not dist.is_initialized():
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend)
+        self.size = dist.get_world_size()
+        self.rank = dist.get_rank()
+        if self.size != size:
+            raise ValueError("mesh size %d does not match the number of ranks %d" % (size, self.size))
+
+    def all_to_all(self, recv, send):
+        """Equal-split all-to-all on flat buffers (torch tensors, or numpy arrays for the CPU oracle)."""
+        t = self.torch
+        if isinstance(send, np.ndarray):
+            s = t.from_numpy(np.ascontiguousarray(send).reshape(-1))
+            r = t.empty_like(s)
+            self.dist.all_to_all_single(r, s)
+            recv[...] = r.numpy().reshape(recv.shape)
+        else:
+            self.dist.all_to_all_single(recv.reshape(-1), send.reshape(-1))
+
+    def allreduce_sum(self, value):
+        t = self.torch
+        dev = "cuda" if (t.cuda.is_available() and self.dist.get_backend() == "nccl") else "cpu"
+        x = t.tensor([float(value)], dtype=t.float64, device=dev)
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM)
+        return float(x.item())
+
+    def allreduce_max(self, value):
+        t = self.torch
+        dev = "cuda" if (t.cuda.is_available() and self.dist.get_backend() == "nccl") else "cpu"
+        x = t.tensor([float(value)], dtype=t.float64, device=dev)
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX)
+        return float(x.item())
+
+    def barrier(self):
+        self.dist.barrier()

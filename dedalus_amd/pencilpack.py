@@ -63,12 +63,14 @@ class TermList:
 
 
 class PencilPack:
-    def __init__(self, dev, nfourier, nrows, nx, ny, kx, ky):
+    def __init__(self, dev, nfourier, nrows, nx, ny, kx, ky, mx_offset=0):
         self.dev = dev
+        self.mx_offset = int(mx_offset)
         self.nf, self.nrows, self.nx, self.ny = int(nfourier), int(nrows), int(nx), int(ny)
         self.kx = np.ascontiguousarray(kx, dtype=np.float64)
         self.ky = np.ascontiguousarray(ky, dtype=np.float64)
-        geom = libhip.PencilGeom(self.nf, self.nrows, self.nx, self.ny, libhip.as_dp(self.kx), libhip.as_dp(self.ky))
+        geom = libhip.PencilGeom(self.nf, self.nrows, self.nx, self.ny, libhip.as_dp(self.kx), libhip.as_dp(self.ky),
+                                 self.mx_offset)
         self.handle = C.c_uint64(0)
         libhip.call("ddh_pencil_create", C.byref(self.handle), C.byref(geom))
         self.S = 2 if self.nf == 2 else 1
@@ -152,11 +154,12 @@ class PencilPack:
                 kyv = self.ky[my] if self.nf == 2 else 0.0
                 for s in range(self.S):
                     sign = 1 if s == 0 else -1
-                    A = a * M.dense(kxv, kyv, mx, my, sign) + b * L.dense(kxv, kyv, mx, my, sign)
+                    gmx = mx + self.mx_offset
+                    A = a * M.dense(kxv, kyv, gmx, my, sign) + b * L.dense(kxv, kyv, gmx, my, sign)
                     A = A[np.ix_(row_perm, col_perm)]
                     # identity pairing of rows/columns that do not exist for this pencil
-                    bad_r = [i for i in range(N) if not _valid(ra[i], mx, my, self.nf)]
-                    bad_c = [i for i in range(N) if not _valid(ca[i], mx, my, self.nf)]
+                    bad_r = [i for i in range(N) if not _valid(ra[i], gmx, my, self.nf)]
+                    bad_c = [i for i in range(N) if not _valid(ca[i], gmx, my, self.nf)]
                     for i, j in zip(bad_r, bad_c):
                         A[i, j] = 1.0
                     inv[f * self.S + s] = np.linalg.inv(A)

@@ -101,6 +101,9 @@ typedef struct {
     long nx, ny;           /* real storage extents of the two cell axes (ny = 1 ... if unused)     */
     const double *kx_h;    /* physical wavenumber per x mode index (nx/2 entries), host            */
     const double *ky_h;    /* physical wavenumber per y mode index (ny/2 entries), host            */
+    long mx_offset;        /* global x mode index of the first local pencil (0 on one GPU): pencils
+                              are sharded over ranks along x like Layout.local_chunks,
+                              core/distributor.py:357-385                                          */
 } ddh_pencil_geom;
 
 typedef struct {

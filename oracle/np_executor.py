@@ -15,7 +15,8 @@ from . import np_transforms as npt
 
 
 class _NpPack:
-    def __init__(self, nf, nrows, nx, ny, kx, ky):
+    def __init__(self, nf, nrows, nx, ny, kx, ky, mx_offset=0):
+        self.mx_offset = mx_offset
         self.nf, self.nrows, self.nx, self.ny = nf, nrows, nx, ny
         self.kx, self.ky = np.asarray(kx, float), np.asarray(ky, float)
         self.mats = []
@@ -28,7 +29,7 @@ class _NpPack:
 
     def matvec(self, mid, x, y):
         A = self.mats[mid]
-        y[...] = npp.matvec(A, x.reshape(A.ncols, self.nx, self.ny), self.nf, self.kx, self.ky)
+        y[...] = npp.matvec(A, x.reshape(A.ncols, self.nx, self.ny), self.nf, self.kx, self.ky, self.mx_offset)
 
     def add_upper_bands(self, nz, offsets, bands):
         from scipy import sparse
@@ -49,7 +50,7 @@ class _NpPack:
 
     def factor(self, matM, matL, a, b, row_perm, col_perm, n_interior, kl, ku, row_axes, col_axes, reuse=-1):
         lu = npp.PencilLU(self.mats[matM], self.mats[matL], a, b, self.nf, self.nx, self.ny, self.kx, self.ky,
-                          np.asarray(row_axes), np.asarray(col_axes))
+                          np.asarray(row_axes), np.asarray(col_axes), self.mx_offset)
         if reuse >= 0:
             self.lus[reuse] = lu
             return reuse
@@ -126,5 +127,14 @@ class NumpyExecutor:
             raise NotImplementedError(kind)
         dst[...] = res.reshape(dst.shape)
 
-    def make_pack(self, nf, nrows, nx, ny, kx, ky):
-        return _NpPack(nf, nrows, nx, ny, kx, ky)
+    def a2a_pack(self, src, dst, outer, na, nb, inner, P):
+        """split_rows / split_columns of AlltoallvTranspose (core/transposes.pyx:359-445) restated"""
+        s = src.reshape(outer, P, na // P, nb * inner)
+        dst[...] = np.ascontiguousarray(np.transpose(s, (1, 0, 2, 3))).reshape(dst.shape)
+
+    def a2a_unpack(self, src, dst, outer, na, nb, inner, P):
+        s = src.reshape(P, outer, na, nb // P, inner)
+        dst[...] = np.ascontiguousarray(np.transpose(s, (1, 2, 0, 3, 4))).reshape(dst.shape)
+
+    def make_pack(self, nf, nrows, nx, ny, kx, ky, mx_offset=0):
+        return _NpPack(nf, nrows, nx, ny, kx, ky, mx_offset)

@@ -68,7 +68,7 @@ def _cells(nf, nx, ny):
             yield mx, my
 
 
-def matvec(A, x, nf, kx, ky):
+def matvec(A, x, nf, kx, ky, mx_offset=0):
     """y = A x for every pencil, x real [ncols][nx][ny] -> y real [nrows][nx][ny]"""
     x = x.reshape(x.shape[0], x.shape[1], -1)
     nx, ny = x.shape[1], x.shape[2]
@@ -77,7 +77,7 @@ def matvec(A, x, nf, kx, ky):
         xs = cell_to_systems(x, nf, mx, my)
         kxv = kx[mx] if nf >= 1 else 0.0
         kyv = ky[my] if nf == 2 else 0.0
-        ys = [A.matrix(kxv, kyv, mx, my, sign=(1 if s == 0 else -1)) @ xs[s] for s in range(len(xs))]
+        ys = [A.matrix(kxv, kyv, mx + mx_offset, my, sign=(1 if s == 0 else -1)) @ xs[s] for s in range(len(xs))]
         systems_to_cell(y, ys, nf, mx, my)
     return y
 
@@ -100,7 +100,7 @@ def border_identity(nrows, row_axes, col_axes, mx, my, nf):
 class PencilLU:
     """One SuperLU factorization per system, like the reference's LHS_solvers per subproblem."""
 
-    def __init__(self, M, L, a, b, nf, nx, ny, kx, ky, row_axes=None, col_axes=None):
+    def __init__(self, M, L, a, b, nf, nx, ny, kx, ky, row_axes=None, col_axes=None, mx_offset=0):
         self.nf, self.nx, self.ny = nf, nx, ny
         self.lus = {}
         N = M.nrows
@@ -110,10 +110,11 @@ class PencilLU:
         for mx, my in _cells(nf, nx, ny):
             kxv = kx[mx] if nf >= 1 else 0.0
             kyv = ky[my] if nf == 2 else 0.0
-            ident = border_identity(N, row_axes, col_axes, mx, my, nf)
+            g = mx + mx_offset
+            ident = border_identity(N, row_axes, col_axes, g, my, nf)
             for s in range(2 if nf == 2 else 1):
                 sign = 1 if s == 0 else -1
-                A = (a * M.matrix(kxv, kyv, mx, my, sign) + b * L.matrix(kxv, kyv, mx, my, sign) + ident).tocsc()
+                A = (a * M.matrix(kxv, kyv, g, my, sign) + b * L.matrix(kxv, kyv, g, my, sign) + ident).tocsc()
                 self.lus[(mx, my, s)] = spla.splu(A)
 
     def solve(self, rhs):
