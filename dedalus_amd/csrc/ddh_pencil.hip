@@ -204,7 +204,7 @@ __device__ __forceinline__ bool axes_valid(unsigned char bits, const CellCtx &c,
 // ------------------------------------------------------------------------------------------------
 template <int NF>
 __global__ void __launch_bounds__(256)
-matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, PostSolve ps) {
+matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, PostSolve ps, int rows_per_chunk) {
     const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= P.ncells) return;
     const CellCtx c = cell_ctx(P, cell);
@@ -221,7 +221,11 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
     double2 h0[4], h1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) h0[j] = h1[j] = make_double2(0.0, 0.0);
-    for (int rr = 0; rr < A.nrows_out; ++rr) {
+    // blockIdx.y splits the rows into independent chunks (one component per chunk with a post-solve):
+    // a single sweep over all rows per thread would leave one wave per SIMD, i.e. latency bound
+    const int rr0 = blockIdx.y * rows_per_chunk;
+    const int rr1 = (rr0 + rows_per_chunk < A.nrows_out) ? rr0 + rows_per_chunk : A.nrows_out;
+    for (int rr = rr0; rr < rr1; ++rr) {
         int r = rr, kz = 0, comp0 = 0;
         if (ps.nz > 0) {
             // descending coupled index inside each component so that y[kz + off] is already final
@@ -838,13 +842,23 @@ static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y,
     const MatDev &A = pp->mats[mat_id]->dev;
     if (ps.nz > 0 && A.nrows_out % ps.nz) return fail("pencil_matvec_solve: rows are not a multiple of nz");
     const unsigned blocks = (unsigned)((P.ncells + 255) / 256);
+    int rpc;
+    if (ps.nz > 0) {
+        rpc = ps.nz;
+    } else {
+        rpc = (A.nrows_out + 31) / 32;
+        if (rpc < 8) rpc = 8;
+    }
+    const unsigned chunks = (unsigned)((A.nrows_out + rpc - 1) / rpc);
+    if (chunks > 65535) return fail("pencil_matvec: too many row chunks");
     hipStream_t s = as_stream(stream);
+    const dim3 grid(blocks, chunks ? chunks : 1);
     if (P.nf == 2)
-        hipLaunchKernelGGL(matvec_kernel<2>, dim3(blocks), dim3(256), 0, s, P, A, x, y, ps);
+        hipLaunchKernelGGL(matvec_kernel<2>, grid, dim3(256), 0, s, P, A, x, y, ps, rpc);
     else if (P.nf == 1)
-        hipLaunchKernelGGL(matvec_kernel<1>, dim3(blocks), dim3(256), 0, s, P, A, x, y, ps);
+        hipLaunchKernelGGL(matvec_kernel<1>, grid, dim3(256), 0, s, P, A, x, y, ps, rpc);
     else
-        hipLaunchKernelGGL(matvec_kernel<0>, dim3(blocks), dim3(256), 0, s, P, A, x, y, ps);
+        hipLaunchKernelGGL(matvec_kernel<0>, grid, dim3(256), 0, s, P, A, x, y, ps, rpc);
     DDH_HIP(hipGetLastError());
     return 0;
 }
