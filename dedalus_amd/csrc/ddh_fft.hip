@@ -7,7 +7,7 @@
 // contiguous one (inner == 1) the two lines are neighbours along the outer axis.
 //
 // The FFT itself is a mixed-radix (2,3,4,5,7) Stockham autosort in LDS, in place with register
-// staging (each thread holds <= 16 complex values per pass), twiddles from an exact table.
+// staging (each thread holds <= 12 complex values per pass), twiddles from an exact table.
 // All of the reference's separate pack / scale / pad / truncate NumPy passes
 // (core/transforms.py:469-509, 726-746, 844-890) are fused into the load and store phases, so each
 // transform is exactly one HBM read of its input and one HBM write of its output.
@@ -164,12 +164,11 @@ template <int R>
 __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int Ns, const FastDiv &fd_nb,
                                          const FastDiv &fd_ns, const double2 *__restrict__ tw, int sign, int tid,
                                          int T) {
-    constexpr int MAXI = 16 / R;
+    constexpr int MAXI = (12 / R) > 0 ? (12 / R) : 1;   // <= 12 complex values staged per thread
     const int nb = N / R;
     const int total = nb * B;
     const int twstep = nb / Ns;  // N / (Ns*R)
     double2 v[MAXI][R];
-    int jsave[MAXI], ksave[MAXI], lsave[MAXI];
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
         const int w = tid + it * T;
@@ -190,9 +189,6 @@ __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int
                 }
             }
             butterfly<R>(v[it], sign);
-            jsave[it] = j;
-            ksave[it] = k;
-            lsave[it] = line;
         }
     }
     __syncthreads();
@@ -200,8 +196,11 @@ __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int
     for (int it = 0; it < MAXI; ++it) {
         const int w = tid + it * T;
         if (w < total) {
-            double2 *x = buf + lsave[it] * ld;
-            const int j0 = (jsave[it] - ksave[it]) * R + ksave[it];
+            unsigned uline, uj, uq, uk;
+            fd_nb.divmod((unsigned)w, uline, uj);
+            fd_ns.divmod(uj, uq, uk);
+            double2 *x = buf + (int)uline * ld;
+            const int j0 = ((int)uj - (int)uk) * R + (int)uk;
 #pragma unroll
             for (int u = 0; u < R; ++u) x[j0 + u * Ns] = v[it][u];
         }
@@ -283,8 +282,8 @@ __device__ __forceinline__ void split_item(int w, const FastDiv &fdB, const Fast
 
 __device__ __forceinline__ int dct_perm(int j, int N) { return (j & 1) ? (N - 1 - (j >> 1)) : (j >> 1); }
 
-template <int MODE, bool INNER>
-__global__ void __launch_bounds__(1024)
+template <int MODE, bool INNER, int TMAX>
+__global__ void __launch_bounds__(TMAX)
 fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ dst, long outer, long inner,
                 long npairs, unsigned blocks_per_outer) {
     extern __shared__ double2 lds[];
@@ -709,7 +708,7 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     else
         npairs = inner_mode ? (inner + 1) / 2 : (outer + 1) / 2;
     // lines per workgroup: 64 B of contiguous data per row when strided; bounded by LDS (<= 64 KiB
-    // so that at least two workgroups share a CU) and by 16 staged values per thread.
+    // so that at least two workgroups share a CU) and by 12 staged values per thread.
     const int N = d.N, M = d.M;
     const bool cheb = (MODE == CHEB_FWD || MODE == CHEB_BWD);
     const size_t per_line = (size_t)(N + (cheb ? M : 0)) * sizeof(double2);
@@ -718,8 +717,8 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     if ((long)B > npairs) B = (int)npairs;
     if (per_line * B > 160 * 1024) return fail("transform: axis too long for the LDS kernel");
     int T = 256;
-    while ((long)N * B > 16L * T && T < 1024) T *= 2;
-    if ((long)N * B > 16L * T) return fail("transform: axis too long for the LDS kernel (registers)");
+    while ((long)N * B > 12L * T && T < 1024) T *= 2;
+    if ((long)N * B > 12L * T) return fail("transform: axis too long for the LDS kernel (registers)");
     d.B = B;
     d.fdB.set((unsigned)B);
     const unsigned bpo = (unsigned)((npairs + B - 1) / B);
@@ -727,17 +726,22 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     if (nblocks > 0x7fffffffUL) return fail("transform: grid too large");
     const size_t lds = per_line * B;
     hipStream_t s = as_stream(stream);
-    if (inner_mode) {
-        auto kern = fft_axis_kernel<MODE, true>;
-        if (lds > 64 * 1024)
-            DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(T), lds, s, d, src, dst, outer, inner, npairs, bpo);
-    } else {
-        auto kern = fft_axis_kernel<MODE, false>;
-        if (lds > 64 * 1024)
-            DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(T), lds, s, d, src, dst, outer, inner, npairs, bpo);
+#define DDH_FFT_LAUNCH(INNERV, TMAXV)                                                                       \
+    {                                                                                                       \
+        auto kern = fft_axis_kernel<MODE, INNERV, TMAXV>;                                                   \
+        if (lds > 64 * 1024)                                                                                \
+            DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                        (int)lds));                                                         \
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(T), lds, s, d, src, dst, outer, inner,       \
+                           npairs, bpo);                                                                    \
     }
+    // register budget follows the real block size (a 1024-thread bound would cap at 64 VGPRs and spill)
+    if (inner_mode) {
+        if (T <= 256) DDH_FFT_LAUNCH(true, 256) else DDH_FFT_LAUNCH(true, 1024)
+    } else {
+        if (T <= 256) DDH_FFT_LAUNCH(false, 256) else DDH_FFT_LAUNCH(false, 1024)
+    }
+#undef DDH_FFT_LAUNCH
     DDH_HIP(hipGetLastError());
     return 0;
 }
