@@ -234,6 +234,54 @@ class SolverBase:
                 ku = max(ku, int((c[m] - i[m]).max()))
         nb = self.R - self.n_interior
         self.kl, self.ku = kl, max(ku, nb)
+        self._build_grading()
+
+    def _build_grading(self):
+        """Z2 gradings that make the pencil matrices real and shared by the +kx / -kx systems.
+
+        For real differential operators every entry of the complex symbol carries the phase i^(order of
+        differentiation); if rows and columns can be two-coloured so that phase(entry) = rot[row] +
+        rot[col] (mod 2), then lambda = D_r A D_c^-1 with A real, D = diag(i^rot).  Likewise if
+        parity(kx exponent) = sgn[row] + sgn[col], then lambda(-kx) = S_r lambda(kx) S_c.  Both are found by
+        a breadth-first two-colouring of the bipartite row/column graph of (a M + b L) P; if either fails
+        (e.g. dispersive KdV: real and imaginary terms in one entry) the general complex path is used."""
+        from ..pencilpack import TermList
+        self.real_grading = None
+        if self.nf == 0 or self.n_interior == 0:
+            return
+        tls = [t for t in (self.MP_tl, self.LP_tl) if t.nterms]
+        if not tls:
+            return
+        row = np.concatenate([t.row for t in tls])
+        col = np.concatenate([t.col for t in tls])
+        coef = np.concatenate([t.coef for t in tls])
+        ex = np.concatenate([t.ex for t in tls])
+        mag = np.abs(coef)
+        is_re = np.abs(coef.imag) <= 1e-13 * mag
+        is_im = np.abs(coef.real) <= 1e-13 * mag
+        if not np.all(is_re | is_im):
+            return
+        rot = _two_colour(self.R, row, col, np.where(is_re, 0, 1))
+        if rot is None:
+            return
+        if self.nf == 2:
+            sgn = _two_colour(self.R, row, col, (ex % 2).astype(int))
+            if sgn is None:
+                return
+        else:
+            sgn = (np.zeros(self.R, dtype=int), np.zeros(self.R, dtype=int))
+        rr, rc = rot
+        sr, sc = sgn
+
+        def graded(tl):
+            c = tl.coef * (1j) ** ((rc[tl.col] - rr[tl.row]) % 4)
+            assert np.all(np.abs(c.imag) <= 1e-12 * np.maximum(np.abs(c), 1e-300)), "grading did not make the matrix real"
+            return TermList(tl.nrows, tl.ncols, tl.row, tl.col, c.real.astype(complex), tl.ex, tl.ey, tl.dx, tl.dy)
+
+        self.real_grading = dict(matM=self.pack.add_matrix(graded(self.MP_tl)),
+                                 matL=self.pack.add_matrix(graded(self.LP_tl)),
+                                 row_code=(rr | (sr << 1)).astype(np.uint8),
+                                 col_code=(rc | (sc << 1)).astype(np.uint8))
 
     # ---- RHS plan --------------------------------------------------------------------------------------------
     def _build_F_plan(self):
@@ -383,7 +431,53 @@ class SolverBase:
 
     def factor(self, a, b, reuse=-1):
         return self.pack.factor(self.MP_id, self.LP_id, a, b, self.row_perm, self.col_perm, self.n_interior,
-                                self.kl, self.ku, self.row_axes, self.col_axes, reuse=reuse)
+                                self.kl, self.ku, self.row_axes, self.col_axes, reuse=reuse,
+                                real=self.real_grading)
+
+
+def _two_colour(n, row, col, label):
+    """x_r[row] + x_c[col] = label (mod 2) for every entry; returns (x_r, x_c) or None if inconsistent."""
+    from collections import deque
+    adj_r = [[] for _ in range(n)]
+    adj_c = [[] for _ in range(n)]
+    seen = {}
+    for r, c, l in zip(row.tolist(), col.tolist(), np.asarray(label).tolist()):
+        key = (r, c)
+        if key in seen:
+            if seen[key] != l:
+                return None
+            continue
+        seen[key] = l
+        adj_r[r].append((c, l))
+        adj_c[c].append((r, l))
+    xr = np.full(n, -1, dtype=int)
+    xc = np.full(n, -1, dtype=int)
+    for start in range(n):
+        if xr[start] != -1 or not adj_r[start]:
+            continue
+        xr[start] = 0
+        dq = deque([("r", start)])
+        while dq:
+            kind, i = dq.popleft()
+            if kind == "r":
+                for c, l in adj_r[i]:
+                    want = (l - xr[i]) % 2
+                    if xc[c] == -1:
+                        xc[c] = want
+                        dq.append(("c", c))
+                    elif xc[c] != want:
+                        return None
+            else:
+                for r, l in adj_c[i]:
+                    want = (l - xc[i]) % 2
+                    if xr[r] == -1:
+                        xr[r] = want
+                        dq.append(("r", r))
+                    elif xr[r] != want:
+                        return None
+    xr[xr == -1] = 0
+    xc[xc == -1] = 0
+    return xr, xc
 
 
 def _termlist_times_matrix(tl, P, cutoff=1e-12):

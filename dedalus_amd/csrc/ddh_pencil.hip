@@ -71,19 +71,23 @@ struct Matrix {
 
 struct LuDev {
     int n, nb, N, kl, ku, W, BW;   // BW = kl + W + 1, W = ku + kl
-    double2 *Aw;                   // [n][BW][G]   band rows, LAPACK-style fill space
-    double2 *Ab;                   // [N][nb][G]   border rows (multipliers | Schur block inverse)
-    unsigned char *piv;            // [n][G]
-    unsigned char *flag;           // [G]
-    double2 *scratch;              // [n][G]
+    int real;                      // 1: real graded matrix shared by the systems of a cell (see factor_real)
+    long GL;                       // number of stored factorizations: G (complex) or ncells (real)
+    void *Aw;                      // [n][BW][GL]  band rows, LAPACK-style fill space (double2 or double)
+    void *Ab;                      // [N][nb][GL]  border rows (multipliers | Schur block inverse)
+    unsigned char *piv;            // [n][GL]
+    unsigned char *flag;           // [GL]
+    double2 *scratch;              // [max(n, nb*nb)][G]
     const int *rowperm, *colperm;  // logical -> physical
     const unsigned char *row_axes, *col_axes;   // per logical border row / col: validity bits
+    const unsigned char *row_code, *col_code;   // real mode, per logical row / col: bit0 rotate by i, bit1 sign for -kx
 };
 
 struct LuFactor {
     LuDev dev;
     size_t bytes = 0;
     void *d_rowperm = nullptr, *d_colperm = nullptr, *d_raxes = nullptr, *d_caxes = nullptr;
+    void *d_rcode = nullptr, *d_ccode = nullptr;
     // dense fallback
     int nflag = 0;
     std::vector<long> flag_cells;   // flagged cell ids
@@ -113,6 +117,8 @@ static void free_lu(LuFactor *lu) {
     (void)hipFree(lu->d_colperm);
     (void)hipFree(lu->d_raxes);
     (void)hipFree(lu->d_caxes);
+    (void)hipFree(lu->d_rcode);
+    (void)hipFree(lu->d_ccode);
     (void)hipFree(lu->d_flag_cells);
     (void)hipFree(lu->d_inv);
     (void)hipFree(lu->d_dense_rhs);
@@ -161,6 +167,38 @@ __device__ __forceinline__ double ipow(double k, unsigned e) {
     if (e & 4u) r *= b;
     return r;
 }
+
+// element type of a stored factorization: complex (general) or real (graded, see ddh_pencil_factor_real)
+template <bool REAL> struct El;
+template <> struct El<false> {
+    typedef double2 T;
+    static __device__ __forceinline__ T zero() { return make_double2(0.0, 0.0); }
+    static __device__ __forceinline__ T one() { return make_double2(1.0, 0.0); }
+    static __device__ __forceinline__ T mul(T a, T b) { return cmul(a, b); }
+    static __device__ __forceinline__ T inv(T a) { return cinv(a); }
+    static __device__ __forceinline__ double abs2(T a) { return cabs2(a); }
+    static __device__ __forceinline__ bool is_zero(T a) { return a.x == 0.0 && a.y == 0.0; }
+    static __device__ __forceinline__ void fms(T &acc, T m, T v) { cfms(acc, m, v); }
+    static __device__ __forceinline__ void add(T &acc, double2 v) { acc.x += v.x; acc.y += v.y; }
+    // complex right-hand sides
+    static __device__ __forceinline__ void fms2(double2 &acc, T m, double2 v) { cfms(acc, m, v); }
+    static __device__ __forceinline__ void fma2(double2 &acc, T m, double2 v) { cfma(acc, m, v); }
+    static __device__ __forceinline__ double2 mul2(double2 a, T m) { return cmul(a, m); }
+};
+template <> struct El<true> {
+    typedef double T;
+    static __device__ __forceinline__ T zero() { return 0.0; }
+    static __device__ __forceinline__ T one() { return 1.0; }
+    static __device__ __forceinline__ T mul(T a, T b) { return a * b; }
+    static __device__ __forceinline__ T inv(T a) { return 1.0 / a; }
+    static __device__ __forceinline__ double abs2(T a) { return a * a; }
+    static __device__ __forceinline__ bool is_zero(T a) { return a == 0.0; }
+    static __device__ __forceinline__ void fms(T &acc, T m, T v) { acc -= m * v; }
+    static __device__ __forceinline__ void add(T &acc, double2 v) { acc += v.x; }
+    static __device__ __forceinline__ void fms2(double2 &acc, T m, double2 v) { acc.x -= m * v.x; acc.y -= m * v.y; }
+    static __device__ __forceinline__ void fma2(double2 &acc, T m, double2 v) { acc.x += m * v.x; acc.y += m * v.y; }
+    static __device__ __forceinline__ double2 mul2(double2 a, T m) { return make_double2(a.x * m, a.y * m); }
+};
 
 struct CellCtx {
     long mx, my;   // local cell indices (addressing)
@@ -347,9 +385,13 @@ __device__ __forceinline__ void store_sys(double *__restrict__ v, long plane, in
 // ------------------------------------------------------------------------------------------------
 // assemble a*M + b*L into band + border storage and factor it, one thread per system
 // ------------------------------------------------------------------------------------------------
+template <bool REAL>
 __device__ __forceinline__ void scatter_terms(const PencilDev &P, const LuDev &L, const MatDev &A, double scale,
                                               const int *__restrict__ rowinv, const int *__restrict__ colinv,
                                               const CellCtx &c, int s, long g, double &anorm, bool &bad) {
+    typedef typename El<REAL>::T E;
+    E *Aw = (E *)L.Aw, *Ab = (E *)L.Ab;
+    const long GL = L.GL;
     if (scale == 0.0) return;
     for (int r = 0; r < A.nrows_out; ++r) {
         const int i = rowinv[r];
@@ -371,36 +413,37 @@ __device__ __forceinline__ void scatter_terms(const PencilDev &P, const LuDev &L
                     bad = true;
                     continue;
                 }
-                double2 *p = L.Aw + ((long)i * L.BW + d) * P.G + g;
-                double2 o = *p;
-                o.x += v.x;
-                o.y += v.y;
+                E *p = Aw + ((long)i * L.BW + d) * GL + g;
+                E o = *p;
+                El<REAL>::add(o, v);
                 *p = o;
             } else {
-                double2 *p = L.Ab + ((long)cc * L.nb + (i - L.n)) * P.G + g;
-                double2 o = *p;
-                o.x += v.x;
-                o.y += v.y;
+                E *p = Ab + ((long)cc * L.nb + (i - L.n)) * GL + g;
+                E o = *p;
+                El<REAL>::add(o, v);
                 *p = o;
             }
         }
     }
 }
 
+template <bool REAL>
 __global__ void __launch_bounds__(64)
 factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, const int *__restrict__ rowinv,
               const int *__restrict__ colinv) {
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= P.G) return;
-    const long cell = g / P.S;
-    const int s = (int)(g % P.S);
+    typedef typename El<REAL>::T E;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;   // index of the stored factorization
+    if (g >= L.GL) return;
+    const long cell = REAL ? g : g / P.S;
+    const int s = REAL ? 0 : (int)(g % P.S);
     const CellCtx c = cell_ctx(P, cell);
-    const long G = P.G;
+    const long G = L.GL;
+    E *Aw = (E *)L.Aw, *Ab = (E *)L.Ab;
     const int n = L.n, nb = L.nb, N = L.N, kl = L.kl, W = L.W, BW = L.BW;
     double anorm = 0.0;
     bool bad = false;
-    scatter_terms(P, L, M, a, rowinv, colinv, c, s, g, anorm, bad);
-    scatter_terms(P, L, Lm, b, rowinv, colinv, c, s, g, anorm, bad);
+    scatter_terms<REAL>(P, L, M, a, rowinv, colinv, c, s, g, anorm, bad);
+    scatter_terms<REAL>(P, L, Lm, b, rowinv, colinv, c, s, g, anorm, bad);
     // border rows / columns that do not exist for this cell are paired into identity entries
     {
         int cb = 0;
@@ -408,7 +451,7 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
             if (axes_valid(L.row_axes[rb], c, P.nf)) continue;
             while (cb < nb && axes_valid(L.col_axes[cb], c, P.nf)) ++cb;
             if (cb < nb) {
-                L.Ab[((long)(n + cb) * nb + rb) * G + g] = make_double2(1.0, 0.0);
+                Ab[((long)(n + cb) * nb + rb) * G + g] = El<REAL>::one();
                 ++cb;
             }
         }
@@ -421,8 +464,7 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
         double best = -1.0;
         const int imax = (j + kl < n) ? kl : (n - 1 - j);
         for (int i = 0; i <= imax; ++i) {
-            const double2 v = L.Aw[((long)(j + i) * BW + (kl - i)) * G + g];
-            const double m = cabs2(v);
+            const double m = El<REAL>::abs2(Aw[((long)(j + i) * BW + (kl - i)) * G + g]);
             if (m > best) {
                 best = m;
                 p = i;
@@ -432,59 +474,58 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
         const int wmax = (j + W < N) ? W : (N - 1 - j);   // columns j .. j+wmax
         if (p != 0) {
             for (int d = 0; d <= wmax; ++d) {
-                double2 *pa = L.Aw + ((long)j * BW + kl + d) * G + g;
-                double2 *pb = L.Aw + ((long)(j + p) * BW + (kl - p) + d) * G + g;
-                const double2 t = *pa;
+                E *pa = Aw + ((long)j * BW + kl + d) * G + g;
+                E *pb = Aw + ((long)(j + p) * BW + (kl - p) + d) * G + g;
+                const E t = *pa;
                 *pa = *pb;
                 *pb = t;
             }
         }
-        double2 piv = L.Aw[((long)j * BW + kl) * G + g];
-        if (!(cabs2(piv) > tiny * tiny)) {
+        E piv = Aw[((long)j * BW + kl) * G + g];
+        if (!(El<REAL>::abs2(piv) > tiny * tiny)) {
             bad = true;
-            piv = make_double2(1.0, 0.0);
-            L.Aw[((long)j * BW + kl) * G + g] = piv;
+            piv = El<REAL>::one();
+            Aw[((long)j * BW + kl) * G + g] = piv;
         }
-        const double2 ip = cinv(piv);
+        const E ip = El<REAL>::inv(piv);
         for (int i = 1; i <= imax; ++i) {
-            double2 *pm = L.Aw + ((long)(j + i) * BW + (kl - i)) * G + g;
-            const double2 m = cmul(*pm, ip);
+            E *pm = Aw + ((long)(j + i) * BW + (kl - i)) * G + g;
+            const E m = El<REAL>::mul(*pm, ip);
             *pm = m;
-            if (m.x == 0.0 && m.y == 0.0) continue;
+            if (El<REAL>::is_zero(m)) continue;
             for (int d = 1; d <= wmax; ++d) {
-                double2 *pt = L.Aw + ((long)(j + i) * BW + (kl - i) + d) * G + g;
-                double2 t = *pt;
-                cfms(t, m, L.Aw[((long)j * BW + kl + d) * G + g]);
+                E *pt = Aw + ((long)(j + i) * BW + (kl - i) + d) * G + g;
+                E t = *pt;
+                El<REAL>::fms(t, m, Aw[((long)j * BW + kl + d) * G + g]);
                 *pt = t;
             }
         }
         for (int rb = 0; rb < nb; ++rb) {
-            double2 *pm = L.Ab + ((long)j * nb + rb) * G + g;
-            const double2 m = cmul(*pm, ip);
+            E *pm = Ab + ((long)j * nb + rb) * G + g;
+            const E m = El<REAL>::mul(*pm, ip);
             *pm = m;
-            if (m.x == 0.0 && m.y == 0.0) continue;
+            if (El<REAL>::is_zero(m)) continue;
             for (int d = 1; d <= wmax; ++d) {
-                double2 *pt = L.Ab + ((long)(j + d) * nb + rb) * G + g;
-                double2 t = *pt;
-                cfms(t, m, L.Aw[((long)j * BW + kl + d) * G + g]);
+                E *pt = Ab + ((long)(j + d) * nb + rb) * G + g;
+                E t = *pt;
+                El<REAL>::fms(t, m, Aw[((long)j * BW + kl + d) * G + g]);
                 *pt = t;
             }
         }
         // store the reciprocal pivot: the solve multiplies instead of dividing
-        L.Aw[((long)j * BW + kl) * G + g] = ip;
+        Aw[((long)j * BW + kl) * G + g] = ip;
     }
     // ---- Schur block (nb x nb) at Ab[n + c][r]: invert in place by Gauss-Jordan with pivoting.
-    //      scratch rows [0, nb) x [0, nb) of L.scratch hold the inverse being built.
     if (nb > 0) {
-        double2 *Sinv = L.scratch;   // [nb*nb][G] (n >= nb*nb is checked on the host)
+        E *Sinv = (E *)L.scratch;   // [nb*nb][GL] workspace (scratch holds >= nb*nb*G complex)
         for (int r = 0; r < nb; ++r)
             for (int cidx = 0; cidx < nb; ++cidx)
-                Sinv[((long)r * nb + cidx) * G + g] = make_double2(r == cidx ? 1.0 : 0.0, 0.0);
+                Sinv[((long)r * nb + cidx) * G + g] = (r == cidx) ? El<REAL>::one() : El<REAL>::zero();
         for (int k = 0; k < nb; ++k) {
             int p = k;
             double best = -1.0;
             for (int r = k; r < nb; ++r) {
-                const double m = cabs2(L.Ab[((long)(n + k) * nb + r) * G + g]);
+                const double m = El<REAL>::abs2(Ab[((long)(n + k) * nb + r) * G + g]);
                 if (m > best) {
                     best = m;
                     p = r;
@@ -492,8 +533,8 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
             }
             if (p != k) {
                 for (int cidx = 0; cidx < nb; ++cidx) {
-                    double2 *pa = L.Ab + ((long)(n + cidx) * nb + k) * G + g, *pb = L.Ab + ((long)(n + cidx) * nb + p) * G + g;
-                    double2 t = *pa;
+                    E *pa = Ab + ((long)(n + cidx) * nb + k) * G + g, *pb = Ab + ((long)(n + cidx) * nb + p) * G + g;
+                    E t = *pa;
                     *pa = *pb;
                     *pb = t;
                     pa = Sinv + ((long)k * nb + cidx) * G + g;
@@ -503,30 +544,30 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
                     *pb = t;
                 }
             }
-            double2 piv = L.Ab[((long)(n + k) * nb + k) * G + g];
-            if (!(cabs2(piv) > tiny * tiny)) {
+            E piv = Ab[((long)(n + k) * nb + k) * G + g];
+            if (!(El<REAL>::abs2(piv) > tiny * tiny)) {
                 bad = true;
-                piv = make_double2(1.0, 0.0);
+                piv = El<REAL>::one();
             }
-            const double2 ip = cinv(piv);
+            const E ip = El<REAL>::inv(piv);
             for (int cidx = 0; cidx < nb; ++cidx) {
-                double2 *pa = L.Ab + ((long)(n + cidx) * nb + k) * G + g;
-                *pa = cmul(*pa, ip);
+                E *pa = Ab + ((long)(n + cidx) * nb + k) * G + g;
+                *pa = El<REAL>::mul(*pa, ip);
                 pa = Sinv + ((long)k * nb + cidx) * G + g;
-                *pa = cmul(*pa, ip);
+                *pa = El<REAL>::mul(*pa, ip);
             }
             for (int r = 0; r < nb; ++r) {
                 if (r == k) continue;
-                const double2 m = L.Ab[((long)(n + k) * nb + r) * G + g];
-                if (m.x == 0.0 && m.y == 0.0) continue;
+                const E m = Ab[((long)(n + k) * nb + r) * G + g];
+                if (El<REAL>::is_zero(m)) continue;
                 for (int cidx = 0; cidx < nb; ++cidx) {
-                    double2 *pt = L.Ab + ((long)(n + cidx) * nb + r) * G + g;
-                    double2 t = *pt;
-                    cfms(t, m, L.Ab[((long)(n + cidx) * nb + k) * G + g]);
+                    E *pt = Ab + ((long)(n + cidx) * nb + r) * G + g;
+                    E t = *pt;
+                    El<REAL>::fms(t, m, Ab[((long)(n + cidx) * nb + k) * G + g]);
                     *pt = t;
                     pt = Sinv + ((long)r * nb + cidx) * G + g;
                     t = *pt;
-                    cfms(t, m, Sinv[((long)k * nb + cidx) * G + g]);
+                    El<REAL>::fms(t, m, Sinv[((long)k * nb + cidx) * G + g]);
                     *pt = t;
                 }
             }
@@ -534,7 +575,7 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
         // copy inverse into the Schur slot: Ab[n + c][r] = Sinv[r][c]
         for (int r = 0; r < nb; ++r)
             for (int cidx = 0; cidx < nb; ++cidx)
-                L.Ab[((long)(n + cidx) * nb + r) * G + g] = Sinv[((long)r * nb + cidx) * G + g];
+                Ab[((long)(n + cidx) * nb + r) * G + g] = Sinv[((long)r * nb + cidx) * G + g];
     }
     L.flag[g] = bad ? 1 : 0;
 }
@@ -543,33 +584,57 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
 // solve: forward sweep (row interchanges, band multipliers, border multipliers), Schur block,
 // backward sweep with a register window of the last W solution entries.
 // ------------------------------------------------------------------------------------------------
-template <int NF, int WT>
+template <int NF, int WT, bool REAL>
 __global__ void __launch_bounds__(256)
 solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__restrict__ xout) {
+    typedef typename El<REAL>::T E;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= P.G) return;   // G is a multiple of S, pairs never straddle the guard
     const long cell = g / P.S;
     const int s = (int)(g % P.S);
     const CellCtx c = cell_ctx(P, cell);
-    const long G = P.G;
+    const long G = P.G;            // right-hand sides / scratch
+    const long GL = L.GL;          // stored factorizations
+    const long gl = REAL ? cell : g;
+    const E *Aw = (const E *)L.Aw, *Ab = (const E *)L.Ab;
     const long plane = P.nx * P.ny;
     const int n = L.n, nb = L.nb, kl = L.kl, W = L.W, BW = L.BW;
+
+    // right-hand side of logical row i, rotated into the real grading when REAL:
+    //   multiply by (-i)^rot, and by -1 for the (-kx) system of x-odd rows
+    auto load_row = [&](int i) -> double2 {
+        double2 v = load_sys<NF>(rhs, plane, L.rowperm[i], P, c, s);
+        if (REAL) {
+            const unsigned char code = L.row_code[i];
+            if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+            if (code & 1) v = make_double2(v.y, -v.x);
+        }
+        return v;
+    };
+    auto store_col = [&](int i, double2 v) {
+        if (REAL) {
+            const unsigned char code = L.col_code[i];
+            if (code & 1) v = make_double2(-v.y, v.x);
+            if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+        }
+        store_sys<NF>(xout, plane, L.colperm[i], P, c, s, v);
+    };
 
     // ---- forward
     double2 w[KLMAX + 1];
 #pragma unroll
     for (int d = 0; d <= KLMAX; ++d) {
         w[d] = make_double2(0.0, 0.0);
-        if (d <= kl && d < n) w[d] = load_sys<NF>(rhs, plane, L.rowperm[d], P, c, s);
+        if (d <= kl && d < n) w[d] = load_row(d);
     }
     double2 gb[NBMAX];
 #pragma unroll
     for (int rb = 0; rb < NBMAX; ++rb) {
         gb[rb] = make_double2(0.0, 0.0);
-        if (rb < nb) gb[rb] = load_sys<NF>(rhs, plane, L.rowperm[n + rb], P, c, s);
+        if (rb < nb) gb[rb] = load_row(n + rb);
     }
     for (int j = 0; j < n; ++j) {
-        const int p = L.piv[(long)j * G + g];
+        const int p = L.piv[(long)j * GL + gl];
         double2 yj = w[0];
 #pragma unroll
         for (int d = 1; d <= KLMAX; ++d) {
@@ -582,15 +647,15 @@ solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__res
 #pragma unroll
         for (int i = 1; i <= KLMAX; ++i) {
             if (i <= kl && j + i < n) {
-                const double2 m = L.Aw[((long)(j + i) * BW + (kl - i)) * G + g];
-                cfms(w[i], m, yj);
+                const E m = Aw[((long)(j + i) * BW + (kl - i)) * GL + gl];
+                El<REAL>::fms2(w[i], m, yj);
             }
         }
 #pragma unroll
         for (int rb = 0; rb < NBMAX; ++rb) {
             if (rb < nb) {
-                const double2 m = L.Ab[((long)j * nb + rb) * G + g];
-                cfms(gb[rb], m, yj);
+                const E m = Ab[((long)j * nb + rb) * GL + gl];
+                El<REAL>::fms2(gb[rb], m, yj);
             }
         }
 #pragma unroll
@@ -598,7 +663,7 @@ solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__res
         w[KLMAX] = make_double2(0.0, 0.0);
         const int nxt = j + kl + 1;
         if (nxt < n) {
-            const double2 v = load_sys<NF>(rhs, plane, L.rowperm[nxt], P, c, s);
+            const double2 v = load_row(nxt);
 #pragma unroll
             for (int d = 0; d <= KLMAX; ++d)
                 if (d == kl) w[d] = v;
@@ -614,7 +679,7 @@ solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__res
             double2 acc = make_double2(0.0, 0.0);
 #pragma unroll
             for (int cidx = 0; cidx < NBMAX; ++cidx) {
-                if (cidx < nb) cfma(acc, L.Ab[((long)(n + cidx) * nb + r) * G + g], gb[cidx]);
+                if (cidx < nb) El<REAL>::fma2(acc, Ab[((long)(n + cidx) * nb + r) * GL + gl], gb[cidx]);
             }
             // border unknown r is logical column n + r
 #pragma unroll
@@ -629,22 +694,22 @@ solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__res
 #pragma unroll
             for (int d = 0; d < WT; ++d)
                 if (d == r) z = win[d];
-            store_sys<NF>(xout, plane, L.colperm[n + r], P, c, s, z);
+            store_col(n + r, z);
         }
     }
     // ---- backward: win[d] = x[j+1+d]
     for (int j = n - 1; j >= 0; --j) {
         double2 acc = L.scratch[(long)j * G + g];
-        const double2 *Ur = L.Aw + ((long)j * BW + kl) * G + g;
+        const E *Ur = Aw + ((long)j * BW + kl) * GL + gl;
 #pragma unroll
         for (int d = 0; d < WT; ++d) {
-            if (d < W) cfms(acc, Ur[(long)(d + 1) * G], win[d]);
+            if (d < W) El<REAL>::fms2(acc, Ur[(long)(d + 1) * GL], win[d]);
         }
-        const double2 xj = cmul(acc, Ur[0]);   // reciprocal pivot stored on the diagonal
+        const double2 xj = El<REAL>::mul2(acc, Ur[0]);   // reciprocal pivot stored on the diagonal
 #pragma unroll
         for (int d = WT - 1; d > 0; --d) win[d] = win[d - 1];
         win[0] = xj;
-        store_sys<NF>(xout, plane, L.colperm[j], P, c, s, xj);
+        store_col(j, xj);
     }
 }
 
@@ -712,20 +777,21 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
     const LuDev &d = lu->dev;
     const unsigned blocks = (unsigned)((P.G + 255) / 256);
     const int W = d.W;
-    if (W <= 8)
-        hipLaunchKernelGGL((solve_kernel<NF, 8>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
-    else if (W <= 16)
-        hipLaunchKernelGGL((solve_kernel<NF, 16>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
-    else if (W <= 24)
-        hipLaunchKernelGGL((solve_kernel<NF, 24>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
-    else if (W <= 32)
-        hipLaunchKernelGGL((solve_kernel<NF, 32>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
-    else if (W <= 40)
-        hipLaunchKernelGGL((solve_kernel<NF, 40>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
-    else if (W <= 48)
-        hipLaunchKernelGGL((solve_kernel<NF, 48>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
-    else
-        hipLaunchKernelGGL((solve_kernel<NF, 64>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);
+#define DDH_SOLVE(WTV)                                                                                         \
+    {                                                                                                          \
+        if (d.real)                                                                                            \
+            hipLaunchKernelGGL((solve_kernel<NF, WTV, true>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);    \
+        else                                                                                                   \
+            hipLaunchKernelGGL((solve_kernel<NF, WTV, false>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);   \
+    }
+    if (W <= 8) DDH_SOLVE(8)
+    else if (W <= 16) DDH_SOLVE(16)
+    else if (W <= 24) DDH_SOLVE(24)
+    else if (W <= 32) DDH_SOLVE(32)
+    else if (W <= 40) DDH_SOLVE(40)
+    else if (W <= 48) DDH_SOLVE(48)
+    else DDH_SOLVE(64)
+#undef DDH_SOLVE
     DDH_HIP(hipGetLastError());
     if (lu->nflag) {
         if (!lu->d_inv) return fail("pencil_solve: flagged pencils need ddh_pencil_set_dense_inverse first");
@@ -900,12 +966,14 @@ int ddh_pencil_matvec_solve(ddh_handle pack, int mat_id, int bands_id, const dou
     return launch_matvec(pp, mat_id, x, y, pp->posts[bands_id], stream);
 }
 
-int ddh_pencil_factor(ddh_handle pack, int matM_id, int matL_id, double a, double b, const int *row_perm_h,
-                      const int *col_perm_h, int n_interior, int kl, int ku, const unsigned char *row_axes_h,
-                      const unsigned char *col_axes_h, int reuse_lu_id, int *lu_id, void *stream) {
+static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, double b, const int *row_perm_h,
+                       const int *col_perm_h, int n_interior, int kl, int ku, const unsigned char *row_axes_h,
+                       const unsigned char *col_axes_h, const unsigned char *row_code_h,
+                       const unsigned char *col_code_h, int reuse_lu_id, int *lu_id, void *stream) {
     PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
     if (!pp) return -1;
     const PencilDev &P = pp->dev;
+    const bool real = (row_code_h != nullptr && col_code_h != nullptr);
     const int nm = (int)pp->mats.size();
     if (matM_id < 0 || matM_id >= nm || matL_id < 0 || matL_id >= nm) return fail("pencil_factor: bad matrix id");
     const int N = P.nrows, n = n_interior, nb = N - n;
@@ -920,33 +988,42 @@ int ddh_pencil_factor(ddh_handle pack, int matM_id, int matL_id, double a, doubl
     LuFactor *lu = nullptr;
     const bool reuse = reuse_lu_id >= 0 && reuse_lu_id < (int)pp->lus.size() && pp->lus[reuse_lu_id] &&
                        pp->lus[reuse_lu_id]->dev.n == n && pp->lus[reuse_lu_id]->dev.kl == kl &&
-                       pp->lus[reuse_lu_id]->dev.ku == ku;
+                       pp->lus[reuse_lu_id]->dev.ku == ku && (pp->lus[reuse_lu_id]->dev.real != 0) == real;
     hipStream_t s = as_stream(stream);
+    const size_t G = (size_t)P.G;
+    const size_t GL = real ? (size_t)P.ncells : G;
+    const size_t esz = real ? sizeof(double) : sizeof(double2);
     if (reuse) {
         lu = pp->lus[reuse_lu_id];
     } else {
         lu = new LuFactor();
         LuDev &d = lu->dev;
+        memset(&d, 0, sizeof(d));
         d.n = n; d.nb = nb; d.N = N; d.kl = kl; d.ku = ku; d.W = W; d.BW = kl + W + 1;
-        const size_t G = (size_t)P.G;
-        const size_t szAw = sizeof(double2) * (size_t)(n > 0 ? n : 1) * d.BW * G;
-        const size_t szAb = sizeof(double2) * (size_t)N * (nb > 0 ? nb : 1) * G;
+        d.real = real ? 1 : 0;
+        d.GL = (long)GL;
+        const size_t szAw = esz * (size_t)(n > 0 ? n : 1) * d.BW * GL;
+        const size_t szAb = esz * (size_t)N * (nb > 0 ? nb : 1) * GL;
         const size_t szScr = sizeof(double2) * (size_t)std::max(n, nb * nb) * G;
         int st = check_hip(hipMalloc((void **)&d.Aw, szAw), "hipMalloc(band LU)");
         if (!st) st = check_hip(hipMalloc((void **)&d.Ab, szAb), "hipMalloc(border LU)");
-        if (!st) st = check_hip(hipMalloc((void **)&d.piv, (size_t)(n > 0 ? n : 1) * G), "hipMalloc(piv)");
-        if (!st) st = check_hip(hipMalloc((void **)&d.flag, G), "hipMalloc(flag)");
+        if (!st) st = check_hip(hipMalloc((void **)&d.piv, (size_t)(n > 0 ? n : 1) * GL), "hipMalloc(piv)");
+        if (!st) st = check_hip(hipMalloc((void **)&d.flag, GL), "hipMalloc(flag)");
         if (!st) st = check_hip(hipMalloc((void **)&d.scratch, szScr), "hipMalloc(scratch)");
         if (!st) st = upload_vec(&lu->d_rowperm, row_perm_h, (size_t)N);
         if (!st) st = upload_vec(&lu->d_colperm, col_perm_h, (size_t)N);
         if (!st) st = upload_vec(&lu->d_raxes, row_axes_h + n, (size_t)nb);
         if (!st) st = upload_vec(&lu->d_caxes, col_axes_h + n, (size_t)nb);
+        if (!st && real) st = upload_vec(&lu->d_rcode, row_code_h, (size_t)N);
+        if (!st && real) st = upload_vec(&lu->d_ccode, col_code_h, (size_t)N);
         if (st) { free_lu(lu); return st; }
         d.rowperm = (const int *)lu->d_rowperm;
         d.colperm = (const int *)lu->d_colperm;
         d.row_axes = (const unsigned char *)lu->d_raxes;
         d.col_axes = (const unsigned char *)lu->d_caxes;
-        lu->bytes = szAw + szAb + szScr + (size_t)n * G + G;
+        d.row_code = (const unsigned char *)lu->d_rcode;
+        d.col_code = (const unsigned char *)lu->d_ccode;
+        lu->bytes = szAw + szAb + szScr + (size_t)n * GL + GL;
         // interior rows / columns must exist for every cell
         for (int i = 0; i < n; ++i)
             if ((row_axes_h[i] & 3) != 3 || (col_axes_h[i] & 3) != 3) {
@@ -955,9 +1032,8 @@ int ddh_pencil_factor(ddh_handle pack, int matM_id, int matL_id, double a, doubl
             }
     }
     LuDev &d = lu->dev;
-    const size_t G = (size_t)P.G;
-    DDH_HIP(hipMemsetAsync(d.Aw, 0, sizeof(double2) * (size_t)(n > 0 ? n : 1) * d.BW * G, s));
-    DDH_HIP(hipMemsetAsync(d.Ab, 0, sizeof(double2) * (size_t)N * (nb > 0 ? nb : 1) * G, s));
+    DDH_HIP(hipMemsetAsync(d.Aw, 0, esz * (size_t)(n > 0 ? n : 1) * d.BW * GL, s));
+    DDH_HIP(hipMemsetAsync(d.Ab, 0, esz * (size_t)N * (nb > 0 ? nb : 1) * GL, s));
     // inverse permutations (physical -> logical) on the device
     std::vector<int> rowinv(N), colinv(N);
     for (int i = 0; i < N; ++i) {
@@ -968,20 +1044,25 @@ int ddh_pencil_factor(ddh_handle pack, int matM_id, int matL_id, double a, doubl
     int st = upload_vec(&d_rowinv, rowinv.data(), (size_t)N);
     if (!st) st = upload_vec(&d_colinv, colinv.data(), (size_t)N);
     if (st) { if (!reuse) free_lu(lu); return st; }
-    const unsigned blocks = (unsigned)((P.G + 63) / 64);
-    hipLaunchKernelGGL(factor_kernel, dim3(blocks), dim3(64), 0, s, P, d, pp->mats[matM_id]->dev,
-                       pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
+    const unsigned blocks = (unsigned)((GL + 63) / 64);
+    if (real)
+        hipLaunchKernelGGL(factor_kernel<true>, dim3(blocks), dim3(64), 0, s, P, d, pp->mats[matM_id]->dev,
+                           pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
+    else
+        hipLaunchKernelGGL(factor_kernel<false>, dim3(blocks), dim3(64), 0, s, P, d, pp->mats[matM_id]->dev,
+                           pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
     DDH_HIP(hipGetLastError());
     DDH_HIP(hipStreamSynchronize(s));
     (void)hipFree(d_rowinv);
     (void)hipFree(d_colinv);
-    // flagged systems -> flagged cells
-    std::vector<unsigned char> flags(G);
-    DDH_HIP(hipMemcpy(flags.data(), d.flag, G, hipMemcpyDeviceToHost));
+    // flagged factorizations -> flagged cells
+    std::vector<unsigned char> flags(GL);
+    DDH_HIP(hipMemcpy(flags.data(), d.flag, GL, hipMemcpyDeviceToHost));
     lu->flag_cells.clear();
+    const int per = real ? 1 : P.S;
     for (long cidx = 0; cidx < P.ncells; ++cidx) {
         bool f = false;
-        for (int sidx = 0; sidx < P.S; ++sidx) f = f || flags[cidx * P.S + sidx];
+        for (int sidx = 0; sidx < per; ++sidx) f = f || flags[cidx * per + sidx];
         if (f) lu->flag_cells.push_back(cidx);
     }
     lu->nflag = (int)lu->flag_cells.size();
@@ -999,6 +1080,23 @@ int ddh_pencil_factor(ddh_handle pack, int matM_id, int matL_id, double a, doubl
         *lu_id = (int)pp->lus.size() - 1;
     }
     return 0;
+}
+
+int ddh_pencil_factor(ddh_handle pack, int matM_id, int matL_id, double a, double b, const int *row_perm_h,
+                      const int *col_perm_h, int n_interior, int kl, int ku, const unsigned char *row_axes_h,
+                      const unsigned char *col_axes_h, int reuse_lu_id, int *lu_id, void *stream) {
+    return factor_impl(pack, matM_id, matL_id, a, b, row_perm_h, col_perm_h, n_interior, kl, ku, row_axes_h,
+                       col_axes_h, nullptr, nullptr, reuse_lu_id, lu_id, stream);
+}
+
+int ddh_pencil_factor_real(ddh_handle pack, int matM_id, int matL_id, double a, double b, const int *row_perm_h,
+                           const int *col_perm_h, int n_interior, int kl, int ku,
+                           const unsigned char *row_axes_h, const unsigned char *col_axes_h,
+                           const unsigned char *row_code_h, const unsigned char *col_code_h, int reuse_lu_id,
+                           int *lu_id, void *stream) {
+    if (!row_code_h || !col_code_h) return fail("pencil_factor_real: grading codes required");
+    return factor_impl(pack, matM_id, matL_id, a, b, row_perm_h, col_perm_h, n_interior, kl, ku, row_axes_h,
+                       col_axes_h, row_code_h, col_code_h, reuse_lu_id, lu_id, stream);
 }
 
 /* number of flagged cells of a factorization and their ids (host array of *count longs) */

@@ -69,6 +69,9 @@ SIGNATURES = {
     "ddh_pencil_matvec_solve": [_h, _i, _i, _vp, _vp, _vp],
     "ddh_pencil_factor": [_h, _i, _i, _d, _d, _ip, _ip, _i, _i, _i,
                           C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte), _i, _ip, _vp],
+    "ddh_pencil_factor_real": [_h, _i, _i, _d, _d, _ip, _ip, _i, _i, _i,
+                               C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte),
+                               C.POINTER(C.c_ubyte), _i, _ip, _vp],
     "ddh_pencil_solve": [_h, _i, _vp, _vp, _vp],
     "ddh_pencil_flagged": [_h, _i, _ip, C.POINTER(_l), _i],
     "ddh_pencil_set_dense_inverse": [_h, _i, _dp],

@@ -122,17 +122,29 @@ class PencilPack:
     def _matvec_solve(self, mat_id, bands_id, x, y):
         libhip.call("ddh_pencil_matvec_solve", self.handle, mat_id, bands_id, ptr(x), ptr(y), self.dev.stream)
 
-    def factor(self, matM, matL, a, b, row_perm, col_perm, n_interior, kl, ku, row_axes, col_axes, reuse=-1):
-        """Factor a*M + b*L for every pencil; returns the LU id."""
+    def factor(self, matM, matL, a, b, row_perm, col_perm, n_interior, kl, ku, row_axes, col_axes, reuse=-1,
+               real=None):
+        """Factor a*M + b*L for every pencil; returns the LU id.
+        real = dict(matM, matL, row_code, col_code) selects the real graded factorization
+        (ddh_pencil_factor_real); matM / matL (complex term lists) are then only used for the dense
+        inverses of flagged pencils."""
         row_perm = np.ascontiguousarray(row_perm, dtype=np.int32)
         col_perm = np.ascontiguousarray(col_perm, dtype=np.int32)
         # masks are passed in LOGICAL order
         ra = np.ascontiguousarray(np.asarray(row_axes, dtype=np.uint8)[row_perm])
         ca = np.ascontiguousarray(np.asarray(col_axes, dtype=np.uint8)[col_perm])
         lu = C.c_int(-1)
-        libhip.call("ddh_pencil_factor", self.handle, matM, matL, float(a), float(b), libhip.as_ip(row_perm),
-                    libhip.as_ip(col_perm), int(n_interior), int(kl), int(ku), libhip.as_ubp(ra), libhip.as_ubp(ca),
-                    int(reuse), C.byref(lu), self.dev.stream)
+        if real is not None:
+            rc = np.ascontiguousarray(np.asarray(real["row_code"], dtype=np.uint8)[row_perm])
+            cc = np.ascontiguousarray(np.asarray(real["col_code"], dtype=np.uint8)[col_perm])
+            libhip.call("ddh_pencil_factor_real", self.handle, real["matM"], real["matL"], float(a), float(b),
+                        libhip.as_ip(row_perm), libhip.as_ip(col_perm), int(n_interior), int(kl), int(ku),
+                        libhip.as_ubp(ra), libhip.as_ubp(ca), libhip.as_ubp(rc), libhip.as_ubp(cc),
+                        int(reuse), C.byref(lu), self.dev.stream)
+        else:
+            libhip.call("ddh_pencil_factor", self.handle, matM, matL, float(a), float(b), libhip.as_ip(row_perm),
+                        libhip.as_ip(col_perm), int(n_interior), int(kl), int(ku), libhip.as_ubp(ra),
+                        libhip.as_ubp(ca), int(reuse), C.byref(lu), self.dev.stream)
         lu_id = lu.value
         # pencils whose band block is singular: explicit dense inverse built here on the host
         count = C.c_int(0)

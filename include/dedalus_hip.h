@@ -141,6 +141,18 @@ int ddh_pencil_factor(ddh_handle pack, int matM_id, int matL_id, double a, doubl
                       const int *row_perm_h, const int *col_perm_h, int n_interior, int kl, int ku,
                       const unsigned char *row_axes_h, const unsigned char *col_axes_h,
                       int reuse_lu_id, int *lu_id, void *stream);
+/* Real graded variant.  For real differential operators the complex pencil symbol factors as
+ *   lambda(kx, ky) = D_r A D_c^-1,   lambda(-kx, ky) = D_r S_r A S_c D_c^-1
+ * with a REAL matrix A(kx, ky), D = diag(i^rot) and S = diag((-1)^sgn) (a Z2 grading of rows and
+ * columns by derivative parity; the host checks that it exists).  One real factorization then serves
+ * both systems of a cell and both their real/imaginary parts: 1/4 of the LU bytes of the complex
+ * path.  matM / matL must be the real-graded term lists (imaginary parts ignored);
+ * row_code_h / col_code_h (logical order): bit0 = rot, bit1 = sgn.                                 */
+int ddh_pencil_factor_real(ddh_handle pack, int matM_id, int matL_id, double a, double b,
+                           const int *row_perm_h, const int *col_perm_h, int n_interior, int kl, int ku,
+                           const unsigned char *row_axes_h, const unsigned char *col_axes_h,
+                           const unsigned char *row_code_h, const unsigned char *col_code_h,
+                           int reuse_lu_id, int *lu_id, void *stream);
 int ddh_pencil_solve(ddh_handle pack, int lu_id, const double *rhs, double *x, void *stream);
 /* Pencils whose band block is singular (e.g. the kx=ky=0 pressure-gauge pencil) are flagged by
  * ddh_pencil_factor and solved with an explicit dense inverse the host supplies: query the flagged

@@ -48,7 +48,8 @@ class _NpPack:
         for c in range(yy.shape[0]):
             yy[c] = spsolve_triangular(C, yy[c].copy(), lower=False)
 
-    def factor(self, matM, matL, a, b, row_perm, col_perm, n_interior, kl, ku, row_axes, col_axes, reuse=-1):
+    def factor(self, matM, matL, a, b, row_perm, col_perm, n_interior, kl, ku, row_axes, col_axes, reuse=-1,
+               real=None):
         lu = npp.PencilLU(self.mats[matM], self.mats[matL], a, b, self.nf, self.nx, self.ny, self.kx, self.ky,
                           np.asarray(row_axes), np.asarray(col_axes), self.mx_offset)
         if reuse >= 0:
