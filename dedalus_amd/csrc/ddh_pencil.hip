@@ -73,6 +73,7 @@ struct LuDev {
     int n, nb, N, kl, ku, W, BW;   // BW = kl + W + 1, W = ku + kl
     int real;                      // 1: real graded matrix shared by the systems of a cell (see factor_real)
     long GL;                       // number of stored factorizations: G (complex) or ncells (real)
+    long nblk;                     // ceil(GL / 64): factor storage is tiled [row][block of 64][entry][lane]
     void *Aw;                      // [n][BW][GL]  band rows, LAPACK-style fill space (double2 or double)
     void *Ab;                      // [N][nb][GL]  border rows (multipliers | Schur block inverse)
     unsigned char *piv;            // [n][GL]
@@ -199,6 +200,19 @@ template <> struct El<true> {
     static __device__ __forceinline__ void fma2(double2 &acc, T m, double2 v) { acc.x += m * v.x; acc.y += m * v.y; }
     static __device__ __forceinline__ double2 mul2(double2 a, T m) { return make_double2(a.x * m, a.y * m); }
 };
+
+// Factor storage index.  All entries of one row for one block of 64 factorizations are contiguous
+// ([row][block][entry][lane]): a wave streams one ~BW*512 B chunk per row instead of touching BW
+// different pages (TLB / DRAM-page locality).
+__device__ __forceinline__ long lu_aw(const LuDev &L, long gl, int row, int d) {
+    return ((((long)row * L.nblk + (gl >> 6)) * L.BW + d) << 6) + (gl & 63);
+}
+__device__ __forceinline__ long lu_ab(const LuDev &L, long gl, int col, int rb) {
+    return ((((long)col * L.nblk + (gl >> 6)) * L.nb + rb) << 6) + (gl & 63);
+}
+__device__ __forceinline__ long lu_pv(const LuDev &L, long gl, int row) {
+    return (((long)row * L.nblk + (gl >> 6)) << 6) + (gl & 63);
+}
 
 struct CellCtx {
     long mx, my;   // local cell indices (addressing)
@@ -413,12 +427,12 @@ __device__ __forceinline__ void scatter_terms(const PencilDev &P, const LuDev &L
                     bad = true;
                     continue;
                 }
-                E *p = Aw + ((long)i * L.BW + d) * GL + g;
+                E *p = Aw + lu_aw(L, g, i, d);
                 E o = *p;
                 El<REAL>::add(o, v);
                 *p = o;
             } else {
-                E *p = Ab + ((long)cc * L.nb + (i - L.n)) * GL + g;
+                E *p = Ab + lu_ab(L, g, cc, i - L.n);
                 E o = *p;
                 El<REAL>::add(o, v);
                 *p = o;
@@ -451,7 +465,7 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
             if (axes_valid(L.row_axes[rb], c, P.nf)) continue;
             while (cb < nb && axes_valid(L.col_axes[cb], c, P.nf)) ++cb;
             if (cb < nb) {
-                Ab[((long)(n + cb) * nb + rb) * G + g] = El<REAL>::one();
+                Ab[lu_ab(L, g, n + cb, rb)] = El<REAL>::one();
                 ++cb;
             }
         }
@@ -464,56 +478,56 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
         double best = -1.0;
         const int imax = (j + kl < n) ? kl : (n - 1 - j);
         for (int i = 0; i <= imax; ++i) {
-            const double m = El<REAL>::abs2(Aw[((long)(j + i) * BW + (kl - i)) * G + g]);
+            const double m = El<REAL>::abs2(Aw[lu_aw(L, g, j + i, kl - i)]);
             if (m > best) {
                 best = m;
                 p = i;
             }
         }
-        L.piv[(long)j * G + g] = (unsigned char)p;
+        L.piv[lu_pv(L, g, j)] = (unsigned char)p;
         const int wmax = (j + W < N) ? W : (N - 1 - j);   // columns j .. j+wmax
         if (p != 0) {
             for (int d = 0; d <= wmax; ++d) {
-                E *pa = Aw + ((long)j * BW + kl + d) * G + g;
-                E *pb = Aw + ((long)(j + p) * BW + (kl - p) + d) * G + g;
+                E *pa = Aw + lu_aw(L, g, j, kl + d);
+                E *pb = Aw + lu_aw(L, g, j + p, (kl - p) + d);
                 const E t = *pa;
                 *pa = *pb;
                 *pb = t;
             }
         }
-        E piv = Aw[((long)j * BW + kl) * G + g];
+        E piv = Aw[lu_aw(L, g, j, kl)];
         if (!(El<REAL>::abs2(piv) > tiny * tiny)) {
             bad = true;
             piv = El<REAL>::one();
-            Aw[((long)j * BW + kl) * G + g] = piv;
+            Aw[lu_aw(L, g, j, kl)] = piv;
         }
         const E ip = El<REAL>::inv(piv);
         for (int i = 1; i <= imax; ++i) {
-            E *pm = Aw + ((long)(j + i) * BW + (kl - i)) * G + g;
+            E *pm = Aw + lu_aw(L, g, j + i, kl - i);
             const E m = El<REAL>::mul(*pm, ip);
             *pm = m;
             if (El<REAL>::is_zero(m)) continue;
             for (int d = 1; d <= wmax; ++d) {
-                E *pt = Aw + ((long)(j + i) * BW + (kl - i) + d) * G + g;
+                E *pt = Aw + lu_aw(L, g, j + i, (kl - i) + d);
                 E t = *pt;
-                El<REAL>::fms(t, m, Aw[((long)j * BW + kl + d) * G + g]);
+                El<REAL>::fms(t, m, Aw[lu_aw(L, g, j, kl + d)]);
                 *pt = t;
             }
         }
         for (int rb = 0; rb < nb; ++rb) {
-            E *pm = Ab + ((long)j * nb + rb) * G + g;
+            E *pm = Ab + lu_ab(L, g, j, rb);
             const E m = El<REAL>::mul(*pm, ip);
             *pm = m;
             if (El<REAL>::is_zero(m)) continue;
             for (int d = 1; d <= wmax; ++d) {
-                E *pt = Ab + ((long)(j + d) * nb + rb) * G + g;
+                E *pt = Ab + lu_ab(L, g, j + d, rb);
                 E t = *pt;
-                El<REAL>::fms(t, m, Aw[((long)j * BW + kl + d) * G + g]);
+                El<REAL>::fms(t, m, Aw[lu_aw(L, g, j, kl + d)]);
                 *pt = t;
             }
         }
         // store the reciprocal pivot: the solve multiplies instead of dividing
-        Aw[((long)j * BW + kl) * G + g] = ip;
+        Aw[lu_aw(L, g, j, kl)] = ip;
     }
     // ---- Schur block (nb x nb) at Ab[n + c][r]: invert in place by Gauss-Jordan with pivoting.
     if (nb > 0) {
@@ -525,7 +539,7 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
             int p = k;
             double best = -1.0;
             for (int r = k; r < nb; ++r) {
-                const double m = El<REAL>::abs2(Ab[((long)(n + k) * nb + r) * G + g]);
+                const double m = El<REAL>::abs2(Ab[lu_ab(L, g, n + k, r)]);
                 if (m > best) {
                     best = m;
                     p = r;
@@ -533,7 +547,7 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
             }
             if (p != k) {
                 for (int cidx = 0; cidx < nb; ++cidx) {
-                    E *pa = Ab + ((long)(n + cidx) * nb + k) * G + g, *pb = Ab + ((long)(n + cidx) * nb + p) * G + g;
+                    E *pa = Ab + lu_ab(L, g, n + cidx, k), *pb = Ab + lu_ab(L, g, n + cidx, p);
                     E t = *pa;
                     *pa = *pb;
                     *pb = t;
@@ -544,26 +558,26 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
                     *pb = t;
                 }
             }
-            E piv = Ab[((long)(n + k) * nb + k) * G + g];
+            E piv = Ab[lu_ab(L, g, n + k, k)];
             if (!(El<REAL>::abs2(piv) > tiny * tiny)) {
                 bad = true;
                 piv = El<REAL>::one();
             }
             const E ip = El<REAL>::inv(piv);
             for (int cidx = 0; cidx < nb; ++cidx) {
-                E *pa = Ab + ((long)(n + cidx) * nb + k) * G + g;
+                E *pa = Ab + lu_ab(L, g, n + cidx, k);
                 *pa = El<REAL>::mul(*pa, ip);
                 pa = Sinv + ((long)k * nb + cidx) * G + g;
                 *pa = El<REAL>::mul(*pa, ip);
             }
             for (int r = 0; r < nb; ++r) {
                 if (r == k) continue;
-                const E m = Ab[((long)(n + k) * nb + r) * G + g];
+                const E m = Ab[lu_ab(L, g, n + k, r)];
                 if (El<REAL>::is_zero(m)) continue;
                 for (int cidx = 0; cidx < nb; ++cidx) {
-                    E *pt = Ab + ((long)(n + cidx) * nb + r) * G + g;
+                    E *pt = Ab + lu_ab(L, g, n + cidx, r);
                     E t = *pt;
-                    El<REAL>::fms(t, m, Ab[((long)(n + cidx) * nb + k) * G + g]);
+                    El<REAL>::fms(t, m, Ab[lu_ab(L, g, n + cidx, k)]);
                     *pt = t;
                     pt = Sinv + ((long)r * nb + cidx) * G + g;
                     t = *pt;
@@ -575,7 +589,7 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
         // copy inverse into the Schur slot: Ab[n + c][r] = Sinv[r][c]
         for (int r = 0; r < nb; ++r)
             for (int cidx = 0; cidx < nb; ++cidx)
-                Ab[((long)(n + cidx) * nb + r) * G + g] = Sinv[((long)r * nb + cidx) * G + g];
+                Ab[lu_ab(L, g, n + cidx, r)] = Sinv[((long)r * nb + cidx) * G + g];
     }
     L.flag[g] = bad ? 1 : 0;
 }
@@ -634,7 +648,7 @@ solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__res
         if (rb < nb) gb[rb] = load_row(n + rb);
     }
     for (int j = 0; j < n; ++j) {
-        const int p = L.piv[(long)j * GL + gl];
+        const int p = L.piv[lu_pv(L, gl, j)];
         double2 yj = w[0];
 #pragma unroll
         for (int d = 1; d <= KLMAX; ++d) {
@@ -647,14 +661,14 @@ solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__res
 #pragma unroll
         for (int i = 1; i <= KLMAX; ++i) {
             if (i <= kl && j + i < n) {
-                const E m = Aw[((long)(j + i) * BW + (kl - i)) * GL + gl];
+                const E m = Aw[lu_aw(L, gl, j + i, kl - i)];
                 El<REAL>::fms2(w[i], m, yj);
             }
         }
 #pragma unroll
         for (int rb = 0; rb < NBMAX; ++rb) {
             if (rb < nb) {
-                const E m = Ab[((long)j * nb + rb) * GL + gl];
+                const E m = Ab[lu_ab(L, gl, j, rb)];
                 El<REAL>::fms2(gb[rb], m, yj);
             }
         }
@@ -679,7 +693,7 @@ solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__res
             double2 acc = make_double2(0.0, 0.0);
 #pragma unroll
             for (int cidx = 0; cidx < NBMAX; ++cidx) {
-                if (cidx < nb) El<REAL>::fma2(acc, Ab[((long)(n + cidx) * nb + r) * GL + gl], gb[cidx]);
+                if (cidx < nb) El<REAL>::fma2(acc, Ab[lu_ab(L, gl, n + cidx, r)], gb[cidx]);
             }
             // border unknown r is logical column n + r
 #pragma unroll
@@ -700,10 +714,10 @@ solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__res
     // ---- backward: win[d] = x[j+1+d]
     for (int j = n - 1; j >= 0; --j) {
         double2 acc = L.scratch[(long)j * G + g];
-        const E *Ur = Aw + ((long)j * BW + kl) * GL + gl;
+        const E *Ur = Aw + lu_aw(L, gl, j, kl);
 #pragma unroll
         for (int d = 0; d < WT; ++d) {
-            if (d < W) El<REAL>::fms2(acc, Ur[(long)(d + 1) * GL], win[d]);
+            if (d < W) El<REAL>::fms2(acc, Ur[(long)(d + 1) << 6], win[d]);
         }
         const double2 xj = El<REAL>::mul2(acc, Ur[0]);   // reciprocal pivot stored on the diagonal
 #pragma unroll
@@ -1002,12 +1016,14 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
         d.n = n; d.nb = nb; d.N = N; d.kl = kl; d.ku = ku; d.W = W; d.BW = kl + W + 1;
         d.real = real ? 1 : 0;
         d.GL = (long)GL;
-        const size_t szAw = esz * (size_t)(n > 0 ? n : 1) * d.BW * GL;
-        const size_t szAb = esz * (size_t)N * (nb > 0 ? nb : 1) * GL;
+        d.nblk = (long)((GL + 63) / 64);
+        const size_t GLp = (size_t)d.nblk * 64;
+        const size_t szAw = esz * (size_t)(n > 0 ? n : 1) * d.BW * GLp;
+        const size_t szAb = esz * (size_t)N * (nb > 0 ? nb : 1) * GLp;
         const size_t szScr = sizeof(double2) * (size_t)std::max(n, nb * nb) * G;
         int st = check_hip(hipMalloc((void **)&d.Aw, szAw), "hipMalloc(band LU)");
         if (!st) st = check_hip(hipMalloc((void **)&d.Ab, szAb), "hipMalloc(border LU)");
-        if (!st) st = check_hip(hipMalloc((void **)&d.piv, (size_t)(n > 0 ? n : 1) * GL), "hipMalloc(piv)");
+        if (!st) st = check_hip(hipMalloc((void **)&d.piv, (size_t)(n > 0 ? n : 1) * GLp), "hipMalloc(piv)");
         if (!st) st = check_hip(hipMalloc((void **)&d.flag, GL), "hipMalloc(flag)");
         if (!st) st = check_hip(hipMalloc((void **)&d.scratch, szScr), "hipMalloc(scratch)");
         if (!st) st = upload_vec(&lu->d_rowperm, row_perm_h, (size_t)N);
@@ -1032,8 +1048,8 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
             }
     }
     LuDev &d = lu->dev;
-    DDH_HIP(hipMemsetAsync(d.Aw, 0, esz * (size_t)(n > 0 ? n : 1) * d.BW * GL, s));
-    DDH_HIP(hipMemsetAsync(d.Ab, 0, esz * (size_t)N * (nb > 0 ? nb : 1) * GL, s));
+    DDH_HIP(hipMemsetAsync(d.Aw, 0, esz * (size_t)(n > 0 ? n : 1) * d.BW * (size_t)d.nblk * 64, s));
+    DDH_HIP(hipMemsetAsync(d.Ab, 0, esz * (size_t)N * (nb > 0 ? nb : 1) * (size_t)d.nblk * 64, s));
     // inverse permutations (physical -> logical) on the device
     std::vector<int> rowinv(N), colinv(N);
     for (int i = 0; i < N; ++i) {
