@@ -29,7 +29,7 @@
 namespace ddh {
 
 constexpr int KLMAX = 16;
-constexpr int NBMAX = 16;
+constexpr int NBMAX = 8;
 
 struct PencilDev {
     int nf;      // separable real-Fourier axes: 0, 1, 2
@@ -598,43 +598,48 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
 // solve: forward sweep (row interchanges, band multipliers, border multipliers), Schur block,
 // backward sweep with a register window of the last W solution entries.
 // ------------------------------------------------------------------------------------------------
-template <int NF, int WT, bool REAL>
+// The solve is split into a forward and a backward kernel (different register needs), both software
+// pipelined: everything row j+1 needs (pivot, multipliers, right-hand side / U row) is requested
+// before row j is consumed, so each row costs one overlapped memory latency instead of several
+// serialized ones.  Permutations and grading codes are staged in LDS.
+template <int NF, bool REAL>
 __global__ void __launch_bounds__(256)
-solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__restrict__ xout) {
+solve_forward_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__restrict__ xout) {
     typedef typename El<REAL>::T E;
+    extern __shared__ int s_lds[];
+    const int N = L.N;
+    int *s_perm = s_lds;                                    // rowperm, then colperm of the border
+    unsigned char *s_code = (unsigned char *)(s_lds + N + L.nb);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        s_perm[i] = L.rowperm[i];
+        s_code[i] = REAL ? L.row_code[i] : 0;
+    }
+    for (int i = threadIdx.x; i < L.nb; i += blockDim.x) {
+        s_perm[N + i] = L.colperm[L.n + i];
+        s_code[N + i] = REAL ? L.col_code[L.n + i] : 0;
+    }
+    __syncthreads();
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= P.G) return;   // G is a multiple of S, pairs never straddle the guard
     const long cell = g / P.S;
     const int s = (int)(g % P.S);
     const CellCtx c = cell_ctx(P, cell);
-    const long G = P.G;            // right-hand sides / scratch
-    const long GL = L.GL;          // stored factorizations
+    const long G = P.G;
     const long gl = REAL ? cell : g;
     const E *Aw = (const E *)L.Aw, *Ab = (const E *)L.Ab;
     const long plane = P.nx * P.ny;
-    const int n = L.n, nb = L.nb, kl = L.kl, W = L.W, BW = L.BW;
+    const int n = L.n, nb = L.nb, kl = L.kl;
 
-    // right-hand side of logical row i, rotated into the real grading when REAL:
-    //   multiply by (-i)^rot, and by -1 for the (-kx) system of x-odd rows
     auto load_row = [&](int i) -> double2 {
-        double2 v = load_sys<NF>(rhs, plane, L.rowperm[i], P, c, s);
+        double2 v = load_sys<NF>(rhs, plane, s_perm[i], P, c, s);
         if (REAL) {
-            const unsigned char code = L.row_code[i];
+            const unsigned char code = s_code[i];
             if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
             if (code & 1) v = make_double2(v.y, -v.x);
         }
         return v;
     };
-    auto store_col = [&](int i, double2 v) {
-        if (REAL) {
-            const unsigned char code = L.col_code[i];
-            if (code & 1) v = make_double2(-v.y, v.x);
-            if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
-        }
-        store_sys<NF>(xout, plane, L.colperm[i], P, c, s, v);
-    };
 
-    // ---- forward
     double2 w[KLMAX + 1];
 #pragma unroll
     for (int d = 0; d <= KLMAX; ++d) {
@@ -647,8 +652,35 @@ solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__res
         gb[rb] = make_double2(0.0, 0.0);
         if (rb < nb) gb[rb] = load_row(n + rb);
     }
+    // prefetch registers for the next row
+    int p_nx = 0;
+    E m_nx[KLMAX], ab_nx[NBMAX];
+    double2 r_nx = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int i = 0; i < KLMAX; ++i) m_nx[i] = El<REAL>::zero();
+#pragma unroll
+    for (int rb = 0; rb < NBMAX; ++rb) ab_nx[rb] = El<REAL>::zero();
+    auto prefetch = [&](int j) {
+        p_nx = L.piv[lu_pv(L, gl, j)];
+#pragma unroll
+        for (int i = 1; i <= KLMAX; ++i)
+            if (i <= kl && j + i < n) m_nx[i - 1] = Aw[lu_aw(L, gl, j + i, kl - i)];
+#pragma unroll
+        for (int rb = 0; rb < NBMAX; ++rb)
+            if (rb < nb) ab_nx[rb] = Ab[lu_ab(L, gl, j, rb)];
+        const int nxt = j + kl + 1;
+        r_nx = (nxt < n) ? load_row(nxt) : make_double2(0.0, 0.0);
+    };
+    if (n > 0) prefetch(0);
     for (int j = 0; j < n; ++j) {
-        const int p = L.piv[lu_pv(L, gl, j)];
+        const int p = p_nx;
+        E m[KLMAX], ab[NBMAX];
+#pragma unroll
+        for (int i = 0; i < KLMAX; ++i) m[i] = m_nx[i];
+#pragma unroll
+        for (int rb = 0; rb < NBMAX; ++rb) ab[rb] = ab_nx[rb];
+        const double2 rnew = r_nx;
+        if (j + 1 < n) prefetch(j + 1);
         double2 yj = w[0];
 #pragma unroll
         for (int d = 1; d <= KLMAX; ++d) {
@@ -659,72 +691,105 @@ solve_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__res
         }
         L.scratch[(long)j * G + g] = yj;
 #pragma unroll
-        for (int i = 1; i <= KLMAX; ++i) {
-            if (i <= kl && j + i < n) {
-                const E m = Aw[lu_aw(L, gl, j + i, kl - i)];
-                El<REAL>::fms2(w[i], m, yj);
-            }
-        }
+        for (int i = 1; i <= KLMAX; ++i)
+            if (i <= kl && j + i < n) El<REAL>::fms2(w[i], m[i - 1], yj);
 #pragma unroll
-        for (int rb = 0; rb < NBMAX; ++rb) {
-            if (rb < nb) {
-                const E m = Ab[lu_ab(L, gl, j, rb)];
-                El<REAL>::fms2(gb[rb], m, yj);
-            }
-        }
+        for (int rb = 0; rb < NBMAX; ++rb)
+            if (rb < nb) El<REAL>::fms2(gb[rb], ab[rb], yj);
 #pragma unroll
         for (int d = 0; d < KLMAX; ++d) w[d] = w[d + 1];
         w[KLMAX] = make_double2(0.0, 0.0);
-        const int nxt = j + kl + 1;
-        if (nxt < n) {
-            const double2 v = load_row(nxt);
 #pragma unroll
-            for (int d = 0; d <= KLMAX; ++d)
-                if (d == kl) w[d] = v;
-        }
+        for (int d = 0; d <= KLMAX; ++d)
+            if (d == kl) w[d] = rnew;
     }
-    // ---- Schur block: z = Sinv * gb
-    double2 win[WT];
-#pragma unroll
-    for (int d = 0; d < WT; ++d) win[d] = make_double2(0.0, 0.0);
+    // ---- Schur block: z = Sinv * gb ; border unknown r is logical column n + r
 #pragma unroll
     for (int r = 0; r < NBMAX; ++r) {
         if (r < nb) {
             double2 acc = make_double2(0.0, 0.0);
 #pragma unroll
-            for (int cidx = 0; cidx < NBMAX; ++cidx) {
+            for (int cidx = 0; cidx < NBMAX; ++cidx)
                 if (cidx < nb) El<REAL>::fma2(acc, Ab[lu_ab(L, gl, n + cidx, r)], gb[cidx]);
+            L.scratch[(long)(n + r) * G + g] = acc;     // graded value for the backward sweep
+            double2 v = acc;
+            if (REAL) {
+                const unsigned char code = s_code[N + r];
+                if (code & 1) v = make_double2(-v.y, v.x);
+                if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
             }
-            // border unknown r is logical column n + r
-#pragma unroll
-            for (int d = 0; d < WT; ++d)
-                if (d == r) win[d] = acc;
+            store_sys<NF>(xout, plane, s_perm[N + r], P, c, s, v);
         }
     }
-#pragma unroll
-    for (int r = 0; r < NBMAX; ++r) {
-        if (r < nb) {
-            double2 z = make_double2(0.0, 0.0);
-#pragma unroll
-            for (int d = 0; d < WT; ++d)
-                if (d == r) z = win[d];
-            store_col(n + r, z);
-        }
+}
+
+template <int NF, int WT, bool REAL>
+__global__ void __launch_bounds__(256)
+solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
+    typedef typename El<REAL>::T E;
+    extern __shared__ int s_lds[];
+    const int n = L.n, nb = L.nb, kl = L.kl, W = L.W;
+    int *s_perm = s_lds;
+    unsigned char *s_code = (unsigned char *)(s_lds + n);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        s_perm[i] = L.colperm[i];
+        s_code[i] = REAL ? L.col_code[i] : 0;
     }
-    // ---- backward: win[d] = x[j+1+d]
-    for (int j = n - 1; j >= 0; --j) {
-        double2 acc = L.scratch[(long)j * G + g];
+    __syncthreads();
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P.G) return;
+    const long cell = g / P.S;
+    const int s = (int)(g % P.S);
+    const CellCtx c = cell_ctx(P, cell);
+    const long G = P.G;
+    const long gl = REAL ? cell : g;
+    const E *Aw = (const E *)L.Aw;
+    const long plane = P.nx * P.ny;
+
+    double2 win[WT];   // win[d] = x[j+1+d] (graded)
+#pragma unroll
+    for (int d = 0; d < WT; ++d) {
+        win[d] = make_double2(0.0, 0.0);
+        if (d < nb) win[d] = L.scratch[(long)(n + d) * G + g];
+    }
+    E ua[WT + 1], ub[WT + 1];
+    double2 ya = make_double2(0.0, 0.0), yb = ya;
+#pragma unroll
+    for (int d = 0; d <= WT; ++d) ua[d] = ub[d] = El<REAL>::zero();
+    auto fetch = [&](int j, E *u, double2 &y) {
+        y = L.scratch[(long)j * G + g];
         const E *Ur = Aw + lu_aw(L, gl, j, kl);
 #pragma unroll
-        for (int d = 0; d < WT; ++d) {
-            if (d < W) El<REAL>::fms2(acc, Ur[(long)(d + 1) << 6], win[d]);
-        }
-        const double2 xj = El<REAL>::mul2(acc, Ur[0]);   // reciprocal pivot stored on the diagonal
+        for (int d = 0; d <= WT; ++d)
+            if (d <= W) u[d] = Ur[(long)d << 6];
+    };
+    auto body = [&](int j, const E *u, double2 y) {
+        double2 acc = y;
+#pragma unroll
+        for (int d = 0; d < WT; ++d)
+            if (d < W) El<REAL>::fms2(acc, u[d + 1], win[d]);
+        const double2 xj = El<REAL>::mul2(acc, u[0]);   // reciprocal pivot stored on the diagonal
 #pragma unroll
         for (int d = WT - 1; d > 0; --d) win[d] = win[d - 1];
         win[0] = xj;
-        store_col(j, xj);
+        double2 v = xj;
+        if (REAL) {
+            const unsigned char code = s_code[j];
+            if (code & 1) v = make_double2(-v.y, v.x);
+            if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+        }
+        store_sys<NF>(xout, plane, s_perm[j], P, c, s, v);
+    };
+    int j = n - 1;
+    if (j >= 0) fetch(j, ua, ya);
+    while (j >= 1) {
+        fetch(j - 1, ub, yb);
+        body(j, ua, ya);
+        if (j - 2 >= 0) fetch(j - 2, ua, ya);
+        body(j - 1, ub, yb);
+        j -= 2;
     }
+    if (j == 0) body(0, ua, ya);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -791,20 +856,28 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
     const LuDev &d = lu->dev;
     const unsigned blocks = (unsigned)((P.G + 255) / 256);
     const int W = d.W;
-#define DDH_SOLVE(WTV)                                                                                         \
-    {                                                                                                          \
-        if (d.real)                                                                                            \
-            hipLaunchKernelGGL((solve_kernel<NF, WTV, true>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);    \
-        else                                                                                                   \
-            hipLaunchKernelGGL((solve_kernel<NF, WTV, false>), dim3(blocks), dim3(256), 0, s, P, d, rhs, x);   \
+    const size_t lds_f = (size_t)(d.N + d.nb) * 5 + 16, lds_b = (size_t)(d.n > 0 ? d.n : 1) * 5 + 16;
+    if (lds_f > 64 * 1024) return fail("pencil_solve: system too large for the LDS permutation cache");
+    if (d.real)
+        hipLaunchKernelGGL((solve_forward_kernel<NF, true>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x);
+    else
+        hipLaunchKernelGGL((solve_forward_kernel<NF, false>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x);
+#define DDH_SOLVE(WTV)                                                                                            \
+    {                                                                                                             \
+        if (d.real)                                                                                               \
+            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
+        else                                                                                                      \
+            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
     }
-    if (W <= 8) DDH_SOLVE(8)
-    else if (W <= 16) DDH_SOLVE(16)
-    else if (W <= 24) DDH_SOLVE(24)
-    else if (W <= 32) DDH_SOLVE(32)
-    else if (W <= 40) DDH_SOLVE(40)
-    else if (W <= 48) DDH_SOLVE(48)
-    else DDH_SOLVE(64)
+    if (d.n > 0) {
+        if (W <= 8) DDH_SOLVE(8)
+        else if (W <= 16) DDH_SOLVE(16)
+        else if (W <= 24) DDH_SOLVE(24)
+        else if (W <= 32) DDH_SOLVE(32)
+        else if (W <= 40) DDH_SOLVE(40)
+        else if (W <= 48) DDH_SOLVE(48)
+        else DDH_SOLVE(64)
+    }
 #undef DDH_SOLVE
     DDH_HIP(hipGetLastError());
     if (lu->nflag) {
@@ -993,7 +1066,7 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
     const int N = P.nrows, n = n_interior, nb = N - n;
     if (n < 0 || nb < 0) return fail("pencil_factor: bad interior size");
     if (kl > KLMAX) return fail("pencil_factor: lower bandwidth " + std::to_string(kl) + " exceeds KLMAX=16");
-    if (nb > NBMAX) return fail("pencil_factor: border size " + std::to_string(nb) + " exceeds NBMAX=16");
+    if (nb > NBMAX) return fail("pencil_factor: border size " + std::to_string(nb) + " exceeds NBMAX=8");
     const int W = ku + kl;
     if (W > 64) return fail("pencil_factor: band too wide (ku+kl=" + std::to_string(W) + " > 64)");
     if (nb > W && n > 0) return fail("pencil_factor: border wider than the band window");
@@ -1020,7 +1093,7 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
         const size_t GLp = (size_t)d.nblk * 64;
         const size_t szAw = esz * (size_t)(n > 0 ? n : 1) * d.BW * GLp;
         const size_t szAb = esz * (size_t)N * (nb > 0 ? nb : 1) * GLp;
-        const size_t szScr = sizeof(double2) * (size_t)std::max(n, nb * nb) * G;
+        const size_t szScr = sizeof(double2) * (size_t)std::max(n + nb, nb * nb) * G;
         int st = check_hip(hipMalloc((void **)&d.Aw, szAw), "hipMalloc(band LU)");
         if (!st) st = check_hip(hipMalloc((void **)&d.Ab, szAb), "hipMalloc(border LU)");
         if (!st) st = check_hip(hipMalloc((void **)&d.piv, (size_t)(n > 0 ? n : 1) * GLp), "hipMalloc(piv)");
