@@ -159,12 +159,73 @@ __device__ __forceinline__ void butterfly<7>(double2 *v, int sign) {
     }
 }
 
+__device__ __forceinline__ void dft4_inplace(double2 &v0, double2 &v1, double2 &v2, double2 &v3, int sign) {
+    const double2 a = cadd(v0, v2), b = csub(v0, v2);
+    const double2 c = cadd(v1, v3), d = muli(csub(v1, v3), sign);
+    v0 = cadd(a, c);
+    v1 = cadd(b, d);
+    v2 = csub(a, c);
+    v3 = csub(b, d);
+}
+// multiply by exp(sign * 2 pi i * q / 16), q = 0..9 (constants)
+__device__ __forceinline__ double2 mul_w16(double2 a, int q, int sign) {
+    const double c1 = 0.92387953251128675612818318939679;   // cos(pi/8)
+    const double s1 = 0.38268343236508977172845998403040;   // sin(pi/8)
+    const double r2 = 0.70710678118654752440084436210485;   // sqrt(1/2)
+    double wr, wi;
+    switch (q) {
+        case 0: return a;
+        case 1: wr = c1; wi = s1; break;
+        case 2: wr = r2; wi = r2; break;
+        case 3: wr = s1; wi = c1; break;
+        case 4: return muli(a, sign);
+        case 6: wr = -r2; wi = r2; break;
+        default: wr = -c1; wi = -s1; break;   // q == 9
+    }
+    if (sign < 0) wi = -wi;
+    return make_double2(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
+}
+template <>
+__device__ __forceinline__ void butterfly<8>(double2 *v, int sign) {
+    // n = 2 n1 + n2, k = k1 + 4 k2
+    double2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    double2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4_inplace(e0, e1, e2, e3, sign);
+    dft4_inplace(o0, o1, o2, o3, sign);
+    o1 = mul_w16(o1, 2, sign);
+    o2 = mul_w16(o2, 4, sign);
+    o3 = mul_w16(o3, 6, sign);
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+template <>
+__device__ __forceinline__ void butterfly<16>(double2 *v, int sign) {
+    // n = 4 n1 + n2, k = k1 + 4 k2: DFT4 over n1 for each n2, twiddle W16^(n2 k1), DFT4 over n2 for each k1
+    double2 y[4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) {
+        y[n2][0] = v[n2]; y[n2][1] = v[4 + n2]; y[n2][2] = v[8 + n2]; y[n2][3] = v[12 + n2];
+        dft4_inplace(y[n2][0], y[n2][1], y[n2][2], y[n2][3], sign);
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+        double2 c0 = y[0][k1];
+        double2 c1 = mul_w16(y[1][k1], k1, sign);
+        double2 c2 = mul_w16(y[2][k1], 2 * k1, sign);
+        double2 c3 = mul_w16(y[3][k1], 3 * k1, sign);
+        dft4_inplace(c0, c1, c2, c3, sign);
+        v[k1] = c0; v[k1 + 4] = c1; v[k1 + 8] = c2; v[k1 + 12] = c3;
+    }
+}
+
 // One Stockham pass of radix R over B lines of length N held in buf[line*ld + j].
 template <int R>
 __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int Ns, const FastDiv &fd_nb,
                                          const FastDiv &fd_ns, const double2 *__restrict__ tw, int sign, int tid,
                                          int T) {
-    constexpr int MAXI = (12 / R) > 0 ? (12 / R) : 1;   // <= 12 complex values staged per thread
+    constexpr int MAXI = (12 + R - 1) / R;   // ceil(12 / R): at least 12 (at most 16) complex values staged per thread
     const int nb = N / R;
     const int total = nb * B;
     const int twstep = nb / Ns;  // N / (Ns*R)
@@ -217,6 +278,8 @@ __device__ __forceinline__ void lds_fft(double2 *buf, const FftDev &p, int sign,
             case 3: fft_pass<3>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
             case 4: fft_pass<4>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
             case 5: fft_pass<5>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
+            case 8: fft_pass<8>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
+            case 16: fft_pass<16>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
             default: fft_pass<7>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
         }
         Ns *= R;
@@ -579,6 +642,8 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
 // ------------------------------------------------------------------------------------------------
 static bool factorize(int n, int *radix, int &nradix) {
     nradix = 0;
+    while (n % 16 == 0) { radix[nradix++] = 16; n /= 16; }
+    while (n % 8 == 0) { radix[nradix++] = 8; n /= 8; }
     while (n % 4 == 0) { radix[nradix++] = 4; n /= 4; }
     while (n % 2 == 0) { radix[nradix++] = 2; n /= 2; }
     while (n % 3 == 0) { radix[nradix++] = 3; n /= 3; }
