@@ -220,6 +220,10 @@ __device__ __forceinline__ void butterfly<16>(double2 *v, int sign) {
     }
 }
 
+// LDS index padding: one extra element after every 16 (= one 256-B bank row), so that the stride-R
+// writes of the first Stockham pass (and the DCT permutation) spread over the banks.
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
+
 // One Stockham pass of radix R over B lines of length N held in buf[line*ld + j].
 template <int R>
 __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int Ns, const FastDiv &fd_nb,
@@ -240,7 +244,7 @@ __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int
             const int line = (int)uline, j = (int)uj, k = (int)uk;
             const double2 *x = buf + line * ld;
 #pragma unroll
-            for (int t = 0; t < R; ++t) v[it][t] = x[j + t * nb];
+            for (int t = 0; t < R; ++t) v[it][t] = x[lpad(j + t * nb)];
             if (Ns > 1) {
 #pragma unroll
                 for (int t = 1; t < R; ++t) {
@@ -263,7 +267,7 @@ __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int
             double2 *x = buf + (int)uline * ld;
             const int j0 = ((int)uj - (int)uk) * R + (int)uk;
 #pragma unroll
-            for (int u = 0; u < R; ++u) x[j0 + u * Ns] = v[it][u];
+            for (int u = 0; u < R; ++u) x[lpad(j0 + u * Ns)] = v[it][u];
         }
     }
     __syncthreads();
@@ -375,7 +379,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             split_item<INNER>(w, p.fdB, p.fdN, j, b);
             double2 v = make_double2(0.0, 0.0);
             if (q0 + b < npairs) v = io.load(src, N, j, q0 + b);
-            buf[b * ld + j] = v;
+            buf[b * ld + lpad(j)] = v;
         }
     } else if (MODE == RFFT_BWD) {
         const int K = p.K;
@@ -385,7 +389,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             unsigned q, r;
             p.fdB.divmod((unsigned)w, q, r);
             const int b = (int)r, j = (int)q;
-            buf[b * ld + K + 1 + j] = make_double2(0.0, 0.0);
+            buf[b * ld + lpad(K + 1 + j)] = make_double2(0.0, 0.0);
         }
         if (INNER) {
             for (int w = tid; w < (K + 1) * B; w += T) {
@@ -400,8 +404,8 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 if (k == 0) {
                     buf[b * ld] = c;  // a0 of line a + i a0 of line b
                 } else {
-                    buf[b * ld + k] = make_double2(0.5 * (c.x - s.y), 0.5 * (s.x + c.y));
-                    buf[b * ld + N - k] = make_double2(0.5 * (c.x + s.y), 0.5 * (c.y - s.x));
+                    buf[b * ld + lpad(k)] = make_double2(0.5 * (c.x - s.y), 0.5 * (s.x + c.y));
+                    buf[b * ld + lpad(N - k)] = make_double2(0.5 * (c.x + s.y), 0.5 * (c.y - s.x));
                 }
             }
         } else {
@@ -418,8 +422,8 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 if (k == 0) {
                     buf[b * ld] = c;
                 } else {
-                    buf[b * ld + k] = make_double2(0.5 * (c.x - s.y), 0.5 * (s.x + c.y));
-                    buf[b * ld + N - k] = make_double2(0.5 * (c.x + s.y), 0.5 * (c.y - s.x));
+                    buf[b * ld + lpad(k)] = make_double2(0.5 * (c.x - s.y), 0.5 * (s.x + c.y));
+                    buf[b * ld + lpad(N - k)] = make_double2(0.5 * (c.x + s.y), 0.5 * (c.y - s.x));
                 }
             }
         }
@@ -429,7 +433,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             split_item<INNER>(w, p.fdB, p.fdN, j, b);
             double2 v = make_double2(0.0, 0.0);
             if (q0 + b < npairs) v = io.load(src, N, j, q0 + b);
-            buf[b * ld + dct_perm(j, N)] = v;
+            buf[b * ld + lpad(dct_perm(j, N))] = v;
         }
     } else if (MODE == CHEB_BWD) {
         for (int w = tid; w < M * B; w += T) {
@@ -487,7 +491,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             // V^a = (e.x - i f.x)(cr + i ci), V^b likewise with .y ; Z = V^a + i V^b
             const double var = e.x * cr + f.x * ci, vai = e.x * ci - f.x * cr;
             const double vbr = e.y * cr + f.y * ci, vbi = e.y * ci - f.y * cr;
-            buf[b * ld + k] = make_double2(var - vbi, vai + vbr);
+            buf[b * ld + lpad(k)] = make_double2(var - vbi, vai + vbr);
         }
     } else if (MODE == CFFT_FWD) {
         // complex lines, no pairing: "pair" slot = one complex line; load() returns (re, im)
@@ -501,7 +505,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                                           : src + 2 * (line * N + j);
                 v = *reinterpret_cast<const double2 *>(ptr);
             }
-            buf[b * ld + j] = v;
+            buf[b * ld + lpad(j)] = v;
         }
     } else if (MODE == CFFT_BWD) {
         const int K = p.K;
@@ -518,7 +522,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                                           : src + 2 * (line * M + m);
                 v = *reinterpret_cast<const double2 *>(ptr);
             }
-            buf[b * ld + j] = v;
+            buf[b * ld + lpad(j)] = v;
         }
     }
     __syncthreads();
@@ -534,7 +538,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             split_item<INNER>(w, p.fdB, p.fdN, j, b);
             if (q0 + b < npairs) {
                 const int pos = (MODE == CHEB_BWD) ? dct_perm(j, N) : j;
-                io.store(dst, N, j, q0 + b, buf[b * ld + pos]);
+                io.store(dst, N, j, q0 + b, buf[b * ld + lpad(pos)]);
             }
         }
     } else if (MODE == RFFT_FWD) {
@@ -549,7 +553,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 const double2 z = buf[b * ld];
                 c = make_double2(z.x * invN, z.y * invN);
             } else if (k <= K) {
-                const double2 z1 = buf[b * ld + k], z2 = buf[b * ld + N - k];
+                const double2 z1 = buf[b * ld + lpad(k)], z2 = buf[b * ld + lpad(N - k)];
                 c = make_double2((z1.x + z2.x) * invN, (z1.y + z2.y) * invN);
                 s = make_double2((z1.y - z2.y) * invN, (z2.x - z1.x) * invN);
             }
@@ -565,7 +569,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 if (q0 + b >= npairs) continue;
                 double2 c = make_double2(0.0, 0.0);
                 if (k < Mk) {
-                    const double2 z1 = buf[b * ld + k], z2 = buf[b * ld + ((k == 0) ? 0 : N - k)];
+                    const double2 z1 = buf[b * ld + lpad(k)], z2 = buf[b * ld + lpad(((k == 0) ? 0 : N - k))];
                     const double2 h = p.half[k];
                     const double s = p.fscale[k];
                     c.x = s * ((z1.x + z2.x) * h.x - (z1.y - z2.y) * h.y);
@@ -580,7 +584,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 const int k = (int)r, b = (int)q;
                 double2 c = make_double2(0.0, 0.0);
                 if (k < Mk) {
-                    const double2 z1 = buf[b * ld + k], z2 = buf[b * ld + ((k == 0) ? 0 : N - k)];
+                    const double2 z1 = buf[b * ld + lpad(k)], z2 = buf[b * ld + lpad(((k == 0) ? 0 : N - k))];
                     const double2 h = p.half[k];
                     const double s = p.fscale[k];
                     c.x = s * ((z1.x + z2.x) * h.x - (z1.y - z2.y) * h.y);
@@ -618,7 +622,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             const int k = (m <= KM) ? m : m - M;
             double2 v = make_double2(0.0, 0.0);
             if (k >= -K && k <= K && !(2 * m == M)) {
-                const double2 z = buf[b * ld + ((k >= 0) ? k : N + k)];
+                const double2 z = buf[b * ld + lpad(((k >= 0) ? k : N + k))];
                 v = make_double2(z.x * invN, z.y * invN);
             }
             const long line = q0 + b;
@@ -632,7 +636,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             if (q0 + b >= npairs) continue;
             const long line = q0 + b;
             double *ptr = INNER ? dst + 2 * ((io.outer_idx * N + j) * inner + line) : dst + 2 * (line * N + j);
-            *reinterpret_cast<double2 *>(ptr) = buf[b * ld + j];
+            *reinterpret_cast<double2 *>(ptr) = buf[b * ld + lpad(j)];
         }
     }
 }
@@ -744,7 +748,7 @@ static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nba
         delete pl;
         return st;
     }
-    d.ld = N;
+    d.ld = N + (N >> 4) + 1;
     d.fdN.set((unsigned)N);
     d.fdM.set((unsigned)M);
     d.fdMh.set((unsigned)(M / 2 > 0 ? M / 2 : 1));
@@ -776,7 +780,7 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     // so that at least two workgroups share a CU) and by 12 staged values per thread.
     const int N = d.N, M = d.M;
     const bool cheb = (MODE == CHEB_FWD || MODE == CHEB_BWD);
-    const size_t per_line = (size_t)(N + (cheb ? M : 0)) * sizeof(double2);
+    const size_t per_line = (size_t)(d.ld + (cheb ? M : 0)) * sizeof(double2);
     int B = inner_mode ? 4 : 2;
     while (B > 1 && per_line * B > 64 * 1024) B /= 2;
     if ((long)B > npairs) B = (int)npairs;

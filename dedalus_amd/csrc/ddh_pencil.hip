@@ -874,6 +874,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
         else if (W <= 16) DDH_SOLVE(16)
         else if (W <= 24) DDH_SOLVE(24)
         else if (W <= 32) DDH_SOLVE(32)
+        else if (W <= 36) DDH_SOLVE(36)
         else if (W <= 40) DDH_SOLVE(40)
         else if (W <= 48) DDH_SOLVE(48)
         else DDH_SOLVE(64)
