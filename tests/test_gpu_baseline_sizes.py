@@ -1,0 +1,65 @@
+"""GPU known-answer tests at BASELINE.json configuration sizes.
+
+The expected numbers are the reference's own end-state checksums measured during the survey by
+running the unmodified reference:
+  KdV-Burgers N=1024, SBDF2, dt=2e-3, 200 steps      sum(u_g^2)  = 1.017795766558e+02
+  2-D RB 512x256, RK222, dt=1e-3, 13 steps           ||b_c||_2   = 1.085400858051743e+00
+  2-D RB 256x64,  RK222, dt=1e-3, 23 steps           ||b_c||_2   = 1.085400744860160e+00
+  3-D RB 32x32x32, RK222, dt=1e-3, 5 steps           ||b_c||_2   = 1.085405276538733e+00
+plus size-independent properties at the full 3-D benchmark size (run by bench.py, not here)."""
+import numpy as np
+import pytest
+
+import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def test_kdv_1024_known_answer():
+    import dedalus_amd.public as d3
+    solver, f = problems.kdv_burgers(d3, Nx=1024, timestepper="SBDF2")
+    for _ in range(200):
+        solver.step(2e-3)
+    f["u"].change_scales(1)
+    val = float(np.sum(np.asarray(f["u"]["g"]) ** 2))
+    assert abs(val - 1.017795766558e+02) / 1.017795766558e+02 < 1e-10, val
+
+
+@pytest.mark.parametrize("Nx,Nz,steps,expect", [(512, 256, 13, 1.085400858051743e+00),
+                                                (256, 64, 23, 1.085400744860160e+00)])
+def test_rb2d_known_answer(Nx, Nz, steps, expect):
+    import dedalus_amd.public as d3
+    solver, f = problems.rayleigh_benard_2d(d3, Nx=Nx, Nz=Nz, timestepper="RK222")
+    for _ in range(steps):
+        solver.step(1e-3)
+    val = float(np.sqrt(np.sum(np.asarray(f["b"]["c"]) ** 2)))
+    assert abs(val - expect) / expect < 1e-12, val
+
+
+def test_rb3d_32_known_answer():
+    import dedalus_amd.public as d3
+    solver, f = problems.rayleigh_benard_3d(d3, Nx=32, Ny=32, Nz=32, timestepper="RK222")
+    for _ in range(5):
+        solver.step(1e-3)
+    val = float(np.sqrt(np.sum(np.asarray(f["b"]["c"]) ** 2)))
+    assert abs(val - 1.085405276538733e+00) / 1.085405276538733e+00 < 1e-12, val
+
+
+def test_rb3d_properties_medium_size():
+    """Size-independent properties on a larger 3-D run: boundary conditions hold, the k=0 msin parts
+    stay zero (valid-mode structure), divergence-free to solver precision."""
+    import dedalus_amd.public as d3
+    solver, f = problems.rayleigh_benard_3d(d3, Nx=64, Ny=64, Nz=32, timestepper="RK222")
+    for _ in range(3):
+        solver.step(1e-3)
+    u, b = f["u"], f["b"]
+    uc = np.asarray(u["c"])
+    assert np.abs(uc[:, 1, :, :]).max() == 0.0          # msin part of kx = 0
+    assert np.abs(uc[:, :, 1, :]).max() == 0.0          # msin part of ky = 0
+    div = d3.div(u).evaluate()
+    assert np.abs(np.asarray(div["c"])[..., :-2]).max() < 1e-10      # tau terms live in the last modes
+    top = b(z=1).evaluate()
+    bot = b(z=0).evaluate()
+    assert np.abs(np.asarray(top["c"])).max() < 1e-12
+    bc = np.asarray(bot["c"]).ravel()
+    assert abs(bc[0] - 1.0) < 1e-12 and np.abs(bc[1:]).max() < 1e-12
