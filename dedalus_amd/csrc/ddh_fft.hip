@@ -373,7 +373,21 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     const double invN = 1.0 / (double)N;
 
     // ---------------------------------------------------------------- load + pre-process
-    if (MODE == RFFT_FWD) {
+    if (MODE == RFFT_FWD && !INNER && (N % 2 == 0)) {
+        const int Nh = N / 2;
+        for (int b = 0; b < B; ++b) {
+            const bool has_a = (q0 + b < npairs);
+            const bool has_b = has_a && (2 * (q0 + b) + 1 < io.nlines);
+            const double *pa = src + (2 * (q0 + b)) * (long)N;
+            for (int jh = tid; jh < Nh; jh += T) {
+                double2 va = make_double2(0.0, 0.0), vb = va;
+                if (has_a) va = *reinterpret_cast<const double2 *>(pa + 2 * jh);
+                if (has_b) vb = *reinterpret_cast<const double2 *>(pa + N + 2 * jh);
+                buf[b * ld + lpad(2 * jh)] = make_double2(va.x, vb.x);
+                buf[b * ld + lpad(2 * jh + 1)] = make_double2(va.y, vb.y);
+            }
+        }
+    } else if (MODE == RFFT_FWD) {
         for (int w = tid; w < N * B; w += T) {
             int j, b;
             split_item<INNER>(w, p.fdB, p.fdN, j, b);
@@ -416,8 +430,13 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 const int k = (int)r, b = (int)q;
                 double2 c = make_double2(0.0, 0.0), s = c;
                 if (q0 + b < npairs) {
-                    c = io.load(src, M, 2 * k, q0 + b);
-                    s = io.load(src, M, 2 * k + 1, q0 + b);
+                    // (cos, msin) of mode k are adjacent: one 16-byte load per line
+                    const double *pa = src + (2 * (q0 + b)) * (long)M + 2 * k;
+                    const double2 va = *reinterpret_cast<const double2 *>(pa);
+                    double2 vb = make_double2(0.0, 0.0);
+                    if (2 * (q0 + b) + 1 < io.nlines) vb = *reinterpret_cast<const double2 *>(pa + M);
+                    c = make_double2(va.x, vb.x);
+                    s = make_double2(va.y, vb.y);
                 }
                 if (k == 0) {
                     buf[b * ld] = c;
@@ -532,7 +551,20 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     lds_fft(buf, p, sign, tid, T);
 
     // ---------------------------------------------------------------- post-process + store
-    if (MODE == RFFT_BWD || MODE == CHEB_BWD) {
+    if (MODE == RFFT_BWD && !INNER && (N % 2 == 0)) {
+        // contiguous lines: each thread stores two consecutive grid points of line a and of line b (16 B each)
+        const int Nh = N / 2;
+        for (int b = 0; b < B; ++b) {
+            if (q0 + b >= npairs) break;
+            double *pa = dst + (2 * (q0 + b)) * (long)N;
+            const bool has_b = (2 * (q0 + b) + 1 < io.nlines);
+            for (int jh = tid; jh < Nh; jh += T) {
+                const double2 z0 = buf[b * ld + lpad(2 * jh)], z1 = buf[b * ld + lpad(2 * jh + 1)];
+                *reinterpret_cast<double2 *>(pa + 2 * jh) = make_double2(z0.x, z1.x);
+                if (has_b) *reinterpret_cast<double2 *>(pa + N + 2 * jh) = make_double2(z0.y, z1.y);
+            }
+        }
+    } else if (MODE == RFFT_BWD || MODE == CHEB_BWD) {
         for (int w = tid; w < N * B; w += T) {
             int j, b;
             split_item<INNER>(w, p.fdB, p.fdN, j, b);
@@ -557,8 +589,14 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 c = make_double2((z1.x + z2.x) * invN, (z1.y + z2.y) * invN);
                 s = make_double2((z1.y - z2.y) * invN, (z2.x - z1.x) * invN);
             }
-            io.store(dst, M, 2 * k, q0 + b, c);
-            io.store(dst, M, 2 * k + 1, q0 + b, s);
+            if (!INNER) {
+                double *pa = dst + (2 * (q0 + b)) * (long)M + 2 * k;
+                *reinterpret_cast<double2 *>(pa) = make_double2(c.x, s.x);
+                if (2 * (q0 + b) + 1 < io.nlines) *reinterpret_cast<double2 *>(pa + M) = make_double2(c.y, s.y);
+            } else {
+                io.store(dst, M, 2 * k, q0 + b, c);
+                io.store(dst, M, 2 * k + 1, q0 + b, s);
+            }
         }
     } else if (MODE == CHEB_FWD) {
         const int Mk = (M < N) ? M : N;

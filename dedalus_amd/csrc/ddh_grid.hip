@@ -44,23 +44,39 @@ struct BilArgs {
     double coef[MAX_BIL];
 };
 
+// Each operand component is loaded once per point (terms are sorted by (ia, ib) on the host); the
+// NOUT accumulators live in registers.
+template <int NOUT>
 __global__ void __launch_bounds__(256)
 bilinear_kernel(double *__restrict__ out, const double *__restrict__ a, const double *__restrict__ b, long n,
                 BilArgs args) {
     const long n2 = n >> 1;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        for (int c = 0; c < args.ncomp_out; ++c) {
-            double2 acc = make_double2(0.0, 0.0);
-            for (int t = 0; t < args.nterms; ++t) {
-                if (args.ic[t] != c) continue;
-                const double2 av = reinterpret_cast<const double2 *>(a + (long)args.ia[t] * n)[i];
-                const double2 bv = reinterpret_cast<const double2 *>(b + (long)args.ib[t] * n)[i];
-                acc.x += args.coef[t] * av.x * bv.x;
-                acc.y += args.coef[t] * av.y * bv.y;
+        double2 acc[NOUT];
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c) acc[c] = make_double2(0.0, 0.0);
+        int last_a = -1, last_b = -1;
+        double2 av = make_double2(0.0, 0.0), bv = av;
+        for (int t = 0; t < args.nterms; ++t) {
+            if (args.ia[t] != last_a) {
+                last_a = args.ia[t];
+                av = reinterpret_cast<const double2 *>(a + (long)last_a * n)[i];
             }
-            reinterpret_cast<double2 *>(out + (long)c * n)[i] = acc;
+            if (args.ib[t] != last_b) {
+                last_b = args.ib[t];
+                bv = reinterpret_cast<const double2 *>(b + (long)last_b * n)[i];
+            }
+            const double cf = args.coef[t];
+            const double2 pr = make_double2(cf * av.x * bv.x, cf * av.y * bv.y);
+            const int ic = args.ic[t];
+#pragma unroll
+            for (int c = 0; c < NOUT; ++c)
+                if (ic == c) { acc[c].x += pr.x; acc[c].y += pr.y; }
         }
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c)
+            if (c < args.ncomp_out) reinterpret_cast<double2 *>(out + (long)c * n)[i] = acc[c];
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         for (int c = 0; c < args.ncomp_out; ++c) {
@@ -184,17 +200,38 @@ int ddh_grid_bilinear(double *out, int ncomp_out, const double *a, const double 
         // component offsets c*n must stay 16-byte aligned for the vector path
         if (ncomp_out > 1) return fail("ddh_grid_bilinear: odd point count with several components unsupported");
     }
+    if (ncomp_out > 9) return fail("ddh_grid_bilinear: at most 9 output components");
     BilArgs args;
     args.nterms = nterms;
     args.ncomp_out = ncomp_out;
-    for (int t = 0; t < nterms; ++t) {
-        args.ic[t] = ic_h[t];
-        args.ia[t] = ia_h[t];
-        args.ib[t] = ib_h[t];
-        args.coef[t] = coef_h[t];
+    // sort terms by (ia, ib) so that every operand component is read once per point
+    int order[MAX_BIL];
+    for (int t = 0; t < nterms; ++t) order[t] = t;
+    for (int i = 1; i < nterms; ++i) {
+        int key = order[i], j = i - 1;
+        while (j >= 0 && (ia_h[order[j]] > ia_h[key] || (ia_h[order[j]] == ia_h[key] && ib_h[order[j]] > ib_h[key]))) {
+            order[j + 1] = order[j];
+            --j;
+        }
+        order[j + 1] = key;
+    }
+    for (int k = 0; k < nterms; ++k) {
+        const int t = order[k];
+        args.ic[k] = ic_h[t];
+        args.ia[k] = ia_h[t];
+        args.ib[k] = ib_h[t];
+        args.coef[k] = coef_h[t];
+        if (ic_h[t] < 0 || ic_h[t] >= ncomp_out) return fail("ddh_grid_bilinear: output component out of range");
         if ((n & 1) && (ia_h[t] || ib_h[t])) return fail("ddh_grid_bilinear: odd point count with several components unsupported");
     }
-    hipLaunchKernelGGL(bilinear_kernel, dim3(stream_grid(n / 2)), dim3(256), 0, as_stream(stream), out, a, b, n, args);
+    const dim3 grid(stream_grid(n / 2)), block(256);
+    hipStream_t st = as_stream(stream);
+    if (ncomp_out <= 1)
+        hipLaunchKernelGGL(bilinear_kernel<1>, grid, block, 0, st, out, a, b, n, args);
+    else if (ncomp_out <= 3)
+        hipLaunchKernelGGL(bilinear_kernel<3>, grid, block, 0, st, out, a, b, n, args);
+    else
+        hipLaunchKernelGGL(bilinear_kernel<9>, grid, block, 0, st, out, a, b, n, args);
     DDH_HIP(hipGetLastError());
     return 0;
 }

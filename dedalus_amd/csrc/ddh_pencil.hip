@@ -763,15 +763,7 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         for (int d = 0; d <= WT; ++d)
             if (d <= W) u[d] = Ur[(long)d << 6];
     };
-    auto body = [&](int j, const E *u, double2 y) {
-        double2 acc = y;
-#pragma unroll
-        for (int d = 0; d < WT; ++d)
-            if (d < W) El<REAL>::fms2(acc, u[d + 1], win[d]);
-        const double2 xj = El<REAL>::mul2(acc, u[0]);   // reciprocal pivot stored on the diagonal
-#pragma unroll
-        for (int d = WT - 1; d > 0; --d) win[d] = win[d - 1];
-        win[0] = xj;
+    auto emit = [&](int j, double2 xj) {
         double2 v = xj;
         if (REAL) {
             const unsigned char code = s_code[j];
@@ -780,16 +772,39 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         }
         store_sys<NF>(xout, plane, s_perm[j], P, c, s, v);
     };
+    // rows are processed in pairs; the register window is shifted once per pair (by two)
+    auto row_even = [&](int j, const E *u, double2 y) -> double2 {
+        double2 acc = y;
+#pragma unroll
+        for (int d = 0; d < WT; ++d)
+            if (d < W) El<REAL>::fms2(acc, u[d + 1], win[d]);
+        const double2 xj = El<REAL>::mul2(acc, u[0]);   // reciprocal pivot stored on the diagonal
+        emit(j, xj);
+        return xj;
+    };
+    auto row_odd = [&](int j, const E *u, double2 y, double2 xprev) {
+        double2 acc = y;
+        El<REAL>::fms2(acc, u[1], xprev);
+#pragma unroll
+        for (int d = 1; d < WT; ++d)
+            if (d < W) El<REAL>::fms2(acc, u[d + 1], win[d - 1]);
+        const double2 xj = El<REAL>::mul2(acc, u[0]);
+        emit(j, xj);
+#pragma unroll
+        for (int d = WT - 1; d > 1; --d) win[d] = win[d - 2];
+        win[1] = xprev;
+        win[0] = xj;
+    };
     int j = n - 1;
     if (j >= 0) fetch(j, ua, ya);
     while (j >= 1) {
         fetch(j - 1, ub, yb);
-        body(j, ua, ya);
+        const double2 xe = row_even(j, ua, ya);
         if (j - 2 >= 0) fetch(j - 2, ua, ya);
-        body(j - 1, ub, yb);
+        row_odd(j - 1, ub, yb, xe);
         j -= 2;
     }
-    if (j == 0) body(0, ua, ya);
+    if (j == 0) row_even(0, ua, ya);
 }
 
 // ------------------------------------------------------------------------------------------------
