@@ -14,6 +14,7 @@
 #include "ddh_common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace ddh {
 
@@ -59,6 +60,7 @@ struct FftDev {
     const double *bands;   // [nbands][M]
     int B;                 // line pairs per workgroup
     int ld;                // LDS leading dimension of the FFT buffer (>= N)
+    unsigned long long *prof;   // optional phase timing (debug): [load, fft, store, count]
 };
 
 struct FftPlan : HandleBase {
@@ -225,10 +227,19 @@ __device__ __forceinline__ void butterfly<16>(double2 *v, int sign) {
 __device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
 
 // One Stockham pass of radix R over B lines of length N held in buf[line*ld + j].
+// Twiddles come from a two-level table held in LDS (W^q = hi[q >> 5] * lo[q & 31], < 1 KiB per
+// workgroup): the per-butterfly table reads from global memory competed with the streaming traffic for
+// L1 and cost an L2 round trip per pass.  Powers w^t are built by binary products (depth <= 4).
+__device__ __forceinline__ double2 lds_twiddle(const double2 *tw_lo, const double2 *tw_hi, int q, int sign) {
+    double2 w = cmul(tw_hi[q >> 5], tw_lo[q & 31]);
+    if (sign > 0) w.y = -w.y;
+    return w;
+}
+
 template <int R>
 __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int Ns, const FastDiv &fd_nb,
-                                         const FastDiv &fd_ns, const double2 *__restrict__ tw, int sign, int tid,
-                                         int T) {
+                                         const FastDiv &fd_ns, const double2 *tw_lo, const double2 *tw_hi, int sign,
+                                         int tid, int T) {
     constexpr int MAXI = (12 + R - 1) / R;   // ceil(12 / R): at least 12 (at most 16) complex values staged per thread
     const int nb = N / R;
     const int total = nb * B;
@@ -246,12 +257,16 @@ __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int
 #pragma unroll
             for (int t = 0; t < R; ++t) v[it][t] = x[lpad(j + t * nb)];
             if (Ns > 1) {
+                double2 wp[R];    // wp[t] = w^t
+                wp[1] = lds_twiddle(tw_lo, tw_hi, k * twstep, sign);
 #pragma unroll
-                for (int t = 1; t < R; ++t) {
-                    double2 wq = tw[t * k * twstep];
-                    if (sign > 0) wq.y = -wq.y;
-                    v[it][t] = cmul(v[it][t], wq);
+                for (int t = 2; t < R; ++t) {
+                    // binary products: t = hb + rest with hb the highest power of two <= t
+                    const int hb = (t >= 8) ? 8 : (t >= 4) ? 4 : 2;
+                    wp[t] = (t == hb) ? cmul(wp[hb / 2], wp[hb / 2]) : cmul(wp[hb], wp[t - hb]);
                 }
+#pragma unroll
+                for (int t = 1; t < R; ++t) v[it][t] = cmul(v[it][t], wp[t]);
             }
             butterfly<R>(v[it], sign);
         }
@@ -273,18 +288,19 @@ __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int
     __syncthreads();
 }
 
-__device__ __forceinline__ void lds_fft(double2 *buf, const FftDev &p, int sign, int tid, int T) {
+__device__ __forceinline__ void lds_fft(double2 *buf, const FftDev &p, const double2 *tw_lo, const double2 *tw_hi,
+                                        int sign, int tid, int T) {
     int Ns = 1;
     for (int i = 0; i < p.nradix; ++i) {
         const int R = p.radix[i];
         switch (R) {
-            case 2: fft_pass<2>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
-            case 3: fft_pass<3>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
-            case 4: fft_pass<4>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
-            case 5: fft_pass<5>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
-            case 8: fft_pass<8>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
-            case 16: fft_pass<16>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
-            default: fft_pass<7>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], p.tw, sign, tid, T); break;
+            case 2: fft_pass<2>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
+            case 3: fft_pass<3>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
+            case 4: fft_pass<4>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
+            case 5: fft_pass<5>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
+            case 8: fft_pass<8>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
+            case 16: fft_pass<16>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
+            default: fft_pass<7>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
         }
         Ns *= R;
     }
@@ -349,13 +365,31 @@ __device__ __forceinline__ void split_item(int w, const FastDiv &fdB, const Fast
 
 __device__ __forceinline__ int dct_perm(int j, int N) { return (j & 1) ? (N - 1 - (j >> 1)) : (j >> 1); }
 
-template <int MODE, bool INNER, int TMAX>
-__global__ void __launch_bounds__(TMAX)
+template <int MODE, bool INNER, int TMAX, int MINW>
+__global__ void __launch_bounds__(TMAX, MINW)
 fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ dst, long outer, long inner,
                 long npairs, unsigned blocks_per_outer) {
     extern __shared__ double2 lds[];
     double2 *buf = lds;                 // [B][ld]
-    double2 *cbuf = lds + p.B * p.ld;   // [B][M]   (Chebyshev coefficient staging only)
+    double2 *tw_lo = lds + p.B * p.ld;  // [32]        W^q
+    double2 *tw_hi = tw_lo + 32;        // [N/32 + 1]  W^(32 q)
+    double2 *cbuf = tw_hi + (p.N >> 5) + 1;   // [B][M]   (Chebyshev coefficient staging only)
+    for (int i = threadIdx.x; i < 32 + (p.N >> 5) + 1; i += blockDim.x) {
+        if (i < 32) {
+            tw_lo[i] = p.tw[i < p.N ? i : 0];
+        } else {
+            const int q = (i - 32) << 5;
+            tw_hi[i - 32] = p.tw[q < p.N ? q : 0];
+        }
+    }
+    // Chebyshev normalisation (Appendix A of SURVEY.md; transforms.py:720-724, 737-746, 823-826, 844-860)
+    // computed on the fly: forward sgn*sqrt(pi/2)/N (k=0: sqrt(pi)/(2N)), backward sgn/(2 sqrt(pi/2)) (k=0: 1/sqrt(pi))
+    const double kSqPi = 1.7724538509055160272981674833411, kSqPi2 = 1.2533141373155002512078826424055;
+    const double fs0 = kSqPi / (2.0 * (double)p.N), fs1 = kSqPi2 / (double)p.N;
+    const double bs0 = 1.0 / kSqPi, bs1 = 0.5 / kSqPi2;
+    auto fscale_of = [&](int k) -> double { return k == 0 ? fs0 : ((k & 1) ? -fs1 : fs1); };
+    auto bscale_of = [&](int k) -> double { return k == 0 ? bs0 : ((k & 1) ? -bs1 : bs1); };
+    auto half_of = [&](int k) -> double2 { return p.half[k]; };   // small table, read once per element
     const int tid = threadIdx.x, T = blockDim.x;
     const unsigned bid = xcd_swizzle(blockIdx.x, gridDim.x);
     PairIO<INNER> io;
@@ -371,6 +405,8 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     }
     const int N = p.N, M = p.M, B = p.B, ld = p.ld;
     const double invN = 1.0 / (double)N;
+    long long t_start = 0, t_loaded = 0, t_fft = 0;
+    if (p.prof) t_start = clock64();
 
     // ---------------------------------------------------------------- load + pre-process
     if (MODE == RFFT_FWD && !INNER && (N % 2 == 0)) {
@@ -454,6 +490,33 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             if (q0 + b < npairs) v = io.load(src, N, j, q0 + b);
             buf[b * ld + lpad(dct_perm(j, N))] = v;
         }
+    } else if (MODE == CHEB_BWD && p.nbands == 0) {
+        // grid basis == coefficient basis: build the DCT-III input straight from global memory
+        // (each coefficient is read as k and as N-k; the second read hits L1/L2), no staging buffer
+        const int Mk = (M < N) ? M : N;
+        for (int w = tid; w < N * B; w += T) {
+            int k, b;
+            split_item<INNER>(w, p.fdB, p.fdN, k, b);
+            double2 e = make_double2(0.0, 0.0), f = e;
+            if (q0 + b < npairs) {
+                if (k < Mk) {
+                    const double s = bscale_of(k);
+                    const double2 c = io.load(src, M, k, q0 + b);
+                    e = make_double2(s * c.x, s * c.y);
+                }
+                const int kr = N - k;
+                if (k > 0 && kr < Mk) {
+                    const double s = bscale_of(kr);
+                    const double2 c = io.load(src, M, kr, q0 + b);
+                    f = make_double2(s * c.x, s * c.y);
+                }
+            }
+            const double2 h = half_of(k);
+            const double cr = h.x, ci = -h.y;
+            const double var = e.x * cr + f.x * ci, vai = e.x * ci - f.x * cr;
+            const double vbr = e.y * cr + f.y * ci, vbi = e.y * ci - f.y * cr;
+            buf[b * ld + lpad(k)] = make_double2(var - vbi, vai + vbr);
+        }
     } else if (MODE == CHEB_BWD) {
         for (int w = tid; w < M * B; w += T) {
             int k, b;
@@ -497,15 +560,15 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             const double2 *c = cbuf + b * M;
             double2 e = make_double2(0.0, 0.0), f = e;
             if (k < Mk) {
-                const double s = p.bscale[k];
+                const double s = bscale_of(k);
                 e = make_double2(s * c[k].x, s * c[k].y);
             }
             const int kr = N - k;
             if (k > 0 && kr < Mk) {
-                const double s = p.bscale[kr];
+                const double s = bscale_of(kr);
                 f = make_double2(s * c[kr].x, s * c[kr].y);
             }
-            const double2 h = p.half[k];  // exp(-i pi k / 2N); we need its conjugate
+            const double2 h = half_of(k);  // exp(-i pi k / 2N); we need its conjugate
             const double cr = h.x, ci = -h.y;
             // V^a = (e.x - i f.x)(cr + i ci), V^b likewise with .y ; Z = V^a + i V^b
             const double var = e.x * cr + f.x * ci, vai = e.x * ci - f.x * cr;
@@ -545,10 +608,12 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
         }
     }
     __syncthreads();
+    if (p.prof) t_loaded = clock64();
 
     // ---------------------------------------------------------------- FFT in LDS
     const int sign = (MODE == RFFT_FWD || MODE == CHEB_FWD || MODE == CFFT_FWD) ? -1 : +1;
-    lds_fft(buf, p, sign, tid, T);
+    lds_fft(buf, p, tw_lo, tw_hi, sign, tid, T);
+    if (p.prof) t_fft = clock64();
 
     // ---------------------------------------------------------------- post-process + store
     if (MODE == RFFT_BWD && !INNER && (N % 2 == 0)) {
@@ -608,8 +673,8 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 double2 c = make_double2(0.0, 0.0);
                 if (k < Mk) {
                     const double2 z1 = buf[b * ld + lpad(k)], z2 = buf[b * ld + lpad(((k == 0) ? 0 : N - k))];
-                    const double2 h = p.half[k];
-                    const double s = p.fscale[k];
+                    const double2 h = half_of(k);
+                    const double s = fscale_of(k);
                     c.x = s * ((z1.x + z2.x) * h.x - (z1.y - z2.y) * h.y);
                     c.y = s * ((z1.y + z2.y) * h.x - (z2.x - z1.x) * h.y);
                 }
@@ -623,8 +688,8 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 double2 c = make_double2(0.0, 0.0);
                 if (k < Mk) {
                     const double2 z1 = buf[b * ld + lpad(k)], z2 = buf[b * ld + lpad(((k == 0) ? 0 : N - k))];
-                    const double2 h = p.half[k];
-                    const double s = p.fscale[k];
+                    const double2 h = half_of(k);
+                    const double s = fscale_of(k);
                     c.x = s * ((z1.x + z2.x) * h.x - (z1.y - z2.y) * h.y);
                     c.y = s * ((z1.y + z2.y) * h.x - (z2.x - z1.x) * h.y);
                 }
@@ -675,6 +740,16 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             const long line = q0 + b;
             double *ptr = INNER ? dst + 2 * ((io.outer_idx * N + j) * inner + line) : dst + 2 * (line * N + j);
             *reinterpret_cast<double2 *>(ptr) = buf[b * ld + lpad(j)];
+        }
+    }
+    if (p.prof) {
+        __syncthreads();
+        if (tid == 0) {
+            const long long t_end = clock64();
+            atomicAdd(&p.prof[0], (unsigned long long)(t_loaded - t_start));
+            atomicAdd(&p.prof[1], (unsigned long long)(t_fft - t_loaded));
+            atomicAdd(&p.prof[2], (unsigned long long)(t_end - t_fft));
+            atomicAdd(&p.prof[3], 1ull);
         }
     }
 }
@@ -787,6 +862,14 @@ static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nba
         return st;
     }
     d.ld = N + (N >> 4) + 1;
+    d.prof = nullptr;
+    if (getenv("DDH_FFT_PROF") && atoi(getenv("DDH_FFT_PROF"))) {
+        void *pm = nullptr;
+        if (hipMalloc(&pm, 4 * sizeof(unsigned long long)) == hipSuccess) {
+            (void)hipMemset(pm, 0, 4 * sizeof(unsigned long long));
+            d.prof = (unsigned long long *)pm;
+        }
+    }
     d.fdN.set((unsigned)N);
     d.fdM.set((unsigned)M);
     d.fdMh.set((unsigned)(M / 2 > 0 ? M / 2 : 1));
@@ -818,9 +901,12 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     // so that at least two workgroups share a CU) and by 12 staged values per thread.
     const int N = d.N, M = d.M;
     const bool cheb = (MODE == CHEB_FWD || MODE == CHEB_BWD);
-    const size_t per_line = (size_t)(d.ld + (cheb ? M : 0)) * sizeof(double2);
-    int B = inner_mode ? 4 : 2;
-    while (B > 1 && per_line * B > 64 * 1024) B /= 2;
+    const size_t per_line = (size_t)(d.ld + ((cheb && d.nbands > 0) ? M : 0)) * sizeof(double2);
+    static const int envB = getenv("DDH_FFT_B") ? atoi(getenv("DDH_FFT_B")) : 0;
+    static const long lds_cap = getenv("DDH_FFT_LDSCAP") ? atol(getenv("DDH_FFT_LDSCAP")) : 64 * 1024;
+    int B = inner_mode ? 8 : 4;      // strided: 128-byte contiguous segments per row when LDS allows
+    if (envB > 0) B = envB;
+    while (B > 1 && (long)(per_line * B) > lds_cap) B /= 2;
     if ((long)B > npairs) B = (int)npairs;
     if (per_line * B > 160 * 1024) return fail("transform: axis too long for the LDS kernel");
     int T = 256;
@@ -831,11 +917,11 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     const unsigned bpo = (unsigned)((npairs + B - 1) / B);
     const unsigned long nblocks = inner_mode ? (unsigned long)bpo * (unsigned long)outer : bpo;
     if (nblocks > 0x7fffffffUL) return fail("transform: grid too large");
-    const size_t lds = per_line * B;
+    const size_t lds = per_line * B + (size_t)(32 + (N >> 5) + 1) * sizeof(double2);
     hipStream_t s = as_stream(stream);
-#define DDH_FFT_LAUNCH(INNERV, TMAXV)                                                                       \
+#define DDH_FFT_LAUNCH(INNERV, TMAXV, MINWV)                                                                \
     {                                                                                                       \
-        auto kern = fft_axis_kernel<MODE, INNERV, TMAXV>;                                                   \
+        auto kern = fft_axis_kernel<MODE, INNERV, TMAXV, MINWV>;                                            \
         if (lds > 64 * 1024)                                                                                \
             DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                         (int)lds));                                                         \
@@ -843,10 +929,13 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
                            npairs, bpo);                                                                    \
     }
     // register budget follows the real block size (a 1024-thread bound would cap at 64 VGPRs and spill)
+    static const int occ4 = (getenv("DDH_FFT_OCC4") && atoi(getenv("DDH_FFT_OCC4"))) ? 1 : 0;
     if (inner_mode) {
-        if (T <= 256) DDH_FFT_LAUNCH(true, 256) else DDH_FFT_LAUNCH(true, 1024)
+        if (T <= 256) { if (occ4) DDH_FFT_LAUNCH(true, 256, 4) else DDH_FFT_LAUNCH(true, 256, 1) }
+        else DDH_FFT_LAUNCH(true, 1024, 1)
     } else {
-        if (T <= 256) DDH_FFT_LAUNCH(false, 256) else DDH_FFT_LAUNCH(false, 1024)
+        if (T <= 256) { if (occ4) DDH_FFT_LAUNCH(false, 256, 4) else DDH_FFT_LAUNCH(false, 256, 1) }
+        else DDH_FFT_LAUNCH(false, 1024, 1)
     }
 #undef DDH_FFT_LAUNCH
     DDH_HIP(hipGetLastError());
@@ -909,6 +998,18 @@ mmt_kernel(const double *__restrict__ mat, const double *__restrict__ in, double
 using namespace ddh;
 
 extern "C" {
+
+/* debug only (not part of the documented ABI): average cycles per workgroup in the three phases */
+int ddh_debug_fft_prof(ddh_handle plan, double *out4) {
+    FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
+    if (!pl || !pl->dev.prof) return fail("no profiling buffer (set DDH_FFT_PROF=1 before planning)");
+    unsigned long long h[4];
+    DDH_HIP(hipMemcpy(h, pl->dev.prof, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; ++i) out4[i] = h[3] ? (double)h[i] / (double)h[3] : 0.0;
+    out4[3] = (double)h[3];
+    (void)hipMemset(pl->dev.prof, 0, sizeof(h));
+    return 0;
+}
 
 int ddh_plan_rfft(ddh_handle *plan, int n_grid, int n_coeff) {
     return make_plan(plan, K_RFFT, n_grid, n_coeff, 0, nullptr, nullptr);

@@ -1,0 +1,31 @@
+"""Secondary BASELINE.json configurations on one GPU (not the headline metric):
+   K  = KdV-Burgers N=1024 SBDF2,  R2 = 2-D Rayleigh-Benard 512x256 RK222.  Prints steps/s."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import problems  # noqa: E402
+import dedalus_amd.public as d3  # noqa: E402
+
+
+def run(name, builder, kw, dt, warm, steps):
+    solver, f = builder(d3, **kw)
+    for _ in range(warm):
+        solver.step(dt)
+    solver.ex.sync()
+    t0 = time.time()
+    for _ in range(steps):
+        solver.step(dt)
+    solver.ex.sync()
+    el = time.time() - t0
+    print("%-28s %8.1f steps/s  (%.3f ms/step, %d steps)" % (name, steps / el, 1e3 * el / steps, steps), flush=True)
+
+
+if __name__ == "__main__":
+    run("K  kdv N=1024 SBDF2", problems.kdv_burgers, dict(Nx=1024, timestepper="SBDF2"), 2e-3, 20, 200)
+    run("R2 rb2d 512x256 RK222", problems.rayleigh_benard_2d, dict(Nx=512, Nz=256), 1e-3, 5, 50)
+    run("rb3d 128x128x64 RK222", problems.rayleigh_benard_3d, dict(Nx=128, Ny=128, Nz=64), 1e-3, 3, 20)

@@ -52,6 +52,18 @@ def main():
         bytes_ = (c.numel() + g.numel()) * 8
         tb = timeit(dev, lambda: libhip.call("ddh_%s_backward" % kind, p, ptr(c), ptr(g), cs[0], cs[2], dev.stream))
         tf = timeit(dev, lambda: libhip.call("ddh_%s_forward" % kind, p, ptr(g), ptr(c2), cs[0], cs[2], dev.stream))
+        if os.environ.get("DDH_FFT_PROF"):
+            lib = libhip.load()
+            lib.ddh_debug_fft_prof.argtypes = [C.c_uint64, C.POINTER(C.c_double)]
+            out = (C.c_double * 4)()
+            # counters accumulated over both directions' launches: reset, then one bwd and one fwd
+            lib.ddh_debug_fft_prof(p, out)
+            libhip.call("ddh_%s_backward" % kind, p, ptr(c), ptr(g), cs[0], cs[2], dev.stream); dev.sync()
+            lib.ddh_debug_fft_prof(p, out); b4 = list(out)
+            libhip.call("ddh_%s_forward" % kind, p, ptr(g), ptr(c2), cs[0], cs[2], dev.stream); dev.sync()
+            lib.ddh_debug_fft_prof(p, out); f4 = list(out)
+            print("   phase cycles/WG  bwd: load %.0f fft %.0f store %.0f | fwd: load %.0f fft %.0f store %.0f  (WGs %d)"
+                  % (b4[0], b4[1], b4[2], f4[0], f4[1], f4[2], int(b4[3])))
         print("%s  bwd %.3f ms %.0f GB/s | fwd %.3f ms %.0f GB/s   (%.2f GB/pass)" %
               (name, tb * 1e3, bytes_ / tb / 1e9, tf * 1e3, bytes_ / tf / 1e9, bytes_ / 1e9), flush=True)
         del c, g, c2
