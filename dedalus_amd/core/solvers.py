@@ -525,6 +525,7 @@ class InitialValueSolver(SolverBase):
         self.run_time_start = None
         self.total_modes = self.R * self.nx * self.ny
         self.handlers = []
+        self._step_hooks = []
         self.evaluator = _HandlerRegistry(self)
 
     @property
@@ -558,6 +559,8 @@ class InitialValueSolver(SolverBase):
             self.ex.sync()
             self.warmup_time = time.time()
         self.dt = dt
+        for hook in self._step_hooks:        # scheduled analysis (CFL frequencies) sees the pre-step state
+            hook(self)
         self.timestepper.step(dt, time.time() - self.start_time)
         self.iteration += 1
         if self.enforce_real_cadence and self.iteration % self.enforce_real_cadence == 0:

@@ -90,8 +90,9 @@ bilinear_kernel(double *__restrict__ out, const double *__restrict__ a, const do
 
 constexpr int MAX_AXES = 3;
 struct CflArgs {
-    const double *inv[MAX_AXES];
-    long len[MAX_AXES];
+    const double *inv[MAX_AXES];   // per velocity component: 1/spacing along its own axis
+    long len[MAX_AXES];            // storage axis lengths
+    int comp_axis[MAX_AXES];       // storage axis of each velocity component
     int naxes;
     int ncomp;
 };
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(256) cfl_kernel(double *result, const double *
             rem /= a.len[ax];
         }
         double f = 0.0;
-        for (int c = 0; c < a.ncomp; ++c) f += fabs(u[(long)c * n + i]) * a.inv[c][idx[c]];
+        for (int c = 0; c < a.ncomp; ++c) f += fabs(u[(long)c * n + i]) * a.inv[c][idx[a.comp_axis[c]]];
         m = fmax(m, f);
     }
     red[threadIdx.x] = m;
@@ -236,17 +237,21 @@ int ddh_grid_bilinear(double *out, int ncomp_out, const double *a, const double 
     return 0;
 }
 
-int ddh_grid_cfl(double *result_d, const double *u, int ncomp, long n, const double *const *inv_spacing_axes,
-                 const long *axis_len_h, int naxes, void *stream) {
-    if (naxes < 1 || naxes > MAX_AXES || ncomp != naxes) return fail("ddh_grid_cfl: ncomp must equal naxes <= 3");
+int ddh_grid_cfl(double *result_d, const double *u, int ncomp, long n, const double *const *inv_spacing_comp,
+                 const int *comp_axis_h, const long *axis_len_h, int naxes, void *stream) {
+    if (naxes < 1 || naxes > MAX_AXES || ncomp < 1 || ncomp > MAX_AXES) return fail("ddh_grid_cfl: 1..3 axes / components");
     CflArgs a;
     a.naxes = naxes;
     a.ncomp = ncomp;
     long tot = 1;
     for (int i = 0; i < naxes; ++i) {
-        a.inv[i] = inv_spacing_axes[i];
         a.len[i] = axis_len_h[i];
         tot *= axis_len_h[i];
+    }
+    for (int c = 0; c < ncomp; ++c) {
+        a.inv[c] = inv_spacing_comp[c];
+        a.comp_axis[c] = comp_axis_h[c];
+        if (comp_axis_h[c] < 0 || comp_axis_h[c] >= naxes) return fail("ddh_grid_cfl: component axis out of range");
     }
     if (tot != n) return fail("ddh_grid_cfl: axis lengths do not multiply to n");
     DDH_HIP(hipMemsetAsync(result_d, 0, sizeof(double), as_stream(stream)));

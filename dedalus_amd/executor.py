@@ -119,6 +119,16 @@ class HipExecutor:
         else:
             libhip.call("ddh_%s_%s" % (kind, direction), h, ptr(src), ptr(dst), outer, inner, self.dev.stream)
 
+    def cfl_max(self, u, ncomp, shape, inv_spacings, comp_axis):
+        """max over the grid of sum_c |u_c| / dx_c; inv_spacings: device arrays per component."""
+        n = int(np.prod(shape))
+        res = self.dev.zeros((1,))
+        arr = (C.c_void_p * ncomp)(*[C.c_void_p(a.data_ptr()) for a in inv_spacings])
+        ca = np.ascontiguousarray(comp_axis, dtype=np.int32)
+        ln = (C.c_long * len(shape))(*[int(x) for x in shape])
+        libhip.call("ddh_grid_cfl", ptr(res), ptr(u), ncomp, n, arr, libhip.as_ip(ca), ln, len(shape), self.dev.stream)
+        return float(res.cpu().item())
+
     def a2a_pack(self, src, dst, outer, na, nb, inner, P):
         libhip.call("ddh_a2a_pack", ptr(src), ptr(dst), outer, na, nb, inner, P, self.dev.stream)
 

@@ -1,4 +1,10 @@
-"""CFL and global flow properties (dedalus/extras/flow_tools.py:49-233), evaluated on the device."""
+"""CFL and global flow properties (dedalus/extras/flow_tools.py:49-233).
+
+The CFL frequency max_x sum_i |u_i| / dx_i is reduced on the device (ddh_grid_cfl) from the
+dealias-scale grid velocity, with the reference's spacings (CartesianAdvectiveCFL,
+core/basis.py:6078-6111) and the reference's scheduling: frequencies are sampled at the start of a step
+whenever iteration % cadence == 0 (the dictionary handler of flow_tools.py:176) and consumed by
+compute_timestep() one step later (flow_tools.py:183-207)."""
 
 import numpy as np
 
@@ -23,33 +29,33 @@ class GlobalFlowProperty:
         if name not in self._cache:
             expr = self.properties[name]
             f = expr.evaluate() if hasattr(expr, "evaluate") else expr
-            f.change_scales(1)
             self._cache[name] = np.array(f["g"])
         return self._cache[name]
 
+    def _reduce(self, val, op):
+        pc = self.solver.dist.pcomm
+        if pc is None:
+            return float(val)
+        return pc.allreduce_max(val) if op == "max" else (-pc.allreduce_max(-val) if op == "min" else pc.allreduce_sum(val))
+
     def min(self, name):
-        return float(np.min(self._grid(name)))
+        return self._reduce(np.min(self._grid(name)), "min")
 
     def max(self, name):
-        return float(np.max(self._grid(name)))
+        return self._reduce(np.max(self._grid(name)), "max")
 
     def grid_average(self, name):
-        return float(np.mean(self._grid(name)))
+        g = self._grid(name)
+        return self._reduce(np.sum(g), "sum") / self._reduce(g.size, "sum")
 
     def volume_integral(self, name):
         from ..core.operators import Integrate
         f = Integrate(self.properties[name]).evaluate()
         return float(np.asarray(f["g"]).ravel()[0])
 
-    def volume_average(self, name):
-        from ..core.operators import Average
-        f = Average(self.properties[name]).evaluate()
-        return float(np.asarray(f["g"]).ravel()[0])
-
 
 class CFL:
-    """Adaptive timestep from the advective CFL frequency (flow_tools.py:113-233;
-    AdvectiveCFL core/operators.py:4342-4419, spacings core/basis.py:6078-6113)."""
+    """Adaptive timestep from the advective CFL frequency (flow_tools.py:113-233)."""
 
     def __init__(self, solver, initial_dt, cadence=1, safety=1.0, max_dt=np.inf, min_dt=0.0, max_change=np.inf,
                  min_change=0.0, threshold=0.0):
@@ -59,50 +65,77 @@ class CFL:
         self.max_dt, self.min_dt = max_dt, min_dt
         self.max_change, self.min_change, self.threshold = max_change, min_change, threshold
         self.velocities = []
+        self._max_freq = None
+        self._setup = {}
+        solver._step_hooks.append(self._sample)
 
     def add_velocity(self, velocity):
+        if len(velocity.tensorsig) != 1:
+            raise ValueError("Velocity must be a vector")
         self.velocities.append(velocity)
 
     def add_frequency(self, freq):
-        raise NotImplementedError
+        raise NotImplementedError("only velocity-based CFL frequencies are implemented")
 
-    def _max_frequency(self):
-        dist = self.solver.dist
+    def _spacings(self, u):
+        """Device arrays 1/dx per velocity component at the dealias grid (basis.py:6083-6106)."""
+        key = id(u)
+        if key in self._setup:
+            return self._setup[key]
+        dist, ex = self.solver.dist, self.solver.ex
+        scales = u.domain.dealias
+        inv, comp_axis = [], []
+        for c in u.tensorsig[0].coords:
+            ax = dist.coord_axis(c)
+            b = u.domain.by_axis[ax]
+            if b is None:
+                raise NotImplementedError("CFL along an axis without a basis")
+            N = b.grid_size(b.dealias)
+            if b.separable:
+                dx = np.full(N, b.dealias * b.length / N)
+            elif b.a0 == b.b0 == -0.5 and b.a == b.b == -0.5:
+                theta = np.pi * (np.arange(N) + 0.5) / N
+                dx = b.dealias * b.stretch * np.sin(theta) * np.pi / N
+            else:
+                dx = np.gradient(b.global_grid(b.dealias), edge_order=2) * b.dealias
+            if ax == dist.shard_grid_axis:
+                lo, hi = dist.local_block(N)
+                dx = dx[lo:hi]
+            inv.append(ex.from_host(1.0 / dx))
+            comp_axis.append(list(dist.storage_order).index(ax))
+        self._setup[key] = (inv, comp_axis, scales)
+        return self._setup[key]
+
+    def _sample(self, solver):
+        """Called at the start of every step (the reference evaluates its frequency handler there)."""
+        if solver.iteration % self.cadence != 0 or not self.velocities:
+            return
+        ex = solver.ex
         fmax = 0.0
         for u in self.velocities:
-            f = u.evaluate() if not hasattr(u, "fill_random") else u
-            f.change_scales(1)
-            g = np.asarray(f["g"])
-            freq = np.zeros(g.shape[1:])
-            cs = f.tensorsig[0]
-            for i, c in enumerate(cs.coords):
-                ax = dist.coord_axis(c)
-                b = f.domain.by_axis[ax]
-                if b is None:
-                    continue
-                if b.separable:
-                    # Fourier: dx = L / N_grid at scale 1 (uniform)
-                    spacing = np.full(b.grid_size(1), b.length / b.grid_size(1))
-                else:
-                    spacing = np.gradient(b.global_grid(1), edge_order=2)
-                shape = [1] * dist.dim
-                shape[ax] = spacing.size
-                freq = freq + np.abs(g[i]) / spacing.reshape(shape)
-            fmax = max(fmax, float(freq.max()))
-        return fmax
+            f = u if hasattr(u, "grid_data") else u.evaluate()
+            inv, comp_axis, scales = self._spacings(f)
+            g = f.grid_data(scales)
+            shape = f.domain.storage_grid_shape(scales)
+            fmax += ex.cfl_max(g, f.ncomp, shape, inv, comp_axis) if len(self.velocities) == 1 else 0.0
+            if len(self.velocities) > 1:
+                raise NotImplementedError("several CFL velocities")
+        if solver.dist.pcomm is not None:
+            fmax = solver.dist.pcomm.allreduce_max(fmax)
+        self._max_freq = fmax
 
     def compute_timestep(self):
-        """flow_tools.py:183-220"""
+        """flow_tools.py:183-207"""
         it = self.solver.iteration
-        if (it - self.solver.initial_iteration) % self.cadence == 0:
-            fmax = self._max_frequency()
-            dt = self.safety / fmax if fmax > 0 else np.inf
-            dt = min(dt, self.max_dt)
-            dt = max(dt, self.min_dt)
-            if self.stored_dt is not None and np.isfinite(self.stored_dt):
-                dt = min(dt, self.max_change * self.stored_dt)
-                dt = max(dt, self.min_change * self.stored_dt)
-                if abs(dt - self.stored_dt) / self.stored_dt < self.threshold:
-                    dt = self.stored_dt
-            self.stored_dt = dt
+        if (it - 1) % self.cadence == 0:
+            if (it - 1) <= self.solver.initial_iteration or self._max_freq is None:
+                return self.stored_dt
+            dt = np.inf if self._max_freq == 0.0 else 1.0 / self._max_freq
+            dt *= self.safety
+            dt = min(dt, self.max_dt, self.max_change * self.stored_dt)
+            dt = max(dt, self.min_dt, self.min_change * self.stored_dt)
+            if abs(dt - self.stored_dt) > self.threshold * self.stored_dt:
+                self.stored_dt = dt
         return self.stored_dt
+
+    compute_dt = compute_timestep

@@ -83,9 +83,12 @@ int ddh_lincomb(double *y, int nterms, const double *const *xs_h, const double *
 int ddh_grid_bilinear(double *out, int ncomp_out, const double *a, const double *b, long n,
                       int nterms, const int *ic_h, const int *ia_h, const int *ib_h,
                       const double *coef_h, void *stream);
-/* max over points of sum_c |u_c| * inv_spacing_c  (AdvectiveCFL, core/operators.py:4342-4419) */
+/* max over grid points of sum_c |u_c| / dx_c  (AdvectiveCFL core/operators.py:4342-4419 with the
+ * spacings of CartesianAdvectiveCFL core/basis.py:6078-6111).  u is [ncomp][grid, naxes storage
+ * axes]; inv_spacing_comp[c] is a device array of 1/dx along storage axis comp_axis_h[c].        */
 int ddh_grid_cfl(double *result_d, const double *u, int ncomp, long n,
-                 const double *const *inv_spacing_axes, const long *axis_len_h, int naxes, void *stream);
+                 const double *const *inv_spacing_comp, const int *comp_axis_h,
+                 const long *axis_len_h, int naxes, void *stream);
 
 /* ---- pencil systems ------------------------------------------ */
 /* A "pencil pack" describes all pencils of a problem at once.  System vectors are real arrays

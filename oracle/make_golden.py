@@ -107,6 +107,11 @@ def golden_ivp():
         for k, v in res.items():
             out[name + "__" + k] = v
         print(name, {k: float(np.linalg.norm(v)) for k, v in res.items()})
+    solver, dts, res = problems.run_cfl_case(d3)
+    out["cfl__dts"] = dts
+    for k, v in res.items():
+        out["cfl__" + k] = v
+    print("cfl dts", dts[:12], "...", dts[-3:])
     np.savez_compressed(os.path.join(GOLD, "ivp.npz"), **out)
     print("wrote ivp.npz")
 

@@ -128,6 +128,16 @@ class NumpyExecutor:
             raise NotImplementedError(kind)
         dst[...] = res.reshape(dst.shape)
 
+    def cfl_max(self, u, ncomp, shape, inv_spacings, comp_axis):
+        """compute_cfl_frequency (core/basis.py:6108-6111) + global max (extras/flow_tools.py:199-204)"""
+        ug = np.abs(u.reshape((ncomp,) + tuple(shape)))
+        f = np.zeros(tuple(shape))
+        for c in range(ncomp):
+            sh = [1] * len(shape)
+            sh[comp_axis[c]] = -1
+            f = f + ug[c] * np.asarray(inv_spacings[c]).reshape(sh)
+        return float(f.max()) if f.size else 0.0
+
     def a2a_pack(self, src, dst, outer, na, nb, inner, P):
         """split_rows / split_columns of AlltoallvTranspose (core/transposes.pyx:359-445) restated"""
         s = src.reshape(outer, P, na // P, nb * inner)

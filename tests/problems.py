@@ -120,3 +120,26 @@ def run_case(d3, name, dist_kw=None):
     for _ in range(nsteps):
         solver.step(dt)
     return solver, {k: np.array(f['c']) for k, f in fields.items()}
+
+
+def run_cfl_case(d3, dist_kw=None, nsteps=45):
+    """2-D RB with an O(1) initial flow and the example's adaptive-timestep loop
+    (examples/ivp_2d_rayleigh_benard/rayleigh_benard.py:97-113)."""
+    solver, f = rayleigh_benard_2d(d3, Nx=32, Nz=16, timestepper="RK222", dist_kw=dist_kw)
+    u = f["u"]
+    dist = u.dist
+    xb, zb = [b for b in u.domain.bases]
+    x, z = dist.local_grids(xb, zb)
+    ug = np.zeros((2,) + np.broadcast(x, z).shape)
+    ug[0] = 0.5 * np.sin(2 * np.pi * x / 4) * z * (1 - z) * 4
+    ug[1] = 0.3 * np.cos(4 * np.pi * x / 4) * z * (1 - z) * 4
+    u['g'] = ug
+    CFL = d3.CFL(solver, initial_dt=0.02, cadence=3, safety=0.5, threshold=0.05, max_change=1.5,
+                 min_change=0.5, max_dt=0.125)
+    CFL.add_velocity(u)
+    dts = []
+    for _ in range(nsteps):
+        dt = CFL.compute_timestep()
+        solver.step(dt)
+        dts.append(dt)
+    return solver, np.array(dts), {k: np.array(v['c']) for k, v in f.items()}

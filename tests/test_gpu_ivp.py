@@ -60,3 +60,13 @@ def test_refactorization_on_dt_change_and_grid_access():
     g2 = np.array(f2["b"]["g"])
     assert rel(g1, g2) < 1e-10
     assert abs(s1.sim_time - 5.5e-3) < 1e-15
+
+
+def test_cfl_on_device_matches_reference(gold):
+    """ddh_grid_cfl + adaptive stepping + device refactorization vs the reference's dt sequence."""
+    import dedalus_amd.public as d3
+    solver, dts, res = problems.run_cfl_case(d3)
+    assert solver.ex.name == "hip"
+    assert np.allclose(dts, gold["cfl__dts"], rtol=1e-11, atol=0), np.max(np.abs(dts - gold["cfl__dts"]))
+    for k in ("p", "b", "u"):
+        assert rel(res[k], gold["cfl__" + k]) < 1e-9, (k, rel(res[k], gold["cfl__" + k]))

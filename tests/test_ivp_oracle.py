@@ -71,3 +71,14 @@ def test_product_has_no_cpu_fallback():
     u['g'] = 1.0
     with pytest.raises(DdhError):
         u['c']
+
+
+def test_cfl_timestep_sequence_matches_reference(gold):
+    """Adaptive stepping (CFL frequency, scheduling, clamps, refactorization on every dt change)
+    against the reference's own dt sequence and end state."""
+    import dedalus_amd.public as d3
+    from oracle.np_executor import NumpyExecutor
+    solver, dts, res = problems.run_cfl_case(d3, dist_kw=dict(executor=NumpyExecutor()))
+    assert np.allclose(dts, gold["cfl__dts"], rtol=1e-12, atol=0)
+    for k in ("p", "b", "u"):
+        assert rel(res[k], gold["cfl__" + k]) < 1e-10, k
