@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace ddh {
 
@@ -602,7 +603,7 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
 // pipelined: everything row j+1 needs (pivot, multipliers, right-hand side / U row) is requested
 // before row j is consumed, so each row costs one overlapped memory latency instead of several
 // serialized ones.  Permutations and grading codes are staged in LDS.
-template <int NF, bool REAL>
+template <int NF, bool REAL, int KLT, int NBT>
 __global__ void __launch_bounds__(256)
 solve_forward_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__restrict__ xout) {
     typedef typename El<REAL>::T E;
@@ -640,33 +641,33 @@ solve_forward_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, doubl
         return v;
     };
 
-    double2 w[KLMAX + 1];
+    double2 w[KLT + 1];
 #pragma unroll
-    for (int d = 0; d <= KLMAX; ++d) {
+    for (int d = 0; d <= KLT; ++d) {
         w[d] = make_double2(0.0, 0.0);
         if (d <= kl && d < n) w[d] = load_row(d);
     }
-    double2 gb[NBMAX];
+    double2 gb[NBT];
 #pragma unroll
-    for (int rb = 0; rb < NBMAX; ++rb) {
+    for (int rb = 0; rb < NBT; ++rb) {
         gb[rb] = make_double2(0.0, 0.0);
         if (rb < nb) gb[rb] = load_row(n + rb);
     }
     // prefetch registers for the next row
     int p_nx = 0;
-    E m_nx[KLMAX], ab_nx[NBMAX];
+    E m_nx[KLT], ab_nx[NBT];
     double2 r_nx = make_double2(0.0, 0.0);
 #pragma unroll
-    for (int i = 0; i < KLMAX; ++i) m_nx[i] = El<REAL>::zero();
+    for (int i = 0; i < KLT; ++i) m_nx[i] = El<REAL>::zero();
 #pragma unroll
-    for (int rb = 0; rb < NBMAX; ++rb) ab_nx[rb] = El<REAL>::zero();
+    for (int rb = 0; rb < NBT; ++rb) ab_nx[rb] = El<REAL>::zero();
     auto prefetch = [&](int j) {
         p_nx = L.piv[lu_pv(L, gl, j)];
 #pragma unroll
-        for (int i = 1; i <= KLMAX; ++i)
+        for (int i = 1; i <= KLT; ++i)
             if (i <= kl && j + i < n) m_nx[i - 1] = Aw[lu_aw(L, gl, j + i, kl - i)];
 #pragma unroll
-        for (int rb = 0; rb < NBMAX; ++rb)
+        for (int rb = 0; rb < NBT; ++rb)
             if (rb < nb) ab_nx[rb] = Ab[lu_ab(L, gl, j, rb)];
         const int nxt = j + kl + 1;
         r_nx = (nxt < n) ? load_row(nxt) : make_double2(0.0, 0.0);
@@ -674,16 +675,16 @@ solve_forward_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, doubl
     if (n > 0) prefetch(0);
     for (int j = 0; j < n; ++j) {
         const int p = p_nx;
-        E m[KLMAX], ab[NBMAX];
+        E m[KLT], ab[NBT];
 #pragma unroll
-        for (int i = 0; i < KLMAX; ++i) m[i] = m_nx[i];
+        for (int i = 0; i < KLT; ++i) m[i] = m_nx[i];
 #pragma unroll
-        for (int rb = 0; rb < NBMAX; ++rb) ab[rb] = ab_nx[rb];
+        for (int rb = 0; rb < NBT; ++rb) ab[rb] = ab_nx[rb];
         const double2 rnew = r_nx;
         if (j + 1 < n) prefetch(j + 1);
         double2 yj = w[0];
 #pragma unroll
-        for (int d = 1; d <= KLMAX; ++d) {
+        for (int d = 1; d <= KLT; ++d) {
             if (d == p) {
                 yj = w[d];
                 w[d] = w[0];
@@ -691,25 +692,25 @@ solve_forward_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, doubl
         }
         L.scratch[(long)j * G + g] = yj;
 #pragma unroll
-        for (int i = 1; i <= KLMAX; ++i)
+        for (int i = 1; i <= KLT; ++i)
             if (i <= kl && j + i < n) El<REAL>::fms2(w[i], m[i - 1], yj);
 #pragma unroll
-        for (int rb = 0; rb < NBMAX; ++rb)
+        for (int rb = 0; rb < NBT; ++rb)
             if (rb < nb) El<REAL>::fms2(gb[rb], ab[rb], yj);
 #pragma unroll
-        for (int d = 0; d < KLMAX; ++d) w[d] = w[d + 1];
-        w[KLMAX] = make_double2(0.0, 0.0);
+        for (int d = 0; d < KLT; ++d) w[d] = w[d + 1];
+        w[KLT] = make_double2(0.0, 0.0);
 #pragma unroll
-        for (int d = 0; d <= KLMAX; ++d)
+        for (int d = 0; d <= KLT; ++d)
             if (d == kl) w[d] = rnew;
     }
     // ---- Schur block: z = Sinv * gb ; border unknown r is logical column n + r
 #pragma unroll
-    for (int r = 0; r < NBMAX; ++r) {
+    for (int r = 0; r < NBT; ++r) {
         if (r < nb) {
             double2 acc = make_double2(0.0, 0.0);
 #pragma unroll
-            for (int cidx = 0; cidx < NBMAX; ++cidx)
+            for (int cidx = 0; cidx < NBT; ++cidx)
                 if (cidx < nb) El<REAL>::fma2(acc, Ab[lu_ab(L, gl, n + cidx, r)], gb[cidx]);
             L.scratch[(long)(n + r) * G + g] = acc;     // graded value for the backward sweep
             double2 v = acc;
@@ -723,7 +724,7 @@ solve_forward_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, doubl
     }
 }
 
-template <int NF, int WT, bool REAL>
+template <int NF, int WT, bool REAL, bool PREF>
 __global__ void __launch_bounds__(256)
 solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     typedef typename El<REAL>::T E;
@@ -796,15 +797,30 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         win[0] = xj;
     };
     int j = n - 1;
-    if (j >= 0) fetch(j, ua, ya);
-    while (j >= 1) {
-        fetch(j - 1, ub, yb);
-        const double2 xe = row_even(j, ua, ya);
-        if (j - 2 >= 0) fetch(j - 2, ua, ya);
-        row_odd(j - 1, ub, yb, xe);
-        j -= 2;
+    if (PREF) {
+        if (j >= 0) fetch(j, ua, ya);
+        while (j >= 1) {
+            fetch(j - 1, ub, yb);
+            const double2 xe = row_even(j, ua, ya);
+            if (j - 2 >= 0) fetch(j - 2, ua, ya);
+            row_odd(j - 1, ub, yb, xe);
+            j -= 2;
+        }
+        if (j == 0) row_even(0, ua, ya);
+    } else {
+        // no register double-buffering: fewer VGPRs -> two waves per SIMD hide each other's latency
+        while (j >= 1) {
+            fetch(j, ua, ya);
+            const double2 xe = row_even(j, ua, ya);
+            fetch(j - 1, ua, ya);
+            row_odd(j - 1, ua, ya, xe);
+            j -= 2;
+        }
+        if (j == 0) {
+            fetch(0, ua, ya);
+            row_even(0, ua, ya);
+        }
     }
-    if (j == 0) row_even(0, ua, ya);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -873,23 +889,36 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
     const int W = d.W;
     const size_t lds_f = (size_t)(d.N + d.nb) * 5 + 16, lds_b = (size_t)(d.n > 0 ? d.n : 1) * 5 + 16;
     if (lds_f > 64 * 1024) return fail("pencil_solve: system too large for the LDS permutation cache");
-    if (d.real)
-        hipLaunchKernelGGL((solve_forward_kernel<NF, true>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x);
-    else
-        hipLaunchKernelGGL((solve_forward_kernel<NF, false>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x);
-#define DDH_SOLVE(WTV)                                                                                            \
-    {                                                                                                             \
-        if (d.real)                                                                                               \
-            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
-        else                                                                                                      \
-            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
+    static const int bwd_pref = getenv("DDH_SOLVE_PREF") ? atoi(getenv("DDH_SOLVE_PREF")) : 1;
+#define DDH_FWD(KLTV, NBTV)                                                                                        \
+    {                                                                                                              \
+        if (d.real)                                                                                                \
+            hipLaunchKernelGGL((solve_forward_kernel<NF, true, KLTV, NBTV>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((solve_forward_kernel<NF, false, KLTV, NBTV>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x); \
+    }
+    if (d.nb <= 2) {
+        if (d.kl <= 8) DDH_FWD(8, 2) else if (d.kl <= 12) DDH_FWD(12, 2) else DDH_FWD(16, 2)
+    } else {
+        if (d.kl <= 8) DDH_FWD(8, 8) else if (d.kl <= 12) DDH_FWD(12, 8) else DDH_FWD(16, 8)
+    }
+#undef DDH_FWD
+#define DDH_SOLVE(WTV)                                                                                             \
+    {                                                                                                              \
+        if (d.real) {                                                                                              \
+            if (bwd_pref)                                                                                          \
+                hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, true>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
+            else                                                                                                   \
+                hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
+        } else                                                                                                     \
+            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false, true>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
     }
     if (d.n > 0) {
         if (W <= 8) DDH_SOLVE(8)
         else if (W <= 16) DDH_SOLVE(16)
         else if (W <= 24) DDH_SOLVE(24)
         else if (W <= 32) DDH_SOLVE(32)
-        else if (W <= 36) DDH_SOLVE(36)
+        else if (W <= 34) DDH_SOLVE(34)
         else if (W <= 40) DDH_SOLVE(40)
         else if (W <= 48) DDH_SOLVE(48)
         else DDH_SOLVE(64)
