@@ -191,11 +191,34 @@ class Transformer:
             raise NotImplementedError("grid-space data of a field that lacks the x or z basis on several ranks")
         return False
 
-    def backward_data(self, domain, ncomp, c, g, scales):
+    def fusable_last_axis(self, domain, scales):
+        """plan spec of the last storage axis when the grid stage can be fused along it (a contiguous
+        RealFourier axis), else None."""
+        steps = self._steps(domain, scales)
+        if not steps:
+            return None
+        pos, b, spec = steps[-1]
+        if pos != len(self.dist.storage_order) - 1 or spec[0] != "rfft":
+            return None
+        if not self.dist.executor.fused_capable(spec):
+            return None
+        return b, spec
+
+    def pregrid_shape(self, domain, ncomp, scales):
+        """[comp][grid...][last axis coefficients]: every axis but the last in grid space (local shape)."""
+        shape = [ncomp] + list(domain.storage_grid_shape(scales))
+        b = domain.by_axis[self.dist.storage_order[-1]]
+        if b is not None:
+            shape[-1] = b.coeff_size            # full size: this layout sits on the grid side of the exchange
+        return tuple(shape)
+
+    def backward_data(self, domain, ncomp, c, g, scales, skip_last=False):
         """coefficient -> grid: z transform (local, kx-sharded), all-to-all (-> z-sharded, kx local),
-        then the Fourier transforms."""
+        then the Fourier transforms.  skip_last stops before the last storage axis ("pre-grid" layout)."""
         ex = self.dist.executor
         steps = self._steps(domain, scales)
+        if skip_last:
+            steps = steps[:-1]
         shape = [ncomp] + list(domain.storage_coeff_shape())
         if not steps:
             ex.copy(g, c)
@@ -226,10 +249,13 @@ class Transformer:
                 ex.a2a_unpack(recv, dst2, nc, Gz // P, nxl * P, rest, P)
                 src = dst2
 
-    def forward_data(self, domain, ncomp, g, scales, c):
+    def forward_data(self, domain, ncomp, g, scales, c, skip_last=False):
         ex = self.dist.executor
         steps = self._steps(domain, scales)
         shape = [ncomp] + list(domain.storage_grid_shape(scales))
+        if skip_last:
+            steps = steps[:-1]
+            shape = list(self.pregrid_shape(domain, ncomp, scales))
         if not steps:
             ex.copy(c, g)
             return

@@ -291,7 +291,81 @@ class Evaluator:
         self.cache[key] = res
         return res
 
-    def _linear_to_grid_fused(self, expr, scales):
+    def eval_pregrid(self, expr):
+        """Data of a field / linear expression with every axis but the last storage axis in (dealiased)
+        grid space: the operand layout of the fused grid stage."""
+        expr = self.canon(expr)
+        key = ("p", id(expr))
+        if key in self.cache:
+            return self.cache[key]
+        scales = expr.domain.dealias
+        tr = self.dist.transformer
+        if self._is_nonlinear_node(expr):
+            raise NotImplementedError("pre-grid data of a nonlinear node")
+        res = None
+        if not isinstance(expr, Field):
+            res = self._linear_to_grid_fused(expr, scales, skip_last=True)
+        if res is None:
+            c = expr.coeff_data() if isinstance(expr, Field) else self.eval_coeff(expr)
+            c = c.reshape((expr.ncomp,) + tuple(expr.domain.storage_coeff_shape()))
+            res = self.ex.empty(tr.pregrid_shape(expr.domain, expr.ncomp, scales))
+            tr.backward_data(expr.domain, expr.ncomp, c, res, scales, skip_last=True)
+        self.cache[key] = res
+        return res
+
+    def fusable_product(self, expr):
+        """(a, b, terms, basis, spec) when the product node can run in the fused grid stage: both factors
+        linear in fields, on the product's full domain, last storage axis a contiguous RealFourier axis.
+        `a` is the factor with fewer components (kept in registers by the kernel)."""
+        expr = self.canon(expr)
+        if not isinstance(expr, (ops.Multiply, ops.DotProduct, ops.CrossProduct)) or not self._is_nonlinear_node(expr):
+            return None
+        last = self.dist.transformer.fusable_last_axis(expr.domain, expr.domain.dealias)
+        if last is None:
+            return None
+        a, b = expr.args
+        sa, a0 = self._strip_scalar(a)
+        sb, b0 = self._strip_scalar(b)
+        a0, b0 = self.canon(a0), self.canon(b0)
+        for x in (a0, b0):
+            if self._is_nonlinear_node(x) or x.domain.dealias != expr.domain.dealias:
+                return None
+            if (x.domain.storage_coeff_shape() != expr.domain.storage_coeff_shape()
+                    or x.domain.storage_grid_shape(x.domain.dealias) != expr.domain.storage_grid_shape(x.domain.dealias)):
+                return None                     # broadcasting products stay on the unfused path
+            if not isinstance(x, Field) and any(self._is_nonlinear_node(l) for l in self._lin(x).leaves):
+                return None
+        terms = [(ic, ia, ib, cf * sa * sb) for (ic, ia, ib, cf) in expr.bilinear_terms()]
+        if b0.ncomp < a0.ncomp:
+            a0, b0 = b0, a0
+            terms = [(ic, ib, ia, cf) for (ic, ia, ib, cf) in terms]
+        lim = self.ex.FUSED_LIMITS
+        if a0.ncomp > lim["na"] or b0.ncomp > lim["nb"] or expr.ncomp > lim["nc"] or len(terms) > lim["terms"]:
+            return None
+        return a0, b0, terms, last[0], last[1]
+
+    def eval_fused_products(self, group, outs):
+        """One fused launch for product nodes that share their register operand `a`.
+        group: [(expr, (a, b, terms, basis, spec))]; outs: pre-grid result arrays [ncomp, ..., M]."""
+        a = group[0][1][0]
+        basis, spec = group[0][1][3], group[0][1][4]
+        pa = self.eval_pregrid(a)
+        a_list = [pa[i] for i in range(a.ncomp)]
+        b_list, out_list, terms, bpos = [], [], [], {}
+        for (expr, (a_, b, tms, _, _)), out in zip(group, outs):
+            kb = id(b)
+            if kb not in bpos:
+                bpos[kb] = len(b_list)
+                pb = self.eval_pregrid(b)
+                b_list.extend(pb[i] for i in range(b.ncomp))
+            ob = len(out_list)
+            out_list.extend(out[i] for i in range(expr.ncomp))
+            terms.extend((ob + ic, ia, bpos[kb] + ib, cf) for (ic, ia, ib, cf) in tms)
+        M = spec[2]
+        nlines = int(np.prod(pa.shape[1:])) // M
+        self.ex.rfft_bilinear_fused(spec, basis, a_list, b_list, out_list, nlines, terms)
+
+    def _linear_to_grid_fused(self, expr, scales, skip_last=False):
         """Linear expression -> grid with the ultraspherical conversion solve fused into the mat-vec."""
         if ("c", id(expr)) in self.cache or not _full_sep(self.dist, expr.domain):
             return None
@@ -307,8 +381,12 @@ class Evaluator:
             return None
         gdom = expr.domain.replace(jac[0], b.clone_with(a=b.a0, b=b.b0))
         c = c.reshape((expr.ncomp,) + tuple(gdom.storage_coeff_shape()))
-        res = self.ex.empty((expr.ncomp,) + tuple(gdom.storage_grid_shape(scales)))
-        self.dist.transformer.backward_data(gdom, expr.ncomp, c, res, scales)
+        tr = self.dist.transformer
+        if skip_last:
+            res = self.ex.empty(tr.pregrid_shape(gdom, expr.ncomp, scales))
+        else:
+            res = self.ex.empty((expr.ncomp,) + tuple(gdom.storage_grid_shape(scales)))
+        tr.backward_data(gdom, expr.ncomp, c, res, scales, skip_last=skip_last)
         return res
 
     @staticmethod

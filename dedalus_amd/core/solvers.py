@@ -11,6 +11,8 @@ calls over ALL pencils:
 
 import time
 
+import os
+
 import numpy as np
 
 from . import operators as ops
@@ -322,6 +324,24 @@ class SolverBase:
                     blk[2] = row0
                     groups["nl"].append(tuple(blk))
         self.nl_leaves, self.nl_rows = nl_leaves, nl_rows
+        # fused grid stage: product leaves that share their register operand run in one launch
+        self.nl_fused, self.nl_plain = [], []
+        lim = self.ex.FUSED_LIMITS
+        for item in nl_leaves:
+            fp = ev.fusable_product(item[0]) if os.environ.get("DDH_NO_FUSED_GRID") is None else None
+            if fp is None:
+                self.nl_plain.append(item)
+                continue
+            for grp in self.nl_fused:
+                g0 = grp[0][1]
+                nbc = sum({id(x[1][1]): x[1][1].ncomp for x in grp + [(None, fp)]}.values())
+                if (g0[0] is fp[0] and g0[4] == fp[4] and nbc <= lim["nb"]
+                        and sum(x[0][0].ncomp for x in grp) + item[0].ncomp <= lim["nc"]
+                        and sum(len(x[1][2]) for x in grp) + len(fp[2]) <= lim["terms"]):
+                    grp.append((item, fp))
+                    break
+            else:
+                self.nl_fused.append([(item, fp)])
         nf, nx, ny, kx, ky = ev.geom()
         self.F_nl = None
         if nl_rows:
@@ -356,10 +376,18 @@ class SolverBase:
         ev.new_pass()
         parts = []
         if self.F_nl is not None:
-            for leaf, row0, rows in self.nl_leaves:
+            tr = self.dist.transformer
+            for grp in self.nl_fused:
+                outs = [ex.empty(tr.pregrid_shape(leaf.domain, leaf.ncomp, leaf.domain.dealias))
+                        for (leaf, row0, rows), fp in grp]
+                ev.eval_fused_products([(item[0], fp) for item, fp in grp], outs)
+                for ((leaf, row0, rows), fp), pg in zip(grp, outs):
+                    dst = self.NLbuf[row0:row0 + rows].reshape((leaf.ncomp,) + tuple(leaf.domain.storage_coeff_shape()))
+                    tr.forward_data(leaf.domain, leaf.ncomp, pg, leaf.domain.dealias, dst, skip_last=True)
+            for leaf, row0, rows in self.nl_plain:
                 g = ev.eval_grid(leaf)
                 dst = self.NLbuf[row0:row0 + rows].reshape((leaf.ncomp,) + tuple(leaf.domain.storage_coeff_shape()))
-                self.dist.transformer.forward_data(leaf.domain, leaf.ncomp, g, leaf.domain.dealias, dst)
+                tr.forward_data(leaf.domain, leaf.ncomp, g, leaf.domain.dealias, dst)
             y = ex.empty((self.R, self.nx, self.ny))
             self.nl_pack.matvec(self.F_nl, self.NLbuf, y)
             parts.append(y)

@@ -12,6 +12,7 @@
 // (core/transforms.py:469-509, 726-746, 844-890) are fused into the load and store phases, so each
 // transform is exactly one HBM read of its input and one HBM write of its output.
 #include "ddh_common.h"
+#include <algorithm>
 
 #include <cmath>
 #include <cstdlib>
@@ -59,6 +60,7 @@ struct FftDev {
     int boff[MAX_BANDS];
     const double *bands;   // [nbands][M]
     int B;                 // line pairs per workgroup
+    int twdirect;          // 1: full twiddle table in LDS (N entries) instead of the two-level table
     int ld;                // LDS leading dimension of the FFT buffer (>= N)
     unsigned long long *prof;   // optional phase timing (debug): [load, fft, store, count]
 };
@@ -230,8 +232,25 @@ __device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
 // Twiddles come from a two-level table held in LDS (W^q = hi[q >> 5] * lo[q & 31], < 1 KiB per
 // workgroup): the per-butterfly table reads from global memory competed with the streaming traffic for
 // L1 and cost an L2 round trip per pass.  Powers w^t are built by binary products (depth <= 4).
+__host__ __device__ __forceinline__ int tw_entries(int N, int direct) { return direct ? N : 32 + (N >> 5) + 1; }
+template <typename P>
+__device__ __forceinline__ void load_twiddles(const P &p, double2 *tw_lo, double2 *&tw_hi, int tid, int T) {
+    if (p.twdirect) {
+        for (int i = tid; i < p.N; i += T) tw_lo[i] = p.tw[i];
+        tw_hi = nullptr;
+        return;
+    }
+    for (int i = tid; i < 32 + (p.N >> 5) + 1; i += T) {
+        if (i < 32) {
+            tw_lo[i] = p.tw[i < p.N ? i : 0];
+        } else {
+            const int q = (i - 32) << 5;
+            tw_hi[i - 32] = p.tw[q < p.N ? q : 0];
+        }
+    }
+}
 __device__ __forceinline__ double2 lds_twiddle(const double2 *tw_lo, const double2 *tw_hi, int q, int sign) {
-    double2 w = cmul(tw_hi[q >> 5], tw_lo[q & 31]);
+    double2 w = tw_hi ? cmul(tw_hi[q >> 5], tw_lo[q & 31]) : tw_lo[q];
     if (sign > 0) w.y = -w.y;
     return w;
 }
@@ -371,17 +390,10 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 long npairs, unsigned blocks_per_outer) {
     extern __shared__ double2 lds[];
     double2 *buf = lds;                 // [B][ld]
-    double2 *tw_lo = lds + p.B * p.ld;  // [32]        W^q
+    double2 *tw_lo = lds + p.B * p.ld;  // [32]        W^q          (or the full table [N])
     double2 *tw_hi = tw_lo + 32;        // [N/32 + 1]  W^(32 q)
-    double2 *cbuf = tw_hi + (p.N >> 5) + 1;   // [B][M]   (Chebyshev coefficient staging only)
-    for (int i = threadIdx.x; i < 32 + (p.N >> 5) + 1; i += blockDim.x) {
-        if (i < 32) {
-            tw_lo[i] = p.tw[i < p.N ? i : 0];
-        } else {
-            const int q = (i - 32) << 5;
-            tw_hi[i - 32] = p.tw[q < p.N ? q : 0];
-        }
-    }
+    double2 *cbuf = tw_lo + tw_entries(p.N, p.twdirect);   // [B][M]   (Chebyshev coefficient staging only)
+    load_twiddles(p, tw_lo, tw_hi, threadIdx.x, blockDim.x);
     // Chebyshev normalisation (Appendix A of SURVEY.md; transforms.py:720-724, 737-746, 823-826, 844-860)
     // computed on the fly: forward sgn*sqrt(pi/2)/N (k=0: sqrt(pi)/(2N)), backward sgn/(2 sqrt(pi/2)) (k=0: 1/sqrt(pi))
     const double kSqPi = 1.7724538509055160272981674833411, kSqPi2 = 1.2533141373155002512078826424055;
@@ -755,6 +767,254 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused "grid stage" along the contiguous real-Fourier axis:
+//     out[ic] = forward_rfft( sum_t coef_t * backward_rfft(a[ia_t]) * backward_rfft(b[ib_t]) )
+// The dealiased grid values of the last axis never leave the CU: the `a` operands (e.g. the velocity) and
+// the accumulators live in registers, one LDS buffer serves all FFTs.  This replaces three HBM passes of
+// the reference sequence (backward transform of every operand, DotProduct/MultiplyFields.operate,
+// forward transform: core/transforms.py:537-565, core/arithmetic.py:666-674, 855-866) by one read of
+// the operands' coefficient lines and one write of the results' coefficient lines.
+// ------------------------------------------------------------------------------------------------
+constexpr int FUSED_NA = 3, FUSED_NC = 4, FUSED_NB = 12, FUSED_TERMS = 32, FUSED_PTS = 6;
+constexpr int FUSED_LOADS = FUSED_NA + FUSED_TERMS;
+
+struct FusedArgs {
+    const double *src[FUSED_LOADS];   // line arrays in load order: the `a` operands first
+    double dscale[FUSED_LOADS];       // != 0: differentiate along the axis while unpacking (2 pi / L)
+    double *out[FUSED_NC];
+    double coef[FUSED_TERMS];
+    short tbeg[FUSED_LOADS + 1];      // terms [tbeg[l], tbeg[l+1]) multiply load l
+    signed char flush[FUSED_LOADS];   // >= 0: result `flush` is complete after this load
+    signed char ia[FUSED_TERMS];
+    int na, nloads;
+};
+
+// LDS-DMA of the 2B coefficient lines of one operand into a raw staging buffer [2B][M/2] double2.
+// Issued through inline asm on purpose: the compiler then does not order later LDS reads behind it
+// (it would insert s_waitcnt vmcnt(0) before the next ds_read), so the copy of operand l+1 runs under
+// the FFT of operand l.  Completion is awaited explicitly with fused_dma_wait().
+__device__ __forceinline__ void fused_dma_lines(const double *src, double2 *stage, const FftDev &p, long q0,
+                                                long nlines, int tid, int T) {
+    const int Mh = p.M >> 1;
+    const int cpl = (Mh + 63) >> 6;   // 1 KiB wave chunks per line
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = T >> 6;
+    for (int line = 0; line < 2 * p.B; ++line) {
+        const long gl = 2 * q0 + line;
+        if (gl >= nlines) break;
+        for (int part = wave; part < cpl; part += nw) {
+            const int e = part * 64 + lane;
+            if (e < Mh) {
+                const double2 *g = reinterpret_cast<const double2 *>(src + gl * (long)p.M) + e;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(__attribute__((address_space(3))) void *)(stage + line * Mh + part * 64));
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                             :
+                             : "v"(g), "s"(dst)
+                             : "memory", "m0");
+            }
+        }
+    }
+}
+__device__ __forceinline__ void fused_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// staged coefficient lines (2b, 2b+1) -> Hermitian-packed spectrum in buf (contiguous-axis RFFT_BWD
+// pre-step), optionally differentiated: (cos, msin) -> (-kappa msin, kappa cos), kappa = dscale * k
+__device__ __forceinline__ void fused_unpack(double2 *buf, const double2 *stage, const FftDev &p, double dscale,
+                                             long q0, long npairs, long nlines, int tid, int T) {
+    const int N = p.N, K = p.K, B = p.B, ld = p.ld, Mh = p.M >> 1;
+    const int nzero = N - 2 * K - 1;
+    for (int w = tid; w < nzero * B; w += T) {
+        unsigned q, r;
+        p.fdB.divmod((unsigned)w, q, r);
+        buf[(int)r * ld + lpad(K + 1 + (int)q)] = make_double2(0.0, 0.0);
+    }
+    for (int w = tid; w < (K + 1) * B; w += T) {
+        unsigned q, r;
+        p.fdK1.divmod((unsigned)w, q, r);
+        const int k = (int)r, b = (int)q;
+        double2 c = make_double2(0.0, 0.0), s = c;
+        if (q0 + b < npairs) {
+            const double2 va = stage[(2 * b) * Mh + k];
+            double2 vb = make_double2(0.0, 0.0);
+            if (2 * (q0 + b) + 1 < nlines) vb = stage[(2 * b + 1) * Mh + k];
+            c = make_double2(va.x, vb.x);
+            s = make_double2(va.y, vb.y);
+            if (dscale != 0.0) {
+                const double kap = dscale * (double)k;
+                const double2 c2 = make_double2(-kap * s.x, -kap * s.y);
+                s = make_double2(kap * c.x, kap * c.y);
+                c = c2;
+            }
+        }
+        if (k == 0) {
+            buf[b * ld] = c;
+        } else {
+            buf[b * ld + lpad(k)] = make_double2(0.5 * (c.x - s.y), 0.5 * (s.x + c.y));
+            buf[b * ld + lpad(N - k)] = make_double2(0.5 * (c.x + s.y), 0.5 * (c.y - s.x));
+        }
+    }
+}
+
+// spectrum in buf -> interleaved (cos, msin) coefficient lines (contiguous-axis RFFT_FWD post-step)
+__device__ __forceinline__ void fused_store_lines(const double2 *buf, const FftDev &p, double *dst, long q0,
+                                                  long npairs, long nlines, int tid, int T) {
+    const int N = p.N, M = p.M, K = p.K, B = p.B, ld = p.ld;
+    const int Mh = M / 2;
+    const double invN = 1.0 / (double)N;
+    for (int w = tid; w < Mh * B; w += T) {
+        unsigned q, r;
+        p.fdMh.divmod((unsigned)w, q, r);
+        const int k = (int)r, b = (int)q;
+        if (q0 + b >= npairs) continue;
+        double2 c = make_double2(0.0, 0.0), s = c;
+        if (k == 0) {
+            const double2 z = buf[b * ld];
+            c = make_double2(z.x * invN, z.y * invN);
+        } else if (k <= K) {
+            const double2 z1 = buf[b * ld + lpad(k)], z2 = buf[b * ld + lpad(N - k)];
+            c = make_double2((z1.x + z2.x) * invN, (z1.y + z2.y) * invN);
+            s = make_double2((z1.y - z2.y) * invN, (z2.x - z1.x) * invN);
+        }
+        double *pa = dst + (2 * (q0 + b)) * (long)M + 2 * k;
+        *reinterpret_cast<double2 *>(pa) = make_double2(c.x, s.x);
+        if (2 * (q0 + b) + 1 < nlines) *reinterpret_cast<double2 *>(pa + M) = make_double2(c.y, s.y);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+fused_rfft_bilinear_kernel(FftDev p, FusedArgs f, long nlines, long npairs) {
+    extern __shared__ double2 lds[];
+    const int Mh = p.M >> 1;
+    double2 *buf = lds;                                // [B][ld]        FFT work buffer
+    double2 *stage = lds + p.B * p.ld;                 // [2][2B][M/2]   raw coefficient lines (double buffer)
+    double2 *tw_lo = stage + 2 * (2 * p.B * Mh);
+    double2 *tw_hi = tw_lo + 32;
+    const int tid = threadIdx.x, T = blockDim.x;
+    load_twiddles(p, tw_lo, tw_hi, tid, T);
+    // kernel arguments indexed at run time go through LDS (static indices here keep them out of scratch)
+    __shared__ const double *s_src[FUSED_LOADS];
+    __shared__ double s_dscale[FUSED_LOADS];
+    __shared__ double *s_out[FUSED_NC];
+    __shared__ double s_coef[FUSED_TERMS];
+    __shared__ short s_tbeg[FUSED_LOADS + 1];
+    __shared__ signed char s_flush[FUSED_LOADS], s_ia[FUSED_TERMS];
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < FUSED_LOADS; ++i) {
+            s_src[i] = f.src[i];
+            s_dscale[i] = f.dscale[i];
+            s_tbeg[i] = f.tbeg[i];
+            s_flush[i] = f.flush[i];
+        }
+        s_tbeg[FUSED_LOADS] = f.tbeg[FUSED_LOADS];
+#pragma unroll
+        for (int i = 0; i < FUSED_TERMS; ++i) {
+            s_coef[i] = f.coef[i];
+            s_ia[i] = f.ia[i];
+        }
+#pragma unroll
+        for (int i = 0; i < FUSED_NC; ++i) s_out[i] = f.out[i];
+    }
+    const unsigned bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const long q0 = (long)bid * p.B;
+    const int N = p.N, B = p.B, ld = p.ld;
+    const int npts = N * B;              // <= FUSED_PTS * T (checked on the host)
+    const int stage_sz = 2 * B * Mh;
+    // first operand on its way before anything else
+    fused_dma_lines(f.src[0], stage, p, q0, nlines, tid, T);
+    // LDS address of this thread's i-th grid point
+    int addr[FUSED_PTS];
+#pragma unroll
+    for (int i = 0; i < FUSED_PTS; ++i) {
+        const int e = tid + i * T;
+        unsigned q = 0, r = 0;
+        if (e < npts) p.fdN.divmod((unsigned)e, q, r);
+        addr[i] = (e < npts) ? (int)q * ld + lpad((int)r) : -1;
+    }
+    double2 areg[FUSED_NA][FUSED_PTS];
+    double2 acc[FUSED_PTS];
+#pragma unroll
+    for (int i = 0; i < FUSED_PTS; ++i) {
+        acc[i] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int ia = 0; ia < FUSED_NA; ++ia) areg[ia][i] = make_double2(0.0, 0.0);
+    }
+    const int na = f.na, nloads = f.nloads;
+    bool waited = false;
+    long long pt[4] = {0, 0, 0, 0}, tc = 0;   // debug phase clocks: wait, unpack, fft, rest
+    if (p.prof) tc = clock64();
+#define DDH_TICK(slot)                      \
+    if (p.prof) {                           \
+        const long long now = clock64();    \
+        pt[slot] += now - tc;               \
+        tc = now;                           \
+    }
+#pragma unroll 1
+    for (int l = 0; l < nloads; ++l) {
+        DDH_TICK(3)
+        if (!waited) fused_dma_wait();
+        waited = false;
+        __syncthreads();                     // stage[l & 1] has landed for every wave; buf is free
+        DDH_TICK(0)
+        if (l + 1 < nloads)
+            fused_dma_lines(s_src[l + 1], stage + ((l + 1) & 1) * stage_sz, p, q0, nlines, tid, T);
+        fused_unpack(buf, stage + (l & 1) * stage_sz, p, s_dscale[l], q0, npairs, nlines, tid, T);
+        __syncthreads();
+        DDH_TICK(1)
+        lds_fft(buf, p, tw_lo, tw_hi, +1, tid, T);
+        DDH_TICK(2)
+        double2 wv[FUSED_PTS];
+#pragma unroll
+        for (int i = 0; i < FUSED_PTS; ++i) wv[i] = (addr[i] >= 0) ? buf[addr[i]] : make_double2(0.0, 0.0);
+        if (l < na) {
+            // `a` operands stay in registers (run-time l, static register selection)
+#pragma unroll
+            for (int i = 0; i < FUSED_PTS; ++i)
+#pragma unroll
+                for (int ia = 0; ia < FUSED_NA; ++ia)
+                    if (l == ia) areg[ia][i] = wv[i];
+            continue;
+        }
+        const int t1 = s_tbeg[l + 1];
+#pragma unroll 1
+        for (int t = s_tbeg[l]; t < t1; ++t) {
+            const double cf = s_coef[t];
+            const int tia = s_ia[t];
+#pragma unroll
+            for (int i = 0; i < FUSED_PTS; ++i) {
+                double2 av = areg[0][i];
+#pragma unroll
+                for (int ia = 1; ia < FUSED_NA; ++ia)
+                    if (tia == ia) av = areg[ia][i];
+                // two packed lines: real parts multiply real parts, imaginary parts imaginary parts
+                acc[i].x += cf * av.x * wv[i].x;
+                acc[i].y += cf * av.y * wv[i].y;
+            }
+        }
+        const int oc = s_flush[l];
+        if (oc >= 0) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < FUSED_PTS; ++i) {
+                if (addr[i] >= 0) buf[addr[i]] = acc[i];
+                acc[i] = make_double2(0.0, 0.0);
+            }
+            __syncthreads();
+            DDH_TICK(3)
+            lds_fft(buf, p, tw_lo, tw_hi, -1, tid, T);
+            DDH_TICK(2)
+            fused_dma_wait();                // the next operand landed long ago; keeps the stores below
+            waited = true;                   // out of the next wait
+            fused_store_lines(buf, p, s_out[oc], q0, npairs, nlines, tid, T);
+        }
+    }
+    DDH_TICK(3)
+#undef DDH_TICK
+    if (p.prof && tid == 0)
+        for (int i = 0; i < 4; ++i) atomicAdd(&p.prof[i], (unsigned long long)pt[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static bool factorize(int n, int *radix, int &nradix) {
@@ -862,6 +1122,24 @@ static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nba
         return st;
     }
     d.ld = N + (N >> 4) + 1;
+    d.twdirect = (getenv("DDH_FFT_TWDIRECT") && atoi(getenv("DDH_FFT_TWDIRECT"))) ? 1 : 0;
+    if (const char *rs = getenv("DDH_FFT_RADIX")) {   // tuning aid: "16,16,3" replaces the schedule when it fits N
+        int r[MAX_RADIX_PASSES], n = 0, prod = 1;
+        for (const char *c = rs; *c && n < MAX_RADIX_PASSES;) {
+            r[n] = atoi(c);
+            prod *= r[n] > 0 ? r[n] : 1;
+            ++n;
+            while (*c && *c != ',') ++c;
+            if (*c == ',') ++c;
+        }
+        bool ok = prod == N;
+        for (int i = 0; i < n; ++i)
+            ok = ok && (r[i] == 2 || r[i] == 3 || r[i] == 4 || r[i] == 5 || r[i] == 7 || r[i] == 8 || r[i] == 16);
+        if (ok) {
+            d.nradix = n;
+            for (int i = 0; i < n; ++i) d.radix[i] = r[i];
+        }
+    }
     d.prof = nullptr;
     if (getenv("DDH_FFT_PROF") && atoi(getenv("DDH_FFT_PROF"))) {
         void *pm = nullptr;
@@ -917,7 +1195,7 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     const unsigned bpo = (unsigned)((npairs + B - 1) / B);
     const unsigned long nblocks = inner_mode ? (unsigned long)bpo * (unsigned long)outer : bpo;
     if (nblocks > 0x7fffffffUL) return fail("transform: grid too large");
-    const size_t lds = per_line * B + (size_t)(32 + (N >> 5) + 1) * sizeof(double2);
+    const size_t lds = per_line * B + (size_t)tw_entries(N, d.twdirect) * sizeof(double2);
     hipStream_t s = as_stream(stream);
 #define DDH_FFT_LAUNCH(INNERV, TMAXV, MINWV)                                                                \
     {                                                                                                       \
@@ -1037,6 +1315,85 @@ DDH_FFT_ENTRY(ddh_cheb_forward, K_CHEB, CHEB_FWD)
 DDH_FFT_ENTRY(ddh_cheb_backward, K_CHEB, CHEB_BWD)
 DDH_FFT_ENTRY(ddh_cfft_forward, K_CFFT, CFFT_FWD)
 DDH_FFT_ENTRY(ddh_cfft_backward, K_CFFT, CFFT_BWD)
+
+int ddh_rfft_bilinear_fused(ddh_handle plan, int na, const double *const *a_h, const double *a_dscale_h, int nb,
+                            const double *const *b_h, const double *b_dscale_h, int nc, double *const *out_h,
+                            long nlines, int nterms, const int *ic_h, const int *ia_h, const int *ib_h,
+                            const double *coef_h, void *stream) {
+    FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
+    if (!pl) return -1;
+    if (pl->tkind != K_RFFT) return fail("rfft_bilinear_fused: needs an rfft plan");
+    if (na < 1 || na > FUSED_NA || nb < 1 || nb > FUSED_NB || nc < 1 || nc > FUSED_NC || nterms < 1 ||
+        nterms > FUSED_TERMS)
+        return fail("rfft_bilinear_fused: operand counts out of range (na<=3, nb<=12, nc<=4, terms<=32)");
+    if (nlines <= 0) return 0;
+    FftDev d = pl->dev;
+    static const int envT = getenv("DDH_FUSED_T") ? atoi(getenv("DDH_FUSED_T")) : 256;
+    const int T = (envT == 128 || envT == 64) ? envT : 256;
+    int B = T / 128 > 0 ? T / 128 : 1;
+    while (B > 1 && (long)d.N * B > (long)FUSED_PTS * T) B /= 2;
+    if ((long)d.N * B > (long)FUSED_PTS * T || (long)d.N * B > 12L * T)
+        return fail("rfft_bilinear_fused: axis too long for the fused kernel");
+    d.B = B;
+    d.fdB.set((unsigned)B);
+    int order[FUSED_TERMS];
+    for (int t = 0; t < nterms; ++t) {
+        if (ia_h[t] < 0 || ia_h[t] >= na || ib_h[t] < 0 || ib_h[t] >= nb || ic_h[t] < 0 || ic_h[t] >= nc)
+            return fail("rfft_bilinear_fused: term index out of range");
+        order[t] = t;
+    }
+    std::stable_sort(order, order + nterms, [&](int x, int y) {
+        return ic_h[x] != ic_h[y] ? ic_h[x] < ic_h[y] : ib_h[x] < ib_h[y];
+    });
+    // load sequence: the `a` operands, then per result its `b` operands (one load per (ic, ib) group)
+    FusedArgs f;
+    memset(&f, 0, sizeof(f));
+    f.na = na;
+    int nl = 0;
+    for (int i = 0; i < na; ++i) {
+        f.src[nl] = a_h[i];
+        f.dscale[nl] = a_dscale_h ? a_dscale_h[i] : 0.0;
+        f.tbeg[nl] = 0;
+        f.flush[nl] = -1;
+        ++nl;
+    }
+    bool has_terms[FUSED_NC] = {false, false, false, false};
+    for (int t = 0; t < nterms; ++t) {
+        const int o = order[t];
+        const bool fresh = (t == 0) || ic_h[o] != ic_h[order[t - 1]] || ib_h[o] != ib_h[order[t - 1]];
+        if (fresh) {
+            f.src[nl] = b_h[ib_h[o]];
+            f.dscale[nl] = b_dscale_h ? b_dscale_h[ib_h[o]] : 0.0;
+            f.tbeg[nl] = (short)t;
+            f.flush[nl] = -1;
+            ++nl;
+        }
+        f.coef[t] = coef_h[o];
+        f.ia[t] = (signed char)ia_h[o];
+        has_terms[ic_h[o]] = true;
+        const bool last_of_result = (t == nterms - 1) || ic_h[order[t + 1]] != ic_h[o];
+        if (last_of_result) f.flush[nl - 1] = (signed char)ic_h[o];
+    }
+    for (int l = nl; l <= FUSED_LOADS; ++l) f.tbeg[l] = (short)nterms;
+    f.nloads = nl;
+    for (int i = 0; i < nc; ++i) {
+        f.out[i] = out_h[i];
+        if (!has_terms[i])
+            DDH_HIP(hipMemsetAsync(out_h[i], 0, (size_t)nlines * d.M * sizeof(double), as_stream(stream)));
+    }
+    const long npairs = (nlines + 1) / 2;
+    const unsigned long nblocks = (unsigned long)((npairs + B - 1) / B);
+    if (nblocks > 0x7fffffffUL) return fail("rfft_bilinear_fused: grid too large");
+    const size_t lds = ((size_t)d.ld * B + (size_t)4 * B * (d.M / 2) + (size_t)tw_entries(d.N, d.twdirect)) *
+                       sizeof(double2);
+    if (lds > 64 * 1024)
+        DDH_HIP(hipFuncSetAttribute((const void *)fused_rfft_bilinear_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fused_rfft_bilinear_kernel, dim3((unsigned)nblocks), dim3(T), lds, as_stream(stream), d, f,
+                       nlines, npairs);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
 
 int ddh_plan_mmt(ddh_handle *plan, int n_out, int n_in, const double *mat_h) {
     if (n_out < 1 || n_in < 1) return fail("plan_mmt: sizes must be positive");

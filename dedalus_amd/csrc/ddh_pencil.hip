@@ -889,7 +889,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
     const int W = d.W;
     const size_t lds_f = (size_t)(d.N + d.nb) * 5 + 16, lds_b = (size_t)(d.n > 0 ? d.n : 1) * 5 + 16;
     if (lds_f > 64 * 1024) return fail("pencil_solve: system too large for the LDS permutation cache");
-    static const int bwd_pref = getenv("DDH_SOLVE_PREF") ? atoi(getenv("DDH_SOLVE_PREF")) : 1;
+    static const int bwd_pref = getenv("DDH_SOLVE_PREF") ? atoi(getenv("DDH_SOLVE_PREF")) : 0;
 #define DDH_FWD(KLTV, NBTV)                                                                                        \
     {                                                                                                              \
         if (d.real)                                                                                                \
@@ -911,7 +911,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
             else                                                                                                   \
                 hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
         } else                                                                                                     \
-            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false, true>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
+            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
     }
     if (d.n > 0) {
         if (W <= 8) DDH_SOLVE(8)

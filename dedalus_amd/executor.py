@@ -77,6 +77,39 @@ class HipExecutor:
         libhip.call("ddh_grid_bilinear", ptr(out), ncomp_out, ptr(a), ptr(b), npts, len(terms),
                     libhip.as_ip(ic), libhip.as_ip(ia), libhip.as_ip(ib), libhip.as_dp(cf), self.dev.stream)
 
+    FUSED_LIMITS = dict(na=3, nb=12, nc=4, terms=32, max_grid=1536)
+
+    def fused_capable(self, spec):
+        """Can the grid stage along a contiguous RealFourier axis with this plan spec run fused?"""
+        return spec[0] == "rfft" and spec[1] <= self.FUSED_LIMITS["max_grid"]
+
+    def rfft_bilinear_fused(self, spec, basis, a_list, b_list, out_list, nlines, terms, a_dscale=None,
+                            b_dscale=None):
+        """out[ic] = rfft_fwd(sum coef * rfft_bwd(D a[ia]) * rfft_bwd(D b[ib])) on [nlines][M] line arrays;
+        a_dscale / b_dscale: per operand 2 pi / L to differentiate along the axis at load, 0 for none."""
+        if self.timer is not None:
+            nb = (len(a_list) + len(b_list) + len(out_list)) * nlines * spec[2] * 8
+            return self.timer.run("rfft_bilinear_fused", nb, self._rfft_bilinear_fused, spec, basis, a_list, b_list,
+                                  out_list, nlines, terms, a_dscale, b_dscale)
+        return self._rfft_bilinear_fused(spec, basis, a_list, b_list, out_list, nlines, terms, a_dscale, b_dscale)
+
+    def _rfft_bilinear_fused(self, spec, basis, a_list, b_list, out_list, nlines, terms, a_dscale=None,
+                             b_dscale=None):
+        kind, h, _ = self._plan(spec, basis)
+        ads = np.ascontiguousarray(a_dscale if a_dscale is not None else np.zeros(len(a_list)), dtype=np.float64)
+        bds = np.ascontiguousarray(b_dscale if b_dscale is not None else np.zeros(len(b_list)), dtype=np.float64)
+        pa = (C.c_void_p * len(a_list))(*[C.c_void_p(x.data_ptr()) for x in a_list])
+        pb = (C.c_void_p * len(b_list))(*[C.c_void_p(x.data_ptr()) for x in b_list])
+        po = (C.c_void_p * len(out_list))(*[C.c_void_p(x.data_ptr()) for x in out_list])
+        ic = np.ascontiguousarray([t[0] for t in terms], dtype=np.int32)
+        ia = np.ascontiguousarray([t[1] for t in terms], dtype=np.int32)
+        ib = np.ascontiguousarray([t[2] for t in terms], dtype=np.int32)
+        cf = np.ascontiguousarray([t[3] for t in terms], dtype=np.float64)
+        libhip.call("ddh_rfft_bilinear_fused", h, len(a_list), pa, libhip.as_dp(ads), len(b_list), pb,
+                    libhip.as_dp(bds), len(out_list), po, nlines,
+                    len(terms), libhip.as_ip(ic), libhip.as_ip(ia), libhip.as_ip(ib), libhip.as_dp(cf),
+                    self.dev.stream)
+
     def _plan(self, spec, basis):
         if spec not in self._plans:
             h = C.c_uint64(0)

@@ -55,6 +55,20 @@ int ddh_plan_cfft(ddh_handle *plan, int n_grid, int n_coeff);
 int ddh_cfft_forward(ddh_handle plan, const double *g, double *c, long outer, long inner, void *stream);
 int ddh_cfft_backward(ddh_handle plan, const double *c, double *g, long outer, long inner, void *stream);
 
+/* Fused grid stage along the contiguous RealFourier axis: for every line
+ *   out[ic] = rfft_forward( sum_t coef[t] * rfft_backward(D a[ia[t]]) * rfft_backward(D b[ib[t]]) )
+ * a_h / b_h / out_h are host arrays of device pointers to [nlines][n_coeff] coefficient-line arrays
+ * (na <= 3, nb <= 12, nc <= 4, nterms <= 32).  a_dscale_h / b_dscale_h (nullable) select per operand
+ * D = d/dy applied while the line is unpacked: a value kappa0 = 2 pi / L != 0 maps mode k
+ * (cos, msin) -> (-k kappa0 msin, k kappa0 cos), i.e. DifferentiateRealFourier (core/basis.py:1233-1260);
+ * 0 means D = identity.  One launch replaces the last backward transform of every operand, the
+ * product (DotProduct / MultiplyFields.operate, core/arithmetic.py:666-674, 855-866) and the first
+ * forward transform of the result; the dealiased grid data of that axis never reaches HBM. */
+int ddh_rfft_bilinear_fused(ddh_handle plan, int na, const double *const *a_h, const double *a_dscale_h,
+                            int nb, const double *const *b_h, const double *b_dscale_h, int nc,
+                            double *const *out_h, long nlines, int nterms, const int *ic_h,
+                            const int *ia_h, const int *ib_h, const double *coef_h, void *stream);
+
 /* Chebyshev-T grid (a0=b0=-1/2) with optional ultraspherical output basis: replaces
  * FFTWFastChebyshevTransform core/transforms.py:801-902 (FastCosineTransform :715-746, FFTWDCT
  * :771-798, conversion apply :862-874, solve_upper_sparse :876-890).

@@ -107,6 +107,40 @@ class NumpyExecutor:
             o[ic] += cf * a2[ia] * b2[ib]
         out[...] = o.reshape(out.shape)
 
+    FUSED_LIMITS = dict(na=3, nb=12, nc=4, terms=32, max_grid=1536)
+
+    def fused_capable(self, spec):
+        return spec[0] == "rfft" and spec[1] <= self.FUSED_LIMITS["max_grid"]
+
+    @staticmethod
+    def _fourier_diff(lines, dscale):
+        """DifferentiateRealFourier (core/basis.py:1233-1260) on [nlines][M] (cos, msin) lines."""
+        if not dscale:
+            return lines
+        M = lines.shape[1]
+        k = dscale * np.arange(M // 2)
+        out = np.empty_like(lines)
+        out[:, 0::2] = -k * lines[:, 1::2]
+        out[:, 1::2] = k * lines[:, 0::2]
+        return out
+
+    def rfft_bilinear_fused(self, spec, basis, a_list, b_list, out_list, nlines, terms, a_dscale=None,
+                            b_dscale=None):
+        """Unfused restatement: (derivative,) backward transforms (core/transforms.py:559-565), product
+        (core/arithmetic.py:666-674), forward transform (:551-557) along the last axis."""
+        N, M = spec[1], spec[2]
+        a_dscale = a_dscale if a_dscale is not None else [0.0] * len(a_list)
+        b_dscale = b_dscale if b_dscale is not None else [0.0] * len(b_list)
+        ga = [npt.rfft_backward(self._fourier_diff(a.reshape(nlines, M), ds).reshape(nlines, M, 1), 1, N)
+              for a, ds in zip(a_list, a_dscale)]
+        gb = [npt.rfft_backward(self._fourier_diff(b.reshape(nlines, M), ds).reshape(nlines, M, 1), 1, N)
+              for b, ds in zip(b_list, b_dscale)]
+        acc = [np.zeros((nlines, N, 1)) for _ in out_list]
+        for (ic, ia, ib, cf) in terms:
+            acc[ic] += cf * ga[ia] * gb[ib]
+        for o, g in zip(out_list, acc):
+            o[...] = npt.rfft_forward(g, 1, M).reshape(o.shape)
+
     def transform(self, spec, basis, direction, src, dst, outer, inner):
         kind = spec[0]
         n_in = src.size // (outer * inner)

@@ -171,3 +171,46 @@ def test_mmt_matches_matrix_definition(dev):
     g = rng.standard_normal((3, N, 37))
     out = _run(dev, "ddh_mmt_apply", h, g, (3, M, 37), 1)
     assert rel(out, npt.apply_matrix_along_axis(F, g, 1)) < TOL
+
+
+@pytest.mark.parametrize("N,M,nlines", [(768, 512, 37), (24, 16, 10), (96, 64, 1), (1536, 1024, 6), (60, 40, 129),
+                                        (384, 256, 64)])
+@pytest.mark.parametrize("na,nbs,ncs", [(3, (3, 9), (1, 3)), (1, (1,), (1,)), (2, (2, 4), (1, 2))])
+def test_fused_grid_stage(dev, N, M, nlines, na, nbs, ncs):
+    """ddh_rfft_bilinear_fused == backward transforms + products + forward transform of the oracle
+    (u.grad(b) and u.grad(u) shaped term tables)."""
+    from dedalus_amd.executor import HipExecutor
+    from oracle.np_executor import NumpyExecutor
+    rng = np.random.default_rng(N + 7 * nlines + na)
+    a = rng.standard_normal((na, nlines, M))
+    bs = [rng.standard_normal((nb, nlines, M)) for nb in nbs]
+    for arr in [a] + bs:
+        arr[..., 1] = 0.0                      # msin slot of k = 0 carries no data
+    terms, ob, bb = [], 0, 0
+    for nb, nc in zip(nbs, ncs):
+        for c in range(nc):
+            for j in range(na):
+                terms.append((ob + c, j, bb + (c * na + j) % nb, float(rng.standard_normal())))
+        ob += nc
+        bb += nb
+    spec = ("rfft", N, M)
+    nex = NumpyExecutor()
+    a_l = [a[i] for i in range(na)]
+    b_l = [b[i] for b in bs for i in range(b.shape[0])]
+    ref = [np.full((nlines, M), np.nan) for _ in range(ob)]
+    ads = [0.0] * na
+    bds = [(1.7 if i % 3 == 1 else 0.0) for i in range(len(b_l))]      # some operands differentiated at load
+    if na > 1:
+        ads[1] = 0.6
+    nex.rfft_bilinear_fused(spec, None, a_l, b_l, ref, nlines, terms, ads, bds)
+    hex_ = HipExecutor(dev)
+    da = hex_.from_host(a)
+    dbs = [hex_.from_host(b) for b in bs]
+    dout = hex_.empty((ob, nlines, M))
+    dout.fill_(float("nan"))
+    hex_.rfft_bilinear_fused(spec, None, [da[i] for i in range(na)], [d[i] for d in dbs for i in range(d.shape[0])],
+                             [dout[i] for i in range(ob)], nlines, terms, ads, bds)
+    hex_.sync()
+    got = hex_.download(dout)
+    for i in range(ob):
+        assert rel(got[i], ref[i]) < TOL, (i, rel(got[i], ref[i]))

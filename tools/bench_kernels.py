@@ -41,7 +41,7 @@ def main():
         # name, kind, N, M, coeff shape [outer, M, inner], as seen by the kernel
         ("z  cheb  bwd/fwd  [kz,kx*ky]", "cheb", Gz, Nz, (1, Nz, Nx * Ny)),
         ("y  rfft  bwd/fwd  contiguous", "rfft", Gy, Ny, (Gz * Nx, Ny, 1)),
-        ("x  rfft  bwd/fwd  inner=Gy  ", "rfft", Gx, Nx, (Gz, Nx, Gy)),
+        ("x  rfft  bwd/fwd  inner=Ny  ", "rfft", Gx, Nx, (Gz, Nx, Ny)),
     ]
     for name, kind, N, M, cs in cases:
         p = plan("ddh_plan_cheb", N, M, 0, None, None) if kind == "cheb" else plan("ddh_plan_rfft", N, M)
@@ -67,6 +67,35 @@ def main():
         print("%s  bwd %.3f ms %.0f GB/s | fwd %.3f ms %.0f GB/s   (%.2f GB/pass)" %
               (name, tb * 1e3, bytes_ / tb / 1e9, tf * 1e3, bytes_ / tf / 1e9, bytes_ / 1e9), flush=True)
         del c, g, c2
+    # fused grid stage along y: u.grad(b) and u.grad(u) (3 + 12 operands, 4 results)
+    from dedalus_amd.executor import HipExecutor
+    hx = HipExecutor(dev)
+    nl = (Gz // int(os.environ.get("FUSED_ZDIV", "4"))) * Gx
+    a = t.randn((3, nl, Ny), dtype=t.float64, device=dev.tdev)
+    bb = t.randn((12, nl, Ny), dtype=t.float64, device=dev.tdev)
+    oo = dev.empty((4, nl, Ny))
+    terms = [(0, j, j, 1.0) for j in range(3)] + [(1 + c, j, 3 + 3 * j + c, 1.0) for c in range(3) for j in range(3)]
+    tfz = timeit(dev, lambda: hx.rfft_bilinear_fused(("rfft", Gy, Ny), None, [a[i] for i in range(3)],
+                                                     [bb[i] for i in range(12)], [oo[i] for i in range(4)], nl, terms))
+    if os.environ.get("DDH_FFT_PROF"):
+        lib = libhip.load()
+        lib.ddh_debug_fft_prof.argtypes = [C.c_uint64, C.POINTER(C.c_double)]
+        out = (C.c_double * 4)()
+        ph = hx._plan(("rfft", Gy, Ny), None)[1]
+        lib.ddh_debug_fft_prof(ph, out)
+        hx.rfft_bilinear_fused(("rfft", Gy, Ny), None, [a[i] for i in range(3)], [bb[i] for i in range(12)],
+                               [oo[i] for i in range(4)], nl, terms)
+        dev.sync()
+        lib.ddh_debug_fft_prof(ph, out)
+        vals = [out[0] * out[3], out[1] * out[3], out[2] * out[3], out[3]]    # the hook divides by slot 3
+        tot = sum(vals)
+        nwg = (nl // 2 + 1) // 2
+        print("   fused phase clocks per WG: wait %.0f unpack %.0f fft %.0f rest %.0f  -> %% %s"
+              % tuple([v / nwg for v in vals] + [[round(100 * x / tot, 1) for x in vals]]))
+    nbytes = 19 * nl * Ny * 8
+    print("y  fused grid stage (19 lines arrays, %d lines): %.3f ms %.0f GB/s -> full size %.2f ms"
+          % (nl, tfz * 1e3, nbytes / tfz / 1e9, tfz * 1e3 * Gz * Gx / nl), flush=True)
+    del a, bb, oo
     # plain copy for reference
     a = t.randn(2 ** 27, dtype=t.float64, device=dev.tdev)
     b = t.empty_like(a)
