@@ -212,29 +212,47 @@ class Transformer:
             shape[-1] = b.coeff_size            # full size: this layout sits on the grid side of the exchange
         return tuple(shape)
 
-    def backward_data(self, domain, ncomp, c, g, scales, skip_last=False):
-        """coefficient -> grid: z transform (local, kx-sharded), all-to-all (-> z-sharded, kx local),
-        then the Fourier transforms.  skip_last stops before the last storage axis ("pre-grid" layout)."""
+    def nsteps(self, domain, scales):
+        return len(self._steps(domain, scales))
+
+    def stage_shape(self, domain, ncomp, scales, k):
+        """Local shape after the first k backward steps (k = 0: coefficient space)."""
+        steps = self._steps(domain, scales)
+        shape = [ncomp] + list(domain.storage_coeff_shape())
+        exchange = self._needs_exchange(domain)
+        for (pos, b, spec) in steps[:k]:
+            ax = self.dist.storage_order[pos]
+            shape[pos + 1] = b.grid_size(scales[ax])
+            if exchange and pos == 0:
+                P = self.dist.size
+                shape[1], shape[2] = shape[1] // P, shape[2] * P
+        return tuple(shape)
+
+    def backward_steps(self, domain, ncomp, src, scales, i0, i1, dst=None, deriv=None):
+        """Apply backward steps i0 .. i1-1 to data that has seen steps < i0 (z transform first, then the
+        all-to-all (-> z-sharded, kx local), then the Fourier transforms).  deriv = (step, 2 pi / L)
+        differentiates along that RealFourier step's axis while its coefficients are loaded.
+        Returns the result (dst when given)."""
         ex = self.dist.executor
         steps = self._steps(domain, scales)
-        if skip_last:
-            steps = steps[:-1]
-        shape = [ncomp] + list(domain.storage_coeff_shape())
-        if not steps:
-            ex.copy(g, c)
-            return
+        shape = list(self.stage_shape(domain, ncomp, scales, i0))
         exchange = self._needs_exchange(domain)
-        src = c
-        for i, (pos, b, spec) in enumerate(steps):
+        for i in range(i0, i1):
+            pos, b, spec = steps[i]
             ax = self.dist.storage_order[pos]
             n_out = b.grid_size(scales[ax])
             outer = int(np.prod(shape[:pos + 1]))
             inner = int(np.prod(shape[pos + 2:]))
             shape[pos + 1] = n_out
-            last = (i == len(steps) - 1)
-            dst = g if (last and not (exchange and pos == 0)) else ex.empty(tuple(shape))
-            ex.transform(spec, b, "backward", src, dst, outer, inner)
-            src = dst
+            last = (i == i1 - 1)
+            out = dst if (last and dst is not None and not (exchange and pos == 0)) else ex.empty(tuple(shape))
+            if deriv is not None and deriv[0] == i:
+                if spec[0] != "rfft":
+                    raise NotImplementedError("derivative at load along a non-Fourier axis")
+                ex.transform(spec, b, "backward", src, out, outer, inner, deriv=deriv[1])
+            else:
+                ex.transform(spec, b, "backward", src, out, outer, inner)
+            src = out
             if exchange and pos == 0:
                 # [comp, Gz, nx_loc, ny] -> [comp, Gz/P, nx, ny]
                 P = self.dist.size
@@ -245,9 +263,18 @@ class Transformer:
                 recv = ex.empty(send.shape)
                 self.dist.pcomm.all_to_all(recv, send)
                 shape[1], shape[2] = Gz // P, nxl * P
-                dst2 = g if last else ex.empty(tuple(shape))
-                ex.a2a_unpack(recv, dst2, nc, Gz // P, nxl * P, rest, P)
-                src = dst2
+                out2 = dst if (last and dst is not None) else ex.empty(tuple(shape))
+                ex.a2a_unpack(recv, out2, nc, Gz // P, nxl * P, rest, P)
+                src = out2
+        return src
+
+    def backward_data(self, domain, ncomp, c, g, scales, skip_last=False):
+        """coefficient -> grid.  skip_last stops before the last storage axis ("pre-grid" layout)."""
+        n = self.nsteps(domain, scales) - (1 if skip_last else 0)
+        if n <= 0:
+            self.dist.executor.copy(g, c)
+            return
+        self.backward_steps(domain, ncomp, c, scales, 0, n, dst=g)
 
     def forward_data(self, domain, ncomp, g, scales, c, skip_last=False):
         ex = self.dist.executor

@@ -15,6 +15,8 @@ expression is split into alternating stages that each map to few large kernel la
 Nothing leaves HBM between the stages.
 """
 
+import os
+
 import numpy as np
 
 from . import operators as ops
@@ -291,6 +293,20 @@ class Evaluator:
         self.cache[key] = res
         return res
 
+    def eval_stage(self, leaf, k):
+        """Data of a Field after the first k backward transform steps (k = 0: coefficients)."""
+        key = ("s", id(leaf), k)
+        if key in self.cache:
+            return self.cache[key]
+        dom = leaf.domain
+        if k == 0:
+            res = leaf.coeff_data().reshape((leaf.ncomp,) + tuple(dom.storage_coeff_shape()))
+        else:
+            prev = self.eval_stage(leaf, k - 1)
+            res = self.dist.transformer.backward_steps(dom, leaf.ncomp, prev, dom.dealias, k - 1, k)
+        self.cache[key] = res
+        return res
+
     def eval_pregrid(self, expr):
         """Data of a field / linear expression with every axis but the last storage axis in (dealiased)
         grid space: the operand layout of the fused grid stage."""
@@ -302,14 +318,123 @@ class Evaluator:
         tr = self.dist.transformer
         if self._is_nonlinear_node(expr):
             raise NotImplementedError("pre-grid data of a nonlinear node")
-        res = None
-        if not isinstance(expr, Field):
-            res = self._linear_to_grid_fused(expr, scales, skip_last=True)
-        if res is None:
-            c = expr.coeff_data() if isinstance(expr, Field) else self.eval_coeff(expr)
-            c = c.reshape((expr.ncomp,) + tuple(expr.domain.storage_coeff_shape()))
-            res = self.ex.empty(tr.pregrid_shape(expr.domain, expr.ncomp, scales))
-            tr.backward_data(expr.domain, expr.ncomp, c, res, scales, skip_last=True)
+        if isinstance(expr, Field):
+            res = self.eval_stage(expr, max(tr.nsteps(expr.domain, scales) - 1, 0))
+        else:
+            res = self._le_to_grid(self._lin(expr), expr.domain, expr.ncomp, scales, skip_last=True)
+        self.cache[key] = res
+        return res
+
+    # ---- operands of the fused grid stage -------------------------------------------------------------------
+    def _derived_component(self, x, items, steps):
+        """(leaf, ci, step, dscale) when component `items` of the linear expression x is a Fourier
+        derivative of one component of a field (up to the Jacobi conversion that the backward transform
+        undoes): its grid data then comes from the field's own partially transformed data, with the
+        derivative applied while that axis' coefficients are loaded."""
+        from .polyop import LinExpr
+        if len(items) != 1:
+            return None
+        leaf, t = items[0]
+        if not isinstance(leaf, Field) or getattr(leaf, "_is_number", False):
+            return None
+        if t.dx or t.dy or t.dt or (t.ex + t.ey) != 1:
+            return None
+        ld, xd = leaf.domain, x.domain
+        if ld.dealias != xd.dealias or ld.storage_coeff_shape() != xd.storage_coeff_shape():
+            return None
+        if ld.storage_grid_shape(ld.dealias) != xd.storage_grid_shape(xd.dealias):
+            return None
+        try:
+            ident = LinExpr.identity(leaf, 1, self.dist.coupled_size(ld))
+            expect = ops.convert_linexpr(ident, self.dist, ld, xd).leaves[leaf][0]
+        except (ValueError, NotImplementedError):
+            return None
+        if expect.dx or expect.dy or expect.Z.shape != t.Z.shape:
+            return None
+        diff = (expect.Z - t.Z)
+        if diff.nnz and abs(diff).max() > 1e-13:
+            return None
+        sep = self.dist.separable_axes
+        axis = sep[0] if t.ex else sep[1]
+        basis = xd.by_axis[axis]
+        r = t.coef / (1j * expect.coef)
+        if basis is None or abs(r.imag) > 1e-14 * max(abs(r), 1.0):
+            return None
+        step = [i for i, (pos, b, spec) in enumerate(steps) if self.dist.storage_order[pos] == axis]
+        if len(step) != 1 or steps[step[0]][2][0] != "rfft":
+            return None
+        return (leaf, t.ci, step[0], float(r.real) * 2.0 * np.pi / basis.length)
+
+    def _component_plan(self, x):
+        """Split the components of a linear expression into Fourier-derivative components (see
+        _derived_component) and generic ones (evaluated by the batched mat-vec)."""
+        plan = getattr(x, "_fuse_plan", None)
+        if plan is not None:
+            return plan
+        from .polyop import LinExpr
+        le = self._lin(x)
+        steps = self.dist.transformer._steps(x.domain, x.domain.dealias)
+        per = {co: [] for co in range(x.ncomp)}
+        for leaf, terms in le.leaves.items():
+            for t in terms:
+                per[t.co].append((leaf, t))
+        derived, generic = {}, []
+        no_deriv = os.environ.get("DDH_NO_DERIV_AT_LOAD") is not None
+        for co in range(x.ncomp):
+            d = None if no_deriv else self._derived_component(x, per[co], steps)
+            if d is None:
+                generic.append(co)
+            else:
+                derived[co] = d
+        sub = None
+        if generic:
+            idx = {co: i for i, co in enumerate(generic)}
+            sub = LinExpr(len(generic), le.nzo,
+                          {leaf: [t.copy(co=idx[t.co]) for t in terms if t.co in idx] for leaf, terms in le.leaves.items()})
+        plan = x._fuse_plan = (derived, generic, sub)
+        return plan
+
+    def _operand_lines(self, x):
+        """Per component of a product factor: (parent array, index, dscale) such that parent[index] holds the
+        component's pre-grid lines and dscale != 0 asks the fused kernel to differentiate at load."""
+        x = self.canon(x)
+        key = ("ol", id(x))
+        if key in self.cache:
+            return self.cache[key]
+        if isinstance(x, Field):
+            pg = self.eval_pregrid(x)
+            res = [(pg, i, 0.0) for i in range(x.ncomp)]
+            self.cache[key] = res
+            return res
+        derived, generic, sub = self._component_plan(x)
+        tr = self.dist.transformer
+        scales = x.domain.dealias
+        res = [None] * x.ncomp
+        if generic:
+            arr = self._le_to_grid(sub, x.domain, len(generic), scales, skip_last=True)
+            for i, co in enumerate(generic):
+                res[co] = (arr, i, 0.0)
+        groups = {}
+        for co, (leaf, ci, step, dscale) in derived.items():
+            groups.setdefault((id(leaf), step, dscale), [leaf, []])[1].append((co, ci))
+        for (lid, step, dscale), (leaf, members) in groups.items():
+            n = tr.nsteps(leaf.domain, scales)
+            if step == n - 1:
+                pg = self.eval_stage(leaf, n - 1)
+                for co, ci in members:
+                    res[co] = (pg, ci, dscale)
+                continue
+            src = self.eval_stage(leaf, step)
+            cis = sorted({ci for _, ci in members})
+            if cis == list(range(leaf.ncomp)):
+                out = tr.backward_steps(leaf.domain, leaf.ncomp, src, scales, step, n - 1, deriv=(step, dscale))
+                for co, ci in members:
+                    res[co] = (out, ci, 0.0)
+            else:
+                outs = {ci: tr.backward_steps(leaf.domain, 1, src[ci:ci + 1], scales, step, n - 1,
+                                              deriv=(step, dscale)) for ci in cis}
+                for co, ci in members:
+                    res[co] = (outs[ci], 0, 0.0)
         self.cache[key] = res
         return res
 
@@ -349,21 +474,51 @@ class Evaluator:
         group: [(expr, (a, b, terms, basis, spec))]; outs: pre-grid result arrays [ncomp, ..., M]."""
         a = group[0][1][0]
         basis, spec = group[0][1][3], group[0][1][4]
-        pa = self.eval_pregrid(a)
-        a_list = [pa[i] for i in range(a.ncomp)]
-        b_list, out_list, terms, bpos = [], [], [], {}
+        la = self._operand_lines(a)
+        a_list = [par[i] for (par, i, ds) in la]
+        a_ds = [ds for (par, i, ds) in la]
+        b_list, b_ds, out_list, terms, bpos = [], [], [], [], {}
         for (expr, (a_, b, tms, _, _)), out in zip(group, outs):
-            kb = id(b)
-            if kb not in bpos:
-                bpos[kb] = len(b_list)
-                pb = self.eval_pregrid(b)
-                b_list.extend(pb[i] for i in range(b.ncomp))
+            lb = self._operand_lines(b)
             ob = len(out_list)
             out_list.extend(out[i] for i in range(expr.ncomp))
-            terms.extend((ob + ic, ia, bpos[kb] + ib, cf) for (ic, ia, ib, cf) in tms)
+            for (ic, ia, ib, cf) in tms:
+                par, i, ds = lb[ib]
+                kb = (id(par), i, ds)
+                if kb not in bpos:
+                    bpos[kb] = len(b_list)
+                    b_list.append(par[i])
+                    b_ds.append(ds)
+                terms.append((ob + ic, ia, bpos[kb], cf))
+        if len(b_list) > self.ex.FUSED_LIMITS["nb"]:
+            raise RuntimeError("fused grid stage: too many distinct operands")
         M = spec[2]
-        nlines = int(np.prod(pa.shape[1:])) // M
-        self.ex.rfft_bilinear_fused(spec, basis, a_list, b_list, out_list, nlines, terms)
+        nlines = int(np.prod(a_list[0].shape)) // M
+        self.ex.rfft_bilinear_fused(spec, basis, a_list, b_list, out_list, nlines, terms, a_ds, b_ds)
+
+    def _le_to_grid(self, le, domain, ncomp, scales, skip_last=False):
+        """Grid (or pre-grid) data of a linear expression given as a LinExpr on `domain`."""
+        tr = self.dist.transformer
+        if not _full_sep(self.dist, domain):
+            raise NotImplementedError("evaluating expressions without all Fourier bases")
+        jac = [ax for ax in self.dist._jacobi_axes if domain.by_axis[ax] is not None]
+        if len(jac) == 1:
+            b = domain.by_axis[jac[0]]
+            if (b.a, b.b) != (b.a0, b.b0) and b.a0 == b.b0 == -0.5:
+                c = self.apply_linear(le, domain, post_basis=b)
+                if c is not None:
+                    gdom = domain.replace(jac[0], b.clone_with(a=b.a0, b=b.b0))
+                    c = c.reshape((ncomp,) + tuple(gdom.storage_coeff_shape()))
+                    shape = tr.pregrid_shape(gdom, ncomp, scales) if skip_last else \
+                        (ncomp,) + tuple(gdom.storage_grid_shape(scales))
+                    res = self.ex.empty(shape)
+                    tr.backward_data(gdom, ncomp, c, res, scales, skip_last=skip_last)
+                    return res
+        c = self.apply_linear(le, domain).reshape((ncomp,) + tuple(domain.storage_coeff_shape()))
+        shape = tr.pregrid_shape(domain, ncomp, scales) if skip_last else (ncomp,) + tuple(domain.storage_grid_shape(scales))
+        res = self.ex.empty(shape)
+        tr.backward_data(domain, ncomp, c, res, scales, skip_last=skip_last)
+        return res
 
     def _linear_to_grid_fused(self, expr, scales, skip_last=False):
         """Linear expression -> grid with the ultraspherical conversion solve fused into the mat-vec."""

@@ -60,6 +60,9 @@ struct FftDev {
     int boff[MAX_BANDS];
     const double *bands;   // [nbands][M]
     int B;                 // line pairs per workgroup
+    double dscale;         // RFFT_BWD: != 0 differentiates along the axis while loading (2 pi / L)
+    int dbg;               // timing ablations (debug): 1 skip butterfly math, 2 skip FFT passes, 4 skip unpack, 8 skip products
+    int rot;               // fused kernel: rotate the butterfly->wave assignment per workgroup
     int twdirect;          // 1: full twiddle table in LDS (N entries) instead of the two-level table
     int ld;                // LDS leading dimension of the FFT buffer (>= N)
     unsigned long long *prof;   // optional phase timing (debug): [load, fft, store, count]
@@ -258,24 +261,40 @@ __device__ __forceinline__ double2 lds_twiddle(const double2 *tw_lo, const doubl
 template <int R>
 __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int Ns, const FastDiv &fd_nb,
                                          const FastDiv &fd_ns, const double2 *tw_lo, const double2 *tw_hi, int sign,
-                                         int tid, int T) {
+                                         int tid, int T, int dbg = 0) {
     constexpr int MAXI = (12 + R - 1) / R;   // ceil(12 / R): at least 12 (at most 16) complex values staged per thread
     const int nb = N / R;
     const int total = nb * B;
     const int twstep = nb / Ns;  // N / (Ns*R)
+    // The padded index lpad(i) = i + (i >> 4) is linear along a butterfly's reads when the read stride nb
+    // is a multiple of 16, and along its writes when Ns is (or for the first radix-16 pass): one add per
+    // LDS access instead of the add/shift/add chain.
+    const bool lin_r = (nb & 15) == 0;
+    const bool lin_w = ((Ns & 15) == 0) || (Ns == 1 && R == 16);
+    const int rstride = nb + (nb >> 4);
+    const int wstride = (Ns == 1) ? 1 : Ns + (Ns >> 4);
     double2 v[MAXI][R];
+    int wl[MAXI], wj[MAXI];     // line * ld (-1: no butterfly) and lpad(j0) (linear writes) or j0
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
         const int w = tid + it * T;
+        wl[it] = -1;
+        wj[it] = 0;
         if (w < total) {
             unsigned uline, uj, uq, uk;
             fd_nb.divmod((unsigned)w, uline, uj);
             fd_ns.divmod(uj, uq, uk);
             const int line = (int)uline, j = (int)uj, k = (int)uk;
             const double2 *x = buf + line * ld;
+            if (lin_r) {
+                const double2 *x0 = x + lpad(j);
 #pragma unroll
-            for (int t = 0; t < R; ++t) v[it][t] = x[lpad(j + t * nb)];
-            if (Ns > 1) {
+                for (int t = 0; t < R; ++t) v[it][t] = x0[t * rstride];
+            } else {
+#pragma unroll
+                for (int t = 0; t < R; ++t) v[it][t] = x[lpad(j + t * nb)];
+            }
+            if (Ns > 1 && !(dbg & 1)) {
                 double2 wp[R];    // wp[t] = w^t
                 wp[1] = lds_twiddle(tw_lo, tw_hi, k * twstep, sign);
 #pragma unroll
@@ -287,39 +306,45 @@ __device__ __forceinline__ void fft_pass(double2 *buf, int ld, int B, int N, int
 #pragma unroll
                 for (int t = 1; t < R; ++t) v[it][t] = cmul(v[it][t], wp[t]);
             }
-            butterfly<R>(v[it], sign);
+            if (!(dbg & 1)) butterfly<R>(v[it], sign);
+            const int j0 = (j - k) * R + k;
+            wl[it] = line * ld;
+            wj[it] = lin_w ? lpad(j0) : j0;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
-        const int w = tid + it * T;
-        if (w < total) {
-            unsigned uline, uj, uq, uk;
-            fd_nb.divmod((unsigned)w, uline, uj);
-            fd_ns.divmod(uj, uq, uk);
-            double2 *x = buf + (int)uline * ld;
-            const int j0 = ((int)uj - (int)uk) * R + (int)uk;
+        if (wl[it] >= 0) {
+            double2 *x = buf + wl[it];
+            if (lin_w) {
+                double2 *x0 = x + wj[it];
 #pragma unroll
-            for (int u = 0; u < R; ++u) x[lpad(j0 + u * Ns)] = v[it][u];
+                for (int u = 0; u < R; ++u) x0[u * wstride] = v[it][u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < R; ++u) x[lpad(wj[it] + u * Ns)] = v[it][u];
+            }
         }
     }
     __syncthreads();
 }
 
 __device__ __forceinline__ void lds_fft(double2 *buf, const FftDev &p, const double2 *tw_lo, const double2 *tw_hi,
-                                        int sign, int tid, int T) {
+                                        int sign, int tid, int T, int nlines_wg = 0) {
     int Ns = 1;
+    if (p.dbg & 2) return;
+    const int B = nlines_wg > 0 ? nlines_wg : p.B;   // lines (pairs) in the workgroup's buffer
     for (int i = 0; i < p.nradix; ++i) {
         const int R = p.radix[i];
         switch (R) {
-            case 2: fft_pass<2>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
-            case 3: fft_pass<3>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
-            case 4: fft_pass<4>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
-            case 5: fft_pass<5>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
-            case 8: fft_pass<8>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
-            case 16: fft_pass<16>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
-            default: fft_pass<7>(buf, p.ld, p.B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T); break;
+            case 2: fft_pass<2>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
+            case 3: fft_pass<3>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
+            case 4: fft_pass<4>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
+            case 5: fft_pass<5>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
+            case 8: fft_pass<8>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
+            case 16: fft_pass<16>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
+            default: fft_pass<7>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
         }
         Ns *= R;
     }
@@ -462,6 +487,12 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 if (q0 + b < npairs) {
                     c = io.load(src, M, 2 * k, q0 + b);
                     s = io.load(src, M, 2 * k + 1, q0 + b);
+                    if (p.dscale != 0.0) {   // d/dx: (cos, msin) -> (-kappa msin, kappa cos)
+                        const double kap = p.dscale * (double)k;
+                        const double2 c2 = make_double2(-kap * s.x, -kap * s.y);
+                        s = make_double2(kap * c.x, kap * c.y);
+                        c = c2;
+                    }
                 }
                 if (k == 0) {
                     buf[b * ld] = c;  // a0 of line a + i a0 of line b
@@ -485,6 +516,12 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                     if (2 * (q0 + b) + 1 < io.nlines) vb = *reinterpret_cast<const double2 *>(pa + M);
                     c = make_double2(va.x, vb.x);
                     s = make_double2(va.y, vb.y);
+                    if (p.dscale != 0.0) {
+                        const double kap = p.dscale * (double)k;
+                        const double2 c2 = make_double2(-kap * s.x, -kap * s.y);
+                        s = make_double2(kap * c.x, kap * c.y);
+                        c = c2;
+                    }
                 }
                 if (k == 0) {
                     buf[b * ld] = c;
@@ -775,8 +812,9 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
 // forward transform: core/transforms.py:537-565, core/arithmetic.py:666-674, 855-866) by one read of
 // the operands' coefficient lines and one write of the results' coefficient lines.
 // ------------------------------------------------------------------------------------------------
-constexpr int FUSED_NA = 3, FUSED_NC = 4, FUSED_NB = 12, FUSED_TERMS = 32, FUSED_PTS = 6;
+constexpr int FUSED_NA = 3, FUSED_NC = 4, FUSED_NB = 12, FUSED_TERMS = 32;
 constexpr int FUSED_LOADS = FUSED_NA + FUSED_TERMS;
+constexpr int FUSED_T = 256;
 
 struct FusedArgs {
     const double *src[FUSED_LOADS];   // line arrays in load order: the `a` operands first
@@ -784,119 +822,81 @@ struct FusedArgs {
     double *out[FUSED_NC];
     double coef[FUSED_TERMS];
     short tbeg[FUSED_LOADS + 1];      // terms [tbeg[l], tbeg[l+1]) multiply load l
-    signed char flush[FUSED_LOADS];   // >= 0: result `flush` is complete after this load
+    short bbeg[FUSED_LOADS + 1];      // batch i transforms loads [bbeg[i], bbeg[i+1]) together
+    signed char flush[FUSED_LOADS];   // per batch: >= 0: result `flush` is complete after it
     signed char ia[FUSED_TERMS];
-    int na, nloads;
+    int na, nbatch;
 };
 
-// LDS-DMA of the 2B coefficient lines of one operand into a raw staging buffer [2B][M/2] double2.
-// Issued through inline asm on purpose: the compiler then does not order later LDS reads behind it
-// (it would insert s_waitcnt vmcnt(0) before the next ds_read), so the copy of operand l+1 runs under
-// the FFT of operand l.  Completion is awaited explicitly with fused_dma_wait().
-__device__ __forceinline__ void fused_dma_lines(const double *src, double2 *stage, const FftDev &p, long q0,
-                                                long nlines, int tid, int T) {
-    const int Mh = p.M >> 1;
-    const int cpl = (Mh + 63) >> 6;   // 1 KiB wave chunks per line
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw = T >> 6;
-    for (int line = 0; line < 2 * p.B; ++line) {
-        const long gl = 2 * q0 + line;
-        if (gl >= nlines) break;
-        for (int part = wave; part < cpl; part += nw) {
-            const int e = part * 64 + lane;
-            if (e < Mh) {
-                const double2 *g = reinterpret_cast<const double2 *>(src + gl * (long)p.M) + e;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(
-                    (unsigned)(size_t)(__attribute__((address_space(3))) void *)(stage + line * Mh + part * 64));
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                             :
-                             : "v"(g), "s"(dst)
-                             : "memory", "m0");
-            }
-        }
-    }
-}
-__device__ __forceinline__ void fused_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// staged coefficient lines (2b, 2b+1) -> Hermitian-packed spectrum in buf (contiguous-axis RFFT_BWD
-// pre-step), optionally differentiated: (cos, msin) -> (-kappa msin, kappa cos), kappa = dscale * k
-__device__ __forceinline__ void fused_unpack(double2 *buf, const double2 *stage, const FftDev &p, double dscale,
-                                             long q0, long npairs, long nlines, int tid, int T) {
-    const int N = p.N, K = p.K, B = p.B, ld = p.ld, Mh = p.M >> 1;
-    const int nzero = N - 2 * K - 1;
-    for (int w = tid; w < nzero * B; w += T) {
-        unsigned q, r;
-        p.fdB.divmod((unsigned)w, q, r);
-        buf[(int)r * ld + lpad(K + 1 + (int)q)] = make_double2(0.0, 0.0);
-    }
-    for (int w = tid; w < (K + 1) * B; w += T) {
-        unsigned q, r;
-        p.fdK1.divmod((unsigned)w, q, r);
-        const int k = (int)r, b = (int)q;
-        double2 c = make_double2(0.0, 0.0), s = c;
-        if (q0 + b < npairs) {
-            const double2 va = stage[(2 * b) * Mh + k];
-            double2 vb = make_double2(0.0, 0.0);
-            if (2 * (q0 + b) + 1 < nlines) vb = stage[(2 * b + 1) * Mh + k];
-            c = make_double2(va.x, vb.x);
-            s = make_double2(va.y, vb.y);
-            if (dscale != 0.0) {
-                const double kap = dscale * (double)k;
-                const double2 c2 = make_double2(-kap * s.x, -kap * s.y);
-                s = make_double2(kap * c.x, kap * c.y);
-                c = c2;
-            }
+// coefficient lines (2q, 2q+1) of one operand -> Hermitian-packed spectrum of the line pair in buf
+// (contiguous-axis RFFT_BWD pre-step), optionally differentiated:
+// (cos, msin) -> (-kappa msin, kappa cos), kappa = dscale * k
+__device__ __forceinline__ void fused_load_lines(double2 *buf, const FftDev &p, const double *src, double dscale,
+                                                 long q, long nlines, int tid, int T) {
+    const int N = p.N, M = p.M, K = p.K;
+    for (int w = K + 1 + tid; w < N - K; w += T) buf[lpad(w)] = make_double2(0.0, 0.0);
+    const bool second = 2 * q + 1 < nlines;
+    const double *pa = src + (2 * q) * (long)M;
+    for (int k = tid; k <= K; k += T) {
+        const double2 va = *reinterpret_cast<const double2 *>(pa + 2 * k);
+        double2 vb = make_double2(0.0, 0.0);
+        if (second) vb = *reinterpret_cast<const double2 *>(pa + M + 2 * k);
+        double2 c = make_double2(va.x, vb.x);
+        double2 s = make_double2(va.y, vb.y);
+        if (dscale != 0.0) {
+            const double kap = dscale * (double)k;
+            const double2 c2 = make_double2(-kap * s.x, -kap * s.y);
+            s = make_double2(kap * c.x, kap * c.y);
+            c = c2;
         }
         if (k == 0) {
-            buf[b * ld] = c;
+            buf[0] = c;
         } else {
-            buf[b * ld + lpad(k)] = make_double2(0.5 * (c.x - s.y), 0.5 * (s.x + c.y));
-            buf[b * ld + lpad(N - k)] = make_double2(0.5 * (c.x + s.y), 0.5 * (c.y - s.x));
+            buf[lpad(k)] = make_double2(0.5 * (c.x - s.y), 0.5 * (s.x + c.y));
+            buf[lpad(N - k)] = make_double2(0.5 * (c.x + s.y), 0.5 * (c.y - s.x));
         }
     }
 }
 
 // spectrum in buf -> interleaved (cos, msin) coefficient lines (contiguous-axis RFFT_FWD post-step)
-__device__ __forceinline__ void fused_store_lines(const double2 *buf, const FftDev &p, double *dst, long q0,
-                                                  long npairs, long nlines, int tid, int T) {
-    const int N = p.N, M = p.M, K = p.K, B = p.B, ld = p.ld;
-    const int Mh = M / 2;
+__device__ __forceinline__ void fused_store_lines(const double2 *buf, const FftDev &p, double *dst, long q,
+                                                  long nlines, int tid, int T) {
+    const int N = p.N, M = p.M, K = p.K;
     const double invN = 1.0 / (double)N;
-    for (int w = tid; w < Mh * B; w += T) {
-        unsigned q, r;
-        p.fdMh.divmod((unsigned)w, q, r);
-        const int k = (int)r, b = (int)q;
-        if (q0 + b >= npairs) continue;
+    const bool second = 2 * q + 1 < nlines;
+    double *pa = dst + (2 * q) * (long)M;
+    for (int k = tid; k < M / 2; k += T) {
         double2 c = make_double2(0.0, 0.0), s = c;
         if (k == 0) {
-            const double2 z = buf[b * ld];
+            const double2 z = buf[0];
             c = make_double2(z.x * invN, z.y * invN);
         } else if (k <= K) {
-            const double2 z1 = buf[b * ld + lpad(k)], z2 = buf[b * ld + lpad(N - k)];
+            const double2 z1 = buf[lpad(k)], z2 = buf[lpad(N - k)];
             c = make_double2((z1.x + z2.x) * invN, (z1.y + z2.y) * invN);
             s = make_double2((z1.y - z2.y) * invN, (z2.x - z1.x) * invN);
         }
-        double *pa = dst + (2 * (q0 + b)) * (long)M + 2 * k;
-        *reinterpret_cast<double2 *>(pa) = make_double2(c.x, s.x);
-        if (2 * (q0 + b) + 1 < nlines) *reinterpret_cast<double2 *>(pa + M) = make_double2(c.y, s.y);
+        *reinterpret_cast<double2 *>(pa + 2 * k) = make_double2(c.x, s.x);
+        if (second) *reinterpret_cast<double2 *>(pa + M + 2 * k) = make_double2(c.y, s.y);
     }
 }
 
-__global__ void __launch_bounds__(256, 2)
+// One workgroup = one pair of lines.  PTS grid points per thread (N <= PTS * 256); up to G operands are
+// transformed together so that the barriers and LDS round trips of an FFT are shared by G transforms.
+template <int PTS, int G>
+__global__ void __launch_bounds__(FUSED_T, 2)
 fused_rfft_bilinear_kernel(FftDev p, FusedArgs f, long nlines, long npairs) {
     extern __shared__ double2 lds[];
-    const int Mh = p.M >> 1;
-    double2 *buf = lds;                                // [B][ld]        FFT work buffer
-    double2 *stage = lds + p.B * p.ld;                 // [2][2B][M/2]   raw coefficient lines (double buffer)
-    double2 *tw_lo = stage + 2 * (2 * p.B * Mh);
+    double2 *buf = lds;                                // [G][ld]   FFT work buffers
+    double2 *tw_lo = lds + G * p.ld;
     double2 *tw_hi = tw_lo + 32;
-    const int tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x, T = FUSED_T;
     load_twiddles(p, tw_lo, tw_hi, tid, T);
     // kernel arguments indexed at run time go through LDS (static indices here keep them out of scratch)
     __shared__ const double *s_src[FUSED_LOADS];
     __shared__ double s_dscale[FUSED_LOADS];
     __shared__ double *s_out[FUSED_NC];
     __shared__ double s_coef[FUSED_TERMS];
-    __shared__ short s_tbeg[FUSED_LOADS + 1];
+    __shared__ short s_tbeg[FUSED_LOADS + 1], s_bbeg[FUSED_LOADS + 1];
     __shared__ signed char s_flush[FUSED_LOADS], s_ia[FUSED_TERMS];
     if (tid == 0) {
 #pragma unroll
@@ -904,9 +904,11 @@ fused_rfft_bilinear_kernel(FftDev p, FusedArgs f, long nlines, long npairs) {
             s_src[i] = f.src[i];
             s_dscale[i] = f.dscale[i];
             s_tbeg[i] = f.tbeg[i];
+            s_bbeg[i] = f.bbeg[i];
             s_flush[i] = f.flush[i];
         }
         s_tbeg[FUSED_LOADS] = f.tbeg[FUSED_LOADS];
+        s_bbeg[FUSED_LOADS] = f.bbeg[FUSED_LOADS];
 #pragma unroll
         for (int i = 0; i < FUSED_TERMS; ++i) {
             s_coef[i] = f.coef[i];
@@ -915,33 +917,26 @@ fused_rfft_bilinear_kernel(FftDev p, FusedArgs f, long nlines, long npairs) {
 #pragma unroll
         for (int i = 0; i < FUSED_NC; ++i) s_out[i] = f.out[i];
     }
-    const unsigned bid = xcd_swizzle(blockIdx.x, gridDim.x);
-    const long q0 = (long)bid * p.B;
-    const int N = p.N, B = p.B, ld = p.ld;
-    const int npts = N * B;              // <= FUSED_PTS * T (checked on the host)
-    const int stage_sz = 2 * B * Mh;
-    // first operand on its way before anything else
-    fused_dma_lines(f.src[0], stage, p, q0, nlines, tid, T);
+    __syncthreads();                                      // argument tables and twiddles are visible
+    const long q = (p.rot & 2) ? (long)blockIdx.x : (long)xcd_swizzle(blockIdx.x, gridDim.x);   // line pair of this workgroup
+    const int N = p.N, ld = p.ld;
     // LDS address of this thread's i-th grid point
-    int addr[FUSED_PTS];
+    int addr[PTS];
 #pragma unroll
-    for (int i = 0; i < FUSED_PTS; ++i) {
+    for (int i = 0; i < PTS; ++i) {
         const int e = tid + i * T;
-        unsigned q = 0, r = 0;
-        if (e < npts) p.fdN.divmod((unsigned)e, q, r);
-        addr[i] = (e < npts) ? (int)q * ld + lpad((int)r) : -1;
+        addr[i] = (e < N) ? lpad(e) : -1;
     }
-    double2 areg[FUSED_NA][FUSED_PTS];
-    double2 acc[FUSED_PTS];
+    double2 areg[FUSED_NA][PTS];
+    double2 acc[PTS];
 #pragma unroll
-    for (int i = 0; i < FUSED_PTS; ++i) {
+    for (int i = 0; i < PTS; ++i) {
         acc[i] = make_double2(0.0, 0.0);
 #pragma unroll
         for (int ia = 0; ia < FUSED_NA; ++ia) areg[ia][i] = make_double2(0.0, 0.0);
     }
-    const int na = f.na, nloads = f.nloads;
-    bool waited = false;
-    long long pt[4] = {0, 0, 0, 0}, tc = 0;   // debug phase clocks: wait, unpack, fft, rest
+    const int na = f.na, nbatch = f.nbatch;
+    long long pt[4] = {0, 0, 0, 0}, tc = 0;   // debug phase clocks: wait, load, fft, rest
     if (p.prof) tc = clock64();
 #define DDH_TICK(slot)                      \
     if (p.prof) {                           \
@@ -950,62 +945,73 @@ fused_rfft_bilinear_kernel(FftDev p, FusedArgs f, long nlines, long npairs) {
         tc = now;                           \
     }
 #pragma unroll 1
-    for (int l = 0; l < nloads; ++l) {
+    for (int ib = 0; ib < nbatch; ++ib) {
+        const int l0 = s_bbeg[ib], cnt = s_bbeg[ib + 1] - l0;
         DDH_TICK(3)
-        if (!waited) fused_dma_wait();
-        waited = false;
-        __syncthreads();                     // stage[l & 1] has landed for every wave; buf is free
+        __syncthreads();                     // buf is free
         DDH_TICK(0)
-        if (l + 1 < nloads)
-            fused_dma_lines(s_src[l + 1], stage + ((l + 1) & 1) * stage_sz, p, q0, nlines, tid, T);
-        fused_unpack(buf, stage + (l & 1) * stage_sz, p, s_dscale[l], q0, npairs, nlines, tid, T);
+        if (!(p.dbg & 4)) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (g < cnt) fused_load_lines(buf + g * ld, p, s_src[l0 + g], s_dscale[l0 + g], q, nlines, tid, T);
+        }
         __syncthreads();
         DDH_TICK(1)
-        lds_fft(buf, p, tw_lo, tw_hi, +1, tid, T);
+        lds_fft(buf, p, tw_lo, tw_hi, +1, tid, T, cnt);
         DDH_TICK(2)
-        double2 wv[FUSED_PTS];
+        if (l0 < na) {
+            // `a` operands stay in registers (run-time index, static register selection)
 #pragma unroll
-        for (int i = 0; i < FUSED_PTS; ++i) wv[i] = (addr[i] >= 0) ? buf[addr[i]] : make_double2(0.0, 0.0);
-        if (l < na) {
-            // `a` operands stay in registers (run-time l, static register selection)
+            for (int g = 0; g < G; ++g) {
+                if (g < cnt) {
 #pragma unroll
-            for (int i = 0; i < FUSED_PTS; ++i)
+                    for (int i = 0; i < PTS; ++i) {
+                        const double2 v = (addr[i] >= 0) ? buf[g * ld + addr[i]] : make_double2(0.0, 0.0);
 #pragma unroll
-                for (int ia = 0; ia < FUSED_NA; ++ia)
-                    if (l == ia) areg[ia][i] = wv[i];
+                        for (int ia = 0; ia < FUSED_NA; ++ia)
+                            if (l0 + g == ia) areg[ia][i] = v;
+                    }
+                }
+            }
             continue;
         }
-        const int t1 = s_tbeg[l + 1];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g < cnt) {
+                double2 wv[PTS];
+#pragma unroll
+                for (int i = 0; i < PTS; ++i) wv[i] = (addr[i] >= 0) ? buf[g * ld + addr[i]] : make_double2(0.0, 0.0);
+                const int t1 = (p.dbg & 8) ? 0 : s_tbeg[l0 + g + 1];
 #pragma unroll 1
-        for (int t = s_tbeg[l]; t < t1; ++t) {
-            const double cf = s_coef[t];
-            const int tia = s_ia[t];
+                for (int t = s_tbeg[l0 + g]; t < t1; ++t) {
+                    const double cf = s_coef[t];
+                    const int tia = s_ia[t];
 #pragma unroll
-            for (int i = 0; i < FUSED_PTS; ++i) {
-                double2 av = areg[0][i];
+                    for (int i = 0; i < PTS; ++i) {
+                        double2 av = areg[0][i];
 #pragma unroll
-                for (int ia = 1; ia < FUSED_NA; ++ia)
-                    if (tia == ia) av = areg[ia][i];
-                // two packed lines: real parts multiply real parts, imaginary parts imaginary parts
-                acc[i].x += cf * av.x * wv[i].x;
-                acc[i].y += cf * av.y * wv[i].y;
+                        for (int ia = 1; ia < FUSED_NA; ++ia)
+                            if (tia == ia) av = areg[ia][i];
+                        // two packed lines: real parts multiply real parts, imaginary parts imaginary parts
+                        acc[i].x += cf * av.x * wv[i].x;
+                        acc[i].y += cf * av.y * wv[i].y;
+                    }
+                }
             }
         }
-        const int oc = s_flush[l];
+        const int oc = s_flush[ib];
         if (oc >= 0) {
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < FUSED_PTS; ++i) {
+            for (int i = 0; i < PTS; ++i) {
                 if (addr[i] >= 0) buf[addr[i]] = acc[i];
                 acc[i] = make_double2(0.0, 0.0);
             }
             __syncthreads();
             DDH_TICK(3)
-            lds_fft(buf, p, tw_lo, tw_hi, -1, tid, T);
+            lds_fft(buf, p, tw_lo, tw_hi, -1, tid, T, 1);
             DDH_TICK(2)
-            fused_dma_wait();                // the next operand landed long ago; keeps the stores below
-            waited = true;                   // out of the next wait
-            fused_store_lines(buf, p, s_out[oc], q0, npairs, nlines, tid, T);
+            fused_store_lines(buf, p, s_out[oc], q, nlines, tid, T);
         }
     }
     DDH_TICK(3)
@@ -1122,6 +1128,8 @@ static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nba
         return st;
     }
     d.ld = N + (N >> 4) + 1;
+    d.rot = getenv("DDH_FUSED_ROT") ? atoi(getenv("DDH_FUSED_ROT")) : 0;
+    d.dbg = getenv("DDH_FFT_DBG") ? atoi(getenv("DDH_FFT_DBG")) : 0;
     d.twdirect = (getenv("DDH_FFT_TWDIRECT") && atoi(getenv("DDH_FFT_TWDIRECT"))) ? 1 : 0;
     if (const char *rs = getenv("DDH_FFT_RADIX")) {   // tuning aid: "16,16,3" replaces the schedule when it fits N
         int r[MAX_RADIX_PASSES], n = 0, prod = 1;
@@ -1165,9 +1173,11 @@ static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nba
 }
 
 template <int MODE>
-static int launch(FftPlan *pl, const double *src, double *dst, long outer, long inner, void *stream) {
+static int launch(FftPlan *pl, const double *src, double *dst, long outer, long inner, void *stream,
+                  double dscale = 0.0) {
     if (outer <= 0 || inner <= 0) return 0;
     FftDev d = pl->dev;
+    d.dscale = dscale;
     const bool is_cfft = (MODE == CFFT_FWD || MODE == CFFT_BWD);
     const bool inner_mode = inner > 1;
     long npairs;
@@ -1311,6 +1321,14 @@ int ddh_plan_cheb(ddh_handle *plan, int n_grid, int n_coeff, int nbands, const i
 
 DDH_FFT_ENTRY(ddh_rfft_forward, K_RFFT, RFFT_FWD)
 DDH_FFT_ENTRY(ddh_rfft_backward, K_RFFT, RFFT_BWD)
+int ddh_rfft_backward_deriv(ddh_handle plan, const double *c, double *g, long outer, long inner, double dscale,
+                            void *stream) {
+    FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
+    if (!pl) return -1;
+    if (pl->tkind != K_RFFT) return fail("ddh_rfft_backward_deriv: plan is of a different transform kind");
+    if ((const void *)c == (const void *)g) return fail("ddh_rfft_backward_deriv: in-place transforms unsupported");
+    return launch<RFFT_BWD>(pl, c, g, outer, inner, stream, dscale);
+}
 DDH_FFT_ENTRY(ddh_cheb_forward, K_CHEB, CHEB_FWD)
 DDH_FFT_ENTRY(ddh_cheb_backward, K_CHEB, CHEB_BWD)
 DDH_FFT_ENTRY(ddh_cfft_forward, K_CFFT, CFFT_FWD)
@@ -1328,14 +1346,14 @@ int ddh_rfft_bilinear_fused(ddh_handle plan, int na, const double *const *a_h, c
         return fail("rfft_bilinear_fused: operand counts out of range (na<=3, nb<=12, nc<=4, terms<=32)");
     if (nlines <= 0) return 0;
     FftDev d = pl->dev;
-    static const int envT = getenv("DDH_FUSED_T") ? atoi(getenv("DDH_FUSED_T")) : 256;
-    const int T = (envT == 128 || envT == 64) ? envT : 256;
-    int B = T / 128 > 0 ? T / 128 : 1;
-    while (B > 1 && (long)d.N * B > (long)FUSED_PTS * T) B /= 2;
-    if ((long)d.N * B > (long)FUSED_PTS * T || (long)d.N * B > 12L * T)
-        return fail("rfft_bilinear_fused: axis too long for the fused kernel");
-    d.B = B;
-    d.fdB.set((unsigned)B);
+    const int T = FUSED_T;
+    if ((long)d.N > 6L * T) return fail("rfft_bilinear_fused: axis too long for the fused kernel");
+    // operands transformed together: 3 when the points fit 3 per thread and 12 staged values per thread
+    static const int envG = getenv("DDH_FUSED_G") ? atoi(getenv("DDH_FUSED_G")) : 0;
+    int G = ((long)d.N <= 3L * T && 3L * d.N <= 12L * T) ? 3 : 1;
+    if (envG == 1) G = 1;
+    d.B = 1;
+    d.fdB.set(1u);
     int order[FUSED_TERMS];
     for (int t = 0; t < nterms; ++t) {
         if (ia_h[t] < 0 || ia_h[t] >= na || ib_h[t] < 0 || ib_h[t] >= nb || ic_h[t] < 0 || ic_h[t] >= nc)
@@ -1345,16 +1363,18 @@ int ddh_rfft_bilinear_fused(ddh_handle plan, int na, const double *const *a_h, c
     std::stable_sort(order, order + nterms, [&](int x, int y) {
         return ic_h[x] != ic_h[y] ? ic_h[x] < ic_h[y] : ib_h[x] < ib_h[y];
     });
-    // load sequence: the `a` operands, then per result its `b` operands (one load per (ic, ib) group)
+    // load sequence: the `a` operands, then per result its `b` operands (one load per (ic, ib) group);
+    // batches of up to G consecutive loads that belong to the same result share one FFT
     FusedArgs f;
     memset(&f, 0, sizeof(f));
     f.na = na;
-    int nl = 0;
+    int nl = 0, nbt = 0;
+    int load_ic[FUSED_LOADS];
     for (int i = 0; i < na; ++i) {
         f.src[nl] = a_h[i];
         f.dscale[nl] = a_dscale_h ? a_dscale_h[i] : 0.0;
         f.tbeg[nl] = 0;
-        f.flush[nl] = -1;
+        load_ic[nl] = -1;
         ++nl;
     }
     bool has_terms[FUSED_NC] = {false, false, false, false};
@@ -1365,32 +1385,41 @@ int ddh_rfft_bilinear_fused(ddh_handle plan, int na, const double *const *a_h, c
             f.src[nl] = b_h[ib_h[o]];
             f.dscale[nl] = b_dscale_h ? b_dscale_h[ib_h[o]] : 0.0;
             f.tbeg[nl] = (short)t;
-            f.flush[nl] = -1;
+            load_ic[nl] = ic_h[o];
             ++nl;
         }
         f.coef[t] = coef_h[o];
         f.ia[t] = (signed char)ia_h[o];
         has_terms[ic_h[o]] = true;
-        const bool last_of_result = (t == nterms - 1) || ic_h[order[t + 1]] != ic_h[o];
-        if (last_of_result) f.flush[nl - 1] = (signed char)ic_h[o];
     }
     for (int l = nl; l <= FUSED_LOADS; ++l) f.tbeg[l] = (short)nterms;
-    f.nloads = nl;
+    for (int l = 0; l < nl;) {
+        int e = l + 1;
+        while (e < nl && e - l < G && load_ic[e] == load_ic[l]) ++e;
+        f.bbeg[nbt] = (short)l;
+        const bool last_of_result = load_ic[l] >= 0 && (e == nl || load_ic[e] != load_ic[l]);
+        f.flush[nbt] = (signed char)(last_of_result ? load_ic[l] : -1);
+        ++nbt;
+        l = e;
+    }
+    for (int i = nbt; i <= FUSED_LOADS; ++i) f.bbeg[i] = (short)nl;
+    f.nbatch = nbt;
     for (int i = 0; i < nc; ++i) {
         f.out[i] = out_h[i];
         if (!has_terms[i])
             DDH_HIP(hipMemsetAsync(out_h[i], 0, (size_t)nlines * d.M * sizeof(double), as_stream(stream)));
     }
     const long npairs = (nlines + 1) / 2;
-    const unsigned long nblocks = (unsigned long)((npairs + B - 1) / B);
-    if (nblocks > 0x7fffffffUL) return fail("rfft_bilinear_fused: grid too large");
-    const size_t lds = ((size_t)d.ld * B + (size_t)4 * B * (d.M / 2) + (size_t)tw_entries(d.N, d.twdirect)) *
-                       sizeof(double2);
-    if (lds > 64 * 1024)
-        DDH_HIP(hipFuncSetAttribute((const void *)fused_rfft_bilinear_kernel,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fused_rfft_bilinear_kernel, dim3((unsigned)nblocks), dim3(T), lds, as_stream(stream), d, f,
-                       nlines, npairs);
+    if ((unsigned long)npairs > 0x7fffffffUL) return fail("rfft_bilinear_fused: grid too large");
+    const size_t lds = ((size_t)d.ld * G + (size_t)tw_entries(d.N, d.twdirect)) * sizeof(double2);
+    const dim3 grid((unsigned)npairs), block(T);
+    hipStream_t st = as_stream(stream);
+    if ((long)d.N <= 3L * T) {
+        if (G == 3) hipLaunchKernelGGL((fused_rfft_bilinear_kernel<3, 3>), grid, block, lds, st, d, f, nlines, npairs);
+        else hipLaunchKernelGGL((fused_rfft_bilinear_kernel<3, 1>), grid, block, lds, st, d, f, nlines, npairs);
+    } else {
+        hipLaunchKernelGGL((fused_rfft_bilinear_kernel<6, 1>), grid, block, lds, st, d, f, nlines, npairs);
+    }
     DDH_HIP(hipGetLastError());
     return 0;
 }

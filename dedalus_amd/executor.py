@@ -137,16 +137,20 @@ class HipExecutor:
                 raise NotImplementedError(kind)
         return self._plans[spec]
 
-    def transform(self, spec, basis, direction, src, dst, outer, inner):
+    def transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0):
         if self.timer is not None:
             name = "%s_%s_%s" % (spec[0], direction, "strided" if inner > 1 else "contig")
             return self.timer.run(name, (src.numel() + dst.numel()) * 8, self._transform, spec, basis, direction,
-                                  src, dst, outer, inner)
-        return self._transform(spec, basis, direction, src, dst, outer, inner)
+                                  src, dst, outer, inner, deriv)
+        return self._transform(spec, basis, direction, src, dst, outer, inner, deriv)
 
-    def _transform(self, spec, basis, direction, src, dst, outer, inner):
+    def _transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0):
         kind, h, h2 = self._plan(spec, basis)
-        if kind == "mmt":
+        if deriv:
+            if kind != "rfft" or direction != "backward":
+                raise NotImplementedError("derivative at load: RealFourier backward transforms only")
+            libhip.call("ddh_rfft_backward_deriv", h, ptr(src), ptr(dst), outer, inner, float(deriv), self.dev.stream)
+        elif kind == "mmt":
             libhip.call("ddh_mmt_apply", h if direction == "forward" else h2, ptr(src), ptr(dst), outer, inner,
                         self.dev.stream)
         else:

@@ -48,6 +48,11 @@ int ddh_destroy(ddh_handle h);                  /* any plan / pack handle */
 int ddh_plan_rfft(ddh_handle *plan, int n_grid, int n_coeff);
 int ddh_rfft_forward(ddh_handle plan, const double *g, double *c, long outer, long inner, void *stream);
 int ddh_rfft_backward(ddh_handle plan, const double *c, double *g, long outer, long inner, void *stream);
+/* backward transform of d/dx of the data: DifferentiateRealFourier (core/basis.py:1233-1260) applied
+ * while the coefficients are loaded, mode k (cos, msin) -> (-k dscale msin, k dscale cos) with
+ * dscale = 2 pi / L; saves transforming the derivative as a separate field.                       */
+int ddh_rfft_backward_deriv(ddh_handle plan, const double *c, double *g, long outer, long inner, double dscale,
+                            void *stream);
 
 /* ComplexFourier: replaces FFTWComplexFFT core/transforms.py:292-330 (resize_coeffs :243-267 fused).
  * Arrays are complex128 stored as interleaved doubles; `inner` counts complex elements.        */

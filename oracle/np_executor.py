@@ -141,10 +141,18 @@ class NumpyExecutor:
         for o, g in zip(out_list, acc):
             o[...] = npt.rfft_forward(g, 1, M).reshape(o.shape)
 
-    def transform(self, spec, basis, direction, src, dst, outer, inner):
+    def transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0):
         kind = spec[0]
         n_in = src.size // (outer * inner)
         s3 = src.reshape(outer, n_in, inner)
+        if deriv:
+            # DifferentiateRealFourier (core/basis.py:1233-1260) along the transformed axis
+            assert kind == "rfft" and direction == "backward"
+            k = (deriv * np.arange(n_in // 2))[None, :, None]
+            d3 = np.empty_like(s3)
+            d3[:, 0::2, :] = -k * s3[:, 1::2, :]
+            d3[:, 1::2, :] = k * s3[:, 0::2, :]
+            s3 = d3
         if kind == "rfft":
             N, M = spec[1], spec[2]
             res = npt.rfft_forward(s3, 1, M) if direction == "forward" else npt.rfft_backward(s3, 1, N)

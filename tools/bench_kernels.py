@@ -71,9 +71,10 @@ def main():
     from dedalus_amd.executor import HipExecutor
     hx = HipExecutor(dev)
     nl = (Gz // int(os.environ.get("FUSED_ZDIV", "4"))) * Gx
-    a = t.randn((3, nl, Ny), dtype=t.float64, device=dev.tdev)
-    bb = t.randn((12, nl, Ny), dtype=t.float64, device=dev.tdev)
-    oo = dev.empty((4, nl, Ny))
+    padl = int(os.environ.get("FUSED_PAD", "0"))      # extra lines between components (HBM channel spread test)
+    a = t.randn((3, nl + padl, Ny), dtype=t.float64, device=dev.tdev)[:, :nl]
+    bb = t.randn((12, nl + padl, Ny), dtype=t.float64, device=dev.tdev)[:, :nl]
+    oo = dev.empty((4, nl + padl, Ny))[:, :nl]
     terms = [(0, j, j, 1.0) for j in range(3)] + [(1 + c, j, 3 + 3 * j + c, 1.0) for c in range(3) for j in range(3)]
     tfz = timeit(dev, lambda: hx.rfft_bilinear_fused(("rfft", Gy, Ny), None, [a[i] for i in range(3)],
                                                      [bb[i] for i in range(12)], [oo[i] for i in range(4)], nl, terms))
@@ -89,7 +90,7 @@ def main():
         lib.ddh_debug_fft_prof(ph, out)
         vals = [out[0] * out[3], out[1] * out[3], out[2] * out[3], out[3]]    # the hook divides by slot 3
         tot = sum(vals)
-        nwg = (nl // 2 + 1) // 2
+        nwg = (nl + 1) // 2
         print("   fused phase clocks per WG: wait %.0f unpack %.0f fft %.0f rest %.0f  -> %% %s"
               % tuple([v / nwg for v in vals] + [[round(100 * x / tot, 1) for x in vals]]))
     nbytes = 19 * nl * Ny * 8
