@@ -61,6 +61,7 @@ struct FftDev {
     const double *bands;   // [nbands][M]
     int B;                 // line pairs per workgroup
     double dscale;         // RFFT_BWD: != 0 differentiates along the axis while loading (2 pi / L)
+    int spread_s, spread_c; // strided kernels: workgroup spreading over the address range (see kernel)
     int dbg;               // timing ablations (debug): 1 skip butterfly math, 2 skip FFT passes, 4 skip unpack, 8 skip products
     int rot;               // fused kernel: rotate the butterfly->wave assignment per workgroup
     int twdirect;          // 1: full twiddle table in LDS (N entries) instead of the two-level table
@@ -407,6 +408,8 @@ __device__ __forceinline__ void split_item(int w, const FastDiv &fdB, const Fast
     }
 }
 
+constexpr int LDU = 6;   // global loads staged per thread before the dependent LDS writes
+
 __device__ __forceinline__ int dct_perm(int j, int N) { return (j & 1) ? (N - 1 - (j >> 1)) : (j >> 1); }
 
 template <int MODE, bool INNER, int TMAX, int MINW>
@@ -428,7 +431,18 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     auto bscale_of = [&](int k) -> double { return k == 0 ? bs0 : ((k & 1) ? -bs1 : bs1); };
     auto half_of = [&](int k) -> double2 { return p.half[k]; };   // small table, read once per element
     const int tid = threadIdx.x, T = blockDim.x;
-    const unsigned bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    unsigned bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    if (INNER && p.spread_s > 1) {
+        // Strided lines whose rows are a large power of two apart map a contiguous window of workgroups
+        // to few HBM channels: spread each XCD's run of workgroups over its whole address range, in
+        // chunks of spread_c neighbours (which share DRAM pages).
+        const unsigned per = gridDim.x >> 3, S = (unsigned)p.spread_s, c = (unsigned)p.spread_c;
+        if (per > 0 && bid < (per << 3) && per % (S * c) == 0) {
+            const unsigned x = bid / per, l = bid - x * per;
+            const unsigned chunk = l / c, r = l - chunk * c, nchunk = per / c;
+            bid = x * per + ((chunk % S) * (nchunk / S) + chunk / S) * c + r;
+        }
+    }
     PairIO<INNER> io;
     long q0;
     if (INNER) {
@@ -446,7 +460,9 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     if (p.prof) t_start = clock64();
 
     // ---------------------------------------------------------------- load + pre-process
-    if (MODE == RFFT_FWD && !INNER && (N % 2 == 0)) {
+    if (p.dbg & 4) {
+        // timing ablation: no loads
+    } else if (MODE == RFFT_FWD && !INNER && (N % 2 == 0)) {
         const int Nh = N / 2;
         for (int b = 0; b < B; ++b) {
             const bool has_a = (q0 + b < npairs);
@@ -461,12 +477,25 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             }
         }
     } else if (MODE == RFFT_FWD) {
-        for (int w = tid; w < N * B; w += T) {
-            int j, b;
-            split_item<INNER>(w, p.fdB, p.fdN, j, b);
-            double2 v = make_double2(0.0, 0.0);
-            if (q0 + b < npairs) v = io.load(src, N, j, q0 + b);
-            buf[b * ld + lpad(j)] = v;
+        // LDU items per thread in flight: all loads of a group are issued before the first LDS write
+        for (int w0 = tid; w0 < N * B; w0 += LDU * T) {
+            double2 v[LDU];
+            int at[LDU];
+#pragma unroll
+            for (int u = 0; u < LDU; ++u) {
+                const int w = w0 + u * T;
+                at[u] = -1;
+                v[u] = make_double2(0.0, 0.0);
+                if (w < N * B) {
+                    int j, b;
+                    split_item<INNER>(w, p.fdB, p.fdN, j, b);
+                    if (q0 + b < npairs) v[u] = io.load(src, N, j, q0 + b);
+                    at[u] = b * ld + lpad(j);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LDU; ++u)
+                if (at[u] >= 0) buf[at[u]] = v[u];
         }
     } else if (MODE == RFFT_BWD) {
         const int K = p.K;
@@ -479,26 +508,43 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             buf[b * ld + lpad(K + 1 + j)] = make_double2(0.0, 0.0);
         }
         if (INNER) {
-            for (int w = tid; w < (K + 1) * B; w += T) {
-                unsigned q, r;
-                p.fdB.divmod((unsigned)w, q, r);
-                const int b = (int)r, k = (int)q;
-                double2 c = make_double2(0.0, 0.0), s = c;
-                if (q0 + b < npairs) {
-                    c = io.load(src, M, 2 * k, q0 + b);
-                    s = io.load(src, M, 2 * k + 1, q0 + b);
+            for (int w0 = tid; w0 < (K + 1) * B; w0 += LDU * T) {
+                double2 cc[LDU], ss[LDU];
+                int kk[LDU], bb[LDU];
+#pragma unroll
+                for (int u = 0; u < LDU; ++u) {
+                    const int w = w0 + u * T;
+                    kk[u] = -1;
+                    bb[u] = 0;
+                    cc[u] = ss[u] = make_double2(0.0, 0.0);
+                    if (w < (K + 1) * B) {
+                        unsigned q, r;
+                        p.fdB.divmod((unsigned)w, q, r);
+                        bb[u] = (int)r;
+                        kk[u] = (int)q;
+                        if (q0 + bb[u] < npairs) {
+                            cc[u] = io.load(src, M, 2 * kk[u], q0 + bb[u]);
+                            ss[u] = io.load(src, M, 2 * kk[u] + 1, q0 + bb[u]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < LDU; ++u) {
+                    if (kk[u] < 0) continue;
+                    const int k = kk[u], b = bb[u];
+                    double2 c = cc[u], s = ss[u];
                     if (p.dscale != 0.0) {   // d/dx: (cos, msin) -> (-kappa msin, kappa cos)
                         const double kap = p.dscale * (double)k;
                         const double2 c2 = make_double2(-kap * s.x, -kap * s.y);
                         s = make_double2(kap * c.x, kap * c.y);
                         c = c2;
                     }
-                }
-                if (k == 0) {
-                    buf[b * ld] = c;  // a0 of line a + i a0 of line b
-                } else {
-                    buf[b * ld + lpad(k)] = make_double2(0.5 * (c.x - s.y), 0.5 * (s.x + c.y));
-                    buf[b * ld + lpad(N - k)] = make_double2(0.5 * (c.x + s.y), 0.5 * (c.y - s.x));
+                    if (k == 0) {
+                        buf[b * ld] = c;  // a0 of line a + i a0 of line b
+                    } else {
+                        buf[b * ld + lpad(k)] = make_double2(0.5 * (c.x - s.y), 0.5 * (s.x + c.y));
+                        buf[b * ld + lpad(N - k)] = make_double2(0.5 * (c.x + s.y), 0.5 * (c.y - s.x));
+                    }
                 }
             }
         } else {
@@ -532,39 +578,63 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             }
         }
     } else if (MODE == CHEB_FWD) {
-        for (int w = tid; w < N * B; w += T) {
-            int j, b;
-            split_item<INNER>(w, p.fdB, p.fdN, j, b);
-            double2 v = make_double2(0.0, 0.0);
-            if (q0 + b < npairs) v = io.load(src, N, j, q0 + b);
-            buf[b * ld + lpad(dct_perm(j, N))] = v;
+        for (int w0 = tid; w0 < N * B; w0 += LDU * T) {
+            double2 v[LDU];
+            int at[LDU];
+#pragma unroll
+            for (int u = 0; u < LDU; ++u) {
+                const int w = w0 + u * T;
+                at[u] = -1;
+                v[u] = make_double2(0.0, 0.0);
+                if (w < N * B) {
+                    int j, b;
+                    split_item<INNER>(w, p.fdB, p.fdN, j, b);
+                    if (q0 + b < npairs) v[u] = io.load(src, N, j, q0 + b);
+                    at[u] = b * ld + lpad(dct_perm(j, N));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LDU; ++u)
+                if (at[u] >= 0) buf[at[u]] = v[u];
         }
     } else if (MODE == CHEB_BWD && p.nbands == 0) {
         // grid basis == coefficient basis: build the DCT-III input straight from global memory
         // (each coefficient is read as k and as N-k; the second read hits L1/L2), no staging buffer
         const int Mk = (M < N) ? M : N;
-        for (int w = tid; w < N * B; w += T) {
-            int k, b;
-            split_item<INNER>(w, p.fdB, p.fdN, k, b);
-            double2 e = make_double2(0.0, 0.0), f = e;
-            if (q0 + b < npairs) {
-                if (k < Mk) {
-                    const double s = bscale_of(k);
-                    const double2 c = io.load(src, M, k, q0 + b);
-                    e = make_double2(s * c.x, s * c.y);
-                }
-                const int kr = N - k;
-                if (k > 0 && kr < Mk) {
-                    const double s = bscale_of(kr);
-                    const double2 c = io.load(src, M, kr, q0 + b);
-                    f = make_double2(s * c.x, s * c.y);
+        for (int w0 = tid; w0 < N * B; w0 += LDU * T) {
+            double2 ce[LDU], cf[LDU], hh[LDU];
+            int kk[LDU], at[LDU];
+#pragma unroll
+            for (int u = 0; u < LDU; ++u) {
+                const int w = w0 + u * T;
+                at[u] = -1;
+                kk[u] = 0;
+                ce[u] = cf[u] = hh[u] = make_double2(0.0, 0.0);
+                if (w < N * B) {
+                    int k, b;
+                    split_item<INNER>(w, p.fdB, p.fdN, k, b);
+                    kk[u] = k;
+                    at[u] = b * ld + lpad(k);
+                    hh[u] = half_of(k);
+                    if (q0 + b < npairs) {
+                        if (k < Mk) ce[u] = io.load(src, M, k, q0 + b);
+                        const int kr = N - k;
+                        if (k > 0 && kr < Mk) cf[u] = io.load(src, M, kr, q0 + b);
+                    }
                 }
             }
-            const double2 h = half_of(k);
-            const double cr = h.x, ci = -h.y;
-            const double var = e.x * cr + f.x * ci, vai = e.x * ci - f.x * cr;
-            const double vbr = e.y * cr + f.y * ci, vbi = e.y * ci - f.y * cr;
-            buf[b * ld + lpad(k)] = make_double2(var - vbi, vai + vbr);
+#pragma unroll
+            for (int u = 0; u < LDU; ++u) {
+                if (at[u] < 0) continue;
+                const int k = kk[u];
+                const double se = bscale_of(k), sf = bscale_of(N - k);
+                const double2 e = make_double2(se * ce[u].x, se * ce[u].y);
+                const double2 f = make_double2(sf * cf[u].x, sf * cf[u].y);
+                const double cr = hh[u].x, ci = -hh[u].y;
+                const double var = e.x * cr + f.x * ci, vai = e.x * ci - f.x * cr;
+                const double vbr = e.y * cr + f.y * ci, vbi = e.y * ci - f.y * cr;
+                buf[at[u]] = make_double2(var - vbi, vai + vbr);
+            }
         }
     } else if (MODE == CHEB_BWD) {
         for (int w = tid; w < M * B; w += T) {
@@ -665,7 +735,9 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     if (p.prof) t_fft = clock64();
 
     // ---------------------------------------------------------------- post-process + store
-    if (MODE == RFFT_BWD && !INNER && (N % 2 == 0)) {
+    if (p.dbg & 16) {
+        // timing ablation: no stores
+    } else if (MODE == RFFT_BWD && !INNER && (N % 2 == 0)) {
         // contiguous lines: each thread stores two consecutive grid points of line a and of line b (16 B each)
         const int Nh = N / 2;
         for (int b = 0; b < B; ++b) {
@@ -1130,6 +1202,14 @@ static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nba
     d.ld = N + (N >> 4) + 1;
     d.rot = getenv("DDH_FUSED_ROT") ? atoi(getenv("DDH_FUSED_ROT")) : 0;
     d.dbg = getenv("DDH_FFT_DBG") ? atoi(getenv("DDH_FFT_DBG")) : 0;
+    d.spread_s = 0;
+    d.spread_c = 1;
+    if (const char *sp = getenv("DDH_FFT_SPREAD")) {
+        d.spread_s = atoi(sp);
+        const char *cm = strchr(sp, ',');
+        d.spread_c = cm ? atoi(cm + 1) : 1;
+        if (d.spread_c < 1) d.spread_c = 1;
+    }
     d.twdirect = (getenv("DDH_FFT_TWDIRECT") && atoi(getenv("DDH_FFT_TWDIRECT"))) ? 1 : 0;
     if (const char *rs = getenv("DDH_FFT_RADIX")) {   // tuning aid: "16,16,3" replaces the schedule when it fits N
         int r[MAX_RADIX_PASSES], n = 0, prod = 1;
