@@ -368,13 +368,21 @@ class SolverBase:
                     # constants only reach the k=0 pencil, cos-cos part
                     if tl.ex[t] == 0 and tl.ey[t] == 0 and self.dist._mx_offset == 0:
                         total[tl.row[t], 0, 0] += (tl.coef[t] * val).real
-            self.F_const = self.ex.from_host(total)
+            nz = np.flatnonzero(total)
+            self.F_const = self.ex.make_scatter(nz, total.reshape(-1)[nz]) if nz.size else None
 
     def evaluate_F(self, out):
         """F system vector for the current state (coefficient space, equation bases)."""
         ev, ex = self.evaluator_core, self.ex
         ev.new_pass()
         parts = []
+
+        def target():
+            """The first full-size contribution is written straight into `out`."""
+            y = out if not parts else ex.empty((self.R, self.nx, self.ny))
+            parts.append(y)
+            return y
+
         if self.F_nl is not None:
             tr = self.dist.transformer
             for grp in self.nl_fused:
@@ -388,26 +396,18 @@ class SolverBase:
                 g = ev.eval_grid(leaf)
                 dst = self.NLbuf[row0:row0 + rows].reshape((leaf.ncomp,) + tuple(leaf.domain.storage_coeff_shape()))
                 tr.forward_data(leaf.domain, leaf.ncomp, g, leaf.domain.dealias, dst)
-            y = ex.empty((self.R, self.nx, self.ny))
-            self.nl_pack.matvec(self.F_nl, self.NLbuf, y)
-            parts.append(y)
+            self.nl_pack.matvec(self.F_nl, self.NLbuf, target())
         if self.F_x is not None:
-            y = ex.empty((self.R, self.nx, self.ny))
-            self.pack.matvec(self.F_x, self.X, y)
-            parts.append(y)
+            self.pack.matvec(self.F_x, self.X, target())
         for leaf, pk, mid in self.F_params:
-            y = ex.empty((self.R, self.nx, self.ny))
-            pk.matvec(mid, ev._leaf_plane_data(leaf), y)
-            parts.append(y)
-        if self.F_const is not None:
-            parts.append(self.F_const)
+            pk.matvec(mid, ev._leaf_plane_data(leaf), target())
         ev.new_pass()
         if not parts:
             ex.fill_zero(out)
-        elif len(parts) == 1:
-            ex.copy(out, parts[0])
-        else:
-            ex.lincomb(out, parts, [1.0] * len(parts))
+        elif len(parts) > 1:
+            ex.lincomb(out, parts, [1.0] * len(parts))      # parts[0] is out itself
+        if self.F_const is not None:
+            ex.scatter_add(out, self.F_const)               # a handful of entries of the k = 0 pencil
 
     # ---- un-aliased variables (no separable bases): tiny copies around each solve ---------------------------
     def push_unaliased(self):

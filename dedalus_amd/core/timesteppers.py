@@ -289,9 +289,9 @@ class RungeKuttaIMEX:
         t0 = s.sim_time
         s.sync_state_to_device()
         pack.matvec(s.M_id, s.X, self.MX0)
-        pack.matvec(s.L_id, s.X, self.LX[0])
         for i in range(1, self.stages + 1):
-            if i > 1:
+            # L.X_{i-1} only where a later stage uses it (the first column of H is zero in these schemes)
+            if any(H[m, i - 1] != 0.0 for m in range(i, self.stages + 1)):
                 pack.matvec(s.L_id, s.X, self.LX[i - 1])
             s.evaluate_F(self.F[i - 1])
             xs, al = [self.MX0], [1.0]

@@ -17,7 +17,7 @@ struct LincombArgs {
     int nterms;
 };
 
-__global__ void __launch_bounds__(256) lincomb_kernel(double *__restrict__ y, LincombArgs a, long n2, long n) {
+__global__ void __launch_bounds__(256) lincomb_kernel(double *y, LincombArgs a, long n2, long n) {
     // n2 = number of double2 elements; tail handled by the last thread block
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
@@ -175,7 +175,21 @@ static unsigned stream_grid(long work_items) {
 
 using namespace ddh;
 
+__global__ void scatter_add_kernel(double *__restrict__ y, const long *__restrict__ idx,
+                                   const double *__restrict__ vals, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[idx[i]] += vals[i];
+}
+
 extern "C" {
+
+int ddh_scatter_add(double *y, const long *idx_d, const double *vals_d, long n, void *stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(scatter_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), y,
+                       idx_d, vals_d, n);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
 
 int ddh_lincomb(double *y, int nterms, const double *const *xs_h, const double *alpha_h, long n, void *stream) {
     if (nterms < 1 || nterms > MAX_TERMS) return fail("ddh_lincomb: 1..16 terms supported");

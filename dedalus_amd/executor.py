@@ -63,6 +63,16 @@ class HipExecutor:
         al = np.ascontiguousarray(alphas, dtype=np.float64)
         libhip.call("ddh_lincomb", ptr(y), len(xs), arr, libhip.as_dp(al), n, self.dev.stream)
 
+    def make_scatter(self, flat_idx, vals):
+        """Device copy of a sparse vector (flat indices, values) for scatter_add."""
+        t = self.torch
+        idx = t.as_tensor(np.ascontiguousarray(flat_idx, dtype=np.int64), device=self.dev.tdev)
+        return (idx, self.from_host(np.ascontiguousarray(vals, dtype=np.float64)))
+
+    def scatter_add(self, y, sparse):
+        idx, vals = sparse
+        libhip.call("ddh_scatter_add", ptr(y), C.c_void_p(idx.data_ptr()), ptr(vals), idx.numel(), self.dev.stream)
+
     def bilinear(self, out, ncomp_out, a, b, npts, terms):
         if self.timer is not None:
             na = len({t[1] for t in terms}) + len({t[2] for t in terms}) + ncomp_out

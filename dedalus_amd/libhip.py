@@ -49,6 +49,7 @@ SIGNATURES = {
     "ddh_stream_sync": [_vp],
     "ddh_destroy": [_h],
     "ddh_plan_rfft": [_hp, _i, _i],
+    "ddh_scatter_add": [_vp, _vp, _vp, _l, _vp],
     "ddh_rfft_forward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward_deriv": [_h, _vp, _vp, _l, _l, _d, _vp],

@@ -93,6 +93,11 @@ int ddh_plan_mmt(ddh_handle *plan, int n_out, int n_in, const double *mat_h);
 int ddh_mmt_apply(ddh_handle plan, const double *in, double *out, long outer, long inner, void *stream);
 
 /* ---- grid-space and vector kernels -------------------------------- */
+/* y[idx[i]] += vals[i] for n distinct indices (device arrays): the constant right-hand-side entries
+ * (e.g. "b(z=0) = Lz", gathered into F by gather_outputs core/timesteppers.py:611-614) touch a handful of
+ * rows of the k = 0 pencil only. */
+int ddh_scatter_add(double *y, const long *idx_d, const double *vals_d, long n, void *stream);
+
 /* y = sum_t alpha[t] * x_t  (RHS assembly timesteppers.py:617-623 / :156-166; BLAS axpy chain).
  * xs_h: host array of nterms device pointers; y may alias one of them only if it is xs_h[0].   */
 int ddh_lincomb(double *y, int nterms, const double *const *xs_h, const double *alpha_h,

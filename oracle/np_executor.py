@@ -100,6 +100,13 @@ class NumpyExecutor:
             acc += a * x.reshape(y.shape)
         y[...] = acc
 
+    def make_scatter(self, flat_idx, vals):
+        return (np.asarray(flat_idx, dtype=np.int64), np.asarray(vals, dtype=np.float64))
+
+    def scatter_add(self, y, sparse):
+        idx, vals = sparse
+        y.reshape(-1)[idx] += vals
+
     def bilinear(self, out, ncomp_out, a, b, npts, terms):
         a2, b2 = a.reshape(-1, npts), b.reshape(-1, npts)
         o = np.zeros((ncomp_out, npts))
