@@ -25,15 +25,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-PMC_FAMILY = {   # kernel family in this file -> device kernels in profiles/r1_pmc_traffic.json
-    "pencil_solve": ["solve_forward_kernel<2, true>", "solve_backward_kernel<2, 40, true>"],
-    "pencil_matvec": ["matvec_kernel<2>"],
-    "rfft_backward_contig": ["fft_axis_kernel<1, false, 256>"],
-    "rfft_backward_strided": ["fft_axis_kernel<1, true, 256>"],
-    "rfft_forward_contig": ["fft_axis_kernel<0, false, 256>"],
-    "rfft_forward_strided": ["fft_axis_kernel<0, true, 256>"],
-    "cheb_forward_strided": ["fft_axis_kernel<2, true, 256>"],
-    "cheb_backward_strided": ["fft_axis_kernel<3, true, 256>"],
+PMC_FAMILY = {   # kernel family in this file -> device kernel name prefixes in profiles/r1_pmc_traffic.json
+    "pencil_solve": ["solve_forward_kernel", "solve_backward_kernel"],
+    "pencil_matvec": ["matvec_kernel"],
+    "rfft_bilinear_fused": ["fused_rfft_bilinear_kernel"],
+    "rfft_backward_contig": ["fft_axis_kernel<1, false"],
+    "rfft_backward_strided": ["fft_axis_kernel<1, true"],
+    "rfft_forward_contig": ["fft_axis_kernel<0, false"],
+    "rfft_forward_strided": ["fft_axis_kernel<0, true"],
+    "cheb_forward_strided": ["fft_axis_kernel<2, true"],
+    "cheb_backward_strided": ["fft_axis_kernel<3, true"],
     "grid_bilinear": ["bilinear_kernel"],
     "lincomb": ["lincomb_kernel"],
 }
@@ -42,16 +43,19 @@ PMC_FAMILY = {   # kernel family in this file -> device kernels in profiles/r1_p
 def pmc_traffic(family):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes
     (profiles/r1_pmc_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes,
-    full-size run).  Returns None when no measurement is on file."""
+    full-size run; a family made of several kernels per call sums their per-launch means).
+    Returns None when no measurement is on file."""
     path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
     if not os.path.exists(path) or family not in PMC_FAMILY:
         return None
     data = json.load(open(path))
     tot = 0.0
-    for k in PMC_FAMILY[family]:
-        if k not in data:
+    for prefix in PMC_FAMILY[family]:
+        hits = [v for k, v in data.items() if k.startswith(prefix)]
+        if not hits:
             return None
-        tot += (data[k]["read_GB_mean"] + data[k]["write_GB_mean"]) * 1e9
+        n = sum(h["launches"] for h in hits)
+        tot += sum((h["read_GB_mean"] + h["write_GB_mean"]) * h["launches"] for h in hits) / n * 1e9
     return tot
 
 
