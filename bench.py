@@ -107,8 +107,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
+        if os.environ.get("DDH_FORCE_DEVICE") is not None:      # test aid: several ranks on one GPU (gloo)
+            local_rank = int(os.environ["DDH_FORCE_DEVICE"])
+            os.environ["LOCAL_RANK"] = str(local_rank)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("DDH_DIST_BACKEND", "nccl"))
     Nx, Ny, Nz = [int(s) for s in args.size.split(",")]
     import problems
     import dedalus_amd.public as d3

@@ -130,22 +130,24 @@ __global__ void __launch_bounds__(256) cfl_kernel(double *result, const double *
 // [outer][na][nb*inner]  ->  [P][outer][na/P][nb*inner]   (split axis a into P blocks)
 __global__ void __launch_bounds__(256)
 a2a_pack_kernel(const double *__restrict__ src, double *__restrict__ dst, long outer, long na, long row, int P) {
-    // one block row = `row` contiguous doubles; grid-stride over (o, ia) rows, 16-byte copies
+    // [o][p][il][row] -> [p][o][il][row]: for fixed (o, p) the (il, row) block is contiguous on both sides
     const long blk = na / P;
-    const long nrows = outer * na;
-    const long row2 = row >> 1;
-    for (long r = blockIdx.x; r < nrows; r += gridDim.x) {
-        const long o = r / na, ia = r % na;
-        const long p = ia / blk, il = ia % blk;
-        const double *s = src + r * row;
-        double *d = dst + ((p * outer + o) * blk + il) * row;
-        for (long i = threadIdx.x; i < row2; i += blockDim.x)
-            reinterpret_cast<double2 *>(d)[i] = reinterpret_cast<const double2 *>(s)[i];
-        if ((row & 1) && threadIdx.x == 0) d[row - 1] = s[row - 1];
+    const long seg = blk * row;
+    const long nseg = outer * P;
+    const bool vec = (seg & 1) == 0;     // even segments keep every 16-byte access aligned
+    for (long r = blockIdx.x; r < nseg; r += gridDim.x) {
+        const long o = r / P, p = r % P;
+        const double *s = src + r * seg;
+        double *d = dst + (p * outer + o) * seg;
+        if (vec) {
+            for (long i = threadIdx.x; i < (seg >> 1); i += blockDim.x)
+                reinterpret_cast<double2 *>(d)[i] = reinterpret_cast<const double2 *>(s)[i];
+        } else {
+            for (long i = threadIdx.x; i < seg; i += blockDim.x) d[i] = s[i];
+        }
     }
 }
 
-// [P][outer][na][nb/P][inner]  ->  [outer][na][nb][inner]   (gather axis b from P blocks)
 __global__ void __launch_bounds__(256)
 a2a_unpack_kernel(const double *__restrict__ src, double *__restrict__ dst, long outer, long na, long nb, long inner,
                   int P) {
@@ -158,9 +160,12 @@ a2a_unpack_kernel(const double *__restrict__ src, double *__restrict__ dst, long
         const long oi = r % (outer * na);
         const double *s = src + r * seg;
         double *d = dst + (oi * nb + p * blk) * inner;
-        for (long i = threadIdx.x; i < seg2; i += blockDim.x)
-            reinterpret_cast<double2 *>(d)[i] = reinterpret_cast<const double2 *>(s)[i];
-        if ((seg & 1) && threadIdx.x == 0) d[seg - 1] = s[seg - 1];
+        if ((seg & 1) == 0 && ((nb * inner) & 1) == 0) {
+            for (long i = threadIdx.x; i < seg2; i += blockDim.x)
+                reinterpret_cast<double2 *>(d)[i] = reinterpret_cast<const double2 *>(s)[i];
+        } else {
+            for (long i = threadIdx.x; i < seg; i += blockDim.x) d[i] = s[i];
+        }
     }
 }
 
@@ -277,8 +282,7 @@ int ddh_grid_cfl(double *result_d, const double *u, int ncomp, long n, const dou
 int ddh_a2a_pack(const double *src, double *dst, long outer, long na, long nb, long inner, int nparts, void *stream) {
     if (nparts < 1 || na % nparts) return fail("ddh_a2a_pack: axis length must be divisible by nparts");
     const long row = nb * inner;
-    if (row & 1) return fail("ddh_a2a_pack: row length must be even");
-    long nrows = outer * na;
+    long nrows = outer * nparts;
     unsigned grid = (unsigned)(nrows < 8192 ? nrows : 8192);
     if (grid == 0) return 0;
     hipLaunchKernelGGL(a2a_pack_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, dst, outer, na, row, nparts);
@@ -288,7 +292,6 @@ int ddh_a2a_pack(const double *src, double *dst, long outer, long na, long nb, l
 
 int ddh_a2a_unpack(const double *src, double *dst, long outer, long na, long nb, long inner, int nparts, void *stream) {
     if (nparts < 1 || nb % nparts) return fail("ddh_a2a_unpack: axis length must be divisible by nparts");
-    if (((nb / nparts) * inner) & 1) return fail("ddh_a2a_unpack: segment length must be even");
     long nseg = (long)nparts * outer * na;
     unsigned grid = (unsigned)(nseg < 8192 ? nseg : 8192);
     if (grid == 0) return 0;

@@ -25,7 +25,7 @@ class Comm:
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         if not dist.is_initialized():
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("DDH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(backend)
         self.size = dist.get_world_size()
@@ -41,6 +41,13 @@ class Comm:
             r = t.empty_like(s)
             self.dist.all_to_all_single(r, s)
             recv[...] = r.numpy().reshape(recv.shape)
+        elif send.is_cuda and self.dist.get_backend() == "gloo":
+            # test configuration only (several ranks sharing one GPU, where RCCL cannot run): stage the
+            # exchange through the host; the production backend is "nccl" (RCCL) on device buffers
+            s = send.reshape(-1).cpu()
+            r = t.empty_like(s)
+            self.dist.all_to_all_single(r, s)
+            recv.reshape(-1).copy_(r)
         else:
             self.dist.all_to_all_single(recv.reshape(-1), send.reshape(-1))
 

@@ -1,6 +1,8 @@
-"""Worker for the multi-process (gloo, CPU) sharding test: every rank runs the same problem script with
-mesh=(world,), the numpy oracle executor and torch.distributed all-to-all, then saves its local
-coefficient blocks."""
+"""Worker for the multi-process sharding tests: every rank runs the same problem script with
+mesh=(world,) and torch.distributed all-to-all (gloo), then saves its local coefficient blocks.
+Default: the numpy oracle executor on CPU.  With a third argument "hip": the HIP executor, all ranks on
+GPU 0 (exercises the sharded pencil packs, a2a pack/unpack kernels and the fused grid stage of the
+multi-GPU path; only RCCL itself is replaced by a host-staged exchange)."""
 import os
 import sys
 
@@ -13,13 +15,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     case, outdir = sys.argv[1], sys.argv[2]
+    use_hip = len(sys.argv) > 3 and sys.argv[3] == "hip"
     import torch.distributed as dist
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     import problems
     import dedalus_amd.public as d3
-    from oracle.np_executor import NumpyExecutor
-    solver, res = problems.run_case(d3, case, dist_kw=dict(executor=NumpyExecutor(), mesh=(world,)))
+    if use_hip:
+        # all ranks share GPU 0 (RCCL needs one GPU per rank; the exchange is staged through the host)
+        os.environ["LOCAL_RANK"] = "0"
+        dist_kw = dict(mesh=(world,))
+    else:
+        from oracle.np_executor import NumpyExecutor
+        dist_kw = dict(executor=NumpyExecutor(), mesh=(world,))
+    solver, res = problems.run_case(d3, case, dist_kw=dist_kw)
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -213,21 +213,23 @@ def test_lincomb_bilinear_cfl_a2a():
                 libhip.as_ip(ic), libhip.as_ip(ia), libhip.as_ip(ib), libhip.as_dp(cf), dev.stream)
     dev.sync()
     assert rel(dev.to_host(out)[0], -(u * g).sum(0)) < 1e-14
-    # a2a pack / unpack are inverse re-orderings of a transpose
-    outer, na, nb_, inner, P = 2, 8, 12, 6, 4
-    src = rng.standard_normal((outer, na, nb_, inner))
-    d_src = dev.from_host(src)
-    d_pk = dev.empty(src.size)
-    libhip.call("ddh_a2a_pack", ptr(d_src), ptr(d_pk), outer, na, nb_, inner, P, dev.stream)
-    dev.sync()
-    pk = dev.to_host(d_pk).reshape(P, outer, na // P, nb_, inner)
-    for p in range(P):
-        assert np.array_equal(pk[p], src[:, p * (na // P):(p + 1) * (na // P)])
-    blocks = rng.standard_normal((P, outer, na, nb_ // P, inner))
-    d_un = dev.empty((outer, na, nb_, inner))
-    d_blocks = dev.from_host(blocks)
-    libhip.call("ddh_a2a_unpack", ptr(d_blocks), ptr(d_un), outer, na, nb_, inner, P, dev.stream)
-    dev.sync()
-    un = dev.to_host(d_un)
-    for p in range(P):
-        assert np.array_equal(un[:, :, p * (nb_ // P):(p + 1) * (nb_ // P)], blocks[p])
+    # a2a pack / unpack are inverse re-orderings of a transpose (even and odd segment lengths)
+    for outer, na, nb_, inner, P in [(2, 8, 12, 6, 4), (3, 6, 1, 1, 2), (2, 10, 3, 5, 1), (5, 4, 6, 1, 2)]:
+        src = rng.standard_normal((outer, na, nb_, inner))
+        d_src = dev.from_host(src)
+        d_pk = dev.empty(src.size)
+        libhip.call("ddh_a2a_pack", ptr(d_src), ptr(d_pk), outer, na, nb_, inner, P, dev.stream)
+        dev.sync()
+        pk = dev.to_host(d_pk).reshape(P, outer, na // P, nb_, inner)
+        for p in range(P):
+            assert np.array_equal(pk[p], src[:, p * (na // P):(p + 1) * (na // P)])
+        if nb_ % P:
+            continue
+        blocks = rng.standard_normal((P, outer, na, nb_ // P, inner))
+        d_un = dev.empty((outer, na, nb_, inner))
+        d_blocks = dev.from_host(blocks)
+        libhip.call("ddh_a2a_unpack", ptr(d_blocks), ptr(d_un), outer, na, nb_, inner, P, dev.stream)
+        dev.sync()
+        un = dev.to_host(d_un)
+        for p in range(P):
+            assert np.array_equal(un[:, :, p * (nb_ // P):(p + 1) * (nb_ // P)], blocks[p])
