@@ -1,0 +1,274 @@
+// Grouped dense transforms: the spin-weighted spherical harmonic colatitude transform.
+// One launch applies, for every local azimuthal wavenumber m, that m's (Lmax+1-|m|) x Ntheta matrix to its
+// slice of the data -- the reference does this in a Python loop of small matmuls
+// (SWSHColatitudeTransform.forward_reduced / backward_reduced, core/transforms.py:1258-1288).
+//
+// The work is bound by streaming the matrices (S: sum_m (255-m) x 384 doubles = 101 MB per spin against
+// 1.5 MB of data), so:
+//   * few right-hand-side columns (sphere fields: 2 = cos/msin parts): one wave per output row, lanes
+//     stride along the contraction index (coalesced matrix rows), wave reduction -- a batched GEMV;
+//   * many columns (shell fields carry the radial axis behind theta): LDS-tiled FP64 GEMM.
+#include "ddh_common.h"
+
+namespace ddh {
+
+struct GroupDev {
+    int mat_rows;            // rows (n_ell) of the matrices, -1: no matrix (|m| > Lmax)
+    long off_f, off_b;       // offsets of the forward / backward matrix in the packed arrays
+    int g_start, c_start, count, ell_start, ell_step, n_ell;
+};
+
+struct GmmtPlan : HandleBase {
+    int n_grid = 0, ngroups = 0, max_ell = 0, max_count = 0;
+    long max_g_end = 0, max_c_end = 0, max_l_end = 0;
+    GroupDev *d_groups = nullptr;
+    double *d_fwd = nullptr, *d_bwd = nullptr;
+    ~GmmtPlan() override {
+        (void)hipFree(d_groups);
+        (void)hipFree(d_fwd);
+        (void)hipFree(d_bwd);
+    }
+};
+
+struct GmmtDims {
+    long n0, n1g, n1c, n2c, n3;
+    int n_grid;
+};
+
+// address helpers (C order)
+__device__ __forceinline__ long g_index(const GmmtDims &d, long o, long i1, long t, long x) {
+    return ((o * d.n1g + i1) * d.n_grid + t) * d.n3 + x;
+}
+__device__ __forceinline__ long c_index(const GmmtDims &d, long o, long i1, long l, long x) {
+    return ((o * d.n1c + i1) * d.n2c + l) * d.n3 + x;
+}
+
+constexpr int GV_COLS = 8;     // GEMV path: at most this many right-hand-side columns
+
+// ---- batched GEMV: block = 4 waves = 4 output rows of one group ---------------------------------------
+template <bool FWD>
+__global__ void __launch_bounds__(256)
+grouped_gemv_kernel(const GroupDev *__restrict__ groups, const double *__restrict__ mats, const double *__restrict__ in,
+                    double *__restrict__ out, GmmtDims d, int ncols) {
+    const GroupDev gr = groups[blockIdx.y];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    const int nrows = FWD ? gr.n_ell : d.n_grid;       // output rows
+    if (gr.mat_rows < 0) {
+        if (!FWD && row < d.n_grid) {
+            for (int col = lane; col < ncols; col += 64) {
+                const long x = col % d.n3, jc = (col / d.n3) % gr.count, o = col / (d.n3 * gr.count);
+                if (o < d.n0) out[g_index(d, o, gr.g_start + jc, row, x)] = 0.0;
+            }
+        }
+        return;
+    }
+    if (row >= nrows) return;
+    const int K = FWD ? d.n_grid : gr.n_ell;            // contraction length
+    const double *A = mats + (FWD ? gr.off_f : gr.off_b) + (long)row * K;
+    double acc[GV_COLS];
+#pragma unroll
+    for (int c = 0; c < GV_COLS; ++c) acc[c] = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const double a = A[k];
+#pragma unroll
+        for (int c = 0; c < GV_COLS; ++c) {
+            if (c < ncols) {
+                const long x = c % d.n3, jc = (c / d.n3) % gr.count, o = c / (d.n3 * gr.count);
+                if (o < d.n0) {
+                    const long idx = FWD ? g_index(d, o, gr.g_start + jc, k, x)
+                                         : c_index(d, o, gr.c_start + jc, gr.ell_start + (long)k * gr.ell_step, x);
+                    acc[c] += a * in[idx];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < GV_COLS; ++c) {
+        if (c < ncols) {
+            double v = acc[c];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            const long o_chk = c / (d.n3 * gr.count);
+            if (lane == 0 && o_chk < d.n0) {
+                const long x = c % d.n3, jc = (c / d.n3) % gr.count, o = c / (d.n3 * gr.count);
+                const long idx = FWD ? c_index(d, o, gr.c_start + jc, gr.ell_start + (long)row * gr.ell_step, x)
+                                     : g_index(d, o, gr.g_start + jc, row, x);
+                out[idx] = v;
+            }
+        }
+    }
+}
+
+// ---- LDS-tiled GEMM: tile = 32 output rows x 64 columns, contraction in steps of 16 --------------------
+constexpr int GT_I = 32, GT_X = 64, GT_J = 16;
+
+template <bool FWD>
+__global__ void __launch_bounds__(256)
+grouped_gemm_kernel(const GroupDev *__restrict__ groups, const double *__restrict__ mats, const double *__restrict__ in,
+                    double *__restrict__ out, GmmtDims d, long ncols) {
+    __shared__ double sA[GT_I][GT_J + 1];
+    __shared__ double sB[GT_J][GT_X];
+    const GroupDev gr = groups[blockIdx.z];
+    const int nrows = FWD ? gr.n_ell : d.n_grid;
+    const int i0 = blockIdx.y * GT_I;
+    if (i0 >= nrows) return;
+    const long x0 = (long)blockIdx.x * GT_X;
+    const int tx = threadIdx.x % GT_X, ty = threadIdx.x / GT_X;
+    // this thread's output column and, for the B tile loads, the column it fetches
+    const long col = x0 + tx;
+    const bool col_ok = col < ncols && col / (d.n3 * gr.count) < d.n0;
+    const long cx = col_ok ? col % d.n3 : 0, cj = col_ok ? (col / d.n3) % gr.count : 0,
+               co = col_ok ? col / (d.n3 * gr.count) : 0;
+    if (gr.mat_rows < 0) {
+        if (!FWD && col_ok) {
+            for (int r = ty; r < GT_I; r += 4)
+                if (i0 + r < d.n_grid) out[g_index(d, co, gr.g_start + cj, i0 + r, cx)] = 0.0;
+        }
+        return;
+    }
+    const int K = FWD ? d.n_grid : gr.n_ell;
+    const double *A = mats + (FWD ? gr.off_f : gr.off_b);
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j0 = 0; j0 < K; j0 += GT_J) {
+        for (int w = threadIdx.x; w < GT_I * GT_J; w += 256) {
+            const int jj = w % GT_J, ii = w / GT_J;
+            sA[ii][jj] = (i0 + ii < nrows && j0 + jj < K) ? A[(long)(i0 + ii) * K + j0 + jj] : 0.0;
+        }
+        for (int jj = ty; jj < GT_J; jj += 4) {
+            double v = 0.0;
+            const int k = j0 + jj;
+            if (col_ok && k < K)
+                v = in[FWD ? g_index(d, co, gr.g_start + cj, k, cx)
+                           : c_index(d, co, gr.c_start + cj, gr.ell_start + (long)k * gr.ell_step, cx)];
+            sB[jj][tx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < GT_J; ++jj) {
+            const double bv = sB[jj][tx];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] += sA[ty * 8 + r][jj] * bv;
+        }
+        __syncthreads();
+    }
+    if (col_ok) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = i0 + ty * 8 + r;
+            if (i < nrows) {
+                const long idx = FWD ? c_index(d, co, gr.c_start + cj, gr.ell_start + (long)i * gr.ell_step, cx)
+                                     : g_index(d, co, gr.g_start + cj, i, cx);
+                out[idx] = acc[r];
+            }
+        }
+    }
+}
+
+template <bool FWD>
+static int launch_grouped(GmmtPlan *pl, const double *in, double *out, long n0, long n1g, long n1c, long n2c, long n3,
+                          void *stream) {
+    if (n0 <= 0 || n3 <= 0 || pl->ngroups == 0) return 0;
+    if (in == out) return fail("grouped_mmt: in-place unsupported");
+    if (pl->max_g_end > n1g || pl->max_c_end > n1c || pl->max_l_end > n2c)
+        return fail("grouped_mmt: a group's slices exceed the array extents");
+    GmmtDims d{n0, n1g, n1c, n2c, n3, pl->n_grid};
+    const long ncols = n0 * (long)pl->max_count * n3;      // columns of the widest group
+    hipStream_t st = as_stream(stream);
+    const int max_rows = FWD ? pl->max_ell : pl->n_grid;
+    const double *mats = FWD ? pl->d_fwd : pl->d_bwd;
+    if (ncols <= GV_COLS) {
+        dim3 grid((unsigned)((max_rows + 3) / 4), (unsigned)pl->ngroups);
+        hipLaunchKernelGGL(grouped_gemv_kernel<FWD>, grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols);
+    } else {
+        dim3 grid((unsigned)((ncols + GT_X - 1) / GT_X), (unsigned)((max_rows + GT_I - 1) / GT_I), (unsigned)pl->ngroups);
+        if (grid.z > 65535 || grid.y > 65535) return fail("grouped_mmt: too many groups / rows for one launch");
+        hipLaunchKernelGGL(grouped_gemm_kernel<FWD>, grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, ncols);
+    }
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace ddh
+
+using namespace ddh;
+
+extern "C" {
+
+int ddh_plan_grouped_mmt(ddh_handle *plan, int n_grid, int ngroups, const ddh_mmt_group *groups_h, int nmats,
+                         const int *mat_rows_h, const double *const *fwd_h, const double *const *bwd_h) {
+    if (n_grid < 1 || ngroups < 0 || nmats < 0) return fail("plan_grouped_mmt: bad sizes");
+    std::vector<long> off(nmats + 1, 0);
+    for (int i = 0; i < nmats; ++i) {
+        if (mat_rows_h[i] < 0) return fail("plan_grouped_mmt: negative matrix size");
+        off[i + 1] = off[i] + (long)mat_rows_h[i] * n_grid;
+    }
+    GmmtPlan *pl = new GmmtPlan();
+    pl->kind = H_GMMT;
+    pl->n_grid = n_grid;
+    pl->ngroups = ngroups;
+    std::vector<GroupDev> gd(ngroups > 0 ? ngroups : 1);
+    for (int g = 0; g < ngroups; ++g) {
+        const ddh_mmt_group &h = groups_h[g];
+        GroupDev &o = gd[g];
+        if (h.mat >= nmats || h.count < 1 || (h.ell_step != 1 && h.ell_step != -1) || h.n_ell < 0) {
+            delete pl;
+            return fail("plan_grouped_mmt: malformed group");
+        }
+        if (h.mat >= 0 && mat_rows_h[h.mat] != h.n_ell) {
+            delete pl;
+            return fail("plan_grouped_mmt: group row count differs from its matrix");
+        }
+        o.mat_rows = h.mat >= 0 ? h.n_ell : -1;
+        o.off_f = o.off_b = h.mat >= 0 ? off[h.mat] : 0;
+        o.g_start = h.g_start; o.c_start = h.c_start; o.count = h.count;
+        o.ell_start = h.ell_start; o.ell_step = h.ell_step; o.n_ell = h.mat >= 0 ? h.n_ell : 0;
+        const long l_lo = h.ell_step > 0 ? h.ell_start : h.ell_start - (long)(o.n_ell > 0 ? o.n_ell - 1 : 0);
+        const long l_hi = h.ell_step > 0 ? h.ell_start + (long)(o.n_ell > 0 ? o.n_ell - 1 : 0) : h.ell_start;
+        if (h.g_start < 0 || h.c_start < 0 || (o.n_ell > 0 && l_lo < 0)) {
+            delete pl;
+            return fail("plan_grouped_mmt: negative slice start");
+        }
+        if (o.n_ell > pl->max_ell) pl->max_ell = o.n_ell;
+        if (h.count > pl->max_count) pl->max_count = h.count;
+        if (h.g_start + h.count > pl->max_g_end) pl->max_g_end = h.g_start + h.count;
+        if (h.mat >= 0 && h.c_start + h.count > pl->max_c_end) pl->max_c_end = h.c_start + h.count;
+        if (o.n_ell > 0 && l_hi + 1 > pl->max_l_end) pl->max_l_end = l_hi + 1;
+    }
+    const size_t nb = (size_t)(off[nmats] > 0 ? off[nmats] : 1) * sizeof(double);
+    std::vector<double> pf((size_t)off[nmats] + 1, 0.0), pb((size_t)off[nmats] + 1, 0.0);
+    for (int i = 0; i < nmats; ++i) {
+        const size_t n = (size_t)mat_rows_h[i] * n_grid;
+        if (n) {
+            memcpy(pf.data() + off[i], fwd_h[i], n * sizeof(double));
+            memcpy(pb.data() + off[i], bwd_h[i], n * sizeof(double));
+        }
+    }
+    if (check_hip(hipMalloc((void **)&pl->d_groups, gd.size() * sizeof(GroupDev)), "hipMalloc") ||
+        check_hip(hipMemcpy(pl->d_groups, gd.data(), gd.size() * sizeof(GroupDev), hipMemcpyHostToDevice), "hipMemcpy") ||
+        check_hip(hipMalloc((void **)&pl->d_fwd, nb), "hipMalloc") ||
+        check_hip(hipMalloc((void **)&pl->d_bwd, nb), "hipMalloc") ||
+        check_hip(hipMemcpy(pl->d_fwd, pf.data(), nb, hipMemcpyHostToDevice), "hipMemcpy") ||
+        check_hip(hipMemcpy(pl->d_bwd, pb.data(), nb, hipMemcpyHostToDevice), "hipMemcpy")) {
+        delete pl;
+        return -2;
+    }
+    *plan = register_handle(pl);
+    return 0;
+}
+
+int ddh_grouped_mmt_forward(ddh_handle plan, const double *g, double *c, long n0, long n1g, long n1c, long n2c,
+                            long n3, void *stream) {
+    GmmtPlan *pl = (GmmtPlan *)lookup_handle(plan, H_GMMT);
+    if (!pl) return -1;
+    return launch_grouped<true>(pl, g, c, n0, n1g, n1c, n2c, n3, stream);
+}
+
+int ddh_grouped_mmt_backward(ddh_handle plan, const double *c, double *g, long n0, long n1g, long n1c, long n2c,
+                             long n3, void *stream) {
+    GmmtPlan *pl = (GmmtPlan *)lookup_handle(plan, H_GMMT);
+    if (!pl) return -1;
+    return launch_grouped<false>(pl, c, g, n0, n1g, n1c, n2c, n3, stream);
+}
+
+}  // extern "C"

@@ -182,10 +182,48 @@ class HipExecutor:
     def a2a_unpack(self, src, dst, outer, na, nb, inner, P):
         libhip.call("ddh_a2a_unpack", ptr(src), ptr(dst), outer, na, nb, inner, P, self.dev.stream)
 
+    def make_grouped_mmt(self, n_grid, groups, ms, fwd_mats, bwd_mats):
+        return GroupedMmt(self, n_grid, groups, ms, fwd_mats, bwd_mats)
+
     def make_pack(self, nf, nrows, nx, ny, kx, ky, mx_offset=0):
         pk = PencilPack(self.dev, nf, nrows, nx, ny, kx, ky, mx_offset)
         pk.executor = self
         return pk
+
+
+class GroupedMmt:
+    """ddh_plan_grouped_mmt handle: groups = rows (m, g_start, c_start, count, ell_start, ell_step, n_ell),
+    ms = the distinct m that own a matrix pair (fwd [n_ell][n_grid], bwd [n_grid][n_ell])."""
+
+    def __init__(self, ex, n_grid, groups, ms, fwd_mats, bwd_mats):
+        self.ex, self.n_grid = ex, int(n_grid)
+        index = {int(m): i for i, m in enumerate(ms)}
+        arr = (libhip.MmtGroup * max(len(groups), 1))()
+        for i, row in enumerate(groups):
+            m = int(row[0])
+            arr[i] = libhip.MmtGroup(index.get(m, -1), int(row[1]), int(row[2]), int(row[3]), int(row[4]), int(row[5]),
+                                     int(row[6]))
+        fw = [np.ascontiguousarray(a, dtype=np.float64) for a in fwd_mats]
+        bw = [np.ascontiguousarray(a, dtype=np.float64) for a in bwd_mats]
+        rows = np.ascontiguousarray([a.shape[0] for a in fw], dtype=np.int32)
+        pf = (C.c_void_p * max(len(fw), 1))(*[a.ctypes.data for a in fw])
+        pb = (C.c_void_p * max(len(bw), 1))(*[a.ctypes.data for a in bw])
+        self.handle = C.c_uint64(0)
+        libhip.call("ddh_plan_grouped_mmt", C.byref(self.handle), self.n_grid, len(groups), C.cast(arr, C.c_void_p),
+                    len(fw), libhip.as_ip(rows), pf, pb)
+
+    def _dims(self, g, c):
+        n0, n1g, nt, n3 = [int(x) for x in g.shape]
+        c0, n1c, n2c, c3 = [int(x) for x in c.shape]
+        if nt != self.n_grid or c0 != n0 or c3 != n3:
+            raise ValueError("grouped transform: inconsistent reduced shapes %s / %s" % (tuple(g.shape), tuple(c.shape)))
+        return n0, n1g, n1c, n2c, n3
+
+    def forward(self, g, c):
+        libhip.call("ddh_grouped_mmt_forward", self.handle, ptr(g), ptr(c), *self._dims(g, c), self.ex.dev.stream)
+
+    def backward(self, c, g):
+        libhip.call("ddh_grouped_mmt_backward", self.handle, ptr(c), ptr(g), *self._dims(g, c), self.ex.dev.stream)
 
 
 class KernelTimer:

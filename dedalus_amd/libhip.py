@@ -50,6 +50,9 @@ SIGNATURES = {
     "ddh_destroy": [_h],
     "ddh_plan_rfft": [_hp, _i, _i],
     "ddh_scatter_add": [_vp, _vp, _vp, _l, _vp],
+    "ddh_plan_grouped_mmt": [_hp, _i, _i, _vp, _i, _ip, C.POINTER(_vp), C.POINTER(_vp)],
+    "ddh_grouped_mmt_forward": [_h, _vp, _vp, _l, _l, _l, _l, _l, _vp],
+    "ddh_grouped_mmt_backward": [_h, _vp, _vp, _l, _l, _l, _l, _l, _vp],
     "ddh_rfft_forward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward_deriv": [_h, _vp, _vp, _l, _l, _d, _vp],
@@ -83,6 +86,12 @@ SIGNATURES = {
     "ddh_a2a_pack": [_vp, _vp, _l, _l, _l, _l, _i, _vp],
     "ddh_a2a_unpack": [_vp, _vp, _l, _l, _l, _l, _i, _vp],
 }
+
+
+class MmtGroup(C.Structure):
+    """ddh_mmt_group of include/dedalus_hip.h"""
+    _fields_ = [("mat", C.c_int), ("g_start", C.c_int), ("c_start", C.c_int), ("count", C.c_int),
+                ("ell_start", C.c_int), ("ell_step", C.c_int), ("n_ell", C.c_int)]
 
 
 def load(build_if_missing=False):

@@ -1,0 +1,68 @@
+"""
+Spin-weighted spherical harmonics on the Gauss-Legendre colatitude grid, and the per-(m, s) matrices
+of the colatitude transform (what SWSHColatitudeTransform builds, core/transforms.py:1290-1340, from
+libraries/dedalus_sphere/sphere.py:8-66).
+
+Derived from the Jacobi toolkit in tools/jacobi.py:  with a = |m+s|, b = |m-s|, Lmin = max(|m|, |s|),
+
+    Y^s_{l,m}(z) = (-1)^max(m,-s) * sqrt((1-z)^a (1+z)^b) * p^{(a,b)}_{l-Lmin}(z),     z = cos(theta),
+
+where p^{(a,b)}_k are the Jacobi polynomials orthonormal for the weight (1-z)^a (1+z)^b, so that
+int Y_l Y_l' dz = delta.  The three-term recurrence is started from the envelope-scaled p_0 in long
+double and in log space, which keeps |m| of several hundred free of over/underflow.
+"""
+
+import numpy as np
+from scipy.special import gammaln
+
+from . import jacobi
+
+LD = np.longdouble
+
+
+def quadrature(Ntheta):
+    """Gauss-Legendre nodes cos(theta) (ascending) and weights, exact to degree 2 Ntheta - 1."""
+    return jacobi.quadrature(Ntheta, 0, 0, dtype=LD)
+
+
+def _log_mass(a, b):
+    # int (1-z)^a (1+z)^b dz = 2^(a+b+1) B(a+1, b+1)
+    return (a + b + 1) * np.log(LD(2)) + LD(gammaln(a + 1) + gammaln(b + 1) - gammaln(a + b + 2))
+
+
+def harmonics(Lmax, m, s, z):
+    """Y^s_{l,m}(z) for l = Lmin..Lmax: array (Lmax + 1 - Lmin, len(z)) in long double."""
+    z = np.atleast_1d(np.asarray(z, dtype=LD))
+    Lmin = max(abs(m), abs(s))
+    n = Lmax + 1 - Lmin
+    a, b = abs(m + s), abs(m - s)
+    if n < 1:
+        return np.zeros((0, z.size), dtype=LD)
+    log_env = 0.5 * (a * np.log1p(-z) + b * np.log1p(z) - _log_mass(a, b))
+    P = np.zeros((n, z.size), dtype=LD)
+    P[0] = np.exp(log_env) * LD((-1.0) ** max(m, -s))
+    if n > 1:
+        J = jacobi.jacobi_matrix(n + 1, a, b).toarray()
+        d, e = np.diag(J), np.diag(J, 1)
+        P[1] = (z - d[0]) * P[0] / e[0]
+        for k in range(1, n - 1):
+            P[k + 1] = ((z - d[k]) * P[k] - e[k - 1] * P[k - 1]) / e[k]
+    return P
+
+
+def swsh_matrices(Ntheta, Lmax, m, s):
+    """(forward, backward) matrices of the colatitude transform for one (m, s):
+    forward (Lmax+1-|m|, Ntheta) = Y * weights, backward (Ntheta, Lmax+1-|m|) = Y^T, both padded with zero
+    rows / columns for l < Lmin and zeroed for l >= Ntheta (core/transforms.py:1300-1316, 1326-1340)."""
+    z, w = quadrature(Ntheta)
+    Y = harmonics(Lmax, m, s, z)
+    Lmin = max(abs(m), abs(s))
+    am = abs(m)
+    fwd = np.zeros((Lmax + 1 - am, Ntheta))
+    bwd = np.zeros((Ntheta, Lmax + 1 - am))
+    fwd[Lmin - am:, :] = (Y * w).astype(np.float64)
+    bwd[:, Lmin - am:] = Y.T.astype(np.float64)
+    if Ntheta - am < Lmax + 1 - am:
+        fwd[max(Ntheta - am, 0):, :] = 0
+        bwd[:, max(Ntheta - am, 0):] = 0
+    return fwd, bwd

@@ -92,6 +92,29 @@ int ddh_cheb_backward(ddh_handle plan, const double *c, double *g, long outer, l
 int ddh_plan_mmt(ddh_handle *plan, int n_out, int n_in, const double *mat_h);
 int ddh_mmt_apply(ddh_handle plan, const double *in, double *out, long outer, long inner, void *stream);
 
+/* ---- grouped dense transforms ---------------------------------------------
+ * Spin-weighted spherical harmonic colatitude transform: replaces the Python loop over the local
+ * azimuthal wavenumbers in SWSHColatitudeTransform.forward_reduced / backward_reduced
+ * (core/transforms.py:1258-1288), each iteration an apply_matrix of one dense (Lmax+1-|m|) x Ntheta
+ * matrix on a slice of the data, by one launch over all groups.
+ * Data are the reference's reduced 4-D views: grid side g[n0][n1g][n_grid][n3], coefficient side
+ * c[n0][n1c][n2c][n3] (C order).  A group is one entry of SphereBasis.m_maps (core/basis.py:2939-2970):
+ * grid slice [g_start, g_start+count) and coefficient slice [c_start, c_start+count) of axis 1, and the
+ * coefficient rows ell_start + r*ell_step (r = 0..n_ell-1; ell_step = -1 for folded modes) of axis 2.
+ * mat = index of the group's matrix pair, or -1 for |m| > Lmax (forward skips the group, backward
+ * writes zeros, :1268-1283).  fwd matrices are [n_ell][n_grid], bwd matrices [n_grid][n_ell].            */
+typedef struct {
+    int mat;
+    int g_start, c_start, count;
+    int ell_start, ell_step, n_ell;
+} ddh_mmt_group;
+int ddh_plan_grouped_mmt(ddh_handle *plan, int n_grid, int ngroups, const ddh_mmt_group *groups_h, int nmats,
+                         const int *mat_rows_h, const double *const *fwd_h, const double *const *bwd_h);
+int ddh_grouped_mmt_forward(ddh_handle plan, const double *g, double *c, long n0, long n1g, long n1c, long n2c,
+                            long n3, void *stream);
+int ddh_grouped_mmt_backward(ddh_handle plan, const double *c, double *g, long n0, long n1g, long n1c, long n2c,
+                             long n3, void *stream);
+
 /* ---- grid-space and vector kernels -------------------------------- */
 /* y[idx[i]] += vals[i] for n distinct indices (device arrays): the constant right-hand-side entries
  * (e.g. "b(z=0) = Lz", gathered into F by gather_outputs core/timesteppers.py:611-614) touch a handful of

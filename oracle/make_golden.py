@@ -96,6 +96,62 @@ def golden_transforms():
     print("wrote transforms.npz with", len(out), "arrays")
 
 
+def golden_swsh():
+    """SWSHColatitudeTransform of the reference (core/transforms.py:1251-1340) on seeded data: the m_maps of
+    real-dtype SphereBases, its matrices for a few (m, s), and forward / backward outputs."""
+    d3 = refshim.load_reference()
+    from dedalus.core import transforms as T
+    rng = np.random.default_rng(11)
+    out = {}
+    coords = d3.S2Coordinates("phi", "theta")
+    dist = d3.Distributor(coords, dtype=np.float64)
+    cases = []
+    for shape in [(16, 8), (8, 8), (4, 8), (32, 16), (24, 20)]:
+        basis = d3.SphereBasis(coords, shape=shape, radius=1, dealias=(3 / 2, 3 / 2), dtype=np.float64)
+        Lmax = basis.Lmax
+        gshape = basis.global_shape((False, True), (1.5, 1.5))       # (m-axis, Ntheta)
+        cshape = basis.global_shape((False, False), (1, 1))
+        Ntheta = int(gshape[1])
+        mm = basis.m_maps(dist)
+        groups = []
+        for (m, mg, mc, es) in mm:
+            n_ell = Lmax + 1 - abs(m) if abs(m) <= Lmax else 0
+            start = int(es.start)
+            step = -1 if es.step == -1 else 1
+            groups.append((int(m), int(mg.start), int(mc.start), int(mg.stop - mg.start), start, step, n_ell))
+        tag = "%dx%d" % shape
+        out[tag + "__groups"] = np.array(groups, dtype=np.int64)
+        out[tag + "__dims"] = np.array([Ntheta, Lmax, int(gshape[0]), int(cshape[0]), int(cshape[1])], dtype=np.int64)
+        for s in (0, 1, -1, 2):
+            plan = T.SWSHColatitudeTransform(Ntheta, Lmax, mm, s)
+            for (N0, N3) in ((1, 1), (2, 3)):
+                g = rng.standard_normal((N0, int(gshape[0]), Ntheta, N3))
+                c = np.zeros((N0, int(cshape[0]), int(cshape[1]), N3))
+                plan.forward_reduced(g, c)
+                c_in = rng.standard_normal(c.shape)
+                g_out = np.full(g.shape, np.nan)
+                plan.backward_reduced(c_in, g_out)
+                key = "%s__s%d__%d_%d" % (tag, s, N0, N3)
+                out[key + "__g"] = g
+                out[key + "__c"] = c
+                out[key + "__cin"] = c_in
+                out[key + "__gout"] = g_out
+            if shape in [(16, 8), (24, 20)]:
+                for m in (0, 1, min(Lmax, basis.mmax)):
+                    out["%s__s%d__fwdmat_m%d" % (tag, s, m)] = plan._forward_SWSH_matrices[m]
+                    out["%s__s%d__bwdmat_m%d" % (tag, s, m)] = plan._backward_SWSH_matrices[m]
+        cases.append(tag)
+    # one large-|m| matrix set (over/underflow regime of the envelope)
+    import dedalus.libraries.dedalus_sphere.sphere as rsphere
+    z, w = rsphere.quadrature(383)
+    out["big__z"] = np.asarray(z, dtype=np.float64)
+    out["big__w"] = np.asarray(w, dtype=np.float64)
+    for (m, s) in ((200, 0), (254, 1), (37, -2)):
+        out["big__Y_m%d_s%d" % (m, s)] = np.asarray(rsphere.harmonics(254, m, s, z), dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, "swsh.npz"), **out)
+    print("wrote swsh.npz with", len(out), "arrays for", cases)
+
+
 def golden_ivp():
     """End states of the reference itself on the shared problem scripts (tests/problems.py)."""
     d3 = refshim.load_reference()

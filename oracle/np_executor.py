@@ -196,5 +196,16 @@ class NumpyExecutor:
         s = src.reshape(P, outer, na, nb // P, inner)
         dst[...] = np.ascontiguousarray(np.transpose(s, (1, 2, 0, 3, 4))).reshape(dst.shape)
 
+    def make_grouped_mmt(self, n_grid, groups, ms, fwd_mats, bwd_mats):
+        from . import np_swsh
+
+        class _Plan:
+            def forward(self_, g, c):
+                np_swsh.forward_reduced(g, c, groups, {int(m): a for m, a in zip(ms, fwd_mats)})
+
+            def backward(self_, c, g):
+                np_swsh.backward_reduced(c, g, groups, {int(m): a for m, a in zip(ms, bwd_mats)})
+        return _Plan()
+
     def make_pack(self, nf, nrows, nx, ny, kx, ky, mx_offset=0):
         return _NpPack(nf, nrows, nx, ny, kx, ky, mx_offset)

@@ -97,6 +97,26 @@ def main():
     print("y  fused grid stage (19 lines arrays, %d lines): %.3f ms %.0f GB/s -> full size %.2f ms"
           % (nl, tfz * 1e3, nbytes / tfz / 1e9, tfz * 1e3 * Gz * Gx / nl), flush=True)
     del a, bb, oo
+    # spin-weighted spherical harmonic colatitude transform at the sphere config (512 x 256 -> Lmax 254,
+    # Ntheta 384): 255 matrices, 2 columns (cos / msin parts) -> batched GEMV bound by the matrix stream
+    if os.environ.get("BENCH_SWSH", "1") != "0":
+        from dedalus_amd.core.curvilinear import SWSHColatitudeTransform
+        Lmax, Nth = 254, 384
+        rows = [(m, 2 * m, 2 * m, 2, 0, 1, Lmax + 1 - m) for m in range(Lmax + 1)]
+        t0 = __import__("time").time()
+        sw = SWSHColatitudeTransform(Nth, Lmax, np.array(rows, dtype=np.int64), 0, executor=hx)
+        tbuild = __import__("time").time() - t0
+        for n3 in (1, 192):
+            gg = t.randn((1, 2 * (Lmax + 1), Nth, n3), dtype=t.float64, device=dev.tdev)
+            cc = dev.zeros((1, 2 * (Lmax + 1), Lmax + 1, n3))
+            tfw = timeit(dev, lambda: sw.forward_reduced(gg, cc), reps=20)
+            tbw = timeit(dev, lambda: sw.backward_reduced(cc, gg), reps=20)
+            mat_bytes = sum((Lmax + 1 - m) * Nth * 8 for m in range(Lmax + 1))
+            flops = 2.0 * sum((Lmax + 1 - m) * Nth for m in range(Lmax + 1)) * 2 * n3
+            print("SWSH colatitude Lmax=254 Ntheta=384, %3d columns/m: fwd %.3f ms, bwd %.3f ms  (matrices %.0f MB -> "
+                  "%.0f GB/s fwd; %.2f TFLOP/s fwd; host matrix build %.1f s)"
+                  % (2 * n3, tfw * 1e3, tbw * 1e3, mat_bytes / 1e6, mat_bytes / tfw / 1e9, flops / tfw / 1e12, tbuild),
+                  flush=True)
     # plain copy for reference
     a = t.randn(2 ** 27, dtype=t.float64, device=dev.tdev)
     b = t.empty_like(a)
