@@ -189,6 +189,53 @@ static int launch_grouped(GmmtPlan *pl, const double *in, double *out, long n0, 
     return 0;
 }
 
+// ---- regularity recombination (row a13) ----------------------------------------------------------------
+// data[ncomp][n1][n2][n3] in place: one workgroup per (i1, i2) = (m slot, ell slot); the 3^rank x 3^rank
+// matrix Q(ell) sits in LDS, threads run along the trailing (radial) axis.  The radial factor (dR/r)^k
+// of ShellBasis.forward/backward_transform_radius multiplies every point and commutes with Q: fused.
+template <int NC>
+__global__ void __launch_bounds__(256)
+regularity_kernel(double *__restrict__ data, const int *__restrict__ ell_map, const double *__restrict__ q,
+                  const double *__restrict__ fac, long n12, long n3, int nell, int forward) {
+    __shared__ double sQ[NC * NC];
+    const long i12 = blockIdx.x;
+    const int ell = ell_map ? ell_map[i12] : -1;
+    const bool mix = (NC > 1) && ell >= 0 && ell < nell;
+    if (mix) {
+        for (int w = threadIdx.x; w < NC * NC; w += blockDim.x) {
+            const int r = w / NC, c = w % NC;
+            sQ[w] = q[((long)ell * NC + r) * NC + c];
+            (void)c;
+            (void)forward;
+        }
+    }
+    __syncthreads();
+    const long cstride = n12 * n3;
+    for (long x = threadIdx.x; x < n3; x += blockDim.x) {
+        double v[NC], o[NC];
+        double *p = data + i12 * n3 + x;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = p[c * cstride];
+        if (mix) {
+#pragma unroll
+            for (int r = 0; r < NC; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc += sQ[r * NC + c] * v[c];
+                o[r] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) o[c] = v[c];
+        }
+        const double f = fac ? fac[x] : 1.0;
+        if (mix || fac) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) p[c * cstride] = f * o[c];
+        }
+    }
+}
+
 }  // namespace ddh
 
 using namespace ddh;
@@ -254,6 +301,31 @@ int ddh_plan_grouped_mmt(ddh_handle *plan, int n_grid, int ngroups, const ddh_mm
         return -2;
     }
     *plan = register_handle(pl);
+    return 0;
+}
+
+int ddh_regularity_recombine(double *data, int ncomp, long n1, long n2, long n3, const int *slot_map_d, int nmats,
+                             const double *mats_d, const double *radial_factor_d, void *stream) {
+    const int *ell_map_d = slot_map_d;
+    const double *q_d = mats_d;
+    const int nell = nmats, forward = 0;
+    if (n1 <= 0 || n2 <= 0 || n3 <= 0) return 0;
+    if (ncomp != 1 && ncomp != 3 && ncomp != 9) return fail("ddh_regularity_recombine: tensor rank 0, 1 or 2 (1, 3, 9 components)");
+    if (ncomp > 1 && (!ell_map_d || !q_d)) return fail("ddh_regularity_recombine: ell map and Q table required");
+    const long n12 = n1 * n2;
+    if (n12 > 0x7fffffffL) return fail("ddh_regularity_recombine: too many (m, ell) slots");
+    const int T = n3 >= 256 ? 256 : (n3 > 64 ? 128 : 64);
+    hipStream_t st = as_stream(stream);
+    if (ncomp == 1)
+        hipLaunchKernelGGL(regularity_kernel<1>, dim3((unsigned)n12), dim3(T), 0, st, data, ell_map_d, q_d,
+                           radial_factor_d, n12, n3, nell, forward);
+    else if (ncomp == 3)
+        hipLaunchKernelGGL(regularity_kernel<3>, dim3((unsigned)n12), dim3(T), 0, st, data, ell_map_d, q_d,
+                           radial_factor_d, n12, n3, nell, forward);
+    else
+        hipLaunchKernelGGL(regularity_kernel<9>, dim3((unsigned)n12), dim3(T), 0, st, data, ell_map_d, q_d,
+                           radial_factor_d, n12, n3, nell, forward);
+    DDH_HIP(hipGetLastError());
     return 0;
 }
 

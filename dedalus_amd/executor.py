@@ -182,6 +182,20 @@ class HipExecutor:
     def a2a_unpack(self, src, dst, outer, na, nb, inner, P):
         libhip.call("ddh_a2a_unpack", ptr(src), ptr(dst), outer, na, nb, inner, P, self.dev.stream)
 
+    def make_recombination(self, slot_map, mats):
+        """Device copy of (slot -> matrix index map [n1][n2] int32, matrices [nmats][nc][nc])."""
+        t = self.torch
+        sm = t.as_tensor(np.ascontiguousarray(slot_map, dtype=np.int32), device=self.dev.tdev)
+        return (sm, self.from_host(np.ascontiguousarray(mats, dtype=np.float64)), int(len(mats)))
+
+    def regularity_recombine(self, data, table, radial_factor_d=None):
+        """In place on data[ncomp][n1][n2][n3] (device)."""
+        nc, n1, n2, n3 = [int(x) for x in data.shape]
+        sm, mats, nm = table if table is not None else (None, None, 0)
+        libhip.call("ddh_regularity_recombine", ptr(data), nc, n1, n2, n3,
+                    C.c_void_p(sm.data_ptr()) if sm is not None else None, nm, ptr(mats) if mats is not None else None,
+                    ptr(radial_factor_d) if radial_factor_d is not None else None, self.dev.stream)
+
     def make_grouped_mmt(self, n_grid, groups, ms, fwd_mats, bwd_mats):
         return GroupedMmt(self, n_grid, groups, ms, fwd_mats, bwd_mats)
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "ddh_plan_grouped_mmt": [_hp, _i, _i, _vp, _i, _ip, C.POINTER(_vp), C.POINTER(_vp)],
     "ddh_grouped_mmt_forward": [_h, _vp, _vp, _l, _l, _l, _l, _l, _vp],
     "ddh_grouped_mmt_backward": [_h, _vp, _vp, _l, _l, _l, _l, _l, _vp],
+    "ddh_regularity_recombine": [_vp, _i, _l, _l, _l, _vp, _i, _vp, _vp, _vp],
     "ddh_rfft_forward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward_deriv": [_h, _vp, _vp, _l, _l, _d, _vp],

@@ -66,3 +66,76 @@ def swsh_matrices(Ntheta, Lmax, m, s):
         fwd[max(Ntheta - am, 0):, :] = 0
         bwd[:, max(Ntheta - am, 0):] = 0
     return fwd, bwd
+
+
+# ---- regularity <-> spin intertwiner ------------------------------------------------------------------
+def intertwiner(ell, rank, indexing=(-1, +1, 0)):
+    """Q(ell)[spin, regularity] for tensors of the given rank: the orthogonal map between regularity
+    components (radial behaviour r^(ell+a)) and spin components at degree ell, both indexed over
+    `indexing`^rank in C order (what dedalus_sphere.spin_operators.Intertwiner(ell, indexing)(rank) returns,
+    libraries/dedalus_sphere/spin_operators.py:276-362; used by radial_recombinations, core/basis.py:3549-3560).
+
+    Recursive definition (Vasil, Lecoanet, Burns, Oishi & Brown 2019, tensor calculus in spherical
+    coordinates): peel the first index (sigma, a) off the spin / regularity tuples,
+        Q_{sigma tau, a b} = C_a( Q_{tau b} [sigma = 0],  R ),      J = ell + sum(b),
+        R = sum_i ( [tau_i = 0] Q_{tau(i->sigma), b} - [tau_i = -sigma] Q_{tau(i->0), b} ) - k(sigma, sum tau) Q_{tau b},
+        k(mu, s) = -mu sqrt((ell - s mu)(ell + s mu + 1) / 2),
+        C_-1 = (Q J - R) / sqrt(J (2J+1)),  C_0 = sigma R / sqrt(J (J+1)),  C_+1 = (Q (J+1) + R) / sqrt((J+1)(2J+1)).
+    Components that cannot exist at this ell (|sum spin| > ell, or a regularity walk that leaves ell >= 0)
+    are zero."""
+    from itertools import product
+    L = int(ell)
+    cache = {}
+
+    def forbidden_spin(spin):
+        return L < abs(sum(spin))
+
+    def forbidden_reg(reg):
+        if L >= len(reg):
+            return False
+        walk = [L]
+        for r in reg[::-1]:
+            walk.append(walk[-1] + r)
+            if walk[-1] < 0 or (walk[-1] == 0 and walk[-2] == 0):
+                return True
+        return False
+
+    def kfun(mu, s):
+        return -mu * np.sqrt((L - s * mu) * (L + s * mu + 1) / 2)
+
+    def q(spin, reg):
+        key = (spin, reg)
+        if key in cache:
+            return cache[key]
+        if len(spin) == 0:
+            val = 1.0
+        elif forbidden_spin(spin) or forbidden_reg(reg):
+            val = 0.0
+        else:
+            sigma, a = spin[0], reg[0]
+            tau, b = spin[1:], reg[1:]
+            R = 0.0
+            for i, t in enumerate(tau):
+                if t + sigma == 0:
+                    R -= q(tau[:i] + (0,) + tau[i + 1:], b)
+                if t == 0:
+                    R += q(tau[:i] + (sigma,) + tau[i + 1:], b)
+            Q0 = q(tau, b)
+            R -= kfun(sigma, sum(tau)) * Q0
+            J = L + sum(b)
+            Qs = Q0 if sigma == 0 else 0.0
+            if a == -1:
+                val = (Qs * J - R) / np.sqrt(J * (2 * J + 1))
+            elif a == 0:
+                val = sigma * R / np.sqrt(J * (J + 1))
+            else:
+                val = (Qs * (J + 1) + R) / np.sqrt((J + 1) * (2 * J + 1))
+        cache[key] = val
+        return val
+
+    idx = list(product(*(rank * (tuple(indexing),))))
+    out = np.zeros((len(idx), len(idx)))
+    for i, spin in enumerate(idx):
+        for j, reg in enumerate(idx):
+            out[i, j] = q(spin, reg)
+    return out

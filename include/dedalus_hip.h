@@ -115,6 +115,20 @@ int ddh_grouped_mmt_forward(ddh_handle plan, const double *g, double *c, long n0
 int ddh_grouped_mmt_backward(ddh_handle plan, const double *c, double *g, long n0, long n1g, long n1c, long n2c,
                              long n3, void *stream);
 
+/* ---- regularity recombination of shell / ball tensor fields ------------------
+ * In place on data[ncomp][n1][n2][n3] (tensor components, m slots, ell slots, radius): the components of
+ * every slot (i1, i2) with k = slot_map_d[i1*n2 + i2] >= 0 are multiplied by the 3^rank x 3^rank matrix
+ * mats_d[k] (row major), replacing the per-ell Python loop of forward/backward_regularity_recombination
+ * (core/basis.py:3595-3626).  The host composes mats from the intertwiners Q(ell): Q(ell)^T forward,
+ * Q(ell) backward, and -- because the reference's ell_maps are bounding-box slices that may overlap --
+ * the ordered product of the matrices of all entries that cover a slot
+ * (dedalus_amd/core/curvilinear.py::recombination_tables).
+ * radial_factor_d (nullable, length n3) multiplies every point: the (dR/r)^(-+k) factor of
+ * ShellBasis.forward/backward_transform_radius (core/basis.py:4474-4508).
+ * The radial transform itself is the Jacobi transform of row a8 (ddh_cheb_* / ddh_mmt_apply).           */
+int ddh_regularity_recombine(double *data, int ncomp, long n1, long n2, long n3, const int *slot_map_d, int nmats,
+                             const double *mats_d, const double *radial_factor_d, void *stream);
+
 /* ---- grid-space and vector kernels -------------------------------- */
 /* y[idx[i]] += vals[i] for n distinct indices (device arrays): the constant right-hand-side entries
  * (e.g. "b(z=0) = Lz", gathered into F by gather_outputs core/timesteppers.py:611-614) touch a handful of

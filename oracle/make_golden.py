@@ -152,6 +152,50 @@ def golden_swsh():
     print("wrote swsh.npz with", len(out), "arrays for", cases)
 
 
+def golden_shell():
+    """Regularity recombination + radial factor of the reference's ShellBasis (core/basis.py:3595-3626,
+    4474-4508, 3793-3795) on seeded data, tensor ranks 0, 1, 2; Q(ell) of the intertwiner."""
+    d3 = refshim.load_reference()
+    rng = np.random.default_rng(13)
+    out = {}
+    coords = d3.SphericalCoordinates("phi", "theta", "r")
+    dist = d3.Distributor(coords, dtype=np.float64)
+    for shape, k in [((8, 6, 5), 0), ((16, 10, 6), 1)]:
+        basis = d3.ShellBasis(coords, shape=shape, radii=(0.5, 1.5), dealias=(3 / 2, 3 / 2, 3 / 2), dtype=np.float64, k=k)
+        rb = basis.radial_basis
+        em = basis.ell_maps(dist)
+        tag = "%dx%dx%d_k%d" % (shape + (k,))
+        f0 = dist.Field(bases=basis)
+        fields = {0: f0, 1: dist.VectorField(coords, bases=basis), 2: dist.TensorField((coords, coords), bases=basis)}
+        cshape = f0["c"].shape                     # (m slots, ell slots, n)
+        Ng = int(np.ceil(1.5 * shape[2]))
+        out[tag + "__ellrows"] = np.array([(int(e), int(ms.start), int(ms.stop), int(ls.start), int(ls.stop))
+                                           for (e, ms, ls) in em], dtype=np.int64)
+        out[tag + "__shape12"] = np.array(cshape[:2], dtype=np.int64)
+        fac = np.asarray(rb.radial_transform_factor(1.5, 4, 1)).reshape(-1)       # (dR/r)^1 on the dealiased grid
+        out[tag + "__fac1"] = fac
+        ells = sorted({int(e[0]) for e in em})
+        for rank in (1, 2):
+            Q = rb.radial_recombinations(fields[rank].tensorsig, tuple(ells))
+            out[tag + "__Q%d" % rank] = np.array([np.nan_to_num(np.asarray(Q[l], dtype=float)) for l in range(max(ells) + 1)
+                                                  if l in Q] )
+            out[tag + "__Q%d_ells" % rank] = np.array([l for l in range(max(ells) + 1) if l in Q])
+        for rank in (0, 1, 2):
+            fld = fields[rank]
+            nc = 3 ** rank
+            data = rng.standard_normal((3,) * rank + tuple(cshape[:2]) + (Ng,))
+            axis = 2
+            fw = data.copy()
+            rb.forward_regularity_recombination(fld.tensorsig, axis, fw, ell_maps=em)
+            bw = data.copy()
+            rb.backward_regularity_recombination(fld.tensorsig, axis, bw, ell_maps=em)
+            out[tag + "__r%d__in" % rank] = data.reshape((nc,) + cshape[:2] + (Ng,))
+            out[tag + "__r%d__fwd" % rank] = fw.reshape((nc,) + cshape[:2] + (Ng,))
+            out[tag + "__r%d__bwd" % rank] = bw.reshape((nc,) + cshape[:2] + (Ng,))
+    np.savez_compressed(os.path.join(GOLD, "shell.npz"), **out)
+    print("wrote shell.npz with", len(out), "arrays")
+
+
 def golden_ivp():
     """End states of the reference itself on the shared problem scripts (tests/problems.py)."""
     d3 = refshim.load_reference()

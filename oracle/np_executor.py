@@ -196,6 +196,21 @@ class NumpyExecutor:
         s = src.reshape(P, outer, na, nb // P, inner)
         dst[...] = np.ascontiguousarray(np.transpose(s, (1, 2, 0, 3, 4))).reshape(dst.shape)
 
+    def make_recombination(self, slot_map, mats):
+        return (np.asarray(slot_map), np.asarray(mats), len(mats))
+
+    def regularity_recombine(self, data, table, radial_factor_d=None):
+        if radial_factor_d is not None:
+            data *= np.asarray(radial_factor_d).reshape(1, 1, 1, -1)
+        if table is None or data.shape[0] == 1:
+            return
+        sm, mats, _ = table
+        for i1 in range(data.shape[1]):
+            for i2 in range(data.shape[2]):
+                k = int(sm[i1, i2])
+                if k >= 0:
+                    data[:, i1, i2, :] = mats[k] @ data[:, i1, i2, :]
+
     def make_grouped_mmt(self, n_grid, groups, ms, fwd_mats, bwd_mats):
         from . import np_swsh
 

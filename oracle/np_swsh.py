@@ -32,3 +32,20 @@ def backward_reduced(cdata, gdata, groups, bwd_mats):
         idx = e0 + es * np.arange(ne)
         crm = cdata[:, c0:c0 + cnt, idx, :]
         gdata[:, g0:g0 + cnt, :, :] = np.einsum("tl,ajlx->ajtx", M, crm)
+
+
+def regularity_recombine(data, ell_maps, Q, forward, radial_factor=None):
+    """In place on data[ncomp, n1, n2, n3]: forward/backward_regularity_recombination (core/basis.py:3595-3626):
+    for every entry (ell, m slice, ell slice) of ell_maps IN ORDER, apply_matrix(Q[ell].T) (forward) or
+    apply_matrix(Q[ell]) (backward) on the flattened tensor axis of that block -- the entries are bounding boxes
+    and may overlap, a slot covered twice is transformed twice -- and the radial factor of
+    ShellBasis.forward/backward_transform_radius (:4474-4508).  ell_maps rows: (ell, m0, m1, l0, l1)."""
+    nc = data.shape[0]
+    if radial_factor is not None:
+        data *= np.asarray(radial_factor).reshape(1, 1, 1, -1)
+    if nc == 1:
+        return
+    for (ell, m0, m1, l0, l1) in ell_maps:
+        M = Q[int(ell)].T if forward else Q[int(ell)]
+        blk = data[:, m0:m1, l0:l1, :]
+        data[:, m0:m1, l0:l1, :] = np.einsum("rc,cmlx->rmlx", M, blk)
