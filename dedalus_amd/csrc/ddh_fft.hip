@@ -17,216 +17,10 @@
 #include <cmath>
 #include <cstdlib>
 
+#include "ddh_fft_dev.h"
+
 namespace ddh {
 
-enum FftKind { K_RFFT = 0, K_CHEB = 1, K_CFFT = 2 };
-enum FftMode { RFFT_FWD = 0, RFFT_BWD, CHEB_FWD, CHEB_BWD, CFFT_FWD, CFFT_BWD };
-
-constexpr int MAX_RADIX_PASSES = 16;
-constexpr int MAX_BANDS = 4;
-
-// division by a runtime constant without the ~40-instruction software divide
-struct FastDiv {
-    unsigned d, m, s;
-    __host__ void set(unsigned dd) {
-        d = dd ? dd : 1;
-        if (d == 1) { m = 0; s = 0; return; }
-        s = 0;
-        while ((1ull << s) < d) ++s;
-        m = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
-    }
-    __device__ __forceinline__ unsigned div(unsigned n) const {
-        return d == 1 ? n : (unsigned)(((unsigned long long)__umulhi(n, m) + n) >> s);
-    }
-    __device__ __forceinline__ void divmod(unsigned n, unsigned &q, unsigned &r) const {
-        q = div(n);
-        r = n - q * d;
-    }
-};
-
-struct FftDev {
-    FastDiv fdN, fdM, fdMh, fdK1, fdB, fd_nb[MAX_RADIX_PASSES], fd_ns[MAX_RADIX_PASSES];
-    int N;       // grid size = FFT length
-    int M;       // coefficient size
-    int K;       // Fourier: largest retained wavenumber
-    int nradix;
-    int radix[MAX_RADIX_PASSES];
-    const double2 *tw;     // exp(-2 pi i q / N)
-    const double2 *half;   // exp(-i pi k / (2N))
-    const double *fscale;  // Chebyshev forward scale per k (includes (-1)^k)
-    const double *bscale;  // Chebyshev backward scale per k
-    int nbands;
-    int gcd_off;           // gcd of the non-zero band offsets (independent back-substitution chains)
-    int boff[MAX_BANDS];
-    const double *bands;   // [nbands][M]
-    int B;                 // line pairs per workgroup
-    double dscale;         // RFFT_BWD: != 0 differentiates along the axis while loading (2 pi / L)
-    int spread_s, spread_c; // strided kernels: workgroup spreading over the address range (see kernel)
-    int dbg;               // timing ablations (debug): 1 skip butterfly math, 2 skip FFT passes, 4 skip unpack, 8 skip products
-    int rot;               // fused kernel: rotate the butterfly->wave assignment per workgroup
-    int twdirect;          // 1: full twiddle table in LDS (N entries) instead of the two-level table
-    int ld;                // LDS leading dimension of the FFT buffer (>= N)
-    unsigned long long *prof;   // optional phase timing (debug): [load, fft, store, count]
-};
-
-struct FftPlan : HandleBase {
-    FftDev dev;
-    int tkind;
-    void *d_tw = nullptr, *d_half = nullptr, *d_fscale = nullptr, *d_bscale = nullptr, *d_bands = nullptr;
-    ~FftPlan() override {
-        (void)hipFree(d_tw);
-        (void)hipFree(d_half);
-        (void)hipFree(d_fscale);
-        (void)hipFree(d_bscale);
-        (void)hipFree(d_bands);
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
-// complex helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
-    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
-// multiply by (sign * i)
-__device__ __forceinline__ double2 muli(double2 a, int sign) {
-    return sign > 0 ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
-}
-
-template <int R>
-__device__ __forceinline__ void butterfly(double2 *v, int sign);
-
-template <>
-__device__ __forceinline__ void butterfly<2>(double2 *v, int) {
-    double2 a = v[0], b = v[1];
-    v[0] = cadd(a, b);
-    v[1] = csub(a, b);
-}
-template <>
-__device__ __forceinline__ void butterfly<3>(double2 *v, int sign) {
-    const double s = 0.86602540378443864676372317075294;  // sqrt(3)/2
-    double2 t = cadd(v[1], v[2]);
-    double2 d = csub(v[1], v[2]);
-    double2 m = make_double2(v[0].x - 0.5 * t.x, v[0].y - 0.5 * t.y);
-    double2 r = muli(make_double2(s * d.x, s * d.y), sign);
-    v[0] = cadd(v[0], t);
-    v[1] = cadd(m, r);
-    v[2] = csub(m, r);
-}
-template <>
-__device__ __forceinline__ void butterfly<4>(double2 *v, int sign) {
-    double2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]);
-    double2 c = cadd(v[1], v[3]), d = muli(csub(v[1], v[3]), sign);
-    v[0] = cadd(a, c);
-    v[1] = cadd(b, d);
-    v[2] = csub(a, c);
-    v[3] = csub(b, d);
-}
-template <>
-__device__ __forceinline__ void butterfly<5>(double2 *v, int sign) {
-    const double c1 = 0.30901699437494742410229341718282;   // cos(2pi/5)
-    const double c2 = -0.80901699437494742410229341718282;  // cos(4pi/5)
-    const double s1 = 0.95105651629515357211643933337938;   // sin(2pi/5)
-    const double s2 = 0.58778525229247312916870595463907;   // sin(4pi/5)
-    double2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
-    double2 d1 = csub(v[1], v[4]), d2 = csub(v[2], v[3]);
-    double2 m1 = make_double2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
-    double2 m2 = make_double2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
-    double2 r1 = muli(make_double2(s1 * d1.x + s2 * d2.x, s1 * d1.y + s2 * d2.y), sign);
-    double2 r2 = muli(make_double2(s2 * d1.x - s1 * d2.x, s2 * d1.y - s1 * d2.y), sign);
-    v[0] = cadd(v[0], cadd(t1, t2));
-    v[1] = cadd(m1, r1);
-    v[4] = csub(m1, r1);
-    v[2] = cadd(m2, r2);
-    v[3] = csub(m2, r2);
-}
-template <>
-__device__ __forceinline__ void butterfly<7>(double2 *v, int sign) {
-    // direct 7-point DFT (rare size): X_u = sum_t v_t exp(sign 2 pi i t u / 7)
-    const double c[7] = {1.0, 0.62348980185873353052500488400424, -0.22252093395631440428890256449679,
-                         -0.90096886790241912623610231950745, -0.90096886790241912623610231950745,
-                         -0.22252093395631440428890256449679, 0.62348980185873353052500488400424};
-    const double s[7] = {0.0, 0.78183148246802980870844452667406, 0.97492791218182360701813168299393,
-                         0.43388373911755812047576833284836, -0.43388373911755812047576833284836,
-                         -0.97492791218182360701813168299393, -0.78183148246802980870844452667406};
-    double2 x[7];
-#pragma unroll
-    for (int t = 0; t < 7; ++t) x[t] = v[t];
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-        double2 acc = x[0];
-#pragma unroll
-        for (int t = 1; t < 7; ++t) {
-            const int q = (t * u) % 7;
-            double2 w = make_double2(c[q], sign > 0 ? s[q] : -s[q]);
-            acc = cadd(acc, cmul(x[t], w));
-        }
-        v[u] = acc;
-    }
-}
-
-__device__ __forceinline__ void dft4_inplace(double2 &v0, double2 &v1, double2 &v2, double2 &v3, int sign) {
-    const double2 a = cadd(v0, v2), b = csub(v0, v2);
-    const double2 c = cadd(v1, v3), d = muli(csub(v1, v3), sign);
-    v0 = cadd(a, c);
-    v1 = cadd(b, d);
-    v2 = csub(a, c);
-    v3 = csub(b, d);
-}
-// multiply by exp(sign * 2 pi i * q / 16), q = 0..9 (constants)
-__device__ __forceinline__ double2 mul_w16(double2 a, int q, int sign) {
-    const double c1 = 0.92387953251128675612818318939679;   // cos(pi/8)
-    const double s1 = 0.38268343236508977172845998403040;   // sin(pi/8)
-    const double r2 = 0.70710678118654752440084436210485;   // sqrt(1/2)
-    double wr, wi;
-    switch (q) {
-        case 0: return a;
-        case 1: wr = c1; wi = s1; break;
-        case 2: wr = r2; wi = r2; break;
-        case 3: wr = s1; wi = c1; break;
-        case 4: return muli(a, sign);
-        case 6: wr = -r2; wi = r2; break;
-        default: wr = -c1; wi = -s1; break;   // q == 9
-    }
-    if (sign < 0) wi = -wi;
-    return make_double2(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
-}
-template <>
-__device__ __forceinline__ void butterfly<8>(double2 *v, int sign) {
-    // n = 2 n1 + n2, k = k1 + 4 k2
-    double2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
-    double2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
-    dft4_inplace(e0, e1, e2, e3, sign);
-    dft4_inplace(o0, o1, o2, o3, sign);
-    o1 = mul_w16(o1, 2, sign);
-    o2 = mul_w16(o2, 4, sign);
-    o3 = mul_w16(o3, 6, sign);
-    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
-    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
-    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
-    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
-}
-template <>
-__device__ __forceinline__ void butterfly<16>(double2 *v, int sign) {
-    // n = 4 n1 + n2, k = k1 + 4 k2: DFT4 over n1 for each n2, twiddle W16^(n2 k1), DFT4 over n2 for each k1
-    double2 y[4][4];
-#pragma unroll
-    for (int n2 = 0; n2 < 4; ++n2) {
-        y[n2][0] = v[n2]; y[n2][1] = v[4 + n2]; y[n2][2] = v[8 + n2]; y[n2][3] = v[12 + n2];
-        dft4_inplace(y[n2][0], y[n2][1], y[n2][2], y[n2][3], sign);
-    }
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) {
-        double2 c0 = y[0][k1];
-        double2 c1 = mul_w16(y[1][k1], k1, sign);
-        double2 c2 = mul_w16(y[2][k1], 2 * k1, sign);
-        double2 c3 = mul_w16(y[3][k1], 3 * k1, sign);
-        dft4_inplace(c0, c1, c2, c3, sign);
-        v[k1] = c0; v[k1 + 4] = c1; v[k1 + 8] = c2; v[k1 + 12] = c3;
-    }
-}
 
 // LDS index padding: one extra element after every 16 (= one 256-B bank row), so that the stride-R
 // writes of the first Stockham pass (and the DCT permutation) spread over the banks.
@@ -884,21 +678,6 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
 // forward transform: core/transforms.py:537-565, core/arithmetic.py:666-674, 855-866) by one read of
 // the operands' coefficient lines and one write of the results' coefficient lines.
 // ------------------------------------------------------------------------------------------------
-constexpr int FUSED_NA = 3, FUSED_NC = 4, FUSED_NB = 12, FUSED_TERMS = 32;
-constexpr int FUSED_LOADS = FUSED_NA + FUSED_TERMS;
-constexpr int FUSED_T = 256;
-
-struct FusedArgs {
-    const double *src[FUSED_LOADS];   // line arrays in load order: the `a` operands first
-    double dscale[FUSED_LOADS];       // != 0: differentiate along the axis while unpacking (2 pi / L)
-    double *out[FUSED_NC];
-    double coef[FUSED_TERMS];
-    short tbeg[FUSED_LOADS + 1];      // terms [tbeg[l], tbeg[l+1]) multiply load l
-    short bbeg[FUSED_LOADS + 1];      // batch i transforms loads [bbeg[i], bbeg[i+1]) together
-    signed char flush[FUSED_LOADS];   // per batch: >= 0: result `flush` is complete after it
-    signed char ia[FUSED_TERMS];
-    int na, nbatch;
-};
 
 // coefficient lines (2q, 2q+1) of one operand -> Hermitian-packed spectrum of the line pair in buf
 // (contiguous-axis RFFT_BWD pre-step), optionally differentiated:
@@ -1091,6 +870,10 @@ fused_rfft_bilinear_kernel(FftDev p, FusedArgs f, long nlines, long npairs) {
     if (p.prof && tid == 0)
         for (int i = 0; i < 4; ++i) atomicAdd(&p.prof[i], (unsigned long long)pt[i]);
 }
+
+// ddh_gridwave.hip: wave-per-line variant of the fused grid stage for N = 128*C
+bool gridwave_supported(const FftDev &d);
+int launch_gridwave(const FftDev &d, const FusedArgs &f, long nlines, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1432,6 +1215,8 @@ int ddh_rfft_bilinear_fused(ddh_handle plan, int na, const double *const *a_h, c
     static const int envG = getenv("DDH_FUSED_G") ? atoi(getenv("DDH_FUSED_G")) : 0;
     int G = ((long)d.N <= 3L * T && 3L * d.N <= 12L * T) ? 3 : 1;
     if (envG == 1) G = 1;
+    const bool wave_path = gridwave_supported(d);     // one wavefront per line (ddh_gridwave.hip)
+    if (wave_path) G = 1;
     d.B = 1;
     d.fdB.set(1u);
     int order[FUSED_TERMS];
@@ -1489,6 +1274,7 @@ int ddh_rfft_bilinear_fused(ddh_handle plan, int na, const double *const *a_h, c
         if (!has_terms[i])
             DDH_HIP(hipMemsetAsync(out_h[i], 0, (size_t)nlines * d.M * sizeof(double), as_stream(stream)));
     }
+    if (wave_path) return launch_gridwave(d, f, nlines, as_stream(stream));
     const long npairs = (nlines + 1) / 2;
     if ((unsigned long)npairs > 0x7fffffffUL) return fail("rfft_bilinear_fused: grid too large");
     const size_t lds = ((size_t)d.ld * G + (size_t)tw_entries(d.N, d.twdirect)) * sizeof(double2);

@@ -174,7 +174,8 @@ def test_mmt_matches_matrix_definition(dev):
 
 
 @pytest.mark.parametrize("N,M,nlines", [(768, 512, 37), (24, 16, 10), (96, 64, 1), (1536, 1024, 6), (60, 40, 129),
-                                        (384, 256, 64)])
+                                        (384, 256, 64), (256, 170, 5), (512, 340, 9), (1024, 682, 3), (768, 640, 7),
+                                        (384, 384, 2), (768, 40, 3)])
 @pytest.mark.parametrize("na,nbs,ncs", [(3, (3, 9), (1, 3)), (1, (1,), (1,)), (2, (2, 4), (1, 2))])
 def test_fused_grid_stage(dev, N, M, nlines, na, nbs, ncs):
     """ddh_rfft_bilinear_fused == backward transforms + products + forward transform of the oracle
