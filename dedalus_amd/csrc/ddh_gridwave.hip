@@ -25,8 +25,6 @@ namespace ddh {
 
 namespace {
 
-constexpr int GW_WAVES = 4;                 // lines (wavefronts) per workgroup
-constexpr int GW_T = 64 * GW_WAVES;
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -55,16 +53,17 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ double2 conj2(double2 a) { return make_double2(a.x, -a.y); }
 
-// (cos, msin) coefficient pair of wavenumber k -> spectrum value X[k] of the unnormalised c2r transform,
-// optionally differentiated: X' = i kappa X, kappa = dscale * k
-__device__ __forceinline__ double2 coef_to_spec(double2 cs, int k, double dscale) {
-    if (k == 0) return (dscale != 0.0) ? make_double2(0.0, 0.0) : make_double2(cs.x, 0.0);
-    double2 x = make_double2(0.5 * cs.x, 0.5 * cs.y);
-    if (dscale != 0.0) {
+// (cos, msin) coefficient pair of wavenumber k -> TWICE the spectrum value X[k] of the unnormalised c2r
+// transform (X[k] = (cos + i msin) / 2 for k > 0, X[0] = cos): the factor 1/2 of every operand is folded into
+// the term coefficients on the host.  DERIV: differentiated, X' = i kappa X with kappa = dscale * k.
+template <bool DERIV, bool MAYBE_ZERO>
+__device__ __forceinline__ double2 coef_to_spec2(double2 cs, int k, double dscale) {
+    if (DERIV) {
         const double kap = dscale * (double)k;
-        x = make_double2(-kap * x.y, kap * x.x);
+        return make_double2(-kap * cs.y, kap * cs.x);
     }
-    return x;
+    if (MAYBE_ZERO && k == 0) return make_double2(2.0 * cs.x, 0.0);
+    return cs;
 }
 
 // staged coefficient pairs of one line: pair k = lane + 64 t
@@ -110,47 +109,70 @@ __device__ __forceinline__ void issue_loads(LineLoads<NT> &ld, const double *lin
     for (int t = 0; t < NT; ++t) ld.x[t] = bload16(r, 16 * lane + 1024 * t);
 }
 
-// Staged pairs -> LDS in natural order (zeros beyond the loaded range), then the spectrum pre-processing
-// for radix-8 butterfly j = lane (< NB): its inputs Z[j + NB a],
+// spectrum pre-processing for radix-8 butterfly j = lane (< NB): its inputs Z[j + NB a] (times 2),
 //   Z = (X[k] + conj X[H-k]) + i w^k (X[k] - conj X[H-k]),  w = exp(+2 pi i / N)
-template <int C, int NT>
-__device__ __forceinline__ void build_z(const LineLoads<NT> &ld, double dscale, double2 *wb, const double2 *tw,
-                                        int lane, double2 *v) {
+template <int C, int NT, bool DERIV>
+__device__ __forceinline__ void build_z_from_lds(double dscale, const double2 *wb, const double2 *tw, int lane,
+                                                 double2 *v) {
     using G = GW<C>;
     constexpr int KM = 64 * NT - 1;                                   // largest loaded wavenumber
     constexpr int ND = (KM / G::NB + 1) < 8 ? (KM / G::NB + 1) : 8;   // direct inputs: a < ND
     constexpr int AM0n = G::H - KM - (G::NB - 1);                     // mirror inputs: a >= AM0
     constexpr int AM0 = AM0n <= 0 ? 0 : (AM0n + G::NB - 1) / G::NB;
 #pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int k = lane + G::NB * a;
+        double2 xd = make_double2(0.0, 0.0), xm = xd;
+        if (a < ND) {
+            if (a == 0) xd = coef_to_spec2<DERIV, true>(wb[k], k, dscale);
+            else xd = coef_to_spec2<DERIV, false>(wb[k], k, dscale);
+        }
+        if (a >= AM0) {
+            xm = coef_to_spec2<DERIV, false>(wb[G::H - k], G::H - k, dscale);
+            if (a == 0 && k == 0) xm = make_double2(0.0, 0.0);        // X[H] is not stored (and is zero)
+        }
+        const double2 w = conj2(tw[G::T_N + k]);
+        if (a < ND && a >= AM0) {
+            const double2 A = make_double2(xd.x + xm.x, xd.y - xm.y);
+            const double2 B = make_double2(xd.x - xm.x, xd.y + xm.y);
+            const double2 wB = cmul(w, B);
+            v[a] = make_double2(A.x - wB.y, A.y + wB.x);
+        } else if (a < ND) {                                           // Z = X + i w X
+            const double2 wB = cmul(w, xd);
+            v[a] = make_double2(xd.x - wB.y, xd.y + wB.x);
+        } else if (a >= AM0) {                                         // Z = conj Xm - i w conj Xm
+            const double2 cm = make_double2(xm.x, -xm.y);
+            const double2 wB = cmul(w, cm);
+            v[a] = make_double2(cm.x + wB.y, cm.y - wB.x);
+        } else {
+            v[a] = make_double2(0.0, 0.0);
+        }
+    }
+}
+
+// Staged pairs -> LDS in natural order (zeros beyond the loaded range), then the pre-processing
+template <int C, int NT>
+__device__ __forceinline__ void build_z(const LineLoads<NT> &ld, double dscale, double2 *wb, const double2 *tw,
+                                        int lane, double2 *v) {
+    using G = GW<C>;
+#pragma unroll
     for (int t = 0; t < C; ++t) wb[lane + 64 * t] = (t < NT) ? ld.x[t] : make_double2(0.0, 0.0);
     wave_sync();
     if (lane < G::NB) {
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const int k = lane + G::NB * a;
-            double2 xd = make_double2(0.0, 0.0), xm = xd;
-            if (a < ND) xd = coef_to_spec(wb[k], k, dscale);
-            if (a >= AM0) {
-                xm = coef_to_spec(wb[G::H - k], G::H - k, dscale);
-                if (a == 0 && k == 0) xm = make_double2(0.0, 0.0);   // X[H] is not stored (and is zero)
-            }
-            const double2 A = make_double2(xd.x + xm.x, xd.y - xm.y);
-            const double2 B = make_double2(xd.x - xm.x, xd.y + xm.y);
-            const double2 w = conj2(tw[G::T_N + k]);
-            const double2 wB = cmul(w, B);
-            v[a] = make_double2(A.x - wB.y, A.y + wB.x);
-        }
+        if (dscale != 0.0) build_z_from_lds<C, NT, true>(dscale, wb, tw, lane, v);     // wave-uniform branch
+        else build_z_from_lds<C, NT, false>(dscale, wb, tw, lane, v);
     }
 }
 
 // backward transform from the pre-processed spectrum v: result g[n3] = x[2n] + i x[2n+1],
 // n = (n1 + 8 n2) + 64 n3, lane = n2 + 8 n1
 template <int C>
-__device__ __forceinline__ void backward_line(double2 *v, double2 *wb, const double2 *tw, int lane, double2 *g) {
+__device__ __forceinline__ void backward_line(double2 *v, double2 *wb, const double2 *tw, int lane, double2 *g,
+                                              int dbg) {
     using G = GW<C>;
     const int b1 = lane / C, c1 = lane - b1 * C;     // pass 1: butterfly j = lane = b*C + c; pass 2: lr = n1*C + c
     if (lane < G::NB) {
-        butterfly<8>(v, +1);
+        if (!(dbg & 1)) butterfly<8>(v, +1);
         // twiddle W64^(n1 b), then exchange 1: [b][n1*C + c]
         wb[b1 * G::S1 + c1] = v[0];
 #pragma unroll
@@ -163,7 +185,7 @@ __device__ __forceinline__ void backward_line(double2 *v, double2 *wb, const dou
     if (lane < G::NB) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) v[b] = wb[b * G::S1 + lane];
-        butterfly<8>(v, +1);
+        if (!(dbg & 1)) butterfly<8>(v, +1);
         // twiddle omega^((n1 + 8 n2) c), omega = exp(2 pi i / H); exchange 2: [c][n2 + 8 n1]
         const int n1 = b1, c = c1;
 #pragma unroll
@@ -175,16 +197,16 @@ __device__ __forceinline__ void backward_line(double2 *v, double2 *wb, const dou
     wave_sync();
 #pragma unroll
     for (int c = 0; c < C; ++c) g[c] = wb[c * G::S2 + lane];
-    butterfly<C>(g, +1);
+    if (!(dbg & 1)) butterfly<C>(g, +1);
 }
 
 // forward transform of the grid values g (same lane/register map) and store of the coefficient line
 template <int C>
 __device__ __forceinline__ void forward_line(double2 *g, double2 *wb, const double2 *tw, int lane, double *dst,
-                                             int M, int K) {
+                                             int M, int K, int dbg) {
     using G = GW<C>;
     const int n2L = lane & 7, n1L = lane >> 3;
-    butterfly<C>(g, -1);
+    if (!(dbg & 1)) butterfly<C>(g, -1);
     {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -198,7 +220,7 @@ __device__ __forceinline__ void forward_line(double2 *g, double2 *wb, const doub
     if (lane < G::NB) {
 #pragma unroll
         for (int n2 = 0; n2 < 8; ++n2) v[n2] = wb[n2 * G::S2F + lane];
-        butterfly<8>(v, -1);
+        if (!(dbg & 1)) butterfly<8>(v, -1);
         // twiddle conj W64^(n1 b); exchange 1: [n1][b*C + c]
         wb[n1 * G::S1 + c1] = v[0];
 #pragma unroll
@@ -211,7 +233,7 @@ __device__ __forceinline__ void forward_line(double2 *g, double2 *wb, const doub
     if (lane < G::NB) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = wb[q * G::S1 + lane];
-        butterfly<8>(v, -1);
+        if (!(dbg & 1)) butterfly<8>(v, -1);
 #pragma unroll
         for (int a = 0; a < 8; ++a) wb[lane + G::NB * a] = v[a];     // natural order Zf[k]
     }
@@ -236,15 +258,19 @@ __device__ __forceinline__ void forward_line(double2 *g, double2 *wb, const doub
                 out.x = 2.0 * invN * (E.x + wO.x);
                 out.y = 2.0 * invN * (E.y + wO.y);
             }
-            gstore16(dst + 2 * k, out);
+            if (!(dbg & 16)) gstore16(dst + 2 * k, out);
         }
     }
     wave_sync();
 }
 
-template <int C, int NT>
-__global__ void __launch_bounds__(GW_T, 2)
+// WAVES lines (wavefronts) per workgroup; DBG compiles the timing-ablation switches in (FftDev::dbg bits:
+// 1 no butterfly math, 4 no global loads, 16 no global stores, 32 no forward transforms)
+template <int C, int NT, int WAVES, bool DBG, int OCC>
+__global__ void __launch_bounds__(64 * WAVES, OCC)
 gridwave_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
+    constexpr int GW_T = 64 * WAVES, GW_WAVES = WAVES;
+    const int dbg = DBG ? p.dbg : 0;
     using G = GW<C>;
     extern __shared__ double2 lds[];
     double2 *tw = lds;                                   // twiddle tables (GW<C>::T_*)
@@ -294,77 +320,96 @@ gridwave_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
     const long off = line * (long)M;
     const int na = f.na, nloads = f.nbatch;              // host builds one load per batch for this kernel
 
-    double2 areg[FUSED_NA][C];
-    double2 acc[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        acc[i] = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int ia = 0; ia < FUSED_NA; ++ia) areg[ia][i] = make_double2(0.0, 0.0);
-    }
     LineLoads<NT> ld;
-    issue_loads<NT>(ld, s_src[0] + off, lane, K);
-#pragma unroll 1
-    for (int l = 0; l < nloads; ++l) {
-        // Lane-derived addresses and constants are re-derived in every iteration (a handful of integer
-        // operations) instead of being hoisted out of the loop, where they would pin ~60 registers.
+    if (!(dbg & 4)) issue_loads<NT>(ld, s_src[0] + off, lane, K);
+    else
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ld.x[t] = make_double2(1.0, 0.5);
+    // One backward transform: operand l (already staged in ld) -> grid values g; prefetches operand l + 1.
+    // Lane-derived addresses and constants are re-derived every time (a handful of integer operations)
+    // instead of being hoisted out of the loops, where they would pin ~60 registers.
+    auto backward = [&](int l, double2 *g) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         double2 v[8];
         build_z<C, NT>(ld, s_dscale[l], wb, tw, ln, v);
-        if (l + 1 < nloads) issue_loads<NT>(ld, s_src[l + 1] + off, ln, K);   // prefetch the next operand
-        double2 g[C];
-        backward_line<C>(v, wb, tw, ln, g);
-        if (l < na) {
+        if (l + 1 < nloads && !(dbg & 4)) issue_loads<NT>(ld, s_src[l + 1] + off, ln, K);
+        backward_line<C>(v, wb, tw, ln, g, dbg);
+    };
+    // the `a` operands stay in registers (twice their grid values, like every transformed operand)
+    double2 areg[FUSED_NA][C];
 #pragma unroll
-            for (int ia = 0; ia < FUSED_NA; ++ia)
-                if (l == ia) {
+    for (int ia = 0; ia < FUSED_NA; ++ia) {
+        if (ia < na) {
+            backward(ia, areg[ia]);
+        } else {
 #pragma unroll
-                    for (int i = 0; i < C; ++i) areg[ia][i] = g[i];
-                }
-            continue;
+            for (int i = 0; i < C; ++i) areg[ia][i] = make_double2(0.0, 0.0);
         }
+    }
+    double2 acc[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) acc[i] = make_double2(0.0, 0.0);
+#pragma unroll 1
+    for (int l = na; l < nloads; ++l) {
+        double2 g[C];
+        backward(l, g);
         const int t1 = s_tbeg[l + 1];
 #pragma unroll 1
         for (int t = s_tbeg[l]; t < t1; ++t) {
-            const double cf = s_coef[t];
-            const int tia = s_ia[t];
+            const double cf = s_coef[t];                 // includes the 1/4 of the two doubled operands
+            const int tia = s_ia[t];                     // wave-uniform
 #pragma unroll
-            for (int i = 0; i < C; ++i) {
-                double2 av = areg[0][i];
+            for (int ia = 0; ia < FUSED_NA; ++ia) {
+                if (tia == ia) {
 #pragma unroll
-                for (int ia = 1; ia < FUSED_NA; ++ia)
-                    if (tia == ia) av = areg[ia][i];
-                // packed even/odd samples: real parts multiply real parts, imaginary parts imaginary parts
-                acc[i].x += cf * av.x * g[i].x;
-                acc[i].y += cf * av.y * g[i].y;
+                    for (int i = 0; i < C; ++i) {
+                        // packed even/odd samples: real parts multiply real parts, imaginary parts imaginary parts
+                        acc[i].x += (cf * g[i].x) * areg[ia][i].x;
+                        acc[i].y += (cf * g[i].y) * areg[ia][i].y;
+                    }
+                }
             }
         }
         const int oc = s_flush[l];
-        if (oc >= 0) {
+        if (oc >= 0 && !(dbg & 32)) {
             int lf = lane;
             asm volatile("" : "+v"(lf));
-            forward_line<C>(acc, wb, tw, lf, s_out[oc] + off, M, K);
+            forward_line<C>(acc, wb, tw, lf, s_out[oc] + off, M, K, dbg);
 #pragma unroll
             for (int i = 0; i < C; ++i) acc[i] = make_double2(0.0, 0.0);
         }
     }
 }
 
-template <int C>
-int launch_c(const FftDev &d, const FusedArgs &f, long nlines, hipStream_t st) {
+template <int C, int WAVES, int OCC>
+int launch_cw(const FftDev &d, const FusedArgs &f_in, long nlines, hipStream_t st) {
     using G = GW<C>;
-    constexpr int NT32 = (2 * C + 2) / 3;                           // 64-pair blocks that hold M/2 = N/3 pairs (3/2 dealiasing)
-    const long nwg = (nlines + GW_WAVES - 1) / GW_WAVES;
+    constexpr int NT32 = (2 * C + 2) / 3;                  // 64-pair blocks that hold M/2 = N/3 pairs (3/2 dealiasing)
+    const long nwg = (nlines + WAVES - 1) / WAVES;
     if ((unsigned long)nwg > 0x7fffffffUL) return fail("rfft_bilinear_fused: grid too large");
-    const size_t lds = ((size_t)G::TW + (size_t)GW_WAVES * G::LDW) * sizeof(double2);
-    const dim3 grid((unsigned)nwg), block(GW_T);
-    if (d.K + 1 <= 64 * NT32)
-        hipLaunchKernelGGL((gridwave_bilinear_kernel<C, NT32>), grid, block, lds, st, d, f, nlines);
+    const size_t lds = ((size_t)G::TW + (size_t)WAVES * G::LDW) * sizeof(double2);
+    const dim3 grid((unsigned)nwg), block(64 * WAVES);
+    const bool narrow = d.K + 1 <= 64 * NT32;
+    FusedArgs f = f_in;
+    for (int t = 0; t < FUSED_TERMS; ++t) f.coef[t] *= 0.25;     // both factors of a term arrive doubled
+    if (C == 6 && d.dbg && narrow)                         // timing ablations (tools/bench_fused.py)
+        hipLaunchKernelGGL((gridwave_bilinear_kernel<C, NT32, WAVES, C == 6, OCC>), grid, block, lds, st, d, f, nlines);
+    else if (narrow)
+        hipLaunchKernelGGL((gridwave_bilinear_kernel<C, NT32, WAVES, false, OCC>), grid, block, lds, st, d, f, nlines);
     else
-        hipLaunchKernelGGL((gridwave_bilinear_kernel<C, C>), grid, block, lds, st, d, f, nlines);
+        hipLaunchKernelGGL((gridwave_bilinear_kernel<C, C, WAVES, false, OCC>), grid, block, lds, st, d, f, nlines);
     DDH_HIP(hipGetLastError());
     return 0;
+}
+
+template <int C>
+int launch_c(const FftDev &d, const FusedArgs &f, long nlines, hipStream_t st) {
+    static const int waves = getenv("DDH_GW_WAVES") ? atoi(getenv("DDH_GW_WAVES")) : 4;
+    static const int occ = getenv("DDH_GW_OCC") ? atoi(getenv("DDH_GW_OCC")) : 2;
+    if (C == 6 && occ == 3) return launch_cw<C, 4, (C == 6 ? 3 : 2)>(d, f, nlines, st);
+    if (waves == 8) return launch_cw<C, 8, 2>(d, f, nlines, st);
+    return launch_cw<C, 4, 2>(d, f, nlines, st);
 }
 
 }  // namespace

@@ -1,0 +1,45 @@
+"""Timing of the fused grid stage alone at the 3-D Rayleigh-Benard line sizes (u.grad(b), u.grad(u):
+3 + 12 operands, 4 results), for kernel experiments.  Environment knobs are read by the library:
+DDH_FFT_DBG (ablations), DDH_GW_WAVES (waves per workgroup), DDH_FUSED_OLD=1 (workgroup-per-pair kernel)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dedalus_amd.device import Device  # noqa: E402
+from dedalus_amd.executor import HipExecutor  # noqa: E402
+
+
+def main():
+    dev = Device.get()
+    t = dev.torch
+    Ny = int(os.environ.get("NXY", "512"))
+    Nz = int(os.environ.get("NZ", "256"))
+    Gx, Gy, Gz = 3 * Ny // 2, 3 * Ny // 2, 3 * Nz // 2
+    hx = HipExecutor(dev)
+    nl = (Gz // int(os.environ.get("FUSED_ZDIV", "1"))) * Gx
+    a = t.randn((3, nl, Ny), dtype=t.float64, device=dev.tdev)
+    bb = t.randn((12, nl, Ny), dtype=t.float64, device=dev.tdev)
+    oo = dev.empty((4, nl, Ny))
+    terms = [(0, j, j, 1.0) for j in range(3)] + [(1 + c, j, 3 + 3 * j + c, 1.0) for c in range(3) for j in range(3)]
+
+    def run():
+        hx.rfft_bilinear_fused(("rfft", Gy, Ny), None, [a[i] for i in range(3)], [bb[i] for i in range(12)],
+                               [oo[i] for i in range(4)], nl, terms)
+    run()
+    dev.sync()
+    e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    dev.sync()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = 19 * nl * Ny * 8
+    print("fused grid stage %d lines  dbg=%s waves=%s old=%s: %.3f ms  %.0f GB/s" % (
+        nl, os.environ.get("DDH_FFT_DBG", "0"), os.environ.get("DDH_GW_WAVES", "4"),
+        os.environ.get("DDH_FUSED_OLD", "0"), ms, nbytes / ms / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()
