@@ -25,10 +25,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-PMC_FAMILY = {   # kernel family in this file -> device kernel name prefixes in profiles/r1_pmc_traffic.json
+PMC_FAMILY = {   # kernel family in this file -> device kernel name prefixes in profiles/r1b_pmc_traffic.json
     "pencil_solve": ["solve_forward_kernel", "solve_backward_kernel"],
     "pencil_matvec": ["matvec_kernel"],
-    "rfft_bilinear_fused": ["fused_rfft_bilinear_kernel"],
+    "rfft_bilinear_fused": ["gw::gridwave_bilinear_kernel", "fused_rfft_bilinear_kernel"],
     "rfft_backward_contig": ["fft_axis_kernel<1, false"],
     "rfft_backward_strided": ["fft_axis_kernel<1, true"],
     "rfft_forward_contig": ["fft_axis_kernel<0, false"],
@@ -42,15 +42,20 @@ PMC_FAMILY = {   # kernel family in this file -> device kernel name prefixes in 
 
 def pmc_traffic(family):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes
-    (profiles/r1_pmc_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes,
+    (profiles/r1b_pmc_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes,
     full-size run; a family made of several kernels per call sums their per-launch means).
     Returns None when no measurement is on file."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1b_pmc_traffic.json")
     if not os.path.exists(path) or family not in PMC_FAMILY:
         return None
     data = json.load(open(path))
     tot = 0.0
-    for prefix in PMC_FAMILY[family]:
+    prefixes = PMC_FAMILY[family]
+    if family == "rfft_bilinear_fused":         # one of the two implementations runs
+        prefixes = [p for p in prefixes if any(k.startswith(p) for k in data)][:1]
+        if not prefixes:
+            return None
+    for prefix in prefixes:
         hits = [v for k, v in data.items() if k.startswith(prefix)]
         if not hits:
             return None
@@ -164,7 +169,7 @@ def main():
                         frac=dom[1]["gbps"] / HBM_PEAK_GBS,
                         traffic=(pmc_traffic(dom[0]) if (Nx, Ny, Nz) == (512, 512, 256) and world == 1 else None),
                         traffic_note="bytes per launch from rocprofv3 PMC passes committed under profiles/ "
-                                     "(r1_pmc_summary.txt); algorithmic bytes and time are measured live",
+                                     "(r1b_pmc_summary.txt); algorithmic bytes and time are measured live",
                         avg_launch_ms=dom[1]["avg_ms"], algorithmic_bytes_per_launch=dom[1]["bytes_per_launch"],
                         launches=dom[1]["launches"])
         total_kernel_ms = sum(v["total_ms"] for v in summ.values())

@@ -39,9 +39,12 @@ struct GW {
     static constexpr int LDW = cmax(cmax(8 * S1, C * S2), cmax(8 * S2F, H + 1));   // double2 per wave
     // twiddle tables in LDS (forward sign; every lookup is lane base + compile-time offset):
     static constexpr int T_N = 0;           // [k]          exp(-2 pi i k / N),                   k < H
-    static constexpr int T_2 = H;           // [n1*C+c][n2] exp(-2 pi i ((n1 + 8 n2) c) / H)
-    static constexpr int T_1 = 2 * H;       // [b][n1]      exp(-2 pi i n1 b / 64)
-    static constexpr int TW = 2 * H + 64;   // table entries
+    // [n2][n1*C+c] exp(-2 pi i ((n1 + 8 n2) c) / H), row stride STR: the backward reads are lane-contiguous,
+    // STR keeps the forward reads (lane = n2 + 8 n1) at most 2-way conflicting
+    static constexpr int STR = C == 2 ? 20 : C == 3 ? 28 : C == 4 ? 33 : C == 6 ? 52 : 65;
+    static constexpr int T_2 = H;
+    static constexpr int T_1 = H + 8 * STR; // [n1][b]      exp(-2 pi i n1 b / 64) (symmetric)
+    static constexpr int TW = T_1 + 64;     // table entries
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -177,7 +180,7 @@ __device__ __forceinline__ void backward_line(double2 *v, double2 *wb, const dou
         wb[b1 * G::S1 + c1] = v[0];
 #pragma unroll
         for (int n1 = 1; n1 < 8; ++n1) {
-            const double2 w = conj2(tw[G::T_1 + b1 * 8 + n1]);
+            const double2 w = conj2(tw[G::T_1 + n1 * 8 + b1]);
             wb[b1 * G::S1 + n1 * C + c1] = cmul(v[n1], w);
         }
     }
@@ -190,7 +193,7 @@ __device__ __forceinline__ void backward_line(double2 *v, double2 *wb, const dou
         const int n1 = b1, c = c1;
 #pragma unroll
         for (int n2 = 0; n2 < 8; ++n2) {
-            const double2 w = conj2(tw[G::T_2 + lane * 8 + n2]);
+            const double2 w = conj2(tw[G::T_2 + n2 * G::STR + lane]);
             wb[c * G::S2 + n2 + 8 * n1] = cmul(v[n2], w);
         }
     }
@@ -210,7 +213,7 @@ __device__ __forceinline__ void forward_line(double2 *g, double2 *wb, const doub
     {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const double2 w = tw[G::T_2 + (n1L * C + c) * 8 + n2L];
+            const double2 w = tw[G::T_2 + n2L * G::STR + n1L * C + c];
             wb[n2L * G::S2F + n1L * C + c] = (c == 0) ? g[0] : cmul(g[c], w);
         }
     }
@@ -280,11 +283,11 @@ gridwave_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
         int q;                                           // index into the plan's exp(-2 pi i q / N)
         if (i < G::H) {
             q = i;
-        } else if (i < 2 * G::H) {
-            const int r = i - G::H, lr = r >> 3, n2 = r & 7, n1 = lr / C, c = lr - n1 * C;
-            q = 2 * (((n1 + 8 * n2) * c) % G::H);
+        } else if (i < G::T_1) {
+            const int r = i - G::T_2, n2 = r / G::STR, lr = r - n2 * G::STR, n1 = lr / C, c = lr - n1 * C;
+            q = (lr < G::NB) ? 2 * (((n1 + 8 * n2) * c) % G::H) : 0;
         } else {
-            const int r = i - 2 * G::H;
+            const int r = i - G::T_1;
             q = (((r >> 3) * (r & 7)) & 63) * (2 * C);
         }
         tw[i] = p.tw[q];
@@ -412,7 +415,9 @@ int launch_c(const FftDev &d, const FusedArgs &f, long nlines, hipStream_t st) {
     return launch_cw<C, 4, 2>(d, f, nlines, st);
 }
 
-}  // namespace
+}  // namespace gw
+
+using namespace gw;
 
 bool gridwave_supported(const FftDev &d) {
     static const bool off = getenv("DDH_FUSED_OLD") != nullptr;
