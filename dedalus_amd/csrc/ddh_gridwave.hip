@@ -23,7 +23,7 @@
 
 namespace ddh {
 
-namespace {
+namespace gw {
 
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }

@@ -1,0 +1,262 @@
+// Coefficient-space kernels of the sphere path (BASELINE config 4: viscous
+// shallow water on S2), gfx950.
+//
+// Layout: a tensor field's coefficients are real arrays [component][2 m + part][ell], part 0/1 = cos/msin of
+// the azimuthal mode m (one complex number z = cos + i msin per (component, m, ell)), ell contiguous;
+// the colatitude-grid stage is [component][2 m + part][theta].
+//
+//  * ddh_spin_recombine: coordinate <-> spin components (SpinRecombinationBasis.forward/
+//    backward_spin_recombination, core/basis.py:1595-1663, libraries/spin_recombination.pyx:9-56): a fixed
+//    small real matrix on the (component, part) pairs of every (m, theta) point.
+//  * ddh_sphere_terms_*: every linear sphere operator of the reference is local in ell -- SeparableSphere
+//    operators multiply (m, ell) groups by a symbol (core/operators.py:2725-2866: grad, div, lap, average,
+//    convert), MulCosine couples ell to ell +- 1 (core/operators.py:2995-3046), SpinSkew multiplies by +-i
+//    (:2125-2147) -- so operators and their compositions are "term lists"
+//        y[co][m][ell] += coef_t[m][ell] * x[ci][m][ell + d_t]          (complex, per term t)
+//    applied by one streaming kernel over all (m, ell); this replaces the reference's per-m Python loop of
+//    scipy CSR products (Subproblem matrices, core/subsystems.py:497-596, timesteppers.py:588-591).
+//  * ddh_cgemv_batch_*: the per-m implicit solve.  The per-m systems (all variables x ell >= m) are small
+//    (<= 3 x 255 unknowns at Lmax = 254); their LHS inverses are formed once per timestep size on the host
+//    and applied as one batched complex GEMV (one wavefront per row), replacing the per-m SuperLU solves
+//    (libraries/matsolvers.py:126-149, timesteppers.py:630-643).
+#include "ddh_common.h"
+
+namespace ddh {
+
+constexpr HandleKind H_STERMS = (HandleKind)5;
+constexpr HandleKind H_CGEMV = (HandleKind)6;
+
+// ------------------------------------------------------------------------------------------------
+struct SpinMat {
+    double r[64];     // [2 nc][2 nc] row major, nc <= 4
+};
+
+template <int NC>
+__global__ void __launch_bounds__(256)
+spin_recombine_kernel(const double *__restrict__ in, double *__restrict__ out, SpinMat M, long npairs, long inner) {
+    const long total = npairs * inner;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long q = i / inner, x = i - q * inner;
+    const long cstride = 2 * npairs * inner;
+    const long base = (2 * q) * inner + x;
+    double v[2 * NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        v[2 * c] = in[c * cstride + base];
+        v[2 * c + 1] = in[c * cstride + base + inner];
+    }
+#pragma unroll
+    for (int r = 0; r < 2 * NC; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 2 * NC; ++c) acc += M.r[r * 2 * NC + c] * v[c];
+        out[(r >> 1) * cstride + base + (r & 1) * inner] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct SphereTerms : HandleBase {
+    int nm = 0, nl = 0, ncomp_out = 0, nterms = 0;
+    int *d_meta = nullptr;       // [nterms][3]: co, ci, d (sorted by co)
+    int *d_first = nullptr;      // [ncomp_out + 1] term ranges per output component
+    double2 *d_coef = nullptr;   // [nterms][nm][nl]
+    ~SphereTerms() override {
+        (void)hipFree(d_meta);
+        (void)hipFree(d_first);
+        (void)hipFree(d_coef);
+    }
+};
+
+__global__ void __launch_bounds__(256)
+sphere_terms_kernel(const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ meta,
+                    const int *__restrict__ first, const double2 *__restrict__ coef, int nm, int nl, int ncomp_out) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    if (l >= nl) return;
+    const long row = (long)nl;
+    const long cstride = 2L * nm * row;
+    for (int co = 0; co < ncomp_out; ++co) {
+        double2 acc = make_double2(0.0, 0.0);
+        for (int t = first[co]; t < first[co + 1]; ++t) {
+            const int ci = meta[3 * t + 1], d = meta[3 * t + 2];
+            const int ls = l + d;
+            if (ls < 0 || ls >= nl) continue;
+            const double2 c = coef[((long)t * nm + m) * row + l];
+            const double xr = x[ci * cstride + (2L * m) * row + ls];
+            const double xi = x[ci * cstride + (2L * m + 1) * row + ls];
+            acc.x += c.x * xr - c.y * xi;
+            acc.y += c.x * xi + c.y * xr;
+        }
+        y[co * cstride + (2L * m) * row + l] = acc.x;
+        y[co * cstride + (2L * m + 1) * row + l] = acc.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct CgemvBatch : HandleBase {
+    int nm = 0, nl = 0, ncomp = 0, max_n = 0;
+    long *d_off = nullptr;       // [nm + 1] matrix offsets (complex elements)
+    double2 *d_mats = nullptr;
+    size_t bytes = 0;
+    ~CgemvBatch() override {
+        (void)hipFree(d_off);
+        (void)hipFree(d_mats);
+    }
+};
+
+// one wavefront per row of one m; unknown j = comp * (nl - m) + (ell - m)
+__global__ void __launch_bounds__(256)
+cgemv_batch_kernel(const double *__restrict__ x, double *__restrict__ y, const long *__restrict__ off,
+                   const double2 *__restrict__ mats, int nm, int nl, int ncomp) {
+    const int m = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nell = nl - m;
+    const int n = ncomp * (nell > 0 ? nell : 0);
+    const long row = (long)nl;
+    const long cstride = 2L * nm * row;
+    if (nell <= 0) {                                  // no mode at this m: zero its slots
+        for (int idx = blockIdx.x * 256 + threadIdx.x; idx < ncomp * nl; idx += gridDim.x * 256) {
+            const int c = idx / nl, l = idx - c * nl;
+            y[c * cstride + (2L * m) * row + l] = 0.0;
+            y[c * cstride + (2L * m + 1) * row + l] = 0.0;
+        }
+        return;
+    }
+    if (j >= ncomp * nl) return;
+    if (j >= n) {
+        // slots below the diagonal (ell < m) of this m carry no mode: zero them once per (comp, ell < m)
+        const int jj = j - n;                      // 0 .. ncomp * m - 1
+        if (m > 0 && jj < ncomp * m && lane == 0) {
+            const int c = jj / m, l = jj - c * m;
+            if (l < nl) {
+                y[c * cstride + (2L * m) * row + l] = 0.0;
+                y[c * cstride + (2L * m + 1) * row + l] = 0.0;
+            }
+        }
+        return;
+    }
+    const double2 *A = mats + off[m] + (long)j * n;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int k = lane; k < n; k += 64) {
+        const int c = k / nell, l = m + (k - c * nell);
+        const double2 a = A[k];
+        const double xr = x[c * cstride + (2L * m) * row + l];
+        const double xi = x[c * cstride + (2L * m + 1) * row + l];
+        acc.x += a.x * xr - a.y * xi;
+        acc.y += a.x * xi + a.y * xr;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        acc.x += __shfl_xor(acc.x, s, 64);
+        acc.y += __shfl_xor(acc.y, s, 64);
+    }
+    if (lane == 0) {
+        const int c = j / nell, l = m + (j - c * nell);
+        y[c * cstride + (2L * m) * row + l] = acc.x;
+        y[c * cstride + (2L * m + 1) * row + l] = acc.y;
+    }
+}
+
+}  // namespace ddh
+
+using namespace ddh;
+
+extern "C" {
+
+int ddh_spin_recombine(const double *in, double *out, int ncomp, long npairs, long inner, const double *mat_h,
+                       void *stream) {
+    if (npairs <= 0 || inner <= 0) return 0;
+    if (in == out) return fail("ddh_spin_recombine: in-place unsupported");
+    if (ncomp != 1 && ncomp != 2 && ncomp != 4) return fail("ddh_spin_recombine: 1, 2 or 4 components (rank 0-2 on S2)");
+    SpinMat M;
+    memset(&M, 0, sizeof(M));
+    for (int i = 0; i < 4 * ncomp * ncomp; ++i) M.r[i] = mat_h[i];
+    const long total = npairs * inner;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipStream_t st = as_stream(stream);
+    if (ncomp == 1) hipLaunchKernelGGL(spin_recombine_kernel<1>, dim3(blocks), dim3(256), 0, st, in, out, M, npairs, inner);
+    else if (ncomp == 2) hipLaunchKernelGGL(spin_recombine_kernel<2>, dim3(blocks), dim3(256), 0, st, in, out, M, npairs, inner);
+    else hipLaunchKernelGGL(spin_recombine_kernel<4>, dim3(blocks), dim3(256), 0, st, in, out, M, npairs, inner);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_sphere_terms_create(ddh_handle *h, int nm, int nl, int ncomp_out, int nterms, const int *co_h, const int *ci_h,
+                            const int *d_h, const double *coef_h) {
+    if (nm < 1 || nl < 1 || ncomp_out < 1 || nterms < 0) return fail("sphere_terms_create: bad sizes");
+    SphereTerms *p = new SphereTerms();
+    p->kind = H_STERMS;
+    p->nm = nm; p->nl = nl; p->ncomp_out = ncomp_out; p->nterms = nterms;
+    std::vector<int> meta(3 * (size_t)(nterms > 0 ? nterms : 1)), first(ncomp_out + 1, 0);
+    for (int t = 0; t < nterms; ++t) {
+        if (co_h[t] < 0 || co_h[t] >= ncomp_out || (t > 0 && co_h[t] < co_h[t - 1])) {
+            delete p;
+            return fail("sphere_terms_create: terms must be sorted by output component");
+        }
+        meta[3 * t] = co_h[t]; meta[3 * t + 1] = ci_h[t]; meta[3 * t + 2] = d_h[t];
+        first[co_h[t] + 1] = t + 1;
+    }
+    for (int c = 0; c < ncomp_out; ++c)
+        if (first[c + 1] < first[c]) first[c + 1] = first[c];
+    const size_t cb = (size_t)(nterms > 0 ? nterms : 1) * nm * nl * sizeof(double2);
+    if (check_hip(hipMalloc((void **)&p->d_meta, meta.size() * sizeof(int)), "hipMalloc") ||
+        check_hip(hipMalloc((void **)&p->d_first, first.size() * sizeof(int)), "hipMalloc") ||
+        check_hip(hipMalloc((void **)&p->d_coef, cb), "hipMalloc") ||
+        check_hip(hipMemcpy(p->d_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy") ||
+        check_hip(hipMemcpy(p->d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy") ||
+        (nterms > 0 && check_hip(hipMemcpy(p->d_coef, coef_h, cb, hipMemcpyHostToDevice), "hipMemcpy"))) {
+        delete p;
+        return -2;
+    }
+    *h = register_handle(p);
+    return 0;
+}
+
+int ddh_sphere_terms_apply(ddh_handle h, const double *x, double *y, void *stream) {
+    SphereTerms *p = (SphereTerms *)lookup_handle(h, H_STERMS);
+    if (!p) return -1;
+    if (x == y) return fail("sphere_terms_apply: in-place unsupported");
+    const dim3 grid((unsigned)((p->nl + 255) / 256), (unsigned)p->nm), block(256);
+    hipLaunchKernelGGL(sphere_terms_kernel, grid, block, 0, as_stream(stream), x, y, p->d_meta, p->d_first, p->d_coef,
+                       p->nm, p->nl, p->ncomp_out);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_cgemv_batch_create(ddh_handle *h, int nm, int nl, int ncomp, const double *mats_h) {
+    if (nm < 1 || nl < 1 || ncomp < 1) return fail("cgemv_batch_create: bad sizes");
+    CgemvBatch *p = new CgemvBatch();
+    p->kind = H_CGEMV;
+    p->nm = nm; p->nl = nl; p->ncomp = ncomp;
+    std::vector<long> off(nm + 1, 0);
+    for (int m = 0; m < nm; ++m) {
+        const long n = (long)ncomp * (nl - m > 0 ? nl - m : 0);
+        off[m + 1] = off[m] + n * n;
+    }
+    p->max_n = ncomp * nl;
+    p->bytes = (size_t)off[nm] * sizeof(double2);
+    if (check_hip(hipMalloc((void **)&p->d_off, off.size() * sizeof(long)), "hipMalloc") ||
+        check_hip(hipMalloc((void **)&p->d_mats, p->bytes ? p->bytes : 16), "hipMalloc") ||
+        check_hip(hipMemcpy(p->d_off, off.data(), off.size() * sizeof(long), hipMemcpyHostToDevice), "hipMemcpy") ||
+        (p->bytes && check_hip(hipMemcpy(p->d_mats, mats_h, p->bytes, hipMemcpyHostToDevice), "hipMemcpy"))) {
+        delete p;
+        return -2;
+    }
+    *h = register_handle(p);
+    return 0;
+}
+
+int ddh_cgemv_batch_apply(ddh_handle h, const double *x, double *y, void *stream) {
+    CgemvBatch *p = (CgemvBatch *)lookup_handle(h, H_CGEMV);
+    if (!p) return -1;
+    if (x == y) return fail("cgemv_batch_apply: in-place unsupported");
+    const dim3 grid((unsigned)((p->max_n + 3) / 4), (unsigned)p->nm), block(256);
+    hipLaunchKernelGGL(cgemv_batch_kernel, grid, block, 0, as_stream(stream), x, y, p->d_off, p->d_mats, p->nm, p->nl,
+                       p->ncomp);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -199,6 +199,21 @@ class HipExecutor:
     def make_grouped_mmt(self, n_grid, groups, ms, fwd_mats, bwd_mats):
         return GroupedMmt(self, n_grid, groups, ms, fwd_mats, bwd_mats)
 
+    # ---- sphere coefficient-space kernels (csrc/ddh_sphere.hip) -----------------------------------------------
+    def spin_recombine(self, src, dst, mat):
+        """dst[(c', p')] = sum mat[(c', p'), (c, p)] src[(c, p)] on [ncomp][2 m + p][inner] arrays."""
+        nc, n2, inner = [int(x) for x in src.shape]
+        m = np.ascontiguousarray(mat, dtype=np.float64)
+        libhip.call("ddh_spin_recombine", ptr(src), ptr(dst), nc, n2 // 2, inner, libhip.as_dp(m), self.dev.stream)
+
+    def make_sphere_terms(self, nm, nl, ncomp_out, terms):
+        """terms: list of (co, ci, d, coef complex [nm][nl]) -> device term list (ddh_sphere_terms_create)."""
+        return SphereTerms(self, nm, nl, ncomp_out, terms)
+
+    def make_cgemv_batch(self, nm, nl, ncomp, mats):
+        """mats: per m a complex (n_m, n_m) array, n_m = ncomp * max(nl - m, 0)."""
+        return CgemvBatch(self, nm, nl, ncomp, mats)
+
     def make_pack(self, nf, nrows, nx, ny, kx, ky, mx_offset=0):
         pk = PencilPack(self.dev, nf, nrows, nx, ny, kx, ky, mx_offset)
         pk.executor = self
@@ -238,6 +253,50 @@ class GroupedMmt:
 
     def backward(self, c, g):
         libhip.call("ddh_grouped_mmt_backward", self.handle, ptr(c), ptr(g), *self._dims(g, c), self.ex.dev.stream)
+
+
+class SphereTerms:
+    def __init__(self, ex, nm, nl, ncomp_out, terms):
+        self.ex = ex
+        terms = sorted(terms, key=lambda t: t[0])
+        co = np.ascontiguousarray([t[0] for t in terms], dtype=np.int32)
+        ci = np.ascontiguousarray([t[1] for t in terms], dtype=np.int32)
+        d = np.ascontiguousarray([t[2] for t in terms], dtype=np.int32)
+        coef = np.zeros((max(len(terms), 1), nm, nl), dtype=np.complex128)
+        for i, t in enumerate(terms):
+            coef[i] = t[3]
+        self.handle = C.c_uint64(0)
+        libhip.call("ddh_sphere_terms_create", C.byref(self.handle), int(nm), int(nl), int(ncomp_out), len(terms),
+                    libhip.as_ip(co), libhip.as_ip(ci), libhip.as_ip(d), libhip.as_dp(coef.view(np.float64)))
+
+    def apply(self, x, y):
+        libhip.call("ddh_sphere_terms_apply", self.handle, ptr(x), ptr(y), self.ex.dev.stream)
+
+    def __del__(self):
+        try:
+            libhip.call("ddh_destroy", self.handle)
+        except Exception:
+            pass
+
+
+class CgemvBatch:
+    def __init__(self, ex, nm, nl, ncomp, mats):
+        self.ex = ex
+        flat = np.concatenate([np.ascontiguousarray(a, dtype=np.complex128).ravel() for a in mats] +
+                              [np.zeros(0, dtype=np.complex128)])
+        self.nbytes = flat.nbytes
+        self.handle = C.c_uint64(0)
+        libhip.call("ddh_cgemv_batch_create", C.byref(self.handle), int(nm), int(nl), int(ncomp),
+                    libhip.as_dp(flat.view(np.float64)) if flat.size else None)
+
+    def apply(self, x, y):
+        libhip.call("ddh_cgemv_batch_apply", self.handle, ptr(x), ptr(y), self.ex.dev.stream)
+
+    def __del__(self):
+        try:
+            libhip.call("ddh_destroy", self.handle)
+        except Exception:
+            pass
 
 
 class KernelTimer:

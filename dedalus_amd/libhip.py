@@ -54,6 +54,11 @@ SIGNATURES = {
     "ddh_grouped_mmt_forward": [_h, _vp, _vp, _l, _l, _l, _l, _l, _vp],
     "ddh_grouped_mmt_backward": [_h, _vp, _vp, _l, _l, _l, _l, _l, _vp],
     "ddh_regularity_recombine": [_vp, _i, _l, _l, _l, _vp, _i, _vp, _vp, _vp],
+    "ddh_spin_recombine": [_vp, _vp, _i, _l, _l, _dp, _vp],
+    "ddh_sphere_terms_create": [_hp, _i, _i, _i, _i, _ip, _ip, _ip, _dp],
+    "ddh_sphere_terms_apply": [_h, _vp, _vp, _vp],
+    "ddh_cgemv_batch_create": [_hp, _i, _i, _i, _dp],
+    "ddh_cgemv_batch_apply": [_h, _vp, _vp, _vp],
     "ddh_rfft_forward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward_deriv": [_h, _vp, _vp, _l, _l, _d, _vp],

@@ -13,3 +13,48 @@ from .core.problems import IVP, LBVP, InitialValueProblem, LinearBoundaryValuePr
 from .core.timesteppers import (schemes, CNAB1, SBDF1, CNAB2, MCNAB2, SBDF2, CNLF2, SBDF3, SBDF4,
                                 RK111, RK222, RK443, RKSMR, RKGFY)
 from .extras.flow_tools import CFL, GlobalFlowProperty
+
+
+# ---- the sphere (core/sphere.py): same names, dispatched on the coordinate system / operand type -----------------
+from .core import sphere as _sphere
+from .core.sphere import S2Coordinates, SphereBasis
+
+_CartesianDistributor = Distributor
+
+
+def Distributor(coordsystems, *args, **kw):
+    if isinstance(coordsystems, S2Coordinates):
+        return _sphere.SphereDistributor(coordsystems, *args, **kw)
+    return _CartesianDistributor(coordsystems, *args, **kw)
+
+
+def _dispatch(name, cart):
+    sph = getattr(_sphere, name)
+
+    def f(operand, *args, **kw):
+        if isinstance(operand, _sphere.SOperand):
+            return sph(operand, *args, **kw)
+        return cart(operand, *args, **kw)
+    f.__name__ = name
+    return f
+
+
+grad, div, lap, skew, ave, dt = (_dispatch(n, c) for n, c in (("grad", grad), ("div", div), ("lap", lap),
+                                                               ("skew", skew), ("ave", ave), ("dt", dt)))
+MulCosine = _sphere.MulCosine
+_CartesianIVP, _CartesianLBVP = IVP, LBVP
+
+
+def IVP(variables, *args, **kw):
+    if isinstance(variables[0], _sphere.SOperand):
+        return _sphere.SphereIVP(variables, *args, **kw)
+    return _CartesianIVP(variables, *args, **kw)
+
+
+def LBVP(variables, *args, **kw):
+    if isinstance(variables[0], _sphere.SOperand):
+        return _sphere.SphereLBVP(variables, *args, **kw)
+    return _CartesianLBVP(variables, *args, **kw)
+
+
+InitialValueProblem, LinearBoundaryValueProblem = IVP, LBVP

@@ -129,6 +129,29 @@ int ddh_grouped_mmt_backward(ddh_handle plan, const double *c, double *g, long n
 int ddh_regularity_recombine(double *data, int ncomp, long n1, long n2, long n3, const int *slot_map_d, int nmats,
                              const double *mats_d, const double *radial_factor_d, void *stream);
 
+/* ---- sphere coefficient-space kernels (csrc/ddh_sphere.hip) -------------------
+ * Tensor fields on S2 are stored as real arrays [component][2 m + part][n] with part 0/1 = cos/msin of the
+ * azimuthal mode m (the reference's real-dtype azimuth layout, core/basis.py:1595-1663), n = ell
+ * (coefficient space) or theta (colatitude grid).
+ * ddh_spin_recombine: out[(c', p')] = sum mat[(c', p'), (c, p)] in[(c, p)] at every (m, n): coordinate <-> spin
+ * components, mat_h = spin_recombination_matrix (core/basis.py:1576-1593), [2 ncomp][2 ncomp] row major.    */
+int ddh_spin_recombine(const double *in, double *out, int ncomp, long npairs, long inner, const double *mat_h,
+                       void *stream);
+/* Linear sphere operators as ell-local term lists: y[co][m][ell] = sum_t coef_t[m][ell] * x[ci_t][m][ell + d_t]
+ * (complex numbers cos + i msin).  Covers the SeparableSphereOperator symbols (core/operators.py:2725-2866;
+ * grad/div/lap/average/convert symbols core/basis.py:3279-3420, 5296-5320), MulCosine (:2995-3046), SpinSkew
+ * (:2125-2147) and their compositions; replaces the per-m CSR products of the subproblem matrices
+ * (core/subsystems.py:497-596; timesteppers.py:588-591).  Terms sorted by co; coef_h complex
+ * [nterms][nm][nl] (re, im interleaved).                                                              */
+int ddh_sphere_terms_create(ddh_handle *h, int nm, int nl, int ncomp_out, int nterms, const int *co_h, const int *ci_h,
+                            const int *d_h, const double *coef_h);
+int ddh_sphere_terms_apply(ddh_handle h, const double *x, double *y, void *stream);
+/* Per-m dense complex systems, unknown j = comp * (nl - m) + (ell - m): y_m = A_m x_m for all m in one launch
+ * (the LHS inverses of the per-m subproblems; replaces the per-m SuperLU solves, libraries/matsolvers.py:
+ * 126-149 / timesteppers.py:630-643).  mats_h: the nm row-major complex matrices concatenated.          */
+int ddh_cgemv_batch_create(ddh_handle *h, int nm, int nl, int ncomp, const double *mats_h);
+int ddh_cgemv_batch_apply(ddh_handle h, const double *x, double *y, void *stream);
+
 /* ---- grid-space and vector kernels -------------------------------- */
 /* y[idx[i]] += vals[i] for n distinct indices (device arrays): the constant right-hand-side entries
  * (e.g. "b(z=0) = Lz", gathered into F by gather_outputs core/timesteppers.py:611-614) touch a handful of

@@ -216,6 +216,38 @@ def golden_ivp():
     print("wrote ivp.npz")
 
 
+def golden_sphere():
+    """The reference's sphere operators and shallow-water example on the shared scripts (tests/problems.py):
+    operator results for seeded fields, the packed coefficient layout maps, and the end state of the
+    shallow-water IVP (LBVP-balanced initial height, 5 RK222 steps) at 32 x 16."""
+    d3 = refshim.load_reference()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import problems
+    out = {}
+    for (Nphi, Ntheta) in ((16, 12), (8, 8), (32, 16)):
+        tag = "ops_%dx%d__" % (Nphi, Ntheta)
+        res = problems.sphere_operator_results(d3, Nphi=Nphi, Ntheta=Ntheta)
+        for k, v in res.items():
+            out[tag + k] = v
+        coords = d3.S2Coordinates('phi', 'theta')
+        basis = d3.SphereBasis(coords, (Nphi, Ntheta), radius=1.3, dealias=3 / 2, dtype=np.float64)
+        cshape = basis.global_shape((False, False), (1, 1))
+        el = np.indices(cshape)
+        m, ell = basis.elements_to_groups((False, False), el)
+        out[tag + "map_m"], out[tag + "map_ell"] = m, ell
+        out[tag + "valid0"] = basis.valid_elements((), (False, False), el)
+        out[tag + "valid1"] = basis.valid_elements((coords,), (False, False), el)
+        out[tag + "valid2"] = basis.valid_elements((coords, coords), (False, False), el)
+        print(tag, {k: float(np.linalg.norm(v)) for k, v in list(res.items())[:6]})
+    for ts in ("RK222", "SBDF2"):
+        solver, res = problems.run_shallow_water(d3, steps=5, Nphi=32, Ntheta=16, timestepper=ts)
+        for k, v in res.items():
+            out["sw_%s__%s" % (ts, k)] = v
+        print("shallow water", ts, {k: float(np.linalg.norm(v)) for k, v in res.items()})
+    np.savez_compressed(os.path.join(GOLD, "sphere.npz"), **out)
+    print("wrote sphere.npz with", len(out), "arrays")
+
+
 def golden_timesteppers():
     """Multistep coefficients of the reference for random step sequences (timesteppers.py:190-495)."""
     refshim.load_reference()

@@ -211,6 +211,49 @@ class NumpyExecutor:
                 if k >= 0:
                     data[:, i1, i2, :] = mats[k] @ data[:, i1, i2, :]
 
+    # ---- sphere coefficient-space operations (restating csrc/ddh_sphere.hip; the reference equivalents are
+    # SpinRecombinationBasis.forward/backward_spin_recombination core/basis.py:1595-1663, the per-m subproblem
+    # matrix products core/subsystems.py:497-596 and the per-m LHS solves libraries/matsolvers.py:126-149)
+    def spin_recombine(self, src, dst, mat):
+        nc, n2, inner = src.shape
+        v = src.reshape(nc, n2 // 2, 2, inner).transpose(0, 2, 1, 3).reshape(2 * nc, n2 // 2, inner)
+        r = np.einsum("rc,cqx->rqx", np.asarray(mat), v)
+        dst[...] = r.reshape(nc, 2, n2 // 2, inner).transpose(0, 2, 1, 3).reshape(nc, n2, inner)
+
+    def make_sphere_terms(self, nm, nl, ncomp_out, terms):
+        class _Terms:
+            def apply(self_, x, y):
+                z = x[:, 0::2, :] + 1j * x[:, 1::2, :]
+                out = np.zeros((ncomp_out, nm, nl), dtype=complex)
+                for (co, ci, d, coef) in terms:
+                    sh = np.zeros((nm, nl), dtype=complex)
+                    if d >= 0:
+                        sh[:, :nl - d] = z[ci][:, d:]
+                    else:
+                        sh[:, -d:] = z[ci][:, :nl + d]
+                    out[co] += coef * sh
+                y[:, 0::2, :] = out.real
+                y[:, 1::2, :] = out.imag
+        return _Terms()
+
+    def make_cgemv_batch(self, nm, nl, ncomp, mats):
+        mats = [np.asarray(a, dtype=complex) for a in mats]
+
+        class _Batch:
+            nbytes = sum(a.nbytes for a in mats)
+
+            def apply(self_, x, y):
+                y[...] = 0.0
+                for m in range(nm):
+                    ne = nl - m
+                    if ne <= 0:
+                        continue
+                    z = (x[:, 2 * m, m:] + 1j * x[:, 2 * m + 1, m:]).reshape(-1)
+                    r = (mats[m] @ z).reshape(ncomp, ne)
+                    y[:, 2 * m, m:] = r.real
+                    y[:, 2 * m + 1, m:] = r.imag
+        return _Batch()
+
     def make_grouped_mmt(self, n_grid, groups, ms, fwd_mats, bwd_mats):
         from . import np_swsh
 

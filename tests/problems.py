@@ -143,3 +143,112 @@ def run_cfl_case(d3, dist_kw=None, nsteps=45):
         solver.step(dt)
         dts.append(dt)
     return solver, np.array(dts), {k: np.array(v['c']) for k, v in f.items()}
+
+
+# ---- sphere (BASELINE config 4) ------------------------------------------------
+
+def sphere_operator_cases(d3, Nphi=16, Ntheta=12, radius=1.3, seed=5, dist_kw=None):
+    """Fields and operator results on the sphere for seeded grid data (the operator set of the reference's
+    shallow-water example, examples/ivp_sphere_shallow_water/shallow_water.py).  Returns dict name -> operand."""
+    dealias = 3 / 2
+    coords = d3.S2Coordinates('phi', 'theta')
+    dist = d3.Distributor(coords, dtype=np.float64, **(dist_kw or {}))
+    basis = d3.SphereBasis(coords, (Nphi, Ntheta), radius=radius, dealias=dealias, dtype=np.float64)
+    u = dist.VectorField(coords, name='u', bases=basis)
+    h = dist.Field(name='h', bases=basis)
+    phi, theta = dist.local_grids(basis)
+    rng = np.random.default_rng(seed)
+    # band-limited smooth data: combinations of low-order harmonics in grid space
+    x, y, z = np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta) + 0 * phi
+    a = rng.standard_normal(10)
+    h['g'] = a[0] + a[1] * x + a[2] * y + a[3] * z + a[4] * x * y + a[5] * y * z + a[6] * z * z + a[7] * x * x * z
+    psi = dist.Field(name='psi', bases=basis)
+    chi = dist.Field(name='chi', bases=basis)
+    b = rng.standard_normal(10)
+    psi['g'] = b[0] * x + b[1] * z + b[2] * x * z + b[3] * y * y + b[4] * x * y * z
+    chi['g'] = b[5] * y + b[6] * z * z + b[7] * x * y + b[8] * x * z * z
+    u0 = (d3.grad(psi) + d3.skew(d3.grad(chi))).evaluate()
+    u0.change_scales(1)
+    u['g'] = u0['g']
+    zcross = lambda A: d3.MulCosine(d3.skew(A))
+    exprs = dict(
+        grad_h=d3.grad(h), lap_h=d3.lap(h), laplap_h=d3.lap(d3.lap(h)), mulcos_h=d3.MulCosine(h),
+        div_u=d3.div(u), lap_u=d3.lap(u), laplap_u=d3.lap(d3.lap(u)), skew_u=d3.skew(u), zcross_u=zcross(u),
+        grad_u=d3.grad(u), u_grad_u=u @ d3.grad(u), hu=h * u, div_hu=d3.div(h * u),
+        vort=-d3.div(d3.skew(u)), rhs_lbvp=-d3.div(u @ d3.grad(u) + 2 * 0.7 * zcross(u)),
+    )
+    return dist, basis, dict(u=u, h=h), exprs
+
+
+def sphere_operator_results(d3, **kw):
+    dist, basis, fields, exprs = sphere_operator_cases(d3, **kw)
+    res = {}
+    for k, f in fields.items():
+        f.change_scales(1)
+        res[k + "__g"] = np.array(f['g'])
+        res[k + "__c"] = np.array(f['c'])
+    for k, e in exprs.items():
+        f = e.evaluate()
+        f.change_scales(1)
+        res[k + "__g"] = np.array(f['g'])
+        res[k + "__c"] = np.array(f['c'])
+    return res
+
+
+def shallow_water(d3, Nphi=32, Ntheta=16, timestepper="RK222", dist_kw=None):
+    """The reference's example examples/ivp_sphere_shallow_water/shallow_water.py:24-92 (Galewsky et al. jet:
+    balanced height from an LBVP, perturbation, IVP), parameterised by resolution only."""
+    meter = 1 / 6.37122e6
+    hour = 1
+    second = hour / 3600
+    dealias = 3 / 2
+    R = 6.37122e6 * meter
+    Omega = 7.292e-5 / second
+    nu = 1e5 * meter ** 2 / second / 32 ** 2
+    g = 9.80616 * meter / second ** 2
+    H = 1e4 * meter
+    dtype = np.float64
+    coords = d3.S2Coordinates('phi', 'theta')
+    dist = d3.Distributor(coords, dtype=dtype, **(dist_kw or {}))
+    basis = d3.SphereBasis(coords, (Nphi, Ntheta), radius=R, dealias=dealias, dtype=dtype)
+    u = dist.VectorField(coords, name='u', bases=basis)
+    h = dist.Field(name='h', bases=basis)
+    zcross = lambda A: d3.MulCosine(d3.skew(A))
+    phi, theta = dist.local_grids(basis)
+    lat = np.pi / 2 - theta + 0 * phi
+    umax = 80 * meter / second
+    lat0 = np.pi / 7
+    lat1 = np.pi / 2 - lat0
+    en = np.exp(-4 / (lat1 - lat0) ** 2)
+    jet = (lat0 <= lat) * (lat <= lat1)
+    u_jet = umax / en * np.exp(1 / (lat[jet] - lat0) / (lat[jet] - lat1))
+    u['g'][0][jet] = u_jet
+    c = dist.Field(name='c')
+    problem = d3.LBVP([h, c], namespace=locals())
+    problem.add_equation("g*lap(h) + c = - div(u@grad(u) + 2*Omega*zcross(u))")
+    problem.add_equation("ave(h) = 0")
+    solver = problem.build_solver()
+    solver.solve()
+    h_balanced = np.array(h['g'])
+    lat2 = np.pi / 4
+    hpert = 120 * meter
+    alpha = 1 / 3
+    beta = 1 / 15
+    h['g'] += hpert * np.cos(lat) * np.exp(-(phi / alpha) ** 2) * np.exp(-((lat2 - lat) / beta) ** 2)
+    problem = d3.IVP([u, h], namespace=locals())
+    problem.add_equation("dt(u) + nu*lap(lap(u)) + g*grad(h) + 2*Omega*zcross(u) = - u@grad(u)")
+    problem.add_equation("dt(h) + nu*lap(lap(h)) + H*div(u) = - div(h*u)")
+    solver = problem.build_solver(getattr(d3, timestepper))
+    return solver, dict(u=u, h=h), dict(h_balanced=h_balanced, timestep=600 * second)
+
+
+def run_shallow_water(d3, steps=5, **kw):
+    solver, fields, extra = shallow_water(d3, **kw)
+    for _ in range(steps):
+        solver.step(extra["timestep"])
+    res = dict(h_balanced=extra["h_balanced"])
+    for k, f in fields.items():
+        f.change_scales(1)
+        res[k + "__g"] = np.array(f['g'])
+        res[k + "__c"] = np.array(f['c'])
+    return solver, res
