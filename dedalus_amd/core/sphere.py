@@ -25,7 +25,9 @@ What the reference does (file:line under /root/reference/dedalus) and what happe
   ddh_cgemv_batch_apply; the IMEX schemes are the shared ones of core/timesteppers.py.
 """
 
+import logging
 import numbers
+import time as _time
 
 import numpy as np
 
@@ -33,6 +35,8 @@ from ..tools import jacobi
 from ..tools import sphere as sph
 from .coords import Coordinate
 
+
+logger = logging.getLogger(__name__)
 
 # ==================================================================================================
 # coordinates, basis, distributor
@@ -182,15 +186,27 @@ class SphereBasis:
         return self._plans[key]
 
     # ---- device transform plans -----------------------------------------------------------------------------------
-    def colatitude_plan(self, ex, Ntheta_g, s):
-        key = ("swsh", id(ex), Ntheta_g, s)
+    def colatitude_plan(self, ex, Ntheta_g, rank):
+        """One grouped-GEMV plan for ALL spin components of a rank-`rank` tensor: the component axis is folded into
+        the m axis of the reduced views ([1][ncomp * 2 nm][n][1]), every (component, m) is one group with the
+        matrix pair of (m, spin weight of the component).  The reference transforms component by component
+        (core/basis.py:3119-3122, 3145-3148); one launch per field streams all matrices at once."""
+        key = ("swsh", id(ex), Ntheta_g, rank)
         if key not in self._plans:
-            groups = np.array([(m, 2 * m, 2 * m, 2, m, 1, max(self.Lmax + 1 - m, 0)) for m in range(self.nm)],
-                              dtype=np.int64)
-            ms = [m for m in range(self.nm) if m <= self.Lmax]
-            mats = {m: sph.swsh_matrices(Ntheta_g, self.Lmax, m, s) for m in ms}
-            self._plans[key] = ex.make_grouped_mmt(Ntheta_g, groups, ms, [mats[m][0] for m in ms],
-                                                   [mats[m][1] for m in ms])
+            spins = self.spin_totals(rank)
+            groups, keys, fwd, bwd = [], [], [], []
+            cache = {}
+            for i, s in enumerate(spins):
+                for m in range(self.nm):
+                    mk = m + 4096 * (s + 8)                    # matrix key of (m, s)
+                    ne = max(self.Lmax + 1 - m, 0)
+                    groups.append((mk if ne > 0 else -1 - m, i * 2 * self.nm + 2 * m, i * 2 * self.nm + 2 * m, 2, m, 1, ne))
+                    if ne > 0 and mk not in cache:
+                        cache[mk] = sph.swsh_matrices(Ntheta_g, self.Lmax, m, s)
+                        keys.append(mk)
+                        fwd.append(cache[mk][0])
+                        bwd.append(cache[mk][1])
+            self._plans[key] = ex.make_grouped_mmt(Ntheta_g, np.array(groups, dtype=np.int64), keys, fwd, bwd)
         return self._plans[key]
 
     def recombination_matrix(self, rank, forward):
@@ -466,9 +482,8 @@ def _backward(dist, basis, rank, c, scales):
     nc = 2 ** rank
     Np, Nt = basis.grid_shape(scales)
     t1 = ex.empty((nc, 2 * basis.nm, Nt))
-    for i, s in enumerate(basis.spin_totals(rank)):
-        plan = basis.colatitude_plan(ex, Nt, s)
-        plan.backward(c[i].reshape(1, 2 * basis.nm, basis.nl, 1), t1[i].reshape(1, 2 * basis.nm, Nt, 1))
+    basis.colatitude_plan(ex, Nt, rank).backward(c.reshape(1, nc * 2 * basis.nm, basis.nl, 1),
+                                                 t1.reshape(1, nc * 2 * basis.nm, Nt, 1))
     if rank > 0:
         t2 = ex.empty((nc, 2 * basis.nm, Nt))
         ex.spin_recombine(t1, t2, basis.recombination_matrix(rank, forward=False))
@@ -491,9 +506,8 @@ def _forward(dist, basis, rank, g, scales):
     else:
         t2 = t1
     c = ex.zeros((nc, 2 * basis.nm, basis.nl))
-    for i, s in enumerate(basis.spin_totals(rank)):
-        plan = basis.colatitude_plan(ex, Nt, s)
-        plan.forward(t2[i].reshape(1, 2 * basis.nm, Nt, 1), c[i].reshape(1, 2 * basis.nm, basis.nl, 1))
+    basis.colatitude_plan(ex, Nt, rank).forward(t2.reshape(1, nc * 2 * basis.nm, Nt, 1),
+                                                c.reshape(1, nc * 2 * basis.nm, basis.nl, 1))
     return c
 
 
@@ -1160,8 +1174,12 @@ class SphereSolverBase:
                 if rv.sum() != cv.sum():
                     raise ValueError("m = %d: %d valid equation modes for %d valid variable modes" % (m, rv.sum(), cv.sum()))
                 if rv.any():
-                    sub = A[np.ix_(rv, cv)]
-                    inv[np.ix_(cv, rv)] = np.linalg.inv(sub)
+                    # the systems are block-banded in ell: sparse LU + identity right-hand sides, O(n^2 b) per m
+                    # instead of the O(n^3) dense inverse
+                    import scipy.sparse as sp
+                    import scipy.sparse.linalg as spla
+                    sub = sp.csc_matrix(A[np.ix_(rv, cv)])
+                    inv[np.ix_(cv, rv)] = spla.splu(sub).solve(np.eye(sub.shape[0], dtype=complex))
             mats.append(inv)
         return self.ex.make_cgemv_batch(nm, nl, self.R, mats)
 
@@ -1218,9 +1236,13 @@ class SphereInitialValueSolver(SphereSolverBase):
         self.stop_iteration = np.inf
         self.dt = None
         self._lus = []
+        self.warmup_iterations = 10
         self.timestepper = timestepper(self)
-        import time as _t
-        self._t0 = _t.time()
+        self.start_time = _time.time()
+        self.warmup_time = None
+        self.total_modes = int(self.col_valid.sum()) * 2
+        from .solvers import _HandlerRegistry
+        self.evaluator = _HandlerRegistry(self)      # analysis output is host-side I/O outside the hot path
 
     # interface used by the shared timesteppers ------------------------------------------------------------------
     def factor(self, a, b, reuse=-1):
@@ -1235,15 +1257,39 @@ class SphereInitialValueSolver(SphereSolverBase):
         self._lus[lu].apply(rhs, x)
 
     def step(self, dt):
+        """Advance one timestep (core/solvers.py:683-711)."""
         if not np.isfinite(dt):
-            raise ValueError("Invalid timestep")
+            raise ValueError("Invalid timestep: %r" % dt)
+        if self.iteration == self.initial_iteration + self.warmup_iterations:
+            self.ex.sync()
+            self.warmup_time = _time.time()
         self.dt = dt
-        self.timestepper.step(dt)
+        self.timestepper.step(dt, _time.time() - self.start_time)
         self.iteration += 1
 
     @property
     def proceed(self):
-        return (self.sim_time < self.stop_sim_time) and (self.iteration < self.stop_iteration)
+        """core/solvers.py:594-618"""
+        if self.sim_time >= self.stop_sim_time:
+            logger.info("Simulation stop time reached.")
+            return False
+        if (_time.time() - self.start_time) >= self.stop_wall_time:
+            logger.info("Wall stop time reached.")
+            return False
+        if self.iteration >= self.stop_iteration:
+            logger.info("Stop iteration reached.")
+            return False
+        return True
 
     def log_stats(self, format=".4g"):
-        pass
+        """core/solvers.py:755-778"""
+        self.ex.sync()
+        end = _time.time()
+        logger.info("Final iteration: %i" % self.iteration)
+        logger.info("Final sim time: %s" % self.sim_time)
+        if self.warmup_time is not None:
+            run = end - self.warmup_time
+            its = self.iteration - self.initial_iteration - self.warmup_iterations
+            logger.info("Run time (iter %d-end): %.4g sec" % (self.warmup_iterations, run))
+            if run > 0:
+                logger.info("Speed: %.4g mode-stages/gpu-sec" % (self.total_modes * its * self.timestepper.stages / run))

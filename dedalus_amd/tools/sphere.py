@@ -20,9 +20,15 @@ from . import jacobi
 LD = np.longdouble
 
 
+_QUAD = {}
+
+
 def quadrature(Ntheta):
-    """Gauss-Legendre nodes cos(theta) (ascending) and weights, exact to degree 2 Ntheta - 1."""
-    return jacobi.quadrature(Ntheta, 0, 0, dtype=LD)
+    """Gauss-Legendre nodes cos(theta) (ascending) and weights, exact to degree 2 Ntheta - 1 (cached: every
+    (m, s) matrix of a transform plan uses the same grid)."""
+    if Ntheta not in _QUAD:
+        _QUAD[Ntheta] = jacobi.quadrature(Ntheta, 0, 0, dtype=LD)
+    return _QUAD[Ntheta]
 
 
 def _log_mass(a, b):

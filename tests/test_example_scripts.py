@@ -36,3 +36,33 @@ def test_reference_2d_rayleigh_benard_example_runs_unmodified(monkeypatch, tmp_p
     assert solver.iteration == 25
     assert np.isfinite(np.asarray(b["c"])).all() and np.isfinite(np.asarray(u["c"])).all()
     assert abs(np.sqrt(np.sum(np.asarray(b["c"]) ** 2)) - 1.0854) < 1e-3
+
+
+SW_EXAMPLE = "/root/reference/examples/ivp_sphere_shallow_water/shallow_water.py"
+
+
+@pytest.mark.skipif(not os.path.exists(SW_EXAMPLE), reason="reference examples only exist in the build container")
+def test_reference_shallow_water_example_runs_unmodified(monkeypatch, tmp_path):
+    """examples/ivp_sphere_shallow_water/shallow_water.py (256 x 128, LBVP + IVP) through dedalus_amd.compat."""
+    import dedalus_amd.compat as compat
+    from dedalus_amd.core import sphere
+    from oracle.np_executor import NumpyExecutor
+    compat.install()
+    orig_init = sphere.SphereDistributor.__init__
+
+    def init(self, *a, **k):
+        k.setdefault("executor", NumpyExecutor())
+        orig_init(self, *a, **k)
+    monkeypatch.setattr(sphere.SphereDistributor, "__init__", init)
+    orig_proceed = sphere.SphereInitialValueSolver.proceed
+
+    def proceed(self):
+        return orig_proceed.fget(self) and self.iteration < 3
+    monkeypatch.setattr(sphere.SphereInitialValueSolver, "proceed", property(proceed))
+    monkeypatch.chdir(tmp_path)
+    ns = runpy.run_path(SW_EXAMPLE, run_name="__main__")
+    solver, h, u = ns["solver"], ns["h"], ns["u"]
+    assert solver.iteration == 3
+    assert np.isfinite(np.asarray(h["g"])).all() and np.isfinite(np.asarray(u["g"])).all()
+    # the jet is still there: max zonal velocity 80 m/s in the script's units
+    assert abs(np.abs(np.asarray(u["g"])[0]).max() - 80 / 6.37122e6 * 3600) < 1e-3

@@ -1,5 +1,6 @@
 """Secondary BASELINE.json configurations on one GPU (not the headline metric):
-   K  = KdV-Burgers N=1024 SBDF2,  R2 = 2-D Rayleigh-Benard 512x256 RK222.  Prints steps/s."""
+   K  = KdV-Burgers N=1024 SBDF2,  R2 = 2-D Rayleigh-Benard 512x256 RK222,
+   S  = sphere shallow water SphereBasis(512, 256) RK222 (`python tools/bench_configs.py sphere`).  Prints steps/s."""
 import os
 import sys
 import time
@@ -25,7 +26,28 @@ def run(name, builder, kw, dt, warm, steps):
     print("%-28s %8.1f steps/s  (%.3f ms/step, %d steps)" % (name, steps / el, 1e3 * el / steps, steps), flush=True)
 
 
+def run_sphere(name, kw, warm, steps):
+    t0 = time.time()
+    solver, f, extra = problems.shallow_water(d3, **kw)
+    dt = extra["timestep"]
+    solver.step(dt)
+    solver.ex.sync()
+    print("%-28s setup + LBVP + first step: %.1f s" % (name, time.time() - t0), flush=True)
+    for _ in range(warm):
+        solver.step(dt)
+    solver.ex.sync()
+    t0 = time.time()
+    for _ in range(steps):
+        solver.step(dt)
+    solver.ex.sync()
+    el = time.time() - t0
+    print("%-28s %8.1f steps/s  (%.3f ms/step, %d steps)" % (name, steps / el, 1e3 * el / steps, steps), flush=True)
+
+
 if __name__ == "__main__":
+    if "sphere" in sys.argv[1:]:
+        run_sphere("S  shallow water 512x256 RK222", dict(Nphi=512, Ntheta=256), 5, 50)
+        sys.exit(0)
     run("K  kdv N=1024 SBDF2", problems.kdv_burgers, dict(Nx=1024, timestepper="SBDF2"), 2e-3, 20, 200)
     run("R2 rb2d 512x256 RK222", problems.rayleigh_benard_2d, dict(Nx=512, Nz=256), 1e-3, 5, 50)
     run("rb3d 128x128x64 RK222", problems.rayleigh_benard_3d, dict(Nx=128, Ny=128, Nz=64), 1e-3, 3, 20)
