@@ -45,57 +45,73 @@ __device__ __forceinline__ long c_index(const GmmtDims &d, long o, long i1, long
 
 constexpr int GV_COLS = 8;     // GEMV path: at most this many right-hand-side columns
 
-// ---- batched GEMV: block = 4 waves = 4 output rows of one group ---------------------------------------
-template <bool FWD>
+// ---- batched GEMV: block = 4 waves, each wave owns GV_ROWS output rows of one group ----------------------
+// The right-hand-side columns (cos / msin parts, leading and trailing axes) are few, so the kernel is bound
+// by streaming the matrices: every lane keeps GV_ROWS matrix loads in flight per step and the (cached)
+// right-hand-side values are loaded once for all the rows of the wave; all index arithmetic is hoisted.
+constexpr int GV_ROWS = 4;
+
+template <bool FWD, int NCOL>
 __global__ void __launch_bounds__(256)
 grouped_gemv_kernel(const GroupDev *__restrict__ groups, const double *__restrict__ mats, const double *__restrict__ in,
                     double *__restrict__ out, GmmtDims d, int ncols) {
     const GroupDev gr = groups[blockIdx.y];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
+    const int row0 = (blockIdx.x * 4 + wave) * GV_ROWS;
     const int nrows = FWD ? gr.n_ell : d.n_grid;       // output rows
-    if (gr.mat_rows < 0) {
-        if (!FWD && row < d.n_grid) {
-            for (int col = lane; col < ncols; col += 64) {
-                const long x = col % d.n3, jc = (col / d.n3) % gr.count, o = col / (d.n3 * gr.count);
-                if (o < d.n0) out[g_index(d, o, gr.g_start + jc, row, x)] = 0.0;
+    // per column: input base / stride along the contraction index, output base / stride along the row index
+    long ibase[NCOL], obase[NCOL];
+    bool cok[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        const long x = c % d.n3, jc = (c / d.n3) % gr.count, o = c / (d.n3 * gr.count);
+        cok[c] = c < ncols && o < d.n0;
+        ibase[c] = FWD ? g_index(d, o, gr.g_start + jc, 0, x) : c_index(d, o, gr.c_start + jc, gr.ell_start, x);
+        obase[c] = FWD ? c_index(d, o, gr.c_start + jc, gr.ell_start, x) : g_index(d, o, gr.g_start + jc, 0, x);
+    }
+    const long istride = FWD ? d.n3 : (long)gr.ell_step * d.n3;
+    const long ostride = FWD ? (long)gr.ell_step * d.n3 : d.n3;
+    if (gr.mat_rows < 0) {                              // |m| > Lmax: forward skips, backward writes zeros
+        if (!FWD && lane == 0) {
+            for (int r = 0; r < GV_ROWS; ++r) {
+                if (row0 + r >= d.n_grid) break;
+#pragma unroll
+                for (int c = 0; c < NCOL; ++c)
+                    if (cok[c]) out[obase[c] + (long)(row0 + r) * ostride] = 0.0;
             }
         }
         return;
     }
-    if (row >= nrows) return;
+    if (row0 >= nrows) return;
     const int K = FWD ? d.n_grid : gr.n_ell;            // contraction length
-    const double *A = mats + (FWD ? gr.off_f : gr.off_b) + (long)row * K;
-    double acc[GV_COLS];
+    const double *A = mats + (FWD ? gr.off_f : gr.off_b) + (long)row0 * K;
+    double acc[GV_ROWS][NCOL];
 #pragma unroll
-    for (int c = 0; c < GV_COLS; ++c) acc[c] = 0.0;
+    for (int r = 0; r < GV_ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) acc[r][c] = 0.0;
+    bool rok[GV_ROWS];
+#pragma unroll
+    for (int r = 0; r < GV_ROWS; ++r) rok[r] = row0 + r < nrows;
     for (int k = lane; k < K; k += 64) {
-        const double a = A[k];
+        double a[GV_ROWS], xv[NCOL];
 #pragma unroll
-        for (int c = 0; c < GV_COLS; ++c) {
-            if (c < ncols) {
-                const long x = c % d.n3, jc = (c / d.n3) % gr.count, o = c / (d.n3 * gr.count);
-                if (o < d.n0) {
-                    const long idx = FWD ? g_index(d, o, gr.g_start + jc, k, x)
-                                         : c_index(d, o, gr.c_start + jc, gr.ell_start + (long)k * gr.ell_step, x);
-                    acc[c] += a * in[idx];
-                }
-            }
-        }
+        for (int r = 0; r < GV_ROWS; ++r) a[r] = rok[r] ? A[(long)r * K + k] : 0.0;
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) xv[c] = cok[c] ? in[ibase[c] + (long)k * istride] : 0.0;
+#pragma unroll
+        for (int r = 0; r < GV_ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) acc[r][c] += a[r] * xv[c];
     }
 #pragma unroll
-    for (int c = 0; c < GV_COLS; ++c) {
-        if (c < ncols) {
-            double v = acc[c];
+    for (int r = 0; r < GV_ROWS; ++r) {
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            double v = acc[r][c];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            const long o_chk = c / (d.n3 * gr.count);
-            if (lane == 0 && o_chk < d.n0) {
-                const long x = c % d.n3, jc = (c / d.n3) % gr.count, o = c / (d.n3 * gr.count);
-                const long idx = FWD ? c_index(d, o, gr.c_start + jc, gr.ell_start + (long)row * gr.ell_step, x)
-                                     : g_index(d, o, gr.g_start + jc, row, x);
-                out[idx] = v;
-            }
+            if (lane == 0 && rok[r] && cok[c]) out[obase[c] + (long)(row0 + r) * ostride] = v;
         }
     }
 }
@@ -178,8 +194,13 @@ static int launch_grouped(GmmtPlan *pl, const double *in, double *out, long n0, 
     const int max_rows = FWD ? pl->max_ell : pl->n_grid;
     const double *mats = FWD ? pl->d_fwd : pl->d_bwd;
     if (ncols <= GV_COLS) {
-        dim3 grid((unsigned)((max_rows + 3) / 4), (unsigned)pl->ngroups);
-        hipLaunchKernelGGL(grouped_gemv_kernel<FWD>, grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols);
+        dim3 grid((unsigned)((max_rows + 4 * GV_ROWS - 1) / (4 * GV_ROWS)), (unsigned)pl->ngroups);
+        if (ncols <= 2)
+            hipLaunchKernelGGL((grouped_gemv_kernel<FWD, 2>), grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols);
+        else if (ncols <= 4)
+            hipLaunchKernelGGL((grouped_gemv_kernel<FWD, 4>), grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols);
+        else
+            hipLaunchKernelGGL((grouped_gemv_kernel<FWD, 8>), grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols);
     } else {
         dim3 grid((unsigned)((ncols + GT_X - 1) / GT_X), (unsigned)((max_rows + GT_I - 1) / GT_I), (unsigned)pl->ngroups);
         if (grid.z > 65535 || grid.y > 65535) return fail("grouped_mmt: too many groups / rows for one launch");
