@@ -140,6 +140,20 @@ class SphereBasis:
             self._plans["pack"] = (rows, cols, ok)
         return self._plans["pack"]
 
+    def packed_ell_rows(self):
+        """(ell, i0, i1, j, j+1) rows of the reference's ell_maps for the packed layout (core/basis.py:2983-3011):
+        per ell and packed column the BOUNDING BOX of the rows holding that ell (local_groupset_slices,
+        core/distributor.py:460-494).  Boxes of different ell overlap in the folded part of the layout; the
+        reference recombines a slot once per covering box, which the shell's regularity tables reproduce."""
+        m, ell = self.packed_groups()
+        rows = []
+        for lg in range(self.Lmax + 1):
+            for j in range(m.shape[1]):
+                hit = np.where(ell[:, j] == lg)[0]
+                if hit.size:
+                    rows.append((lg, int(hit.min()), int(hit.max()) + 1, j, j + 1))
+        return np.array(rows, dtype=np.int64).reshape(-1, 5)
+
     # ---- spin bookkeeping ---------------------------------------------------------------------------------------
     @staticmethod
     def spin_indices(rank):

@@ -28,7 +28,7 @@ constexpr HandleKind H_CGEMV = (HandleKind)6;
 
 // ------------------------------------------------------------------------------------------------
 struct SpinMat {
-    double r[64];     // [2 nc][2 nc] row major, nc <= 4
+    double r[324];    // [2 nc][2 nc] row major, nc <= 9 (rank 2 in spherical coordinates)
 };
 
 template <int NC>
@@ -169,7 +169,8 @@ int ddh_spin_recombine(const double *in, double *out, int ncomp, long npairs, lo
                        void *stream) {
     if (npairs <= 0 || inner <= 0) return 0;
     if (in == out) return fail("ddh_spin_recombine: in-place unsupported");
-    if (ncomp != 1 && ncomp != 2 && ncomp != 4) return fail("ddh_spin_recombine: 1, 2 or 4 components (rank 0-2 on S2)");
+    if (ncomp != 1 && ncomp != 2 && ncomp != 4 && ncomp != 3 && ncomp != 9)
+        return fail("ddh_spin_recombine: 1, 2, 4 (rank 0-2 on S2) or 3, 9 (rank 1-2 in spherical coordinates) components");
     SpinMat M;
     memset(&M, 0, sizeof(M));
     for (int i = 0; i < 4 * ncomp * ncomp; ++i) M.r[i] = mat_h[i];
@@ -178,7 +179,9 @@ int ddh_spin_recombine(const double *in, double *out, int ncomp, long npairs, lo
     hipStream_t st = as_stream(stream);
     if (ncomp == 1) hipLaunchKernelGGL(spin_recombine_kernel<1>, dim3(blocks), dim3(256), 0, st, in, out, M, npairs, inner);
     else if (ncomp == 2) hipLaunchKernelGGL(spin_recombine_kernel<2>, dim3(blocks), dim3(256), 0, st, in, out, M, npairs, inner);
-    else hipLaunchKernelGGL(spin_recombine_kernel<4>, dim3(blocks), dim3(256), 0, st, in, out, M, npairs, inner);
+    else if (ncomp == 4) hipLaunchKernelGGL(spin_recombine_kernel<4>, dim3(blocks), dim3(256), 0, st, in, out, M, npairs, inner);
+    else if (ncomp == 3) hipLaunchKernelGGL(spin_recombine_kernel<3>, dim3(blocks), dim3(256), 0, st, in, out, M, npairs, inner);
+    else hipLaunchKernelGGL(spin_recombine_kernel<9>, dim3(blocks), dim3(256), 0, st, in, out, M, npairs, inner);
     DDH_HIP(hipGetLastError());
     return 0;
 }

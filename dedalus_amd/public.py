@@ -18,11 +18,15 @@ from .extras.flow_tools import CFL, GlobalFlowProperty
 # ---- the sphere (core/sphere.py): same names, dispatched on the coordinate system / operand type -----------------
 from .core import sphere as _sphere
 from .core.sphere import S2Coordinates, SphereBasis
+from .core import shell as _shell
+from .core.shell import SphericalCoordinates, ShellBasis
 
 _CartesianDistributor = Distributor
 
 
 def Distributor(coordsystems, *args, **kw):
+    if isinstance(coordsystems, SphericalCoordinates):
+        return _shell.ShellDistributor(coordsystems, *args, **kw)
     if isinstance(coordsystems, S2Coordinates):
         return _sphere.SphereDistributor(coordsystems, *args, **kw)
     return _CartesianDistributor(coordsystems, *args, **kw)

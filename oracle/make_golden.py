@@ -248,6 +248,41 @@ def golden_sphere():
     print("wrote sphere.npz with", len(out), "arrays")
 
 
+def golden_shellfields():
+    """Field-level transforms of the reference's ShellBasis (azimuth FFT, spin recombination + SWSH, radial Jacobi
+    transform + regularity recombination, core/basis.py:4474-4508 and Spherical3DBasis): for seeded valid
+    coefficients, the grid data at scales 1 and 3/2 and the coefficients recovered from the grid."""
+    d3 = refshim.load_reference()
+    rng = np.random.default_rng(21)
+    out = {}
+    coords = d3.SphericalCoordinates("phi", "theta", "r")
+    dist = d3.Distributor(coords, dtype=np.float64)
+    for shape, radii, k in [((16, 12, 6), (0.7, 1.9), 0), ((8, 8, 5), (14.0, 15.0), 0), ((16, 10, 6), (0.5, 1.5), 1)]:
+        shell = d3.ShellBasis(coords, shape=shape, radii=radii, dealias=3 / 2, dtype=np.float64, k=k)
+        tag = "%dx%dx%d_k%d__" % (shape + (k,))
+        out[tag + "radii"] = np.array(radii)
+        for rank in (0, 1, 2):
+            sig = (coords,) * rank
+            f = dist.TensorField(sig, bases=shell) if rank else dist.Field(bases=shell)
+            el = np.indices(f['c'].shape[rank:])
+            valid = shell.valid_elements(f.tensorsig, (False, False, False), el)
+            cin = rng.standard_normal(f['c'].shape) * valid
+            f['c'] = cin
+            out[tag + "r%d__cin" % rank] = cin.copy()
+            out[tag + "r%d__g1" % rank] = np.array(f['g'])
+            f.change_scales(3 / 2)
+            out[tag + "r%d__g15" % rank] = np.array(f['g'])
+            f.change_scales(1)
+            g = rng.standard_normal(f['g'].shape)
+            f['g'] = g
+            out[tag + "r%d__gin" % rank] = g.copy()
+            out[tag + "r%d__cout" % rank] = np.array(f['c'])
+        phi, theta, r = dist.local_grids(shell)
+        out[tag + "r_grid"] = np.ravel(r)
+    np.savez_compressed(os.path.join(GOLD, "shellfields.npz"), **out)
+    print("wrote shellfields.npz with", len(out), "arrays")
+
+
 def golden_timesteppers():
     """Multistep coefficients of the reference for random step sequences (timesteppers.py:190-495)."""
     refshim.load_reference()
