@@ -944,6 +944,29 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
 }
 
 
+// Per-row upper width of the factors: wrow[j] = max over all factorizations of the last non-zero offset d of
+// U(j, j + d).  Partial pivoting can fill up to kl extra super-diagonals, but rows where no factorization
+// actually interchanged keep the original ku: the backward sweep then skips the all-zero tail entries.
+template <bool REAL>
+__global__ void __launch_bounds__(256)
+lu_width_kernel(LuDev L, int *__restrict__ wrow) {
+    typedef typename El<REAL>::T E;
+    const long gl = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = gl < L.GL;
+    const E *Aw = (const E *)L.Aw;
+    for (int j = 0; j < L.n; ++j) {
+        int w = 0;
+        if (act) {
+            const E *Ur = Aw + lu_aw(L, gl, j, L.kl);
+            for (int d = L.W; d > 0; --d)
+                if (!El<REAL>::is_zero(Ur[(long)d << 6])) { w = d; break; }
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) w = max(w, __shfl_xor(w, sft, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(&wrow[j], w);
+    }
+}
+
 }  // namespace ddh
 
 using namespace ddh;
@@ -1271,6 +1294,24 @@ int ddh_pencil_solve(ddh_handle pack, int lu_id, const double *rhs, double *x, v
     if (pp->dev.nf == 2) return launch_solve<2>(pp, lu, rhs, x, s);
     if (pp->dev.nf == 1) return launch_solve<1>(pp, lu, rhs, x, s);
     return launch_solve<0>(pp, lu, rhs, x, s);
+}
+
+int ddh_pencil_lu_row_widths(ddh_handle pack, int lu_id, int *wrow_h) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_lu_row_widths: bad LU id");
+    const LuDev &d = pp->lus[lu_id]->dev;
+    if (d.n <= 0) return 0;
+    int *dw = nullptr;
+    DDH_HIP(hipMalloc((void **)&dw, d.n * sizeof(int)));
+    DDH_HIP(hipMemset(dw, 0, d.n * sizeof(int)));
+    const unsigned blocks = (unsigned)((d.GL + 255) / 256);
+    if (d.real) hipLaunchKernelGGL(lu_width_kernel<true>, dim3(blocks), dim3(256), 0, 0, d, dw);
+    else hipLaunchKernelGGL(lu_width_kernel<false>, dim3(blocks), dim3(256), 0, 0, d, dw);
+    DDH_HIP(hipGetLastError());
+    DDH_HIP(hipMemcpy(wrow_h, dw, d.n * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dw);
+    return 0;
 }
 
 int ddh_pencil_lu_bytes(ddh_handle pack, int lu_id, size_t *bytes) {

@@ -89,6 +89,7 @@ SIGNATURES = {
     "ddh_pencil_flagged": [_h, _i, _ip, C.POINTER(_l), _i],
     "ddh_pencil_set_dense_inverse": [_h, _i, _dp],
     "ddh_pencil_lu_bytes": [_h, _i, C.POINTER(C.c_size_t)],
+    "ddh_pencil_lu_row_widths": [_h, _i, _ip],
     "ddh_a2a_pack": [_vp, _vp, _l, _l, _l, _l, _i, _vp],
     "ddh_a2a_unpack": [_vp, _vp, _l, _l, _l, _l, _i, _vp],
 }

@@ -248,6 +248,9 @@ int ddh_pencil_solve(ddh_handle pack, int lu_id, const double *rhs, double *x, v
 int ddh_pencil_flagged(ddh_handle pack, int lu_id, int *count, long *cells_h, int max_cells);
 int ddh_pencil_set_dense_inverse(ddh_handle pack, int lu_id, const double *inv_h);
 int ddh_pencil_lu_bytes(ddh_handle pack, int lu_id, size_t *bytes);
+/* wrow_h[j] (n_interior ints) = max over all factorizations of the last non-zero super-diagonal offset of U row j:
+ * how much of the partial-pivoting fill space (kl extra super-diagonals, LAPACK gbtrf storage) is really used.  */
+int ddh_pencil_lu_row_widths(ddh_handle pack, int lu_id, int *wrow_h);
 
 /* ---- distributed transposes ----------------------------------------------- */
 /* Local pack / unpack for the all-to-all that replaces FFTWTranspose / AlltoallvTranspose
