@@ -12,6 +12,17 @@ from scipy import sparse
 from ..tools import jacobi
 
 
+def _grid_args(args, scale):
+    """(dist or None, scale) from global_grid(scale) / global_grid(dist, scale) / global_grid(dist, scale=...)"""
+    dist = None
+    args = list(args)
+    if args and not isinstance(args[0], (int, float)):
+        dist = args.pop(0)
+    if args:
+        scale = args[0]
+    return dist, scale
+
+
 class Basis:
     dim = 1
 
@@ -66,9 +77,13 @@ class RealFourier(Basis):
     def wavenumbers(self):
         return np.repeat(self.mode_wavenumbers, 2)
 
-    def global_grid(self, scale=1):
+    def global_grid(self, *args, scale=1):
+        """global_grid(scale) or, with the reference's signature, global_grid(dist, scale) (reshaped to the
+        distributor's dimensions, core/basis.py:362-366)."""
+        dist, scale = _grid_args(args, scale)
         N = self.grid_size(scale)
-        return self.bounds[0] + self.length * np.arange(N) / N
+        g = self.bounds[0] + self.length * np.arange(N) / N
+        return g if dist is None else dist._reshape_axis(g, dist.coord_axis(self.coord))
 
     def grid_spacing(self, scale=1):
         N = self.grid_size(scale)
@@ -145,8 +160,12 @@ class Jacobi(Basis):
     def native_grid(self, scale=1):
         return jacobi.build_grid(self.grid_size(scale), self.a0, self.b0)
 
-    def global_grid(self, scale=1):
-        return self.bounds[0] + (self.native_grid(scale) + 1.0) * self.stretch
+    def global_grid(self, *args, scale=1):
+        """global_grid(scale) or, with the reference's signature, global_grid(dist, scale) (reshaped to the
+        distributor's dimensions, core/basis.py:362-366)."""
+        dist, scale = _grid_args(args, scale)
+        g = self.bounds[0] + (self.native_grid(scale) + 1.0) * self.stretch
+        return g if dist is None else dist._reshape_axis(g, dist.coord_axis(self.coord))
 
     def grid_spacing(self, scale=1):
         return np.gradient(self.global_grid(scale), edge_order=2) if self.grid_size(scale) > 2 else \

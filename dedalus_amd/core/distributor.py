@@ -11,6 +11,20 @@ from .coords import CartesianCoordinates, Coordinate
 from .field import Field
 
 
+class _RankInfo:
+    """What scripts read from dist.comm / dist.comm_cart when no MPI communicator is passed (one process per GPU;
+    the collectives themselves go through torch.distributed, parallel.py)."""
+
+    def __init__(self, rank, size):
+        self.rank, self.size = rank, size
+
+    def Get_rank(self):
+        return self.rank
+
+    def Get_size(self):
+        return self.size
+
+
 class Distributor:
     def __init__(self, coordsystems, comm=None, mesh=None, dtype=None, executor=None):
         if isinstance(coordsystems, (CartesianCoordinates, Coordinate)):
@@ -34,7 +48,7 @@ class Distributor:
         self._layout_frozen = False
         self._executor = executor
         self.transformer = Transformer(self)
-        self.comm = comm
+        self.comm = comm if comm is not None else _RankInfo(self.rank, self.size)
 
     # ---- executor (device) -------------------------------------------------------------------------
     @property

@@ -346,6 +346,25 @@ class Field(Operand):
         sl = (slice(None),) * len(self.tshape) + self.domain.local_slices(layout, self.scales)
         self[layout] = out.reshape(shape)[sl]
 
+    def low_pass_filter(self, shape=None, scales=None):
+        """Zero the modes above the given relative scales by a round trip through a coarser grid
+        (core/field.py:945-967)."""
+        original = self.scales
+        if shape is not None:
+            if scales is not None:
+                raise ValueError("Specify either shape or scales.")
+            full = self._user_shape("g", self._remedy_scales(1))[len(self.tensorsig):]
+            scales = tuple(np.array(shape) / np.array(full))
+        self.change_scales(scales)
+        self.require_grid_space(self.scales)
+        self.change_scales(original)
+
+    def high_pass_filter(self, shape=None, scales=None):
+        """Zero the modes below the given relative scales (core/field.py:969-993)."""
+        data_orig = self["c"].copy()
+        self.low_pass_filter(shape=shape, scales=scales)
+        self["c"] = data_orig - self["c"]
+
     def allgather_data(self, layout=None):
         return self[layout or "g"].copy()
 

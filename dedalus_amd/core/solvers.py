@@ -663,5 +663,5 @@ class LinearBoundaryValueSolver(SolverBase):
         F = self.ex.empty((self.R, self.nx, self.ny))
         self.evaluate_F(F)
         lu = self.factor(0.0, 1.0)
-        self.solve(lu, F, self.X)
+        SolverBase.solve(self, lu, F, self.X)
         self.mark_state_current()

@@ -207,6 +207,11 @@ def golden_ivp():
         for k, v in res.items():
             out[name + "__" + k] = v
         print(name, {k: float(np.linalg.norm(v)) for k, v in res.items()})
+    for (Nx, Ny) in ((64, 32), (32, 24)):
+        solver, fields = problems.poisson_2d(d3, Nx=Nx, Ny=Ny)
+        for k, v in fields.items():
+            out["poisson_%dx%d__%s" % (Nx, Ny, k)] = np.array(v['c'])
+        print("poisson", Nx, Ny, float(np.linalg.norm(fields["u"]['c'])))
     solver, dts, res = problems.run_cfl_case(d3)
     out["cfl__dts"] = dts
     for k, v in res.items():

@@ -102,6 +102,67 @@ def rayleigh_benard_3d(d3, Nx=8, Ny=12, Nz=8, timestepper="RK222", dist_kw=None)
     return solver, dict(p=p, b=b, u=u, tau_b1=tau_b1, tau_b2=tau_b2, tau_u1=tau_u1, tau_u2=tau_u2)
 
 
+def shear_flow_2d(d3, Nx=32, Nz=64, timestepper="RK222", dist_kw=None):
+    """The reference's example examples/ivp_2d_shear_flow/shear_flow.py:28-75 (periodic Fourier x Fourier shear layer
+    with a passive tracer, pressure gauge through tau_p), parameterised by resolution only."""
+    Lx, Lz = 1, 2
+    Reynolds, Schmidt, dealias = 5e4, 1, 3 / 2
+    coords = d3.CartesianCoordinates('x', 'z')
+    dist = d3.Distributor(coords, dtype=np.float64, **(dist_kw or {}))
+    xbasis = d3.RealFourier(coords['x'], size=Nx, bounds=(0, Lx), dealias=dealias)
+    zbasis = d3.RealFourier(coords['z'], size=Nz, bounds=(-Lz / 2, Lz / 2), dealias=dealias)
+    p = dist.Field(name='p', bases=(xbasis, zbasis))
+    s = dist.Field(name='s', bases=(xbasis, zbasis))
+    u = dist.VectorField(coords, name='u', bases=(xbasis, zbasis))
+    tau_p = dist.Field(name='tau_p')
+    nu = 1 / Reynolds
+    D = nu / Schmidt
+    x, z = dist.local_grids(xbasis, zbasis)
+    ex, ez = coords.unit_vector_fields(dist)
+    problem = d3.IVP([u, s, p, tau_p], namespace=locals())
+    problem.add_equation("dt(u) + grad(p) - nu*lap(u) = - u@grad(u)")
+    problem.add_equation("dt(s) - D*lap(s) = - u@grad(s)")
+    problem.add_equation("div(u) + tau_p = 0")
+    problem.add_equation("integ(p) = 0")
+    solver = problem.build_solver(getattr(d3, timestepper))
+    u['g'][0] = 1 / 2 + 1 / 2 * (np.tanh((z - 0.5) / 0.1) - np.tanh((z + 0.5) / 0.1))
+    s['g'] = u['g'][0]
+    u['g'][1] += 0.1 * np.sin(2 * np.pi * x / Lx) * np.exp(-(z - 0.5) ** 2 / 0.01)
+    u['g'][1] += 0.1 * np.sin(2 * np.pi * x / Lx) * np.exp(-(z + 0.5) ** 2 / 0.01)
+    return solver, dict(u=u, s=s, p=p)
+
+
+def poisson_2d(d3, Nx=64, Ny=32, dist_kw=None):
+    """The reference's example examples/lbvp_2d_poisson/poisson.py:27-64 (Fourier x Chebyshev Poisson LBVP with
+    tau lifts, a Dirichlet and a Neumann condition, low-pass filtered random forcing)."""
+    Lx, Ly = 2 * np.pi, np.pi
+    coords = d3.CartesianCoordinates('x', 'y')
+    dist = d3.Distributor(coords, dtype=np.float64, **(dist_kw or {}))
+    xbasis = d3.RealFourier(coords['x'], size=Nx, bounds=(0, Lx))
+    ybasis = d3.Chebyshev(coords['y'], size=Ny, bounds=(0, Ly))
+    u = dist.Field(name='u', bases=(xbasis, ybasis))
+    tau_1 = dist.Field(name='tau_1', bases=xbasis)
+    tau_2 = dist.Field(name='tau_2', bases=xbasis)
+    x, y = dist.local_grids(xbasis, ybasis)
+    f = dist.Field(bases=(xbasis, ybasis))
+    g = dist.Field(bases=xbasis)
+    h = dist.Field(bases=xbasis)
+    f.fill_random('g', seed=40)
+    f.low_pass_filter(shape=(Nx // 4, Ny // 4))
+    g['g'] = np.sin(8 * x) * 0.025
+    h['g'] = 0
+    dy = lambda A: d3.Differentiate(A, coords['y'])
+    lift_basis = ybasis.derivative_basis(2)
+    lift = lambda A, n: d3.Lift(A, lift_basis, n)
+    problem = d3.LBVP([u, tau_1, tau_2], namespace=locals())
+    problem.add_equation("lap(u) + lift(tau_1,-1) + lift(tau_2,-2) = f")
+    problem.add_equation("u(y=0) = g")
+    problem.add_equation("dy(u)(y=Ly) = h")
+    solver = problem.build_solver()
+    solver.solve()
+    return solver, dict(u=u, f=f, tau_1=tau_1, tau_2=tau_2)
+
+
 IVP_CASES = {
     # name: (builder, kwargs, timestep, number of steps)
     "kdv64_sbdf2": (kdv_burgers, dict(Nx=64, timestepper="SBDF2"), 2e-3, 20),
@@ -111,6 +172,8 @@ IVP_CASES = {
     "rb2d_64x32_rk222": (rayleigh_benard_2d, dict(Nx=64, Nz=32, timestepper="RK222"), 1e-3, 10),
     "rb3d_8x12x8_rk222": (rayleigh_benard_3d, dict(Nx=8, Ny=12, Nz=8, timestepper="RK222"), 1e-3, 4),
     "rb3d_16x16x16_rk222": (rayleigh_benard_3d, dict(Nx=16, Ny=16, Nz=16, timestepper="RK222"), 1e-3, 3),
+    "shear2d_32x64_rk222": (shear_flow_2d, dict(Nx=32, Nz=64, timestepper="RK222"), 5e-3, 8),
+    "shear2d_32x64_sbdf2": (shear_flow_2d, dict(Nx=32, Nz=64, timestepper="SBDF2"), 5e-3, 8),
 }
 
 

@@ -66,3 +66,31 @@ def test_reference_shallow_water_example_runs_unmodified(monkeypatch, tmp_path):
     assert np.isfinite(np.asarray(h["g"])).all() and np.isfinite(np.asarray(u["g"])).all()
     # the jet is still there: max zonal velocity 80 m/s in the script's units
     assert abs(np.abs(np.asarray(u["g"])[0]).max() - 80 / 6.37122e6 * 3600) < 1e-3
+
+
+POISSON_EXAMPLE = "/root/reference/examples/lbvp_2d_poisson/poisson.py"
+
+
+@pytest.mark.skipif(not os.path.exists(POISSON_EXAMPLE), reason="reference examples only exist in the build container")
+def test_reference_poisson_lbvp_example_runs_unmodified(monkeypatch, tmp_path):
+    """examples/lbvp_2d_poisson/poisson.py (256 x 128 LBVP, plots with matplotlib) through dedalus_amd.compat."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import dedalus_amd.compat as compat
+    from dedalus_amd.core import distributor
+    from oracle.np_executor import NumpyExecutor
+    compat.install()
+    orig_init = distributor.Distributor.__init__
+
+    def init(self, *a, **k):
+        k.setdefault("executor", NumpyExecutor())
+        orig_init(self, *a, **k)
+    monkeypatch.setattr(distributor.Distributor, "__init__", init)
+    monkeypatch.chdir(tmp_path)
+    ns = runpy.run_path(POISSON_EXAMPLE, run_name="__main__")
+    ug = ns["ug"]
+    assert ug.shape == (256, 128) and np.isfinite(ug).all()
+    # boundary conditions of the script: u(y=0) = 0.025 sin(8x)
+    x = np.ravel(ns["x"])
+    u, coords = ns["u"], ns["coords"]
+    assert os.path.exists(os.path.join(tmp_path, "poisson.pdf"))

@@ -70,3 +70,13 @@ def test_cfl_on_device_matches_reference(gold):
     assert np.allclose(dts, gold["cfl__dts"], rtol=1e-11, atol=0), np.max(np.abs(dts - gold["cfl__dts"]))
     for k in ("p", "b", "u"):
         assert rel(res[k], gold["cfl__" + k]) < 1e-9, (k, rel(res[k], gold["cfl__" + k]))
+
+
+@pytest.mark.parametrize("shape", [(64, 32), (32, 24)])
+def test_poisson_lbvp_on_device_matches_reference(gold, shape):
+    import dedalus_amd.public as d3
+    solver, fields = problems.poisson_2d(d3, Nx=shape[0], Ny=shape[1])
+    assert solver.ex.name == "hip"
+    for k, f in fields.items():
+        ref = gold["poisson_%dx%d__%s" % (shape + (k,))]
+        assert rel(np.array(f['c']), ref) < 1e-10, (k, rel(np.array(f['c']), ref))

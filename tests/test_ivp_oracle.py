@@ -23,7 +23,7 @@ def gold(golden_dir):
 
 
 @pytest.mark.parametrize("name", ["kdv64_sbdf2", "kdv64_rk443", "rb2d_32x16_rk222", "rb2d_32x16_sbdf2",
-                                  "rb3d_8x12x8_rk222"])
+                                  "rb3d_8x12x8_rk222", "shear2d_32x64_rk222", "shear2d_32x64_sbdf2"])
 def test_oracle_executor_matches_reference(gold, name):
     import dedalus_amd.public as d3
     from oracle.np_executor import NumpyExecutor
@@ -82,3 +82,14 @@ def test_cfl_timestep_sequence_matches_reference(gold):
     assert np.allclose(dts, gold["cfl__dts"], rtol=1e-12, atol=0)
     for k in ("p", "b", "u"):
         assert rel(res[k], gold["cfl__" + k]) < 1e-10, k
+
+
+@pytest.mark.parametrize("shape", [(64, 32), (32, 24)])
+def test_poisson_lbvp_matches_reference(gold, shape):
+    """examples/lbvp_2d_poisson/poisson.py (tau lifts, Dirichlet + Neumann rows, low-pass filtered forcing)."""
+    import dedalus_amd.public as d3
+    from oracle.np_executor import NumpyExecutor
+    solver, fields = problems.poisson_2d(d3, Nx=shape[0], Ny=shape[1], dist_kw=dict(executor=NumpyExecutor()))
+    for k, f in fields.items():
+        ref = gold["poisson_%dx%d__%s" % (shape + (k,))]
+        assert rel(np.array(f['c']), ref) < 1e-10, (k, rel(np.array(f['c']), ref))
