@@ -79,11 +79,33 @@ class ShellBasis:
 
     @property
     def outer_surface(self):
-        return SphereBasis(self.coordsys.S2coordsys, self.shape[:2], radius=self.radii[1], dealias=self.dealias[:2])
+        return self.S2_basis(self.radii[1])
 
     @property
     def inner_surface(self):
-        return SphereBasis(self.coordsys.S2coordsys, self.shape[:2], radius=self.radii[0], dealias=self.dealias[:2])
+        return self.S2_basis(self.radii[0])
+
+    def S2_basis(self, radius=1):
+        key = ("surf", float(radius))
+        if key not in self._plans:
+            self._plans[key] = SurfaceBasis(self, radius)
+        return self._plans[key]
+
+    def derivative_basis(self, order=1):
+        return self.clone_with(k=self.k + order)
+
+    def clone_with(self, **kw):
+        args = dict(shape=self.shape, radii=self.radii, alpha=self.alpha, dealias=self.dealias, k=self.k)
+        args.update(kw)
+        key = ("clone", args["k"], tuple(args["shape"]))
+        root = getattr(self, "_root", self)
+        if key not in root._plans:
+            b = ShellBasis(self.coordsys, dtype=self.dtype, **args)
+            b._root = root
+            if tuple(args["shape"]) == tuple(root.shape):
+                b.sphere = root.sphere
+            root._plans[key] = b
+        return root._plans[key]
 
     def grid_shape(self, scales):
         return self.sphere.grid_shape(scales[:2]) + (int(np.ceil(scales[2] * self.Nr)),)
@@ -115,7 +137,8 @@ class ShellBasis:
     def colatitude_plan(self, ex, Ntheta_g, rank):
         """grouped SWSH plan over all (component, m) of a rank-`rank` tensor (as SphereBasis.colatitude_plan)"""
         key = ("swsh", id(ex), Ntheta_g, rank)
-        if key not in self._plans:
+        store = getattr(self, "_root", self)._plans        # shared by the derivative bases (same angular part)
+        if key not in store:
             sb = self.sphere
             groups, keys, fwd, bwd, cache = [], [], [], [], {}
             for i, s in enumerate(self.spin_totals(rank)):
@@ -128,8 +151,8 @@ class ShellBasis:
                         keys.append(mk)
                         fwd.append(cache[mk][0])
                         bwd.append(cache[mk][1])
-            self._plans[key] = ex.make_grouped_mmt(Ntheta_g, np.array(groups, dtype=np.int64), keys, fwd, bwd)
-        return self._plans[key]
+            store[key] = ex.make_grouped_mmt(Ntheta_g, np.array(groups, dtype=np.int64), keys, fwd, bwd)
+        return store[key]
 
     def regularity_plan(self, ex, rank):
         """Q(ell) tables on the natural (2 m + part, ell) slots.  Built from the reference's ell_maps of the packed
@@ -137,15 +160,16 @@ class ShellBasis:
         turn, core/basis.py:3595-3626) and gathered to the natural slots, so every mode sees exactly the
         matrix product the reference applies to it."""
         key = ("reg", id(ex), rank)
-        if key not in self._plans:
+        store = getattr(self, "_root", self)._plans
+        if key not in store:
             sb = self.sphere
             slot_p, fwd, bwd = curvilinear.recombination_tables(sb.packed_ell_rows(), sb.packed_shape(), rank)
             rows, cols, ok = sb.pack_index()
             slot = -np.ones((2 * sb.nm, sb.nl), dtype=np.int32)
             slot[rows[ok], cols[ok]] = slot_p[ok]
-            self._plans[key] = (ex.make_recombination(slot, fwd) if rank > 0 else None,
-                                ex.make_recombination(slot, bwd) if rank > 0 else None)
-        return self._plans[key]
+            store[key] = (ex.make_recombination(slot, fwd) if rank > 0 else None,
+                          ex.make_recombination(slot, bwd) if rank > 0 else None)
+        return store[key]
 
     def radial_factor(self, ex, scale, power):
         key = ("fac", id(ex), scale, power)
@@ -177,8 +201,8 @@ class ShellDistributor:
     def Field(self, name=None, bases=None, tensorsig=None, dtype=None):
         if isinstance(bases, (tuple, list)):
             bases = bases[0] if bases else None
-        if not isinstance(bases, ShellBasis):
-            raise NotImplementedError("fields in spherical coordinates need a ShellBasis in this round")
+        if not isinstance(bases, (ShellBasis, SurfaceBasis)):
+            raise NotImplementedError("fields in spherical coordinates need a ShellBasis or one of its surfaces in this round")
         return ShellField(self, bases, rank=len(tensorsig) if tensorsig else 0, name=name)
 
     ScalarField = Field
@@ -200,6 +224,39 @@ class ShellDistributor:
         return phi[:, None, None], theta[None, :, None], r[None, None, :]
 
 
+class SurfaceBasis:
+    """A SphereBasis used by fields of a SphericalCoordinates distributor (shell.outer_surface / inner_surface, tau
+    fields): 3^rank spin components (-, +, 0) per (m, ell), one radial point (core/basis.py SphereBasis with a
+    SphericalCoordinates coordsys, :2683-2686)."""
+
+    def __init__(self, shell, radius):
+        self.shell, self.radius = shell, float(radius)
+        self.sphere = shell.sphere
+        self.dealias = shell.dealias
+        self.Nr = 1
+        self.k = 0
+        self.coordsys = shell.coordsys
+
+    def grid_shape(self, scales):
+        return self.sphere.grid_shape(scales[:2]) + (1,)
+
+    def grids(self, scales):
+        phi, theta = self.sphere.grids(scales[:2])
+        return phi, theta, np.array([self.radius])
+
+    def colatitude_plan(self, ex, Nt, rank):
+        return self.shell.colatitude_plan(ex, Nt, rank)
+
+    def recombination_matrix(self, rank, forward):
+        return self.shell.recombination_matrix(rank, forward)
+
+    def __eq__(self, other):
+        return isinstance(other, SurfaceBasis) and other.shell is self.shell and other.radius == self.radius
+
+    def __hash__(self):
+        return hash((id(self.shell), self.radius))
+
+
 def backward(dist, basis, rank, c, scales):
     """coefficients [nc][2 nm][nl][Nr] (regularity components) -> grid [nc][Nphi_g][Ntheta_g][Nr_g] (coordinate components)"""
     ex = dist.executor
@@ -207,10 +264,13 @@ def backward(dist, basis, rank, c, scales):
     nc = 3 ** rank
     Np, Nt, Ng = basis.grid_shape(scales)
     nslots = nc * 2 * sb.nm * sb.nl
-    t0 = ex.empty((nc, 2 * sb.nm, sb.nl, Ng))
-    ex.transform(basis.radial.plan_spec(scales[2]), basis.radial, "backward", c, t0, nslots, 1)
-    ex.regularity_recombine(t0, basis.regularity_plan(ex, rank)[1],
-                            basis.radial_factor(ex, scales[2], basis.k) if basis.k > 0 else None)
+    if isinstance(basis, SurfaceBasis):
+        t0 = c                                             # spin components, no radial axis
+    else:
+        t0 = ex.empty((nc, 2 * sb.nm, sb.nl, Ng))
+        ex.transform(basis.radial.plan_spec(scales[2]), basis.radial, "backward", c, t0, nslots, 1)
+        ex.regularity_recombine(t0, basis.regularity_plan(ex, rank)[1],
+                                basis.radial_factor(ex, scales[2], basis.k) if basis.k > 0 else None)
     t1 = ex.empty((nc, 2 * sb.nm, Nt, Ng))
     basis.colatitude_plan(ex, Nt, rank).backward(t0.reshape(1, nc * 2 * sb.nm, sb.nl, Ng),
                                                  t1.reshape(1, nc * 2 * sb.nm, Nt, Ng))
@@ -239,6 +299,8 @@ def forward(dist, basis, rank, g, scales):
     t3 = ex.zeros((nc, 2 * sb.nm, sb.nl, Ng))
     basis.colatitude_plan(ex, Nt, rank).forward(t2.reshape(1, nc * 2 * sb.nm, Nt, Ng),
                                                 t3.reshape(1, nc * 2 * sb.nm, sb.nl, Ng))
+    if isinstance(basis, SurfaceBasis):
+        return t3
     ex.regularity_recombine(t3, basis.regularity_plan(ex, rank)[0],
                             basis.radial_factor(ex, scales[2], -basis.k) if basis.k > 0 else None)
     c = ex.empty((nc, 2 * sb.nm, sb.nl, basis.Nr))
@@ -246,8 +308,443 @@ def forward(dist, basis, rank, g, scales):
     return c
 
 
-class ShellField:
-    """Tensor field on a ShellBasis: device-resident data with lazily synchronised host mirrors, `['g']` / `['c']`
+
+# ==================================================================================================
+# ell-dependent radial term lists and operands
+# ==================================================================================================
+
+class NonlinearError(ValueError):
+    pass
+
+
+class EllTermList:
+    """Linear map between shell coefficient arrays: out[co][i1][ell][:] = sum A[ell] in[ci][i1][ell][:], matrices
+    stored as [nl][Nr][Nr] (sphere-surface operands use the leading 1 x Nr / Nr x 1 / 1 x 1 block)."""
+
+    def __init__(self, nco, nci, terms=None):
+        self.nco, self.nci = nco, nci
+        self.terms = list(terms or [])          # (co, ci, mats [nl][Nr][Nr])
+
+    @staticmethod
+    def identity(nc, nl, Nr, nr):
+        m = np.zeros((nl, Nr, Nr))
+        m[:, np.arange(nr), np.arange(nr)] = 1.0
+        return EllTermList(nc, nc, [(c, c, m.copy()) for c in range(nc)])
+
+    def scaled(self, a):
+        return EllTermList(self.nco, self.nci, [(co, ci, a * m) for (co, ci, m) in self.terms])
+
+    def __add__(self, other):
+        assert (self.nco, self.nci) == (other.nco, other.nci)
+        return EllTermList(self.nco, self.nci, self.terms + other.terms).merged()
+
+    def merged(self):
+        acc = {}
+        for (co, ci, m) in self.terms:
+            acc[(co, ci)] = acc[(co, ci)] + m if (co, ci) in acc else np.array(m, dtype=np.float64)
+        return EllTermList(self.nco, self.nci, [(co, ci, m) for (co, ci), m in sorted(acc.items()) if np.any(m != 0)])
+
+    def compose(self, inner):
+        assert self.nci == inner.nco
+        out = []
+        for (co, cm, A) in self.terms:
+            for (cm2, ci, B) in inner.terms:
+                if cm2 == cm:
+                    out.append((co, ci, np.matmul(A, B)))
+        return EllTermList(self.nco, inner.nci, out).merged()
+
+    def embed(self, row0, col0, nrows, ncols):
+        return EllTermList(nrows, ncols, [(co + row0, ci + col0, m) for (co, ci, m) in self.terms])
+
+
+REG = (-1, +1, 0)
+
+
+def reg_indices(rank):
+    return list(np.ndindex(*((3,) * rank)))
+
+
+def regtotal(idx):
+    return sum(REG[a] for a in idx)
+
+
+def regularity_allowed(ell, idx):
+    """RegularityBasis.regularity_allowed (core/basis.py:3531-3535, vectorised form :3585-3593)."""
+    walk = ell
+    for a in idx[::-1]:
+        dr = REG[a]
+        walk = walk + dr
+        if walk < 0 or (dr == 0 and walk == 0):
+            return False
+    return True
+
+
+def spin_allowed(ell, idx):
+    return ell >= abs(sum(REG[a] for a in idx))
+
+
+def shell_op_termlist(kind, shell, rank_in, k, **kw):
+    """Term list of one operator of the reference's SphericalEllOperator family acting on a rank-`rank_in` tensor
+    in the k-th shell basis: lap (core/operators.py:4109-4152), grad (:3240-3288), div (:3546-3600), convert
+    (ConvertSpherical3D, core/basis.py:4822-4842), lift (LiftShell :5155-5199), interp (ShellRadialInterpolate
+    :5823-5889)."""
+    from ..tools import shellops as so
+    sb = shell.sphere
+    nl, Nr, radii, alpha = sb.nl, shell.Nr, shell.radii, shell.alpha
+    idx_in = reg_indices(rank_in)
+
+    def stack(fn, allow_in, allow_out):
+        m = np.zeros((nl, Nr, Nr))
+        for ell in range(nl):
+            if allow_in(ell) and allow_out(ell):
+                a = np.asarray(fn(ell))
+                m[ell, :a.shape[0], :a.shape[1]] = a
+        return m
+
+    terms = []
+    if kind == "lap":
+        for ci, t in enumerate(idx_in):
+            rt = regtotal(t)
+            terms.append((ci, ci, stack(lambda ell: so.operator_matrix("L", ell, rt, Nr, k, radii, alpha),
+                                        lambda ell: regularity_allowed(ell, t), lambda ell: True)))
+        return EllTermList(len(idx_in), len(idx_in), terms)
+    if kind == "convert":
+        dk = kw["dk"]
+        E = so.E_power(Nr, k, dk, radii, alpha)
+        for ci, t in enumerate(idx_in):
+            terms.append((ci, ci, stack(lambda ell: E, lambda ell: regularity_allowed(ell, t), lambda ell: True)))
+        return EllTermList(len(idx_in), len(idx_in), terms)
+    if kind == "grad":
+        idx_out = reg_indices(rank_in + 1)
+        for ci, t in enumerate(idx_in):
+            rt = regtotal(t)
+            for a, (mu, name) in enumerate(((-1, "D-"), (+1, "D+"))):
+                to = (a,) + tuple(t)
+                co = idx_out.index(to)
+                terms.append((co, ci, stack(lambda ell: so.xi(mu, ell + rt) * so.operator_matrix(name, ell, rt, Nr, k, radii, alpha),
+                                            lambda ell: regularity_allowed(ell, t), lambda ell: regularity_allowed(ell, to))))
+        return EllTermList(len(idx_out), len(idx_in), terms)
+    if kind == "div":
+        idx_out = reg_indices(rank_in - 1)
+        for ci, t in enumerate(idx_in):
+            if t[0] == 2:
+                continue
+            rt = regtotal(t)
+            to = tuple(t[1:])
+            co = idx_out.index(to)
+            if t[0] == 0:
+                fn = lambda ell: so.xi(-1, ell + rt + 1) * so.operator_matrix("D+", ell, rt, Nr, k, radii, alpha)
+            else:
+                fn = lambda ell: so.xi(+1, ell + rt - 1) * so.operator_matrix("D-", ell, rt, Nr, k, radii, alpha)
+            terms.append((co, ci, stack(fn, lambda ell: regularity_allowed(ell, t), lambda ell: regularity_allowed(ell, to))))
+        return EllTermList(len(idx_out), len(idx_in), terms)
+    if kind == "lift":               # sphere-surface spin components -> regularity components, radial mode n
+        n = kw["n"]
+        n_idx = n if n >= 0 else Nr + n
+        for co, to in enumerate(idx_in):
+            for ci, ti in enumerate(idx_in):
+                def fn(ell):
+                    q = sph.intertwiner(ell, rank_in)[ci, co] if rank_in else 1.0      # Q^T[co, ci]
+                    a = np.zeros((Nr, 1))
+                    a[n_idx, 0] = q
+                    return a
+                m = stack(fn, lambda ell: spin_allowed(ell, ti), lambda ell: regularity_allowed(ell, to))
+                if np.any(m != 0):
+                    terms.append((co, ci, m))
+        return EllTermList(len(idx_in), len(idx_in), terms)
+    if kind == "interp":             # regularity components -> spin components on the sphere r = position
+        vec = so.interpolation(kw["position"], Nr, k, radii, alpha)
+        for co, to in enumerate(idx_in):
+            for ci, ti in enumerate(idx_in):
+                def fn(ell):
+                    q = sph.intertwiner(ell, rank_in)[co, ci] if rank_in else 1.0      # Q[co, ci]
+                    return q * vec.reshape(1, Nr)
+                m = stack(fn, lambda ell: regularity_allowed(ell, ti), lambda ell: spin_allowed(ell, to))
+                if np.any(m != 0):
+                    terms.append((co, ci, m))
+        return EllTermList(len(idx_in), len(idx_in), terms)
+    raise ValueError(kind)
+
+
+def operate_slot_sequences(sb):
+    """(extra sequences, slot map [2 nm][nl]) for operator EVALUATION: matrix index ell for a slot covered by its own
+    ell_maps box only, nl + j for a slot covered by the boxes listed in seqs[j]; -1 where there is no mode."""
+    key = "operate_slots"
+    if key not in sb._plans:
+        rows_p = sb.packed_ell_rows()
+        ps = sb.packed_shape()
+        cover = [[[] for _ in range(ps[1])] for _ in range(ps[0])]
+        for (ell, i0, i1, j0, j1) in rows_p:
+            for i in range(i0, i1):
+                for j in range(j0, j1):
+                    cover[i][j].append(int(ell))
+        rows, cols, ok = sb.pack_index()
+        slot = -np.ones((2 * sb.nm, sb.nl), dtype=np.int32)
+        seqs, index = [], {}
+        for i in range(ps[0]):
+            for j in range(ps[1]):
+                if not ok[i, j]:
+                    continue
+                r, l = int(rows[i, j]), int(cols[i, j])
+                seq = tuple(cover[i][j])
+                if seq == (l,):
+                    slot[r, l] = l
+                else:
+                    if seq not in index:
+                        index[seq] = len(seqs)
+                        seqs.append(seq)
+                    slot[r, l] = sb.nl + index[seq]
+        sb._plans[key] = (seqs, slot)
+    return sb._plans[key]
+
+
+class ShOperand:
+    """Expression node in spherical coordinates.  basis: ShellBasis (k), SurfaceBasis or None."""
+    __array_priority__ = 100.0
+    __array_ufunc__ = None
+
+    @property
+    def ncomp(self):
+        return 3 ** self.rank
+
+    def __add__(self, other):
+        return ShAdd.make(self, other)
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return ShAdd.make(self, -1 * other if isinstance(other, ShOperand) else -other)
+
+    def __rsub__(self, other):
+        return ShAdd.make(-1 * self, other)
+
+    def __neg__(self):
+        return ShScale(-1.0, self)
+
+    def __mul__(self, other):
+        if isinstance(other, numbers.Number):
+            return ShScale(other, self)
+        raise NotImplementedError("products of shell fields (RHS nonlinearities, NCCs): next round")
+
+    def __rmul__(self, other):
+        if isinstance(other, numbers.Number):
+            return ShScale(other, self)
+        return NotImplemented
+
+    def __truediv__(self, other):
+        if isinstance(other, numbers.Number):
+            return ShScale(1.0 / other, self)
+        return NotImplemented
+
+    def __call__(self, **kw):
+        """T(r=Ri): interpolation along the radius (core/operators.py interpolate dispatch)."""
+        if len(kw) != 1:
+            raise ValueError("one coordinate at a time")
+        (name, pos), = kw.items()
+        if name != self.dist.coordsys.radius.name:
+            raise NotImplementedError("interpolation along %r" % name)
+        return ShLinear("interp", self, position=float(pos))
+
+    def has_dt(self):
+        return any(a.has_dt() for a in getattr(self, "args", ()) if isinstance(a, ShOperand))
+
+    def evaluate(self):
+        f = ShellField(self.dist, self.basis, rank=self.rank)
+        f._set_device_coeff(self.eval_c())
+        return f
+
+
+class ShScale(ShOperand):
+    def __init__(self, a, arg):
+        self.a, self.arg, self.args = float(a), arg, (arg,)
+        self.dist, self.basis, self.rank = arg.dist, arg.basis, arg.rank
+
+    def eval_c(self):
+        ex = self.dist.executor
+        c = self.arg.eval_c()
+        out = ex.empty(tuple(c.shape))
+        ex.lincomb(out, [c], [self.a])
+        return out
+
+    def lin(self, variables):
+        d, dt = self.arg.lin(variables)
+        return {i: t.scaled(self.a) for i, t in d.items()}, dt
+
+
+def _common_basis(a, b):
+    """Sum basis: shells of the same geometry meet in the larger k (core/basis.py ShellBasis.__add__ :4415-4424)."""
+    if isinstance(a.basis, ShellBasis) and isinstance(b.basis, ShellBasis):
+        return a.basis if a.basis.k >= b.basis.k else b.basis
+    if a.basis == b.basis:
+        return a.basis
+    raise NotImplementedError("sum of operands on different bases")
+
+
+def _converted(x, basis):
+    if isinstance(basis, ShellBasis) and x.basis.k != basis.k:
+        return ShLinear("convert", x, dk=basis.k - x.basis.k)
+    return x
+
+
+class ShAdd(ShOperand):
+    @staticmethod
+    def make(a, b):
+        for x, y in ((a, b), (b, a)):
+            if isinstance(x, numbers.Number):
+                if x == 0:
+                    return y
+                raise NotImplementedError("adding a number to a shell field")
+        return ShAdd(a, b)
+
+    def __init__(self, a, b):
+        if a.rank != b.rank:
+            raise ValueError("cannot add tensors of different rank")
+        self.dist, self.rank = a.dist, a.rank
+        self.basis = _common_basis(a, b)
+        self.args = (_converted(a, self.basis), _converted(b, self.basis))
+
+    def eval_c(self):
+        ex = self.dist.executor
+        cs = [x.eval_c() for x in self.args]
+        out = ex.empty(tuple(cs[0].shape))
+        ex.lincomb(out, cs, [1.0, 1.0])
+        return out
+
+    def lin(self, variables):
+        out, anydt = {}, None
+        for x in self.args:
+            d, dt = x.lin(variables)
+            if anydt is None:
+                anydt = dt
+            elif anydt != dt:
+                raise NonlinearError("dt and non-dt terms inside one sum node")
+            for i, t in d.items():
+                out[i] = out[i] + t if i in out else t
+        return out, bool(anydt)
+
+
+class ShLinear(ShOperand):
+    """lap / grad / div / convert / lift / interp of an operand."""
+
+    def __init__(self, kind, arg, **kw):
+        if not isinstance(arg, ShOperand):
+            raise ValueError("%s needs a field operand" % kind)
+        self.kind, self.arg, self.args, self.kw = kind, arg, (arg,), kw
+        self.dist = arg.dist
+        ab = arg.basis
+        if kind in ("lap", "grad", "div", "convert", "interp") and not isinstance(ab, ShellBasis):
+            raise NotImplementedError("%s of an operand without a shell basis" % kind)
+        if kind == "lap":
+            self.basis, self.rank = ab.derivative_basis(2), arg.rank
+        elif kind == "grad":
+            self.basis, self.rank = ab.derivative_basis(1), arg.rank + 1
+        elif kind == "div":
+            if arg.rank < 1:
+                raise ValueError("div needs a tensor of rank >= 1")
+            self.basis, self.rank = ab.derivative_basis(1), arg.rank - 1
+        elif kind == "convert":
+            self.basis, self.rank = ab.derivative_basis(kw["dk"]), arg.rank
+        elif kind == "interp":
+            self.basis, self.rank = ab.S2_basis(kw["position"]), arg.rank
+        elif kind == "lift":
+            if not isinstance(ab, SurfaceBasis):
+                raise NotImplementedError("Lift of an operand that is not a surface field")
+            self.basis, self.rank = kw["basis"], arg.rank
+        else:
+            raise ValueError(kind)
+        self._dev = None
+
+    @property
+    def shell(self):
+        b = self.arg.basis
+        return b.shell if isinstance(b, SurfaceBasis) else b
+
+    def termlist(self):
+        kw = {k: v for k, v in self.kw.items() if k != "basis"}
+        k = self.kw["basis"].k if self.kind == "lift" else self.arg.basis.k
+        shell = self.kw["basis"] if self.kind == "lift" else self.shell
+        return shell_op_termlist(self.kind, shell, self.arg.rank, k, **kw)
+
+    def eval_c(self):
+        ex = self.dist.executor
+        shell = self.shell
+        sb = shell.sphere
+        if self._dev is None or self._dev[0] is not ex:
+            # evaluation follows SphericalEllOperator.operate (core/operators.py:3132-3160), which loops over the
+            # ell_maps bounding boxes and ACCUMULATES: a slot covered by several boxes receives the sum of their
+            # matrices (the per-group subproblem matrices used by the solvers do not have this overlap)
+            tl = self.termlist()
+            seqs, slot_map = operate_slot_sequences(sb)
+            terms = [(co, ci, np.concatenate([m] + [sum(m[l] for l in seq)[None] for seq in seqs])) for (co, ci, m) in tl.terms]
+            self._dev = (ex, ex.make_ell_terms(sb.nm, sb.nl, shell.Nr, tl.nco, terms, slot_map))
+        x = _padded(ex, self.arg.eval_c(), shell.Nr)
+        y = ex.empty((self.ncomp, 2 * sb.nm, sb.nl, shell.Nr))
+        self._dev[1].apply(x, y)
+        return _unpadded(ex, y, self.basis.Nr)
+
+    def lin(self, variables):
+        d, dt = self.arg.lin(variables)
+        tl = self.termlist()
+        return {i: tl.compose(t) for i, t in d.items()}, dt
+
+
+class ShDt(ShOperand):
+    def __init__(self, arg):
+        self.arg, self.args = arg, (arg,)
+        self.dist, self.basis, self.rank = arg.dist, arg.basis, arg.rank
+
+    def has_dt(self):
+        return True
+
+    def lin(self, variables):
+        d, dt = self.arg.lin(variables)
+        if dt:
+            raise NonlinearError("nested time derivatives")
+        return d, True
+
+    def eval_c(self):
+        raise ValueError("dt() cannot be evaluated")
+
+
+def _padded(ex, c, Nr):
+    """[nc][2 nm][nl][nr] -> [nc][2 nm][nl][Nr] (surface operands have nr = 1)"""
+    if int(c.shape[-1]) == Nr:
+        return c
+    out = ex.zeros(tuple(c.shape[:-1]) + (Nr,))
+    ex.assign(out[..., :int(c.shape[-1])], c)
+    return out
+
+
+def _unpadded(ex, c, nr):
+    if int(c.shape[-1]) == nr:
+        return c
+    out = ex.empty(tuple(c.shape[:-1]) + (nr,))
+    ex.assign(out, c[..., :nr])
+    return out
+
+
+def lap(a):
+    return ShLinear("lap", a)
+
+
+def grad(a):
+    return ShLinear("grad", a)
+
+
+def div(a):
+    return ShLinear("div", a)
+
+
+def dt(a):
+    return ShDt(a)
+
+
+def Lift(a, basis, n):
+    return ShLinear("lift", a, basis=basis, n=int(n))
+
+
+class ShellField(ShOperand):
+    """Tensor field on a ShellBasis (or one of its surfaces): device-resident data with lazily synchronised host mirrors, `['g']` / `['c']`
     in the reference's shapes (packed (m, ell) coefficient layout, core/basis.py:2839-2891)."""
 
     def __init__(self, dist, basis, rank=0, name=None):
@@ -261,14 +758,39 @@ class ShellField:
         self._host_layout = None
         self._host_scales = None
         self._authority = "device"
+        self.args = ()
 
     @property
-    def ncomp(self):
-        return 3 ** self.rank
+    def shell(self):
+        return self.basis.shell if isinstance(self.basis, SurfaceBasis) else self.basis
+
+    @property
+    def k(self):
+        return self.basis.k
 
     @property
     def tensorsig(self):
         return (self.dist.coordsys,) * self.rank
+
+    # ---- expression protocol ---------------------------------------------------------------------------------------
+    def eval_c(self):
+        return self.require_coeff_space()
+
+    def lin(self, variables):
+        for i, v in enumerate(variables):
+            if v is self:
+                sb = self.basis.sphere
+                return {i: EllTermList.identity(self.ncomp, sb.nl, self.shell.Nr, self.basis.Nr)}, False
+        raise NonlinearError("%r is not a problem variable" % (self,))
+
+    def has_dt(self):
+        return False
+
+    def evaluate(self):
+        return self
+
+    def __repr__(self):
+        return self.name or "<ShellField %d>" % id(self)
 
     @property
     def ex(self):
@@ -277,6 +799,12 @@ class ShellField:
     def _cshape(self):
         sb = self.basis.sphere
         return (self.ncomp, 2 * sb.nm, sb.nl, self.basis.Nr)
+
+    def _set_device_coeff(self, c):
+        self._c = c
+        self.layout = "c"
+        self._authority = "device"
+        self._g = None
 
     def _user_shape(self, layout, scales):
         t = (3,) * self.rank
@@ -385,3 +913,298 @@ class ShellField:
             self._host = host
         self._host_layout, self._host_scales = layout, self.scales
         self._authority = "host"
+
+
+# ==================================================================================================
+# problems and solvers (per-ell systems)
+# ==================================================================================================
+
+class ShellProblem:
+    def __init__(self, variables, namespace=None, time="t"):
+        self.variables = list(variables)
+        self.dist = self.variables[0].dist
+        shells = [v.shell for v in self.variables]
+        self.shell = getattr(shells[0], "_root", shells[0])
+        self.equations = []
+        self.namespace = dict(lap=lap, grad=grad, div=div, dt=dt, Lift=Lift, lift=Lift, Laplacian=lap, Gradient=grad,
+                              Divergence=div, TimeDerivative=dt, np=np, numpy=np)
+        if namespace:
+            self.namespace.update(namespace)
+        for v in self.variables:
+            if v.name:
+                self.namespace[v.name] = v
+
+    def _parse(self, side):
+        if isinstance(side, (ShOperand, numbers.Number)):
+            return side
+        return eval(side, dict(self.namespace))
+
+    def add_equation(self, equation, condition=None):
+        from .problems import _split_equation
+        if isinstance(equation, str):
+            lhs_s, rhs_s = _split_equation(equation)
+            lhs, rhs = self._parse(lhs_s), self._parse(rhs_s)
+        else:
+            lhs, rhs = [self._parse(x) for x in equation]
+        if not isinstance(lhs, ShOperand):
+            raise ValueError("LHS must involve the problem variables")
+        if isinstance(rhs, ShOperand) and rhs.has_dt():
+            raise ValueError("time derivatives must be on the LHS")
+        M, L = self._linearize(lhs)
+        if isinstance(rhs, numbers.Number):
+            F = None if rhs == 0 else float(rhs)
+        else:
+            if rhs.rank != lhs.rank:
+                raise ValueError("LHS and RHS tensor signatures differ")
+            F = _converted(rhs, lhs.basis) if isinstance(lhs.basis, ShellBasis) else rhs
+        eq = dict(lhs=lhs, basis=lhs.basis, rank=lhs.rank, ncomp=lhs.ncomp, M=M, L=L, F=F,
+                  string=equation if isinstance(equation, str) else None)
+        self.equations.append(eq)
+        return eq
+
+    def _linearize(self, lhs):
+        terms = []
+
+        def flatten(node, scale):
+            if isinstance(node, ShAdd):
+                for a in node.args:
+                    flatten(a, scale)
+            elif isinstance(node, ShScale):
+                flatten(node.arg, scale * node.a)
+            else:
+                terms.append((scale, node))
+        flatten(lhs, 1.0)
+        M, L = {}, {}
+        for scale, node in terms:
+            try:
+                d, isdt = node.lin(self.variables)
+            except NonlinearError as e:
+                raise ValueError("LHS must be linear in the problem variables: %s" % e)
+            tgt = M if isdt else L
+            for i, tl in d.items():
+                tl = tl.scaled(scale)
+                tgt[i] = tgt[i] + tl if i in tgt else tl
+        return M, L
+
+    def build_solver(self, *args, **kw):
+        return self.solver_class(self, *args, **kw)
+
+
+class ShellIVP(ShellProblem):
+    @property
+    def solver_class(self):
+        return ShellInitialValueSolver
+
+
+class ShellLBVP(ShellProblem):
+    @property
+    def solver_class(self):
+        return ShellBoundaryValueSolver
+
+
+class _EllPack:
+    def __init__(self):
+        self.mats = []
+
+    def add(self, dev):
+        self.mats.append(dev)
+        return len(self.mats) - 1
+
+    def matvec(self, mid, x, y):
+        self.mats[mid].apply(x, y)
+
+
+def _valid_modes(basis, rank, nl, Nr):
+    """[ncomp][nl][Nr] validity of (component, ell, n): regularity components of a shell field, spin components of
+    a surface field (n = 0 only)."""
+    out = np.zeros((3 ** rank, nl, Nr), dtype=bool)
+    for c, idx in enumerate(reg_indices(rank)):
+        for ell in range(nl):
+            if isinstance(basis, SurfaceBasis):
+                out[c, ell, 0] = spin_allowed(ell, idx)
+            else:
+                out[c, ell, :] = regularity_allowed(ell, idx)
+    return out
+
+
+class ShellSolverBase:
+    """Per-ell systems: the matrices depend on ell only (matrix_dependence of the reference), every
+    (m, part) slot of that ell is a right-hand-side column.  System vectors are [R][2 nm][nl][Nr]."""
+
+    def __init__(self, problem):
+        self.problem, self.dist = problem, problem.dist
+        self.ex = self.dist.executor
+        self.shell = shell = problem.shell
+        self.variables = problem.variables
+        sb = shell.sphere
+        self.nm, self.nl, self.Nr = sb.nm, sb.nl, shell.Nr
+        self.col0, c = [], 0
+        for v in self.variables:
+            self.col0.append(c)
+            c += v.ncomp
+        self.R = c
+        self.row0, r = [], 0
+        for eq in problem.equations:
+            self.row0.append(r)
+            r += eq["ncomp"]
+        if r != c:
+            raise ValueError("the problem is not square: %d equation components for %d variable components" % (r, c))
+        self.nx, self.ny = 2 * self.nm, self.nl * self.Nr          # timestepper buffers: (R, nx, ny) elements
+        self.col_valid = np.concatenate([_valid_modes(v.basis, v.rank, self.nl, self.Nr) for v in self.variables])
+        self.row_valid = np.concatenate([_valid_modes(eq["basis"], eq["rank"], self.nl, self.Nr)
+                                         for eq in problem.equations])
+        self.M_tl = self._system_termlist("M")
+        self.L_tl = self._system_termlist("L")
+        self.pack = _EllPack()
+        mk = lambda tl: self.ex.make_ell_terms(self.nm, self.nl, self.Nr, self.R, tl.terms)
+        self.M_id = self.pack.add(_Reshaped(self, mk(self.M_tl)))
+        self.L_id = self.pack.add(_Reshaped(self, mk(self.L_tl)))
+        self.X = self.ex.zeros((self.R, self.nx, self.ny))
+        self.X4 = self.X.reshape(self.R, 2 * self.nm, self.nl, self.Nr)
+
+    def _system_termlist(self, which):
+        tl = EllTermList(self.R, self.R, [])
+        for eq, r0 in zip(self.problem.equations, self.row0):
+            for i, t in eq[which].items():
+                tl.terms += t.embed(r0, self.col0[i], self.R, self.R).terms
+        tl = tl.merged()
+        out = []
+        for (co, ci, m) in tl.terms:
+            out.append((co, ci, m * self.row_valid[co][:, :, None] * self.col_valid[ci][:, None, :]))
+        return EllTermList(self.R, self.R, out).merged()
+
+    def _dense(self, tl, ell):
+        A = np.zeros((self.R * self.Nr, self.R * self.Nr))
+        for (co, ci, m) in tl.terms:
+            A[co * self.Nr:(co + 1) * self.Nr, ci * self.Nr:(ci + 1) * self.Nr] += m[ell]
+        return A
+
+    def _inverse_terms(self, a, b):
+        """Per-ell inverse of (a M + b L) on the valid modes as a device term list (blocks of the dense inverses)."""
+        inv = np.zeros((self.nl, self.R * self.Nr, self.R * self.Nr))
+        for ell in range(self.nl):
+            A = a * self._dense(self.M_tl, ell) + b * self._dense(self.L_tl, ell)
+            rv = self.row_valid[:, ell, :].reshape(-1)
+            cv = self.col_valid[:, ell, :].reshape(-1)
+            if rv.sum() != cv.sum():
+                raise ValueError("ell = %d: %d valid equation modes for %d valid variable modes" % (ell, rv.sum(), cv.sum()))
+            if rv.any():
+                inv[ell][np.ix_(cv, rv)] = np.linalg.inv(A[np.ix_(rv, cv)])
+        terms = []
+        Nr = self.Nr
+        for co in range(self.R):
+            for ci in range(self.R):
+                blk = inv[:, co * Nr:(co + 1) * Nr, ci * Nr:(ci + 1) * Nr]
+                if np.any(blk != 0):
+                    terms.append((co, ci, np.ascontiguousarray(blk)))
+        return _Reshaped(self, self.ex.make_ell_terms(self.nm, self.nl, self.Nr, self.R, terms))
+
+    # ---- state <-> variables -----------------------------------------------------------------------------------------
+    def sync_state_to_device(self):
+        for v, c0 in zip(self.variables, self.col0):
+            c = v.require_coeff_space()
+            self.ex.assign(self.X4[c0:c0 + v.ncomp, :, :, :v.basis.Nr], c)
+
+    def mark_state_current(self):
+        for v, c0 in zip(self.variables, self.col0):
+            c = self.ex.empty(v._cshape())
+            self.ex.assign(c, self.X4[c0:c0 + v.ncomp, :, :, :v.basis.Nr])
+            v._set_device_coeff(c)
+
+    def evaluate_F(self, out):
+        ex = self.ex
+        ex.fill_zero(out)
+        out4 = out.reshape(self.R, 2 * self.nm, self.nl, self.Nr)
+        for eq, r0 in zip(self.problem.equations, self.row0):
+            F = eq["F"]
+            if F is None:
+                continue
+            nr = eq["basis"].Nr
+            if isinstance(F, float):
+                # constant right-hand side of a scalar equation (e.g. "T(r=Ri) = 1"): the ell = 0 mode, sqrt(2) amplitude
+                if eq["rank"] != 0:
+                    raise NotImplementedError("constant right-hand side of a tensor equation")
+                col = np.zeros((1, 2 * self.nm, self.nl, nr))
+                col[0, 0, 0, 0] = F / SphereBasis.constant_mode_value * \
+                    (1.0 if isinstance(eq["basis"], SurfaceBasis) else 1.0 / self._radial_constant(eq["basis"]))
+                ex.assign(out4[r0:r0 + 1, :, :, :nr], ex.from_host(col))
+            else:
+                ex.assign(out4[r0:r0 + eq["ncomp"], :, :, :nr], F.eval_c())
+
+    def _radial_constant(self, basis):
+        from ..tools import jacobi
+        return float(jacobi.polynomials(1, basis.k + basis.alpha[0], basis.k + basis.alpha[1], np.array([0.0]))[0, 0])
+
+
+class _Reshaped:
+    """device term list applied to the timesteppers' (R, nx, ny) buffers"""
+
+    def __init__(self, solver, dev):
+        self.solver, self.dev = solver, dev
+
+    def apply(self, x, y):
+        s = self.solver
+        shape = (s.R, 2 * s.nm, s.nl, s.Nr)
+        self.dev.apply(x.reshape(shape), y.reshape(shape))
+
+
+class ShellBoundaryValueSolver(ShellSolverBase):
+    def __init__(self, problem, **kw):
+        super().__init__(problem)
+        if self.M_tl.terms:
+            raise ValueError("LBVP equations cannot contain time derivatives")
+        self._inv = None
+
+    def solve(self):
+        if self._inv is None:
+            self._inv = self._inverse_terms(0.0, 1.0)
+        F = self.ex.zeros((self.R, self.nx, self.ny))
+        self.evaluate_F(F)
+        self._inv.apply(F, self.X)
+        self.mark_state_current()
+
+
+class ShellInitialValueSolver(ShellSolverBase):
+    """IMEX timestepping of M.dt(X) + L.X = F in a shell with the shared schemes of core/timesteppers.py."""
+
+    def __init__(self, problem, timestepper, **kw):
+        super().__init__(problem)
+        import time as _time
+        from . import timesteppers as ts
+        from .solvers import _HandlerRegistry
+        if isinstance(timestepper, str):
+            timestepper = ts.schemes[timestepper]
+        self.sim_time = self.initial_sim_time = 0.0
+        self.iteration = self.initial_iteration = 0
+        self.stop_sim_time = self.stop_wall_time = np.inf
+        self.stop_iteration = np.inf
+        self.dt = None
+        self._lus = []
+        self.timestepper = timestepper(self)
+        self.start_time = _time.time()
+        self.evaluator = _HandlerRegistry(self)
+
+    def factor(self, a, b, reuse=-1):
+        inv = self._inverse_terms(a, b)
+        if reuse is not None and reuse >= 0:
+            self._lus[reuse] = inv
+            return reuse
+        self._lus.append(inv)
+        return len(self._lus) - 1
+
+    def solve(self, lu, rhs, x):
+        self._lus[lu].apply(rhs, x)
+
+    def step(self, dt):
+        if not np.isfinite(dt):
+            raise ValueError("Invalid timestep: %r" % dt)
+        self.dt = dt
+        self.timestepper.step(dt, 0.0)
+        self.iteration += 1
+
+    @property
+    def proceed(self):
+        return self.sim_time < self.stop_sim_time and self.iteration < self.stop_iteration
+
+    def log_stats(self, format=".4g"):
+        pass

@@ -159,6 +159,54 @@ cgemv_batch_kernel(const double *__restrict__ x, double *__restrict__ y, const l
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ell-dependent radial operators of shell fields (csrc of core/shell.py): fields are
+// [component][2 m + part][ell][n]; a term maps component ci to co through a real matrix A_t[ell] (n_out x n_in),
+// the same for every m and part:  y[co][i1][ell][:] = sum_t A_t[ell] x[ci_t][i1][ell][:].
+// This is SphericalEllOperator.operate / subproblem_matrix (core/operators.py:3108-3222: per (m, ell)
+// apply_matrix of a radial matrix in a Python loop over ell_maps) for all slots in one launch, and -- with
+// the per-ell LHS inverses as the matrices -- the per-ell solve of the shell's subproblems.
+constexpr HandleKind H_ELLT = (HandleKind)7;
+
+struct EllTerms : HandleBase {
+    int nm = 0, nl = 0, nr = 0, ncomp_out = 0, nterms = 0, nmat = 0;
+    int *d_meta = nullptr;       // [nterms][2]: co, ci (sorted by co)
+    int *d_first = nullptr;      // [ncomp_out + 1]
+    int *d_slot = nullptr;       // [2 nm][nl]: matrix index of the slot, -1: no mode
+    double *d_mats = nullptr;    // [nterms][nmat][n_in][n_out]  (transposed: threads run along n_out)
+    ~EllTerms() override {
+        (void)hipFree(d_meta);
+        (void)hipFree(d_first);
+        (void)hipFree(d_slot);
+        (void)hipFree(d_mats);
+    }
+};
+
+__global__ void __launch_bounds__(256)
+ell_terms_kernel(const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ meta,
+                 const int *__restrict__ first, const int *__restrict__ slot_map, const double *__restrict__ mats, int nm,
+                 int nl, int nr, int nmat, int ncomp_out) {
+    const int l = blockIdx.x, i1 = blockIdx.y;
+    const long slot = ((long)i1 * nl + l) * nr;
+    const long cstride = 2L * nm * nl * nr;
+    const int mid = slot_map[i1 * nl + l];           // matrix of this slot; -1: (m, ell) carries no mode
+    const bool live = mid >= 0;
+    for (int co = 0; co < ncomp_out; ++co) {
+        for (int no = threadIdx.x; no < nr; no += blockDim.x) {
+            double acc = 0.0;
+            if (live) {
+                for (int t = first[co]; t < first[co + 1]; ++t) {
+                    const int ci = meta[2 * t + 1];
+                    const double *A = mats + (((long)t * nmat + mid) * nr) * nr + no;
+                    const double *xv = x + ci * cstride + slot;
+                    for (int ni = 0; ni < nr; ++ni) acc += A[(long)ni * nr] * xv[ni];
+                }
+            }
+            y[co * cstride + slot + no] = acc;
+        }
+    }
+}
+
 }  // namespace ddh
 
 using namespace ddh;
@@ -224,6 +272,61 @@ int ddh_sphere_terms_apply(ddh_handle h, const double *x, double *y, void *strea
     const dim3 grid((unsigned)((p->nl + 255) / 256), (unsigned)p->nm), block(256);
     hipLaunchKernelGGL(sphere_terms_kernel, grid, block, 0, as_stream(stream), x, y, p->d_meta, p->d_first, p->d_coef,
                        p->nm, p->nl, p->ncomp_out);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_ell_terms_create(ddh_handle *h, int nm, int nl, int nr, int ncomp_out, int nterms, const int *co_h,
+                         const int *ci_h, int nmat, const double *mats_h, const int *slot_map_h) {
+    if (nm < 1 || nl < 1 || nr < 1 || ncomp_out < 1 || nterms < 0 || nmat < 1) return fail("ell_terms_create: bad sizes");
+    for (long i = 0; i < 2L * nm * nl; ++i)
+        if (slot_map_h[i] >= nmat) return fail("ell_terms_create: slot map points past the matrices");
+    EllTerms *p = new EllTerms();
+    p->kind = H_ELLT;
+    p->nm = nm; p->nl = nl; p->nr = nr; p->ncomp_out = ncomp_out; p->nterms = nterms; p->nmat = nmat;
+    std::vector<int> meta(2 * (size_t)(nterms > 0 ? nterms : 1)), first(ncomp_out + 1, 0);
+    for (int t = 0; t < nterms; ++t) {
+        if (co_h[t] < 0 || co_h[t] >= ncomp_out || (t > 0 && co_h[t] < co_h[t - 1])) {
+            delete p;
+            return fail("ell_terms_create: terms must be sorted by output component");
+        }
+        meta[2 * t] = co_h[t]; meta[2 * t + 1] = ci_h[t];
+        first[co_h[t] + 1] = t + 1;
+    }
+    for (int c = 0; c < ncomp_out; ++c)
+        if (first[c + 1] < first[c]) first[c + 1] = first[c];
+    const size_t per = (size_t)nmat * nr * nr;
+    const size_t mb = (size_t)(nterms > 0 ? nterms : 1) * per * sizeof(double);
+    // transpose every matrix to [n_in][n_out]
+    std::vector<double> tr((size_t)(nterms > 0 ? nterms : 1) * per, 0.0);
+    for (size_t t = 0; t < (size_t)nterms; ++t)
+        for (size_t l = 0; l < (size_t)nmat; ++l)
+            for (int i = 0; i < nr; ++i)
+                for (int j = 0; j < nr; ++j)
+                    tr[(t * nmat + l) * nr * nr + (size_t)j * nr + i] = mats_h[(t * nmat + l) * nr * nr + (size_t)i * nr + j];
+    if (check_hip(hipMalloc((void **)&p->d_meta, meta.size() * sizeof(int)), "hipMalloc") ||
+        check_hip(hipMalloc((void **)&p->d_first, first.size() * sizeof(int)), "hipMalloc") ||
+        check_hip(hipMalloc((void **)&p->d_mats, mb), "hipMalloc") ||
+        check_hip(hipMalloc((void **)&p->d_slot, 2L * nm * nl * sizeof(int)), "hipMalloc") ||
+        check_hip(hipMemcpy(p->d_slot, slot_map_h, 2L * nm * nl * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy") ||
+        check_hip(hipMemcpy(p->d_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy") ||
+        check_hip(hipMemcpy(p->d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy") ||
+        check_hip(hipMemcpy(p->d_mats, tr.data(), mb, hipMemcpyHostToDevice), "hipMemcpy")) {
+        delete p;
+        return -2;
+    }
+    *h = register_handle(p);
+    return 0;
+}
+
+int ddh_ell_terms_apply(ddh_handle h, const double *x, double *y, void *stream) {
+    EllTerms *p = (EllTerms *)lookup_handle(h, H_ELLT);
+    if (!p) return -1;
+    if (x == y) return fail("ell_terms_apply: in-place unsupported");
+    const int T = p->nr >= 256 ? 256 : (p->nr > 64 ? 128 : 64);
+    const dim3 grid((unsigned)p->nl, (unsigned)(2 * p->nm)), block(T);
+    hipLaunchKernelGGL(ell_terms_kernel, grid, block, 0, as_stream(stream), x, y, p->d_meta, p->d_first, p->d_slot,
+                       p->d_mats, p->nm, p->nl, p->nr, p->nmat, p->ncomp_out);
     DDH_HIP(hipGetLastError());
     return 0;
 }

@@ -210,6 +210,11 @@ class HipExecutor:
         """terms: list of (co, ci, d, coef complex [nm][nl]) -> device term list (ddh_sphere_terms_create)."""
         return SphereTerms(self, nm, nl, ncomp_out, terms)
 
+    def make_ell_terms(self, nm, nl, nr, ncomp_out, terms, slot_map=None):
+        """terms: list of (co, ci, mats [nmat][nr][nr]); slot_map [2 nm][nl] -> matrix index or -1 (default: ell where
+        ell >= m) -> device radial operator (ddh_ell_terms_create)."""
+        return EllTerms(self, nm, nl, nr, ncomp_out, terms, slot_map)
+
     def make_cgemv_batch(self, nm, nl, ncomp, mats):
         """mats: per m a complex (n_m, n_m) array, n_m = ncomp * max(nl - m, 0)."""
         return CgemvBatch(self, nm, nl, ncomp, mats)
@@ -271,6 +276,36 @@ class SphereTerms:
 
     def apply(self, x, y):
         libhip.call("ddh_sphere_terms_apply", self.handle, ptr(x), ptr(y), self.ex.dev.stream)
+
+    def __del__(self):
+        try:
+            libhip.call("ddh_destroy", self.handle)
+        except Exception:
+            pass
+
+
+def default_slot_map(nm, nl):
+    i1, ell = np.indices((2 * nm, nl))
+    return np.where(i1 // 2 <= ell, ell, -1).astype(np.int32)
+
+
+class EllTerms:
+    def __init__(self, ex, nm, nl, nr, ncomp_out, terms, slot_map=None):
+        self.ex = ex
+        terms = sorted(terms, key=lambda t: t[0])
+        co = np.ascontiguousarray([t[0] for t in terms], dtype=np.int32)
+        ci = np.ascontiguousarray([t[1] for t in terms], dtype=np.int32)
+        nmat = int(terms[0][2].shape[0]) if terms else nl
+        mats = np.zeros((max(len(terms), 1), nmat, nr, nr))
+        for i, t in enumerate(terms):
+            mats[i] = t[2]
+        sm = np.ascontiguousarray(default_slot_map(nm, nl) if slot_map is None else slot_map, dtype=np.int32)
+        self.handle = C.c_uint64(0)
+        libhip.call("ddh_ell_terms_create", C.byref(self.handle), int(nm), int(nl), int(nr), int(ncomp_out), len(terms),
+                    libhip.as_ip(co), libhip.as_ip(ci), nmat, libhip.as_dp(mats), libhip.as_ip(sm))
+
+    def apply(self, x, y):
+        libhip.call("ddh_ell_terms_apply", self.handle, ptr(x), ptr(y), self.ex.dev.stream)
 
     def __del__(self):
         try:

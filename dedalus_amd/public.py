@@ -35,9 +35,13 @@ def Distributor(coordsystems, *args, **kw):
 def _dispatch(name, cart):
     sph = getattr(_sphere, name)
 
+    shl = getattr(_shell, name, None)
+
     def f(operand, *args, **kw):
         if isinstance(operand, _sphere.SOperand):
             return sph(operand, *args, **kw)
+        if shl is not None and isinstance(operand, _shell.ShOperand):
+            return shl(operand, *args, **kw)
         return cart(operand, *args, **kw)
     f.__name__ = name
     return f
@@ -49,13 +53,26 @@ MulCosine = _sphere.MulCosine
 _CartesianIVP, _CartesianLBVP = IVP, LBVP
 
 
+_CartesianLift = Lift
+
+
+def Lift(operand, *args, **kw):
+    if isinstance(operand, _shell.ShOperand):
+        return _shell.Lift(operand, *args, **kw)
+    return _CartesianLift(operand, *args, **kw)
+
+
 def IVP(variables, *args, **kw):
+    if isinstance(variables[0], _shell.ShOperand):
+        return _shell.ShellIVP(variables, *args, **kw)
     if isinstance(variables[0], _sphere.SOperand):
         return _sphere.SphereIVP(variables, *args, **kw)
     return _CartesianIVP(variables, *args, **kw)
 
 
 def LBVP(variables, *args, **kw):
+    if isinstance(variables[0], _shell.ShOperand):
+        return _shell.ShellLBVP(variables, *args, **kw)
     if isinstance(variables[0], _sphere.SOperand):
         return _sphere.SphereLBVP(variables, *args, **kw)
     return _CartesianLBVP(variables, *args, **kw)

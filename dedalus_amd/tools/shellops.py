@@ -53,6 +53,19 @@ def E(N, k, radii, alpha=(-0.5, -0.5)):
     return 0.5 * (conversion(N + 1, a, b) @ _zrect(N, a, b, rho))[:N, :N]
 
 
+def E_power(N, k, dk, radii, alpha=(-0.5, -0.5)):
+    """E^dk: k -> k + dk (ShellRadialBasis.conversion_matrix, core/basis.py:3868-3872).  Each factor raises the
+    polynomial degree by one, so the product runs through rectangular (N+j+1) x (N+j) factors and is truncated
+    to N x N only at the end, like the reference's operator algebra."""
+    dR = radii[1] - radii[0]
+    rho = (radii[1] + radii[0]) / dR
+    M = np.eye(N)
+    for j in range(dk):
+        a, b = k + j + alpha[0], k + j + alpha[1]
+        M = 0.5 * (conversion(N + j + 1, a, b) @ _zrect(N + j, a, b, rho)) @ M
+    return M[:N, :N]
+
+
 def R(N, k, radii, alpha=(-0.5, -0.5)):
     """'R': multiplication by r within the same k (truncated to N x N)."""
     dR = radii[1] - radii[0]

@@ -151,6 +151,14 @@ int ddh_sphere_terms_apply(ddh_handle h, const double *x, double *y, void *strea
  * 126-149 / timesteppers.py:630-643).  mats_h: the nm row-major complex matrices concatenated.          */
 int ddh_cgemv_batch_create(ddh_handle *h, int nm, int nl, int ncomp, const double *mats_h);
 int ddh_cgemv_batch_apply(ddh_handle h, const double *x, double *y, void *stream);
+/* Shell fields [component][2 m + part][ell][n]: y[co][i1][ell][:] = sum_t A_t[id] x[ci_t][i1][ell][:] with real
+ * radial matrices (nr x nr, row major in mats_h [nterms][nmat][nr][nr]) selected per slot by
+ * id = slot_map_h[i1 * nl + ell] (-1: the slot carries no mode and is zeroed; normally id = ell).  Replaces
+ * SphericalEllOperator.operate / subproblem_matrix (core/operators.py:3108-3222) and, with the per-ell LHS inverses
+ * as matrices, the per-ell subproblem solves.  Terms sorted by co.                                              */
+int ddh_ell_terms_create(ddh_handle *h, int nm, int nl, int nr, int ncomp_out, int nterms, const int *co_h,
+                         const int *ci_h, int nmat, const double *mats_h, const int *slot_map_h);
+int ddh_ell_terms_apply(ddh_handle h, const double *x, double *y, void *stream);
 
 /* ---- grid-space and vector kernels -------------------------------- */
 /* y[idx[i]] += vals[i] for n distinct indices (device arrays): the constant right-hand-side entries

@@ -284,6 +284,15 @@ def golden_shellfields():
             out[tag + "r%d__cout" % rank] = np.array(f['c'])
         phi, theta, r = dist.local_grids(shell)
         out[tag + "r_grid"] = np.ravel(r)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import problems
+    for ts in ("SBDF2", "RK222"):
+        solver, res = problems.run_shell_heat(d3, steps=5, timestepper=ts)
+        for k, v in res.items():
+            out["heat_%s__%s" % (ts, k)] = v
+        print("shell heat", ts, {k: float(np.linalg.norm(v)) for k, v in res.items()})
+    for k, v in problems.shell_operator_results(d3).items():
+        out["shellops__" + k] = v
     np.savez_compressed(os.path.join(GOLD, "shellfields.npz"), **out)
     print("wrote shellfields.npz with", len(out), "arrays")
 

@@ -236,6 +236,23 @@ class NumpyExecutor:
                 y[:, 1::2, :] = out.imag
         return _Terms()
 
+    def make_ell_terms(self, nm, nl, nr, ncomp_out, terms, slot_map=None):
+        """SphericalEllOperator.operate (core/operators.py:3132-3160): per slot its radial matrix applied along n"""
+        if slot_map is None:
+            i1, ell = np.indices((2 * nm, nl))
+            slot_map = np.where(i1 // 2 <= ell, ell, -1)
+        sm = np.asarray(slot_map)
+        live = sm >= 0
+
+        class _Terms:
+            def apply(self_, x, y):
+                out = np.zeros((ncomp_out, 2 * nm, nl, nr))
+                for (co, ci, mats) in terms:
+                    per_slot = mats[np.where(live, sm, 0)]                  # [2 nm][nl][nr][nr]
+                    out[co] += np.einsum("alij,alj->ali", per_slot, x[ci])
+                y[...] = out * live[None, :, :, None]
+        return _Terms()
+
     def make_cgemv_batch(self, nm, nl, ncomp, mats):
         mats = [np.asarray(a, dtype=complex) for a in mats]
 

@@ -315,3 +315,59 @@ def run_shallow_water(d3, steps=5, **kw):
         res[k + "__g"] = np.array(f['g'])
         res[k + "__c"] = np.array(f['c'])
     return solver, res
+
+
+# ---- spherical shell ----------------------------------------------------------------
+
+def shell_heat(d3, shape=(16, 12, 10), timestepper="SBDF2", dist_kw=None):
+    """Heat equation in a spherical shell with tau lifts and Dirichlet conditions on both spheres: the scalar core of
+    the reference's shell-convection example (examples/ivp_shell_convection/shell_convection.py:41-77) in second-order
+    form, as in examples/lbvp_2d_poisson/poisson.py:55-57."""
+    Ri, Ro, kappa = 0.7, 1.9, 0.05
+    coords = d3.SphericalCoordinates('phi', 'theta', 'r')
+    dist = d3.Distributor(coords, dtype=np.float64, **(dist_kw or {}))
+    shell = d3.ShellBasis(coords, shape=shape, radii=(Ri, Ro), dealias=3 / 2, dtype=np.float64)
+    sphere = shell.outer_surface
+    T = dist.Field(name='T', bases=shell)
+    tau1 = dist.Field(name='tau1', bases=sphere)
+    tau2 = dist.Field(name='tau2', bases=sphere)
+    lift_basis = shell.derivative_basis(2)
+    lift = lambda A, n: d3.Lift(A, lift_basis, n)
+    phi, theta, r = dist.local_grids(shell)
+    problem = d3.IVP([T, tau1, tau2], namespace=locals())
+    problem.add_equation("dt(T) - kappa*lap(T) + lift(tau1,-1) + lift(tau2,-2) = 0")
+    problem.add_equation("T(r=Ri) = 0")
+    problem.add_equation("T(r=Ro) = 0")
+    solver = problem.build_solver(getattr(d3, timestepper))
+    T['g'] = (r - Ri) * (Ro - r) * (1 + 0.5 * np.sin(theta) * np.cos(phi) + 0.3 * np.cos(theta) * r
+                                    + 0.2 * np.sin(theta) ** 2 * np.sin(2 * phi))
+    return solver, dict(T=T, tau1=tau1, tau2=tau2)
+
+
+def run_shell_heat(d3, steps=5, dt=0.01, **kw):
+    solver, fields = shell_heat(d3, **kw)
+    for _ in range(steps):
+        solver.step(dt)
+    res = {}
+    for k, f in fields.items():
+        res[k + "__c"] = np.array(f['c'])
+    fields["T"].change_scales(1)
+    res["T__g"] = np.array(fields["T"]['g'])
+    return solver, res
+
+
+def shell_operator_results(d3, shape=(16, 12, 8), dist_kw=None):
+    """lap / grad / div of a smooth scalar field in the shell (evaluated, coefficient data)."""
+    Ri, Ro = 0.7, 1.9
+    coords = d3.SphericalCoordinates('phi', 'theta', 'r')
+    dist = d3.Distributor(coords, dtype=np.float64, **(dist_kw or {}))
+    shell = d3.ShellBasis(coords, shape=shape, radii=(Ri, Ro), dealias=3 / 2, dtype=np.float64)
+    T = dist.Field(name='T', bases=shell)
+    phi, theta, r = dist.local_grids(shell)
+    x, y, z = r * np.sin(theta) * np.cos(phi), r * np.sin(theta) * np.sin(phi), r * np.cos(theta) + 0 * phi
+    T['g'] = 1 / r + 0.3 * x * y + 0.2 * z * z * x - 0.5 * y + 0.1 * x * x * z / r
+    exprs = dict(lap_T=d3.lap(T), grad_T=d3.grad(T), div_grad_T=d3.div(d3.grad(T)), T_inner=T(r=Ri), T_outer=T(r=Ro))
+    res = {"T__c": np.array(T['c'])}
+    for k, e in exprs.items():
+        res[k + "__c"] = np.array(e.evaluate()['c'])
+    return res
