@@ -85,6 +85,14 @@ class ShellBasis:
     def inner_surface(self):
         return self.S2_basis(self.radii[0])
 
+    @property
+    def radial_basis(self):
+        """Tag for fields that depend on the radius only (NCCs: er, rvec; core/basis.py ShellRadialBasis)."""
+        key = ("radial",)
+        if key not in self._plans:
+            self._plans[key] = RadialBasis(self)
+        return self._plans[key]
+
     def S2_basis(self, radius=1):
         key = ("surf", float(radius))
         if key not in self._plans:
@@ -201,9 +209,16 @@ class ShellDistributor:
     def Field(self, name=None, bases=None, tensorsig=None, dtype=None):
         if isinstance(bases, (tuple, list)):
             bases = bases[0] if bases else None
+        rank = len(tensorsig) if tensorsig else 0
+        if bases is None:
+            if rank:
+                raise NotImplementedError("constant tensor fields in spherical coordinates")
+            return ConstField(self, name=name)
+        if isinstance(bases, RadialBasis):
+            return RadialField(self, bases.shell, rank=rank, name=name)
         if not isinstance(bases, (ShellBasis, SurfaceBasis)):
-            raise NotImplementedError("fields in spherical coordinates need a ShellBasis or one of its surfaces in this round")
-        return ShellField(self, bases, rank=len(tensorsig) if tensorsig else 0, name=name)
+            raise NotImplementedError("fields in spherical coordinates need a ShellBasis, one of its surfaces or its radial basis")
+        return ShellField(self, bases, rank=rank, name=name)
 
     ScalarField = Field
 
@@ -222,6 +237,12 @@ class ShellDistributor:
             scales = (scales,) * 3
         phi, theta, r = basis.grids(scales)
         return phi[:, None, None], theta[None, :, None], r[None, None, :]
+
+
+class RadialBasis:
+    def __init__(self, shell):
+        self.shell = shell
+        self.k = shell.k
 
 
 class SurfaceBasis:
@@ -438,6 +459,36 @@ def shell_op_termlist(kind, shell, rank_in, k, **kw):
                 fn = lambda ell: so.xi(+1, ell + rt - 1) * so.operator_matrix("D-", ell, rt, Nr, k, radii, alpha)
             terms.append((co, ci, stack(fn, lambda ell: regularity_allowed(ell, t), lambda ell: regularity_allowed(ell, to))))
         return EllTermList(len(idx_out), len(idx_in), terms)
+    if kind == "trace":              # SphericalTrace (core/operators.py:1783-1826): Q_out^T trace_spin Q_in, identity in n
+        if rank_in != 2:
+            raise NotImplementedError("trace of a rank-%d tensor" % rank_in)
+        tr = np.zeros(9)
+        tr[[1, 3, 8]] = 1.0
+        for ci, t in enumerate(idx_in):
+            def fn(ell, ci=ci):
+                return float(tr @ sph.intertwiner(ell, 2)[:, ci]) * np.eye(Nr)
+            m = stack(fn, lambda ell: regularity_allowed(ell, t), lambda ell: True)
+            if np.any(m != 0):
+                terms.append((0, ci, m))
+        return EllTermList(1, len(idx_in), terms)
+    if kind == "integ":              # IntegrateShell (core/basis.py:5555-5575): ell = 0 only -> a constant
+        from ..tools import jacobi
+        z0, w0 = jacobi.quadrature(2 * Nr, 0, 0)
+        z0, w0 = np.asarray(z0, dtype=np.float64), np.asarray(w0, dtype=np.float64)
+        dR = radii[1] - radii[0]
+        r0 = dR / 2 * (z0 + (radii[1] + radii[0]) / dR)
+        Qk = np.asarray(jacobi.polynomials(Nr, alpha[0] + k, alpha[1] + k, z0))
+        row = (r0 ** 2 * w0 * (r0 / dR) ** (-k)) @ Qk.T * (dR / 2) * (4 * np.pi / np.sqrt(2))
+        m = np.zeros((nl, Nr, Nr))
+        m[0, 0, :] = row
+        return EllTermList(1, 1, [(0, 0, m)])
+    if kind == "convert_const":      # ConvertConstantShell (core/basis.py:4782-4819): constant -> ell = 0, k-th basis
+        from ..tools import jacobi
+        cmv = float(np.asarray(jacobi.polynomials(1, alpha[0], alpha[1], np.array([0.0])))[0, 0]) / np.sqrt(2)
+        col = so.E_power(Nr, 0, k, radii, alpha)[:, 0] / cmv
+        m = np.zeros((nl, Nr, Nr))
+        m[0, :, 0] = col
+        return EllTermList(1, 1, [(0, 0, m)])
     if kind == "lift":               # sphere-surface spin components -> regularity components, radial mode n
         n = kw["n"]
         n_idx = n if n >= 0 else Nr + n
@@ -524,12 +575,20 @@ class ShOperand:
     def __mul__(self, other):
         if isinstance(other, numbers.Number):
             return ShScale(other, self)
-        raise NotImplementedError("products of shell fields (RHS nonlinearities, NCCs): next round")
+        if isinstance(other, ShOperand):
+            return ShProduct(self, other)
+        return NotImplemented
 
     def __rmul__(self, other):
         if isinstance(other, numbers.Number):
             return ShScale(other, self)
         return NotImplemented
+
+    def __matmul__(self, other):
+        return ShProduct(self, other, contract=True)
+
+    def eval_g(self):
+        return _eval_grid(self)
 
     def __truediv__(self, other):
         if isinstance(other, numbers.Number):
@@ -548,6 +607,10 @@ class ShOperand:
     def has_dt(self):
         return any(a.has_dt() for a in getattr(self, "args", ()) if isinstance(a, ShOperand))
 
+    def grid_native(self):
+        """Grid data when the operand is formed in grid space (products), else None."""
+        return None
+
     def evaluate(self):
         f = ShellField(self.dist, self.basis, rank=self.rank)
         f._set_device_coeff(self.eval_c())
@@ -558,6 +621,15 @@ class ShScale(ShOperand):
     def __init__(self, a, arg):
         self.a, self.arg, self.args = float(a), arg, (arg,)
         self.dist, self.basis, self.rank = arg.dist, arg.basis, arg.rank
+
+    def grid_native(self):
+        g = self.arg.grid_native()
+        if g is None:
+            return None
+        ex = self.dist.executor
+        out = ex.empty(tuple(g.shape))
+        ex.lincomb(out, [g], [self.a])
+        return out
 
     def eval_c(self):
         ex = self.dist.executor
@@ -575,12 +647,18 @@ def _common_basis(a, b):
     """Sum basis: shells of the same geometry meet in the larger k (core/basis.py ShellBasis.__add__ :4415-4424)."""
     if isinstance(a.basis, ShellBasis) and isinstance(b.basis, ShellBasis):
         return a.basis if a.basis.k >= b.basis.k else b.basis
+    if a.basis is None and isinstance(b.basis, ShellBasis):
+        return b.basis
+    if b.basis is None and isinstance(a.basis, ShellBasis):
+        return a.basis
     if a.basis == b.basis:
         return a.basis
     raise NotImplementedError("sum of operands on different bases")
 
 
 def _converted(x, basis):
+    if isinstance(basis, ShellBasis) and x.basis is None:
+        return ShLinear("convert_const", x, basis=basis)
     if isinstance(basis, ShellBasis) and x.basis.k != basis.k:
         return ShLinear("convert", x, dk=basis.k - x.basis.k)
     return x
@@ -632,7 +710,7 @@ class ShLinear(ShOperand):
         self.kind, self.arg, self.args, self.kw = kind, arg, (arg,), kw
         self.dist = arg.dist
         ab = arg.basis
-        if kind in ("lap", "grad", "div", "convert", "interp") and not isinstance(ab, ShellBasis):
+        if kind in ("lap", "grad", "div", "convert", "interp", "trace", "integ") and not isinstance(ab, ShellBasis):
             raise NotImplementedError("%s of an operand without a shell basis" % kind)
         if kind == "lap":
             self.basis, self.rank = ab.derivative_basis(2), arg.rank
@@ -646,6 +724,14 @@ class ShLinear(ShOperand):
             self.basis, self.rank = ab.derivative_basis(kw["dk"]), arg.rank
         elif kind == "interp":
             self.basis, self.rank = ab.S2_basis(kw["position"]), arg.rank
+        elif kind == "trace":
+            self.basis, self.rank = ab, arg.rank - 2
+        elif kind == "integ":
+            if arg.rank:
+                raise NotImplementedError("integ of a tensor")
+            self.basis, self.rank = None, 0
+        elif kind == "convert_const":
+            self.basis, self.rank = kw["basis"], 0
         elif kind == "lift":
             if not isinstance(ab, SurfaceBasis):
                 raise NotImplementedError("Lift of an operand that is not a surface field")
@@ -656,19 +742,26 @@ class ShLinear(ShOperand):
 
     @property
     def shell(self):
+        if self.kind in ("lift", "convert_const"):
+            return self.kw["basis"]
         b = self.arg.basis
         return b.shell if isinstance(b, SurfaceBasis) else b
 
     def termlist(self):
         kw = {k: v for k, v in self.kw.items() if k != "basis"}
-        k = self.kw["basis"].k if self.kind == "lift" else self.arg.basis.k
-        shell = self.kw["basis"] if self.kind == "lift" else self.shell
-        return shell_op_termlist(self.kind, shell, self.arg.rank, k, **kw)
+        k = self.kw["basis"].k if self.kind in ("lift", "convert_const") else self.arg.basis.k
+        return shell_op_termlist(self.kind, self.shell, self.arg.rank, k, **kw)
 
     def eval_c(self):
         ex = self.dist.executor
         shell = self.shell
         sb = shell.sphere
+        if self.kind == "convert":
+            # Convert.operate (core/operators.py:1627-1638): an argument that sits in grid space is copied and then
+            # transformed straight into the output basis; only coefficient-space arguments see the E matrices
+            g = self.arg.grid_native()
+            if g is not None:
+                return forward(self.dist, self.basis, self.rank, g, self.basis.dealias)
         if self._dev is None or self._dev[0] is not ex:
             # evaluation follows SphericalEllOperator.operate (core/operators.py:3132-3160), which loops over the
             # ell_maps bounding boxes and ACCUMULATES: a slot covered by several boxes receives the sum of their
@@ -680,7 +773,10 @@ class ShLinear(ShOperand):
         x = _padded(ex, self.arg.eval_c(), shell.Nr)
         y = ex.empty((self.ncomp, 2 * sb.nm, sb.nl, shell.Nr))
         self._dev[1].apply(x, y)
-        return _unpadded(ex, y, self.basis.Nr)
+        return _unpadded(ex, y, self.basis.Nr if self.basis is not None else 1)
+
+    def eval_g(self):
+        return _eval_grid(self)
 
     def lin(self, variables):
         d, dt = self.arg.lin(variables)
@@ -723,8 +819,142 @@ def _unpadded(ex, c, nr):
     return out
 
 
+def _eval_grid(x):
+    """grid data [nc][Nphi_g][Ntheta_g][Nr_g] of an operand at the dealias scales"""
+    return backward(x.dist, x.basis, x.rank, x.eval_c(), x.basis.dealias)
+
+
+class ShProduct(ShOperand):
+    """a * b (tensor product) or a @ b (contraction of the last index of a with the first of b).  With a radial NCC
+    (RadialField) as one factor the product is linear in the other one (LHS terms: rvec*lift(tau), b*er); otherwise
+    it is evaluated on the dealiased grid (MultiplyFields / DotProduct, core/arithmetic.py:586-674)."""
+
+    def __init__(self, a, b, contract=False):
+        self.args, self.contract = (a, b), contract
+        self.dist = a.dist
+        if contract and (a.rank < 1 or b.rank < 1):
+            raise ValueError("dot product needs tensors of rank >= 1")
+        self.rank = a.rank + b.rank - (2 if contract else 0)
+        ncc = [x for x in (a, b) if isinstance(x, RadialField)]
+        other = [x for x in (a, b) if not isinstance(x, RadialField)]
+        if len(ncc) == 1:
+            self.basis = other[0].basis              # k_ncc = 0: the operand's basis
+        elif not ncc:
+            if not (isinstance(a.basis, ShellBasis) and isinstance(b.basis, ShellBasis)):
+                raise NotImplementedError("grid products of operands without shell bases")
+            self.basis = a.basis.clone_with(k=a.basis.k + b.basis.k)
+        else:
+            raise NotImplementedError("product of two radial fields")
+
+    def grid_native(self):
+        """grid data of the product at the dealias scales (the layout the product is formed in)"""
+        a, b = self.args
+        if isinstance(a, RadialField) or isinstance(b, RadialField):
+            raise NotImplementedError("evaluation of NCC products (they are LHS terms)")
+        ex = self.dist.executor
+        ga, gb = a.eval_g(), b.eval_g()
+        terms, nout = _bilinear_terms3(a.rank, b.rank, self.contract)
+        Np, Nt, Ng = self.basis.grid_shape(self.basis.dealias)
+        out = ex.empty((nout, Np, Nt, Ng))
+        ex.bilinear(out, nout, ga, gb, Np * Nt * Ng, terms)
+        return out
+
+    def eval_c(self):
+        return forward(self.dist, self.basis, self.rank, self.grid_native(), self.basis.dealias)
+
+    def eval_g(self):
+        return self.grid_native()
+
+    def lin(self, variables):
+        a, b = self.args
+        if isinstance(a, RadialField):
+            ncc, arg, ncc_first = a, b, True
+        elif isinstance(b, RadialField):
+            ncc, arg, ncc_first = b, a, False
+        else:
+            raise NonlinearError("products of fields are nonlinear")
+        if not isinstance(arg.basis, ShellBasis):
+            raise NotImplementedError("NCC product with an operand that has no shell basis")
+        d, isdt = arg.lin(variables)
+        tl = ncc_termlist(ncc, arg.basis, arg.rank, ncc_first, self.contract)
+        return {i: tl.compose(t) for i, t in d.items()}, isdt
+
+
+def _bilinear_terms3(rank_a, rank_b, contract):
+    ia_list = list(np.ndindex(*((3,) * rank_a)))
+    ib_list = list(np.ndindex(*((3,) * rank_b)))
+    out_list = list(np.ndindex(*((3,) * (rank_a + rank_b - (2 if contract else 0)))))
+    terms = []
+    for ia, ta in enumerate(ia_list):
+        for ib, tb in enumerate(ib_list):
+            if contract:
+                if ta[-1] != tb[0]:
+                    continue
+                tc = tuple(ta[:-1]) + tuple(tb[1:])
+            else:
+                tc = tuple(ta) + tuple(tb)
+            terms.append((out_list.index(tc), ia, ib, 1.0))
+    return terms, len(out_list)
+
+
+def ncc_termlist(ncc, arg_basis, rank_arg, ncc_first, contract):
+    """LHS matrix blocks of a product with a radial NCC (Basis._last_axis_field_ncc_matrix, core/basis.py:283-330, with
+    ShellRadialBasis._last_axis_component_ncc_matrix :3879-3910): block (gamma <- beta) at ell =
+    sum_alpha Gamma_ell[alpha, beta, gamma] * Mult(a_alpha), Mult = multiplication by the NCC's regularity component
+    alpha as a function of r in the operand's Jacobi family (exact Gauss quadrature; the reference's Clenshaw sum
+    of the same polynomial)."""
+    from ..tools import jacobi
+    shell = arg_basis
+    sb = shell.sphere
+    nl, Nr, k = sb.nl, shell.Nr, arg_basis.k
+    a_fam, b_fam = k + shell.alpha[0], k + shell.alpha[1]
+    # NCC regularity components as functions of z: coefficients in the k = 0 family, evaluated at the quadrature nodes
+    coef = ncc.regularity_coefficients()                     # [3^rank_ncc][Nr]
+    nq = Nr + coef.shape[1] + 2
+    zq, wq = jacobi.quadrature(nq, a_fam, b_fam)
+    zq, wq = np.asarray(zq, dtype=np.float64), np.asarray(wq, dtype=np.float64)
+    P = np.asarray(jacobi.polynomials(Nr, a_fam, b_fam, zq))                         # [Nr][nq]
+    P0 = np.asarray(jacobi.polynomials(coef.shape[1], shell.alpha[0], shell.alpha[1], zq))
+    mult = []
+    for alpha_c in range(coef.shape[0]):
+        f = coef[alpha_c] @ P0
+        mult.append((P * (wq * f)) @ P.T if np.any(np.abs(coef[alpha_c]) > 1e-14) else None)
+    rank_ncc = ncc.rank
+    rank_out = rank_ncc + rank_arg - (2 if contract else 0)
+    idx_arg, idx_out = reg_indices(rank_arg), reg_indices(rank_out)
+    acc = {}
+    for ell in range(nl):
+        if ncc_first:
+            G = gamma_regularity(rank_ncc, rank_arg, 0, ell, ell, contract)          # [alpha, beta, gamma]
+        else:
+            G = gamma_regularity(rank_arg, rank_ncc, ell, 0, ell, contract).transpose(1, 0, 2)
+        if np.abs(G.imag).max() > 1e-12:
+            raise NotImplementedError("complex product coefficients for real fields")
+        G = G.real
+        for be, tb in enumerate(idx_arg):
+            if not regularity_allowed(ell, tb):
+                continue
+            for ga, tg in enumerate(idx_out):
+                if not regularity_allowed(ell, tg):
+                    continue
+                for al in range(G.shape[0]):
+                    if mult[al] is None or abs(G[al, be, ga]) <= 1e-6:             # ncc_cutoff of the reference
+                        continue
+                    m = acc.setdefault((ga, be), np.zeros((nl, Nr, Nr)))
+                    m[ell] += G[al, be, ga] * mult[al]
+    return EllTermList(len(idx_out), len(idx_arg), [(co, ci, m) for (co, ci), m in sorted(acc.items())])
+
+
 def lap(a):
     return ShLinear("lap", a)
+
+
+def trace(a):
+    return ShLinear("trace", a)
+
+
+def integ(a, *coords):
+    return ShLinear("integ", a)
 
 
 def grad(a):
@@ -741,6 +971,89 @@ def dt(a):
 
 def Lift(a, basis, n):
     return ShLinear("lift", a, basis=basis, n=int(n))
+
+
+class ConstField(ShOperand):
+    """A field without bases in a SphericalCoordinates distributor (tau_p): one number."""
+
+    def __init__(self, dist, name=None):
+        self.dist, self.name, self.basis, self.rank = dist, name, None, 0
+        self.value = np.zeros((1, 1, 1))
+        self.args = ()
+
+    def __repr__(self):
+        return self.name or "<ConstField %d>" % id(self)
+
+    def __getitem__(self, key):
+        return self.value
+
+    def __setitem__(self, key, data):
+        self.value[...] = data
+
+    def change_scales(self, scales):
+        pass
+
+    def has_dt(self):
+        return False
+
+    def lin(self, variables):
+        for i, v in enumerate(variables):
+            if v is self:
+                shell = [x.shell for x in variables if hasattr(x, "shell")][0]
+                sb = shell.sphere
+                return {i: EllTermList.identity(1, sb.nl, getattr(shell, "_root", shell).Nr, 1)}, False
+        raise NonlinearError("%r is not a problem variable" % (self,))
+
+    def eval_c(self):
+        raise NotImplementedError("constants are converted to a shell basis before evaluation")
+
+    # solver interface
+    def _cshape_in(self, shell):
+        sb = shell.sphere
+        return (1, 2 * sb.nm, sb.nl, 1)
+
+
+class RadialField(ShOperand):
+    """Tensor field that depends on r only (NCC: er, rvec): coordinate components on the radial Gauss grid, kept on the
+    host (it only enters the LHS matrices)."""
+
+    def __init__(self, dist, shell, rank=0, name=None):
+        self.dist, self.shell_basis, self.rank, self.name = dist, shell, rank, name
+        self.basis = shell
+        self.args = ()
+        self._g = np.zeros((3,) * rank + (1, 1, shell.Nr))
+
+    def __getitem__(self, key):
+        if key not in ("g", "grid"):
+            raise NotImplementedError("coefficient access of radial fields")
+        return self._g
+
+    def __setitem__(self, key, data):
+        self._g[...] = data
+
+    def has_dt(self):
+        return False
+
+    def lin(self, variables):
+        raise NonlinearError("a radial field is a coefficient, not a variable")
+
+    def regularity_coefficients(self):
+        """[3^rank][Nr]: Jacobi (k = 0 family) coefficients of the regularity components at ell = 0."""
+        from ..tools import jacobi
+        shell = self.shell_basis
+        nc = 3 ** self.rank
+        g = self._g.reshape(nc, shell.Nr)
+        if self.rank:
+            U = SphericalCoordinates.U_forward(self.rank)
+            spin = U @ g
+            if np.abs(spin.imag).max() > 1e-14:
+                raise NotImplementedError("radial NCC with angular components")
+            reg = sph.intertwiner(0, self.rank).T @ spin.real
+        else:
+            reg = g
+        z, w = jacobi.quadrature(shell.Nr, shell.alpha[0], shell.alpha[1])
+        P = np.asarray(jacobi.polynomials(shell.Nr, shell.alpha[0], shell.alpha[1], z))
+        return reg @ (P * np.asarray(w, dtype=np.float64)).T
 
 
 class ShellField(ShOperand):
@@ -914,6 +1227,25 @@ class ShellField(ShOperand):
         self._host_layout, self._host_scales = layout, self.scales
         self._authority = "host"
 
+    def fill_random(self, layout=None, scales=None, seed=None, chunk_size=2 ** 20, distribution="standard_normal", **kw):
+        """The reference's reproducible global random stream (core/field.py:898-943, tools/random_arrays.py:7-55)."""
+        if scales is not None:
+            self.change_scales(scales)
+        layout = "c" if (layout or self.layout) in ("c", "coeff") else "g"
+        shape = self._user_shape(layout, self.scales)
+        n = int(np.prod(shape))
+        cs = min(n, chunk_size)
+        rng = np.random.default_rng(seed)
+        draw = getattr(rng, distribution)
+        out = np.empty(n)
+        pos = 0
+        while pos < n:
+            chunk = draw(size=cs, **kw)
+            m = min(cs, n - pos)
+            out[pos:pos + m] = chunk[:m]
+            pos += m
+        self[layout] = out.reshape(shape)
+
 
 # ==================================================================================================
 # problems and solvers (per-ell systems)
@@ -923,11 +1255,12 @@ class ShellProblem:
     def __init__(self, variables, namespace=None, time="t"):
         self.variables = list(variables)
         self.dist = self.variables[0].dist
-        shells = [v.shell for v in self.variables]
+        shells = [v.shell for v in self.variables if hasattr(v, "shell")]
         self.shell = getattr(shells[0], "_root", shells[0])
         self.equations = []
-        self.namespace = dict(lap=lap, grad=grad, div=div, dt=dt, Lift=Lift, lift=Lift, Laplacian=lap, Gradient=grad,
-                              Divergence=div, TimeDerivative=dt, np=np, numpy=np)
+        self.namespace = dict(lap=lap, grad=grad, div=div, dt=dt, Lift=Lift, lift=Lift, trace=trace, integ=integ,
+                              Laplacian=lap, Gradient=grad, Divergence=div, TimeDerivative=dt, Trace=trace,
+                              Integrate=integ, np=np, numpy=np)
         if namespace:
             self.namespace.update(namespace)
         for v in self.variables:
@@ -1018,6 +1351,9 @@ def _valid_modes(basis, rank, nl, Nr):
     """[ncomp][nl][Nr] validity of (component, ell, n): regularity components of a shell field, spin components of
     a surface field (n = 0 only)."""
     out = np.zeros((3 ** rank, nl, Nr), dtype=bool)
+    if basis is None:                       # constants: the (ell = 0, n = 0) mode only
+        out[0, 0, 0] = True
+        return out
     for c, idx in enumerate(reg_indices(rank)):
         for ell in range(nl):
             if isinstance(basis, SurfaceBasis):
@@ -1102,11 +1438,19 @@ class ShellSolverBase:
     # ---- state <-> variables -----------------------------------------------------------------------------------------
     def sync_state_to_device(self):
         for v, c0 in zip(self.variables, self.col0):
+            if isinstance(v, ConstField):
+                col = np.zeros((1, 2 * self.nm, self.nl, 1))
+                col[0, 0, 0, 0] = float(v.value.reshape(-1)[0])
+                self.ex.assign(self.X4[c0:c0 + 1, :, :, :1], self.ex.from_host(col))
+                continue
             c = v.require_coeff_space()
             self.ex.assign(self.X4[c0:c0 + v.ncomp, :, :, :v.basis.Nr], c)
 
     def mark_state_current(self):
         for v, c0 in zip(self.variables, self.col0):
+            if isinstance(v, ConstField):
+                v.value[...] = float(np.asarray(self.ex.download(self.X4[c0:c0 + 1, 0:1, 0:1, 0:1])).reshape(-1)[0])
+                continue
             c = self.ex.empty(v._cshape())
             self.ex.assign(c, self.X4[c0:c0 + v.ncomp, :, :, :v.basis.Nr])
             v._set_device_coeff(c)
@@ -1119,7 +1463,7 @@ class ShellSolverBase:
             F = eq["F"]
             if F is None:
                 continue
-            nr = eq["basis"].Nr
+            nr = eq["basis"].Nr if eq["basis"] is not None else 1
             if isinstance(F, float):
                 # constant right-hand side of a scalar equation (e.g. "T(r=Ri) = 1"): the ell = 0 mode, sqrt(2) amplitude
                 if eq["rank"] != 0:
@@ -1200,7 +1544,16 @@ class ShellInitialValueSolver(ShellSolverBase):
             raise ValueError("Invalid timestep: %r" % dt)
         self.dt = dt
         self.timestepper.step(dt, 0.0)
+        # Hermitian-symmetry enforcement of the reference (core/solvers.py:675-681, 704-708): the state makes a round
+        # trip through the dealiased grid during the first `steps` iterations of every cadence
+        if self.enforce_real_cadence and self.iteration % self.enforce_real_cadence < self.timestepper.steps:
+            for v in self.variables:
+                if isinstance(v, ShellField):
+                    v.require_grid_space(v.basis.dealias)
+                    v.require_coeff_space()
         self.iteration += 1
+
+    enforce_real_cadence = 100
 
     @property
     def proceed(self):
@@ -1208,3 +1561,38 @@ class ShellInitialValueSolver(ShellSolverBase):
 
     def log_stats(self, format=".4g"):
         pass
+
+
+# ==================================================================================================
+# products with radial non-constant coefficients (NCCs) on the LHS
+# ==================================================================================================
+
+def gamma_regularity(rank_a, rank_b, ell_a, ell_b, ell_c, contract=False):
+    """Gamma[alpha, beta, gamma]: regularity components of a product, out_gamma = sum Gamma a_alpha b_beta
+    (Product.Gamma, core/arithmetic.py:560-580: the coordinate-component product tensor carried through the spin
+    intertwiner U and the regularity intertwiners Q(ell) of the three operands).  contract: DotProduct of the last
+    index of a with the first of b (GammaCoord :649-664), else the tensor product (MultiplyFields)."""
+    ia_list = reg_indices(rank_a)
+    ib_list = reg_indices(rank_b)
+    rank_c = rank_a + rank_b - (2 if contract else 0)
+    ic_list = reg_indices(rank_c)
+    G = np.zeros((len(ia_list), len(ib_list), len(ic_list)), dtype=complex)
+    for ia, a in enumerate(ia_list):
+        for ib, b in enumerate(ib_list):
+            if contract:
+                if a[-1] != b[0]:
+                    continue
+                c = tuple(a[:-1]) + tuple(b[1:])
+            else:
+                c = tuple(a) + tuple(b)
+            G[ia, ib, ic_list.index(c)] = 1.0
+    # coordinate -> spin components
+    UA = np.conj(SphericalCoordinates.U_forward(rank_a))
+    UB = np.conj(SphericalCoordinates.U_forward(rank_b))
+    UC = SphericalCoordinates.U_forward(rank_c)
+    G = np.einsum("ai,bj,ck,ijk->abc", UA, UB, UC, G)
+    # spin -> regularity components
+    QA = sph.intertwiner(ell_a, rank_a).T if rank_a else np.eye(1)
+    QB = sph.intertwiner(ell_b, rank_b).T if rank_b else np.eye(1)
+    QC = sph.intertwiner(ell_c, rank_c).T if rank_c else np.eye(1)
+    return np.einsum("ai,bj,ck,ijk->abc", QA, QB, QC, G)

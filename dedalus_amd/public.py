@@ -33,12 +33,11 @@ def Distributor(coordsystems, *args, **kw):
 
 
 def _dispatch(name, cart):
-    sph = getattr(_sphere, name)
-
+    sph = getattr(_sphere, name, None)
     shl = getattr(_shell, name, None)
 
     def f(operand, *args, **kw):
-        if isinstance(operand, _sphere.SOperand):
+        if sph is not None and isinstance(operand, _sphere.SOperand):
             return sph(operand, *args, **kw)
         if shl is not None and isinstance(operand, _shell.ShOperand):
             return shl(operand, *args, **kw)
@@ -47,8 +46,9 @@ def _dispatch(name, cart):
     return f
 
 
-grad, div, lap, skew, ave, dt = (_dispatch(n, c) for n, c in (("grad", grad), ("div", div), ("lap", lap),
-                                                               ("skew", skew), ("ave", ave), ("dt", dt)))
+grad, div, lap, skew, ave, dt, trace, integ = (_dispatch(n, c) for n, c in (
+    ("grad", grad), ("div", div), ("lap", lap), ("skew", skew), ("ave", ave), ("dt", dt), ("trace", trace),
+    ("integ", integ)))
 MulCosine = _sphere.MulCosine
 _CartesianIVP, _CartesianLBVP = IVP, LBVP
 

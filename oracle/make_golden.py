@@ -293,6 +293,11 @@ def golden_shellfields():
         print("shell heat", ts, {k: float(np.linalg.norm(v)) for k, v in res.items()})
     for k, v in problems.shell_operator_results(d3).items():
         out["shellops__" + k] = v
+    for ts in ("SBDF2", "RK222"):
+        solver, res = problems.run_shell_convection(d3, steps=4, timestepper=ts)
+        for k, v in res.items():
+            out["conv_%s__%s" % (ts, k)] = v
+        print("shell convection", ts, {k: float(np.linalg.norm(v)) for k, v in res.items()})
     np.savez_compressed(os.path.join(GOLD, "shellfields.npz"), **out)
     print("wrote shellfields.npz with", len(out), "arrays")
 

@@ -371,3 +371,55 @@ def shell_operator_results(d3, shape=(16, 12, 8), dist_kw=None):
     for k, e in exprs.items():
         res[k + "__c"] = np.array(e.evaluate()['c'])
     return res
+
+
+def shell_convection(d3, shape=(16, 12, 8), timestepper="SBDF2", dist_kw=None):
+    """The reference's example examples/ivp_shell_convection/shell_convection.py:31-91 (Boussinesq convection in a
+    spherical shell: first-order tau formulation with radial NCCs, no-slip fixed-temperature walls, pressure gauge),
+    parameterised by resolution; fixed timestep instead of the CFL loop."""
+    Ri, Ro = 14, 15
+    Rayleigh, Prandtl, dealias = 3500, 1, 3 / 2
+    coords = d3.SphericalCoordinates('phi', 'theta', 'r')
+    dist = d3.Distributor(coords, dtype=np.float64, **(dist_kw or {}))
+    shell = d3.ShellBasis(coords, shape=shape, radii=(Ri, Ro), dealias=dealias, dtype=np.float64)
+    sphere = shell.outer_surface
+    p = dist.Field(name='p', bases=shell)
+    b = dist.Field(name='b', bases=shell)
+    u = dist.VectorField(coords, name='u', bases=shell)
+    tau_p = dist.Field(name='tau_p')
+    tau_b1 = dist.Field(name='tau_b1', bases=sphere)
+    tau_b2 = dist.Field(name='tau_b2', bases=sphere)
+    tau_u1 = dist.VectorField(coords, name='tau_u1', bases=sphere)
+    tau_u2 = dist.VectorField(coords, name='tau_u2', bases=sphere)
+    kappa = (Rayleigh * Prandtl) ** (-1 / 2)
+    nu = (Rayleigh / Prandtl) ** (-1 / 2)
+    phi, theta, r = dist.local_grids(shell)
+    er = dist.VectorField(coords, bases=shell.radial_basis)
+    er['g'][2] = 1
+    rvec = dist.VectorField(coords, bases=shell.radial_basis)
+    rvec['g'][2] = r
+    lift_basis = shell.derivative_basis(1)
+    lift = lambda A: d3.Lift(A, lift_basis, -1)
+    grad_u = d3.grad(u) + rvec * lift(tau_u1)
+    grad_b = d3.grad(b) + rvec * lift(tau_b1)
+    problem = d3.IVP([p, b, u, tau_p, tau_b1, tau_b2, tau_u1, tau_u2], namespace=locals())
+    problem.add_equation("trace(grad_u) + tau_p = 0")
+    problem.add_equation("dt(b) - kappa*div(grad_b) + lift(tau_b2) = - u@grad(b)")
+    problem.add_equation("dt(u) - nu*div(grad_u) + grad(p) - b*er + lift(tau_u2) = - u@grad(u)")
+    problem.add_equation("b(r=Ri) = 1")
+    problem.add_equation("u(r=Ri) = 0")
+    problem.add_equation("b(r=Ro) = 0")
+    problem.add_equation("u(r=Ro) = 0")
+    problem.add_equation("integ(p) = 0")
+    solver = problem.build_solver(getattr(d3, timestepper))
+    b.fill_random('g', seed=42, distribution='normal', scale=1e-3)
+    b['g'] *= (r - Ri) * (Ro - r)
+    b['g'] += (Ri - Ri * Ro / r) / (Ri - Ro)
+    return solver, dict(p=p, b=b, u=u, tau_p=tau_p, tau_b1=tau_b1, tau_b2=tau_b2, tau_u1=tau_u1, tau_u2=tau_u2)
+
+
+def run_shell_convection(d3, steps=4, dt=0.05, **kw):
+    solver, fields = shell_convection(d3, **kw)
+    for _ in range(steps):
+        solver.step(dt)
+    return solver, {k: np.array(f['c']) for k, f in fields.items()}
