@@ -918,7 +918,12 @@ def ncc_termlist(ncc, arg_basis, rank_arg, ncc_first, contract):
     mult = []
     for alpha_c in range(coef.shape[0]):
         f = coef[alpha_c] @ P0
-        mult.append((P * (wq * f)) @ P.T if np.any(np.abs(coef[alpha_c]) > 1e-14) else None)
+        if np.any(np.abs(coef[alpha_c]) > 1e-14):
+            M = (P * (wq * f)) @ P.T
+            M[np.abs(M) < 1e-13 * np.abs(M).max()] = 0.0         # quadrature round-off outside the band of the polynomial
+            mult.append(M)
+        else:
+            mult.append(None)
     rank_ncc = ncc.rank
     rank_out = rank_ncc + rank_arg - (2 if contract else 0)
     idx_arg, idx_out = reg_indices(rank_arg), reg_indices(rank_out)
@@ -1406,7 +1411,9 @@ class ShellSolverBase:
         tl = tl.merged()
         out = []
         for (co, ci, m) in tl.terms:
-            out.append((co, ci, m * self.row_valid[co][:, :, None] * self.col_valid[ci][:, None, :]))
+            m = m * self.row_valid[co][:, :, None] * self.col_valid[ci][:, None, :]
+            m[np.abs(m) < 1e-12] = 0.0          # entry_cutoff of the reference's subproblem matrices (core/subsystems.py:536)
+            out.append((co, ci, m))
         return EllTermList(self.R, self.R, out).merged()
 
     def _dense(self, tl, ell):

@@ -173,36 +173,100 @@ struct EllTerms : HandleBase {
     int *d_meta = nullptr;       // [nterms][2]: co, ci (sorted by co)
     int *d_first = nullptr;      // [ncomp_out + 1]
     int *d_slot = nullptr;       // [2 nm][nl]: matrix index of the slot, -1: no mode
+    short *d_band = nullptr;     // [nterms][nmat][2]: lower / upper bandwidth of the non-zeros
     double *d_mats = nullptr;    // [nterms][nmat][n_in][n_out]  (transposed: threads run along n_out)
+    int ncomp_in = 0;
     ~EllTerms() override {
         (void)hipFree(d_meta);
         (void)hipFree(d_first);
         (void)hipFree(d_slot);
+        (void)hipFree(d_band);
         (void)hipFree(d_mats);
     }
 };
 
-__global__ void __launch_bounds__(256)
+// One workgroup = ELL_S consecutive (m, part) slots of one ell, threads run along the output radial index.  The
+// input rows of all components are staged once in LDS ([component][n][slot], so a thread reads its ELL_S
+// right-hand sides with one wide LDS load per n); every matrix element fetched from L2/HBM is used ELL_S times.
+// Per term and matrix the band offsets (kl, ku) of the non-zeros bound the inner loop: differential operators are
+// banded in n, the LHS inverses are dense.
+constexpr int ELL_S = 8;     // slots per workgroup
+constexpr int ELL_CO = 4;    // output components processed concurrently (threadIdx.y)
+
+__global__ void __launch_bounds__(1024)
 ell_terms_kernel(const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ meta,
-                 const int *__restrict__ first, const int *__restrict__ slot_map, const double *__restrict__ mats, int nm,
-                 int nl, int nr, int nmat, int ncomp_out) {
-    const int l = blockIdx.x, i1 = blockIdx.y;
-    const long slot = ((long)i1 * nl + l) * nr;
+                 const int *__restrict__ first, const int *__restrict__ slot_map, const short *__restrict__ band,
+                 const double *__restrict__ mats, int nm, int nl, int nr, int nmat, int ncomp_in, int ncomp_out) {
+    extern __shared__ double sx[];                   // [ncomp_in][nr][ELL_S]
+    const int l = blockIdx.y, i0 = blockIdx.x * ELL_S;   // groups of one ell are neighbours: they stream the same matrices
+    const int tlin = threadIdx.y * blockDim.x + threadIdx.x, tall = blockDim.x * blockDim.y;
     const long cstride = 2L * nm * nl * nr;
-    const int mid = slot_map[i1 * nl + l];           // matrix of this slot; -1: (m, ell) carries no mode
-    const bool live = mid >= 0;
-    for (int co = 0; co < ncomp_out; ++co) {
+    int mid[ELL_S];
+    bool same = true;
+    int mid0 = -1;
+#pragma unroll
+    for (int s = 0; s < ELL_S; ++s) {
+        const int i1 = i0 + s;
+        mid[s] = (i1 < 2 * nm) ? slot_map[i1 * nl + l] : -1;
+        if (mid[s] >= 0) {
+            if (mid0 < 0) mid0 = mid[s];
+            else if (mid[s] != mid0) same = false;
+        }
+    }
+    if (mid0 < 0) {                                   // no slot of the group carries a mode: zero them
+        for (int co = threadIdx.y; co < ncomp_out; co += ELL_CO)
+            for (int no = threadIdx.x; no < nr; no += blockDim.x)
+#pragma unroll
+                for (int s = 0; s < ELL_S; ++s)
+                    if (i0 + s < 2 * nm) y[co * cstride + ((long)(i0 + s) * nl + l) * nr + no] = 0.0;
+        return;
+    }
+    for (int w = tlin; w < ncomp_in * nr; w += tall) {
+        const int ci = w / nr, ni = w - ci * nr;
+#pragma unroll
+        for (int s = 0; s < ELL_S; ++s) {
+            const int i1 = i0 + s;
+            sx[(long)w * ELL_S + s] = (mid[s] >= 0) ? x[ci * cstride + ((long)i1 * nl + l) * nr + ni] : 0.0;
+        }
+    }
+    __syncthreads();
+    for (int co = threadIdx.y; co < ncomp_out; co += ELL_CO) {
         for (int no = threadIdx.x; no < nr; no += blockDim.x) {
-            double acc = 0.0;
-            if (live) {
-                for (int t = first[co]; t < first[co + 1]; ++t) {
-                    const int ci = meta[2 * t + 1];
-                    const double *A = mats + (((long)t * nmat + mid) * nr) * nr + no;
-                    const double *xv = x + ci * cstride + slot;
-                    for (int ni = 0; ni < nr; ++ni) acc += A[(long)ni * nr] * xv[ni];
+            double acc[ELL_S];
+#pragma unroll
+            for (int s = 0; s < ELL_S; ++s) acc[s] = 0.0;
+            for (int t = first[co]; t < first[co + 1]; ++t) {
+                const int ci = meta[2 * t + 1];
+                const double *xs = sx + (long)ci * nr * ELL_S;
+                if (same) {
+                    const short kl = band[2 * ((long)t * nmat + mid0)], ku = band[2 * ((long)t * nmat + mid0) + 1];
+                    const double *A = mats + (((long)t * nmat + mid0) * nr) * nr + no;
+                    const int n0 = max(0, no - kl), n1 = min(nr, no + ku + 1);
+                    for (int ni = n0; ni < n1; ++ni) {
+                        const double a = A[(long)ni * nr];
+                        const double4 xv = *reinterpret_cast<const double4 *>(xs + (long)ni * ELL_S);
+                        const double4 xw = *reinterpret_cast<const double4 *>(xs + (long)ni * ELL_S + 4);
+                        acc[0] += a * xv.x;
+                        acc[1] += a * xv.y;
+                        acc[2] += a * xv.z;
+                        acc[3] += a * xv.w;
+                        acc[4] += a * xw.x;
+                        acc[5] += a * xw.y;
+                        acc[6] += a * xw.z;
+                        acc[7] += a * xw.w;
+                    }
+                } else {                              // slots of the group use different matrices (rare)
+#pragma unroll
+                    for (int s = 0; s < ELL_S; ++s) {
+                        if (mid[s] < 0) continue;
+                        const double *A = mats + (((long)t * nmat + mid[s]) * nr) * nr + no;
+                        for (int ni = 0; ni < nr; ++ni) acc[s] += A[(long)ni * nr] * xs[(long)ni * ELL_S + s];
+                    }
                 }
             }
-            y[co * cstride + slot + no] = acc;
+#pragma unroll
+            for (int s = 0; s < ELL_S; ++s)
+                if (i0 + s < 2 * nm) y[co * cstride + ((long)(i0 + s) * nl + l) * nr + no] = (mid[s] >= 0) ? acc[s] : 0.0;
         }
     }
 }
@@ -292,22 +356,37 @@ int ddh_ell_terms_create(ddh_handle *h, int nm, int nl, int nr, int ncomp_out, i
         }
         meta[2 * t] = co_h[t]; meta[2 * t + 1] = ci_h[t];
         first[co_h[t] + 1] = t + 1;
+        if (ci_h[t] + 1 > p->ncomp_in) p->ncomp_in = ci_h[t] + 1;
     }
+    if (p->ncomp_in < 1) p->ncomp_in = 1;
     for (int c = 0; c < ncomp_out; ++c)
         if (first[c + 1] < first[c]) first[c + 1] = first[c];
     const size_t per = (size_t)nmat * nr * nr;
     const size_t mb = (size_t)(nterms > 0 ? nterms : 1) * per * sizeof(double);
     // transpose every matrix to [n_in][n_out]
     std::vector<double> tr((size_t)(nterms > 0 ? nterms : 1) * per, 0.0);
+    std::vector<short> band(2 * (size_t)(nterms > 0 ? nterms : 1) * nmat, 0);
     for (size_t t = 0; t < (size_t)nterms; ++t)
-        for (size_t l = 0; l < (size_t)nmat; ++l)
+        for (size_t l = 0; l < (size_t)nmat; ++l) {
+            int kl = 0, ku = 0;
             for (int i = 0; i < nr; ++i)
-                for (int j = 0; j < nr; ++j)
-                    tr[(t * nmat + l) * nr * nr + (size_t)j * nr + i] = mats_h[(t * nmat + l) * nr * nr + (size_t)i * nr + j];
+                for (int j = 0; j < nr; ++j) {
+                    const double v = mats_h[(t * nmat + l) * nr * nr + (size_t)i * nr + j];
+                    tr[(t * nmat + l) * nr * nr + (size_t)j * nr + i] = v;
+                    if (v != 0.0) {
+                        if (i - j > kl) kl = i - j;
+                        if (j - i > ku) ku = j - i;
+                    }
+                }
+            band[2 * (t * nmat + l)] = (short)kl;
+            band[2 * (t * nmat + l) + 1] = (short)ku;
+        }
     if (check_hip(hipMalloc((void **)&p->d_meta, meta.size() * sizeof(int)), "hipMalloc") ||
         check_hip(hipMalloc((void **)&p->d_first, first.size() * sizeof(int)), "hipMalloc") ||
         check_hip(hipMalloc((void **)&p->d_mats, mb), "hipMalloc") ||
         check_hip(hipMalloc((void **)&p->d_slot, 2L * nm * nl * sizeof(int)), "hipMalloc") ||
+        check_hip(hipMalloc((void **)&p->d_band, band.size() * sizeof(short)), "hipMalloc") ||
+        check_hip(hipMemcpy(p->d_band, band.data(), band.size() * sizeof(short), hipMemcpyHostToDevice), "hipMemcpy") ||
         check_hip(hipMemcpy(p->d_slot, slot_map_h, 2L * nm * nl * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy") ||
         check_hip(hipMemcpy(p->d_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy") ||
         check_hip(hipMemcpy(p->d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy") ||
@@ -324,9 +403,14 @@ int ddh_ell_terms_apply(ddh_handle h, const double *x, double *y, void *stream) 
     if (!p) return -1;
     if (x == y) return fail("ell_terms_apply: in-place unsupported");
     const int T = p->nr >= 256 ? 256 : (p->nr > 64 ? 128 : 64);
-    const dim3 grid((unsigned)p->nl, (unsigned)(2 * p->nm)), block(T);
-    hipLaunchKernelGGL(ell_terms_kernel, grid, block, 0, as_stream(stream), x, y, p->d_meta, p->d_first, p->d_slot,
-                       p->d_mats, p->nm, p->nl, p->nr, p->nmat, p->ncomp_out);
+    const dim3 grid((unsigned)((2 * p->nm + ELL_S - 1) / ELL_S), (unsigned)p->nl), block(T, ELL_CO);
+    const size_t lds = (size_t)p->ncomp_in * p->nr * ELL_S * sizeof(double);
+    if (lds > 64 * 1024) {
+        if (lds > 160 * 1024) return fail("ell_terms_apply: too many components x radial modes for the LDS staging");
+        DDH_HIP(hipFuncSetAttribute((const void *)ell_terms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(ell_terms_kernel, grid, block, lds, as_stream(stream), x, y, p->d_meta, p->d_first, p->d_slot,
+                       p->d_band, p->d_mats, p->nm, p->nl, p->nr, p->nmat, p->ncomp_in, p->ncomp_out);
     DDH_HIP(hipGetLastError());
     return 0;
 }

@@ -1,6 +1,8 @@
 """Secondary BASELINE.json configurations on one GPU (not the headline metric):
    K  = KdV-Burgers N=1024 SBDF2,  R2 = 2-D Rayleigh-Benard 512x256 RK222,
-   S  = sphere shallow water SphereBasis(512, 256) RK222 (`python tools/bench_configs.py sphere`).  Prints steps/s."""
+   S  = sphere shallow water SphereBasis(512, 256) RK222 (`python tools/bench_configs.py sphere`),
+   H  = shell convection ShellBasis(256, 128, 128) SBDF2 on one GPU (`python tools/bench_configs.py shell`).
+   Prints steps/s."""
 import os
 import sys
 import time
@@ -44,7 +46,30 @@ def run_sphere(name, kw, warm, steps):
     print("%-28s %8.1f steps/s  (%.3f ms/step, %d steps)" % (name, steps / el, 1e3 * el / steps, steps), flush=True)
 
 
+def run_shell(name, kw, dt, warm, steps):
+    t0 = time.time()
+    solver, f = problems.shell_convection(d3, **kw)
+    solver.step(dt)
+    solver.ex.sync()
+    print("%-34s setup + first step: %.1f s" % (name, time.time() - t0), flush=True)
+    for _ in range(warm):
+        solver.step(dt)
+    solver.ex.sync()
+    t0 = time.time()
+    for _ in range(steps):
+        solver.step(dt)
+    solver.ex.sync()
+    el = time.time() - t0
+    b = np.asarray(f["b"]['c'])
+    print("%-34s %8.2f steps/s  (%.2f ms/step, %d steps)  |b_c| = %.12f finite=%s" % (
+        name, steps / el, 1e3 * el / steps, steps, float(np.linalg.norm(b)), bool(np.isfinite(b).all())), flush=True)
+
+
 if __name__ == "__main__":
+    if "shell" in sys.argv[1:]:
+        shape = tuple(int(x) for x in os.environ.get("SHELL_SHAPE", "256,128,128").split(","))
+        run_shell("H  shell convection %dx%dx%d SBDF2" % shape, dict(shape=shape, timestepper="SBDF2"), 0.05, 3, 10)
+        sys.exit(0)
     if "sphere" in sys.argv[1:]:
         run_sphere("S  shallow water 512x256 RK222", dict(Nphi=512, Ntheta=256), 5, 50)
         sys.exit(0)
