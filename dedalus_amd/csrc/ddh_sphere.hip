@@ -21,6 +21,8 @@
 //    (libraries/matsolvers.py:126-149, timesteppers.py:630-643).
 #include "ddh_common.h"
 
+#include <cstdlib>
+
 namespace ddh {
 
 constexpr HandleKind H_STERMS = (HandleKind)5;
@@ -173,8 +175,10 @@ struct EllTerms : HandleBase {
     int *d_meta = nullptr;       // [nterms][2]: co, ci (sorted by co)
     int *d_first = nullptr;      // [ncomp_out + 1]
     int *d_slot = nullptr;       // [2 nm][nl]: matrix index of the slot, -1: no mode
-    short *d_band = nullptr;     // [nterms][nmat][2]: lower / upper bandwidth of the non-zeros
+    short *d_band = nullptr;     // [nterms][nmat][nr][2]: first / one-past-last non-zero column of every row
     double *d_mats = nullptr;    // [nterms][nmat][n_in][n_out]  (transposed: threads run along n_out)
+    int *d_tmap = nullptr;       // dense path: [ncomp_out][ncomp_in] -> term index or -1
+    int dense = 0;               // 1: mostly full blocks, default slot map -> per-ell FP64 MFMA GEMM
     int ncomp_in = 0;
     ~EllTerms() override {
         (void)hipFree(d_meta);
@@ -182,8 +186,79 @@ struct EllTerms : HandleBase {
         (void)hipFree(d_slot);
         (void)hipFree(d_band);
         (void)hipFree(d_mats);
+        (void)hipFree(d_tmap);
     }
 };
+
+// Dense blocks (the per-ell LHS inverses): C[(co, no)][slot] = sum_(ci, ni) A_ell[(co, no)][(ci, ni)] X_ell[(ci, ni)][slot] is
+// a per-ell GEMM with up to 2 (ell + 1) right-hand-side columns.  Workgroup tile: 64 rows (4 waves x 16) x 128 slots,
+// FP64 MFMA 16x16x4 (A: one f64 per lane, row = lane & 15, k = lane >> 4; B: k = lane >> 4, col = lane & 15;
+// C/D: col = lane & 15, row = (lane >> 4) + 4 r); X is staged through LDS in chunks of 64 k, every matrix element
+// loaded from L2/HBM feeds 8 MFMAs.  Results leave through LDS so the stores run along the contiguous radial index.
+constexpr int EG_M = 64, EG_N = 128, EG_K = 64, EG_LD = EG_N + 1;
+typedef double d4v __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+ell_gemm_kernel(const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tmap,
+                const double *__restrict__ mats, int nm, int nl, int nr, int nmat, int ncomp_in, int ncomp_out) {
+    extern __shared__ double sm[];                    // [EG_K][EG_LD] (X chunk), reused as [EG_N][EG_M] for the output
+    const int l = blockIdx.y;
+    const int i1_0 = blockIdx.z * EG_N;
+    const int m0 = blockIdx.x * EG_M;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long cstride = 2L * nm * nl * nr;
+    const int mrow = m0 + 16 * wave;                  // first output row of this wave
+    const int co = mrow / nr, no0 = mrow - co * nr;
+    const bool any_live = (i1_0 >> 1) <= l;           // slot i1 is live iff i1 / 2 <= ell
+    if (!any_live) {
+        for (int w = tid; w < EG_N * EG_M; w += 256) {
+            const int j = w / EG_M, r = w - j * EG_M, i1 = i1_0 + j;
+            const int mm = m0 + r, c2 = mm / nr, n2 = mm - c2 * nr;
+            if (i1 < 2 * nm) y[c2 * cstride + ((long)i1 * nl + l) * nr + n2] = 0.0;
+        }
+        return;
+    }
+    d4v acc[EG_N / 16];
+#pragma unroll
+    for (int jt = 0; jt < EG_N / 16; ++jt) acc[jt] = (d4v){0.0, 0.0, 0.0, 0.0};
+    for (int ci = 0; ci < ncomp_in; ++ci) {
+        const int t = tmap[co * ncomp_in + ci];       // wave-uniform (a 16-row tile lies inside one component)
+        for (int k0 = 0; k0 < nr; k0 += EG_K) {
+            __syncthreads();
+            // stage X[(ci, k0 + k)][slot j]: one slot per wave instruction, 64 consecutive radial modes
+            for (int j = wave; j < EG_N; j += 4) {
+                const int i1 = i1_0 + j;
+                double v = 0.0;
+                if (i1 < 2 * nm && (i1 >> 1) <= l) v = x[ci * cstride + ((long)i1 * nl + l) * nr + k0 + lane];
+                sm[lane * EG_LD + j] = v;
+            }
+            __syncthreads();
+            if (t < 0) continue;
+            const double *A = mats + (((long)t * nmat + l) * nr + k0) * nr + no0;
+#pragma unroll 4
+            for (int k4 = 0; k4 < EG_K; k4 += 4) {
+                const double a = A[(long)(k4 + (lane >> 4)) * nr + (lane & 15)];
+                const double *xr = sm + (k4 + (lane >> 4)) * EG_LD + (lane & 15);
+#pragma unroll
+                for (int jt = 0; jt < EG_N / 16; ++jt)
+                    acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xr[jt * 16], acc[jt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    // C/D -> LDS [slot j][row r of the 64-row tile]
+#pragma unroll
+    for (int jt = 0; jt < EG_N / 16; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            sm[(jt * 16 + (lane & 15)) * EG_M + 16 * wave + (lane >> 4) + 4 * r] = acc[jt][r];
+    __syncthreads();
+    for (int w = tid; w < EG_N * EG_M; w += 256) {
+        const int j = w / EG_M, r = w - j * EG_M, i1 = i1_0 + j;
+        const int mm = m0 + r, c2 = mm / nr, n2 = mm - c2 * nr;
+        if (i1 < 2 * nm) y[c2 * cstride + ((long)i1 * nl + l) * nr + n2] = sm[w];
+    }
+}
 
 // One workgroup = ELL_S consecutive (m, part) slots of one ell, threads run along the output radial index.  The
 // input rows of all components are staged once in LDS ([component][n][slot], so a thread reads its ELL_S
@@ -239,9 +314,9 @@ ell_terms_kernel(const double *__restrict__ x, double *__restrict__ y, const int
                 const int ci = meta[2 * t + 1];
                 const double *xs = sx + (long)ci * nr * ELL_S;
                 if (same) {
-                    const short kl = band[2 * ((long)t * nmat + mid0)], ku = band[2 * ((long)t * nmat + mid0) + 1];
+                    const long bi = 2 * (((long)t * nmat + mid0) * nr + no);
+                    const int n0 = band[bi], n1 = band[bi + 1];          // non-zero columns of this row
                     const double *A = mats + (((long)t * nmat + mid0) * nr) * nr + no;
-                    const int n0 = max(0, no - kl), n1 = min(nr, no + ku + 1);
                     for (int ni = n0; ni < n1; ++ni) {
                         const double a = A[(long)ni * nr];
                         const double4 xv = *reinterpret_cast<const double4 *>(xs + (long)ni * ELL_S);
@@ -365,22 +440,43 @@ int ddh_ell_terms_create(ddh_handle *h, int nm, int nl, int nr, int ncomp_out, i
     const size_t mb = (size_t)(nterms > 0 ? nterms : 1) * per * sizeof(double);
     // transpose every matrix to [n_in][n_out]
     std::vector<double> tr((size_t)(nterms > 0 ? nterms : 1) * per, 0.0);
-    std::vector<short> band(2 * (size_t)(nterms > 0 ? nterms : 1) * nmat, 0);
+    std::vector<short> band(2 * (size_t)(nterms > 0 ? nterms : 1) * nmat * nr, 0);
     for (size_t t = 0; t < (size_t)nterms; ++t)
-        for (size_t l = 0; l < (size_t)nmat; ++l) {
-            int kl = 0, ku = 0;
-            for (int i = 0; i < nr; ++i)
+        for (size_t l = 0; l < (size_t)nmat; ++l)
+            for (int i = 0; i < nr; ++i) {
+                int lo = nr, hi = 0;
                 for (int j = 0; j < nr; ++j) {
                     const double v = mats_h[(t * nmat + l) * nr * nr + (size_t)i * nr + j];
                     tr[(t * nmat + l) * nr * nr + (size_t)j * nr + i] = v;
                     if (v != 0.0) {
-                        if (i - j > kl) kl = i - j;
-                        if (j - i > ku) ku = j - i;
+                        if (j < lo) lo = j;
+                        hi = j + 1;
                     }
                 }
-            band[2 * (t * nmat + l)] = (short)kl;
-            band[2 * (t * nmat + l) + 1] = (short)ku;
+                if (hi == 0) lo = 0;
+                band[2 * ((t * nmat + l) * nr + i)] = (short)lo;
+                band[2 * ((t * nmat + l) * nr + i) + 1] = (short)hi;
+            }
+    // dense path: default slot map (matrix index = ell), rows mostly full, sizes that tile
+    {
+        bool def_map = (nmat == nl);
+        for (int i1 = 0; def_map && i1 < 2 * nm; ++i1)
+            for (int l = 0; l < nl; ++l) {
+                const int want = ((i1 >> 1) <= l) ? l : -1;
+                if (slot_map_h[i1 * nl + l] != want) { def_map = false; break; }
+            }
+        double fill = 0.0;
+        for (size_t i = 0; i < band.size() / 2; ++i) fill += band[2 * i + 1] - band[2 * i];
+        fill /= (double)(band.size() / 2) * nr;
+        p->dense = def_map && nterms > 0 && fill > 0.5 && nr % EG_K == 0 && (ncomp_out * nr) % EG_M == 0;
+        std::vector<int> tmap((size_t)ncomp_out * p->ncomp_in, -1);
+        for (int t = 0; t < nterms; ++t) tmap[(size_t)co_h[t] * p->ncomp_in + ci_h[t]] = t;
+        if (check_hip(hipMalloc((void **)&p->d_tmap, tmap.size() * sizeof(int)), "hipMalloc") ||
+            check_hip(hipMemcpy(p->d_tmap, tmap.data(), tmap.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy")) {
+            delete p;
+            return -2;
         }
+    }
     if (check_hip(hipMalloc((void **)&p->d_meta, meta.size() * sizeof(int)), "hipMalloc") ||
         check_hip(hipMalloc((void **)&p->d_first, first.size() * sizeof(int)), "hipMalloc") ||
         check_hip(hipMalloc((void **)&p->d_mats, mb), "hipMalloc") ||
@@ -402,6 +498,16 @@ int ddh_ell_terms_apply(ddh_handle h, const double *x, double *y, void *stream) 
     EllTerms *p = (EllTerms *)lookup_handle(h, H_ELLT);
     if (!p) return -1;
     if (x == y) return fail("ell_terms_apply: in-place unsupported");
+    static const bool no_gemm = getenv("DDH_ELL_NO_GEMM") != nullptr;
+    if (p->dense && !no_gemm) {
+        const dim3 grid((unsigned)(p->ncomp_out * p->nr / EG_M), (unsigned)p->nl, (unsigned)((2 * p->nm + EG_N - 1) / EG_N));
+        const size_t lds = (size_t)(EG_K * EG_LD > EG_N * EG_M ? EG_K * EG_LD : EG_N * EG_M) * sizeof(double);
+        DDH_HIP(hipFuncSetAttribute((const void *)ell_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ell_gemm_kernel, grid, dim3(256), lds, as_stream(stream), x, y, p->d_tmap, p->d_mats, p->nm, p->nl,
+                           p->nr, p->nmat, p->ncomp_in, p->ncomp_out);
+        DDH_HIP(hipGetLastError());
+        return 0;
+    }
     const int T = p->nr >= 256 ? 256 : (p->nr > 64 ? 128 : 64);
     const dim3 grid((unsigned)((2 * p->nm + ELL_S - 1) / ELL_S), (unsigned)p->nl), block(T, ELL_CO);
     const size_t lds = (size_t)p->ncomp_in * p->nr * ELL_S * sizeof(double);

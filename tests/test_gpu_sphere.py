@@ -119,3 +119,35 @@ def test_shallow_water_config_size():
     h00_after = np.array(h['c'])[0, 0]
     assert abs(h00_after - h00_before) <= 1e-12 * max(1.0, abs(h00_before))
     assert np.all(np.isfinite(np.array(fields["u"]['g'])))
+
+
+@pytest.mark.parametrize("nm,nl,nr,nco,nci,dense", [(8, 7, 10, 3, 2, False), (4, 9, 64, 2, 3, True), (16, 15, 64, 4, 4, True),
+                                                    (8, 7, 128, 1, 2, True), (8, 7, 64, 3, 3, False)])
+def test_ell_terms(exs, nm, nl, nr, nco, nci, dense):
+    """ddh_ell_terms_apply (band-limited slot-tile kernel and the FP64-MFMA per-ell GEMM used for dense blocks) against
+    the numpy oracle executor; quirky slot maps on the banded path."""
+    hx, nx = exs
+    rng = np.random.default_rng(nm * 31 + nr + nco)
+    nmat = nl if dense else nl + 2
+    terms = []
+    for co in range(nco):
+        for ci in range(nci):
+            if rng.random() < 0.8 or (co == 0 and ci == 0):
+                m = rng.standard_normal((nmat, nr, nr))
+                if not dense:
+                    i, j = np.indices((nr, nr))
+                    m = m * (np.abs(i - j) <= 2)[None]
+                terms.append((co, ci, m))
+    i1, ell = np.indices((2 * nm, nl))
+    slot_map = np.where(i1 // 2 <= ell, ell, -1).astype(np.int32)
+    if not dense:
+        slot_map[2, 1] = nl          # slots that use the extra (summed) matrices
+        slot_map[3, 3] = nl + 1
+    x = rng.standard_normal((nci, 2 * nm, nl, nr))
+    ref = np.full((nco, 2 * nm, nl, nr), np.nan)
+    nx.make_ell_terms(nm, nl, nr, nco, terms, slot_map).apply(x, ref)
+    y = hx.empty((nco, 2 * nm, nl, nr))
+    y.fill_(float("nan"))
+    hx.make_ell_terms(nm, nl, nr, nco, terms, slot_map).apply(hx.from_host(x), y)
+    hx.sync()
+    assert rel(hx.download(y), ref) < 1e-13
