@@ -176,6 +176,7 @@ struct EllTerms : HandleBase {
     int *d_first = nullptr;      // [ncomp_out + 1]
     int *d_slot = nullptr;       // [2 nm][nl]: matrix index of the slot, -1: no mode
     short *d_band = nullptr;     // [nterms][nmat][nr][2]: first / one-past-last non-zero column of every row
+    short *d_rows = nullptr;     // [nterms][nmat][2]: first / one-past-last non-zero row
     double *d_mats = nullptr;    // [nterms][nmat][n_in][n_out]  (transposed: threads run along n_out)
     int *d_tmap = nullptr;       // dense path: [ncomp_out][ncomp_in] -> term index or -1
     int dense = 0;               // 1: mostly full blocks, default slot map -> per-ell FP64 MFMA GEMM
@@ -185,6 +186,7 @@ struct EllTerms : HandleBase {
         (void)hipFree(d_first);
         (void)hipFree(d_slot);
         (void)hipFree(d_band);
+        (void)hipFree(d_rows);
         (void)hipFree(d_mats);
         (void)hipFree(d_tmap);
     }
@@ -200,7 +202,8 @@ typedef double d4v __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256)
 ell_gemm_kernel(const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ tmap,
-                const double *__restrict__ mats, int nm, int nl, int nr, int nmat, int ncomp_in, int ncomp_out) {
+                const double *__restrict__ mats, int nm, int nl, int nr, int nmat, int ncomp_in, int ncomp_out,
+                int accumulate) {
     extern __shared__ double sm[];                    // [EG_K][EG_LD] (X chunk), reused as [EG_N][EG_M] for the output
     const int l = blockIdx.y;
     const int i1_0 = blockIdx.z * EG_N;
@@ -211,12 +214,18 @@ ell_gemm_kernel(const double *__restrict__ x, double *__restrict__ y, const int 
     const int co = mrow / nr, no0 = mrow - co * nr;
     const bool any_live = (i1_0 >> 1) <= l;           // slot i1 is live iff i1 / 2 <= ell
     if (!any_live) {
+        if (accumulate) return;
         for (int w = tid; w < EG_N * EG_M; w += 256) {
             const int j = w / EG_M, r = w - j * EG_M, i1 = i1_0 + j;
             const int mm = m0 + r, c2 = mm / nr, n2 = mm - c2 * nr;
             if (i1 < 2 * nm) y[c2 * cstride + ((long)i1 * nl + l) * nr + n2] = 0.0;
         }
         return;
+    }
+    if (accumulate) {                                 // nothing to add for an output component without dense blocks
+        bool any = false;                             // (the 64-row tile lies inside one component: nr % 64 == 0)
+        for (int ci = 0; ci < ncomp_in; ++ci) any = any || tmap[co * ncomp_in + ci] >= 0;
+        if (!any) return;
     }
     d4v acc[EG_N / 16];
 #pragma unroll
@@ -256,7 +265,10 @@ ell_gemm_kernel(const double *__restrict__ x, double *__restrict__ y, const int 
     for (int w = tid; w < EG_N * EG_M; w += 256) {
         const int j = w / EG_M, r = w - j * EG_M, i1 = i1_0 + j;
         const int mm = m0 + r, c2 = mm / nr, n2 = mm - c2 * nr;
-        if (i1 < 2 * nm) y[c2 * cstride + ((long)i1 * nl + l) * nr + n2] = sm[w];
+        if (i1 < 2 * nm) {
+            const long yi = c2 * cstride + ((long)i1 * nl + l) * nr + n2;
+            y[yi] = accumulate ? y[yi] + sm[w] : sm[w];
+        }
     }
 }
 
@@ -271,7 +283,8 @@ constexpr int ELL_CO = 4;    // output components processed concurrently (thread
 __global__ void __launch_bounds__(1024)
 ell_terms_kernel(const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ meta,
                  const int *__restrict__ first, const int *__restrict__ slot_map, const short *__restrict__ band,
-                 const double *__restrict__ mats, int nm, int nl, int nr, int nmat, int ncomp_in, int ncomp_out) {
+                 const short *__restrict__ rows, const double *__restrict__ mats, int nm, int nl, int nr, int nmat,
+                 int ncomp_in, int ncomp_out) {
     extern __shared__ double sx[];                   // [ncomp_in][nr][ELL_S]
     const int l = blockIdx.y, i0 = blockIdx.x * ELL_S;   // groups of one ell are neighbours: they stream the same matrices
     const int tlin = threadIdx.y * blockDim.x + threadIdx.x, tall = blockDim.x * blockDim.y;
@@ -314,6 +327,8 @@ ell_terms_kernel(const double *__restrict__ x, double *__restrict__ y, const int
                 const int ci = meta[2 * t + 1];
                 const double *xs = sx + (long)ci * nr * ELL_S;
                 if (same) {
+                    const long ri = 2 * ((long)t * nmat + mid0);
+                    if (no < rows[ri] || no >= rows[ri + 1]) continue;      // this row of the block is empty
                     const long bi = 2 * (((long)t * nmat + mid0) * nr + no);
                     const int n0 = band[bi], n1 = band[bi + 1];          // non-zero columns of this row
                     const double *A = mats + (((long)t * nmat + mid0) * nr) * nr + no;
@@ -441,8 +456,10 @@ int ddh_ell_terms_create(ddh_handle *h, int nm, int nl, int nr, int ncomp_out, i
     // transpose every matrix to [n_in][n_out]
     std::vector<double> tr((size_t)(nterms > 0 ? nterms : 1) * per, 0.0);
     std::vector<short> band(2 * (size_t)(nterms > 0 ? nterms : 1) * nmat * nr, 0);
+    std::vector<short> rows(2 * (size_t)(nterms > 0 ? nterms : 1) * nmat, 0);
     for (size_t t = 0; t < (size_t)nterms; ++t)
-        for (size_t l = 0; l < (size_t)nmat; ++l)
+        for (size_t l = 0; l < (size_t)nmat; ++l) {
+            int r0 = nr, r1 = 0;
             for (int i = 0; i < nr; ++i) {
                 int lo = nr, hi = 0;
                 for (int j = 0; j < nr; ++j) {
@@ -454,9 +471,17 @@ int ddh_ell_terms_create(ddh_handle *h, int nm, int nl, int nr, int ncomp_out, i
                     }
                 }
                 if (hi == 0) lo = 0;
+                else {
+                    if (i < r0) r0 = i;
+                    r1 = i + 1;
+                }
                 band[2 * ((t * nmat + l) * nr + i)] = (short)lo;
                 band[2 * ((t * nmat + l) * nr + i) + 1] = (short)hi;
             }
+            if (r1 == 0) r0 = 0;
+            rows[2 * (t * nmat + l)] = (short)r0;
+            rows[2 * (t * nmat + l) + 1] = (short)r1;
+        }
     // dense path: default slot map (matrix index = ell), rows mostly full, sizes that tile
     {
         bool def_map = (nmat == nl);
@@ -483,6 +508,8 @@ int ddh_ell_terms_create(ddh_handle *h, int nm, int nl, int nr, int ncomp_out, i
         check_hip(hipMalloc((void **)&p->d_slot, 2L * nm * nl * sizeof(int)), "hipMalloc") ||
         check_hip(hipMalloc((void **)&p->d_band, band.size() * sizeof(short)), "hipMalloc") ||
         check_hip(hipMemcpy(p->d_band, band.data(), band.size() * sizeof(short), hipMemcpyHostToDevice), "hipMemcpy") ||
+        check_hip(hipMalloc((void **)&p->d_rows, rows.size() * sizeof(short)), "hipMalloc") ||
+        check_hip(hipMemcpy(p->d_rows, rows.data(), rows.size() * sizeof(short), hipMemcpyHostToDevice), "hipMemcpy") ||
         check_hip(hipMemcpy(p->d_slot, slot_map_h, 2L * nm * nl * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy") ||
         check_hip(hipMemcpy(p->d_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy") ||
         check_hip(hipMemcpy(p->d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy") ||
@@ -495,6 +522,10 @@ int ddh_ell_terms_create(ddh_handle *h, int nm, int nl, int nr, int ncomp_out, i
 }
 
 int ddh_ell_terms_apply(ddh_handle h, const double *x, double *y, void *stream) {
+    return ddh_ell_terms_apply_acc(h, x, y, 0, stream);
+}
+
+int ddh_ell_terms_apply_acc(ddh_handle h, const double *x, double *y, int accumulate, void *stream) {
     EllTerms *p = (EllTerms *)lookup_handle(h, H_ELLT);
     if (!p) return -1;
     if (x == y) return fail("ell_terms_apply: in-place unsupported");
@@ -504,10 +535,11 @@ int ddh_ell_terms_apply(ddh_handle h, const double *x, double *y, void *stream) 
         const size_t lds = (size_t)(EG_K * EG_LD > EG_N * EG_M ? EG_K * EG_LD : EG_N * EG_M) * sizeof(double);
         DDH_HIP(hipFuncSetAttribute((const void *)ell_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(ell_gemm_kernel, grid, dim3(256), lds, as_stream(stream), x, y, p->d_tmap, p->d_mats, p->nm, p->nl,
-                           p->nr, p->nmat, p->ncomp_in, p->ncomp_out);
+                           p->nr, p->nmat, p->ncomp_in, p->ncomp_out, accumulate);
         DDH_HIP(hipGetLastError());
         return 0;
     }
+    if (accumulate) return fail("ell_terms_apply_acc: accumulation is implemented for the dense (GEMM) path only");
     const int T = p->nr >= 256 ? 256 : (p->nr > 64 ? 128 : 64);
     const dim3 grid((unsigned)((2 * p->nm + ELL_S - 1) / ELL_S), (unsigned)p->nl), block(T, ELL_CO);
     const size_t lds = (size_t)p->ncomp_in * p->nr * ELL_S * sizeof(double);
@@ -516,7 +548,7 @@ int ddh_ell_terms_apply(ddh_handle h, const double *x, double *y, void *stream) 
         DDH_HIP(hipFuncSetAttribute((const void *)ell_terms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     hipLaunchKernelGGL(ell_terms_kernel, grid, block, lds, as_stream(stream), x, y, p->d_meta, p->d_first, p->d_slot,
-                       p->d_band, p->d_mats, p->nm, p->nl, p->nr, p->nmat, p->ncomp_in, p->ncomp_out);
+                       p->d_band, p->d_rows, p->d_mats, p->nm, p->nl, p->nr, p->nmat, p->ncomp_in, p->ncomp_out);
     DDH_HIP(hipGetLastError());
     return 0;
 }

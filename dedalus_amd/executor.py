@@ -290,8 +290,19 @@ def default_slot_map(nm, nl):
 
 
 class EllTerms:
-    def __init__(self, ex, nm, nl, nr, ncomp_out, terms, slot_map=None):
+    """Device term list.  With the default slot map, blocks that are mostly full (the per-ell LHS inverses between shell
+    variables) go to a second handle that runs as an FP64 MFMA GEMM and accumulates onto the banded part."""
+
+    def __init__(self, ex, nm, nl, nr, ncomp_out, terms, slot_map=None, _split=True):
         self.ex = ex
+        self.dense_part = None
+        if _split and slot_map is None and nr % 64 == 0 and (ncomp_out * nr) % 64 == 0 and len(terms) > 1:
+            fill = [np.count_nonzero(t[2]) / t[2].size for t in terms]
+            dense = [t for t, f in zip(terms, fill) if f > 0.5]
+            sparse = [t for t, f in zip(terms, fill) if f <= 0.5]
+            if dense and sparse:
+                self.dense_part = EllTerms(ex, nm, nl, nr, ncomp_out, dense, None, _split=False)
+                terms = sparse
         terms = sorted(terms, key=lambda t: t[0])
         co = np.ascontiguousarray([t[0] for t in terms], dtype=np.int32)
         ci = np.ascontiguousarray([t[1] for t in terms], dtype=np.int32)
@@ -306,6 +317,8 @@ class EllTerms:
 
     def apply(self, x, y):
         libhip.call("ddh_ell_terms_apply", self.handle, ptr(x), ptr(y), self.ex.dev.stream)
+        if self.dense_part is not None:
+            libhip.call("ddh_ell_terms_apply_acc", self.dense_part.handle, ptr(x), ptr(y), 1, self.ex.dev.stream)
 
     def __del__(self):
         try:

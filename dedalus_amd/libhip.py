@@ -61,6 +61,7 @@ SIGNATURES = {
     "ddh_cgemv_batch_apply": [_h, _vp, _vp, _vp],
     "ddh_ell_terms_create": [_hp, _i, _i, _i, _i, _i, _ip, _ip, _i, _dp, _ip],
     "ddh_ell_terms_apply": [_h, _vp, _vp, _vp],
+    "ddh_ell_terms_apply_acc": [_h, _vp, _vp, _i, _vp],
     "ddh_rfft_forward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward_deriv": [_h, _vp, _vp, _l, _l, _d, _vp],

@@ -159,6 +159,9 @@ int ddh_cgemv_batch_apply(ddh_handle h, const double *x, double *y, void *stream
 int ddh_ell_terms_create(ddh_handle *h, int nm, int nl, int nr, int ncomp_out, int nterms, const int *co_h,
                          const int *ci_h, int nmat, const double *mats_h, const int *slot_map_h);
 int ddh_ell_terms_apply(ddh_handle h, const double *x, double *y, void *stream);
+/* accumulate != 0: y += A x (dense term lists only: the FP64 MFMA per-ell GEMM path); used to apply a term list
+ * split into its banded part (first, writes y) and its dense blocks (second, accumulates).              */
+int ddh_ell_terms_apply_acc(ddh_handle h, const double *x, double *y, int accumulate, void *stream);
 
 /* ---- grid-space and vector kernels -------------------------------- */
 /* y[idx[i]] += vals[i] for n distinct indices (device arrays): the constant right-hand-side entries
