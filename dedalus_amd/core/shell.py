@@ -1370,7 +1370,10 @@ def _valid_modes(basis, rank, nl, Nr):
 
 class ShellSolverBase:
     """Per-ell systems: the matrices depend on ell only (matrix_dependence of the reference), every
-    (m, part) slot of that ell is a right-hand-side column.  System vectors are [R][2 nm][nl][Nr]."""
+    (m, part) slot of that ell is a right-hand-side column.  System vectors are [R][2 nm][nl][Nr]: one system component
+    per component of a shell-basis variable / equation, while the components that have a single radial point (surface
+    tau fields, constants, boundary rows) are PACKED along n of shared components, so that the system stays a small
+    number of full Nr x Nr blocks (dense GEMM blocks for the inverse) instead of many single-row / single-column ones."""
 
     def __init__(self, problem):
         self.problem, self.dist = problem, problem.dist
@@ -1379,21 +1382,17 @@ class ShellSolverBase:
         self.variables = problem.variables
         sb = shell.sphere
         self.nm, self.nl, self.Nr = sb.nm, sb.nl, shell.Nr
-        self.col0, c = [], 0
-        for v in self.variables:
-            self.col0.append(c)
-            c += v.ncomp
-        self.R = c
-        self.row0, r = [], 0
-        for eq in problem.equations:
-            self.row0.append(r)
-            r += eq["ncomp"]
-        if r != c:
-            raise ValueError("the problem is not square: %d equation components for %d variable components" % (r, c))
+        self.vmap = self._pack_layout([(v.basis, v.ncomp) for v in self.variables])
+        self.emap = self._pack_layout([(eq["basis"], eq["ncomp"]) for eq in problem.equations])
+        self.R = max(sc for m in self.vmap for (sc, off, nr) in m) + 1
+        Re = max(sc for m in self.emap for (sc, off, nr) in m) + 1
+        nv = sum(nr for m in self.vmap for (sc, off, nr) in m)
+        ne = sum(nr for m in self.emap for (sc, off, nr) in m)
+        if nv != ne or Re != self.R:
+            raise ValueError("the problem is not square: %d equation rows for %d unknowns per (m, ell)" % (ne, nv))
         self.nx, self.ny = 2 * self.nm, self.nl * self.Nr          # timestepper buffers: (R, nx, ny) elements
-        self.col_valid = np.concatenate([_valid_modes(v.basis, v.rank, self.nl, self.Nr) for v in self.variables])
-        self.row_valid = np.concatenate([_valid_modes(eq["basis"], eq["rank"], self.nl, self.Nr)
-                                         for eq in problem.equations])
+        self.col_valid = self._packed_valid([(v.basis, v.rank) for v in self.variables], self.vmap)
+        self.row_valid = self._packed_valid([(eq["basis"], eq["rank"]) for eq in problem.equations], self.emap)
         self.M_tl = self._system_termlist("M")
         self.L_tl = self._system_termlist("L")
         self.pack = _EllPack()
@@ -1403,18 +1402,51 @@ class ShellSolverBase:
         self.X = self.ex.zeros((self.R, self.nx, self.ny))
         self.X4 = self.X.reshape(self.R, 2 * self.nm, self.nl, self.Nr)
 
+    def _pack_layout(self, items):
+        """items: (basis, ncomp) per variable / equation -> per item a list over its components of
+        (system component, n offset, radial size)."""
+        out, sc = [None] * len(items), 0
+        for i, (basis, nc) in enumerate(items):           # full-radius components first
+            if isinstance(basis, ShellBasis):
+                out[i] = [(sc + c, 0, self.Nr) for c in range(nc)]
+                sc += nc
+        off = self.Nr                                      # then the single-point ones, packed along n
+        for i, (basis, nc) in enumerate(items):
+            if out[i] is None:
+                lst = []
+                for c in range(nc):
+                    if off >= self.Nr:                     # open a new packed component
+                        sc, off = sc + 1, 0
+                    lst.append((sc - 1, off, 1))
+                    off += 1
+                out[i] = lst
+        return out
+
+    def _packed_valid(self, items, maps):
+        valid = np.zeros((self.R, self.nl, self.Nr), dtype=bool)
+        for (basis, rank), m in zip(items, maps):
+            v = _valid_modes(basis, rank, self.nl, self.Nr)
+            for c, (sc, off, nr) in enumerate(m):
+                valid[sc, :, off:off + nr] = v[c, :, :nr]
+        return valid
+
     def _system_termlist(self, which):
-        tl = EllTermList(self.R, self.R, [])
-        for eq, r0 in zip(self.problem.equations, self.row0):
+        blocks = {}
+        Nr = self.Nr
+        for eq, em in zip(self.problem.equations, self.emap):
             for i, t in eq[which].items():
-                tl.terms += t.embed(r0, self.col0[i], self.R, self.R).terms
-        tl = tl.merged()
+                vm = self.vmap[i]
+                for (co, ci, m) in t.terms:
+                    (so, oo, nro), (si, oi, nri) = em[co], vm[ci]
+                    blk = blocks.setdefault((so, si), np.zeros((self.nl, Nr, Nr)))
+                    blk[:, oo:oo + nro, oi:oi + nri] += m[:, :nro, :nri]
         out = []
-        for (co, ci, m) in tl.terms:
+        for (co, ci), m in sorted(blocks.items()):
             m = m * self.row_valid[co][:, :, None] * self.col_valid[ci][:, None, :]
             m[np.abs(m) < 1e-12] = 0.0          # entry_cutoff of the reference's subproblem matrices (core/subsystems.py:536)
-            out.append((co, ci, m))
-        return EllTermList(self.R, self.R, out).merged()
+            if np.any(m != 0):
+                out.append((co, ci, m))
+        return EllTermList(self.R, self.R, out)
 
     def _dense(self, tl, ell):
         A = np.zeros((self.R * self.Nr, self.R * self.Nr))
@@ -1444,43 +1476,49 @@ class ShellSolverBase:
 
     # ---- state <-> variables -----------------------------------------------------------------------------------------
     def sync_state_to_device(self):
-        for v, c0 in zip(self.variables, self.col0):
+        for v, m in zip(self.variables, self.vmap):
             if isinstance(v, ConstField):
+                sc, off, nr = m[0]
                 col = np.zeros((1, 2 * self.nm, self.nl, 1))
                 col[0, 0, 0, 0] = float(v.value.reshape(-1)[0])
-                self.ex.assign(self.X4[c0:c0 + 1, :, :, :1], self.ex.from_host(col))
+                self.ex.assign(self.X4[sc:sc + 1, :, :, off:off + 1], self.ex.from_host(col))
                 continue
             c = v.require_coeff_space()
-            self.ex.assign(self.X4[c0:c0 + v.ncomp, :, :, :v.basis.Nr], c)
+            for comp, (sc, off, nr) in enumerate(m):
+                self.ex.assign(self.X4[sc:sc + 1, :, :, off:off + nr], c[comp:comp + 1])
 
     def mark_state_current(self):
-        for v, c0 in zip(self.variables, self.col0):
+        for v, m in zip(self.variables, self.vmap):
             if isinstance(v, ConstField):
-                v.value[...] = float(np.asarray(self.ex.download(self.X4[c0:c0 + 1, 0:1, 0:1, 0:1])).reshape(-1)[0])
+                sc, off, nr = m[0]
+                v.value[...] = float(np.asarray(self.ex.download(self.X4[sc:sc + 1, 0:1, 0:1, off:off + 1])).reshape(-1)[0])
                 continue
             c = self.ex.empty(v._cshape())
-            self.ex.assign(c, self.X4[c0:c0 + v.ncomp, :, :, :v.basis.Nr])
+            for comp, (sc, off, nr) in enumerate(m):
+                self.ex.assign(c[comp:comp + 1], self.X4[sc:sc + 1, :, :, off:off + nr])
             v._set_device_coeff(c)
 
     def evaluate_F(self, out):
         ex = self.ex
         ex.fill_zero(out)
         out4 = out.reshape(self.R, 2 * self.nm, self.nl, self.Nr)
-        for eq, r0 in zip(self.problem.equations, self.row0):
+        for eq, m in zip(self.problem.equations, self.emap):
             F = eq["F"]
             if F is None:
                 continue
-            nr = eq["basis"].Nr if eq["basis"] is not None else 1
             if isinstance(F, float):
                 # constant right-hand side of a scalar equation (e.g. "T(r=Ri) = 1"): the ell = 0 mode, sqrt(2) amplitude
                 if eq["rank"] != 0:
                     raise NotImplementedError("constant right-hand side of a tensor equation")
+                sc, off, nr = m[0]
                 col = np.zeros((1, 2 * self.nm, self.nl, nr))
                 col[0, 0, 0, 0] = F / SphereBasis.constant_mode_value * \
                     (1.0 if isinstance(eq["basis"], SurfaceBasis) else 1.0 / self._radial_constant(eq["basis"]))
-                ex.assign(out4[r0:r0 + 1, :, :, :nr], ex.from_host(col))
+                ex.assign(out4[sc:sc + 1, :, :, off:off + nr], ex.from_host(col))
             else:
-                ex.assign(out4[r0:r0 + eq["ncomp"], :, :, :nr], F.eval_c())
+                c = F.eval_c()
+                for comp, (sc, off, nr) in enumerate(m):
+                    ex.assign(out4[sc:sc + 1, :, :, off:off + nr], c[comp:comp + 1])
 
     def _radial_constant(self, basis):
         from ..tools import jacobi
