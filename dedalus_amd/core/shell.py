@@ -14,7 +14,9 @@ factor fused, ddh_grouped_mmt_* with the radial points as GEMM columns, ddh_spin
 Operators and the per-ell radial solves of the shell are not built yet.
 """
 
+import logging
 import numbers
+import time as _time
 
 import numpy as np
 
@@ -23,6 +25,9 @@ from . import curvilinear
 from .basis import Jacobi
 from .coords import Coordinate
 from .sphere import S2Coordinates, SphereBasis
+
+
+logger = logging.getLogger(__name__)
 
 
 class SphericalCoordinates:
@@ -552,7 +557,25 @@ def operate_slot_sequences(sb):
 class ShOperand:
     """Expression node in spherical coordinates.  basis: ShellBasis (k), SurfaceBasis or None."""
     __array_priority__ = 100.0
-    __array_ufunc__ = None
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        """numpy scalars and ufuncs applied to operands (np.sqrt(u@u), np.float64(2) * u, ...)"""
+        if method != "__call__" or kw:
+            return NotImplemented
+        if len(inputs) == 1:
+            return ShUnary(ufunc, inputs[0])
+        a, b = inputs
+        if ufunc is np.multiply:
+            return a * b if isinstance(a, ShOperand) else b * a
+        if ufunc is np.add:
+            return a + b if isinstance(a, ShOperand) else b + a
+        if ufunc is np.subtract:
+            return a - b if isinstance(a, ShOperand) else (-1 * b) + a
+        if ufunc is np.true_divide and isinstance(b, numbers.Number):
+            return a * (1.0 / b)
+        if ufunc is np.matmul:
+            return ShProduct(a, b, contract=True)
+        return NotImplemented
 
     @property
     def ncomp(self):
@@ -601,7 +624,7 @@ class ShOperand:
             raise ValueError("one coordinate at a time")
         (name, pos), = kw.items()
         if name != self.dist.coordsys.radius.name:
-            raise NotImplementedError("interpolation along %r" % name)
+            return ShUnsupported("interpolation along %r (analysis tasks only)" % name, self)
         return ShLinear("interp", self, position=float(pos))
 
     def has_dt(self):
@@ -615,6 +638,44 @@ class ShOperand:
         f = ShellField(self.dist, self.basis, rank=self.rank)
         f._set_device_coeff(self.eval_c())
         return f
+
+
+class ShUnsupported(ShOperand):
+    """Placeholder for expressions that scripts build for output tasks but that nothing evaluates here."""
+
+    def __init__(self, what, arg):
+        self.what, self.args = what, (arg,)
+        self.dist, self.basis, self.rank = arg.dist, arg.basis, arg.rank
+
+    def eval_c(self):
+        raise NotImplementedError(self.what)
+
+    def lin(self, variables):
+        raise NonlinearError(self.what)
+
+
+class ShUnary(ShOperand):
+    """ufunc(operand) point by point on the dealiased grid (UnaryGridFunction, core/operators.py:460-560); an
+    analysis-only path: the grid data make a round trip through the host."""
+
+    def __init__(self, func, arg):
+        if arg.rank:
+            raise NotImplementedError("ufuncs of tensor fields")
+        self.func, self.args = func, (arg,)
+        self.dist, self.basis, self.rank = arg.dist, arg.basis, 0
+
+    def grid_native(self):
+        ex = self.dist.executor
+        return ex.from_host(np.ascontiguousarray(self.func(np.asarray(ex.download(self.args[0].eval_g())))))
+
+    def eval_g(self):
+        return self.grid_native()
+
+    def eval_c(self):
+        return forward(self.dist, self.basis, 0, self.grid_native(), self.basis.dealias)
+
+    def lin(self, variables):
+        raise NonlinearError("grid functions are nonlinear")
 
 
 class ShScale(ShOperand):
@@ -1232,6 +1293,26 @@ class ShellField(ShOperand):
         self._host_layout, self._host_scales = layout, self.scales
         self._authority = "host"
 
+    def cfl_frequency_max(self):
+        """max over the dealiased grid of the advective CFL frequency of this velocity field (Spherical3DAdvectiveCFL,
+        core/basis.py:6183-6204), reduced on the device."""
+        if self.rank != 1 or not isinstance(self.basis, ShellBasis):
+            raise ValueError("CFL velocity must be a vector field on a shell")
+        ex = self.ex
+        key = ("cfl", id(ex))
+        shell = self.basis
+        store = getattr(shell, "_root", shell)._plans
+        if key not in store:
+            sc = shell.dealias
+            r = shell.radius_grid(sc[2])
+            Lmax = shell.sphere.Lmax
+            h = r / np.sqrt(Lmax * (Lmax + 1)) if Lmax > 0 else np.full_like(r, np.inf)
+            dr = np.gradient(r, edge_order=2) * sc[2]
+            store[key] = (ex.from_host(np.ascontiguousarray(1.0 / h)), ex.from_host(np.ascontiguousarray(1.0 / np.abs(dr))))
+        inv_h, inv_dr = store[key]
+        g = self.eval_g()
+        return ex.cfl_max_spherical(g, inv_h, inv_dr)
+
     def fill_random(self, layout=None, scales=None, seed=None, chunk_size=2 ** 20, distribution="standard_normal", **kw):
         """The reference's reproducible global random stream (core/field.py:898-943, tools/random_arrays.py:7-55)."""
         if scales is not None:
@@ -1558,7 +1639,6 @@ class ShellInitialValueSolver(ShellSolverBase):
 
     def __init__(self, problem, timestepper, **kw):
         super().__init__(problem)
-        import time as _time
         from . import timesteppers as ts
         from .solvers import _HandlerRegistry
         if isinstance(timestepper, str):
@@ -1571,6 +1651,9 @@ class ShellInitialValueSolver(ShellSolverBase):
         self._lus = []
         self.timestepper = timestepper(self)
         self.start_time = _time.time()
+        self.warmup_iterations, self.warmup_time = 10, None
+        self._step_hooks = []
+        self.total_modes = int(self.col_valid.sum()) * 2 * self.nm
         self.evaluator = _HandlerRegistry(self)
 
     def factor(self, a, b, reuse=-1):
@@ -1588,6 +1671,11 @@ class ShellInitialValueSolver(ShellSolverBase):
         if not np.isfinite(dt):
             raise ValueError("Invalid timestep: %r" % dt)
         self.dt = dt
+        if self.iteration == self.initial_iteration + self.warmup_iterations:
+            self.ex.sync()
+            self.warmup_time = _time.time()
+        for hook in self._step_hooks:        # scheduled analysis (CFL frequencies) sees the pre-step state
+            hook(self)
         self.timestepper.step(dt, 0.0)
         # Hermitian-symmetry enforcement of the reference (core/solvers.py:675-681, 704-708): the state makes a round
         # trip through the dealiased grid during the first `steps` iterations of every cadence
@@ -1605,7 +1693,16 @@ class ShellInitialValueSolver(ShellSolverBase):
         return self.sim_time < self.stop_sim_time and self.iteration < self.stop_iteration
 
     def log_stats(self, format=".4g"):
-        pass
+        """core/solvers.py:755-778"""
+        self.ex.sync()
+        logger.info("Final iteration: %i" % self.iteration)
+        logger.info("Final sim time: %s" % self.sim_time)
+        if self.warmup_time is not None:
+            run = _time.time() - self.warmup_time
+            its = self.iteration - self.initial_iteration - self.warmup_iterations
+            logger.info("Run time (iter %d-end): %.4g sec" % (self.warmup_iterations, run))
+            if run > 0:
+                logger.info("Speed: %.4g mode-stages/gpu-sec" % (self.total_modes * its * self.timestepper.stages / run))
 
 
 # ==================================================================================================

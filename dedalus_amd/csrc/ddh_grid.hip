@@ -127,6 +127,29 @@ __global__ void __launch_bounds__(256) cfl_kernel(double *result, const double *
     if (threadIdx.x == 0) atomic_max_double(result, red[0]);
 }
 
+// spherical advective CFL (Spherical3DAdvectiveCFL, core/basis.py:6183-6204 with S2AdvectiveCFL :6156-6180):
+// max over the grid of sqrt(u_phi^2 + u_theta^2) * inv_h[r] + |u_r| * inv_dr[r],  u = [3][n_ang][nr]
+__global__ void __launch_bounds__(256)
+cfl_spherical_kernel(double *result, const double *__restrict__ u, long n_ang, int nr, const double *__restrict__ inv_h,
+                     const double *__restrict__ inv_dr) {
+    __shared__ double red[256];
+    double m = 0.0;
+    const long n = n_ang * nr;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int ir = (int)(i % nr);
+        const double up = u[i], ut = u[n + i], ur = u[2 * n + i];
+        m = fmax(m, sqrt(up * up + ut * ut) * inv_h[ir] + fabs(ur) * inv_dr[ir]);
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomic_max_double(result, red[0]);
+}
+
 // [outer][na][nb*inner]  ->  [P][outer][na/P][nb*inner]   (split axis a into P blocks)
 __global__ void __launch_bounds__(256)
 a2a_pack_kernel(const double *__restrict__ src, double *__restrict__ dst, long outer, long na, long row, int P) {
@@ -275,6 +298,16 @@ int ddh_grid_cfl(double *result_d, const double *u, int ncomp, long n, const dou
     if (tot != n) return fail("ddh_grid_cfl: axis lengths do not multiply to n");
     DDH_HIP(hipMemsetAsync(result_d, 0, sizeof(double), as_stream(stream)));
     hipLaunchKernelGGL(cfl_kernel, dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), result_d, u, n, a);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_grid_cfl_spherical(double *result_d, const double *u, long n_ang, int nr, const double *inv_h_d,
+                           const double *inv_dr_d, void *stream) {
+    if (n_ang <= 0 || nr <= 0) return fail("ddh_grid_cfl_spherical: empty grid");
+    DDH_HIP(hipMemsetAsync(result_d, 0, sizeof(double), as_stream(stream)));
+    hipLaunchKernelGGL(cfl_spherical_kernel, dim3(stream_grid(n_ang * nr)), dim3(256), 0, as_stream(stream), result_d, u,
+                       n_ang, nr, inv_h_d, inv_dr_d);
     DDH_HIP(hipGetLastError());
     return 0;
 }

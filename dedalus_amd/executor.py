@@ -176,6 +176,14 @@ class HipExecutor:
         libhip.call("ddh_grid_cfl", ptr(res), ptr(u), ncomp, n, arr, libhip.as_ip(ca), ln, len(shape), self.dev.stream)
         return float(res.cpu().item())
 
+    def cfl_max_spherical(self, u, inv_h, inv_dr):
+        """u [3][Nphi][Ntheta][Nr] (device), inv_h / inv_dr device arrays over r -> max CFL frequency (float)."""
+        nr = int(u.shape[-1])
+        n_ang = int(u.shape[1]) * int(u.shape[2])
+        res = self.empty((1,))
+        libhip.call("ddh_grid_cfl_spherical", ptr(res), ptr(u), n_ang, nr, ptr(inv_h), ptr(inv_dr), self.dev.stream)
+        return float(self.download(res)[0])
+
     def a2a_pack(self, src, dst, outer, na, nb, inner, P):
         libhip.call("ddh_a2a_pack", ptr(src), ptr(dst), outer, na, nb, inner, P, self.dev.stream)
 

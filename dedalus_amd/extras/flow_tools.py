@@ -18,22 +18,38 @@ class GlobalFlowProperty:
         self.properties = {}
         self._cache = {}
         self._cache_iter = None
+        self._sampled = {}
+        # the reference evaluates the properties with a dictionary handler scheduled at iter % cadence == 0, i.e. at
+        # the START of those steps (flow_tools.py:60-63, core/solvers.py evaluate_scheduled); max()/min()/... read the
+        # last scheduled evaluation
+        if hasattr(solver, "_step_hooks"):
+            solver._step_hooks.append(self._sample)
 
     def add_property(self, property, name, precompute_integral=False):
         self.properties[name] = property
 
+    def _evaluate(self, name):
+        expr = self.properties[name]
+        f = expr.evaluate() if hasattr(expr, "evaluate") else expr
+        return np.array(f["g"])
+
+    def _sample(self, solver):
+        if solver.iteration % self.cadence == 0:
+            for name in self.properties:
+                self._sampled[name] = self._evaluate(name)
+
     def _grid(self, name):
+        if name in self._sampled:
+            return self._sampled[name]
         it = self.solver.iteration
         if self._cache_iter != it:
             self._cache, self._cache_iter = {}, it
         if name not in self._cache:
-            expr = self.properties[name]
-            f = expr.evaluate() if hasattr(expr, "evaluate") else expr
-            self._cache[name] = np.array(f["g"])
+            self._cache[name] = self._evaluate(name)
         return self._cache[name]
 
     def _reduce(self, val, op):
-        pc = self.solver.dist.pcomm
+        pc = getattr(self.solver.dist, "pcomm", None)
         if pc is None:
             return float(val)
         return pc.allreduce_max(val) if op == "max" else (-pc.allreduce_max(-val) if op == "min" else pc.allreduce_sum(val))
@@ -113,6 +129,9 @@ class CFL:
         ex = solver.ex
         fmax = 0.0
         for u in self.velocities:
+            if hasattr(u, "cfl_frequency_max"):             # curvilinear fields carry their own CFL reduction
+                fmax = max(fmax, u.cfl_frequency_max())
+                continue
             f = u if hasattr(u, "grid_data") else u.evaluate()
             inv, comp_axis, scales = self._spacings(f)
             g = f.grid_data(scales)
@@ -120,7 +139,7 @@ class CFL:
             fmax += ex.cfl_max(g, f.ncomp, shape, inv, comp_axis) if len(self.velocities) == 1 else 0.0
             if len(self.velocities) > 1:
                 raise NotImplementedError("several CFL velocities")
-        if solver.dist.pcomm is not None:
+        if getattr(solver.dist, "pcomm", None) is not None:
             fmax = solver.dist.pcomm.allreduce_max(fmax)
         self._max_freq = fmax
 

@@ -78,6 +78,7 @@ SIGNATURES = {
     "ddh_lincomb": [_vp, _i, C.POINTER(_vp), _dp, _l, _vp],
     "ddh_grid_bilinear": [_vp, _i, _vp, _vp, _l, _i, _ip, _ip, _ip, _dp, _vp],
     "ddh_grid_cfl": [_vp, _vp, _i, _l, C.POINTER(_vp), _ip, C.POINTER(_l), _i, _vp],
+    "ddh_grid_cfl_spherical": [_vp, _vp, _l, _i, _vp, _vp, _vp],
     "ddh_pencil_create": [_hp, C.POINTER(PencilGeom)],
     "ddh_pencil_add_matrix": [_h, C.POINTER(PolyMat), _i, _ip],
     "ddh_pencil_matvec": [_h, _i, _vp, _vp, _vp],

@@ -185,6 +185,12 @@ int ddh_grid_cfl(double *result_d, const double *u, int ncomp, long n,
                  const double *const *inv_spacing_comp, const int *comp_axis_h,
                  const long *axis_len_h, int naxes, void *stream);
 
+/* Spherical shells: max over the grid of sqrt(u_phi^2 + u_theta^2) * inv_h[r] + |u_r| * inv_dr[r] with
+ * u = [3][n_ang][nr] coordinate components (Spherical3DAdvectiveCFL, core/basis.py:6183-6204: horizontal spacing
+ * r / sqrt(Lmax (Lmax + 1)), radial spacing of the dealiased Gauss grid).                                 */
+int ddh_grid_cfl_spherical(double *result_d, const double *u, long n_ang, int nr, const double *inv_h_d,
+                           const double *inv_dr_d, void *stream);
+
 /* ---- pencil systems ------------------------------------------ */
 /* A "pencil pack" describes all pencils of a problem at once.  System vectors are real arrays
  * [nrows][nx][ny] (cell index fastest).  With nfourier real-Fourier separable axes a cell holds

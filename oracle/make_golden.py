@@ -298,6 +298,11 @@ def golden_shellfields():
         for k, v in res.items():
             out["conv_%s__%s" % (ts, k)] = v
         print("shell convection", ts, {k: float(np.linalg.norm(v)) for k, v in res.items()})
+    solver, dts, speeds, res = problems.run_shell_cfl_case(d3)
+    out["shellcfl__dts"], out["shellcfl__speeds"] = dts, speeds
+    for k, v in res.items():
+        out["shellcfl__" + k] = v
+    print("shell cfl dts", dts, "speeds", speeds)
     np.savez_compressed(os.path.join(GOLD, "shellfields.npz"), **out)
     print("wrote shellfields.npz with", len(out), "arrays")
 

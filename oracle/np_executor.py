@@ -187,6 +187,10 @@ class NumpyExecutor:
             f = f + ug[c] * np.asarray(inv_spacings[c]).reshape(sh)
         return float(f.max()) if f.size else 0.0
 
+    def cfl_max_spherical(self, u, inv_h, inv_dr):
+        """Spherical3DAdvectiveCFL.compute_cfl_frequency (core/basis.py:6199-6204) reduced with max"""
+        return float(np.max(np.sqrt(u[0] ** 2 + u[1] ** 2) * inv_h + np.abs(u[2]) * inv_dr))
+
     def a2a_pack(self, src, dst, outer, na, nb, inner, P):
         """split_rows / split_columns of AlltoallvTranspose (core/transposes.pyx:359-445) restated"""
         s = src.reshape(outer, P, na // P, nb * inner)

@@ -423,3 +423,40 @@ def run_shell_convection(d3, steps=4, dt=0.05, **kw):
     for _ in range(steps):
         solver.step(dt)
     return solver, {k: np.array(f['c']) for k, f in fields.items()}
+
+
+def run_shell_cfl_case(d3, dist_kw=None, nsteps=20):
+    """Shell convection with an O(1) initial flow and the example's adaptive-timestep loop
+    (examples/ivp_shell_convection/shell_convection.py:97-118): the dt sequence pins the spherical CFL reduction,
+    its scheduling and the refactorization on every dt change."""
+    solver, f = shell_convection(d3, shape=(16, 12, 8), timestepper="SBDF2", dist_kw=dist_kw)
+    u = f["u"]
+    dist = u.dist
+    shell = [v for v in (f["b"],)][0]
+    coords = dist.coords
+    phi, theta, r = dist.local_grids(_shell_basis_of(f["b"]))
+    ug = np.zeros((3,) + np.broadcast(phi, theta, r).shape)
+    ug[0] = 8.0 * np.sin(theta) * (r - 14) * (15 - r) * 4
+    ug[1] = 5.0 * np.sin(theta) * np.cos(phi) * (r - 14) * (15 - r) * 4
+    ug[2] = 3.0 * np.cos(theta) * (r - 14) * (15 - r) * 4
+    u['g'] = ug
+    CFL = d3.CFL(solver, initial_dt=0.006, cadence=2, safety=0.5, threshold=0.05, max_change=1.5, min_change=0.5,
+                 max_dt=0.1)
+    CFL.add_velocity(u)
+    flow = d3.GlobalFlowProperty(solver, cadence=2)
+    flow.add_property(np.sqrt(u @ u), name='speed')
+    dts, speeds = [], []
+    for _ in range(nsteps):
+        dt = CFL.compute_timestep()
+        solver.step(dt)
+        dts.append(dt)
+        if (solver.iteration - 1) % 2 == 0:
+            speeds.append(flow.max('speed'))
+    return solver, np.array(dts), np.array(speeds), {k: np.array(f[k]['c']) for k in ("p", "b", "u")}
+
+
+def _shell_basis_of(field):
+    b = getattr(field, "basis", None)
+    if b is not None:
+        return b
+    return field.domain.bases[0]

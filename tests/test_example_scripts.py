@@ -94,3 +94,32 @@ def test_reference_poisson_lbvp_example_runs_unmodified(monkeypatch, tmp_path):
     x = np.ravel(ns["x"])
     u, coords = ns["u"], ns["coords"]
     assert os.path.exists(os.path.join(tmp_path, "poisson.pdf"))
+
+
+SHELL_EXAMPLE = "/root/reference/examples/ivp_shell_convection/shell_convection.py"
+
+
+@pytest.mark.skipif(not os.path.exists(SHELL_EXAMPLE), reason="reference examples only exist in the build container")
+def test_reference_shell_convection_example_runs_unmodified(monkeypatch, tmp_path):
+    """examples/ivp_shell_convection/shell_convection.py (192 x 96 x 6, CFL-driven SBDF2 loop, flow properties,
+    output tasks) through dedalus_amd.compat."""
+    import dedalus_amd.compat as compat
+    from dedalus_amd.core import shell
+    from oracle.np_executor import NumpyExecutor
+    compat.install()
+    orig_init = shell.ShellDistributor.__init__
+
+    def init(self, *a, **k):
+        k.setdefault("executor", NumpyExecutor())
+        orig_init(self, *a, **k)
+    monkeypatch.setattr(shell.ShellDistributor, "__init__", init)
+    orig_proceed = shell.ShellInitialValueSolver.proceed
+
+    def proceed(self):
+        return orig_proceed.fget(self) and self.iteration < 3
+    monkeypatch.setattr(shell.ShellInitialValueSolver, "proceed", property(proceed))
+    monkeypatch.chdir(tmp_path)
+    ns = runpy.run_path(SHELL_EXAMPLE, run_name="__main__")
+    solver, b, u = ns["solver"], ns["b"], ns["u"]
+    assert solver.iteration == 3 and solver.sim_time == 3.0
+    assert np.isfinite(np.asarray(b["g"])).all() and np.isfinite(np.asarray(u["g"])).all()

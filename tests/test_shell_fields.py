@@ -138,3 +138,26 @@ def test_shell_convection_oracle(ts):
 def test_shell_convection_gpu(ts):
     solver = check_convection(ts, None)
     assert solver.ex.name == "hip"
+
+
+def check_cfl(dist_kw):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import problems
+    import dedalus_amd.public as d3
+    solver, dts, speeds, res = problems.run_shell_cfl_case(d3, dist_kw=dist_kw)
+    assert np.allclose(dts, GOLD["shellcfl__dts"], rtol=1e-10, atol=0), (dts, GOLD["shellcfl__dts"])
+    assert np.allclose(speeds, GOLD["shellcfl__speeds"], rtol=1e-10, atol=0)
+    for k in ("p", "b", "u"):
+        assert _rel(res[k], GOLD["shellcfl__" + k]) < 1e-9, (k, _rel(res[k], GOLD["shellcfl__" + k]))
+
+
+def test_shell_cfl_timestep_sequence_oracle():
+    """The example's adaptive loop: spherical CFL frequency (device reduction), scheduling, refactorization on every
+    dt change, GlobalFlowProperty of np.sqrt(u@u) -- dt sequence and end state of the reference."""
+    check_cfl(_np_kw())
+
+
+@pytest.mark.gpu
+def test_shell_cfl_timestep_sequence_gpu():
+    check_cfl(None)
