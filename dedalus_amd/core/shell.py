@@ -155,10 +155,12 @@ class ShellBasis:
             sb = self.sphere
             groups, keys, fwd, bwd, cache = [], [], [], [], {}
             for i, s in enumerate(self.spin_totals(rank)):
-                for m in range(sb.nm):
+                for ml in range(sb.nml):
+                    m = sb.m0 + ml
                     mk = m + 4096 * (s + 8)
                     ne = max(sb.Lmax + 1 - m, 0)
-                    groups.append((mk if ne > 0 else -1 - m, i * 2 * sb.nm + 2 * m, i * 2 * sb.nm + 2 * m, 2, m, 1, ne))
+                    row = i * 2 * sb.nml + 2 * ml
+                    groups.append((mk if ne > 0 else -1 - m, row, row, 2, m, 1, ne))
                     if ne > 0 and mk not in cache:
                         cache[mk] = sph.swsh_matrices(Ntheta_g, sb.Lmax, m, s)
                         keys.append(mk)
@@ -180,6 +182,7 @@ class ShellBasis:
             rows, cols, ok = sb.pack_index()
             slot = -np.ones((2 * sb.nm, sb.nl), dtype=np.int32)
             slot[rows[ok], cols[ok]] = slot_p[ok]
+            slot = np.ascontiguousarray(slot[2 * sb.m0:2 * (sb.m0 + sb.nml)])
             store[key] = (ex.make_recombination(slot, fwd) if rank > 0 else None,
                           ex.make_recombination(slot, bwd) if rank > 0 else None)
         return store[key]
@@ -199,10 +202,24 @@ class ShellDistributor:
         self.coords = coordsys.coords
         self.dim = 3
         self.dtype = np.dtype(np.float64 if dtype is None else dtype)
-        if mesh is not None and int(np.prod(mesh)) > 1:
-            raise NotImplementedError("shell fields live on one device in this round")
-        self.mesh, self.size, self.rank, self.comm = (), 1, 0, comm
+        P = int(np.prod(mesh)) if mesh is not None and len(tuple(mesh)) else 1
+        self.mesh, self.size, self.rank, self.comm, self.pcomm = (), 1, 0, comm, None
+        if P > 1:
+            # one process per GPU on a 1-D mesh: azimuthal wavenumbers block-distributed in coefficient space,
+            # colatitudes in grid space (the reference's layouts for a 1-D mesh, core/distributor.py:60-70)
+            from ..parallel import Comm
+            self.pcomm = Comm(P)
+            self.mesh, self.size, self.rank = (P,), P, self.pcomm.rank
+        coordsys.dist = self
+        coordsys.S2coordsys.dist = self
         self._executor = executor
+
+    def theta_range(self, Nt):
+        """(first local colatitude index, number of local colatitudes) of a grid with Nt colatitudes"""
+        if Nt % self.size:
+            raise ValueError("%d colatitudes do not divide over %d ranks" % (Nt, self.size))
+        n = Nt // self.size
+        return self.rank * n, n
 
     @property
     def executor(self):
@@ -241,7 +258,8 @@ class ShellDistributor:
         elif isinstance(scales, numbers.Number):
             scales = (scales,) * 3
         phi, theta, r = basis.grids(scales)
-        return phi[:, None, None], theta[None, :, None], r[None, None, :]
+        t0, nt = self.theta_range(theta.size)
+        return phi[:, None, None], theta[None, t0:t0 + nt, None], r[None, None, :]
 
 
 class RadialBasis:
@@ -284,29 +302,44 @@ class SurfaceBasis:
 
 
 def backward(dist, basis, rank, c, scales):
-    """coefficients [nc][2 nm][nl][Nr] (regularity components) -> grid [nc][Nphi_g][Ntheta_g][Nr_g] (coordinate components)"""
+    """coefficients [nc][2 nml][nl][Nr] (regularity components, local m) -> grid [nc][Nphi_g][Ntheta_g / P][Nr_g]
+    (coordinate components, local colatitudes).  On P ranks the only exchange is the all-to-all between "m local
+    block, all colatitudes" and "all m, colatitude block" that replaces the reference's (azimuth, colatitude)
+    transpose (core/distributor.py:770-924), placed before the azimuthal FFT."""
     ex = dist.executor
     sb = basis.sphere
     nc = 3 ** rank
+    nml = sb.nml
     Np, Nt, Ng = basis.grid_shape(scales)
-    nslots = nc * 2 * sb.nm * sb.nl
+    nslots = nc * 2 * nml * sb.nl
     if isinstance(basis, SurfaceBasis):
         t0 = c                                             # spin components, no radial axis
     else:
-        t0 = ex.empty((nc, 2 * sb.nm, sb.nl, Ng))
+        t0 = ex.empty((nc, 2 * nml, sb.nl, Ng))
         ex.transform(basis.radial.plan_spec(scales[2]), basis.radial, "backward", c, t0, nslots, 1)
         ex.regularity_recombine(t0, basis.regularity_plan(ex, rank)[1],
                                 basis.radial_factor(ex, scales[2], basis.k) if basis.k > 0 else None)
-    t1 = ex.empty((nc, 2 * sb.nm, Nt, Ng))
-    basis.colatitude_plan(ex, Nt, rank).backward(t0.reshape(1, nc * 2 * sb.nm, sb.nl, Ng),
-                                                 t1.reshape(1, nc * 2 * sb.nm, Nt, Ng))
+    t1 = ex.empty((nc, 2 * nml, Nt, Ng))
+    basis.colatitude_plan(ex, Nt, rank).backward(t0.reshape(1, nc * 2 * nml, sb.nl, Ng),
+                                                 t1.reshape(1, nc * 2 * nml, Nt, Ng))
     if rank > 0:
-        t2 = ex.empty((nc, 2 * sb.nm, Nt * Ng))
-        ex.spin_recombine(t1.reshape(nc, 2 * sb.nm, Nt * Ng), t2, basis.recombination_matrix(rank, forward=False))
+        t2 = ex.empty((nc, 2 * nml, Nt * Ng))
+        ex.spin_recombine(t1.reshape(nc, 2 * nml, Nt * Ng), t2, basis.recombination_matrix(rank, forward=False))
     else:
         t2 = t1
-    g = ex.empty((nc, Np, Nt, Ng))
-    ex.transform(("rfft", Np, sb.Nphi), None, "backward", t2, g, nc, Nt * Ng)
+    P = dist.size
+    Ntl = Nt
+    if P > 1:
+        # [nc][2 nml][Nt][Ng] -> [nc][2 nm][Nt / P][Ng]
+        Ntl = dist.theta_range(Nt)[1]
+        n_el = nc * 2 * nml * Nt * Ng
+        send, recv = ex.empty((n_el,)), ex.empty((n_el,))
+        ex.a2a_pack(t2, send, nc * 2 * nml, Nt, 1, Ng, P)
+        dist.pcomm.all_to_all(recv, send)
+        t2 = ex.empty((nc, 2 * sb.nm, Ntl * Ng))
+        ex.a2a_unpack(recv, t2, nc, 1, 2 * nml * P, Ntl * Ng, P)
+    g = ex.empty((nc, Np, Ntl, Ng))
+    ex.transform(("rfft", Np, sb.Nphi), None, "backward", t2, g, nc, Ntl * Ng)
     return g
 
 
@@ -314,23 +347,34 @@ def forward(dist, basis, rank, g, scales):
     ex = dist.executor
     sb = basis.sphere
     nc = 3 ** rank
+    nml = sb.nml
     Np, Nt, Ng = basis.grid_shape(scales)
-    t1 = ex.empty((nc, 2 * sb.nm, Nt * Ng))
-    ex.transform(("rfft", Np, sb.Nphi), None, "forward", g, t1, nc, Nt * Ng)
+    P = dist.size
+    Ntl = dist.theta_range(Nt)[1] if P > 1 else Nt
+    t1 = ex.empty((nc, 2 * sb.nm, Ntl * Ng))
+    ex.transform(("rfft", Np, sb.Nphi), None, "forward", g, t1, nc, Ntl * Ng)
+    if P > 1:
+        # [nc][2 nm][Nt / P][Ng] -> [nc][2 nml][Nt][Ng]
+        n_el = nc * 2 * sb.nm * Ntl * Ng
+        send, recv = ex.empty((n_el,)), ex.empty((n_el,))
+        ex.a2a_pack(t1, send, nc, 2 * sb.nm, Ntl, Ng, P)
+        dist.pcomm.all_to_all(recv, send)
+        t1 = ex.empty((nc, 2 * nml, Nt * Ng))
+        ex.a2a_unpack(recv, t1, nc, 2 * nml, Ntl * P, Ng, P)
     if rank > 0:
-        t2 = ex.empty((nc, 2 * sb.nm, Nt * Ng))
+        t2 = ex.empty((nc, 2 * nml, Nt * Ng))
         ex.spin_recombine(t1, t2, basis.recombination_matrix(rank, forward=True))
     else:
         t2 = t1
-    t3 = ex.zeros((nc, 2 * sb.nm, sb.nl, Ng))
-    basis.colatitude_plan(ex, Nt, rank).forward(t2.reshape(1, nc * 2 * sb.nm, Nt, Ng),
-                                                t3.reshape(1, nc * 2 * sb.nm, sb.nl, Ng))
+    t3 = ex.zeros((nc, 2 * nml, sb.nl, Ng))
+    basis.colatitude_plan(ex, Nt, rank).forward(t2.reshape(1, nc * 2 * nml, Nt, Ng),
+                                                t3.reshape(1, nc * 2 * nml, sb.nl, Ng))
     if isinstance(basis, SurfaceBasis):
         return t3
     ex.regularity_recombine(t3, basis.regularity_plan(ex, rank)[0],
                             basis.radial_factor(ex, scales[2], -basis.k) if basis.k > 0 else None)
-    c = ex.empty((nc, 2 * sb.nm, sb.nl, basis.Nr))
-    ex.transform(basis.radial.plan_spec(scales[2]), basis.radial, "forward", t3, c, nc * 2 * sb.nm * sb.nl, 1)
+    c = ex.empty((nc, 2 * nml, sb.nl, basis.Nr))
+    ex.transform(basis.radial.plan_spec(scales[2]), basis.radial, "forward", t3, c, nc * 2 * nml * sb.nl, 1)
     return c
 
 
@@ -830,9 +874,10 @@ class ShLinear(ShOperand):
             tl = self.termlist()
             seqs, slot_map = operate_slot_sequences(sb)
             terms = [(co, ci, np.concatenate([m] + [sum(m[l] for l in seq)[None] for seq in seqs])) for (co, ci, m) in tl.terms]
-            self._dev = (ex, ex.make_ell_terms(sb.nm, sb.nl, shell.Nr, tl.nco, terms, slot_map))
+            slot_map = np.ascontiguousarray(slot_map[2 * sb.m0:2 * (sb.m0 + sb.nml)])
+            self._dev = (ex, ex.make_ell_terms(sb.nml, sb.nl, shell.Nr, tl.nco, terms, slot_map))
         x = _padded(ex, self.arg.eval_c(), shell.Nr)
-        y = ex.empty((self.ncomp, 2 * sb.nm, sb.nl, shell.Nr))
+        y = ex.empty((self.ncomp, 2 * sb.nml, sb.nl, shell.Nr))
         self._dev[1].apply(x, y)
         return _unpadded(ex, y, self.basis.Nr if self.basis is not None else 1)
 
@@ -916,6 +961,7 @@ class ShProduct(ShOperand):
         ga, gb = a.eval_g(), b.eval_g()
         terms, nout = _bilinear_terms3(a.rank, b.rank, self.contract)
         Np, Nt, Ng = self.basis.grid_shape(self.basis.dealias)
+        Nt = self.dist.theta_range(Nt)[1]               # local colatitudes
         out = ex.empty((nout, Np, Nt, Ng))
         ex.bilinear(out, nout, ga, gb, Np * Nt * Ng, terms)
         return out
@@ -1076,7 +1122,7 @@ class ConstField(ShOperand):
     # solver interface
     def _cshape_in(self, shell):
         sb = shell.sphere
-        return (1, 2 * sb.nm, sb.nl, 1)
+        return (1, 2 * sb.nml, sb.nl, 1)
 
 
 class RadialField(ShOperand):
@@ -1177,7 +1223,7 @@ class ShellField(ShOperand):
 
     def _cshape(self):
         sb = self.basis.sphere
-        return (self.ncomp, 2 * sb.nm, sb.nl, self.basis.Nr)
+        return (self.ncomp, 2 * sb.nml, sb.nl, self.basis.Nr)
 
     def _set_device_coeff(self, c):
         self._c = c
@@ -1185,11 +1231,56 @@ class ShellField(ShOperand):
         self._authority = "device"
         self._g = None
 
-    def _user_shape(self, layout, scales):
+    def _global_shape(self, layout, scales):
         t = (3,) * self.rank
         if layout == "g":
             return t + self.basis.grid_shape(scales)
         return t + self.basis.sphere.packed_shape() + (self.basis.Nr,)
+
+    def _local_slices(self, layout, scales):
+        """slices of the global user array held by this rank: colatitude block in grid space, block of the packed
+        azimuthal axis in coefficient space (Layout.local_chunks of the reference, core/distributor.py:357-385)"""
+        sl = [slice(None)] * (self.rank + 3)
+        d = self.dist
+        if d.size > 1:
+            if layout == "g":
+                t0, nt = d.theta_range(self.basis.grid_shape(scales)[1])
+                sl[self.rank + 1] = slice(t0, t0 + nt)
+            else:
+                n = self.basis.sphere.packed_shape()[0]
+                if n % (2 * d.size):
+                    raise ValueError("packed azimuthal axis of %d does not divide over %d ranks" % (n, d.size))
+                sl[self.rank] = slice(d.rank * (n // d.size), (d.rank + 1) * (n // d.size))
+        return tuple(sl)
+
+    def _user_shape(self, layout, scales):
+        g = self._global_shape(layout, scales)
+        return tuple(len(range(*sl.indices(n))) for sl, n in zip(self._local_slices(layout, scales), g))
+
+    def _natural_from_packed(self, h):
+        """user (packed, local block) coefficients -> natural [ncomp][2 nml][nl][Nr] of the local wavenumbers.  On several
+        ranks the folded part of the packed layout belongs to other ranks' wavenumbers: the blocks are all-gathered
+        (user access is a synchronisation point, not part of the step)."""
+        sb = self.basis.sphere
+        rows, cols, ok = sb.pack_index()
+        h = h.reshape((self.ncomp, -1, rows.shape[1], self.basis.Nr))
+        if self.dist.size > 1:
+            h = self.dist.pcomm.all_gather_host(h, axis=1)
+        nat = np.zeros((self.ncomp, 2 * sb.nm, sb.nl, self.basis.Nr))
+        for c in range(self.ncomp):
+            nat[c][rows[ok], cols[ok], :] = h[c][ok]
+        return np.ascontiguousarray(nat[:, 2 * sb.m0:2 * (sb.m0 + sb.nml)])
+
+    def _packed_from_natural(self, nat):
+        sb = self.basis.sphere
+        if self.dist.size > 1:
+            nat = self.dist.pcomm.all_gather_host(np.ascontiguousarray(nat), axis=1)
+        rows, cols, ok = sb.pack_index()
+        out = np.zeros((self.ncomp,) + rows.shape + (self.basis.Nr,))
+        for c in range(self.ncomp):
+            out[c][ok] = nat[c][rows[ok], cols[ok], :]
+        out = out.reshape(self._global_shape("c", self.scales))
+        return np.ascontiguousarray(out[self._local_slices("c", self.scales)])
 
     def _remedy(self, scales):
         if scales is None:
@@ -1204,17 +1295,13 @@ class ShellField(ShOperand):
         self._authority = "device"
         lay, sc = self._host_layout, self._host_scales
         if lay == "c":
-            rows, cols, ok = self.basis.sphere.pack_index()
-            nat = np.zeros(self._cshape())
-            h = self._host.reshape((self.ncomp,) + rows.shape + (self.basis.Nr,))
-            for c in range(self.ncomp):
-                nat[c][rows[ok], cols[ok], :] = h[c][ok]
+            nat = self._natural_from_packed(self._host)
             if self._c is None:
                 self._c = self.ex.zeros(self._cshape())
             self.ex.upload(self._c, nat)
             self.layout = "c"
         else:
-            shape = (self.ncomp,) + self.basis.grid_shape(sc)
+            shape = (self.ncomp,) + self._user_shape("g", sc)[self.rank:]
             if self._g is None or self._g_scales != sc:
                 self._g = self.ex.empty(shape)
                 self._g_scales = sc
@@ -1267,11 +1354,7 @@ class ShellField(ShOperand):
             shape = self._user_shape(layout, self.scales)
             if layout == "c":
                 nat = np.asarray(self.ex.download(self.require_coeff_space()))
-                rows, cols, ok = self.basis.sphere.pack_index()
-                out = np.zeros((self.ncomp,) + rows.shape + (self.basis.Nr,))
-                for c in range(self.ncomp):
-                    out[c][ok] = nat[c][rows[ok], cols[ok], :]
-                self._host = out.reshape(shape)
+                self._host = self._packed_from_natural(nat).reshape(shape)
             else:
                 self._host = np.array(self.ex.download(self.require_grid_space(self.scales))).reshape(shape)
             self._host_layout, self._host_scales = layout, self.scales
@@ -1318,7 +1401,7 @@ class ShellField(ShOperand):
         if scales is not None:
             self.change_scales(scales)
         layout = "c" if (layout or self.layout) in ("c", "coeff") else "g"
-        shape = self._user_shape(layout, self.scales)
+        shape = self._global_shape(layout, self.scales)
         n = int(np.prod(shape))
         cs = min(n, chunk_size)
         rng = np.random.default_rng(seed)
@@ -1330,7 +1413,7 @@ class ShellField(ShOperand):
             m = min(cs, n - pos)
             out[pos:pos + m] = chunk[:m]
             pos += m
-        self[layout] = out.reshape(shape)
+        self[layout] = out.reshape(shape)[self._local_slices(layout, self.scales)]
 
 
 # ==================================================================================================
@@ -1462,7 +1545,8 @@ class ShellSolverBase:
         self.shell = shell = problem.shell
         self.variables = problem.variables
         sb = shell.sphere
-        self.nm, self.nl, self.Nr = sb.nm, sb.nl, shell.Nr
+        self.nm, self.nl, self.Nr = sb.nml, sb.nl, shell.Nr          # nm: LOCAL azimuthal wavenumbers
+        self.m0 = sb.m0
         self.vmap = self._pack_layout([(v.basis, v.ncomp) for v in self.variables])
         self.emap = self._pack_layout([(eq["basis"], eq["ncomp"]) for eq in problem.equations])
         self.R = max(sc for m in self.vmap for (sc, off, nr) in m) + 1
@@ -1538,7 +1622,7 @@ class ShellSolverBase:
     def _inverse_terms(self, a, b):
         """Per-ell inverse of (a M + b L) on the valid modes as a device term list (blocks of the dense inverses)."""
         inv = np.zeros((self.nl, self.R * self.Nr, self.R * self.Nr))
-        for ell in range(self.nl):
+        for ell in range(self.m0, self.nl):                # ell < first local m: no local modes
             A = a * self._dense(self.M_tl, ell) + b * self._dense(self.L_tl, ell)
             rv = self.row_valid[:, ell, :].reshape(-1)
             cv = self.col_valid[:, ell, :].reshape(-1)
@@ -1561,7 +1645,8 @@ class ShellSolverBase:
             if isinstance(v, ConstField):
                 sc, off, nr = m[0]
                 col = np.zeros((1, 2 * self.nm, self.nl, 1))
-                col[0, 0, 0, 0] = float(v.value.reshape(-1)[0])
+                if self.m0 == 0:                           # the (m = 0, ell = 0) slot lives on the first rank
+                    col[0, 0, 0, 0] = float(v.value.reshape(-1)[0])
                 self.ex.assign(self.X4[sc:sc + 1, :, :, off:off + 1], self.ex.from_host(col))
                 continue
             c = v.require_coeff_space()
@@ -1572,7 +1657,10 @@ class ShellSolverBase:
         for v, m in zip(self.variables, self.vmap):
             if isinstance(v, ConstField):
                 sc, off, nr = m[0]
-                v.value[...] = float(np.asarray(self.ex.download(self.X4[sc:sc + 1, 0:1, 0:1, off:off + 1])).reshape(-1)[0])
+                val = float(np.asarray(self.ex.download(self.X4[sc:sc + 1, 0:1, 0:1, off:off + 1])).reshape(-1)[0])
+                if self.dist.size > 1:
+                    val = self.dist.pcomm.allreduce_sum(val if self.m0 == 0 else 0.0)
+                v.value[...] = val
                 continue
             c = self.ex.empty(v._cshape())
             for comp, (sc, off, nr) in enumerate(m):
@@ -1593,8 +1681,9 @@ class ShellSolverBase:
                     raise NotImplementedError("constant right-hand side of a tensor equation")
                 sc, off, nr = m[0]
                 col = np.zeros((1, 2 * self.nm, self.nl, nr))
-                col[0, 0, 0, 0] = F / SphereBasis.constant_mode_value * \
-                    (1.0 if isinstance(eq["basis"], SurfaceBasis) else 1.0 / self._radial_constant(eq["basis"]))
+                if self.m0 == 0:
+                    col[0, 0, 0, 0] = F / SphereBasis.constant_mode_value * \
+                        (1.0 if isinstance(eq["basis"], SurfaceBasis) else 1.0 / self._radial_constant(eq["basis"]))
                 ex.assign(out4[sc:sc + 1, :, :, off:off + nr], ex.from_host(col))
             else:
                 c = F.eval_c()

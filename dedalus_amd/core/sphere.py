@@ -94,6 +94,23 @@ class SphereBasis:
         self.volume = 4 * np.pi * radius ** 2
         self._plans = {}
 
+    def m_range(self):
+        """(first local m, number of local m): block distribution of the azimuthal wavenumbers over the ranks of the
+        distributor's 1-D mesh (the reference distributes the first coefficient axis, core/distributor.py:357-385)."""
+        d = getattr(self.coordsys, "dist", None)
+        P, r = (int(getattr(d, "size", 1)), int(getattr(d, "rank", 0))) if d is not None else (1, 0)
+        if self.nm % P:
+            raise ValueError("%d azimuthal wavenumbers do not divide over %d ranks" % (self.nm, P))
+        return r * (self.nm // P), self.nm // P
+
+    @property
+    def m0(self):
+        return self.m_range()[0]
+
+    @property
+    def nml(self):
+        return self.m_range()[1]
+
     constant_mode_value = 1 / np.sqrt(2)
 
     def grid_shape(self, scales):

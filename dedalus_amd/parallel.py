@@ -51,6 +51,17 @@ class Comm:
         else:
             self.dist.all_to_all_single(recv.reshape(-1), send.reshape(-1))
 
+    def all_gather_host(self, a, axis=0):
+        """concatenate equal-shaped host arrays of all ranks along `axis` (user-boundary accesses only)"""
+        t = self.torch
+        src = t.from_numpy(np.ascontiguousarray(a))
+        cuda = t.cuda.is_available() and self.dist.get_backend() == "nccl"
+        if cuda:
+            src = src.cuda()
+        parts = [t.empty_like(src) for _ in range(self.size)]
+        self.dist.all_gather(parts, src)
+        return np.concatenate([p.cpu().numpy() for p in parts], axis=axis)
+
     def allreduce_sum(self, value):
         t = self.torch
         dev = "cuda" if (t.cuda.is_available() and self.dist.get_backend() == "nccl") else "cpu"

@@ -28,7 +28,14 @@ def main():
     else:
         from oracle.np_executor import NumpyExecutor
         dist_kw = dict(executor=NumpyExecutor(), mesh=(world,))
-    solver, res = problems.run_case(d3, case, dist_kw=dist_kw)
+    if case.startswith("shell_conv_"):
+        # m-sharded shell convection: local blocks of the packed coefficient arrays (+ tau_p, replicated)
+        solver, res = problems.run_shell_convection(d3, steps=4, timestepper=case.split("_")[-1], dist_kw=dist_kw)
+    elif case == "shell_cfl":
+        solver, dts, speeds, res = problems.run_shell_cfl_case(d3, dist_kw=dist_kw)
+        res = dict(res, dts=np.array(dts), speeds=np.array(speeds))
+    else:
+        solver, res = problems.run_case(d3, case, dist_kw=dist_kw)
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **res)
     dist.barrier()
     dist.destroy_process_group()

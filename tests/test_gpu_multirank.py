@@ -37,3 +37,15 @@ def test_sharded_hip_run_matches_reference(golden_dir, case, world):
             full = np.concatenate([p[key] for p in parts], axis=xaxis)
             assert full.shape == ref.shape
             assert rel(full, ref) < tol, (key, rel(full, ref))
+
+
+@pytest.mark.parametrize("ts", ["SBDF2"])
+def test_m_sharded_shell_hip_run_matches_reference(golden_dir, ts):
+    """Shell convection, azimuthal wavenumbers sharded over 2 processes that share the GPU: local SWSH / regularity /
+    radial plans, ell-term kernels on the local slots, a2a pack/unpack around the (host-staged) exchange."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_multiprocess import _run_worker, check_shell_parts, SHELL_TOL
+    gold = np.load(os.path.join(golden_dir, "shellfields.npz"))
+    with tempfile.TemporaryDirectory() as tmp:
+        parts = _run_worker("shell_conv_" + ts, 2, tmp, extra=["hip"], env_extra=dict(DDH_DIST_BACKEND="gloo"))
+        check_shell_parts(parts, gold, "conv_%s__" % ts, list(SHELL_TOL))

@@ -35,3 +35,52 @@ def test_sharded_run_matches_reference(golden_dir, case, world):
             full = np.concatenate([p[key] for p in parts], axis=xaxis)
             assert full.shape == ref.shape
             assert rel(full, ref) < 1e-9, (key, rel(full, ref))
+
+
+def _run_worker(case, world, tmp, extra=(), env_extra=None, timeout=900):
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "mp_worker.py"), case, tmp] + list(extra)
+    env = dict(os.environ, OMP_NUM_THREADS="1", **(env_extra or {}))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return [np.load(os.path.join(tmp, "rank%d.npz" % k)) for k in range(world)]
+
+
+SHELL_TOL = dict(p=1e-10, b=1e-10, u=1e-9, tau_p=1e-8, tau_b1=1e-8, tau_b2=1e-8, tau_u1=1e-8, tau_u2=1e-8)
+
+
+def check_shell_parts(parts, gold, prefix, keys):
+    for key in keys:
+        ref = gold[prefix + key]
+        if key == "tau_p":
+            full = parts[0][key]                         # a constant: replicated
+            assert all(np.array_equal(p[key], full) for p in parts)
+            assert abs(float(full.reshape(-1)[0]) - float(ref.reshape(-1)[0])) < 1e-10
+            continue
+        else:
+            # the packed azimuthal axis is block-distributed (third axis from the end)
+            full = np.concatenate([p[key] for p in parts], axis=ref.ndim - 3)
+        assert full.shape == ref.shape, (key, full.shape, ref.shape)
+        assert rel(full, ref) < SHELL_TOL[key], (key, rel(full, ref))
+
+
+@pytest.mark.parametrize("ts,world", [("SBDF2", 2), ("RK222", 2)])
+def test_m_sharded_shell_convection_matches_reference(golden_dir, ts, world):
+    """Shell convection (config 5) with the azimuthal wavenumbers block-distributed over the ranks, colatitudes
+    distributed in grid space, one all-to-all per transform: the reference's (serial) end state."""
+    gold = np.load(os.path.join(golden_dir, "shellfields.npz"))
+    with tempfile.TemporaryDirectory() as tmp:
+        parts = _run_worker("shell_conv_" + ts, world, tmp)
+        check_shell_parts(parts, gold, "conv_%s__" % ts, list(SHELL_TOL))
+
+
+def test_m_sharded_shell_cfl_sequence(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "shellfields.npz"))
+    with tempfile.TemporaryDirectory() as tmp:
+        parts = _run_worker("shell_cfl", 2, tmp)
+        for p in parts:
+            assert np.allclose(p["dts"], gold["shellcfl__dts"], rtol=1e-10, atol=0)
+            assert np.allclose(p["speeds"], gold["shellcfl__speeds"], rtol=1e-10, atol=0)
+        check_shell_parts(parts, gold, "shellcfl__", ["p", "b", "u"])

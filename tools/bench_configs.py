@@ -47,6 +47,12 @@ def run_sphere(name, kw, warm, steps):
 
 
 def run_shell(name, kw, dt, warm, steps):
+    """Under torch.distributed.run (one rank per GPU) the azimuthal wavenumbers are sharded over the ranks
+    (mesh = (WORLD_SIZE,)): `python -m torch.distributed.run --nproc-per-node 4 ... tools/bench_configs.py shell`."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        kw = dict(kw, dist_kw=dict(mesh=(world,)))
+        name += " x%d ranks" % world
     t0 = time.time()
     solver, f = problems.shell_convection(d3, **kw)
     solver.step(dt)
@@ -61,8 +67,13 @@ def run_shell(name, kw, dt, warm, steps):
     solver.ex.sync()
     el = time.time() - t0
     b = np.asarray(f["b"]['c'])
-    print("%-34s %8.2f steps/s  (%.2f ms/step, %d steps)  |b_c| = %.12f finite=%s" % (
-        name, steps / el, 1e3 * el / steps, steps, float(np.linalg.norm(b)), bool(np.isfinite(b).all())), flush=True)
+    nrm2 = float(np.sum(b * b))
+    if world > 1:
+        nrm2 = solver.dist.pcomm.allreduce_sum(nrm2)
+        el = solver.dist.pcomm.allreduce_max(el)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("%-34s %8.2f steps/s  (%.2f ms/step, %d steps)  |b_c| = %.12f finite=%s" % (
+            name, steps / el, 1e3 * el / steps, steps, np.sqrt(nrm2), bool(np.isfinite(b).all())), flush=True)
 
 
 if __name__ == "__main__":
