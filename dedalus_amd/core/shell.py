@@ -667,8 +667,10 @@ class ShOperand:
         if len(kw) != 1:
             raise ValueError("one coordinate at a time")
         (name, pos), = kw.items()
+        if name == self.dist.coordsys.coords[0].name:
+            return ShAzimuthalInterp(self, float(pos))
         if name != self.dist.coordsys.radius.name:
-            return ShUnsupported("interpolation along %r (analysis tasks only)" % name, self)
+            return ShUnsupported("interpolation along %r" % name, self)
         return ShLinear("interp", self, position=float(pos))
 
     def has_dt(self):
@@ -682,6 +684,54 @@ class ShOperand:
         f = ShellField(self.dist, self.basis, rank=self.rank)
         f._set_device_coeff(self.eval_c())
         return f
+
+
+class ShAzimuthalInterp(ShOperand):
+    """f(phi=phi0) (core/operators.py interpolate dispatch -> SphereBasis azimuthal interpolation): an ANALYSIS-ONLY
+    operand (output tasks such as the example's meridional flux slices).  The operand is evaluated on the grid at the
+    requested scales and its trigonometric interpolant along phi is evaluated on the host; the result keeps a phi
+    axis of size one (a constant axis in the output file)."""
+
+    const_axes = (0,)
+
+    def __init__(self, arg, position):
+        self.args, self.position = (arg,), position
+        self.dist, self.basis, self.rank = arg.dist, arg.basis, arg.rank
+        self.scales = (1.0, 1.0, 1.0)
+        self._field = None
+
+    def evaluate(self):
+        out = ShAzimuthalInterp(self.args[0], self.position)
+        arg = self.args[0]
+        out._field = arg if isinstance(arg, ShellField) else arg.evaluate()
+        return out
+
+    def require_coeff_space(self):
+        self._field.require_coeff_space()
+
+    def change_scales(self, scales):
+        self.scales = self._field._remedy(scales)
+
+    def __getitem__(self, layout):
+        if layout not in ("g", "grid"):
+            raise NotImplementedError("coefficient data of an azimuthal interpolation")
+        f = self._field
+        f.change_scales(self.scales)
+        g = np.asarray(f["g"])
+        ax = self.rank
+        Np = g.shape[ax]
+        c = np.fft.rfft(g, axis=ax) / Np
+        k = np.arange(c.shape[ax])
+        w = np.where((k == 0) | ((Np % 2 == 0) & (k == Np // 2)), 1.0, 2.0) * np.exp(1j * k * self.position)
+        shape = [1] * g.ndim
+        shape[ax] = k.size
+        return np.sum((c * w.reshape(shape)).real, axis=ax, keepdims=True)
+
+    def eval_c(self):
+        raise NotImplementedError("azimuthal interpolation is an output task, not a term of an equation")
+
+    def lin(self, variables):
+        raise NonlinearError("azimuthal interpolation in an equation")
 
 
 class ShUnsupported(ShOperand):
@@ -955,13 +1005,12 @@ class ShProduct(ShOperand):
     def grid_native(self):
         """grid data of the product at the dealias scales (the layout the product is formed in)"""
         a, b = self.args
-        if isinstance(a, RadialField) or isinstance(b, RadialField):
-            raise NotImplementedError("evaluation of NCC products (they are LHS terms)")
         ex = self.dist.executor
-        ga, gb = a.eval_g(), b.eval_g()
-        terms, nout = _bilinear_terms3(a.rank, b.rank, self.contract)
         Np, Nt, Ng = self.basis.grid_shape(self.basis.dealias)
-        Nt = self.dist.theta_range(Nt)[1]               # local colatitudes
+        Nt = self.dist.theta_range(Nt)[1]
+        ga = a.grid_broadcast(ex, self.basis, (Np, Nt, Ng)) if isinstance(a, RadialField) else a.eval_g()
+        gb = b.grid_broadcast(ex, self.basis, (Np, Nt, Ng)) if isinstance(b, RadialField) else b.eval_g()
+        terms, nout = _bilinear_terms3(a.rank, b.rank, self.contract)
         out = ex.empty((nout, Np, Nt, Ng))
         ex.bilinear(out, nout, ga, gb, Np * Nt * Ng, terms)
         return out
@@ -1148,6 +1197,26 @@ class RadialField(ShOperand):
 
     def lin(self, variables):
         raise NonlinearError("a radial field is a coefficient, not a variable")
+
+    def grid_broadcast(self, ex, basis, shape):
+        """coordinate components on the dealiased grid [3^rank][Nphi_g][Ntheta_local][Nr_g] (analysis products such as
+        er @ flux): the radial profile is re-sampled spectrally on the finer radial grid and repeated over the angles"""
+        from ..tools import jacobi
+        shell = self.shell_basis
+        Np, Nt, Ng = shape
+        key = ("ncc_grid", id(ex), id(self), shape)
+        store = getattr(shell, "_root", shell)._plans
+        if key not in store or store[key][0] != self._g.tobytes():
+            nc = 3 ** self.rank
+            z, w = jacobi.quadrature(shell.Nr, shell.alpha[0], shell.alpha[1])
+            P = np.asarray(jacobi.polynomials(shell.Nr, shell.alpha[0], shell.alpha[1], z))
+            coef = self._g.reshape(nc, shell.Nr) @ (P * np.asarray(w, dtype=np.float64)).T
+            zg, _ = jacobi.quadrature(Ng, shell.alpha[0], shell.alpha[1])
+            Pg = np.asarray(jacobi.polynomials(shell.Nr, shell.alpha[0], shell.alpha[1], zg), dtype=np.float64)
+            prof = coef @ Pg                                   # [nc][Ng]
+            full = np.ascontiguousarray(np.broadcast_to(prof[:, None, None, :], (nc, Np, Nt, Ng)))
+            store[key] = (self._g.tobytes(), ex.from_host(full))
+        return store[key][1]
 
     def regularity_coefficients(self):
         """[3^rank][Nr]: Jacobi (k = 0 family) coefficients of the regularity components at ell = 0."""
@@ -1729,7 +1798,7 @@ class ShellInitialValueSolver(ShellSolverBase):
     def __init__(self, problem, timestepper, **kw):
         super().__init__(problem)
         from . import timesteppers as ts
-        from .solvers import _HandlerRegistry
+        from .output import OutputEvaluator
         if isinstance(timestepper, str):
             timestepper = ts.schemes[timestepper]
         self.sim_time = self.initial_sim_time = 0.0
@@ -1741,9 +1810,14 @@ class ShellInitialValueSolver(ShellSolverBase):
         self.timestepper = timestepper(self)
         self.start_time = _time.time()
         self.warmup_iterations, self.warmup_time = 10, None
-        self._step_hooks = []
+        self.evaluator = OutputEvaluator(self)       # analysis handlers: evaluated at the start of a step
+        self._step_hooks = [self.evaluator.step_hook]
         self.total_modes = int(self.col_valid.sum()) * 2 * self.nm
-        self.evaluator = _HandlerRegistry(self)
+
+    def load_state(self, path, index=-1, allow_missing=False):
+        """core/solvers.py:632-673"""
+        from .output import load_state
+        return load_state(self, path, index=index, allow_missing=allow_missing)
 
     def factor(self, a, b, reuse=-1):
         inv = self._inverse_terms(a, b)

@@ -553,8 +553,9 @@ class InitialValueSolver(SolverBase):
         self.run_time_start = None
         self.total_modes = self.R * self.nx * self.ny
         self.handlers = []
-        self._step_hooks = []
-        self.evaluator = _HandlerRegistry(self)
+        from .output import OutputEvaluator
+        self.evaluator = OutputEvaluator(self)       # analysis handlers: evaluated at the start of a step
+        self._step_hooks = [self.evaluator.step_hook]
 
     @property
     def sim_time(self):
@@ -629,30 +630,10 @@ class InitialValueSolver(SolverBase):
             if run > 0:
                 logger.info("Speed: %.4g mode-stages/gpu-sec" % (self.total_modes * stages / run))
 
-    def load_state(self, path, index=-1):
-        raise NotImplementedError("HDF5 restart files: out of scope this round (SURVEY section 8f #4)")
-
-
-class _HandlerRegistry:
-    """Minimal stand-in for solver.evaluator: analysis output is host-side I/O outside the hot path."""
-
-    def __init__(self, solver):
-        self.solver = solver
-        self.handlers = []
-
-    def add_file_handler(self, *a, **k):
-        return _NullHandler()
-
-    def add_dictionary_handler(self, *a, **k):
-        return _NullHandler()
-
-
-class _NullHandler:
-    def add_task(self, *a, **k):
-        pass
-
-    def add_tasks(self, *a, **k):
-        pass
+    def load_state(self, path, index=-1, allow_missing=False):
+        """core/solvers.py:632-673"""
+        from .output import load_state
+        return load_state(self, path, index=index, allow_missing=allow_missing)
 
 
 class LinearBoundaryValueSolver(SolverBase):

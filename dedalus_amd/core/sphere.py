@@ -1272,8 +1272,9 @@ class SphereInitialValueSolver(SphereSolverBase):
         self.start_time = _time.time()
         self.warmup_time = None
         self.total_modes = int(self.col_valid.sum()) * 2
-        from .solvers import _HandlerRegistry
-        self.evaluator = _HandlerRegistry(self)      # analysis output is host-side I/O outside the hot path
+        from .output import OutputEvaluator
+        self.evaluator = OutputEvaluator(self)       # analysis handlers: evaluated at the start of a step
+        self._step_hooks = [self.evaluator.step_hook]
 
     # interface used by the shared timesteppers ------------------------------------------------------------------
     def factor(self, a, b, reuse=-1):
@@ -1295,8 +1296,15 @@ class SphereInitialValueSolver(SphereSolverBase):
             self.ex.sync()
             self.warmup_time = _time.time()
         self.dt = dt
+        for hook in self._step_hooks:        # scheduled analysis sees the pre-step state
+            hook(self)
         self.timestepper.step(dt, _time.time() - self.start_time)
         self.iteration += 1
+
+    def load_state(self, path, index=-1, allow_missing=False):
+        """core/solvers.py:632-673"""
+        from .output import load_state
+        return load_state(self, path, index=index, allow_missing=allow_missing)
 
     @property
     def proceed(self):

@@ -307,6 +307,17 @@ def golden_shellfields():
     print("wrote shellfields.npz with", len(out), "arrays")
 
 
+def golden_shellanalysis():
+    """Output tasks of the shell example evaluated by the reference (radial NCC product on the grid, radial and
+    azimuthal interpolation)."""
+    d3 = refshim.load_reference()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import problems
+    out = problems.shell_analysis_results(d3)
+    print({k: (v.shape, float(np.linalg.norm(v))) for k, v in out.items()})
+    np.savez_compressed(os.path.join(GOLD, "shellanalysis.npz"), **out)
+
+
 def golden_timesteppers():
     """Multistep coefficients of the reference for random step sequences (timesteppers.py:190-495)."""
     refshim.load_reference()

@@ -31,11 +31,26 @@ def main():
     if case.startswith("shell_conv_"):
         # m-sharded shell convection: local blocks of the packed coefficient arrays (+ tau_p, replicated)
         solver, res = problems.run_shell_convection(d3, steps=4, timestepper=case.split("_")[-1], dist_kw=dist_kw)
+        # gathered analysis output of the sharded state: rank 0 writes the global arrays
+        fields = {v.name: v for v in solver.variables}
+        h = solver.evaluator.add_file_handler(os.path.join(outdir, "final"), iter=1)
+        h.add_task(fields["b"], layout='c', name="b_c")
+        h.add_task(fields["u"], layout='g', name="u_g", scales=1.5)
+        solver.evaluator.evaluate_handlers([h], iteration=solver.iteration, sim_time=solver.sim_time, timestep=0.05,
+                                           wall_time=0.0)
+        h.close()
     elif case == "shell_cfl":
         solver, dts, speeds, res = problems.run_shell_cfl_case(d3, dist_kw=dist_kw)
         res = dict(res, dts=np.array(dts), speeds=np.array(speeds))
     else:
         solver, res = problems.run_case(d3, case, dist_kw=dist_kw)
+        fields = {v.name: v for v in solver.state}
+        h = solver.evaluator.add_file_handler(os.path.join(outdir, "final"), iter=1)
+        h.add_task(fields["b"], layout='c', name="b_c")
+        h.add_task(fields["b"], layout='g', name="b_g")
+        solver.evaluator.evaluate_handlers([h], iteration=solver.iteration, sim_time=solver.sim_time, timestep=0.0,
+                                           wall_time=0.0)
+        h.close()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **res)
     dist.barrier()
     dist.destroy_process_group()

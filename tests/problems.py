@@ -373,6 +373,37 @@ def shell_operator_results(d3, shape=(16, 12, 8), dist_kw=None):
     return res
 
 
+def shell_analysis_results(d3, shape=(16, 12, 8), dist_kw=None):
+    """The output tasks of the reference's shell example (examples/ivp_shell_convection/shell_convection.py:93-99):
+    a radial NCC contracted with a flux on the grid, radial and azimuthal interpolations, at the dealias scales."""
+    Ri, Ro = 0.7, 1.9
+    coords = d3.SphericalCoordinates('phi', 'theta', 'r')
+    dist = d3.Distributor(coords, dtype=np.float64, **(dist_kw or {}))
+    shell = d3.ShellBasis(coords, shape=shape, radii=(Ri, Ro), dealias=3 / 2, dtype=np.float64)
+    b = dist.Field(name='b', bases=shell)
+    u = dist.VectorField(coords, name='u', bases=shell)
+    phi, theta, r = dist.local_grids(shell)
+    x, y, z = r * np.sin(theta) * np.cos(phi), r * np.sin(theta) * np.sin(phi), r * np.cos(theta) + 0 * phi
+    b['g'] = 1 / r + 0.3 * x * y + 0.2 * z * z * x - 0.5 * y + 0.1 * x * x * z / r
+    ug = np.zeros((3,) + np.broadcast(phi, theta, r).shape)
+    ug[0] = 0.8 * np.sin(theta) * (r - Ri) * (Ro - r) * (1 + 0.2 * np.sin(2 * phi))
+    ug[1] = 0.5 * np.sin(theta) * np.cos(phi) * (r - Ri) * (Ro - r)
+    ug[2] = 0.3 * np.cos(theta) * (r - Ri) * (Ro - r) + 0.1 * np.sin(theta) * np.sin(phi)
+    u['g'] = ug
+    er = dist.VectorField(coords, bases=shell.radial_basis)
+    er['g'][2] = 1
+    kappa = 0.3
+    flux = er @ (-kappa * d3.grad(b) + u * b)
+    tasks = dict(bmid=b(r=(Ri + Ro) / 2), flux_r_outer=flux(r=Ro), flux_r_inner=flux(r=Ri), flux_phi_start=flux(phi=0),
+                 flux_phi_end=flux(phi=3 * np.pi / 2), flux=flux)
+    res = {}
+    for k, e in tasks.items():
+        out = e.evaluate()
+        out.change_scales(3 / 2)
+        res[k] = np.array(out['g'])
+    return res
+
+
 def shell_convection(d3, shape=(16, 12, 8), timestepper="SBDF2", dist_kw=None):
     """The reference's example examples/ivp_shell_convection/shell_convection.py:31-91 (Boussinesq convection in a
     spherical shell: first-order tau formulation with radial NCCs, no-slip fixed-temperature walls, pressure gauge),

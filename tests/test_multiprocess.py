@@ -9,6 +9,8 @@ import tempfile
 import numpy as np
 import pytest
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -35,6 +37,12 @@ def test_sharded_run_matches_reference(golden_dir, case, world):
             full = np.concatenate([p[key] for p in parts], axis=xaxis)
             assert full.shape == ref.shape
             assert rel(full, ref) < 1e-9, (key, rel(full, ref))
+        # gathered analysis output (rank 0 writes the global arrays)
+        from dedalus_amd.tools import h5lite
+        r = h5lite.read(os.path.join(tmp, "final", "final_s1.h5"))
+        ref = gold[case + "__b"]
+        assert r["tasks/b_c"].shape == (1,) + ref.shape and rel(r["tasks/b_c"].read(0), ref) < 1e-9
+        assert r["tasks/b_g"].shape == (1,) + ref.shape and np.isfinite(r["tasks/b_g"].read(0)).all()
 
 
 def _run_worker(case, world, tmp, extra=(), env_extra=None, timeout=900):
@@ -74,6 +82,13 @@ def test_m_sharded_shell_convection_matches_reference(golden_dir, ts, world):
     with tempfile.TemporaryDirectory() as tmp:
         parts = _run_worker("shell_conv_" + ts, world, tmp)
         check_shell_parts(parts, gold, "conv_%s__" % ts, list(SHELL_TOL))
+        # the analysis set written by rank 0 from the gathered blocks holds the global arrays
+        from dedalus_amd.tools import h5lite
+        r = h5lite.read(os.path.join(tmp, "final", "final_s1.h5"))
+        ref = gold["conv_%s__b" % ts]
+        assert r["tasks/b_c"].shape == (1,) + ref.shape and rel(r["tasks/b_c"].read(0), ref) < SHELL_TOL["b"]
+        assert r["tasks/u_g"].shape == (1, 3, 24, 18, 12) and np.isfinite(r["tasks/u_g"].read(0)).all()
+        assert np.array_equal(r["scales/iteration"].read(), [4])
 
 
 def test_m_sharded_shell_cfl_sequence(golden_dir):

@@ -161,3 +161,26 @@ def test_shell_cfl_timestep_sequence_oracle():
 @pytest.mark.gpu
 def test_shell_cfl_timestep_sequence_gpu():
     check_cfl(None)
+
+
+def check_analysis(dist_kw):
+    """Output tasks of the shell example: er @ (-kappa grad(b) + u b) on the grid (radial NCC re-sampled on the
+    dealiased grid), f(r=...), f(phi=...) at the dealias scales -- against the reference's evaluation."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import problems
+    import dedalus_amd.public as d3
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "shellanalysis.npz"))
+    res = problems.shell_analysis_results(d3, dist_kw=dist_kw)
+    for k in gold.files:
+        assert res[k].shape == gold[k].shape, (k, res[k].shape, gold[k].shape)
+        assert _rel(res[k], gold[k]) < 1e-11, (k, _rel(res[k], gold[k]))
+
+
+def test_shell_analysis_tasks_oracle():
+    check_analysis(_np_kw())
+
+
+@pytest.mark.gpu
+def test_shell_analysis_tasks_gpu():
+    check_analysis(None)
