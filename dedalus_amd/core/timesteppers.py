@@ -262,12 +262,28 @@ class RungeKuttaIMEX:
     steps = 1
 
     def __init__(self, solver):
+        import os
         self.solver = solver
         ex, shape = solver.ex, (solver.R, solver.nx, solver.ny)
-        self.RHS = ex.zeros(shape)
+        H = self.H
         self.MX0 = ex.zeros(shape)
-        self.LX = [ex.zeros(shape) for _ in range(self.stages)]
         self.F = [ex.zeros(shape) for _ in range(self.stages)]
+        # Which L.X_j enter a later stage?  (the first column of H is zero in the registered schemes)
+        self._need_lx = [any(H[m, j] != 0.0 for m in range(j + 1, self.stages + 1)) for j in range(self.stages + 1)]
+        # L.X_j of a solved stage j >= 1 is not formed by a mat-vec: the stage equation (M + k H_jj L) X_j = RHS_j
+        # gives L.X_j = (RHS_j - M.X_j) / (k H_jj) exactly, and M has ~1/3 of L's entries (and none of its
+        # wavenumber-dependent terms).  The term enters later right-hand sides multiplied by k H_ij, so the solve
+        # residual hidden in the identity is scaled by H_ij / H_jj = O(1): round-off level, like any reordering of the
+        # sums.  DDH_RK_DIRECT_LX=1 restores the explicit products (reference order of operations,
+        # core/timesteppers.py:588-604).
+        self._direct = os.environ.get("DDH_RK_DIRECT_LX", "0") == "1"
+        scratch = ex.zeros(shape)                              # right-hand sides nobody needs later share a buffer
+        self.RHS = [None] + [ex.zeros(shape) if (self._need_lx[i] and not self._direct) else scratch
+                             for i in range(1, self.stages + 1)]
+        self.LX = [ex.zeros(shape) if (self._need_lx[j] and (self._direct or j == 0)) else None
+                   for j in range(self.stages + 1)]
+        self.MX = [None] + [ex.zeros(shape) if (self._need_lx[j] and not self._direct) else None
+                            for j in range(1, self.stages + 1)]
         self._k = None
         self._lus = {}          # H_ii -> lu id
 
@@ -290,18 +306,26 @@ class RungeKuttaIMEX:
         s.sync_state_to_device()
         pack.matvec(s.M_id, s.X, self.MX0)
         for i in range(1, self.stages + 1):
-            # L.X_{i-1} only where a later stage uses it (the first column of H is zero in these schemes)
-            if any(H[m, i - 1] != 0.0 for m in range(i, self.stages + 1)):
-                pack.matvec(s.L_id, s.X, self.LX[i - 1])
+            j = i - 1                                   # s.X holds X_j
+            if self._need_lx[j]:
+                if self._direct or j == 0:
+                    pack.matvec(s.L_id, s.X, self.LX[j])
+                else:
+                    pack.matvec(s.M_id, s.X, self.MX[j])
             s.evaluate_F(self.F[i - 1])
             xs, al = [self.MX0], [1.0]
             for j in range(i):
                 if A[i, j] != 0.0:
                     xs.append(self.F[j]); al.append(k * A[i, j])
                 if H[i, j] != 0.0:
-                    xs.append(self.LX[j]); al.append(-k * H[i, j])
-            ex.lincomb(self.RHS, xs, al)
-            s.solve(self._lus[float(H[i, i])], self.RHS, s.X)
+                    if self._direct or j == 0:
+                        xs.append(self.LX[j]); al.append(-k * H[i, j])
+                    else:
+                        r = H[i, j] / H[j, j]           # -k H_ij (RHS_j - M.X_j) / (k H_jj)
+                        xs.append(self.RHS[j]); al.append(-r)
+                        xs.append(self.MX[j]); al.append(r)
+            ex.lincomb(self.RHS[i], xs, al)
+            s.solve(self._lus[float(H[i, i])], self.RHS[i], s.X)
             s.mark_state_current()
             s.sim_time = t0 + k * c[i]
 

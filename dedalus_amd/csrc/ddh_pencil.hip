@@ -51,6 +51,7 @@ struct MatDev {
     const int *col;
     const double2 *coef;
     const unsigned *expo;  // ex | ey<<8 | dx<<16 | dy<<24
+    const int *order;      // optional processing order of the rows (locality of the column accesses), or null
 };
 
 // optional upper-banded back-substitution along the coupled index fused into a mat-vec:
@@ -67,7 +68,7 @@ struct Matrix {
     std::vector<int> row_h, col_h;
     std::vector<double2> coef_h;
     std::vector<unsigned> expo_h;
-    void *d_rowptr = nullptr, *d_col = nullptr, *d_coef = nullptr, *d_expo = nullptr;
+    void *d_rowptr = nullptr, *d_col = nullptr, *d_coef = nullptr, *d_expo = nullptr, *d_order = nullptr;
 };
 
 struct LuDev {
@@ -135,6 +136,7 @@ PencilPack::~PencilPack() {
         (void)hipFree(m->d_col);
         (void)hipFree(m->d_coef);
         (void)hipFree(m->d_expo);
+        if (m->d_order) (void)hipFree(m->d_order);
         delete m;
     }
     for (auto l : lus) free_lu(l);
@@ -279,7 +281,7 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
     const int rr0 = blockIdx.y * rows_per_chunk;
     const int rr1 = (rr0 + rows_per_chunk < A.nrows_out) ? rr0 + rows_per_chunk : A.nrows_out;
     for (int rr = rr0; rr < rr1; ++rr) {
-        int r = rr, kz = 0, comp0 = 0;
+        int r = A.order ? A.order[rr] : rr, kz = 0, comp0 = 0;
         if (ps.nz > 0) {
             // descending coupled index inside each component so that y[kz + off] is already final
             const int comp = rr / ps.nz;
@@ -1051,6 +1053,26 @@ int ddh_pencil_add_matrix(ddh_handle pack, const ddh_polymat *mat, int nrows_out
     m->dev.col = (const int *)m->d_col;
     m->dev.coef = (const double2 *)m->d_coef;
     m->dev.expo = (const unsigned *)m->d_expo;
+    m->dev.order = nullptr;
+    // Row processing order for locality: with the rows of the system vector laid out [component][kz] a row (c, kz)
+    // reads the columns (c', kz .. kz + band) of several components c'.  Processing the rows component by component
+    // touches every column once per coupled component (x is re-read ~nnz/row times); processing them kz-major makes
+    // all uses of a column fall into one short window of one thread block.  nz comes from DDH_MV_LOCALITY (experiment).
+    {
+        const char *e = getenv("DDH_MV_LOCALITY");
+        const int nz = e ? atoi(e) : 0;
+        if (nz > 1 && nrows_out >= 2 * nz) {
+            const int nfield = (pp->dev.nrows / nz) * nz;
+            std::vector<int> key(nrows_out, nz), ord(nrows_out);
+            for (int k = 0; k < nt; ++k) {
+                const int c = m->col_h[k];
+                if (c < nfield) key[m->row_h[k]] = std::min(key[m->row_h[k]], c % nz);
+            }
+            for (int r = 0; r < nrows_out; ++r) ord[r] = r;
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] < key[b]; });
+            if (!upload_vec(&m->d_order, ord.data(), ord.size())) m->dev.order = (const int *)m->d_order;
+        }
+    }
     pp->mats.push_back(m);
     *mat_id = (int)pp->mats.size() - 1;
     return 0;
@@ -1067,7 +1089,10 @@ static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y,
     if (ps.nz > 0) {
         rpc = ps.nz;
     } else {
-        rpc = (A.nrows_out + 31) / 32;
+        static const int nch = getenv("DDH_MV_CHUNKS") ? atoi(getenv("DDH_MV_CHUNKS")) : 32;
+        // few cells: more, shorter row chunks (the rows are independent) so that the launch still fills the chip
+        const int want = (blocks >= 64) ? nch : (int)std::min<long>(512, 2048 / blocks);
+        rpc = (A.nrows_out + want - 1) / want;
         if (rpc < 8) rpc = 8;
     }
     const unsigned chunks = (unsigned)((A.nrows_out + rpc - 1) / rpc);

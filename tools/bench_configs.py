@@ -81,6 +81,9 @@ if __name__ == "__main__":
         shape = tuple(int(x) for x in os.environ.get("SHELL_SHAPE", "256,128,128").split(","))
         run_shell("H  shell convection %dx%dx%d SBDF2" % shape, dict(shape=shape, timestepper="SBDF2"), 0.05, 3, 10)
         sys.exit(0)
+    if "r2" in sys.argv[1:]:
+        run("R2 rb2d 512x256 RK222", problems.rayleigh_benard_2d, dict(Nx=512, Nz=256), 1e-3, 5, 50)
+        sys.exit(0)
     if "sphere" in sys.argv[1:]:
         run_sphere("S  shallow water 512x256 RK222", dict(Nphi=512, Ntheta=256), 5, 50)
         sys.exit(0)
