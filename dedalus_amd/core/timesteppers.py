@@ -78,11 +78,17 @@ class MultistepIMEX:
         self.RHS = ex.zeros(shape)
         self.dt = deque([0.0] * self.steps)
         self.MX = deque(ex.zeros(shape) for _ in range(self.amax))
-        self.LX = deque(ex.zeros(shape) for _ in range(self.bmax))
         self.F = deque(ex.zeros(shape) for _ in range(self.cmax))
         self._iteration = 0
         self._LHS_params = None
         self._lu = -1
+        # L.X history only where the scheme's explicit-in-L weights b_1.. are not identically zero (the SBDF family
+        # never reads it: skip the product)
+        self._need_lx = False
+        for it in range(self.steps + 1):
+            _, b, _ = self.compute_coefficients([1.0] * self.steps, it)
+            self._need_lx = self._need_lx or bool(np.any(np.asarray(b)[1:] != 0.0))
+        self.LX = deque((ex.zeros(shape) if self._need_lx else None) for _ in range(self.bmax))
 
     def step(self, dt, wall_time=None):
         s = self.solver
@@ -96,7 +102,8 @@ class MultistepIMEX:
         self.F.rotate()
         s.sync_state_to_device()
         pack.matvec(s.M_id, s.X, self.MX[0])
-        pack.matvec(s.L_id, s.X, self.LX[0])
+        if self._need_lx:
+            pack.matvec(s.L_id, s.X, self.LX[0])
         s.evaluate_F(self.F[0])
         xs, al = [], []
         for j in range(1, len(c)):
