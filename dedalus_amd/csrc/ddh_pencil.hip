@@ -188,6 +188,7 @@ template <> struct El<false> {
     static __device__ __forceinline__ void fms2(double2 &acc, T m, double2 v) { cfms(acc, m, v); }
     static __device__ __forceinline__ void fma2(double2 &acc, T m, double2 v) { cfma(acc, m, v); }
     static __device__ __forceinline__ double2 mul2(double2 a, T m) { return cmul(a, m); }
+    static __device__ __forceinline__ T scale(T a, double f) { return make_double2(a.x * f, a.y * f); }
 };
 template <> struct El<true> {
     typedef double T;
@@ -202,6 +203,7 @@ template <> struct El<true> {
     static __device__ __forceinline__ void fms2(double2 &acc, T m, double2 v) { acc.x -= m * v.x; acc.y -= m * v.y; }
     static __device__ __forceinline__ void fma2(double2 &acc, T m, double2 v) { acc.x += m * v.x; acc.y += m * v.y; }
     static __device__ __forceinline__ double2 mul2(double2 a, T m) { return make_double2(a.x * m, a.y * m); }
+    static __device__ __forceinline__ T scale(T a, double f) { return a * f; }
 };
 
 // Factor storage index.  All entries of one row for one block of 64 factorizations are contiguous
@@ -362,15 +364,15 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
 // system <-> real storage (used by factor's nothing, solve's RHS load and solution store)
 // thread g = cell*S + s.  For NF == 2 lanes (2i, 2i+1) hold the P and Q systems of one cell.
 // ------------------------------------------------------------------------------------------------
-template <int NF>
+template <int NF, int XD = 1>
 __device__ __forceinline__ double2 load_sys(const double *__restrict__ v, long plane, int row, const PencilDev &P,
                                             const CellCtx &c, int s) {
     const double *vr = v + (long)row * plane;
     if (NF == 2) {
         const double2 mine = *reinterpret_cast<const double2 *>(vr + (2 * c.mx + s) * P.ny + 2 * c.my);
         double2 other;
-        other.x = __shfl_xor(mine.x, 1);
-        other.y = __shfl_xor(mine.y, 1);
+        other.x = __shfl_xor(mine.x, XD);
+        other.y = __shfl_xor(mine.y, XD);
         // s==0: mine=(cc,cs), other=(sc,ss) -> P ; s==1: mine=(sc,ss), other=(cc,cs) -> Q
         return s == 0 ? make_double2(mine.x - other.y, mine.y + other.x)
                       : make_double2(other.x + mine.y, other.y - mine.x);
@@ -381,21 +383,21 @@ __device__ __forceinline__ double2 load_sys(const double *__restrict__ v, long p
     }
 }
 
-template <int NF>
+template <int NF, int XD = 1>
 __device__ __forceinline__ void store_sys(double *__restrict__ v, long plane, int row, const PencilDev &P,
-                                          const CellCtx &c, int s, double2 val) {
+                                          const CellCtx &c, int s, double2 val, bool writer = true) {
     double *vr = v + (long)row * plane;
     if (NF == 2) {
         double2 other;
-        other.x = __shfl_xor(val.x, 1);
-        other.y = __shfl_xor(val.y, 1);
+        other.x = __shfl_xor(val.x, XD);
+        other.y = __shfl_xor(val.y, XD);
         const double2 out = (s == 0) ? make_double2(0.5 * (val.x + other.x), 0.5 * (val.y + other.y))    // cc, cs
                                      : make_double2(0.5 * (other.y - val.y), 0.5 * (val.x - other.x));  // sc, ss
-        *reinterpret_cast<double2 *>(vr + (2 * c.mx + s) * P.ny + 2 * c.my) = out;
+        if (writer) *reinterpret_cast<double2 *>(vr + (2 * c.mx + s) * P.ny + 2 * c.my) = out;
     } else if (NF == 1) {
-        *reinterpret_cast<double2 *>(vr + 2 * c.mx) = val;
+        if (writer) *reinterpret_cast<double2 *>(vr + 2 * c.mx) = val;
     } else {
-        vr[0] = val.x;
+        if (writer) vr[0] = val.x;
     }
 }
 
@@ -825,6 +827,265 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Cooperative sweeps for FEW systems (2-D problems, small 3-D ones): with one thread per system a launch of a few
+// hundred systems leaves the chip empty and every row costs a full memory latency (2-D Rayleigh-Benard 512 x 256:
+// 0.6-0.8 us per row, 2060 rows).  Here CH = 16 lanes share one system:
+//  * forward: lane h holds the window row i = h (mod 16) (kl < 16: one live row per lane); per step the pivot row
+//    and row j are exchanged by two lane broadcasts, every lane updates its own row with its own multiplier;
+//  * backward: lane h holds the solution entries x[k], k = h (mod 16), inside the upper band; per row each lane
+//    forms the partial dot product over its <= ceil(W/16) entries, a 4-step butterfly adds the partials;
+//  * every lane prefetches its own few factor entries COOP_D rows ahead (a rotating register file indexed at
+//    compile time), so the per-row cost is a handful of FMAs and lane exchanges instead of a memory round trip.
+// Results are identical in exact arithmetic and equal up to the summation order in floating point.
+// ------------------------------------------------------------------------------------------------
+constexpr int CH = 16;
+constexpr int COOP_D = 8;
+
+// lane exchange inside a row of 16 lanes by DPP (VALU speed; a ds_bpermute round trip costs ~100 cycles and the
+// backward sweep has four dependent ones per row)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a row, identical bits in every lane (each step adds a lane and its mirror partner)
+__device__ __forceinline__ double row16_sum(double v) {
+    static_assert(CH == 16, "DPP rows are 16 lanes");
+    v += dpp_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);    // row_half_mirror
+    v += dpp_f64<0x140>(v);    // row_mirror
+    return v;
+}
+
+template <int NF, bool REAL, int NBT>
+__global__ void __launch_bounds__(256)
+solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__restrict__ xout) {
+    typedef typename El<REAL>::T E;
+    extern __shared__ int s_lds[];
+    const int N = L.N;
+    int *s_perm = s_lds;
+    unsigned char *s_code = (unsigned char *)(s_lds + N + L.nb);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        s_perm[i] = L.rowperm[i];
+        s_code[i] = REAL ? L.row_code[i] : 0;
+    }
+    for (int i = threadIdx.x; i < L.nb; i += blockDim.x) {
+        s_perm[N + i] = L.colperm[L.n + i];
+        s_code[N + i] = REAL ? L.col_code[L.n + i] : 0;
+    }
+    __syncthreads();
+    const int h = threadIdx.x & (CH - 1);
+    const long g = (long)blockIdx.x * (256 / CH) + (threadIdx.x / CH);
+    if (g >= P.G) return;   // whole lane groups leave together; P/Q partner groups are adjacent and leave together
+    const long cell = g / P.S;
+    const int s = (int)(g % P.S);
+    const CellCtx c = cell_ctx(P, cell);
+    const long G = P.G;
+    const long gl = REAL ? cell : g;
+    const E *Aw = (const E *)L.Aw, *Ab = (const E *)L.Ab;
+    const long plane = P.nx * P.ny;
+    const int n = L.n, nb = L.nb, kl = L.kl;
+
+    auto load_row = [&](int i) -> double2 {
+        double2 v = load_sys<NF, CH>(rhs, plane, s_perm[i], P, c, s);
+        if (REAL) {
+            const unsigned char code = s_code[i];
+            if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+            if (code & 1) v = make_double2(v.y, -v.x);
+        }
+        return v;
+    };
+
+    double2 wv = make_double2(0.0, 0.0);          // window row i = h (mod CH), i in [j, j + kl]
+    if (h <= kl && h < n) wv = load_row(h);
+    double2 gb[NBT];
+#pragma unroll
+    for (int rb = 0; rb < NBT; ++rb) {
+        gb[rb] = make_double2(0.0, 0.0);
+        if (rb < nb) gb[rb] = load_row(n + rb);
+    }
+    int pp[COOP_D];
+    E pm[COOP_D], pab[COOP_D][NBT];
+    double2 pr[COOP_D];
+    // branch-free: every lane issues the same number of loads per row (clamped addresses, masked values), so the
+    // compiler can wait for exactly the oldest outstanding row (s_waitcnt vmcnt(k)) instead of draining the queue
+    // issue() is called for jj = 0, 1, 2, ...: running pointers instead of 64-bit index arithmetic per entry (the
+    // address computations were the dominant VALU work of a row)
+    const long aw_rs = (long)L.nblk * L.BW * 64, ab_rs = (long)L.nblk * L.nb * 64, pv_rs = (long)L.nblk * 64;
+    const int aw_step = (int)(aw_rs - 64);                   // (row + 1, d - 1) relative to (row, d)
+    const unsigned char *pv_ptr = L.piv + lu_pv(L, gl, 0);
+    const E *aw_ptr = Aw + lu_aw(L, gl, 0, kl);              // (row jj, diagonal)
+    const E *ab_ptr = Ab + lu_ab(L, gl, 0, 0);
+    auto issue = [&](int jj, int slot) {
+        const int dl = (h - jj) & (CH - 1);
+        const bool live = dl >= 1 && dl <= kl && jj + dl < n;
+        const int dc = live ? dl : 0;                       // the diagonal itself is always a valid entry
+        pp[slot] = *pv_ptr;
+        // raw values only: whether an entry is used is decided when the row is consumed (touching the value here
+        // would make the wave wait for the load it has just issued)
+        pm[slot] = aw_ptr[dc * aw_step];
+#pragma unroll
+        for (int rb = 0; rb < NBT; ++rb) pab[slot][rb] = ab_ptr[(rb < nb ? rb : 0) << 6];
+        const int nxt = jj + kl + 1;
+        pr[slot] = load_row(nxt < n ? nxt : n - 1);          // every lane of the group reads the same row
+        const bool adv = jj < n - 1;                         // past the end the last row is re-read (and never used)
+        pv_ptr += adv ? pv_rs : 0;
+        aw_ptr += adv ? aw_rs : 0;
+        ab_ptr += adv ? ab_rs : 0;
+    };
+    double2 *sc_ptr = L.scratch + g;
+#pragma unroll
+    for (int r = 0; r < COOP_D; ++r) issue(r, r);
+    // One row.  The main loop runs whole blocks of COOP_D rows without any guard: straight-line code lets the compiler
+    // wait for exactly the oldest outstanding prefetch (vmcnt(k)); a guard per row merges control-flow paths with
+    // different numbers of issued loads and degrades every wait to "almost everything".
+#define DDH_COOP_FWD_ROW(r, j)                                                                                     \
+    {                                                                                                              \
+        const int p = pp[r];                                                                                       \
+        const E m = pm[r];                                                                                         \
+        E ab[NBT];                                                                                                 \
+        _Pragma("unroll") for (int rb = 0; rb < NBT; ++rb) ab[rb] = pab[r][rb];                                    \
+        const double2 rnew = pr[r];                                                                                \
+        issue((j) + COOP_D, r);                                                                                    \
+        const int a = (j) & (CH - 1), bq = ((j) + p) & (CH - 1);                                                   \
+        double2 yj, wj;                                                                                            \
+        yj.x = __shfl(wv.x, bq, CH);                                                                               \
+        yj.y = __shfl(wv.y, bq, CH);                                                                               \
+        wj.x = __shfl(wv.x, a, CH);                                                                                \
+        wj.y = __shfl(wv.y, a, CH);                                                                                \
+        if (h == bq) wv = wj; /* the interchange (a no-op for p = 0) */                                            \
+        *sc_ptr = yj; /* row j of the scratch (all lanes of the group store the same value) */                     \
+        sc_ptr += G;                                                                                               \
+        const int dl = (h - (j)) & (CH - 1);                                                                       \
+        if (dl >= 1 && dl <= kl && (j) + dl < n) El<REAL>::fms2(wv, m, yj);                                        \
+        _Pragma("unroll") for (int rb = 0; rb < NBT; ++rb) if (rb < nb) El<REAL>::fms2(gb[rb], ab[rb], yj);        \
+        const int nxt = (j) + kl + 1;                                                                              \
+        if (nxt < n && (nxt & (CH - 1)) == h) wv = rnew;                                                           \
+    }
+    int j0 = 0;
+    for (; j0 + COOP_D <= n; j0 += COOP_D) {
+#pragma unroll
+        for (int r = 0; r < COOP_D; ++r) DDH_COOP_FWD_ROW(r, j0 + r)
+    }
+#pragma unroll
+    for (int r = 0; r < COOP_D; ++r)
+        if (j0 + r < n) DDH_COOP_FWD_ROW(r, j0 + r)
+#undef DDH_COOP_FWD_ROW
+    // ---- Schur block (every lane of the group computes it; lane 0 stores)
+#pragma unroll
+    for (int r = 0; r < NBT; ++r) {
+        if (r < nb) {
+            double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int cidx = 0; cidx < NBT; ++cidx)
+                if (cidx < nb) El<REAL>::fma2(acc, Ab[lu_ab(L, gl, n + cidx, r)], gb[cidx]);
+            L.scratch[(long)(n + r) * G + g] = acc;
+            double2 v = acc;
+            if (REAL) {
+                const unsigned char code = s_code[N + r];
+                if (code & 1) v = make_double2(-v.y, v.x);
+                if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+            }
+            store_sys<NF, CH>(xout, plane, s_perm[N + r], P, c, s, v);
+        }
+    }
+}
+
+template <int NF, int TT, bool REAL>
+__global__ void __launch_bounds__(256)
+solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
+    typedef typename El<REAL>::T E;
+    extern __shared__ int s_lds[];
+    const int n = L.n, nb = L.nb, kl = L.kl, W = L.W;
+    int *s_perm = s_lds;
+    unsigned char *s_code = (unsigned char *)(s_lds + n);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        s_perm[i] = L.colperm[i];
+        s_code[i] = REAL ? L.col_code[i] : 0;
+    }
+    __syncthreads();
+    const int h = threadIdx.x & (CH - 1);
+    const long g = (long)blockIdx.x * (256 / CH) + (threadIdx.x / CH);
+    if (g >= P.G) return;
+    const long cell = g / P.S;
+    const int s = (int)(g % P.S);
+    const CellCtx c = cell_ctx(P, cell);
+    const long G = P.G;
+    const long gl = REAL ? cell : g;
+    const E *Aw = (const E *)L.Aw;
+    const long plane = P.nx * P.ny;
+
+    // xr[t] = x[k_t]: the entries k = h (mod CH) above the current row, k_t = j + 1 + e + CH t, e = (h - j - 1) mod CH
+    double2 xr[TT];
+    {
+        const int e = (h - n) & (CH - 1);              // row j = n - 1
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int kb = e + CH * t;                 // k - n
+            xr[t] = (kb < nb) ? L.scratch[(long)(n + kb) * G + g] : make_double2(0.0, 0.0);
+        }
+    }
+    E pu[COOP_D][TT], pu0[COOP_D];
+    double2 py[COOP_D];
+    // issue() is called for jj = n - 1, n - 2, ...: running pointers (see the forward kernel)
+    const long aw_rs = (long)L.nblk * L.BW * 64;
+    const E *u_ptr = Aw + lu_aw(L, gl, n - 1, kl);
+    const double2 *y_ptr = L.scratch + (long)(n - 1) * G + g;
+    auto issue = [&](int jj, int slot) {                  // branch-free
+        py[slot] = *y_ptr;
+        pu0[slot] = u_ptr[0];
+        const int e = (h - jj - 1) & (CH - 1);
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int d = 1 + e + CH * t;
+            pu[slot][t] = u_ptr[(d <= W ? d : 0) << 6];               // raw; entries beyond the band are dropped at use
+        }
+        const bool adv = jj > 0;
+        u_ptr -= adv ? aw_rs : 0;
+        y_ptr -= adv ? G : 0;
+    };
+#pragma unroll
+    for (int r = 0; r < COOP_D; ++r) issue(n - 1 - r, r);
+#define DDH_COOP_BWD_ROW(r, j)                                                                                     \
+    {                                                                                                              \
+        E u[TT];                                                                                                   \
+        const int ej = (h - (j) - 1) & (CH - 1);                                                                   \
+        _Pragma("unroll") for (int t = 0; t < TT; ++t) u[t] = (1 + ej + CH * t <= W) ? pu[r][t] : El<REAL>::zero(); \
+        const E u0 = pu0[r];                                                                                       \
+        const double2 y = py[r];                                                                                   \
+        issue((j) - COOP_D, r);                                                                                    \
+        double2 acc = make_double2(0.0, 0.0);                                                                      \
+        _Pragma("unroll") for (int t = 0; t < TT; ++t) El<REAL>::fma2(acc, u[t], xr[t]);                           \
+        acc.x = row16_sum(acc.x);                                                                                  \
+        acc.y = row16_sum(acc.y);                                                                                  \
+        const double2 xj = El<REAL>::mul2(make_double2(y.x - acc.x, y.y - acc.y), u0);                             \
+        double2 v = xj;                                                                                            \
+        if (REAL) {                                                                                                \
+            const unsigned char code = s_code[j];                                                                  \
+            if (code & 1) v = make_double2(-v.y, v.x);                                                             \
+            if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);                                                \
+        }                                                                                                          \
+        store_sys<NF, CH>(xout, plane, s_perm[j], P, c, s, v); /* (same value from all lanes of the group) */      \
+        if ((((j) - h) & (CH - 1)) == 0) { /* the lane that owns k = j takes the new entry */                      \
+            _Pragma("unroll") for (int t = TT - 1; t > 0; --t) xr[t] = xr[t - 1];                                  \
+            xr[0] = xj;                                                                                            \
+        }                                                                                                          \
+    }
+    int jt0 = 0;
+    for (; jt0 + COOP_D <= n; jt0 += COOP_D) {           // guard-free whole blocks (see the forward kernel)
+#pragma unroll
+        for (int r = 0; r < COOP_D; ++r) DDH_COOP_BWD_ROW(r, n - 1 - (jt0 + r))
+    }
+#pragma unroll
+    for (int r = 0; r < COOP_D; ++r)
+        if (jt0 + r < n) DDH_COOP_BWD_ROW(r, n - 1 - (jt0 + r))
+#undef DDH_COOP_BWD_ROW
+}
+
 // ------------------------------------------------------------------------------------------------
 // dense fallback for flagged cells: x = Inv * rhs (explicit inverse built on the host)
 // ------------------------------------------------------------------------------------------------
@@ -883,6 +1144,29 @@ static int upload_vec(void **dptr, const T *src, size_t count) {
     return 0;
 }
 
+// dense fallback for the flagged pencils (after either sweep variant)
+template <int NF>
+static int finish_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double *x, hipStream_t s) {
+    const PencilDev &P = pp->dev;
+    const LuDev &d = lu->dev;
+    if (lu->nflag) {
+        if (!lu->d_inv) return fail("pencil_solve: flagged pencils need ddh_pencil_set_dense_inverse first");
+        const int nsys = lu->nflag * P.S;
+        double2 *drhs = (double2 *)lu->d_dense_rhs;
+        double2 *dx = drhs + (size_t)nsys * d.N;
+        const long work = (long)lu->nflag * d.N * P.S;
+        const unsigned gb = (unsigned)((work + 255) / 256);
+        hipLaunchKernelGGL(dense_gather_kernel<NF>, dim3(gb), dim3(256), 0, s, P, d, (const long *)lu->d_flag_cells,
+                           lu->nflag, rhs, drhs);
+        hipLaunchKernelGGL(dense_apply_kernel, dim3((unsigned)((d.N + 3) / 4), (unsigned)nsys), dim3(256), 0, s, d.N,
+                           (const double2 *)lu->d_inv, (const double2 *)drhs, dx);
+        hipLaunchKernelGGL(dense_scatter_kernel<NF>, dim3(gb), dim3(256), 0, s, P, d, (const long *)lu->d_flag_cells,
+                           lu->nflag, (const double2 *)dx, x);
+        DDH_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
 template <int NF>
 static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double *x, hipStream_t s) {
     const PencilDev &P = pp->dev;
@@ -892,6 +1176,32 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
     const size_t lds_f = (size_t)(d.N + d.nb) * 5 + 16, lds_b = (size_t)(d.n > 0 ? d.n : 1) * 5 + 16;
     if (lds_f > 64 * 1024) return fail("pencil_solve: system too large for the LDS permutation cache");
     static const int bwd_pref = getenv("DDH_SOLVE_PREF") ? atoi(getenv("DDH_SOLVE_PREF")) : 0;
+    // few systems: 16 lanes per system (see the cooperative kernels); DDH_SOLVE_COOP = 0 never, 2 always
+    const int coop_mode = getenv("DDH_SOLVE_COOP") ? atoi(getenv("DDH_SOLVE_COOP")) : 1;
+    const bool coop_ok = d.kl < CH && W <= 4 * CH && d.nb <= 8;
+    if (coop_ok && d.n > 0 && (coop_mode == 2 || (coop_mode == 1 && P.G <= 16384))) {
+        const unsigned cblocks = (unsigned)((P.G + (256 / CH) - 1) / (256 / CH));
+#define DDH_CFWD(NBTV)                                                                                             \
+    {                                                                                                              \
+        if (d.real)                                                                                                \
+            hipLaunchKernelGGL((solve_forward_coop_kernel<NF, true, NBTV>), dim3(cblocks), dim3(256), lds_f, s, P, d, rhs, x); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((solve_forward_coop_kernel<NF, false, NBTV>), dim3(cblocks), dim3(256), lds_f, s, P, d, rhs, x); \
+    }
+        if (d.nb <= 2) DDH_CFWD(2) else DDH_CFWD(8)
+#undef DDH_CFWD
+#define DDH_CBWD(TTV)                                                                                              \
+    {                                                                                                              \
+        if (d.real)                                                                                                \
+            hipLaunchKernelGGL((solve_backward_coop_kernel<NF, TTV, true>), dim3(cblocks), dim3(256), lds_b, s, P, d, x); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((solve_backward_coop_kernel<NF, TTV, false>), dim3(cblocks), dim3(256), lds_b, s, P, d, x); \
+    }
+        if (W <= CH) DDH_CBWD(1) else if (W <= 2 * CH) DDH_CBWD(2) else if (W <= 3 * CH) DDH_CBWD(3) else DDH_CBWD(4)
+#undef DDH_CBWD
+        DDH_HIP(hipGetLastError());
+        return finish_solve<NF>(pp, lu, rhs, x, s);
+    }
 #define DDH_FWD(KLTV, NBTV)                                                                                        \
     {                                                                                                              \
         if (d.real)                                                                                                \
@@ -927,22 +1237,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
     }
 #undef DDH_SOLVE
     DDH_HIP(hipGetLastError());
-    if (lu->nflag) {
-        if (!lu->d_inv) return fail("pencil_solve: flagged pencils need ddh_pencil_set_dense_inverse first");
-        const int nsys = lu->nflag * P.S;
-        double2 *drhs = (double2 *)lu->d_dense_rhs;
-        double2 *dx = drhs + (size_t)nsys * d.N;
-        const long work = (long)lu->nflag * d.N * P.S;
-        const unsigned gb = (unsigned)((work + 255) / 256);
-        hipLaunchKernelGGL(dense_gather_kernel<NF>, dim3(gb), dim3(256), 0, s, P, d, (const long *)lu->d_flag_cells,
-                           lu->nflag, rhs, drhs);
-        hipLaunchKernelGGL(dense_apply_kernel, dim3((unsigned)((d.N + 3) / 4), (unsigned)nsys), dim3(256), 0, s, d.N,
-                           (const double2 *)lu->d_inv, (const double2 *)drhs, dx);
-        hipLaunchKernelGGL(dense_scatter_kernel<NF>, dim3(gb), dim3(256), 0, s, P, d, (const long *)lu->d_flag_cells,
-                           lu->nflag, (const double2 *)dx, x);
-        DDH_HIP(hipGetLastError());
-    }
-    return 0;
+    return finish_solve<NF>(pp, lu, rhs, x, s);
 }
 
 

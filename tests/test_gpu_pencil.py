@@ -102,7 +102,10 @@ def bandwidth(tlists, perm, n):
 
 @pytest.mark.parametrize("nf,ncx,ncy", [(2, 6, 10), (1, 40, 1), (0, 1, 1)])
 @pytest.mark.parametrize("gauge", [False, True])
-def test_matvec_factor_solve_vs_oracle(nf, ncx, ncy, gauge):
+@pytest.mark.parametrize("coop", [0, 2])
+def test_matvec_factor_solve_vs_oracle(nf, ncx, ncy, gauge, coop, monkeypatch):
+    # coop = 2: the cooperative sweeps (16 lanes per system, used for few systems); 0: one thread per system
+    monkeypatch.setenv("DDH_SOLVE_COOP", str(coop))
     from dedalus_amd.device import Device
     from dedalus_amd.pencilpack import PencilPack, TermList
     from oracle import np_pencil as npp
