@@ -176,20 +176,30 @@ class Jacobi(Basis):
         """(offsets, bands[d][k] = C[k, k+offset_d]) of the grid-basis -> this-basis conversion."""
         if self.a == self.a0 and self.b == self.b0:
             return (), None
+        cached = getattr(self, "_conv_bands", None)
+        if cached is not None:
+            return cached
         conv = jacobi.conversion_matrix(self.size, self.a0, self.b0, self.a, self.b).toarray()
         offs = [o for o in range(self.size) if np.any(np.diagonal(conv, o) != 0)]
         bands = np.zeros((len(offs), self.size))
         for d, o in enumerate(offs):
             bands[d, :self.size - o] = np.diagonal(conv, o)
-        return tuple(offs), bands
+        self._conv_bands = (tuple(offs), bands)       # (called for every transform of every step)
+        return self._conv_bands
 
     def plan_spec(self, scale):
+        cache = self.__dict__.setdefault("_plan_specs", {})
+        if scale in cache:
+            return cache[scale]
         N = self.grid_size(scale)
         if self.a0 == self.b0 == -0.5 and self.library in (None, "fftw_dct", "scipy_dct", "hip"):
             offs, bands = self.conversion_bands()
             key = bands.tobytes() if bands is not None else b""
-            return ("cheb", N, self.size, offs, key)
-        return ("mmt", N, self.size, self.a, self.b, self.a0, self.b0)
+            spec = ("cheb", N, self.size, offs, key)
+        else:
+            spec = ("mmt", N, self.size, self.a, self.b, self.a0, self.b0)
+        cache[scale] = spec
+        return spec
 
     def mmt_matrices(self, N):
         """JacobiMMT definition (transforms.py:118-158): forward (size x N), backward (N x size)."""
