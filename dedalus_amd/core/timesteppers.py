@@ -284,9 +284,7 @@ class RungeKuttaIMEX:
         # sums.  DDH_RK_DIRECT_LX=1 restores the explicit products (reference order of operations,
         # core/timesteppers.py:588-604).
         self._direct = os.environ.get("DDH_RK_DIRECT_LX", "0") == "1"
-        scratch = ex.zeros(shape)                              # right-hand sides nobody needs later share a buffer
-        self.RHS = [None] + [ex.zeros(shape) if (self._need_lx[i] and not self._direct) else scratch
-                             for i in range(1, self.stages + 1)]
+        self.RHS = ex.zeros(shape)
         self.LX = [ex.zeros(shape) if (self._need_lx[j] and (self._direct or j == 0)) else None
                    for j in range(self.stages + 1)]
         self.MX = [None] + [ex.zeros(shape) if (self._need_lx[j] and not self._direct) else None
@@ -312,6 +310,7 @@ class RungeKuttaIMEX:
         t0 = s.sim_time
         s.sync_state_to_device()
         pack.matvec(s.M_id, s.X, self.MX0)
+        combs = {}
         for i in range(1, self.stages + 1):
             j = i - 1                                   # s.X holds X_j
             if self._need_lx[j]:
@@ -320,19 +319,26 @@ class RungeKuttaIMEX:
                 else:
                     pack.matvec(s.M_id, s.X, self.MX[j])
             s.evaluate_F(self.F[i - 1])
-            xs, al = [self.MX0], [1.0]
+            # RHS_i as a combination of the stored vectors.  RHS_j of an earlier stage is itself such a combination
+            # (it is not kept): -k H_ij L.X_j = -(H_ij / H_jj) (RHS_j - M.X_j) expands into MX0, F_*, MX_* terms.
+            comb = {("MX0",): 1.0}
             for j in range(i):
                 if A[i, j] != 0.0:
-                    xs.append(self.F[j]); al.append(k * A[i, j])
+                    comb[("F", j)] = comb.get(("F", j), 0.0) + k * A[i, j]
                 if H[i, j] != 0.0:
                     if self._direct or j == 0:
-                        xs.append(self.LX[j]); al.append(-k * H[i, j])
+                        comb[("LX", j)] = comb.get(("LX", j), 0.0) - k * H[i, j]
                     else:
-                        r = H[i, j] / H[j, j]           # -k H_ij (RHS_j - M.X_j) / (k H_jj)
-                        xs.append(self.RHS[j]); al.append(-r)
-                        xs.append(self.MX[j]); al.append(r)
-            ex.lincomb(self.RHS[i], xs, al)
-            s.solve(self._lus[float(H[i, i])], self.RHS[i], s.X)
+                        r = H[i, j] / H[j, j]
+                        for key, v in combs[j].items():
+                            comb[key] = comb.get(key, 0.0) - r * v
+                        comb[("MX", j)] = comb.get(("MX", j), 0.0) + r
+            combs[i] = comb
+            vec = {"MX0": lambda q: self.MX0, "F": lambda q: self.F[q], "LX": lambda q: self.LX[q], "MX": lambda q: self.MX[q]}
+            xs = [vec[key[0]](key[1] if len(key) > 1 else None) for key, v in comb.items() if v != 0.0]
+            al = [v for v in comb.values() if v != 0.0]
+            ex.lincomb(self.RHS, xs, al)
+            s.solve(self._lus[float(H[i, i])], self.RHS, s.X)
             s.mark_state_current()
             s.sim_time = t0 + k * c[i]
 
