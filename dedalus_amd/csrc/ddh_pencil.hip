@@ -361,6 +361,83 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
 }
 
 // ------------------------------------------------------------------------------------------------
+// The banded back-substitution of a mat-vec as its own pass (few cells): y[comp, kz] <- (y[comp, kz] -
+// sum_{d>=1} band[d][kz] y[comp, kz+off_d]) / band[0][kz], kz descending.  Fused into the mat-vec (large problems:
+// no second pass over y) the recurrence serializes the whole row computation behind it -- one memory latency per kz;
+// for a few hundred cells it is cheaper to form all rows in parallel first and run only this light recurrence
+// sequentially, with the next rows' values prefetched (their addresses do not depend on the recurrence).
+// ------------------------------------------------------------------------------------------------
+template <int NF>
+__global__ void __launch_bounds__(64)
+postsolve_kernel(PencilDev P, double *y, PostSolve ps) {
+    const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= P.ncells) return;
+    const CellCtx c = cell_ctx(P, cell);
+    const long plane = P.nx * P.ny;
+    long off0, off1 = 0;
+    if (NF == 2) {
+        off0 = (2 * c.mx) * P.ny + 2 * c.my;
+        off1 = off0 + P.ny;
+    } else if (NF == 1) {
+        off0 = 2 * c.mx;
+    } else {
+        off0 = 0;
+    }
+    const int comp0 = blockIdx.y * ps.nz;
+    double2 h0[4], h1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h0[j] = h1[j] = make_double2(0.0, 0.0);
+    constexpr int PF = 8;
+    for (int k0 = ps.nz - 1; k0 >= 0; k0 -= PF) {
+        double2 a0[PF], a1[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int kz = k0 - q;
+            a0[q] = a1[q] = make_double2(0.0, 0.0);
+            if (kz >= 0) {
+                const double *yr = y + (long)(comp0 + kz) * plane;
+                if (NF == 0) a0[q].x = yr[0];
+                else a0[q] = *reinterpret_cast<const double2 *>(yr + off0);
+                if (NF == 2) a1[q] = *reinterpret_cast<const double2 *>(yr + off1);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int kz = k0 - q;
+            if (kz < 0) break;
+            double2 v0 = a0[q], v1 = a1[q];
+            for (int d = 1; d < ps.nbands; ++d) {
+                const int o = ps.off[d];
+                if (kz + o < ps.nz) {
+                    const double bnd = ps.bands[d * ps.nz + kz];
+                    double2 p0 = make_double2(0.0, 0.0), p1 = p0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (o - 1 == j) { p0 = h0[j]; p1 = h1[j]; }
+                    v0.x -= bnd * p0.x; v0.y -= bnd * p0.y;
+                    v1.x -= bnd * p1.x; v1.y -= bnd * p1.y;
+                }
+            }
+            const double inv = 1.0 / ps.bands[kz];
+            v0.x *= inv; v0.y *= inv; v1.x *= inv; v1.y *= inv;
+#pragma unroll
+            for (int j = 3; j > 0; --j) { h0[j] = h0[j - 1]; h1[j] = h1[j - 1]; }
+            h0[0] = v0;
+            h1[0] = v1;
+            double *yr = y + (long)(comp0 + kz) * plane;
+            if (NF == 2) {
+                *reinterpret_cast<double2 *>(yr + off0) = v0;
+                *reinterpret_cast<double2 *>(yr + off1) = v1;
+            } else if (NF == 1) {
+                *reinterpret_cast<double2 *>(yr + off0) = v0;
+            } else {
+                yr[0] = v0.x;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // system <-> real storage (used by factor's nothing, solve's RHS load and solution store)
 // thread g = cell*S + s.  For NF == 2 lanes (2i, 2i+1) hold the P and Q systems of one cell.
 // ------------------------------------------------------------------------------------------------
@@ -1380,6 +1457,23 @@ static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y,
     const MatDev &A = pp->mats[mat_id]->dev;
     if (ps.nz > 0 && A.nrows_out % ps.nz) return fail("pencil_matvec_solve: rows are not a multiple of nz");
     const unsigned blocks = (unsigned)((P.ncells + 255) / 256);
+    hipStream_t s = as_stream(stream);
+    if (ps.nz > 0 && blocks < 64 && !getenv("DDH_MV_FUSED_POST")) {
+        // few cells: all rows in parallel first, then the light sequential recurrence (see postsolve_kernel)
+        PostSolve none;
+        memset(&none, 0, sizeof(none));
+        const int st = launch_matvec(pp, mat_id, x, y, none, stream);
+        if (st) return st;
+        const dim3 g2((unsigned)((P.ncells + 63) / 64), (unsigned)(A.nrows_out / ps.nz));
+        if (P.nf == 2)
+            hipLaunchKernelGGL(postsolve_kernel<2>, g2, dim3(64), 0, s, P, y, ps);
+        else if (P.nf == 1)
+            hipLaunchKernelGGL(postsolve_kernel<1>, g2, dim3(64), 0, s, P, y, ps);
+        else
+            hipLaunchKernelGGL(postsolve_kernel<0>, g2, dim3(64), 0, s, P, y, ps);
+        DDH_HIP(hipGetLastError());
+        return 0;
+    }
     int rpc;
     if (ps.nz > 0) {
         rpc = ps.nz;
@@ -1392,7 +1486,6 @@ static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y,
     }
     const unsigned chunks = (unsigned)((A.nrows_out + rpc - 1) / rpc);
     if (chunks > 65535) return fail("pencil_matvec: too many row chunks");
-    hipStream_t s = as_stream(stream);
     const dim3 grid(blocks, chunks ? chunks : 1);
     if (P.nf == 2)
         hipLaunchKernelGGL(matvec_kernel<2>, grid, dim3(256), 0, s, P, A, x, y, ps, rpc);
