@@ -191,7 +191,7 @@ def main():
                             "total_ms": round(v["total_ms"], 2)} for k, v in sorted(summ.items())},
             "build_s": build_s, "checksum_b_c_l2": chk,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(5 * Nx * Ny * Nz)
         print(json.dumps(out))
     if world > 1:
