@@ -928,13 +928,15 @@ __device__ __forceinline__ double dpp_f64(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
-// sum over the 16 lanes of a row, identical bits in every lane (each step adds a lane and its mirror partner)
-__device__ __forceinline__ double row16_sum(double v) {
-    static_assert(CH == 16, "DPP rows are 16 lanes");
-    v += dpp_f64<0xB1>(v);     // quad_perm [1,0,3,2]
-    v += dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]
-    v += dpp_f64<0x141>(v);    // row_half_mirror
-    v += dpp_f64<0x140>(v);    // row_mirror
+// sum over aligned groups of CB = 4, 8 or 16 lanes, identical bits in every lane of the group (each step adds a lane
+// and its mirror partner)
+template <int CB>
+__device__ __forceinline__ double group_sum(double v) {
+    static_assert(CB == 4 || CB == 8 || CB == 16, "DPP groups of 4, 8 or 16 lanes");
+    v += dpp_f64<0xB1>(v);                   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);                   // quad_perm [2,3,0,1]
+    if (CB >= 8) v += dpp_f64<0x141>(v);     // row_half_mirror
+    if (CB >= 16) v += dpp_f64<0x140>(v);    // row_mirror
     return v;
 }
 
@@ -1072,7 +1074,7 @@ solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, 
     }
 }
 
-template <int NF, int TT, bool REAL>
+template <int NF, int TT, bool REAL, int CB>
 __global__ void __launch_bounds__(256)
 solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     typedef typename El<REAL>::T E;
@@ -1085,8 +1087,8 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         s_code[i] = REAL ? L.col_code[i] : 0;
     }
     __syncthreads();
-    const int h = threadIdx.x & (CH - 1);
-    const long g = (long)blockIdx.x * (256 / CH) + (threadIdx.x / CH);
+    const int h = threadIdx.x & (CB - 1);
+    const long g = (long)blockIdx.x * (256 / CB) + (threadIdx.x / CB);
     if (g >= P.G) return;
     const long cell = g / P.S;
     const int s = (int)(g % P.S);
@@ -1096,13 +1098,13 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     const E *Aw = (const E *)L.Aw;
     const long plane = P.nx * P.ny;
 
-    // xr[t] = x[k_t]: the entries k = h (mod CH) above the current row, k_t = j + 1 + e + CH t, e = (h - j - 1) mod CH
+    // xr[t] = x[k_t]: the entries k = h (mod CB) above the current row, k_t = j + 1 + e + CB t, e = (h - j - 1) mod CB
     double2 xr[TT];
     {
-        const int e = (h - n) & (CH - 1);              // row j = n - 1
+        const int e = (h - n) & (CB - 1);              // row j = n - 1
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            const int kb = e + CH * t;                 // k - n
+            const int kb = e + CB * t;                 // k - n
             xr[t] = (kb < nb) ? L.scratch[(long)(n + kb) * G + g] : make_double2(0.0, 0.0);
         }
     }
@@ -1115,10 +1117,10 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     auto issue = [&](int jj, int slot) {                  // branch-free
         py[slot] = *y_ptr;
         pu0[slot] = u_ptr[0];
-        const int e = (h - jj - 1) & (CH - 1);
+        const int e = (h - jj - 1) & (CB - 1);
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            const int d = 1 + e + CH * t;
+            const int d = 1 + e + CB * t;
             pu[slot][t] = u_ptr[(d <= W ? d : 0) << 6];               // raw; entries beyond the band are dropped at use
         }
         const bool adv = jj > 0;
@@ -1130,15 +1132,15 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
 #define DDH_COOP_BWD_ROW(r, j)                                                                                     \
     {                                                                                                              \
         E u[TT];                                                                                                   \
-        const int ej = (h - (j) - 1) & (CH - 1);                                                                   \
-        _Pragma("unroll") for (int t = 0; t < TT; ++t) u[t] = (1 + ej + CH * t <= W) ? pu[r][t] : El<REAL>::zero(); \
+        const int ej = (h - (j) - 1) & (CB - 1);                                                                   \
+        _Pragma("unroll") for (int t = 0; t < TT; ++t) u[t] = (1 + ej + CB * t <= W) ? pu[r][t] : El<REAL>::zero(); \
         const E u0 = pu0[r];                                                                                       \
         const double2 y = py[r];                                                                                   \
         issue((j) - COOP_D, r);                                                                                    \
         double2 acc = make_double2(0.0, 0.0);                                                                      \
         _Pragma("unroll") for (int t = 0; t < TT; ++t) El<REAL>::fma2(acc, u[t], xr[t]);                           \
-        acc.x = row16_sum(acc.x);                                                                                  \
-        acc.y = row16_sum(acc.y);                                                                                  \
+        acc.x = group_sum<CB>(acc.x);                                                                                  \
+        acc.y = group_sum<CB>(acc.y);                                                                                  \
         const double2 xj = El<REAL>::mul2(make_double2(y.x - acc.x, y.y - acc.y), u0);                             \
         double2 v = xj;                                                                                            \
         if (REAL) {                                                                                                \
@@ -1146,8 +1148,8 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
             if (code & 1) v = make_double2(-v.y, v.x);                                                             \
             if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);                                                \
         }                                                                                                          \
-        store_sys<NF, CH>(xout, plane, s_perm[j], P, c, s, v); /* (same value from all lanes of the group) */      \
-        if ((((j) - h) & (CH - 1)) == 0) { /* the lane that owns k = j takes the new entry */                      \
+        store_sys<NF, CB>(xout, plane, s_perm[j], P, c, s, v); /* (same value from all lanes of the group) */      \
+        if ((((j) - h) & (CB - 1)) == 0) { /* the lane that owns k = j takes the new entry */                      \
             _Pragma("unroll") for (int t = TT - 1; t > 0; --t) xr[t] = xr[t - 1];                                  \
             xr[0] = xj;                                                                                            \
         }                                                                                                          \
@@ -1255,8 +1257,26 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
     static const int bwd_pref = getenv("DDH_SOLVE_PREF") ? atoi(getenv("DDH_SOLVE_PREF")) : 0;
     // few systems: 16 lanes per system (see the cooperative kernels); DDH_SOLVE_COOP = 0 never, 2 always
     const int coop_mode = getenv("DDH_SOLVE_COOP") ? atoi(getenv("DDH_SOLVE_COOP")) : 1;
-    const bool coop_ok = d.kl < CH && W <= 4 * CH && d.nb <= 8;
-    if (coop_ok && d.n > 0 && (coop_mode == 2 || (coop_mode == 1 && P.G <= 16384))) {
+    // forward: 16 lanes per system (needs kl < 16); backward: 16, 8 or 4 lanes per system (fewer lanes = less redundant
+    // work per system, more products per lane); the choice follows the number of systems, measured on MI355X with
+    // 5156-row systems: G <= 16384 -> both sweeps cooperative.  DDH_COOP_FWD / DDH_COOP_CB override (experiments).
+    // Measured on MI355X (5156-row systems of the 3-D benchmark, solve = both sweeps, ms):
+    //   G = 16384: one thread per system 5.79 | fwd coop + bwd 16 lanes 4.24 | + bwd 8 lanes 3.49 | + bwd 4 lanes 3.28
+    //   G = 32768: 6.13 | fwd coop 6.5-8.4 | fwd per-thread + bwd 4 lanes 5.75      G = 65536: 6.76 (anything else slower)
+    // (these are the per-rank sizes of the 512 x 512 x 256 problem on 8 / 4 / 2 GPUs); 2-D problems (a few hundred
+    // systems) were tuned with 16 lanes in both sweeps.
+    const bool coop_auto = coop_mode == 1 && NF > 0;
+    int use_fwd = (coop_mode == 2 || (coop_auto && P.G <= 16384)) ? 1 : 0;
+    int cb = 0;
+    if (coop_mode == 2 || (coop_auto && P.G <= 1024)) cb = 16;
+    else if (coop_auto && P.G <= 32768) cb = 4;
+    if (getenv("DDH_COOP_FWD")) use_fwd = atoi(getenv("DDH_COOP_FWD"));
+    if (getenv("DDH_COOP_CB")) cb = atoi(getenv("DDH_COOP_CB"));
+    if (NF == 0 || d.kl >= CH || d.nb > 8) use_fwd = 0;
+    if (NF == 0 || (cb != 4 && cb != 16)) cb = 0;
+    if (cb && (W + cb - 1) / cb > (cb == 4 ? 12 : 3)) cb = 0;
+    if (d.n <= 0) use_fwd = cb = 0;
+    if (use_fwd) {
         const unsigned cblocks = (unsigned)((P.G + (256 / CH) - 1) / (256 / CH));
 #define DDH_CFWD(NBTV)                                                                                             \
     {                                                                                                              \
@@ -1265,19 +1285,10 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
         else                                                                                                       \
             hipLaunchKernelGGL((solve_forward_coop_kernel<NF, false, NBTV>), dim3(cblocks), dim3(256), lds_f, s, P, d, rhs, x); \
     }
-        if (d.nb <= 2) DDH_CFWD(2) else DDH_CFWD(8)
+        if constexpr (NF > 0) {
+            if (d.nb <= 2) DDH_CFWD(2) else DDH_CFWD(8)
+        }
 #undef DDH_CFWD
-#define DDH_CBWD(TTV)                                                                                              \
-    {                                                                                                              \
-        if (d.real)                                                                                                \
-            hipLaunchKernelGGL((solve_backward_coop_kernel<NF, TTV, true>), dim3(cblocks), dim3(256), lds_b, s, P, d, x); \
-        else                                                                                                       \
-            hipLaunchKernelGGL((solve_backward_coop_kernel<NF, TTV, false>), dim3(cblocks), dim3(256), lds_b, s, P, d, x); \
-    }
-        if (W <= CH) DDH_CBWD(1) else if (W <= 2 * CH) DDH_CBWD(2) else if (W <= 3 * CH) DDH_CBWD(3) else DDH_CBWD(4)
-#undef DDH_CBWD
-        DDH_HIP(hipGetLastError());
-        return finish_solve<NF>(pp, lu, rhs, x, s);
     }
 #define DDH_FWD(KLTV, NBTV)                                                                                        \
     {                                                                                                              \
@@ -1286,12 +1297,32 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
         else                                                                                                       \
             hipLaunchKernelGGL((solve_forward_kernel<NF, false, KLTV, NBTV>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x); \
     }
-    if (d.nb <= 2) {
+    if (use_fwd) {
+    } else if (d.nb <= 2) {
         if (d.kl <= 8) DDH_FWD(8, 2) else if (d.kl <= 12) DDH_FWD(12, 2) else DDH_FWD(16, 2)
     } else {
         if (d.kl <= 8) DDH_FWD(8, 8) else if (d.kl <= 12) DDH_FWD(12, 8) else DDH_FWD(16, 8)
     }
 #undef DDH_FWD
+    if (cb) {
+#define DDH_CBWD(TTV, CBV)                                                                                         \
+    {                                                                                                              \
+        const unsigned cblocks = (unsigned)((P.G + (256 / CBV) - 1) / (256 / CBV));                                \
+        if (d.real)                                                                                                \
+            hipLaunchKernelGGL((solve_backward_coop_kernel<NF, TTV, true, CBV>), dim3(cblocks), dim3(256), lds_b, s, P, d, x); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((solve_backward_coop_kernel<NF, TTV, false, CBV>), dim3(cblocks), dim3(256), lds_b, s, P, d, x); \
+    }
+        const int tt = (W + cb - 1) / cb;
+        if constexpr (NF > 0) {
+            if (cb == 16) {
+                if (tt <= 2) DDH_CBWD(2, 16) else DDH_CBWD(3, 16)
+            } else {
+                if (tt <= 9) DDH_CBWD(9, 4) else DDH_CBWD(12, 4)
+            }
+        }
+#undef DDH_CBWD
+    }
 #define DDH_SOLVE(WTV)                                                                                             \
     {                                                                                                              \
         if (d.real) {                                                                                              \
@@ -1302,7 +1333,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
         } else                                                                                                     \
             hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
     }
-    if (d.n > 0) {
+    if (d.n > 0 && !cb) {
         if (W <= 8) DDH_SOLVE(8)
         else if (W <= 16) DDH_SOLVE(16)
         else if (W <= 24) DDH_SOLVE(24)

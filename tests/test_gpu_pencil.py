@@ -102,10 +102,13 @@ def bandwidth(tlists, perm, n):
 
 @pytest.mark.parametrize("nf,ncx,ncy", [(2, 6, 10), (1, 40, 1), (0, 1, 1)])
 @pytest.mark.parametrize("gauge", [False, True])
-@pytest.mark.parametrize("coop", [0, 2])
+@pytest.mark.parametrize("coop", [0, 2, 4])
 def test_matvec_factor_solve_vs_oracle(nf, ncx, ncy, gauge, coop, monkeypatch):
-    # coop = 2: the cooperative sweeps (16 lanes per system, used for few systems); 0: one thread per system
-    monkeypatch.setenv("DDH_SOLVE_COOP", str(coop))
+    # coop = 2: the cooperative sweeps (16 lanes per system, used for few systems); 0: one thread per system;
+    # 4: one thread per system forward, 4 lanes per system backward (the mid-range choice)
+    monkeypatch.setenv("DDH_SOLVE_COOP", "0" if coop == 4 else str(coop))
+    if coop == 4:
+        monkeypatch.setenv("DDH_COOP_CB", "4")
     from dedalus_amd.device import Device
     from dedalus_amd.pencilpack import PencilPack, TermList
     from oracle import np_pencil as npp
