@@ -1254,7 +1254,6 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
     const int W = d.W;
     const size_t lds_f = (size_t)(d.N + d.nb) * 5 + 16, lds_b = (size_t)(d.n > 0 ? d.n : 1) * 5 + 16;
     if (lds_f > 64 * 1024) return fail("pencil_solve: system too large for the LDS permutation cache");
-    static const int bwd_pref = getenv("DDH_SOLVE_PREF") ? atoi(getenv("DDH_SOLVE_PREF")) : 0;
     // few systems: 16 lanes per system (see the cooperative kernels); DDH_SOLVE_COOP = 0 never, 2 always
     const int coop_mode = getenv("DDH_SOLVE_COOP") ? atoi(getenv("DDH_SOLVE_COOP")) : 1;
     // forward: 16 lanes per system (needs kl < 16); backward: 16, 8 or 4 lanes per system (fewer lanes = less redundant
@@ -1325,21 +1324,17 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
     }
 #define DDH_SOLVE(WTV)                                                                                             \
     {                                                                                                              \
-        if (d.real) {                                                                                              \
-            if (bwd_pref)                                                                                          \
-                hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, true>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
-            else                                                                                                   \
-                hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
-        } else                                                                                                     \
+        if (d.real)                                                                                                \
+            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
+        else                                                                                                       \
             hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
     }
+    // (window sizes: few instantiations -- every one is a fully unrolled kernel and this file dominates the build time)
     if (d.n > 0 && !cb) {
         if (W <= 8) DDH_SOLVE(8)
         else if (W <= 16) DDH_SOLVE(16)
-        else if (W <= 24) DDH_SOLVE(24)
         else if (W <= 32) DDH_SOLVE(32)
         else if (W <= 34) DDH_SOLVE(34)
-        else if (W <= 40) DDH_SOLVE(40)
         else if (W <= 48) DDH_SOLVE(48)
         else DDH_SOLVE(64)
     }
