@@ -123,3 +123,52 @@ def test_reference_shell_convection_example_runs_unmodified(monkeypatch, tmp_pat
     solver, b, u = ns["solver"], ns["b"], ns["u"]
     assert solver.iteration == 3 and solver.sim_time == 3.0
     assert np.isfinite(np.asarray(b["g"])).all() and np.isfinite(np.asarray(u["g"])).all()
+
+
+def _cartesian_example(monkeypatch, tmp_path, path, max_iter):
+    import dedalus_amd.compat as compat
+    from dedalus_amd.core import distributor
+    from dedalus_amd.core import solvers
+    from oracle.np_executor import NumpyExecutor
+    compat.install()
+    orig_init = distributor.Distributor.__init__
+
+    def init(self, *a, **k):
+        k.setdefault("executor", NumpyExecutor())
+        orig_init(self, *a, **k)
+    monkeypatch.setattr(distributor.Distributor, "__init__", init)
+    orig_proceed = solvers.InitialValueSolver.proceed
+
+    def proceed(self):
+        return orig_proceed.fget(self) and self.iteration < max_iter
+    monkeypatch.setattr(solvers.InitialValueSolver, "proceed", property(proceed))
+    monkeypatch.chdir(tmp_path)
+    import matplotlib
+    matplotlib.use("Agg")
+    return runpy.run_path(path, run_name="__main__")
+
+
+KDV_EXAMPLE = "/root/reference/examples/ivp_1d_kdv_burgers/kdv_burgers.py"
+SHEAR_EXAMPLE = "/root/reference/examples/ivp_2d_shear_flow/shear_flow.py"
+
+
+@pytest.mark.skipif(not os.path.exists(KDV_EXAMPLE), reason="reference examples only exist in the build container")
+def test_reference_kdv_burgers_example_runs_unmodified(monkeypatch, tmp_path):
+    ns = _cartesian_example(monkeypatch, tmp_path, KDV_EXAMPLE, 60)
+    solver, u = ns["solver"], ns["u"]
+    assert solver.iteration == 60
+    assert np.isfinite(np.asarray(u["g"])).all()
+    assert os.path.exists(os.path.join(tmp_path, "kdv_burgers.pdf")) or os.path.exists(os.path.join(tmp_path, "kdv_burgers.png"))
+
+
+@pytest.mark.skipif(not os.path.exists(SHEAR_EXAMPLE), reason="reference examples only exist in the build container")
+def test_reference_shear_flow_example_runs_unmodified(monkeypatch, tmp_path):
+    """Also exercises the example's analysis handlers (tracer, pressure, vorticity snapshots) through the HDF5 writer."""
+    from dedalus_amd.tools import h5lite
+    ns = _cartesian_example(monkeypatch, tmp_path, SHEAR_EXAMPLE, 5)
+    solver, u, s = ns["solver"], ns["u"], ns["s"]
+    assert solver.iteration == 5
+    assert np.isfinite(np.asarray(u["c"])).all() and np.isfinite(np.asarray(s["c"])).all()
+    r = h5lite.read(os.path.join(tmp_path, "snapshots", "snapshots_s1.h5"))
+    assert sorted(r["tasks"].keys()) == ["pressure", "tracer", "vorticity"]
+    assert r["tasks/vorticity"].shape[0] >= 1 and np.isfinite(r["tasks/vorticity"].read(0)).all()
