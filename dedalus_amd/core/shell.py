@@ -301,6 +301,34 @@ class SurfaceBasis:
         return hash((id(self.shell), self.radius))
 
 
+def _radial_gemm(dist, basis, scale, nc, forward_dir):
+    """The radial Jacobi transform of all (component, m, ell) lines as ONE dense GEMM with the (Ng x Ng, zero-padded)
+    transform matrix (JacobiMMT, core/transforms.py:114-158) shared by every ell: `ddh_ell_terms_apply` runs it on the
+    FP64 MFMA path.  OPT-IN (DDH_RADIAL_GEMM=1 when the radial grid size tiles by 64, =2 always): measured at config
+    H it is slower than the LDS FFT kernel (step 13.4 ms against 10.3 ms) -- the per-ell GEMM tiles are mostly empty at
+    low ell and the padded copies cost two more passes -- so the FFT path stays the default; the parity tests keep the
+    matrix path alive as the independent check of the fast transform (the reference's own fast-vs-matrix test)."""
+    import os
+    mode = int(os.environ.get("DDH_RADIAL_GEMM", "0"))
+    Ng = basis.grid_shape((1.0, 1.0, scale))[2]
+    if mode == 0 or dist.size > 1 or Ng < basis.Nr or (mode == 1 and (Ng % 64 != 0 or basis.Nr < 64)):
+        return None
+    ex = dist.executor
+    key = ("rgemm", id(ex), scale, nc, forward_dir)
+    if key not in basis._plans:
+        sb = basis.sphere
+        fwd, bwd = basis.radial.mmt_matrices(Ng)              # (Nr x Ng), (Ng x Nr)
+        A = np.zeros((1, Ng, Ng))
+        if forward_dir:
+            A[0, :basis.Nr, :] = fwd
+        else:
+            A[0, :, :basis.Nr] = bwd
+        live = (np.arange(2 * sb.nml)[:, None] // 2) <= np.arange(sb.nl)[None, :]
+        slot_map = np.where(live, 0, -1).astype(np.int32)
+        basis._plans[key] = ex.make_ell_terms(sb.nml, sb.nl, Ng, nc, [(c, c, A) for c in range(nc)], slot_map)
+    return basis._plans[key]
+
+
 def backward(dist, basis, rank, c, scales):
     """coefficients [nc][2 nml][nl][Nr] (regularity components, local m) -> grid [nc][Nphi_g][Ntheta_g / P][Nr_g]
     (coordinate components, local colatitudes).  On P ranks the only exchange is the all-to-all between "m local
@@ -316,7 +344,11 @@ def backward(dist, basis, rank, c, scales):
         t0 = c                                             # spin components, no radial axis
     else:
         t0 = ex.empty((nc, 2 * nml, sb.nl, Ng))
-        ex.transform(basis.radial.plan_spec(scales[2]), basis.radial, "backward", c, t0, nslots, 1)
+        gemm = _radial_gemm(dist, basis, scales[2], nc, False)
+        if gemm is not None:
+            gemm.apply(_padded(ex, c, Ng), t0)
+        else:
+            ex.transform(basis.radial.plan_spec(scales[2]), basis.radial, "backward", c, t0, nslots, 1)
         ex.regularity_recombine(t0, basis.regularity_plan(ex, rank)[1],
                                 basis.radial_factor(ex, scales[2], basis.k) if basis.k > 0 else None)
     t1 = ex.empty((nc, 2 * nml, Nt, Ng))
@@ -373,6 +405,11 @@ def forward(dist, basis, rank, g, scales):
         return t3
     ex.regularity_recombine(t3, basis.regularity_plan(ex, rank)[0],
                             basis.radial_factor(ex, scales[2], -basis.k) if basis.k > 0 else None)
+    gemm = _radial_gemm(dist, basis, scales[2], nc, True)
+    if gemm is not None:
+        full = ex.empty((nc, 2 * nml, sb.nl, Ng))
+        gemm.apply(t3, full)
+        return _unpadded(ex, full, basis.Nr)
     c = ex.empty((nc, 2 * nml, sb.nl, basis.Nr))
     ex.transform(basis.radial.plan_spec(scales[2]), basis.radial, "forward", t3, c, nc * 2 * nml * sb.nl, 1)
     return c

@@ -243,7 +243,7 @@ ell_gemm_kernel(const double *__restrict__ x, double *__restrict__ y, const int 
             }
             __syncthreads();
             if (t < 0) continue;
-            const double *A = mats + (((long)t * nmat + l) * nr + k0) * nr + no0;
+            const double *A = mats + (((long)t * nmat + (nmat == 1 ? 0 : l)) * nr + k0) * nr + no0;
 #pragma unroll 4
             for (int k4 = 0; k4 < EG_K; k4 += 4) {
                 const double a = A[(long)(k4 + (lane >> 4)) * nr + (lane & 15)];
@@ -484,10 +484,11 @@ int ddh_ell_terms_create(ddh_handle *h, int nm, int nl, int nr, int ncomp_out, i
         }
     // dense path: default slot map (matrix index = ell), rows mostly full, sizes that tile
     {
-        bool def_map = (nmat == nl);
+        // (nmat == 1: one matrix shared by every ell -- the radial transforms as GEMMs -- with the default liveness)
+        bool def_map = (nmat == nl || nmat == 1);
         for (int i1 = 0; def_map && i1 < 2 * nm; ++i1)
             for (int l = 0; l < nl; ++l) {
-                const int want = ((i1 >> 1) <= l) ? l : -1;
+                const int want = ((i1 >> 1) <= l) ? (nmat == 1 ? 0 : l) : -1;
                 if (slot_map_h[i1 * nl + l] != want) { def_map = false; break; }
             }
         double fill = 0.0;

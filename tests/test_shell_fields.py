@@ -184,3 +184,20 @@ def test_shell_analysis_tasks_oracle():
 @pytest.mark.gpu
 def test_shell_analysis_tasks_gpu():
     check_analysis(None)
+
+
+def test_shell_radial_transform_as_gemm_oracle(monkeypatch):
+    """The radial transforms as one GEMM with the shared JacobiMMT matrix (the path taken when the radial grid size
+    tiles by 64, e.g. config 5), forced here at the golden sizes: same end state of the convection run."""
+    monkeypatch.setenv("DDH_RADIAL_GEMM", "2")
+    check_convection("SBDF2", _np_kw())
+    check_operators(_np_kw())
+
+
+@pytest.mark.gpu
+def test_shell_radial_transform_as_gemm_gpu(monkeypatch):
+    monkeypatch.setenv("DDH_RADIAL_GEMM", "2")
+    solver = check_convection("SBDF2", None)
+    assert solver.ex.name == "hip"
+    check_operators(None)
+    check_analysis(None)
