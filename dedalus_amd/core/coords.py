@@ -1,4 +1,4 @@
-"""Coordinate systems (Cartesian only in this round). Mirrors the names of dedalus/core/coords.py:1-413."""
+"""Cartesian coordinate systems (S2Coordinates: core/sphere.py, SphericalCoordinates: core/shell.py). Mirrors the names of dedalus/core/coords.py:1-413."""
 
 import numpy as np
 
