@@ -169,6 +169,13 @@ class Distributor:
         return self._reshape_axis(np.arange(basis.size), ax)
 
 
+def _overlap():
+    """DDH_A2A_OVERLAP=1: exchange the components of a field one by one with the packing / unpacking of its neighbours
+    overlapped (opt-in until it has been timed on a multi-GPU node: the single-GPU test box cannot run RCCL)."""
+    import os
+    return os.environ.get("DDH_A2A_OVERLAP", "0") == "1"
+
+
 class Transformer:
     """Walks a field through its axes (the reference's Transform.increment/decrement loop,
     core/distributor.py:601-661): backward = Jacobi axis first then Fourier axes in storage order,
@@ -272,13 +279,30 @@ class Transformer:
                 P = self.dist.size
                 nc, Gz, nxl = shape[0], shape[1], shape[2]
                 rest = int(np.prod(shape[3:]))
-                send = ex.empty((int(nc * Gz * nxl * rest),))
-                ex.a2a_pack(src, send, nc, Gz, nxl, rest, P)
-                recv = ex.empty(send.shape)
-                self.dist.pcomm.all_to_all(recv, send)
                 shape[1], shape[2] = Gz // P, nxl * P
                 out2 = dst if (last and dst is not None) else ex.empty(tuple(shape))
-                ex.a2a_unpack(recv, out2, nc, Gz // P, nxl * P, rest, P)
+                if nc > 1 and _overlap():
+                    # per-component pipeline: the exchange of component c runs (on the communicator's stream) while
+                    # component c + 1 is packed and component c - 1 is unpacked
+                    n1 = int(Gz * nxl * rest)
+                    pend = None
+                    for c in range(nc):
+                        send = ex.empty((n1,))
+                        ex.a2a_pack(src[c:c + 1], send, 1, Gz, nxl, rest, P)
+                        recv = ex.empty((n1,))
+                        work = self.dist.pcomm.all_to_all_start(recv, send)
+                        if pend is not None:
+                            pend[0].wait()
+                            ex.a2a_unpack(pend[1], out2[pend[2]:pend[2] + 1], 1, Gz // P, nxl * P, rest, P)
+                        pend = (work, recv, c, send)
+                    pend[0].wait()
+                    ex.a2a_unpack(pend[1], out2[pend[2]:pend[2] + 1], 1, Gz // P, nxl * P, rest, P)
+                else:
+                    send = ex.empty((int(nc * Gz * nxl * rest),))
+                    ex.a2a_pack(src, send, nc, Gz, nxl, rest, P)
+                    recv = ex.empty(send.shape)
+                    self.dist.pcomm.all_to_all(recv, send)
+                    ex.a2a_unpack(recv, out2, nc, Gz // P, nxl * P, rest, P)
                 src = out2
         return src
 
@@ -310,13 +334,28 @@ class Transformer:
                 nc, Gzl, nx = shape[0], shape[1], shape[2]
                 rest = int(np.prod(shape[3:]))
                 n_el = nc * Gzl * nx * rest
-                send = ex.empty((n_el,))
-                ex.a2a_pack(src, send, nc * Gzl, nx, 1, rest, P)
-                recv = ex.empty((n_el,))
-                self.dist.pcomm.all_to_all(recv, send)
                 shape[1], shape[2] = Gzl * P, nx // P
                 tmp = ex.empty(tuple(shape))
-                ex.a2a_unpack(recv, tmp, nc, 1, Gzl * P, (nx // P) * rest, P)
+                if nc > 1 and _overlap():
+                    n1 = Gzl * nx * rest
+                    pend = None
+                    for cc in range(nc):
+                        send = ex.empty((n1,))
+                        ex.a2a_pack(src[cc:cc + 1], send, Gzl, nx, 1, rest, P)
+                        recv = ex.empty((n1,))
+                        work = self.dist.pcomm.all_to_all_start(recv, send)
+                        if pend is not None:
+                            pend[0].wait()
+                            ex.a2a_unpack(pend[1], tmp[pend[2]:pend[2] + 1], 1, 1, Gzl * P, (nx // P) * rest, P)
+                        pend = (work, recv, cc, send)
+                    pend[0].wait()
+                    ex.a2a_unpack(pend[1], tmp[pend[2]:pend[2] + 1], 1, 1, Gzl * P, (nx // P) * rest, P)
+                else:
+                    send = ex.empty((n_el,))
+                    ex.a2a_pack(src, send, nc * Gzl, nx, 1, rest, P)
+                    recv = ex.empty((n_el,))
+                    self.dist.pcomm.all_to_all(recv, send)
+                    ex.a2a_unpack(recv, tmp, nc, 1, Gzl * P, (nx // P) * rest, P)
                 src = tmp
             outer = int(np.prod(shape[:pos + 1]))
             inner = int(np.prod(shape[pos + 2:]))

@@ -18,8 +18,11 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-@pytest.mark.parametrize("case,world", [("rb3d_8x12x8_rk222", 2), ("rb2d_32x16_rk222", 2)])
-def test_sharded_run_matches_reference(golden_dir, case, world):
+@pytest.mark.parametrize("case,world,overlap", [("rb3d_8x12x8_rk222", 2, "0"), ("rb2d_32x16_rk222", 2, "0"),
+                                                ("rb3d_8x12x8_rk222", 2, "1")])
+def test_sharded_run_matches_reference(golden_dir, case, world, overlap, monkeypatch):
+    # overlap = "1": the per-component exchange pipeline (DDH_A2A_OVERLAP, opt-in)
+    monkeypatch.setenv("DDH_A2A_OVERLAP", overlap)
     gold = np.load(os.path.join(golden_dir, "ivp.npz"))
     with tempfile.TemporaryDirectory() as tmp:
         port = 29500 + (os.getpid() % 2000)
