@@ -389,16 +389,24 @@ postsolve_kernel(PencilDev P, double *y, PostSolve ps) {
     for (int j = 0; j < 4; ++j) h0[j] = h1[j] = make_double2(0.0, 0.0);
     constexpr int PF = 8;
     for (int k0 = ps.nz - 1; k0 >= 0; k0 -= PF) {
+        // everything the next PF rows need -- their values AND their band coefficients -- is requested before the
+        // recurrence touches the first of them
         double2 a0[PF], a1[PF];
+        double bnd[PF][4];
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
             const int kz = k0 - q;
             a0[q] = a1[q] = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) bnd[q][d] = 0.0;
             if (kz >= 0) {
                 const double *yr = y + (long)(comp0 + kz) * plane;
                 if (NF == 0) a0[q].x = yr[0];
                 else a0[q] = *reinterpret_cast<const double2 *>(yr + off0);
                 if (NF == 2) a1[q] = *reinterpret_cast<const double2 *>(yr + off1);
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    if (d < ps.nbands) bnd[q][d] = ps.bands[d * ps.nz + kz];
             }
         }
 #pragma unroll
@@ -406,19 +414,22 @@ postsolve_kernel(PencilDev P, double *y, PostSolve ps) {
             const int kz = k0 - q;
             if (kz < 0) break;
             double2 v0 = a0[q], v1 = a1[q];
-            for (int d = 1; d < ps.nbands; ++d) {
-                const int o = ps.off[d];
-                if (kz + o < ps.nz) {
-                    const double bnd = ps.bands[d * ps.nz + kz];
-                    double2 p0 = make_double2(0.0, 0.0), p1 = p0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (o - 1 == j) { p0 = h0[j]; p1 = h1[j]; }
-                    v0.x -= bnd * p0.x; v0.y -= bnd * p0.y;
-                    v1.x -= bnd * p1.x; v1.y -= bnd * p1.y;
+            for (int d = 1; d < 4; ++d) {
+                if (d < ps.nbands) {
+                    const int o = ps.off[d];
+                    if (kz + o < ps.nz) {
+                        const double b = bnd[q][d];
+                        double2 p0 = make_double2(0.0, 0.0), p1 = p0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (o - 1 == j) { p0 = h0[j]; p1 = h1[j]; }
+                        v0.x -= b * p0.x; v0.y -= b * p0.y;
+                        v1.x -= b * p1.x; v1.y -= b * p1.y;
+                    }
                 }
             }
-            const double inv = 1.0 / ps.bands[kz];
+            const double inv = 1.0 / bnd[q][0];
             v0.x *= inv; v0.y *= inv; v1.x *= inv; v1.y *= inv;
 #pragma unroll
             for (int j = 3; j > 0; --j) { h0[j] = h0[j - 1]; h1[j] = h1[j - 1]; }
