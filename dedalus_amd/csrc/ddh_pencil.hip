@@ -1307,11 +1307,12 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
         else                                                                                                       \
             hipLaunchKernelGGL((solve_forward_kernel<NF, false, KLTV, NBTV>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x); \
     }
+    // (few window sizes: every instantiation is a fully unrolled kernel and this file dominates the build time)
     if (use_fwd) {
     } else if (d.nb <= 2) {
-        if (d.kl <= 8) DDH_FWD(8, 2) else if (d.kl <= 12) DDH_FWD(12, 2) else DDH_FWD(16, 2)
+        if (d.kl <= 12) DDH_FWD(12, 2) else DDH_FWD(16, 2)
     } else {
-        if (d.kl <= 8) DDH_FWD(8, 8) else if (d.kl <= 12) DDH_FWD(12, 8) else DDH_FWD(16, 8)
+        if (d.kl <= 12) DDH_FWD(12, 8) else DDH_FWD(16, 8)
     }
 #undef DDH_FWD
     if (cb) {
@@ -1342,9 +1343,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
     }
     // (window sizes: few instantiations -- every one is a fully unrolled kernel and this file dominates the build time)
     if (d.n > 0 && !cb) {
-        if (W <= 8) DDH_SOLVE(8)
-        else if (W <= 16) DDH_SOLVE(16)
-        else if (W <= 32) DDH_SOLVE(32)
+        if (W <= 32) DDH_SOLVE(32)
         else if (W <= 34) DDH_SOLVE(34)
         else if (W <= 48) DDH_SOLVE(48)
         else DDH_SOLVE(64)
