@@ -224,20 +224,54 @@ class SphereBasis:
         (core/basis.py:3119-3122, 3145-3148); one launch per field streams all matrices at once."""
         key = ("swsh", id(ex), Ntheta_g, rank)
         if key not in self._plans:
+            import os
             spins = self.spin_totals(rank)
+            # Components of opposite spin weight share their matrices: F_{-s}[l, j] = (-1)^(l + m) F_{+s}[l, N-1-j]
+            # (and two components of equal spin weight trivially do).  On the device the partner rides along as a
+            # second right-hand-side set of the +s group (ddh_grouped_mmt_set_pairs): the transform is bound by
+            # streaming the matrices, which are then stored and read once instead of twice.
+            pairs = []                                     # (primary component, partner or None, mode)
+            if getattr(ex, "mmt_pairs", False) and os.environ.get("DDH_SWSH_PAIRS", "1") != "0":
+                by_spin = {}
+                for i, sv in enumerate(spins):
+                    by_spin.setdefault(sv, []).append(i)
+                used = set()
+                for sv in sorted(by_spin, reverse=True):
+                    if sv > 0:
+                        for a, b in zip(by_spin[sv], by_spin.get(-sv, [])):
+                            pairs.append((a, b, 2))
+                            used.update((a, b))
+                    elif sv == 0:
+                        z = by_spin[0]
+                        for a, b in zip(z[0::2], z[1::2]):
+                            pairs.append((a, b, 1))
+                            used.update((a, b))
+                pairs += [(i, None, 0) for i in range(len(spins)) if i not in used]
+            else:
+                pairs = [(i, None, 0) for i in range(len(spins))]
             groups, keys, fwd, bwd = [], [], [], []
+            pg, pc, pm, pp = [], [], [], []
             cache = {}
-            for i, s in enumerate(spins):
+            for (i, partner, mode) in pairs:
+                sv = spins[i]
                 for m in range(self.nm):
-                    mk = m + 4096 * (s + 8)                    # matrix key of (m, s)
+                    mk = m + 4096 * (sv + 8)                   # matrix key of (m, s)
                     ne = max(self.Lmax + 1 - m, 0)
                     groups.append((mk if ne > 0 else -1 - m, i * 2 * self.nm + 2 * m, i * 2 * self.nm + 2 * m, 2, m, 1, ne))
+                    j = partner if partner is not None else 0
+                    pg.append(j * 2 * self.nm + 2 * m)
+                    pc.append(j * 2 * self.nm + 2 * m)
+                    pm.append(mode)
+                    pp.append(m & 1)
                     if ne > 0 and mk not in cache:
-                        cache[mk] = sph.swsh_matrices(Ntheta_g, self.Lmax, m, s)
+                        cache[mk] = sph.swsh_matrices(Ntheta_g, self.Lmax, m, sv)
                         keys.append(mk)
                         fwd.append(cache[mk][0])
                         bwd.append(cache[mk][1])
-            self._plans[key] = ex.make_grouped_mmt(Ntheta_g, np.array(groups, dtype=np.int64), keys, fwd, bwd)
+            plan = ex.make_grouped_mmt(Ntheta_g, np.array(groups, dtype=np.int64), keys, fwd, bwd)
+            if any(pm):
+                plan.set_pairs(pg, pc, pm, pp)
+            self._plans[key] = plan
         return self._plans[key]
 
     def recombination_matrix(self, rank, forward):

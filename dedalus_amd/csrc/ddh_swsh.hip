@@ -16,10 +16,14 @@ struct GroupDev {
     int mat_rows;            // rows (n_ell) of the matrices, -1: no matrix (|m| > Lmax)
     long off_f, off_b;       // offsets of the forward / backward matrix in the packed arrays
     int g_start, c_start, count, ell_start, ell_step, n_ell;
+    // second set of right-hand sides served by the SAME matrices (GEMV path): pair_mode 0 none, 1 plain,
+    // 2 mirrored: the spin -s transform from the spin +s matrices, F_{-s}[l, j] = (-1)^(l + m) F_{+s}[l, N-1-j]
+    int pair_g, pair_c, pair_mode, parity;
 };
 
 struct GmmtPlan : HandleBase {
-    int n_grid = 0, ngroups = 0, max_ell = 0, max_count = 0;
+    std::vector<GroupDev> hgroups;
+    int n_grid = 0, ngroups = 0, max_ell = 0, max_count = 0, paired = 0;
     long max_g_end = 0, max_c_end = 0, max_l_end = 0;
     GroupDev *d_groups = nullptr;
     double *d_fwd = nullptr, *d_bwd = nullptr;
@@ -51,7 +55,7 @@ constexpr int GV_COLS = 8;     // GEMV path: at most this many right-hand-side c
 // right-hand-side values are loaded once for all the rows of the wave; all index arithmetic is hoisted.
 constexpr int GV_ROWS = 4;
 
-template <bool FWD, int NCOL>
+template <bool FWD, int NCOL, bool PAIRS>
 __global__ void __launch_bounds__(256)
 grouped_gemv_kernel(const GroupDev *__restrict__ groups, const double *__restrict__ mats, const double *__restrict__ in,
                     double *__restrict__ out, GmmtDims d, int ncols) {
@@ -71,13 +75,24 @@ grouped_gemv_kernel(const GroupDev *__restrict__ groups, const double *__restric
     }
     const long istride = FWD ? d.n3 : (long)gr.ell_step * d.n3;
     const long ostride = FWD ? (long)gr.ell_step * d.n3 : d.n3;
+    // paired right-hand sides (same matrices, read once): bases of the partner slices
+    const bool paired = PAIRS && gr.pair_mode != 0, mirror = PAIRS && gr.pair_mode == 2;
+    long ibase2[NCOL], obase2[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        const long x = c % d.n3, jc = (c / d.n3) % gr.count, o = c / (d.n3 * gr.count);
+        ibase2[c] = FWD ? g_index(d, o, gr.pair_g + jc, 0, x) : c_index(d, o, gr.pair_c + jc, gr.ell_start, x);
+        obase2[c] = FWD ? c_index(d, o, gr.pair_c + jc, gr.ell_start, x) : g_index(d, o, gr.pair_g + jc, 0, x);
+    }
     if (gr.mat_rows < 0) {                              // |m| > Lmax: forward skips, backward writes zeros
         if (!FWD && lane == 0) {
             for (int r = 0; r < GV_ROWS; ++r) {
                 if (row0 + r >= d.n_grid) break;
 #pragma unroll
-                for (int c = 0; c < NCOL; ++c)
+                for (int c = 0; c < NCOL; ++c) {
                     if (cok[c]) out[obase[c] + (long)(row0 + r) * ostride] = 0.0;
+                    if (cok[c] && paired) out[obase2[c] + (long)(row0 + r) * ostride] = 0.0;
+                }
             }
         }
         return;
@@ -85,33 +100,59 @@ grouped_gemv_kernel(const GroupDev *__restrict__ groups, const double *__restric
     if (row0 >= nrows) return;
     const int K = FWD ? d.n_grid : gr.n_ell;            // contraction length
     const double *A = mats + (FWD ? gr.off_f : gr.off_b) + (long)row0 * K;
-    double acc[GV_ROWS][NCOL];
+    double acc[GV_ROWS][NCOL], acc2[GV_ROWS][NCOL];
 #pragma unroll
     for (int r = 0; r < GV_ROWS; ++r)
 #pragma unroll
-        for (int c = 0; c < NCOL; ++c) acc[r][c] = 0.0;
+        for (int c = 0; c < NCOL; ++c) acc[r][c] = acc2[r][c] = 0.0;
     bool rok[GV_ROWS];
 #pragma unroll
     for (int r = 0; r < GV_ROWS; ++r) rok[r] = row0 + r < nrows;
     for (int k = lane; k < K; k += 64) {
-        double a[GV_ROWS], xv[NCOL];
+        double a[GV_ROWS], xv[NCOL], xw[NCOL];
 #pragma unroll
         for (int r = 0; r < GV_ROWS; ++r) a[r] = rok[r] ? A[(long)r * K + k] : 0.0;
 #pragma unroll
         for (int c = 0; c < NCOL; ++c) xv[c] = cok[c] ? in[ibase[c] + (long)k * istride] : 0.0;
+        if (PAIRS && paired) {
+            // forward: the partner's grid values in reversed colatitude order; backward: its coefficients with the
+            // sign (-1)^(l + m) of the contraction index l = ell_start + k
+            const long kk = (FWD && mirror) ? (long)(K - 1 - k) : (long)k;
+            const double sg = (!FWD && mirror && ((gr.ell_start + k + gr.parity) & 1)) ? -1.0 : 1.0;
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) xw[c] = cok[c] ? sg * in[ibase2[c] + kk * istride] : 0.0;
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c) xw[c] = 0.0;
+        }
 #pragma unroll
         for (int r = 0; r < GV_ROWS; ++r)
 #pragma unroll
-            for (int c = 0; c < NCOL; ++c) acc[r][c] += a[r] * xv[c];
+            for (int c = 0; c < NCOL; ++c) {
+                acc[r][c] += a[r] * xv[c];
+                if (PAIRS) acc2[r][c] += a[r] * xw[c];
+            }
     }
 #pragma unroll
     for (int r = 0; r < GV_ROWS; ++r) {
 #pragma unroll
         for (int c = 0; c < NCOL; ++c) {
-            double v = acc[r][c];
+            double v = acc[r][c], w = acc2[r][c];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0 && rok[r] && cok[c]) out[obase[c] + (long)(row0 + r) * ostride] = v;
+            for (int off = 32; off > 0; off >>= 1) {
+                v += __shfl_down(v, off, 64);
+                if (PAIRS) w += __shfl_down(w, off, 64);
+            }
+            if (lane == 0 && rok[r] && cok[c]) {
+                out[obase[c] + (long)(row0 + r) * ostride] = v;
+                if (paired) {
+                    // forward: sign of the output row l = ell_start + row; backward: reversed output row
+                    const int row = row0 + r;
+                    const double so = (FWD && mirror && ((gr.ell_start + row + gr.parity) & 1)) ? -1.0 : 1.0;
+                    const long orow = (!FWD && mirror) ? (long)(nrows - 1 - row) : (long)row;
+                    out[obase2[c] + orow * ostride] = so * w;
+                }
+            }
         }
     }
 }
@@ -193,14 +234,19 @@ static int launch_grouped(GmmtPlan *pl, const double *in, double *out, long n0, 
     hipStream_t st = as_stream(stream);
     const int max_rows = FWD ? pl->max_ell : pl->n_grid;
     const double *mats = FWD ? pl->d_fwd : pl->d_bwd;
+    if (pl->paired && ncols > GV_COLS)
+        return fail("grouped_mmt: paired groups are implemented for the GEMV path (few columns) only");
     if (ncols <= GV_COLS) {
         dim3 grid((unsigned)((max_rows + 4 * GV_ROWS - 1) / (4 * GV_ROWS)), (unsigned)pl->ngroups);
-        if (ncols <= 2)
-            hipLaunchKernelGGL((grouped_gemv_kernel<FWD, 2>), grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols);
-        else if (ncols <= 4)
-            hipLaunchKernelGGL((grouped_gemv_kernel<FWD, 4>), grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols);
-        else
-            hipLaunchKernelGGL((grouped_gemv_kernel<FWD, 8>), grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols);
+#define DDH_GEMV(NC)                                                                                               \
+    {                                                                                                              \
+        if (pl->paired)                                                                                            \
+            hipLaunchKernelGGL((grouped_gemv_kernel<FWD, NC, true>), grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((grouped_gemv_kernel<FWD, NC, false>), grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols); \
+    }
+        if (ncols <= 2) DDH_GEMV(2) else if (ncols <= 4) DDH_GEMV(4) else DDH_GEMV(8)
+#undef DDH_GEMV
     } else {
         dim3 grid((unsigned)((ncols + GT_X - 1) / GT_X), (unsigned)((max_rows + GT_I - 1) / GT_I), (unsigned)pl->ngroups);
         if (grid.z > 65535 || grid.y > 65535) return fail("grouped_mmt: too many groups / rows for one launch");
@@ -291,6 +337,7 @@ int ddh_plan_grouped_mmt(ddh_handle *plan, int n_grid, int ngroups, const ddh_mm
         o.off_f = o.off_b = h.mat >= 0 ? off[h.mat] : 0;
         o.g_start = h.g_start; o.c_start = h.c_start; o.count = h.count;
         o.ell_start = h.ell_start; o.ell_step = h.ell_step; o.n_ell = h.mat >= 0 ? h.n_ell : 0;
+        o.pair_g = o.pair_c = 0; o.pair_mode = 0; o.parity = 0;
         const long l_lo = h.ell_step > 0 ? h.ell_start : h.ell_start - (long)(o.n_ell > 0 ? o.n_ell - 1 : 0);
         const long l_hi = h.ell_step > 0 ? h.ell_start + (long)(o.n_ell > 0 ? o.n_ell - 1 : 0) : h.ell_start;
         if (h.g_start < 0 || h.c_start < 0 || (o.n_ell > 0 && l_lo < 0)) {
@@ -321,7 +368,33 @@ int ddh_plan_grouped_mmt(ddh_handle *plan, int n_grid, int ngroups, const ddh_mm
         delete pl;
         return -2;
     }
+    pl->hgroups = gd;
     *plan = register_handle(pl);
+    return 0;
+}
+
+// Second right-hand-side set per group, served by the group's own matrices (GEMV path only, ell_step = +1):
+// pair_mode[g] = 0 none, 1 plain (another component with the same spin weight), 2 mirrored (the component of
+// opposite spin weight: F_{-s}[l, j] = (-1)^(l + m) F_{+s}[l, N-1-j], parity[g] = m & 1).  pair_g / pair_c are the
+// first grid / coefficient slice of the partner (same count as the group).
+int ddh_grouped_mmt_set_pairs(ddh_handle plan, int ngroups, const int *pair_g_h, const int *pair_c_h,
+                              const int *pair_mode_h, const int *parity_h) {
+    GmmtPlan *pl = (GmmtPlan *)lookup_handle(plan, H_GMMT);
+    if (!pl) return -1;
+    if (ngroups != pl->ngroups) return fail("grouped_mmt_set_pairs: group count differs from the plan");
+    for (int g = 0; g < ngroups; ++g) {
+        GroupDev &o = pl->hgroups[g];
+        if (pair_mode_h[g] < 0 || pair_mode_h[g] > 2) return fail("grouped_mmt_set_pairs: bad pair mode");
+        if (pair_mode_h[g] && (o.ell_step != 1 || pair_g_h[g] < 0 || pair_c_h[g] < 0))
+            return fail("grouped_mmt_set_pairs: pairs need ell_step = 1 and valid slices");
+        o.pair_g = pair_g_h[g]; o.pair_c = pair_c_h[g]; o.pair_mode = pair_mode_h[g]; o.parity = parity_h[g] & 1;
+        if (o.pair_mode) {
+            if (o.pair_g + o.count > pl->max_g_end) pl->max_g_end = o.pair_g + o.count;
+            if (o.mat_rows >= 0 && o.pair_c + o.count > pl->max_c_end) pl->max_c_end = o.pair_c + o.count;
+        }
+    }
+    DDH_HIP(hipMemcpy(pl->d_groups, pl->hgroups.data(), pl->hgroups.size() * sizeof(GroupDev), hipMemcpyHostToDevice));
+    pl->paired = 1;
     return 0;
 }
 

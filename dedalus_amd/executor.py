@@ -15,6 +15,7 @@ from .pencilpack import PencilPack
 
 class HipExecutor:
     name = "hip"
+    mmt_pairs = True            # grouped transforms accept paired right-hand sides (ddh_grouped_mmt_set_pairs)
 
     def __init__(self, device=None):
         self.dev = device or Device.get()
@@ -253,6 +254,11 @@ class GroupedMmt:
         self.handle = C.c_uint64(0)
         libhip.call("ddh_plan_grouped_mmt", C.byref(self.handle), self.n_grid, len(groups), C.cast(arr, C.c_void_p),
                     len(fw), libhip.as_ip(rows), pf, pb)
+
+    def set_pairs(self, pair_g, pair_c, pair_mode, parity):
+        """second right-hand-side set per group served by the same matrices (ddh_grouped_mmt_set_pairs)"""
+        a = [np.ascontiguousarray(v, dtype=np.int32) for v in (pair_g, pair_c, pair_mode, parity)]
+        libhip.call("ddh_grouped_mmt_set_pairs", self.handle, len(a[0]), *[libhip.as_ip(v) for v in a])
 
     def _dims(self, g, c):
         n0, n1g, nt, n3 = [int(x) for x in g.shape]

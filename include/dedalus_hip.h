@@ -110,6 +110,13 @@ typedef struct {
 } ddh_mmt_group;
 int ddh_plan_grouped_mmt(ddh_handle *plan, int n_grid, int ngroups, const ddh_mmt_group *groups_h, int nmats,
                          const int *mat_rows_h, const double *const *fwd_h, const double *const *bwd_h);
+/* Second right-hand-side set per group served by the group's own matrices (few-column / GEMV path): pair_mode 0 none,
+ * 1 plain (another tensor component with the same spin weight), 2 mirrored -- the component of opposite spin weight,
+ * whose matrices are the colatitude-reversed ones with signs: F_{-s}[l, j] = (-1)^(l + m) F_{+s}[l, N-1-j]
+ * (parity = m & 1).  The reference builds and applies the +s and -s matrices separately
+ * (core/transforms.py:1251-1340); here only one of them is stored and streamed. */
+int ddh_grouped_mmt_set_pairs(ddh_handle plan, int ngroups, const int *pair_g_h, const int *pair_c_h,
+                              const int *pair_mode_h, const int *parity_h);
 int ddh_grouped_mmt_forward(ddh_handle plan, const double *g, double *c, long n0, long n1g, long n1c, long n2c,
                             long n3, void *stream);
 int ddh_grouped_mmt_backward(ddh_handle plan, const double *c, double *g, long n0, long n1g, long n1c, long n2c,

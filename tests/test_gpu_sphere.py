@@ -151,3 +151,31 @@ def test_ell_terms(exs, nm, nl, nr, nco, nci, dense):
     hx.make_ell_terms(nm, nl, nr, nco, terms, slot_map).apply(hx.from_host(x), y)
     hx.sync()
     assert rel(hx.download(y), ref) < 1e-13
+
+
+@pytest.mark.parametrize("rank", [1, 2])
+def test_paired_spin_components_share_matrices(rank, monkeypatch):
+    """Spin -s from the spin +s matrices (colatitude-reversed, (-1)^(l+m)) and equal-spin components as a second
+    right-hand-side set: identical transforms to the one-matrix-set-per-component plan."""
+    import dedalus_amd.public as d3
+    res = {}
+    rng = np.random.default_rng(5)
+    g0 = None
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DDH_SWSH_PAIRS", mode)
+        coords = d3.S2Coordinates('phi', 'theta')
+        dist = d3.Distributor(coords, dtype=np.float64)
+        basis = d3.SphereBasis(coords, (64, 32), radius=1.0, dealias=3 / 2, dtype=np.float64)
+        f = dist.TensorField(coords, bases=basis, order=rank)
+        f.change_scales(3 / 2)
+        if g0 is None:
+            g0 = rng.standard_normal(np.asarray(f["g"]).shape)
+        f["g"] = g0
+        c = np.array(f["c"])
+        f.change_scales(3 / 2)
+        g = np.array(f["g"])
+        res[mode] = (c, g)
+    for k in (0, 1):
+        a, b = res["0"][k], res["1"][k]
+        assert np.isfinite(b).all()
+        assert np.linalg.norm(a - b) / np.linalg.norm(a) < 1e-13
