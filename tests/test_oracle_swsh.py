@@ -84,3 +84,19 @@ def test_oracle_matches_reference(gold, s):
             assert not np.isnan(gout).any() or np.array_equal(np.isnan(gout), np.isnan(gref))
             mask = ~np.isnan(gref)
             assert rel(gout[mask], gref[mask]) < 1e-13, (key,)
+
+
+@pytest.mark.parametrize("s", [1, 2])
+def test_opposite_spin_weights_share_matrices(s):
+    """The identity the paired device transform rests on (ddh_grouped_mmt_set_pairs):
+    F_{-s}[l, j] = (-1)^(l + m) F_{+s}[l, N-1-j] and the same for the backward matrices."""
+    from dedalus_amd.tools import sphere as sph
+    N, Lmax = 36, 22
+    for m in (0, 1, 2, 5, 11, 22):
+        fp, bp = sph.swsh_matrices(N, Lmax, m, s)
+        fm, bm = sph.swsh_matrices(N, Lmax, m, -s)
+        assert fp.shape == fm.shape and bp.shape == bm.shape
+        ells = Lmax + 1 - fp.shape[0] + np.arange(fp.shape[0])          # rows are ell = max(m, |s|) .. Lmax
+        sg = (-1.0) ** (ells + m)
+        assert np.abs(fm - sg[:, None] * fp[:, ::-1]).max() < 1e-14
+        assert np.abs(bm - sg[None, :] * bp[::-1, :]).max() < 1e-14
