@@ -205,3 +205,35 @@ def test_shell_file_handler(tmp_path):
     assert r['tasks/u'].attrs['DIMENSION_LABELS'] == ['t', '', 'phi', 'theta', 'r']
     assert r['tasks/tau'].attrs['DIMENSION_LABELS'] == ['t', 'phi', 'theta', 'constant']
     assert np.allclose(r['tasks/b'].read(0), before, rtol=0, atol=1e-13)
+
+
+def test_h5lite_index_growth_and_capacity(tmp_path, monkeypatch):
+    """Leaf split, root creation and the capacity limit of the chunk index, exercised with a tiny node size
+    (own reader only: libhdf5 assumes the default node size of a version-0 superblock)."""
+    monkeypatch.setattr(h5lite, "CHUNK_K", 2)                 # 4 entries per node -> 16 chunks per dataset
+    path = str(tmp_path / "k2.h5")
+    f = h5lite.File(path)
+    d = f.create_dataset("x", shape=(0, 600), maxshape=(None, 600), dtype=np.float64)     # 4800 B rows: 1 row per chunk
+    f.commit()
+    assert d.chunk_rows == 1 and d.capacity == 16
+    for w in range(16):
+        d.append(np.full(600, float(w)))
+        f.flush()
+        r = h5lite.read(path)["x"]
+        assert r.shape == (w + 1, 600) and np.array_equal(r.read()[:, 0], np.arange(w + 1.0))
+    with pytest.raises(RuntimeError):
+        d.append(np.zeros(600))
+    f.close()
+
+
+def test_file_handler_rolls_over_when_a_dataset_is_full(tmp_path, monkeypatch):
+    monkeypatch.setattr(h5lite, "CHUNK_K", 1)                 # 2 entries per node -> 4 chunks per dataset
+    d3, (solver, f) = _rb()
+    h = solver.evaluator.add_file_handler(str(tmp_path / "roll"), iter=1)          # no max_writes
+    h.add_task(f["b"], name="b")                                                    # 4 KB rows: one row per chunk
+    for _ in range(6):
+        solver.step(0.01)
+    s1 = h5lite.read(str(tmp_path / "roll" / "roll_s1.h5"))
+    s2 = h5lite.read(str(tmp_path / "roll" / "roll_s2.h5"))
+    assert s1["tasks/b"].shape[0] == 4 and s2["tasks/b"].shape[0] == 2
+    assert np.array_equal(s2["scales/write_number"].read(), [5, 6])
