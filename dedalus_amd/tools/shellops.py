@@ -13,6 +13,8 @@ Restated directly from the calculus, with the orthonormal-Jacobi toolkit of tool
   N x (N+1) differentiation matrices, and every result is expressed in the (k+1) polynomial family.
 All matrices are N x N, real, banded.
 """
+import functools
+
 import numpy as np
 
 from . import jacobi
@@ -35,14 +37,26 @@ def conversion(N, a, b):
     return _arr(jacobi.conversion_matrix(N, a, b, a + 1, b + 1))
 
 
-def D(dl, ell, N, k, radii, alpha=(-0.5, -0.5)):
-    """shell.operator(3, radii, 'D')(dl, ell)(N, k): k -> k + 1."""
+@functools.lru_cache(maxsize=64)
+def _D_parts(N, k, radii, alpha):
+    """The ell-independent pieces of D: d/dz[(z + rho) .] and the (k -> k + 1) conversion.  D is requested once per
+    operator and ell (hundreds of times while the matrices of a shell problem are built)."""
     dR = radii[1] - radii[0]
     rho = (radii[1] + radii[0]) / dR
     a, b = k + alpha[0], k + alpha[1]
     D1 = _arr(jacobi.differentiation_matrix(N + 1, a, b))[:N, :N + 1]
+    P, C = D1 @ _zrect(N, a, b, rho), conversion(N, a, b)
+    P.setflags(write=False)
+    C.setflags(write=False)
+    return P, C
+
+
+def D(dl, ell, N, k, radii, alpha=(-0.5, -0.5)):
+    """shell.operator(3, radii, 'D')(dl, ell)(N, k): k -> k + 1."""
+    dR = radii[1] - radii[0]
+    P, C = _D_parts(int(N), int(k), (float(radii[0]), float(radii[1])), (float(alpha[0]), float(alpha[1])))
     K = k + 1 + dl * ell - (1 if dl == -1 else 0)
-    return (D1 @ _zrect(N, a, b, rho) - K * conversion(N, a, b)) / dR
+    return (P - K * C) / dR
 
 
 def E(N, k, radii, alpha=(-0.5, -0.5)):
