@@ -5,8 +5,9 @@ RK222, fixed dt) -- BASELINE.json's metric.
     python bench.py --gpus N --steps K --warmup W [--size NX,NY,NZ]
 
 N=1 runs the largest configuration that fits one MI355X (the metric's 512x512x256 by default).
-For N>1 (launched by torch.distributed.run, one rank per GPU) the pencils are sharded across ranks
-(the metric's problem size is fixed, so this is "strong" scaling: total work constant).
+For N>1 the pencils are sharded across N ranks, one per GPU, exchanging through RCCL (the metric's problem size is
+fixed, so this is "strong" scaling: total work constant).  `python bench.py --gpus N` launches the N ranks itself
+(re-executing under torch.distributed.run on 127.0.0.1) when it was not already started by a launcher.
 
 Rank 0 prints ONE JSON line with the timing, the roofline of the dominant kernel (algorithmic bytes
 per launch / HIP-event time, measured inside the timed region) and a CPU baseline (the numpy/scipy
@@ -74,42 +75,122 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=str, default=os.environ.get("BENCH_SIZE", "512,512,256"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dt", type=float, default=1e-3)
     return ap.parse_args()
 
 
-def cpu_baseline(full_modes, budget_s=20.0):
-    """The oracle executor (reference algorithm: per-pencil scipy CSR + SuperLU, scipy.fft + NumPy
-    pack passes) on 3-D RB 32x32x32, one core.  Extrapolated to the metric's size by modes."""
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run --nproc-per-node N bench.py ...`."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(cmd[0], cmd, env)
+
+
+def host_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return dict(cpu_model=model, cores_total=os.cpu_count(), cores_usable=usable)
+
+
+def cpu_baseline(full_shape, budget_s=30.0):
+    """The oracle executor ("port": the reference's per-pencil algorithm restated -- scipy CSR + SuperLU per pencil,
+    scipy.fft + NumPy pack passes, oracle/np_executor.py) timed on this box's host, ONE core, on bounded samples of
+    the same problem family: 3-D RB 32^3 and 64x64x32 and the 2-D config 512x256.  The metric's size is far beyond
+    host memory for the reference's algorithm, so `value` extrapolates the largest 3-D sample with the
+    reference's own speed figure, mode-stages per cpu-second (core/solvers.py:755-778).  `port_vs_reference` is the
+    calibration of this port against the unmodified reference on the build container
+    (profiles/r2_cpu_port_vs_reference.json, tools/cpu_calibration.py)."""
     import problems
     import dedalus_amd.public as d3
     from oracle.np_executor import NumpyExecutor
     os.environ.setdefault("OMP_NUM_THREADS", "1")
-    n = (32, 32, 32)
-    solver, fields = problems.rayleigh_benard_3d(d3, Nx=n[0], Ny=n[1], Nz=n[2], dist_kw=dict(executor=NumpyExecutor()))
-    solver.step(1e-3)                      # factorizations happen here
-    t0 = time.time()
-    steps = 0
-    while time.time() - t0 < budget_s and steps < 200:
-        solver.step(1e-3)
-        steps += 1
-    el = time.time() - t0
-    sps = steps / el
-    modes = 5 * n[0] * n[1] * n[2]
-    extrap = sps * modes / full_modes
-    return dict(value=extrap, unit="timesteps/sec (extrapolated to the metric's size by mode count)",
-                cores=1, kind="port",
-                sample="3-D RB %dx%dx%d RK222 dt=1e-3, %d steps in %.1f s = %.3f steps/s measured on 1 core; "
-                       "x (modes %d / %d)" % (n[0], n[1], n[2], steps, el, sps, modes, full_modes),
-                measured_steps_per_sec=sps)
+    samples = []
+    cases = [("rb3d", dict(Nx=32, Ny=32, Nz=32), 0.25), ("rb3d", dict(Nx=64, Ny=64, Nz=32), 0.4),
+             ("rb2d", dict(Nx=512, Nz=256), 0.35)]
+    for kind, kw, share in cases:
+        build = problems.rayleigh_benard_3d if kind == "rb3d" else problems.rayleigh_benard_2d
+        t0 = time.time()
+        solver, fields = build(d3, timestepper="RK222", dist_kw=dict(executor=NumpyExecutor()), **kw)
+        solver.step(1e-3)                      # factorizations happen here
+        setup = time.time() - t0
+        t0 = time.time()
+        steps = 0
+        while steps < 2 or (time.time() - t0 < share * budget_s * 0.5 and steps < 100):
+            solver.step(1e-3)
+            steps += 1
+        el = time.time() - t0
+        nvar = 5 if kind == "rb3d" else 4
+        modes = nvar * int(np.prod(list(kw.values())))
+        samples.append(dict(case="%s %s" % (kind, "x".join(str(v) for v in kw.values())), steps=steps, seconds=round(el, 2),
+                            setup_s=round(setup, 2), steps_per_s=steps / el, modes=modes,
+                            mode_stages_per_cpu_s=modes * 2 * steps / el))
+    ref3d = samples[1]
+    full_modes = 5 * int(np.prod(full_shape))
+    value = ref3d["mode_stages_per_cpu_s"] / (2 * full_modes)
+    calib = None
+    cpath = os.path.join(ROOT, "profiles", "r2_cpu_port_vs_reference.json")
+    if os.path.exists(cpath):
+        cj = json.load(open(cpath))
+        calib = dict(geomean=cj["port_vs_reference_geomean"], measured_on=cj["host"]["cpu_model"],
+                     per_case={"%s %s" % (c["case"], "x".join(str(v) for v in c["size"].values())): round(c["port_vs_reference"], 3)
+                               for c in cj["cases"]},
+                     source="profiles/r2_cpu_port_vs_reference.json")
+    return dict(value=value, unit="timesteps/sec (extrapolated to the metric's size with mode-stages per cpu-second)",
+                cores=1, kind="port", host=host_info(), cores_total=os.cpu_count(),
+                sample="3 bounded samples on 1 core, RK222 dt=1e-3: " + "; ".join(
+                    "%s: %d steps in %.1f s = %.3f steps/s" % (x["case"], x["steps"], x["seconds"], x["steps_per_s"]) for x in samples)
+                       + "; value = mode-stages/cpu-s of the 64x64x32 sample / (2 stages x %d modes)" % full_modes,
+                samples=samples, port_vs_reference=calib,
+                reference_estimate=(value / calib["geomean"]) if calib else None)
+
+
+def parity_check(solver, dt):
+    """One extra (untimed) step at the metric's size with every solve of the sampled pencils compared with the
+    REFERENCE's own pencil matrices (tests/pencil_check.py, tests/golden/pencils_nz256.npz)."""
+    import pencil_check
+    ref = pencil_check.ReferencePencils()
+    lo = solver.dist._mx_offset
+    hi = lo + solver.nx // 2
+    mine = [g for g in ref.groups if lo <= ref.modes(g)[0] < hi]
+    solver.solve_probe = dict(groups=[ref.modes(g) for g in mine], records=[])
+    solver.step(dt)
+    recs = solver.solve_probe["records"]
+    solver.solve_probe = None
+    res = pencil_check.check_records(ref, recs, mine) if mine else []
+    return dict(pencils_checked=len(mine), solves=len(recs),
+                max_residual=max((r["residual"] for r in res), default=0.0),
+                max_solution_error=max((r["solution"] for r in res), default=0.0),
+                max_invalid_mode=max((r["dropped_max"] for r in res), default=0.0))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)                   # does not return
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, world, world),
+              file=sys.stderr)
     if world > 1:
         import torch.distributed as dist
         if os.environ.get("DDH_FORCE_DEVICE") is not None:      # test aid: several ranks on one GPU (gloo)
@@ -152,11 +233,33 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
     summ = timer.summary()
+    ranks_seen, backend, exch = 1, None, None
+    if world > 1:
+        ranks_seen = torch.distributed.get_world_size()
+        backend = torch.distributed.get_backend()
+        pc = solver.dist.pcomm
+        via = "libdedalus_hip RCCL plan (ddh_a2a_localize_*)" if pc.library_comm() is not None else "torch.distributed all_to_all_single"
+        ex_ms = summ.get("a2a_exchange", {}).get("total_ms", 0.0) / args.steps
+        exch = dict(per_rank_bytes_sent_per_step=pc.stats["bytes_sent"] / (args.warmup + args.steps),
+                    exchanges_per_step=pc.stats["exchanges"] / (args.warmup + args.steps), ms_per_step_rank0=ex_ms, via=via)
     chk2 = float(np.sum(np.asarray(fields["b"]["c"]) ** 2))
     if world > 1:
         t = torch.tensor([chk2], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t)
         chk2 = float(t.item())
+    parity = None
+    if (Nx, Ny, Nz) == (512, 512, 256) and not args.no_parity:
+        parity = parity_check(solver, args.dt)
+        if world > 1:
+            vals = torch.tensor([parity["max_residual"], parity["max_solution_error"], parity["max_invalid_mode"]],
+                                device="cuda", dtype=torch.float64)
+            cnt = torch.tensor([float(parity["pencils_checked"])], device="cuda", dtype=torch.float64)
+            torch.distributed.all_reduce(vals, op=torch.distributed.ReduceOp.MAX)
+            torch.distributed.all_reduce(cnt)
+            parity.update(max_residual=float(vals[0]), max_solution_error=float(vals[1]),
+                          max_invalid_mode=float(vals[2]), pencils_checked=int(cnt.item()))
+        parity["what"] = ("every solve of one extra step on a 4x4 sample of pencils (modes 0, 85, 170, 255) against the "
+                          "reference's own M_min/L_min (SuperLU solution and residual); tests/pencil_check.py")
     chk = float(np.sqrt(chk2))
 
     if rank == 0:
@@ -176,7 +279,7 @@ def main():
         total_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in summ.values())
         out = {
             "metric": "timesteps/sec, 3D Rayleigh-Benard %dx%dx%d (Fourier x Fourier x Chebyshev, RK222)" % (Nx, Ny, Nz),
-            "value": steps_per_s, "unit": "timesteps/sec", "n_gpus": world, "steps": args.steps,
+            "value": steps_per_s, "unit": "timesteps/sec", "n_gpus": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "3-D Rayleigh-Benard IVP %dx%dx%d, dealias 3/2, RK222, fixed dt=%g, Ra=2e6 Pr=1, "
@@ -189,10 +292,11 @@ def main():
                            "achieved_GBps_all_kernels": (total_bytes / 1e9) / (total_kernel_ms / 1e3) if total_kernel_ms else None},
             "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4), "GBps": round(v["gbps"], 1),
                             "total_ms": round(v["total_ms"], 2)} for k, v in sorted(summ.items())},
-            "build_s": build_s, "checksum_b_c_l2": chk,
+            "build_s": build_s, "checksum_b_c_l2": chk, "parity": parity,
+            "ranks_seen": ranks_seen, "dist_backend": backend, "exchange": exch,
         }
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(5 * Nx * Ny * Nz)
+            out["cpu_baseline"] = cpu_baseline((Nx, Ny, Nz))
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

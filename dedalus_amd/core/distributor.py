@@ -298,13 +298,43 @@ class Transformer:
                     pend[0].wait()
                     ex.a2a_unpack(pend[1], out2[pend[2]:pend[2] + 1], 1, Gz // P, nxl * P, rest, P)
                 else:
-                    send = ex.empty((int(nc * Gz * nxl * rest),))
-                    ex.a2a_pack(src, send, nc, Gz, nxl, rest, P)
-                    recv = ex.empty(send.shape)
-                    self.dist.pcomm.all_to_all(recv, send)
-                    ex.a2a_unpack(recv, out2, nc, Gz // P, nxl * P, rest, P)
+                    self._exchange(ex, "rows", src, out2, nc, Gz, nxl * P, rest)
                 src = out2
         return src
+
+    def _exchange(self, ex, which, src, dst, n0, n1, n2, n3):
+        """One pencil transpose of the global [n0][n1][n2][n3] view (n1 = Jacobi axis, n2 = first Fourier axis):
+        "rows":    CL [n0][n1][n2/P][n3] -> RL [n0][n1/P][n2][n3]   (backward direction here: kx-sharded -> z-sharded)
+        "columns": RL -> CL                                          (forward direction)
+        Through the library's RCCL plan (ddh_a2a_localize_*) on the GPUs; through torch.distributed around the
+        ddh_a2a_pack / unpack kernels in the gloo test configurations and on the CPU oracle."""
+        P = self.dist.size
+        pcomm = self.dist.pcomm
+        nbytes = 8 * int(n0 * n1 * n2 * n3) // P
+        timer = getattr(ex, "timer", None)
+
+        def run():
+            plan = ex.a2a_plan(pcomm, n0, n1, n2, n3) if hasattr(ex, "a2a_plan") else None
+            if plan is not None:
+                (ex.a2a_localize_rows if which == "rows" else ex.a2a_localize_columns)(plan, src, dst)
+                return
+            send = ex.empty((nbytes // 8,))
+            recv = ex.empty((nbytes // 8,))
+            if which == "rows":
+                ex.a2a_pack(src, send, n0, n1, n2 // P, n3, P)
+                pcomm.all_to_all(recv, send)
+                ex.a2a_unpack(recv, dst, n0, n1 // P, n2, n3, P)
+            else:
+                ex.a2a_pack(src, send, n0 * (n1 // P), n2, 1, n3, P)
+                pcomm.all_to_all(recv, send)
+                ex.a2a_unpack(recv, dst, n0, 1, n1, (n2 // P) * n3, P)
+
+        pcomm.stats["exchanges"] += 1
+        pcomm.stats["bytes_sent"] += nbytes * (P - 1) // P
+        if timer is not None:
+            timer.run("a2a_exchange", 2 * nbytes, run)         # pack read+write, unpack read+write ~ 4x; wire 1x
+        else:
+            run()
 
     def backward_data(self, domain, ncomp, c, g, scales, skip_last=False):
         """coefficient -> grid.  skip_last stops before the last storage axis ("pre-grid" layout)."""
@@ -351,11 +381,7 @@ class Transformer:
                     pend[0].wait()
                     ex.a2a_unpack(pend[1], tmp[pend[2]:pend[2] + 1], 1, 1, Gzl * P, (nx // P) * rest, P)
                 else:
-                    send = ex.empty((n_el,))
-                    ex.a2a_pack(src, send, nc * Gzl, nx, 1, rest, P)
-                    recv = ex.empty((n_el,))
-                    self.dist.pcomm.all_to_all(recv, send)
-                    ex.a2a_unpack(recv, tmp, nc, 1, Gzl * P, (nx // P) * rest, P)
+                    self._exchange(ex, "columns", src, tmp, nc, Gzl * P, nx, rest)
                 src = tmp
             outer = int(np.prod(shape[:pos + 1]))
             inner = int(np.prod(shape[pos + 2:]))

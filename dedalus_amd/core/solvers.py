@@ -456,11 +456,47 @@ class SolverBase:
             Y = self.ex.empty((self.R, self.nx, self.ny))
             self.pack.solve(lu, rhs, Y)
             self.pack.matvec(self.P_id, Y, out)
+        probe = getattr(self, "solve_probe", None)
+        if probe is not None:
+            a, b = self._lu_params[lu]
+            probe["records"].append(dict(a=a, b=b,
+                                         rhs=[self.gather_pencil(rhs, "equations", gx, gy) for gx, gy in probe["groups"]],
+                                         x=[self.gather_pencil(out, "variables", gx, gy) for gx, gy in probe["groups"]]))
+
+    def gather_pencil(self, vec, which, gx, gy=0):
+        """One pencil of a system vector in the reference's gathered order (Subproblem.gather_inputs /
+        gather_outputs before pre_right_pinv / pre_left, core/subsystems.py:302-365): for every variable (or equation)
+        in problem order its slice [component..., 2 modes of x group gx, 2 modes of y group gy, all z], C order;
+        operands without a Fourier basis belong to group 0 only.  Diagnostics / parity checks: a few KB per call."""
+        infos = self.var_info if which == "variables" else self.eq_info
+        lx = gx - (self.dist._mx_offset if self.nf >= 1 else 0)
+        parts = []
+        for info in infos:
+            bits = info["bits"]
+            if self.nf >= 1:
+                sx = slice(2 * lx, 2 * lx + 2) if (bits & 1) else (slice(0, 1) if gx == 0 else slice(0, 0))
+            else:
+                sx = slice(0, 1)
+            if self.nf >= 2:
+                sy = slice(2 * gy, 2 * gy + 2) if (bits & 2) else (slice(0, 1) if gy == 0 else slice(0, 0))
+            else:
+                sy = slice(0, 1)
+            blk = vec[info["row0"]:info["row0"] + info["rows"]].reshape(info["ncomp"], info["nz"], self.nx, self.ny)
+            blk = self.ex.download(blk[:, :, sx, sy].contiguous() if hasattr(blk, "contiguous") else blk[:, :, sx, sy])
+            blk = np.asarray(blk).transpose(0, 2, 3, 1)
+            if self.nf < 2:
+                blk = blk[:, :, 0, :] if self.nf == 1 else blk[:, 0, 0, :]
+            parts.append(np.ascontiguousarray(blk).ravel())
+        return np.concatenate(parts)
 
     def factor(self, a, b, reuse=-1):
-        return self.pack.factor(self.MP_id, self.LP_id, a, b, self.row_perm, self.col_perm, self.n_interior,
-                                self.kl, self.ku, self.row_axes, self.col_axes, reuse=reuse,
-                                real=self.real_grading)
+        lu = self.pack.factor(self.MP_id, self.LP_id, a, b, self.row_perm, self.col_perm, self.n_interior,
+                              self.kl, self.ku, self.row_axes, self.col_axes, reuse=reuse,
+                              real=self.real_grading)
+        if not hasattr(self, "_lu_params"):
+            self._lu_params = {}
+        self._lu_params[lu] = (float(a), float(b))
+        return lu
 
 
 def _two_colour(n, row, col, label):

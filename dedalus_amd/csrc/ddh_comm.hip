@@ -1,0 +1,205 @@
+// Distributed pencil transposes with a library-owned RCCL communicator (boundary B3).
+//
+// Replaces FFTWTranspose / AlltoallvTranspose (core/transposes.pyx:22-445) and the MPI communicator they are planned
+// on (core/distributor.py:696-768): one process per GPU, xGMI point-to-point links underneath.  A plan describes the
+// reference's reduced 4-D view (N0, N1, N2, N3) of a block-distributed array and moves it between
+//     column-local  CL: [N0][N1     ][N2 / P][N3]     (axis N1 local, N2 distributed)
+//     row-local     RL: [N0][N1 / P ][N2    ][N3]     (axis N2 local, N1 distributed)
+// as   pack (ddh_a2a_pack kernel: contiguous 16-byte copies)  ->  P grouped ncclSend / ncclRecv pairs on the caller's
+// stream  ->  unpack.  RCCL is bound at run time (dlopen of librccl.so.1: the copy torch already loaded when present),
+// so the library itself has no link-time dependency and loads on boxes without a GPU.
+#include "ddh_common.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace ddh {
+
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static Rccl g_rccl;
+
+static int load_rccl() {
+    if (g_rccl.lib) return 0;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : names) {
+        lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);      // the copy already in the process (torch's), if any
+        if (lib) break;
+    }
+    for (int i = 0; !lib && i < 3; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(std::string("RCCL not found: ") + dlerror());
+#define DDH_SYM(field, name)                                                        \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, name));      \
+    if (!g_rccl.field) return fail(std::string("RCCL symbol missing: ") + name);
+    DDH_SYM(GetUniqueId, "ncclGetUniqueId")
+    DDH_SYM(CommInitRank, "ncclCommInitRank")
+    DDH_SYM(CommDestroy, "ncclCommDestroy")
+    DDH_SYM(GroupStart, "ncclGroupStart")
+    DDH_SYM(GroupEnd, "ncclGroupEnd")
+    DDH_SYM(Send, "ncclSend")
+    DDH_SYM(Recv, "ncclRecv")
+    DDH_SYM(AllReduce, "ncclAllReduce")
+    DDH_SYM(GetErrorString, "ncclGetErrorString")
+#undef DDH_SYM
+    g_rccl.lib = lib;
+    return 0;
+}
+
+static int check_nccl(ncclResult_t r, const char *what) {
+    if (r == ncclSuccess) return 0;
+    return fail(std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error"));
+}
+#define DDH_NCCL(call)                                   \
+    do {                                                 \
+        int _s = check_nccl((call), #call);              \
+        if (_s) return _s;                               \
+    } while (0)
+
+struct Comm : HandleBase {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    ~Comm() override {
+        if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
+    }
+};
+
+struct A2aPlan : HandleBase {
+    Comm *comm = nullptr;
+    long n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    size_t local = 0;          // doubles per rank
+    double *send = nullptr, *recv = nullptr;
+    ~A2aPlan() override {
+        (void)hipFree(send);
+        (void)hipFree(recv);
+    }
+};
+
+// equal-split all-to-all of `local` doubles: block p of `send` goes to rank p, block q of `recv` comes from rank q
+static int exchange(A2aPlan *pl, hipStream_t s) {
+    const Comm *c = pl->comm;
+    const size_t chunk = pl->local / (size_t)c->nranks;
+    DDH_NCCL(g_rccl.GroupStart());
+    for (int p = 0; p < c->nranks; ++p) {
+        DDH_NCCL(g_rccl.Send(pl->send + (size_t)p * chunk, chunk, ncclDouble, p, c->comm, s));
+        DDH_NCCL(g_rccl.Recv(pl->recv + (size_t)p * chunk, chunk, ncclDouble, p, c->comm, s));
+    }
+    DDH_NCCL(g_rccl.GroupEnd());
+    return 0;
+}
+
+}  // namespace ddh
+
+using namespace ddh;
+
+extern "C" {
+
+int ddh_comm_unique_id(unsigned char *id_h) {
+    if (!id_h) return fail("ddh_comm_unique_id: null buffer");
+    if (int s = load_rccl()) return s;
+    ncclUniqueId id;
+    DDH_NCCL(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(ncclUniqueId) == DDH_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id_h, &id, sizeof(id));
+    return 0;
+}
+
+int ddh_comm_create(ddh_handle *comm, int rank, int nranks, const unsigned char *id_h) {
+    if (!comm || !id_h) return fail("ddh_comm_create: null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("ddh_comm_create: rank out of range");
+    if (int s = load_rccl()) return s;
+    ncclUniqueId id;
+    memcpy(&id, id_h, sizeof(id));
+    Comm *c = new Comm();
+    c->kind = H_COMM;
+    c->rank = rank;
+    c->nranks = nranks;
+    if (int s = check_nccl(g_rccl.CommInitRank(&c->comm, nranks, id, rank), "ncclCommInitRank")) {
+        c->comm = nullptr;
+        delete c;
+        return s;
+    }
+    *comm = register_handle(c);
+    return 0;
+}
+
+int ddh_comm_info(ddh_handle comm, int *rank, int *nranks) {
+    Comm *c = (Comm *)lookup_handle(comm, H_COMM);
+    if (!c) return -1;
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = c->nranks;
+    return 0;
+}
+
+int ddh_comm_allreduce(ddh_handle comm, double *buf, long count, int op, void *stream) {
+    Comm *c = (Comm *)lookup_handle(comm, H_COMM);
+    if (!c) return -1;
+    if (op < 0 || op > 2) return fail("ddh_comm_allreduce: op must be 0 (sum), 1 (max) or 2 (min)");
+    const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
+    DDH_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ops[op], c->comm, as_stream(stream)));
+    return 0;
+}
+
+int ddh_a2a_plan(ddh_handle *plan, ddh_handle comm, long n0, long n1, long n2, long n3) {
+    Comm *c = (Comm *)lookup_handle(comm, H_COMM);
+    if (!c) return -1;
+    if (!plan || n0 < 1 || n1 < 1 || n2 < 1 || n3 < 1) return fail("ddh_a2a_plan: bad shape");
+    if (n1 % c->nranks || n2 % c->nranks)
+        return fail("ddh_a2a_plan: both transposed axes must be divisible by the number of ranks (equal blocks)");
+    A2aPlan *pl = new A2aPlan();
+    pl->kind = H_A2A;
+    pl->comm = c;
+    pl->n0 = n0; pl->n1 = n1; pl->n2 = n2; pl->n3 = n3;
+    pl->local = (size_t)(n0 * n1 * n2 * n3) / (size_t)c->nranks;
+    if (check_hip(hipMalloc((void **)&pl->send, pl->local * sizeof(double) + 16), "hipMalloc") ||
+        check_hip(hipMalloc((void **)&pl->recv, pl->local * sizeof(double) + 16), "hipMalloc")) {
+        delete pl;
+        return -2;
+    }
+    *plan = register_handle(pl);
+    return 0;
+}
+
+// CL [N0][N1][N2/P][N3] -> RL [N0][N1/P][N2][N3]    (Transpose.decrement: towards coefficient space)
+int ddh_a2a_localize_rows(ddh_handle plan, const double *cl, double *rl, void *stream) {
+    A2aPlan *pl = (A2aPlan *)lookup_handle(plan, H_A2A);
+    if (!pl) return -1;
+    const int P = pl->comm->nranks;
+    if (cl == rl) return fail("ddh_a2a_localize_rows: the two layouts must be different buffers");
+    // split N1 into P row blocks, exchange, gather the P column blocks along N2
+    if (int s = ddh_a2a_pack(cl, pl->send, pl->n0, pl->n1, pl->n2 / P, pl->n3, P, stream)) return s;
+    if (int s = exchange(pl, as_stream(stream))) return s;
+    return ddh_a2a_unpack(pl->recv, rl, pl->n0, pl->n1 / P, pl->n2, pl->n3, P, stream);
+}
+
+// RL [N0][N1/P][N2][N3] -> CL [N0][N1][N2/P][N3]    (Transpose.increment: towards grid space)
+int ddh_a2a_localize_columns(ddh_handle plan, const double *rl, double *cl, void *stream) {
+    A2aPlan *pl = (A2aPlan *)lookup_handle(plan, H_A2A);
+    if (!pl) return -1;
+    const int P = pl->comm->nranks;
+    if (cl == rl) return fail("ddh_a2a_localize_columns: the two layouts must be different buffers");
+    // split N2 into P column blocks ([N0 N1/P][N2][1][N3] view), exchange, gather the P row blocks along N1
+    if (int s = ddh_a2a_pack(rl, pl->send, pl->n0 * (pl->n1 / P), pl->n2, 1, pl->n3, P, stream)) return s;
+    if (int s = exchange(pl, as_stream(stream))) return s;
+    return ddh_a2a_unpack(pl->recv, cl, pl->n0, 1, pl->n1, (pl->n2 / P) * pl->n3, P, stream);
+}
+
+int ddh_a2a_forward(ddh_handle plan, const double *cl, double *rl, void *stream) {
+    return ddh_a2a_localize_rows(plan, cl, rl, stream);
+}
+int ddh_a2a_backward(ddh_handle plan, const double *rl, double *cl, void *stream) {
+    return ddh_a2a_localize_columns(plan, rl, cl, stream);
+}
+
+}  // extern "C"

@@ -21,7 +21,7 @@ int check_hip(hipError_t e, const char *what);    // 0 or negative
         if (_s) return _s;                                       \
     } while (0)
 
-enum HandleKind : uint32_t { H_FFT = 1, H_MMT = 2, H_PENCIL = 3, H_GMMT = 4 };
+enum HandleKind : uint32_t { H_FFT = 1, H_MMT = 2, H_PENCIL = 3, H_GMMT = 4, H_COMM = 5, H_A2A = 6 };
 
 struct HandleBase {
     HandleKind kind;

@@ -106,6 +106,11 @@ struct PencilPack : HandleBase {
     std::vector<LuFactor *> lus;
     std::vector<PostSolve> posts;
     std::vector<void *> post_mem;
+    // sweep variant of ddh_pencil_solve: mode 1 = by the number of systems, 0 = one thread per system, 2 = cooperative;
+    // fwd / cb >= 0 override the forward kernel (0 / 1) and the backward lanes per system (0, 4, 16).  Initialised
+    // once from DDH_SOLVE_COOP / DDH_COOP_FWD / DDH_COOP_CB when the pack is created (not per launch);
+    // ddh_pencil_set_solve_variant changes them.
+    int coop_mode = 1, coop_fwd = -1, coop_cb = -1;
     ~PencilPack() override;
 };
 
@@ -479,10 +484,16 @@ __device__ __forceinline__ void store_sys(double *__restrict__ v, long plane, in
         double2 other;
         other.x = __shfl_xor(val.x, XD);
         other.y = __shfl_xor(val.y, XD);
-        const double2 out = (s == 0) ? make_double2(0.5 * (val.x + other.x), 0.5 * (val.y + other.y))    // cc, cs
-                                     : make_double2(0.5 * (other.y - val.y), 0.5 * (val.x - other.x));  // sc, ss
+        double2 out = (s == 0) ? make_double2(0.5 * (val.x + other.x), 0.5 * (val.y + other.y))    // cc, cs
+                               : make_double2(0.5 * (other.y - val.y), 0.5 * (val.x - other.x));  // sc, ss
+        // the msin parts of a k = 0 mode are not modes of a real field (the reference never stores them: valid-mode
+        // filtering, core/subsystems.py:540-556).  The P and Q systems of such a cell are complex conjugates solved
+        // independently, which would leave round-off there: write exact zeros.
+        if (c.my == 0) out.y = 0.0;
+        if (c.gmx == 0 && s == 1) out = make_double2(0.0, 0.0);
         if (writer) *reinterpret_cast<double2 *>(vr + (2 * c.mx + s) * P.ny + 2 * c.my) = out;
     } else if (NF == 1) {
+        if (c.gmx == 0) val.y = 0.0;
         if (writer) *reinterpret_cast<double2 *>(vr + 2 * c.mx) = val;
     } else {
         if (writer) vr[0] = val.x;
@@ -1266,7 +1277,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
     const size_t lds_f = (size_t)(d.N + d.nb) * 5 + 16, lds_b = (size_t)(d.n > 0 ? d.n : 1) * 5 + 16;
     if (lds_f > 64 * 1024) return fail("pencil_solve: system too large for the LDS permutation cache");
     // few systems: 16 lanes per system (see the cooperative kernels); DDH_SOLVE_COOP = 0 never, 2 always
-    const int coop_mode = getenv("DDH_SOLVE_COOP") ? atoi(getenv("DDH_SOLVE_COOP")) : 1;
+    const int coop_mode = pp->coop_mode;
     // forward: 16 lanes per system (needs kl < 16); backward: 16, 8 or 4 lanes per system (fewer lanes = less redundant
     // work per system, more products per lane); the choice follows the number of systems, measured on MI355X with
     // 5156-row systems: G <= 16384 -> both sweeps cooperative.  DDH_COOP_FWD / DDH_COOP_CB override (experiments).
@@ -1280,8 +1291,8 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
     int cb = 0;
     if (coop_mode == 2 || (coop_auto && P.G <= 1024)) cb = 16;
     else if (coop_auto && P.G <= 32768) cb = 4;
-    if (getenv("DDH_COOP_FWD")) use_fwd = atoi(getenv("DDH_COOP_FWD"));
-    if (getenv("DDH_COOP_CB")) cb = atoi(getenv("DDH_COOP_CB"));
+    if (pp->coop_fwd >= 0) use_fwd = pp->coop_fwd;
+    if (pp->coop_cb >= 0) cb = pp->coop_cb;
     if (NF == 0 || d.kl >= CH || d.nb > 8) use_fwd = 0;
     if (NF == 0 || (cb != 4 && cb != 16)) cb = 0;
     if (cb && (W + cb - 1) / cb > (cb == 4 ? 12 : 3)) cb = 0;
@@ -1414,7 +1425,22 @@ int ddh_pencil_create(ddh_handle *pack, const ddh_pencil_geom *geom) {
     if (st) { delete pp; return st; }
     d.kx = (const double *)pp->d_kx;
     d.ky = (const double *)pp->d_ky;
+    if (const char *e = getenv("DDH_SOLVE_COOP")) pp->coop_mode = atoi(e);
+    if (const char *e = getenv("DDH_COOP_FWD")) pp->coop_fwd = atoi(e);
+    if (const char *e = getenv("DDH_COOP_CB")) pp->coop_cb = atoi(e);
     *pack = register_handle(pp);
+    return 0;
+}
+
+int ddh_pencil_set_solve_variant(ddh_handle pack, int mode, int fwd, int backward_lanes) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (mode < 0 || mode > 2) return fail("pencil_set_solve_variant: mode must be 0, 1 or 2");
+    if (backward_lanes > 0 && backward_lanes != 4 && backward_lanes != 16)
+        return fail("pencil_set_solve_variant: backward lanes per system must be 0, 4 or 16");
+    pp->coop_mode = mode;
+    pp->coop_fwd = fwd < 0 ? -1 : (fwd ? 1 : 0);
+    pp->coop_cb = backward_lanes < 0 ? -1 : backward_lanes;
     return 0;
 }
 

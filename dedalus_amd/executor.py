@@ -185,6 +185,27 @@ class HipExecutor:
         libhip.call("ddh_grid_cfl_spherical", ptr(res), ptr(u), n_ang, nr, ptr(inv_h), ptr(inv_dr), self.dev.stream)
         return float(self.download(res)[0])
 
+    def a2a_plan(self, pcomm, n0, n1, n2, n3):
+        """Library-owned transpose plan (ddh_a2a_plan on the RCCL communicator of `pcomm`), cached per shape; None when
+        the exchange goes through torch.distributed (parallel.Comm.library_comm)."""
+        comm = pcomm.library_comm()
+        if comm is None:
+            return None
+        key = ("a2a", int(n0), int(n1), int(n2), int(n3))
+        if key not in self._plans:
+            h = C.c_uint64(0)
+            libhip.call("ddh_a2a_plan", C.byref(h), comm, int(n0), int(n1), int(n2), int(n3))
+            self._plans[key] = h
+        return self._plans[key]
+
+    def a2a_localize_rows(self, plan, cl, rl):
+        """CL [n0][n1][n2/P][n3] -> RL [n0][n1/P][n2][n3]: gathers axis 2, splits axis 1"""
+        libhip.call("ddh_a2a_localize_rows", plan, ptr(cl), ptr(rl), self.dev.stream)
+
+    def a2a_localize_columns(self, plan, rl, cl):
+        """RL [n0][n1/P][n2][n3] -> CL [n0][n1][n2/P][n3]: gathers axis 1, splits axis 2"""
+        libhip.call("ddh_a2a_localize_columns", plan, ptr(rl), ptr(cl), self.dev.stream)
+
     def a2a_pack(self, src, dst, outer, na, nb, inner, P):
         libhip.call("ddh_a2a_pack", ptr(src), ptr(dst), outer, na, nb, inner, P, self.dev.stream)
 

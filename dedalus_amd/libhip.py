@@ -91,10 +91,20 @@ SIGNATURES = {
                                C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte),
                                C.POINTER(C.c_ubyte), _i, _ip, _vp],
     "ddh_pencil_solve": [_h, _i, _vp, _vp, _vp],
+    "ddh_pencil_set_solve_variant": [_h, _i, _i, _i],
     "ddh_pencil_flagged": [_h, _i, _ip, C.POINTER(_l), _i],
     "ddh_pencil_set_dense_inverse": [_h, _i, _dp],
     "ddh_pencil_lu_bytes": [_h, _i, C.POINTER(C.c_size_t)],
     "ddh_pencil_lu_row_widths": [_h, _i, _ip],
+    "ddh_comm_unique_id": [C.POINTER(C.c_ubyte)],
+    "ddh_comm_create": [_hp, _i, _i, C.POINTER(C.c_ubyte)],
+    "ddh_comm_info": [_h, _ip, _ip],
+    "ddh_comm_allreduce": [_h, _vp, _l, _i, _vp],
+    "ddh_a2a_plan": [_hp, _h, _l, _l, _l, _l],
+    "ddh_a2a_localize_rows": [_h, _vp, _vp, _vp],
+    "ddh_a2a_localize_columns": [_h, _vp, _vp, _vp],
+    "ddh_a2a_forward": [_h, _vp, _vp, _vp],
+    "ddh_a2a_backward": [_h, _vp, _vp, _vp],
     "ddh_a2a_pack": [_vp, _vp, _l, _l, _l, _l, _i, _vp],
     "ddh_a2a_unpack": [_vp, _vp, _l, _l, _l, _l, _i, _vp],
 }

@@ -37,6 +37,31 @@ class Comm:
         self.rank = dist.get_rank()
         if self.size != size:
             raise ValueError("mesh size %d does not match the number of ranks %d" % (size, self.size))
+        self.backend = dist.get_backend()
+        self._lib_comm = None
+        self.stats = dict(exchanges=0, bytes_sent=0)      # per rank, device exchanges only (bench.py reads it)
+
+    # ---- RCCL communicator owned by libdedalus_hip (ddh_comm_*): the production exchange path on the GPUs ----------
+    def library_comm(self):
+        """ddh communicator handle spanning the same ranks, or None when the exchange has to go through
+        torch.distributed (gloo test configurations, DDH_A2A_VIA=torch).  The RCCL unique id travels from rank 0 to
+        the others through the already initialised process group."""
+        if self.backend != "nccl" or os.environ.get("DDH_A2A_VIA", "rccl") == "torch":
+            return None
+        if self._lib_comm is None:
+            import ctypes as C
+            from . import libhip
+            t = self.torch
+            buf = (C.c_ubyte * 128)()
+            if self.rank == 0:
+                libhip.call("ddh_comm_unique_id", buf)
+            ident = t.tensor(list(buf), dtype=t.uint8, device="cuda")
+            self.dist.broadcast(ident, src=0)
+            buf = (C.c_ubyte * 128)(*[int(v) for v in ident.cpu().tolist()])
+            h = C.c_uint64(0)
+            libhip.call("ddh_comm_create", C.byref(h), self.rank, self.size, buf)
+            self._lib_comm = h
+        return self._lib_comm
 
     def all_to_all(self, recv, send):
         """Equal-split all-to-all on flat buffers (torch tensors, or numpy arrays for the CPU oracle)."""

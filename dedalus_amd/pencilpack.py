@@ -191,6 +191,11 @@ class PencilPack:
     def _solve(self, lu_id, rhs, x):
         libhip.call("ddh_pencil_solve", self.handle, lu_id, ptr(rhs), ptr(x), self.dev.stream)
 
+    def set_solve_variant(self, mode=1, fwd=-1, backward_lanes=-1):
+        """Sweep variant of solve(): mode 1 by the number of systems (default), 0 one thread per system, 2 cooperative;
+        fwd (0 / 1) and backward_lanes (0 / 4 / 16) override the two sweeps individually."""
+        libhip.call("ddh_pencil_set_solve_variant", self.handle, int(mode), int(fwd), int(backward_lanes))
+
     def lu_bytes(self, lu_id):
         n = C.c_size_t(0)
         libhip.call("ddh_pencil_lu_bytes", self.handle, lu_id, C.byref(n))

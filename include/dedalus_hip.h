@@ -265,6 +265,12 @@ int ddh_pencil_factor_real(ddh_handle pack, int matM_id, int matL_id, double a, 
                            const unsigned char *row_code_h, const unsigned char *col_code_h,
                            int reuse_lu_id, int *lu_id, void *stream);
 int ddh_pencil_solve(ddh_handle pack, int lu_id, const double *rhs, double *x, void *stream);
+/* Sweep variant used by ddh_pencil_solve (all variants compute the same factorization's solution; they differ in how
+ * many lanes share one system).  mode 1 (default): chosen by the number of systems; 0: one
+ * thread per system; 2: cooperative (16 lanes) in both sweeps.  fwd = 0 / 1 and backward_lanes = 0 / 4 / 16 override
+ * the forward and backward kernel individually, -1 leaves the choice to `mode`.  The defaults can also be preset with
+ * the environment variables DDH_SOLVE_COOP / DDH_COOP_FWD / DDH_COOP_CB, which are read ONCE, by ddh_pencil_create. */
+int ddh_pencil_set_solve_variant(ddh_handle pack, int mode, int fwd, int backward_lanes);
 /* Pencils whose band block is singular (e.g. the kx=ky=0 pressure-gauge pencil) are flagged by
  * ddh_pencil_factor and solved with an explicit dense inverse the host supplies: query the flagged
  * cell ids, then upload inverses in logical (permuted) ordering, complex row-major N x N per
@@ -276,12 +282,39 @@ int ddh_pencil_lu_bytes(ddh_handle pack, int lu_id, size_t *bytes);
  * how much of the partial-pivoting fill space (kl extra super-diagonals, LAPACK gbtrf storage) is really used.  */
 int ddh_pencil_lu_row_widths(ddh_handle pack, int lu_id, int *wrow_h);
 
-/* ---- distributed transposes ----------------------------------------------- */
-/* Local pack / unpack for the all-to-all that replaces FFTWTranspose / AlltoallvTranspose
- * (core/transposes.pyx:22-445).  The exchange itself is issued by the host through RCCL
- * (torch.distributed all_to_all_single on the packed buffers).
- * Splits axis `a` (length na) of [outer][na][nb][inner] into P blocks of `blk` and writes
- * [P][outer][blk][nb][inner] (pack) or the inverse gathers along nb (unpack).                     */
+/* ---- distributed transposes (boundary B3) ------------------------------------ */
+/* Communicator: one process per GPU, RCCL over xGMI, owned by the library (replaces the mpi4py communicator the
+ * reference plans its transposes on, core/distributor.py:696-768).  Rank 0 obtains an id and hands it to the other
+ * ranks through any out-of-band channel (the launcher's store, a file, MPI_Bcast); then every rank calls
+ * ddh_comm_create, collectively.  RCCL is bound at run time (librccl.so.1).  Destroy plans before their communicator. */
+#define DDH_COMM_ID_BYTES 128
+int ddh_comm_unique_id(unsigned char *id_h);                       /* DDH_COMM_ID_BYTES bytes */
+int ddh_comm_create(ddh_handle *comm, int rank, int nranks, const unsigned char *id_h);
+int ddh_comm_info(ddh_handle comm, int *rank, int *nranks);
+/* in-place all-reduce of `count` doubles: op 0 sum, 1 max, 2 min (the MPI Allreduce of GlobalArrayReducer,
+ * extras/flow_tools.py:9-47, and of the CFL frequency) */
+int ddh_comm_allreduce(ddh_handle comm, double *buf, long count, int op, void *stream);
+
+/* Transpose plan = FFTWTranspose / AlltoallvTranspose (core/transposes.pyx:22-445, planner interface
+ * core/distributor.py:696-768): (n0, n1, n2, n3) is the reference's reduced GLOBAL shape (N0, N1, N2, N3) around the
+ * transposed axis pair (axis, axis + 1); both transposed axes must be divisible by the number of ranks (equal
+ * blocks).  Local layouts, C order:
+ *     column-local CL [n0][n1][n2 / P][n3]      row-local RL [n0][n1 / P][n2][n3]
+ * ddh_a2a_localize_rows(plan, CL, RL)     = plan.localize_rows(CL, RL)     (:248-256; Transpose.decrement, forward)
+ * ddh_a2a_localize_columns(plan, RL, CL)  = plan.localize_columns(RL, CL)  (:258-266; Transpose.increment, backward)
+ * ddh_a2a_forward / ddh_a2a_backward are the same two calls under the transform-direction names.
+ * Each is pack kernel -> grouped ncclSend/ncclRecv to every peer -> unpack kernel, asynchronous on `stream`; source
+ * and destination must be different buffers (the reference's CL/RL views alias one FFTW buffer and are transposed
+ * through an internal copy; here the plan owns the two staging buffers). */
+int ddh_a2a_plan(ddh_handle *plan, ddh_handle comm, long n0, long n1, long n2, long n3);
+int ddh_a2a_localize_rows(ddh_handle plan, const double *cl, double *rl, void *stream);
+int ddh_a2a_localize_columns(ddh_handle plan, const double *rl, double *cl, void *stream);
+int ddh_a2a_forward(ddh_handle plan, const double *cl, double *rl, void *stream);
+int ddh_a2a_backward(ddh_handle plan, const double *rl, double *cl, void *stream);
+/* The two local re-ordering kernels of a transpose on their own (split_rows / split_columns and their inverses,
+ * core/transposes.pyx:359-445), for callers that issue the exchange themselves (e.g. torch.distributed):
+ * pack splits axis `a` (length na) of [outer][na][nb][inner] into P blocks and writes [P][outer][na/P][nb][inner];
+ * unpack reads [P][outer][na][nb/P][inner] and gathers along nb into [outer][na][nb][inner].                    */
 int ddh_a2a_pack(const double *src, double *dst, long outer, long na, long nb, long inner,
                  int nparts, void *stream);
 int ddh_a2a_unpack(const double *src, double *dst, long outer, long na, long nb, long inner,

@@ -221,6 +221,62 @@ def golden_ivp():
     print("wrote ivp.npz")
 
 
+def golden_pencils():
+    """The reference's OWN pencil matrices (Subproblem.build_matrices, core/subsystems.py:497-596: M_min, L_min and
+    the pre_left / pre_right_pinv selections) of the 3-D Rayleigh-Benard problem at the BASELINE coupled size Nz = 256
+    for a 4 x 4 sample of wavenumber pairs of the 512 x 512 x 256 problem.  The matrices depend on (kx, ky, Nz) only,
+    so a small reference problem with Lx = Ly = 4/STRIDE has exactly the pencils (STRIDE gx, STRIDE gy), g = 0..3, of
+    the full problem (Lx = Ly = 4): modes 0, 85, 170, 255 on either axis, including kx = 0, ky = 0 and (0, 0).
+    Also the end states of two larger runs the per-thread solve kernels are tested on."""
+    d3 = refshim.load_reference()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import problems
+    out = {}
+    STRIDE, Nz = 85, 256
+    solver, f = problems.rayleigh_benard_3d(d3, Nx=8, Ny=8, Nz=Nz, Lx=4 / STRIDE, Ly=4 / STRIDE)
+    out["stride"] = np.array([STRIDE, Nz])
+    out["variables"] = np.array([v.name for v in solver.problem.variables])
+    groups = []
+    for sp in solver.subproblems:
+        gx, gy = int(sp.group[0]), int(sp.group[1])
+        tag = "g%d_%d__" % (gx, gy)
+        groups.append((gx, gy))
+        for name in ("M_min", "L_min"):
+            m = getattr(sp, name).tocsr()
+            m.sort_indices()
+            out[tag + name + "_indptr"] = m.indptr.astype(np.int32)
+            out[tag + name + "_indices"] = m.indices.astype(np.int32)
+            out[tag + name + "_data"] = np.asarray(m.data, dtype=np.float64)
+        for name in ("pre_left", "pre_right_pinv"):
+            m = getattr(sp, name).tocsr()
+            assert np.all(m.data == 1.0) and np.all(np.diff(m.indptr) == 1)      # pure selections / permutations
+            out[tag + name + "_cols"] = m.indices.astype(np.int32)
+            out[tag + name + "_ncols"] = np.array(m.shape[1])
+        out[tag + "var_sizes"] = np.array([sp.field_size(v) for v in solver.problem.variables])
+        out[tag + "eq_sizes"] = np.array([sp.field_size(eq["F"]) for eq in solver.problem.equations])
+    out["groups"] = np.array(groups)
+    np.savez_compressed(os.path.join(GOLD, "pencils_nz256.npz"), **out)
+    print("wrote pencils_nz256.npz:", len(groups), "pencils,", os.path.getsize(os.path.join(GOLD, "pencils_nz256.npz")) >> 10, "KiB")
+    # end states at sizes that reach other solve variants (3-D 32^3: 256 cells; 2-D 512 x 256: the BASELINE config 2)
+    big = {}
+    solver, f = problems.rayleigh_benard_3d(d3, Nx=32, Ny=32, Nz=32, timestepper="RK222")
+    for _ in range(5):
+        solver.step(1e-3)
+    for k in ("p", "b", "u"):
+        big["rb3d_32__" + k] = np.array(f[k]["c"])
+    print("rb3d 32^3 |b_c| =", repr(float(np.linalg.norm(big["rb3d_32__b"]))))
+    solver, f = problems.rayleigh_benard_2d(d3, Nx=512, Nz=256, timestepper="RK222")
+    for _ in range(13):
+        solver.step(1e-3)
+    for k in ("p", "b", "u"):
+        a = np.array(f[k]["c"])
+        big["rb2d_512x256__" + k] = a[..., ::8, :]                 # every 8th x mode, all z modes
+        big["rb2d_512x256__" + k + "_norm"] = np.array(np.linalg.norm(a))
+    print("rb2d 512x256 |b_c| =", repr(float(big["rb2d_512x256__b_norm"])))
+    np.savez_compressed(os.path.join(GOLD, "ivp_large.npz"), **big)
+    print("wrote ivp_large.npz", os.path.getsize(os.path.join(GOLD, "ivp_large.npz")) >> 10, "KiB")
+
+
 def golden_sphere():
     """The reference's sphere operators and shallow-water example on the shared scripts (tests/problems.py):
     operator results for seeded fields, the packed coefficient layout maps, and the end state of the

@@ -25,6 +25,14 @@ class TermList:
         self.dx = np.asarray(dx, dtype=np.int8)
         self.dy = np.asarray(dy, dtype=np.int8)
 
+    def cached_matrix(self, kx, ky, mx, my, sign=1):
+        """The reference builds every subproblem's matrices once and keeps them (core/subsystems.py:497-596)."""
+        cache = self.__dict__.setdefault("_cache", {})
+        key = (float(kx), float(ky), int(mx), int(my), int(sign))
+        if key not in cache:
+            cache[key] = self.matrix(kx, ky, mx, my, sign)
+        return cache[key]
+
     def matrix(self, kx, ky, mx, my, sign=1):
         """scipy CSR complex matrix of one system: sign=+1 -> (kx, ky), sign=-1 -> (-kx, ky)."""
         val = self.coef * (sign * kx) ** self.ex.astype(float) * ky ** self.ey.astype(float)
@@ -77,7 +85,7 @@ def matvec(A, x, nf, kx, ky, mx_offset=0):
         xs = cell_to_systems(x, nf, mx, my)
         kxv = kx[mx] if nf >= 1 else 0.0
         kyv = ky[my] if nf == 2 else 0.0
-        ys = [A.matrix(kxv, kyv, mx + mx_offset, my, sign=(1 if s == 0 else -1)) @ xs[s] for s in range(len(xs))]
+        ys = [A.cached_matrix(kxv, kyv, mx + mx_offset, my, sign=(1 if s == 0 else -1)) @ xs[s] for s in range(len(xs))]
         systems_to_cell(y, ys, nf, mx, my)
     return y
 

@@ -17,13 +17,18 @@ def main():
     case, outdir = sys.argv[1], sys.argv[2]
     use_hip = len(sys.argv) > 3 and sys.argv[3] == "hip"
     import torch.distributed as dist
-    dist.init_process_group("gloo")
+    backend = os.environ.get("DDH_DIST_BACKEND", "gloo") if use_hip else "gloo"
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))        # one GPU per rank, RCCL exchanges
+    dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     import problems
     import dedalus_amd.public as d3
     if use_hip:
-        # all ranks share GPU 0 (RCCL needs one GPU per rank; the exchange is staged through the host)
-        os.environ["LOCAL_RANK"] = "0"
+        if backend != "nccl":
+            # all ranks share GPU 0 (RCCL needs one GPU per rank; the exchange is staged through the host)
+            os.environ["LOCAL_RANK"] = "0"
         dist_kw = dict(mesh=(world,))
     else:
         from oracle.np_executor import NumpyExecutor

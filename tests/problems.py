@@ -61,8 +61,8 @@ def rayleigh_benard_2d(d3, Nx=32, Nz=16, timestepper="RK222", dist_kw=None):
     return solver, dict(p=p, b=b, u=u, tau_b1=tau_b1, tau_b2=tau_b2, tau_u1=tau_u1, tau_u2=tau_u2)
 
 
-def rayleigh_benard_3d(d3, Nx=8, Ny=12, Nz=8, timestepper="RK222", dist_kw=None):
-    Lx, Ly, Lz = 4, 4, 1
+def rayleigh_benard_3d(d3, Nx=8, Ny=12, Nz=8, timestepper="RK222", dist_kw=None, Lx=4, Ly=4):
+    Lz = 1
     Rayleigh, Prandtl, dealias = 2e6, 1, 3 / 2
     coords = d3.CartesianCoordinates('x', 'y', 'z')
     dist = d3.Distributor(coords, dtype=np.float64, **(dist_kw or {}))

@@ -103,12 +103,9 @@ def bandwidth(tlists, perm, n):
 @pytest.mark.parametrize("nf,ncx,ncy", [(2, 6, 10), (1, 40, 1), (0, 1, 1)])
 @pytest.mark.parametrize("gauge", [False, True])
 @pytest.mark.parametrize("coop", [0, 2, 4])
-def test_matvec_factor_solve_vs_oracle(nf, ncx, ncy, gauge, coop, monkeypatch):
+def test_matvec_factor_solve_vs_oracle(nf, ncx, ncy, gauge, coop):
     # coop = 2: the cooperative sweeps (16 lanes per system, used for few systems); 0: one thread per system;
     # 4: one thread per system forward, 4 lanes per system backward (the mid-range choice)
-    monkeypatch.setenv("DDH_SOLVE_COOP", "0" if coop == 4 else str(coop))
-    if coop == 4:
-        monkeypatch.setenv("DDH_COOP_CB", "4")
     from dedalus_amd.device import Device
     from dedalus_amd.pencilpack import PencilPack, TermList
     from oracle import np_pencil as npp
@@ -127,6 +124,7 @@ def test_matvec_factor_solve_vs_oracle(nf, ncx, ncy, gauge, coop, monkeypatch):
     Mo = npp.TermList(N, N, M.row, M.col, M.coef, M.ex, M.ey, M.dx, M.dy)
     Lo = npp.TermList(N, N, L.row, L.col, L.coef, L.ex, L.ey, L.dx, L.dy)
     pack = PencilPack(dev, nf, N, nx, ny, kx, ky)
+    pack.set_solve_variant(0 if coop == 4 else coop, -1, 4 if coop == 4 else -1)
     idM, idL = pack.add_matrix(M), pack.add_matrix(L)
     # random data obeying the real-Fourier structure (msin parts of m=0 vanish)
     x = rng.standard_normal((N, nx, ny))
