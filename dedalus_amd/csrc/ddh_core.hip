@@ -37,6 +37,26 @@ HandleBase *lookup_handle(ddh_handle h, HandleKind kind) {
     return it->second;
 }
 
+static void *g_alias_buf = nullptr;
+static size_t g_alias_cap = 0;
+
+int resolve_alias(const double **in, const double *out, size_t in_elems, size_t out_elems, hipStream_t s) {
+    const char *a0 = (const char *)*in, *a1 = a0 + in_elems * sizeof(double);
+    const char *b0 = (const char *)out, *b1 = b0 + out_elems * sizeof(double);
+    if (a1 <= b0 || b1 <= a0) return 0;
+    const size_t bytes = in_elems * sizeof(double);
+    if (bytes > g_alias_cap) {
+        if (g_alias_buf) DDH_HIP(hipFree(g_alias_buf));       // hipFree waits for work that may still read it
+        g_alias_buf = nullptr;
+        g_alias_cap = 0;
+        DDH_HIP(hipMalloc(&g_alias_buf, bytes + 256));
+        g_alias_cap = bytes;
+    }
+    DDH_HIP(hipMemcpyAsync(g_alias_buf, *in, bytes, hipMemcpyDeviceToDevice, s));
+    *in = (const double *)g_alias_buf;
+    return 0;
+}
+
 }  // namespace ddh
 
 using namespace ddh;

@@ -1178,7 +1178,13 @@ int ddh_plan_cheb(ddh_handle *plan, int n_grid, int n_coeff, int nbands, const i
         FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);                                          \
         if (!pl) return -1;                                                                           \
         if (pl->tkind != KIND) return fail(#name ": plan is of a different transform kind");           \
-        if ((const void *)a == (const void *)b) return fail(#name ": in-place transforms unsupported"); \
+        if (outer <= 0 || inner <= 0) return 0;                                                       \
+        {                                                                                             \
+            const size_t cx = (KIND == K_CFFT) ? 2 : 1;                                               \
+            const bool fwd = (MODE == RFFT_FWD || MODE == CHEB_FWD || MODE == CFFT_FWD);              \
+            const size_t ng = (size_t)pl->dev.N * outer * inner * cx, nc = (size_t)pl->dev.M * outer * inner * cx; \
+            if (int st0 = resolve_alias(&a, b, fwd ? ng : nc, fwd ? nc : ng, as_stream(stream))) return st0; \
+        }                                                                                             \
         return launch<MODE>(pl, a, b, outer, inner, stream);                                          \
     }
 
@@ -1189,7 +1195,10 @@ int ddh_rfft_backward_deriv(ddh_handle plan, const double *c, double *g, long ou
     FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
     if (!pl) return -1;
     if (pl->tkind != K_RFFT) return fail("ddh_rfft_backward_deriv: plan is of a different transform kind");
-    if ((const void *)c == (const void *)g) return fail("ddh_rfft_backward_deriv: in-place transforms unsupported");
+    if (outer <= 0 || inner <= 0) return 0;
+    if (int st0 = resolve_alias(&c, g, (size_t)pl->dev.M * outer * inner, (size_t)pl->dev.N * outer * inner,
+                                as_stream(stream)))
+        return st0;
     return launch<RFFT_BWD>(pl, c, g, outer, inner, stream, dscale);
 }
 DDH_FFT_ENTRY(ddh_cheb_forward, K_CHEB, CHEB_FWD)
@@ -1309,8 +1318,10 @@ int ddh_plan_mmt(ddh_handle *plan, int n_out, int n_in, const double *mat_h) {
 int ddh_mmt_apply(ddh_handle plan, const double *in, double *out, long outer, long inner, void *stream) {
     MmtPlan *pl = (MmtPlan *)lookup_handle(plan, H_MMT);
     if (!pl) return -1;
-    if (in == out) return fail("ddh_mmt_apply: in-place unsupported");
     if (outer <= 0 || inner <= 0) return 0;
+    if (int st0 = resolve_alias(&in, out, (size_t)pl->n_in * outer * inner, (size_t)pl->n_out * outer * inner,
+                                as_stream(stream)))
+        return st0;
     dim3 grid((unsigned)((inner + MT_X - 1) / MT_X), (unsigned)((pl->n_out + MT_I - 1) / MT_I), (unsigned)outer);
     if (outer > 65535) return fail("ddh_mmt_apply: outer too large");
     hipLaunchKernelGGL(mmt_kernel, grid, dim3(256), 0, as_stream(stream), pl->d_mat, in, out, pl->n_out, pl->n_in,

@@ -25,8 +25,6 @@
 
 namespace ddh {
 
-constexpr HandleKind H_STERMS = (HandleKind)5;
-constexpr HandleKind H_CGEMV = (HandleKind)6;
 
 // ------------------------------------------------------------------------------------------------
 struct SpinMat {
@@ -168,7 +166,6 @@ cgemv_batch_kernel(const double *__restrict__ x, double *__restrict__ y, const l
 // This is SphericalEllOperator.operate / subproblem_matrix (core/operators.py:3108-3222: per (m, ell)
 // apply_matrix of a radial matrix in a Python loop over ell_maps) for all slots in one launch, and -- with
 // the per-ell LHS inverses as the matrices -- the per-ell solve of the shell's subproblems.
-constexpr HandleKind H_ELLT = (HandleKind)7;
 
 struct EllTerms : HandleBase {
     int nm = 0, nl = 0, nr = 0, ncomp_out = 0, nterms = 0, nmat = 0;
@@ -370,7 +367,9 @@ extern "C" {
 int ddh_spin_recombine(const double *in, double *out, int ncomp, long npairs, long inner, const double *mat_h,
                        void *stream) {
     if (npairs <= 0 || inner <= 0) return 0;
-    if (in == out) return fail("ddh_spin_recombine: in-place unsupported");
+    if (int st0 = resolve_alias(&in, out, (size_t)(2 * ncomp) * npairs * inner, (size_t)(2 * ncomp) * npairs * inner,
+                                as_stream(stream)))
+        return st0;
     if (ncomp != 1 && ncomp != 2 && ncomp != 4 && ncomp != 3 && ncomp != 9)
         return fail("ddh_spin_recombine: 1, 2, 4 (rank 0-2 on S2) or 3, 9 (rank 1-2 in spherical coordinates) components");
     SpinMat M;

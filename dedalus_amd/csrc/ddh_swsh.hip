@@ -226,7 +226,10 @@ template <bool FWD>
 static int launch_grouped(GmmtPlan *pl, const double *in, double *out, long n0, long n1g, long n1c, long n2c, long n3,
                           void *stream) {
     if (n0 <= 0 || n3 <= 0 || pl->ngroups == 0) return 0;
-    if (in == out) return fail("grouped_mmt: in-place unsupported");
+    {
+        const size_t ng = (size_t)n0 * n1g * pl->n_grid * n3, nc = (size_t)n0 * n1c * n2c * n3;
+        if (int st0 = resolve_alias(&in, out, FWD ? ng : nc, FWD ? nc : ng, as_stream(stream))) return st0;
+    }
     if (pl->max_g_end > n1g || pl->max_c_end > n1c || pl->max_l_end > n2c)
         return fail("grouped_mmt: a group's slices exceed the array extents");
     GmmtDims d{n0, n1g, n1c, n2c, n3, pl->n_grid};

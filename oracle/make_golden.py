@@ -96,6 +96,53 @@ def golden_transforms():
     print("wrote transforms.npz with", len(out), "arrays")
 
 
+def golden_transforms_extra():
+    """Cases the boundary classes (dedalus_amd/bindings.py) add to the transform set: forward Chebyshev transforms with
+    dealias_before_converting=False (conversion before truncation, core/transforms.py:833-842, 862-874) from both the
+    fast and the matrix plan of the reference, and JacobiMMT on non-Chebyshev grids (Legendre a0 = b0 = 0)."""
+    refshim.load_reference()
+    from dedalus.core import transforms as T
+    rng = np.random.default_rng(4321)
+    out = {}
+    cases = []
+    for alpha in (1, 2):
+        for (N, M) in [(24, 16), (18, 12), (12, 12)]:
+            for axis, shape in [(0, (N, 5)), (1, (3, N, 4))]:
+                a = b = alpha - 0.5
+                fast = T.FFTWFastChebyshevTransform(N, M, a, b, -0.5, -0.5, dealias_before_converting=False)
+                mmt = T.JacobiMMT(N, M, a, b, -0.5, -0.5, dealias_before_converting=False)
+                g = rng.standard_normal(shape)
+                cshape = list(shape)
+                cshape[axis] = M
+                c, c_m = np.zeros(cshape), np.zeros(cshape)
+                fast.forward(g.copy(), c, axis)
+                mmt.forward(g.copy(), c_m, axis)
+                cin = rng.standard_normal(cshape)
+                gb = np.zeros(shape)
+                fast.backward(cin.copy(), gb, axis)
+                key = "nd_%d_%d_%d_%d" % (alpha, N, M, axis)
+                cases.append(key)
+                out[key + "_g"], out[key + "_c"], out[key + "_c_mmt"], out[key + "_cin"], out[key + "_gb"] = g, c, c_m, cin, gb
+    out["nd_cases"] = np.array(cases)
+    cases = []
+    for (a0, b0, a, b) in [(0.0, 0.0, 0.0, 0.0), (0.0, 0.0, 1.0, 1.0), (0.5, -0.5, 1.5, 0.5)]:
+        for (N, M) in [(18, 12), (12, 12), (8, 12)]:
+            mmt = T.JacobiMMT(N, M, a, b, a0, b0)
+            g = rng.standard_normal((3, N, 4))
+            c = np.zeros((3, M, 4))
+            mmt.forward(g.copy(), c, 1)
+            cin = rng.standard_normal((3, M, 4))
+            gb = np.zeros((3, N, 4))
+            mmt.backward(cin.copy(), gb, 1)
+            key = "jac_%g_%g_%g_%g_%d_%d" % (a0, b0, a, b, N, M)
+            cases.append(key)
+            out[key + "_g"], out[key + "_c"], out[key + "_cin"], out[key + "_gb"] = g, c, cin, gb
+            out[key + "_par"] = np.array([a0, b0, a, b, N, M])
+    out["jac_cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(GOLD, "transforms_extra.npz"), **out)
+    print("wrote transforms_extra.npz with", len(out), "arrays")
+
+
 def golden_swsh():
     """SWSHColatitudeTransform of the reference (core/transforms.py:1251-1340) on seeded data: the m_maps of
     real-dtype SphereBases, its matrices for a few (m, s), and forward / backward outputs."""
