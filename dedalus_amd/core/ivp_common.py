@@ -1,0 +1,136 @@
+"""
+Life cycle shared by the three initial-value solvers (Cartesian pencils, sphere, shell): the reference has ONE
+InitialValueSolver (core/solvers.py:503-806) and its stop conditions, clocks, step bookkeeping, Hermitian-symmetry
+schedule, evolve loop and statistics apply to every geometry alike.
+
+Clocks are WORLD clocks: on several ranks rank 0's time is broadcast (core/solvers.py:603-611), so every rank takes
+the same stop / wall_dt-schedule decision and the collectives inside a step (transposes, gathered output) always
+match up.
+"""
+
+import logging
+import time
+
+import numpy as np
+
+logger = logging.getLogger("solvers")
+
+
+class IVPLifecycle:
+    enforce_real_cadence = 100
+    warmup_iterations = 10
+
+    def _init_lifecycle(self, enforce_real_cadence=100, warmup_iterations=10):
+        self.iteration = self.initial_iteration = 0
+        self.stop_sim_time = np.inf
+        self.stop_wall_time = np.inf
+        self.stop_iteration = np.inf
+        self.enforce_real_cadence = enforce_real_cadence
+        self.warmup_iterations = warmup_iterations
+        self.dt = None
+        self.init_time = self.start_time = self.world_time          # (start_time: older name, kept for scripts)
+        self.warmup_time = None
+        self.run_time_start = None
+
+    # ---- clocks ------------------------------------------------------------------------------------------------
+    @property
+    def world_time(self):
+        """core/solvers.py:603-611: root's clock on every rank"""
+        t = time.time()
+        pcomm = getattr(self.dist, "pcomm", None)
+        if pcomm is not None and getattr(self.dist, "size", 1) > 1:
+            t = pcomm.bcast_float(t)
+        return t
+
+    @property
+    def wall_time(self):
+        """Seconds elapsed since instantiation (core/solvers.py:613-616)."""
+        return self.world_time - self.init_time
+
+    # ---- stop conditions -----------------------------------------------------------------------------------------
+    @property
+    def proceed(self):
+        """core/solvers.py:618-630"""
+        if self.sim_time >= self.stop_sim_time:
+            logger.info("Simulation stop time reached.")
+            return False
+        if self.wall_time >= self.stop_wall_time:
+            logger.info("Wall stop time reached.")
+            return False
+        if self.iteration >= self.stop_iteration:
+            logger.info("Stop iteration reached.")
+            return False
+        return True
+
+    # ---- one step --------------------------------------------------------------------------------------------------
+    def step(self, dt):
+        """Advance one timestep (core/solvers.py:683-711)."""
+        if not np.isfinite(dt):
+            raise ValueError("Invalid timestep")
+        wall_time = self.wall_time
+        if self.iteration == self.initial_iteration + self.warmup_iterations:
+            self.ex.sync()
+            self.warmup_time = self.world_time
+            self.run_time_start = wall_time
+        if self.dt is None:
+            self.dt = dt
+        # scheduled analysis sees the pre-step state (the reference's timesteppers call evaluate_scheduled first,
+        # core/timesteppers.py:137-139, 578-580), with the same world wall time on every rank
+        self._step_wall_time = wall_time
+        for hook in self._step_hooks:
+            hook(self)
+        self.timestepper.step(dt, wall_time)
+        # Hermitian symmetry for real variables: for as many iterations as the scheme uses internally, every cadence
+        # (core/solvers.py:704-708) -- checked BEFORE the iteration count is advanced, so the first step takes part
+        if self.enforce_real_cadence and self.iteration % self.enforce_real_cadence < self.timestepper.steps:
+            self.enforce_hermitian_symmetry(self.state)
+        self.iteration += 1
+        self.dt = dt
+
+    def enforce_hermitian_symmetry(self, fields):
+        """Grid and back at the dealias scales (core/solvers.py:675-681)."""
+        for f in fields:
+            self._hermitian_round_trip(f)
+
+    def _hermitian_round_trip(self, f):
+        raise NotImplementedError
+
+    # ---- main loop ---------------------------------------------------------------------------------------------------
+    def evolve(self, timestep_function, log_cadence=100):
+        """core/solvers.py:713-735"""
+        if np.isinf(self.stop_sim_time) and np.isinf(self.stop_wall_time) and np.isinf(self.stop_iteration):
+            raise ValueError("No stopping criterion specified.")
+        try:
+            logger.info("Starting main loop")
+            while self.proceed:
+                timestep = timestep_function()
+                self.step(timestep)
+                if (self.iteration - 1) % log_cadence == 0:
+                    logger.info("Iteration=%i, Time=%e, Step=%e" % (self.iteration, self.sim_time, timestep))
+        except Exception:
+            logger.error("Exception raised, triggering end of main loop.")
+            raise
+        finally:
+            self.log_stats()
+
+    def log_stats(self, format=".4g"):
+        """core/solvers.py:755-778: setup / warm-up / run time and mode-stages per (device-)second."""
+        self.ex.sync()
+        end = self.world_time
+        logger.info("Final iteration: %i" % self.iteration)
+        logger.info("Final sim time: %s" % self.sim_time)
+        logger.info("Setup time (init - iter 0): %.4g sec" % getattr(self, "setup_time", 0.0))
+        if self.warmup_time is not None:
+            run = end - self.warmup_time
+            its = self.iteration - self.initial_iteration - self.warmup_iterations
+            stages = its * self.timestepper.stages
+            logger.info("Run time (iter %d-end): %.4g sec" % (self.warmup_iterations, run))
+            if run > 0:
+                logger.info("Speed: %.4g mode-stages/gpu-sec" % (self.total_modes * stages / run))
+        else:
+            logger.info("Timings unavailable because warmup did not complete.")
+
+    def load_state(self, path, index=-1, allow_missing=False):
+        """core/solvers.py:632-673"""
+        from .output import load_state
+        return load_state(self, path, index=index, allow_missing=allow_missing)

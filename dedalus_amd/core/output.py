@@ -331,7 +331,10 @@ class OutputEvaluator:
     def step_hook(self, solver):
         if not self.handlers:
             return
-        self.evaluate_scheduled(iteration=int(solver.iteration), wall_time=time.time() - solver.start_time,
+        wall = getattr(solver, "_step_wall_time", None)           # the world clock of this step (same on every rank)
+        if wall is None:
+            wall = time.time() - solver.start_time
+        self.evaluate_scheduled(iteration=int(solver.iteration), wall_time=wall,
                                 sim_time=float(solver.sim_time), timestep=float(solver.dt))
 
 

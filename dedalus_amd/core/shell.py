@@ -24,6 +24,7 @@ from ..tools import sphere as sph
 from . import curvilinear
 from .basis import Jacobi
 from .coords import Coordinate
+from .ivp_common import IVPLifecycle
 from .sphere import S2Coordinates, SphereBasis
 
 
@@ -1829,32 +1830,35 @@ class ShellBoundaryValueSolver(ShellSolverBase):
         self.mark_state_current()
 
 
-class ShellInitialValueSolver(ShellSolverBase):
-    """IMEX timestepping of M.dt(X) + L.X = F in a shell with the shared schemes of core/timesteppers.py."""
+class ShellInitialValueSolver(IVPLifecycle, ShellSolverBase):
+    """IMEX timestepping of M.dt(X) + L.X = F in a shell with the shared schemes of core/timesteppers.py and the shared
+    life cycle of core/ivp_common.py::IVPLifecycle (stop conditions incl. stop_wall_time, world clocks, evolve)."""
 
-    def __init__(self, problem, timestepper, **kw):
-        super().__init__(problem)
+    def __init__(self, problem, timestepper, enforce_real_cadence=100, warmup_iterations=10, **kw):
+        t0 = _time.time()
+        ShellSolverBase.__init__(self, problem)
         from . import timesteppers as ts
         from .output import OutputEvaluator
         if isinstance(timestepper, str):
             timestepper = ts.schemes[timestepper]
         self.sim_time = self.initial_sim_time = 0.0
-        self.iteration = self.initial_iteration = 0
-        self.stop_sim_time = self.stop_wall_time = np.inf
-        self.stop_iteration = np.inf
-        self.dt = None
+        self._init_lifecycle(enforce_real_cadence, warmup_iterations)
         self._lus = []
         self.timestepper = timestepper(self)
-        self.start_time = _time.time()
-        self.warmup_iterations, self.warmup_time = 10, None
+        self.setup_time = _time.time() - t0
         self.evaluator = OutputEvaluator(self)       # analysis handlers: evaluated at the start of a step
         self._step_hooks = [self.evaluator.step_hook]
         self.total_modes = int(self.col_valid.sum()) * 2 * self.nm
 
-    def load_state(self, path, index=-1, allow_missing=False):
-        """core/solvers.py:632-673"""
-        from .output import load_state
-        return load_state(self, path, index=index, allow_missing=allow_missing)
+    @property
+    def state(self):
+        return self.variables
+
+    def _hermitian_round_trip(self, f):
+        """the state makes a round trip through the dealiased grid (core/solvers.py:675-681)"""
+        if isinstance(f, ShellField):
+            f.require_grid_space(f.basis.dealias)
+            f.require_coeff_space()
 
     def factor(self, a, b, reuse=-1):
         inv = self._inverse_terms(a, b)
@@ -1867,42 +1871,6 @@ class ShellInitialValueSolver(ShellSolverBase):
     def solve(self, lu, rhs, x):
         self._lus[lu].apply(rhs, x)
 
-    def step(self, dt):
-        if not np.isfinite(dt):
-            raise ValueError("Invalid timestep: %r" % dt)
-        self.dt = dt
-        if self.iteration == self.initial_iteration + self.warmup_iterations:
-            self.ex.sync()
-            self.warmup_time = _time.time()
-        for hook in self._step_hooks:        # scheduled analysis (CFL frequencies) sees the pre-step state
-            hook(self)
-        self.timestepper.step(dt, 0.0)
-        # Hermitian-symmetry enforcement of the reference (core/solvers.py:675-681, 704-708): the state makes a round
-        # trip through the dealiased grid during the first `steps` iterations of every cadence
-        if self.enforce_real_cadence and self.iteration % self.enforce_real_cadence < self.timestepper.steps:
-            for v in self.variables:
-                if isinstance(v, ShellField):
-                    v.require_grid_space(v.basis.dealias)
-                    v.require_coeff_space()
-        self.iteration += 1
-
-    enforce_real_cadence = 100
-
-    @property
-    def proceed(self):
-        return self.sim_time < self.stop_sim_time and self.iteration < self.stop_iteration
-
-    def log_stats(self, format=".4g"):
-        """core/solvers.py:755-778"""
-        self.ex.sync()
-        logger.info("Final iteration: %i" % self.iteration)
-        logger.info("Final sim time: %s" % self.sim_time)
-        if self.warmup_time is not None:
-            run = _time.time() - self.warmup_time
-            its = self.iteration - self.initial_iteration - self.warmup_iterations
-            logger.info("Run time (iter %d-end): %.4g sec" % (self.warmup_iterations, run))
-            if run > 0:
-                logger.info("Speed: %.4g mode-stages/gpu-sec" % (self.total_modes * its * self.timestepper.stages / run))
 
 
 # ==================================================================================================

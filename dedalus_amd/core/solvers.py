@@ -19,6 +19,7 @@ from . import operators as ops
 from . import timesteppers as ts_mod
 from .evaluator import Evaluator, SystemBuffer, _full_sep
 from .field import Field
+from .ivp_common import IVPLifecycle
 from .polyop import flatten
 from .problems import LinCtx
 
@@ -545,7 +546,9 @@ def _two_colour(n, row, col, label):
 
 
 def _termlist_times_matrix(tl, P, cutoff=1e-12):
-    """(term list) @ (constant sparse matrix): same monomials, columns mixed by P."""
+    """(term list) @ (constant sparse matrix): same monomials, columns mixed by P.  Entries below `cutoff` RELATIVE to
+    the largest entry of their monomial block are cancellation residue of the recombination and are dropped (an
+    absolute threshold would also remove genuine entries of problems with tiny physical coefficients)."""
     from scipy import sparse
     from ..pencilpack import TermList
     if tl.nterms == 0:
@@ -558,7 +561,7 @@ def _termlist_times_matrix(tl, P, cutoff=1e-12):
         sel = inv == u
         A = sparse.coo_matrix((tl.coef[sel], (tl.row[sel], tl.col[sel])), shape=(tl.nrows, tl.ncols)).tocsr()
         AP = (A @ P).tocoo()
-        keep = np.abs(AP.data) > cutoff
+        keep = np.abs(AP.data) > cutoff * (np.abs(AP.data).max() if AP.nnz else 1.0)
         rows.append(AP.row[keep]); cols.append(AP.col[keep]); coefs.append(AP.data[keep])
         exs.append(np.tile(uniq[u], (int(keep.sum()), 1)))
     e = np.concatenate(exs)
@@ -566,27 +569,20 @@ def _termlist_times_matrix(tl, P, cutoff=1e-12):
                     e[:, 0], e[:, 1], e[:, 2], e[:, 3])
 
 
-class InitialValueSolver(SolverBase):
+class InitialValueSolver(IVPLifecycle, SolverBase):
+    """The life cycle (proceed / step / evolve / log_stats / clocks / Hermitian schedule) is the shared
+    core/ivp_common.py::IVPLifecycle, i.e. the reference's core/solvers.py:594-778."""
+
     def __init__(self, problem, timestepper, enforce_real_cadence=100, warmup_iterations=10, **kw):
         t0 = time.time()
-        super().__init__(problem, **kw)
+        SolverBase.__init__(self, problem, **kw)
         self.sim_time_field = problem.time
         self._sim_time = 0.0
-        self.iteration = 0
-        self.initial_iteration = 0
-        self.stop_sim_time = np.inf
-        self.stop_wall_time = np.inf
-        self.stop_iteration = np.inf
-        self.enforce_real_cadence = enforce_real_cadence
-        self.warmup_iterations = warmup_iterations
-        self.dt = None
+        self._init_lifecycle(enforce_real_cadence, warmup_iterations)
         if isinstance(timestepper, str):
             timestepper = ts_mod.schemes[timestepper]
         self.timestepper = timestepper(self)
-        self.start_time = time.time()
-        self.init_time = self.start_time - t0
-        self.warmup_time = None
-        self.run_time_start = None
+        self.setup_time = time.time() - t0
         self.total_modes = self.R * self.nx * self.ny
         self.handlers = []
         from .output import OutputEvaluator
@@ -602,83 +598,29 @@ class InitialValueSolver(SolverBase):
         self._sim_time = float(t)
         self.sim_time_field["g"] = float(t)
 
-    @property
-    def proceed(self):
-        """core/solvers.py:594-618"""
-        if self.sim_time >= self.stop_sim_time:
-            logger.info("Simulation stop time reached.")
-            return False
-        if (time.time() - self.start_time) >= self.stop_wall_time:
-            logger.info("Wall stop time reached.")
-            return False
-        if self.iteration >= self.stop_iteration:
-            logger.info("Stop iteration reached.")
-            return False
-        return True
-
-    def step(self, dt):
-        """Advance one timestep (core/solvers.py:683-711)."""
-        if not np.isfinite(dt):
-            raise ValueError("Invalid timestep: %r" % dt)
-        if self.iteration == self.initial_iteration + self.warmup_iterations:
-            self.ex.sync()
-            self.warmup_time = time.time()
-        self.dt = dt
-        for hook in self._step_hooks:        # scheduled analysis (CFL frequencies) sees the pre-step state
-            hook(self)
-        self.timestepper.step(dt, time.time() - self.start_time)
-        self.iteration += 1
-        if self.enforce_real_cadence and self.iteration % self.enforce_real_cadence == 0:
-            self.enforce_hermitian_symmetry(self.state)
-
-    def enforce_hermitian_symmetry(self, fields):
-        """Grid and back (core/solvers.py:675-681): removes the invalid modes of real data."""
-        for f in fields:
-            f.require_grid_space(f.domain.dealias)
-            f.require_coeff_space()
-
-    def evolve(self, timestep_function, log_cadence=100):
-        try:
-            logger.info("Starting main loop")
-            while self.proceed:
-                dt = timestep_function()
-                self.step(dt)
-                if (self.iteration - 1) % log_cadence == 0:
-                    logger.info("Iteration=%i, Time=%e, dt=%e" % (self.iteration, self.sim_time, dt))
-        except Exception:
-            logger.error("Exception raised, triggering end of main loop.")
-            raise
-        finally:
-            self.log_stats()
-
-    def log_stats(self, format=".4g"):
-        """core/solvers.py:755-778: modes*stages per (device-)second."""
-        self.ex.sync()
-        end = time.time()
-        logger.info("Final iteration: %i" % self.iteration)
-        logger.info("Final sim time: %s" % self.sim_time)
-        logger.info("Setup time (init - iter 0): %.4g sec" % self.init_time)
-        if self.warmup_time is not None:
-            run = end - self.warmup_time
-            its = self.iteration - self.initial_iteration - self.warmup_iterations
-            stages = its * self.timestepper.stages
-            logger.info("Run time (iter %d-end): %.4g sec" % (self.warmup_iterations, run))
-            if run > 0:
-                logger.info("Speed: %.4g mode-stages/gpu-sec" % (self.total_modes * stages / run))
-
-    def load_state(self, path, index=-1, allow_missing=False):
-        """core/solvers.py:632-673"""
-        from .output import load_state
-        return load_state(self, path, index=index, allow_missing=allow_missing)
+    def _hermitian_round_trip(self, f):
+        if self.dist.size > 1 and any(b is None for b in f.domain.by_axis):
+            # tau / constant fields on several ranks: they have no distributed grid layout here, and the round trip
+            # could only clear modes the solve already writes as exact zeros (store_sys, csrc/ddh_pencil.hip)
+            return
+        scales = f.scales
+        f.require_grid_space(f.domain.dealias)
+        f.require_coeff_space()
+        f.change_scales(scales)              # (coefficient layout: bookkeeping only)
 
 
 class LinearBoundaryValueSolver(SolverBase):
     """L.X = F in one batched factor + solve (core/solvers.py LBVP role)."""
 
-    def solve(self):
+    _lu = None
+
+    def solve(self, rebuild_matrices=False):
+        """The LHS does not change between calls: it is factored once (the reference factors at build time,
+        core/solvers.py:393-406) and re-factored into the same device storage only on request."""
         self.sync_state_to_device()
         F = self.ex.empty((self.R, self.nx, self.ny))
         self.evaluate_F(F)
-        lu = self.factor(0.0, 1.0)
-        SolverBase.solve(self, lu, F, self.X)
+        if self._lu is None or rebuild_matrices:
+            self._lu = self.factor(0.0, 1.0, reuse=(-1 if self._lu is None else self._lu))
+        SolverBase.solve(self, self._lu, F, self.X)
         self.mark_state_current()

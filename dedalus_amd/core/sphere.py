@@ -34,6 +34,7 @@ import numpy as np
 from ..tools import jacobi
 from ..tools import sphere as sph
 from .coords import Coordinate
+from .ivp_common import IVPLifecycle
 
 
 logger = logging.getLogger(__name__)
@@ -1286,29 +1287,34 @@ class SphereBoundaryValueSolver(SphereSolverBase):
                 v._authority = "device"
 
 
-class SphereInitialValueSolver(SphereSolverBase):
+class SphereInitialValueSolver(IVPLifecycle, SphereSolverBase):
     """IMEX timestepping of M.dt(X) + L.X = F on the sphere (core/solvers.py:InitialValueSolver); the schemes are
-    the shared ones of core/timesteppers.py."""
+    the shared ones of core/timesteppers.py, the life cycle is the shared core/ivp_common.py::IVPLifecycle."""
 
-    def __init__(self, problem, timestepper, **kw):
-        super().__init__(problem)
+    def __init__(self, problem, timestepper, enforce_real_cadence=100, warmup_iterations=10, **kw):
+        t0 = _time.time()
+        SphereSolverBase.__init__(self, problem)
         from . import timesteppers as ts
         if isinstance(timestepper, str):
             timestepper = ts.schemes[timestepper]
         self.sim_time = self.initial_sim_time = 0.0
-        self.iteration = self.initial_iteration = 0
-        self.stop_sim_time = self.stop_wall_time = np.inf
-        self.stop_iteration = np.inf
-        self.dt = None
+        self._init_lifecycle(enforce_real_cadence, warmup_iterations)
         self._lus = []
-        self.warmup_iterations = 10
         self.timestepper = timestepper(self)
-        self.start_time = _time.time()
-        self.warmup_time = None
+        self.setup_time = _time.time() - t0
         self.total_modes = int(self.col_valid.sum()) * 2
         from .output import OutputEvaluator
         self.evaluator = OutputEvaluator(self)       # analysis handlers: evaluated at the start of a step
         self._step_hooks = [self.evaluator.step_hook]
+
+    @property
+    def state(self):
+        return self.variables
+
+    def _hermitian_round_trip(self, f):
+        if isinstance(f, SField) and f.basis is not None:
+            f.require_grid_space(f.basis.dealias)
+            f.require_coeff_space()
 
     # interface used by the shared timesteppers ------------------------------------------------------------------
     def factor(self, a, b, reuse=-1):
@@ -1322,47 +1328,3 @@ class SphereInitialValueSolver(SphereSolverBase):
     def solve(self, lu, rhs, x):
         self._lus[lu].apply(rhs, x)
 
-    def step(self, dt):
-        """Advance one timestep (core/solvers.py:683-711)."""
-        if not np.isfinite(dt):
-            raise ValueError("Invalid timestep: %r" % dt)
-        if self.iteration == self.initial_iteration + self.warmup_iterations:
-            self.ex.sync()
-            self.warmup_time = _time.time()
-        self.dt = dt
-        for hook in self._step_hooks:        # scheduled analysis sees the pre-step state
-            hook(self)
-        self.timestepper.step(dt, _time.time() - self.start_time)
-        self.iteration += 1
-
-    def load_state(self, path, index=-1, allow_missing=False):
-        """core/solvers.py:632-673"""
-        from .output import load_state
-        return load_state(self, path, index=index, allow_missing=allow_missing)
-
-    @property
-    def proceed(self):
-        """core/solvers.py:594-618"""
-        if self.sim_time >= self.stop_sim_time:
-            logger.info("Simulation stop time reached.")
-            return False
-        if (_time.time() - self.start_time) >= self.stop_wall_time:
-            logger.info("Wall stop time reached.")
-            return False
-        if self.iteration >= self.stop_iteration:
-            logger.info("Stop iteration reached.")
-            return False
-        return True
-
-    def log_stats(self, format=".4g"):
-        """core/solvers.py:755-778"""
-        self.ex.sync()
-        end = _time.time()
-        logger.info("Final iteration: %i" % self.iteration)
-        logger.info("Final sim time: %s" % self.sim_time)
-        if self.warmup_time is not None:
-            run = end - self.warmup_time
-            its = self.iteration - self.initial_iteration - self.warmup_iterations
-            logger.info("Run time (iter %d-end): %.4g sec" % (self.warmup_iterations, run))
-            if run > 0:
-                logger.info("Speed: %.4g mode-stages/gpu-sec" % (self.total_modes * its * self.timestepper.stages / run))

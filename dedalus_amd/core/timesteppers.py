@@ -11,7 +11,7 @@ but every per-subproblem Python loop is one batched kernel over all pencils:
 The variable-step multistep coefficients are not tabulated: they are computed from their defining
 conditions (finite-difference / extrapolation / Adams weights on the actual time nodes), which
 reproduces the closed forms of Wang & Ruuth (2008) used by the reference to round-off
-(pinned by tests/test_timestepper_coefficients.py against reference-generated fixtures).
+(pinned by tests/test_ivp_oracle.py against reference-generated fixtures, tests/golden/timesteppers.npz).
 """
 
 import math

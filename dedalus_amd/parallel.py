@@ -116,5 +116,13 @@ class Comm:
         self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX)
         return float(x.item())
 
+    def bcast_float(self, value, src=0):
+        """rank `src`'s value on every rank (the reference's world_time broadcast, core/solvers.py:603-611)"""
+        t = self.torch
+        dev = "cuda" if (t.cuda.is_available() and self.dist.get_backend() == "nccl") else "cpu"
+        x = t.tensor([float(value)], dtype=t.float64, device=dev)
+        self.dist.broadcast(x, src=src)
+        return float(x.item())
+
     def barrier(self):
         self.dist.barrier()
