@@ -298,6 +298,19 @@ class Field(Operand):
         self._authority = "host"
         return self._host
 
+    def snapshot_async(self, layout):
+        """Start copying the current data to the host without blocking the device (executor.download_async); returns a
+        callable that yields the user-ordered array, or None when the executor has no asynchronous path.  Used by the
+        file handlers: the copy overlaps the following timesteps."""
+        ex = self.ex
+        if not hasattr(ex, "download_async") or self._authority == "host":
+            return None
+        layout = "c" if layout in ("c", "coeff") else "g"
+        scales = self.scales
+        dev = self.require_coeff_space() if layout == "c" else self.require_grid_space(scales)
+        pend = ex.download_async(dev)
+        return lambda: self._from_storage(pend.wait(), layout, scales)
+
     def __setitem__(self, key, data):
         if isinstance(key, tuple):
             layout, scales = key

@@ -209,6 +209,9 @@ class FileHandler(Handler):
         self.file_write_num = 0
         self._file = None
         self._dsets = None
+        self._queue = []
+        # asynchronous device-to-host staging of the task data (DDH_OUTPUT_SYNC=1: fetch and write immediately)
+        self.async_staging = os.environ.get("DDH_OUTPUT_SYNC", "0") != "1"
 
     @property
     def current_file(self):
@@ -264,24 +267,52 @@ class FileHandler(Handler):
             data = pc.all_gather_host(np.ascontiguousarray(data), axis=shard)
         return np.array(data), axes, const, scales
 
+    def _start(self, task):
+        """Begin fetching a task's data: device fields on one rank are staged asynchronously (device snapshot + pinned
+        host copy on a side stream, Field.snapshot_async) and resolved when the write is flushed -- at the next
+        scheduled output or at close -- so the copy overlaps the timesteps in between.  Returns a callable ->
+        (data, axes, constant flags, scales)."""
+        out = task['out']
+        pc = getattr(self.dist, "pcomm", None)
+        if self.async_staging and pc is None and hasattr(out, "snapshot_async") and hasattr(out, "domain"):
+            pend = out.snapshot_async(task['layout'])
+            if pend is not None:
+                axes, const, scales, _ = _describe(self.dist, out, task['layout'], None)
+                self._staged = True
+                return lambda: (pend(), axes, const, scales)
+        res = self._gather(task)
+        return lambda: res
+
     def process(self, iteration=0, wall_time=0.0, sim_time=0.0, timestep=0.0, **kw):
+        self.flush()                                   # the previous write: its copies had a whole output interval
         self.total_write_num += 1
+        meta = dict(sim_time=sim_time, wall_time=wall_time, timestep=timestep, iteration=iteration,
+                    write_number=self.total_write_num)
+        self._staged = False
+        self._queue.append((meta, [self._start(task) for task in self.tasks]))
+        if not self._staged:
+            self.flush()                               # nothing in flight (host data, gathered ranks): write now
+
+    def flush(self):
+        """Write every staged output to the analysis set (in order)."""
+        while self._queue:
+            meta, entries = self._queue.pop(0)
+            self._write(meta, [e() for e in entries])
+
+    def _write(self, meta, gathered):
         self.file_write_num += 1
         roll = self.max_writes is not None and self.file_write_num > self.max_writes
         if self._dsets is not None and any(d.nrows >= d.capacity for d in self._dsets.values()):
             roll = True
         if roll:
-            self.close()
+            self._close_file()
             self.set_num += 1
             self.file_write_num = 1
-        gathered = [self._gather(task) for task in self.tasks]
         if not self.is_root:
             return
         if self._file is None:
             self._create_file(gathered)
         f = self._file
-        meta = dict(sim_time=sim_time, wall_time=wall_time, timestep=timestep, iteration=iteration,
-                    write_number=self.total_write_num)
         for n, v in meta.items():
             self._tsc[n].append(v)
         for task, (data, _, _, _) in zip(self.tasks, gathered):
@@ -290,6 +321,10 @@ class FileHandler(Handler):
         f.flush()
 
     def close(self):
+        self.flush()
+        self._close_file()
+
+    def _close_file(self):
         if self._file is not None:
             self._file.close()
         self._file = self._dsets = None

@@ -192,6 +192,57 @@ a2a_unpack_kernel(const double *__restrict__ src, double *__restrict__ dst, long
     }
 }
 
+// min / max / sum of n doubles: fixed-shape tree (block partials in a fixed order, then one block over the partials),
+// so the result does not depend on scheduling.  out3 = {min, max, sum}.
+constexpr int RED_BLOCKS = 1024;
+
+__device__ __forceinline__ void red3_combine(double &mn, double &mx, double &sm, double a, double b, double c) {
+    mn = fmin(mn, a);
+    mx = fmax(mx, b);
+    sm += c;
+}
+
+__device__ __forceinline__ void red3_block(double mn, double mx, double sm, double *out3) {
+    __shared__ double s_mn[4], s_mx[4], s_sm[4];
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1)
+        red3_combine(mn, mx, sm, __shfl_xor(mn, sft, 64), __shfl_xor(mx, sft, 64), __shfl_xor(sm, sft, 64));
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_mn[w] = mn;
+        s_mx[w] = mx;
+        s_sm[w] = sm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) red3_combine(mn, mx, sm, s_mn[i], s_mx[i], s_sm[i]);
+        out3[0] = mn;
+        out3[1] = mx;
+        out3[2] = sm;
+    }
+}
+
+__global__ void __launch_bounds__(256) reduce3_partial_kernel(const double *__restrict__ x, long n, double *__restrict__ part) {
+    // block b owns the contiguous chunk [b * per, (b + 1) * per): partial sums are independent of the launch shape
+    const long per = (n + RED_BLOCKS - 1) / RED_BLOCKS;
+    const long lo = (long)blockIdx.x * per;
+    const long hi = lo + per < n ? lo + per : n;
+    double mn = INFINITY, mx = -INFINITY, sm = 0.0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const double v = x[i];
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
+        sm += v;
+    }
+    red3_block(mn, mx, sm, part + 3 * blockIdx.x);
+}
+
+__global__ void __launch_bounds__(256) reduce3_final_kernel(const double *__restrict__ part, double *__restrict__ out3) {
+    double mn = INFINITY, mx = -INFINITY, sm = 0.0;
+    for (int i = threadIdx.x; i < RED_BLOCKS; i += 256) red3_combine(mn, mx, sm, part[3 * i], part[3 * i + 1], part[3 * i + 2]);
+    red3_block(mn, mx, sm, out3);
+}
+
 static unsigned stream_grid(long work_items) {
     long blocks = (work_items + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
@@ -308,6 +359,14 @@ int ddh_grid_cfl_spherical(double *result_d, const double *u, long n_ang, int nr
     DDH_HIP(hipMemsetAsync(result_d, 0, sizeof(double), as_stream(stream)));
     hipLaunchKernelGGL(cfl_spherical_kernel, dim3(stream_grid(n_ang * nr)), dim3(256), 0, as_stream(stream), result_d, u,
                        n_ang, nr, inv_h_d, inv_dr_d);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_grid_reduce(double *out3_d, const double *x, long n, double *work_d, void *stream) {
+    if (n <= 0) return fail("ddh_grid_reduce: empty array");
+    hipLaunchKernelGGL(reduce3_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, as_stream(stream), x, n, work_d);
+    hipLaunchKernelGGL(reduce3_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const double *)work_d, out3_d);
     DDH_HIP(hipGetLastError());
     return 0;
 }

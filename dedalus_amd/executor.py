@@ -36,6 +36,28 @@ class HipExecutor:
     def download(self, t):
         return t.detach().cpu().numpy()
 
+    def download_async(self, t):
+        """Start a device-to-host copy that overlaps the following kernels: the data are snapshotted on the compute
+        stream (the next step overwrites state views), then copied into pinned host memory on a side stream.
+        Returns a handle whose .wait() gives the host array (analysis output staging, SURVEY 8f #4)."""
+        torch = self.torch
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream()
+            self._pinned = {}
+        snap = t.detach().clone()
+        key = (int(snap.numel()), snap.dtype)
+        pool = self._pinned.setdefault(key, [])
+        host = pool.pop() if pool else torch.empty(snap.numel(), dtype=snap.dtype, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(ready)
+            host.copy_(snap.reshape(-1), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        snap.record_stream(self._copy_stream)
+        return _AsyncDownload(host, done, tuple(snap.shape), pool)
+
     def upload(self, dst, a):
         dst.copy_(self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).reshape(dst.shape))
 
@@ -185,6 +207,16 @@ class HipExecutor:
         libhip.call("ddh_grid_cfl_spherical", ptr(res), ptr(u), n_ang, nr, ptr(inv_h), ptr(inv_dr), self.dev.stream)
         return float(self.download(res)[0])
 
+    def reduce3(self, x):
+        """(min, max, sum) of a device array: one reduction launch pair + a 24-byte copy to the host (ddh_grid_reduce)."""
+        if not hasattr(self, "_red_work"):
+            self._red_work = self.dev.empty((3072,))
+            self._red_out = self.dev.empty((3,))
+        x = x if x.is_contiguous() else x.contiguous()
+        libhip.call("ddh_grid_reduce", ptr(self._red_out), ptr(x), int(x.numel()), ptr(self._red_work), self.dev.stream)
+        mn, mx, sm = self._red_out.cpu().tolist()
+        return mn, mx, sm
+
     def a2a_plan(self, pcomm, n0, n1, n2, n3):
         """Library-owned transpose plan (ddh_a2a_plan on the RCCL communicator of `pcomm`), cached per shape; None when
         the exchange goes through torch.distributed (parallel.Comm.library_comm)."""
@@ -253,6 +285,19 @@ class HipExecutor:
         pk = PencilPack(self.dev, nf, nrows, nx, ny, kx, ky, mx_offset)
         pk.executor = self
         return pk
+
+
+class _AsyncDownload:
+    def __init__(self, host, done, shape, pool):
+        self.host, self.done, self.shape, self.pool = host, done, shape, pool
+
+    def wait(self):
+        """host copy of the snapshot (a fresh array; the pinned buffer goes back to the pool)"""
+        self.done.synchronize()
+        out = self.host.numpy().reshape(self.shape).copy()
+        self.pool.append(self.host)
+        self.host = None
+        return out
 
 
 class GroupedMmt:

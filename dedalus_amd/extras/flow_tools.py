@@ -29,16 +29,25 @@ class GlobalFlowProperty:
         self.properties[name] = property
 
     def _evaluate(self, name):
+        """(min, max, sum, count) of the property's grid data.  The reduction runs on the device (ddh_grid_reduce, the
+        local part of GlobalArrayReducer, flow_tools.py:32-47): 24 bytes reach the host, not the grid."""
         expr = self.properties[name]
         f = expr.evaluate() if hasattr(expr, "evaluate") else expr
-        return np.array(f["g"])
+        ex = self.solver.ex
+        if hasattr(f, "require_grid_space") and hasattr(ex, "reduce3"):
+            g = f.require_grid_space(f.scales)
+            n = int(g.numel()) if hasattr(g, "numel") else int(np.size(g))
+            mn, mx, sm = ex.reduce3(g)
+            return (mn, mx, sm, n)
+        g = np.asarray(f["g"])                       # operands evaluated on the host (analysis-only expressions)
+        return (float(g.min()), float(g.max()), float(g.sum()), int(g.size))
 
     def _sample(self, solver):
         if solver.iteration % self.cadence == 0:
             for name in self.properties:
                 self._sampled[name] = self._evaluate(name)
 
-    def _grid(self, name):
+    def _stats(self, name):
         if name in self._sampled:
             return self._sampled[name]
         it = self.solver.iteration
@@ -55,14 +64,14 @@ class GlobalFlowProperty:
         return pc.allreduce_max(val) if op == "max" else (-pc.allreduce_max(-val) if op == "min" else pc.allreduce_sum(val))
 
     def min(self, name):
-        return self._reduce(np.min(self._grid(name)), "min")
+        return self._reduce(self._stats(name)[0], "min")
 
     def max(self, name):
-        return self._reduce(np.max(self._grid(name)), "max")
+        return self._reduce(self._stats(name)[1], "max")
 
     def grid_average(self, name):
-        g = self._grid(name)
-        return self._reduce(np.sum(g), "sum") / self._reduce(g.size, "sum")
+        st = self._stats(name)
+        return self._reduce(st[2], "sum") / self._reduce(st[3], "sum")
 
     def volume_integral(self, name):
         from ..core.operators import Integrate

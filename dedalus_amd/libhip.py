@@ -80,6 +80,7 @@ SIGNATURES = {
     "ddh_grid_bilinear": [_vp, _i, _vp, _vp, _l, _i, _ip, _ip, _ip, _dp, _vp],
     "ddh_grid_cfl": [_vp, _vp, _i, _l, C.POINTER(_vp), _ip, C.POINTER(_l), _i, _vp],
     "ddh_grid_cfl_spherical": [_vp, _vp, _l, _i, _vp, _vp, _vp],
+    "ddh_grid_reduce": [_vp, _vp, _l, _vp, _vp],
     "ddh_pencil_create": [_hp, C.POINTER(PencilGeom)],
     "ddh_pencil_add_matrix": [_h, C.POINTER(PolyMat), _i, _ip],
     "ddh_pencil_matvec": [_h, _i, _vp, _vp, _vp],

@@ -198,6 +198,12 @@ int ddh_grid_cfl(double *result_d, const double *u, int ncomp, long n,
 int ddh_grid_cfl_spherical(double *result_d, const double *u, long n_ang, int nr, const double *inv_h_d,
                            const double *inv_dr_d, void *stream);
 
+/* out3_d = {min, max, sum} over n grid values (device), the local reductions of GlobalArrayReducer / GlobalFlowProperty
+ * (extras/flow_tools.py:9-47, 49-111: np.min / np.max / np.sum of the grid data followed by an 8-byte Allreduce).
+ * work_d: 3 * 1024 doubles of scratch.  Fixed reduction tree: the sum is reproducible from run to run.           */
+#define DDH_REDUCE_WORK_DOUBLES 3072
+int ddh_grid_reduce(double *out3_d, const double *x, long n, double *work_d, void *stream);
+
 /* ---- pencil systems ------------------------------------------ */
 /* A "pencil pack" describes all pencils of a problem at once.  System vectors are real arrays
  * [nrows][nx][ny] (cell index fastest).  With nfourier real-Fourier separable axes a cell holds

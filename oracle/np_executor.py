@@ -191,6 +191,11 @@ class NumpyExecutor:
         """Spherical3DAdvectiveCFL.compute_cfl_frequency (core/basis.py:6199-6204) reduced with max"""
         return float(np.max(np.sqrt(u[0] ** 2 + u[1] ** 2) * inv_h + np.abs(u[2]) * inv_dr))
 
+    def reduce3(self, x):
+        """np.min / np.max / np.sum of the grid data (extras/flow_tools.py:32-47)"""
+        x = np.asarray(x)
+        return float(x.min()), float(x.max()), float(x.sum())
+
     def a2a_pack(self, src, dst, outer, na, nb, inner, P):
         """split_rows / split_columns of AlltoallvTranspose (core/transposes.pyx:359-445) restated"""
         s = src.reshape(outer, P, na // P, nb * inner)

@@ -81,3 +81,68 @@ def test_poisson_lbvp_on_device_matches_reference(gold, shape):
         ref = gold["poisson_%dx%d__%s" % (shape + (k,))]
         tol = 1e-10 if k in ("u", "f") else 1e-6          # the tau amplitudes are ~1e-20 (spectrally small residuals)
         assert rel(np.array(f['c']), ref) < tol, (k, rel(np.array(f['c']), ref))
+
+
+def test_flow_properties_reduce_on_device():
+    """GlobalFlowProperty min / max / grid_average through ddh_grid_reduce (extras/flow_tools.py:49-111) against NumPy
+    on the downloaded grid, and the raw kernel on odd sizes."""
+    import ctypes as C
+    import dedalus_amd.public as d3
+    from dedalus_amd import libhip
+    from dedalus_amd.device import ptr
+    solver, f = problems.rayleigh_benard_2d(d3, Nx=64, Nz=32)
+    for _ in range(3):
+        solver.step(1e-3)
+    u, b = f["u"], f["b"]
+    flow = d3.GlobalFlowProperty(solver, cadence=1)
+    flow.add_property(u @ u, name="uu")
+    flow.add_property(b, name="b")
+    g = np.asarray((u @ u).evaluate()["g"])
+    assert abs(flow.max("uu") - g.max()) <= 1e-15 * abs(g.max())
+    assert abs(flow.min("uu") - g.min()) <= 1e-15 * abs(g.max())
+    assert abs(flow.grid_average("uu") - g.mean()) <= 1e-13 * abs(g.mean())
+    gb = np.asarray(b["g"])
+    assert abs(flow.grid_average("b") - gb.mean()) <= 1e-13 and flow.max("b") == gb.max() and flow.min("b") == gb.min()
+    dev = solver.ex.dev
+    rng = np.random.default_rng(0)
+    for n in (1, 63, 1025, 300007):
+        x = rng.standard_normal(n)
+        mn, mx, sm = solver.ex.reduce3(dev.from_host(x))
+        assert mn == x.min() and mx == x.max() and abs(sm - x.sum()) <= 1e-12 * np.abs(x).sum()
+
+
+def test_file_output_and_restart_from_device_fields(tmp_path):
+    """Analysis sets written from DEVICE fields through the asynchronous staging path (device snapshot + pinned host
+    copy on a side stream, flushed at the next output / close), read back with h5lite; load_state restart on the GPU
+    reproduces the uninterrupted run (core/evaluator.py:366-618, core/solvers.py:632-673)."""
+    import dedalus_amd.public as d3
+    from dedalus_amd.tools import h5lite
+    solver, f = problems.rayleigh_benard_2d(d3, Nx=64, Nz=32)
+    snap = solver.evaluator.add_file_handler(str(tmp_path / "snap"), iter=2, max_writes=10)
+    snap.add_task(f["b"], name="b")
+    snap.add_task(f["u"], layout="c", name="u_c")
+    chk = solver.evaluator.add_file_handler(str(tmp_path / "chk"), iter=4, max_writes=10)
+    chk.add_tasks(solver.state, layout="g")
+    assert snap.async_staging
+    seen = {}
+    for i in range(9):
+        if i % 2 == 0:
+            f["b"]["c"]
+            seen[i] = (np.array(f["b"]["g"]), np.array(f["u"]["c"]))
+        solver.step(1e-3)
+    end = {k: np.array(v["c"]) for k, v in f.items()}
+    snap.close()
+    chk.close()
+    r = h5lite.read(str(tmp_path / "snap" / "snap_s1.h5"))
+    assert np.array_equal(r["scales/iteration"].read(), [0, 2, 4, 6, 8])
+    for k, it in enumerate((0, 2, 4, 6, 8)):
+        assert np.allclose(r["tasks/b"].read(k), seen[it][0], rtol=0, atol=1e-13)
+        assert np.allclose(r["tasks/u_c"].read(k), seen[it][1], rtol=0, atol=1e-13)
+    # restart from the checkpoint written at iteration 4 and redo steps 4..8
+    solver2, f2 = problems.rayleigh_benard_2d(d3, Nx=64, Nz=32)
+    write, dt = solver2.load_state(str(tmp_path / "chk" / "chk_s1.h5"), index=1)
+    assert solver2.iteration == 4 and abs(dt - 1e-3) < 1e-18
+    for _ in range(5):
+        solver2.step(1e-3)
+    for k in ("p", "b", "u"):
+        assert rel(np.array(f2[k]["c"]), end[k]) < 1e-9, k
