@@ -464,6 +464,21 @@ class SolverBase:
                                          rhs=[self.gather_pencil(rhs, "equations", gx, gy) for gx, gy in probe["groups"]],
                                          x=[self.gather_pencil(out, "variables", gx, gy) for gx, gy in probe["groups"]]))
 
+    def solve_lincomb(self, lu, xs, alphas, out):
+        """out = (a M + b L)^-1 (sum_t alphas[t] xs[t]).  The combination is formed inside the forward sweep of the band
+        solve; with a parity probe attached (or more terms than the kernel takes) it is materialised first."""
+        if getattr(self, "solve_probe", None) is not None or len(xs) > self.pack.MAX_RHS_TERMS or not hasattr(self.pack, "solve_lincomb"):
+            rhs = self.ex.empty((self.R, self.nx, self.ny))
+            self.ex.lincomb(rhs, xs, alphas)
+            self._last_rhs = rhs                       # (kept for the parity tests)
+            return self.solve(lu, rhs, out)
+        if self.P_id is None:
+            self.pack.solve_lincomb(lu, xs, alphas, out)
+        else:
+            Y = self.ex.empty((self.R, self.nx, self.ny))
+            self.pack.solve_lincomb(lu, xs, alphas, Y)
+            self.pack.matvec(self.P_id, Y, out)
+
     def gather_pencil(self, vec, which, gx, gy=0):
         """One pencil of a system vector in the reference's gathered order (Subproblem.gather_inputs /
         gather_outputs before pre_right_pinv / pre_left, core/subsystems.py:302-365): for every variable (or equation)

@@ -69,13 +69,34 @@ def _times(timesteps, n):
 # multistep
 # ==================================================================================================
 
-class MultistepIMEX:
+class _SolveMixin:
+    """RHS = sum_t alpha_t x_t followed by the LHS solve: solvers with a fused path (SolverBase.solve_lincomb, the band
+    engine's forward sweep forms the combination on the fly) never materialise the RHS; the others get the axpy chain
+    into a RHS buffer (timesteppers.py:156-166, 617-623) and a plain solve."""
+    _RHS = None
+
+    @property
+    def RHS(self):
+        if self._RHS is None:
+            s = self.solver
+            self._RHS = s.ex.zeros((s.R, s.nx, s.ny))
+        return self._RHS
+
+    def _solve_combination(self, xs, al, lu):
+        s = self.solver
+        if hasattr(s, "solve_lincomb"):
+            s.solve_lincomb(lu, xs, al, s.X)
+        else:
+            s.ex.lincomb(self.RHS, xs, al)
+            s.solve(lu, self.RHS, s.X)
+
+
+class MultistepIMEX(_SolveMixin):
     stages = 1
 
     def __init__(self, solver):
         self.solver = solver
         ex, shape = solver.ex, (solver.R, solver.nx, solver.ny)
-        self.RHS = ex.zeros(shape)
         self.dt = deque([0.0] * self.steps)
         self.MX = deque(ex.zeros(shape) for _ in range(self.amax))
         self.F = deque(ex.zeros(shape) for _ in range(self.cmax))
@@ -115,11 +136,10 @@ class MultistepIMEX:
         for j in range(1, len(b)):
             if b[j] != 0.0:
                 xs.append(self.LX[j - 1]); al.append(-b[j])
-        ex.lincomb(self.RHS, xs, al)
         if (a[0], b[0]) != self._LHS_params:
             self._lu = s.factor(a[0], b[0], reuse=self._lu)
             self._LHS_params = (a[0], b[0])
-        s.solve(self._lu, self.RHS, s.X)
+        self._solve_combination(xs, al, self._lu)
         s.mark_state_current()
         s.sim_time = s.sim_time + dt
 
@@ -265,7 +285,7 @@ class SBDF4(_SBDF):
 # Runge-Kutta
 # ==================================================================================================
 
-class RungeKuttaIMEX:
+class RungeKuttaIMEX(_SolveMixin):
     steps = 1
 
     def __init__(self, solver):
@@ -284,7 +304,6 @@ class RungeKuttaIMEX:
         # sums.  DDH_RK_DIRECT_LX=1 restores the explicit products (reference order of operations,
         # core/timesteppers.py:588-604).
         self._direct = os.environ.get("DDH_RK_DIRECT_LX", "0") == "1"
-        self.RHS = ex.zeros(shape)
         self.LX = [ex.zeros(shape) if (self._need_lx[j] and (self._direct or j == 0)) else None
                    for j in range(self.stages + 1)]
         self.MX = [None] + [ex.zeros(shape) if (self._need_lx[j] and not self._direct) else None
@@ -337,8 +356,7 @@ class RungeKuttaIMEX:
             vec = {"MX0": lambda q: self.MX0, "F": lambda q: self.F[q], "LX": lambda q: self.LX[q], "MX": lambda q: self.MX[q]}
             xs = [vec[key[0]](key[1] if len(key) > 1 else None) for key, v in comb.items() if v != 0.0]
             al = [v for v in comb.values() if v != 0.0]
-            ex.lincomb(self.RHS, xs, al)
-            s.solve(self._lus[float(H[i, i])], self.RHS, s.X)
+            self._solve_combination(xs, al, self._lus[float(H[i, i])])
             s.mark_state_current()
             s.sim_time = t0 + k * c[i]
 

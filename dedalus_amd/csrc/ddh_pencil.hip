@@ -476,6 +476,48 @@ __device__ __forceinline__ double2 load_sys(const double *__restrict__ v, long p
     }
 }
 
+// Right-hand side of a solve given as a linear combination of stored system vectors (RHS assembly of
+// timesteppers.py:156-166, 617-623 fused into the forward sweep: the combined vector is never written to HBM).
+constexpr int RHS_MAX = 8;
+struct RhsSrc {
+    int n;
+    const double *p[RHS_MAX];
+    double a[RHS_MAX];
+};
+
+template <int NF, int XD = 1>
+__device__ __forceinline__ double2 load_sys(const RhsSrc &r, long plane, int row, const PencilDev &P,
+                                            const CellCtx &c, int s) {
+    if (r.n == 1 && r.a[0] == 1.0) return load_sys<NF, XD>(r.p[0], plane, row, P, c, s);
+    const long roff = (long)row * plane;
+    if (NF == 2) {
+        const long off = roff + (2 * c.mx + s) * P.ny + 2 * c.my;
+        double2 mine = make_double2(0.0, 0.0);
+        for (int t = 0; t < r.n; ++t) {
+            const double2 v = *reinterpret_cast<const double2 *>(r.p[t] + off);
+            mine.x += r.a[t] * v.x;
+            mine.y += r.a[t] * v.y;
+        }
+        double2 other;
+        other.x = __shfl_xor(mine.x, XD);
+        other.y = __shfl_xor(mine.y, XD);
+        return s == 0 ? make_double2(mine.x - other.y, mine.y + other.x)
+                      : make_double2(other.x + mine.y, other.y - mine.x);
+    } else if (NF == 1) {
+        double2 acc = make_double2(0.0, 0.0);
+        for (int t = 0; t < r.n; ++t) {
+            const double2 v = *reinterpret_cast<const double2 *>(r.p[t] + roff + 2 * c.mx);
+            acc.x += r.a[t] * v.x;
+            acc.y += r.a[t] * v.y;
+        }
+        return acc;
+    } else {
+        double acc = 0.0;
+        for (int t = 0; t < r.n; ++t) acc += r.a[t] * r.p[t][roff];
+        return make_double2(acc, 0.0);
+    }
+}
+
 template <int NF, int XD = 1>
 __device__ __forceinline__ void store_sys(double *__restrict__ v, long plane, int row, const PencilDev &P,
                                           const CellCtx &c, int s, double2 val, bool writer = true) {
@@ -708,7 +750,7 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
 // serialized ones.  Permutations and grading codes are staged in LDS.
 template <int NF, bool REAL, int KLT, int NBT>
 __global__ void __launch_bounds__(256)
-solve_forward_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__restrict__ xout) {
+solve_forward_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__restrict__ xout) {
     typedef typename El<REAL>::T E;
     extern __shared__ int s_lds[];
     const int N = L.N;
@@ -964,7 +1006,7 @@ __device__ __forceinline__ double group_sum(double v) {
 
 template <int NF, bool REAL, int NBT>
 __global__ void __launch_bounds__(256)
-solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__restrict__ xout) {
+solve_forward_coop_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__restrict__ xout) {
     typedef typename El<REAL>::T E;
     extern __shared__ int s_lds[];
     const int N = L.N;
@@ -1193,7 +1235,7 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
 template <int NF>
 __global__ void __launch_bounds__(256)
 dense_gather_kernel(PencilDev P, LuDev L, const long *__restrict__ cells, int ncellsf,
-                    const double *__restrict__ rhs, double2 *__restrict__ out) {
+                    const RhsSrc rhs, double2 *__restrict__ out) {
     // thread -> (flagged cell f, system s, logical row i); pairs (s=0,1) adjacent lanes for NF == 2
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long per = (long)L.N * P.S;
@@ -1247,7 +1289,7 @@ static int upload_vec(void **dptr, const T *src, size_t count) {
 
 // dense fallback for the flagged pencils (after either sweep variant)
 template <int NF>
-static int finish_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double *x, hipStream_t s) {
+static int finish_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double *x, hipStream_t s) {
     const PencilDev &P = pp->dev;
     const LuDev &d = lu->dev;
     if (lu->nflag) {
@@ -1269,7 +1311,7 @@ static int finish_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double 
 }
 
 template <int NF>
-static int launch_solve(PencilPack *pp, LuFactor *lu, const double *rhs, double *x, hipStream_t s) {
+static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double *x, hipStream_t s) {
     const PencilDev &P = pp->dev;
     const LuDev &d = lu->dev;
     const unsigned blocks = (unsigned)((P.G + 255) / 256);
@@ -1764,11 +1806,29 @@ int ddh_pencil_solve(ddh_handle pack, int lu_id, const double *rhs, double *x, v
     if (!pp) return -1;
     if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_solve: bad LU id");
     if (rhs == x) return fail("pencil_solve: in-place unsupported");
+    const double one = 1.0;
+    return ddh_pencil_solve_lincomb(pack, lu_id, 1, &rhs, &one, x, stream);
+}
+
+int ddh_pencil_solve_lincomb(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h, const double *alpha_h,
+                             double *x, void *stream) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_solve: bad LU id");
+    if (nterms < 1 || nterms > RHS_MAX) return fail("pencil_solve_lincomb: 1 to 8 right-hand-side terms");
+    RhsSrc r;
+    memset(&r, 0, sizeof(r));
+    r.n = nterms;
+    for (int t = 0; t < nterms; ++t) {
+        if (xs_h[t] == x) return fail("pencil_solve: in-place unsupported");
+        r.p[t] = xs_h[t];
+        r.a[t] = alpha_h[t];
+    }
     LuFactor *lu = pp->lus[lu_id];
     hipStream_t s = as_stream(stream);
-    if (pp->dev.nf == 2) return launch_solve<2>(pp, lu, rhs, x, s);
-    if (pp->dev.nf == 1) return launch_solve<1>(pp, lu, rhs, x, s);
-    return launch_solve<0>(pp, lu, rhs, x, s);
+    if (pp->dev.nf == 2) return launch_solve<2>(pp, lu, r, x, s);
+    if (pp->dev.nf == 1) return launch_solve<1>(pp, lu, r, x, s);
+    return launch_solve<0>(pp, lu, r, x, s);
 }
 
 int ddh_pencil_lu_row_widths(ddh_handle pack, int lu_id, int *wrow_h) {

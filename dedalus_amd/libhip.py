@@ -93,6 +93,7 @@ SIGNATURES = {
                                C.POINTER(C.c_ubyte), _i, _ip, _vp],
     "ddh_pencil_solve": [_h, _i, _vp, _vp, _vp],
     "ddh_pencil_set_solve_variant": [_h, _i, _i, _i],
+    "ddh_pencil_solve_lincomb": [_h, _i, _i, C.POINTER(_vp), _dp, _vp, _vp],
     "ddh_pencil_flagged": [_h, _i, _ip, C.POINTER(_l), _i],
     "ddh_pencil_set_dense_inverse": [_h, _i, _dp],
     "ddh_pencil_lu_bytes": [_h, _i, C.POINTER(C.c_size_t)],

@@ -191,6 +191,22 @@ class PencilPack:
     def _solve(self, lu_id, rhs, x):
         libhip.call("ddh_pencil_solve", self.handle, lu_id, ptr(rhs), ptr(x), self.dev.stream)
 
+    def solve_lincomb(self, lu_id, xs, alphas, x):
+        """x = (a M + b L)^-1 (sum_t alphas[t] xs[t]): the right-hand-side combination is formed inside the forward sweep
+        (ddh_pencil_solve_lincomb)."""
+        t = self._timer()
+        if t is not None:
+            nb = self.lu_bytes(lu_id) + (sum(v.numel() for v in xs) + x.numel()) * 8
+            return t.run("pencil_solve", nb, self._solve_lincomb, lu_id, xs, alphas, x)
+        return self._solve_lincomb(lu_id, xs, alphas, x)
+
+    def _solve_lincomb(self, lu_id, xs, alphas, x):
+        arr = (C.c_void_p * len(xs))(*[C.c_void_p(v.data_ptr()) for v in xs])
+        al = np.ascontiguousarray(alphas, dtype=np.float64)
+        libhip.call("ddh_pencil_solve_lincomb", self.handle, lu_id, len(xs), arr, libhip.as_dp(al), ptr(x), self.dev.stream)
+
+    MAX_RHS_TERMS = 8
+
     def set_solve_variant(self, mode=1, fwd=-1, backward_lanes=-1):
         """Sweep variant of solve(): mode 1 by the number of systems (default), 0 one thread per system, 2 cooperative;
         fwd (0 / 1) and backward_lanes (0 / 4 / 16) override the two sweeps individually."""

@@ -271,6 +271,12 @@ int ddh_pencil_factor_real(ddh_handle pack, int matM_id, int matL_id, double a, 
                            const unsigned char *row_code_h, const unsigned char *col_code_h,
                            int reuse_lu_id, int *lu_id, void *stream);
 int ddh_pencil_solve(ddh_handle pack, int lu_id, const double *rhs, double *x, void *stream);
+/* Solve with the right-hand side given as a linear combination rhs = sum_t alpha[t] * xs[t] of stored system vectors
+ * (1 <= nterms <= 8): the RHS assembly of the IMEX schemes (timesteppers.py:156-166, 617-623: an axpy chain into a RHS
+ * buffer, then LHS_solver.solve) fused into the forward sweep -- the combined vector is never written to or re-read
+ * from HBM.  xs_h: host array of device pointers; none may alias x.                                              */
+int ddh_pencil_solve_lincomb(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h, const double *alpha_h,
+                             double *x, void *stream);
 /* Sweep variant used by ddh_pencil_solve (all variants compute the same factorization's solution; they differ in how
  * many lanes share one system).  mode 1 (default): chosen by the number of systems; 0: one
  * thread per system; 2: cooperative (16 lanes) in both sweeps.  fwd = 0 / 1 and backward_lanes = 0 / 4 / 16 override

@@ -61,6 +61,15 @@ class _NpPack:
     def solve(self, lu_id, rhs, x):
         x[...] = self.lus[lu_id].solve(rhs).reshape(x.shape)
 
+    MAX_RHS_TERMS = 8
+
+    def solve_lincomb(self, lu_id, xs, alphas, x):
+        """axpy chain into the RHS buffer, then the per-pencil solves (timesteppers.py:617-623, 641-643)"""
+        rhs = np.zeros_like(x)
+        for v, a in zip(xs, alphas):
+            rhs += a * np.asarray(v).reshape(x.shape)
+        self.solve(lu_id, rhs, x)
+
     def lu_bytes(self, lu_id):
         return 0
 

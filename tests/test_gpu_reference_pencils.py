@@ -56,7 +56,7 @@ def test_every_sweep_variant_at_full_size(full_size, variant):
     solver.solve_probe["records"] = []
     solver.pack.set_solve_variant(*VARIANTS[variant])
     try:
-        solver.solve(lu, ts.RHS, out)            # the last stage's right-hand side is still in the buffer
+        solver.solve(lu, solver._last_rhs, out)  # the last stage's right-hand side (materialised while probing)
         solver.ex.sync()
     finally:
         solver.pack.set_solve_variant(1, -1, -1)
@@ -65,6 +65,23 @@ def test_every_sweep_variant_at_full_size(full_size, variant):
     assert summ["max_residual"] < 1e-12 and summ["max_solution_error"] < 1e-10, (variant, summ)
     # and the whole vector agrees with the state the default kernels produced from the same right-hand side
     assert rel(solver.ex.download(out), solver.ex.download(solver.X)) < 1e-12
+
+
+def test_fused_rhs_combination_matches_materialised_rhs(full_size):
+    """ddh_pencil_solve_lincomb (RHS formed inside the forward sweep) == lincomb kernel + ddh_pencil_solve, at the
+    benchmark size, for the 4-term combination of the second RK222 stage"""
+    solver, f, ref = full_size
+    ts = solver.timestepper
+    lu = list(ts._lus.values())[0]
+    xs = [ts.MX0, ts.F[0], ts.F[1], ts.MX[1]]
+    al = [0.3, -1.7e-3, 2.2e-3, 0.7]
+    ex = solver.ex
+    rhs, y1, y2 = (ex.empty((solver.R, solver.nx, solver.ny)) for _ in range(3))
+    ex.lincomb(rhs, xs, al)
+    solver.pack.solve(lu, rhs, y1)
+    solver.pack.solve_lincomb(lu, xs, al, y2)
+    ex.sync()
+    assert rel(ex.download(y2), ex.download(y1)) < 1e-14
 
 
 @pytest.fixture(scope="module")
