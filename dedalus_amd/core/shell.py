@@ -1726,25 +1726,26 @@ class ShellSolverBase:
             A[co * self.Nr:(co + 1) * self.Nr, ci * self.Nr:(ci + 1) * self.Nr] += m[ell]
         return A
 
-    def _inverse_terms(self, a, b):
-        """Per-ell inverse of (a M + b L) on the valid modes as a device term list (blocks of the dense inverses)."""
-        inv = np.zeros((self.nl, self.R * self.Nr, self.R * self.Nr))
-        for ell in range(self.m0, self.nl):                # ell < first local m: no local modes
-            A = a * self._dense(self.M_tl, ell) + b * self._dense(self.L_tl, ell)
-            rv = self.row_valid[:, ell, :].reshape(-1)
-            cv = self.col_valid[:, ell, :].reshape(-1)
-            if rv.sum() != cv.sum():
-                raise ValueError("ell = %d: %d valid equation modes for %d valid variable modes" % (ell, rv.sum(), cv.sum()))
-            if rv.any():
-                inv[ell][np.ix_(cv, rv)] = np.linalg.inv(A[np.ix_(rv, cv)])
-        terms = []
-        Nr = self.Nr
-        for co in range(self.R):
-            for ci in range(self.R):
-                blk = inv[:, co * Nr:(co + 1) * Nr, ci * Nr:(ci + 1) * Nr]
-                if np.any(blk != 0):
-                    terms.append((co, ci, np.ascontiguousarray(blk)))
-        return _Reshaped(self, self.ex.make_ell_terms(self.nm, self.nl, self.Nr, self.R, terms))
+    _dinv = None
+
+    def _inverse_terms(self, a, b, old=None):
+        """Per-ell inverse of (a M + b L) on the valid modes, formed and inverted on the device
+        (executor.make_dense_inverse: M_ell and L_ell are uploaded once; a change of the timestep costs no host work),
+        then applied as a term list of dense blocks."""
+        if self._dinv is None:
+            ells = range(self.nl)
+            Ms = [self._dense(self.M_tl, ell) for ell in ells]
+            Ls = [self._dense(self.L_tl, ell) for ell in ells]
+            # ell < first local m: no local modes -> everything invalid -> a zero block
+            rvs = [self.row_valid[:, ell, :].reshape(-1) & (ell >= self.m0) for ell in ells]
+            cvs = [self.col_valid[:, ell, :].reshape(-1) & (ell >= self.m0) for ell in ells]
+            for ell, (rv, cv) in enumerate(zip(rvs, cvs)):
+                if rv.sum() != cv.sum():
+                    raise ValueError("ell = %d: %d valid equation modes for %d valid variable modes" % (ell, rv.sum(), cv.sum()))
+            self._dinv = self.ex.make_dense_inverse(Ms, Ls, rvs, cvs, complex_=False)
+        flat = self._dinv.compute(a, b)
+        inner = old.dev if isinstance(old, _Reshaped) else None
+        return _Reshaped(self, self.ex.make_ell_terms_from_dense(self.nm, self.nl, self.Nr, self.R, flat, old=inner))
 
     # ---- state <-> variables -----------------------------------------------------------------------------------------
     def sync_state_to_device(self):
@@ -1861,7 +1862,8 @@ class ShellInitialValueSolver(IVPLifecycle, ShellSolverBase):
             f.require_coeff_space()
 
     def factor(self, a, b, reuse=-1):
-        inv = self._inverse_terms(a, b)
+        old = self._lus[reuse] if (reuse is not None and reuse >= 0) else None
+        inv = self._inverse_terms(a, b, old=old)
         if reuse is not None and reuse >= 0:
             self._lus[reuse] = inv
             return reuse

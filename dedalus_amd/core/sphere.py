@@ -1225,29 +1225,33 @@ class SphereSolverBase:
             A[co * ne + (ell[ok] - m), ci * ne + (src[ok] - m)] += cf[m, ell[ok]]
         return A
 
+    _dinv = None
+
     def _inverse_batch(self, a, b):
-        """Per-m inverse of (a M + b L) restricted to the valid modes, embedded with zeros elsewhere."""
+        """Per-m inverse of (a M + b L) restricted to the valid modes, embedded with zeros elsewhere: formed and
+        inverted on the device (executor.make_dense_inverse; M_m, L_m are uploaded once) and applied as one batched
+        complex GEMV."""
         nm, nl = self.basis.nm, self.basis.nl
-        mats = []
-        for m in range(nm):
-            ne = nl - m
-            n = self.R * max(ne, 0)
-            inv = np.zeros((n, n), dtype=complex)
-            if ne > 0:
-                A = a * self._dense(self.M_tl, m) + b * self._dense(self.L_tl, m)
-                rv = self.row_valid[:, m, m:].reshape(-1)
-                cv = self.col_valid[:, m, m:].reshape(-1)
-                if rv.sum() != cv.sum():
-                    raise ValueError("m = %d: %d valid equation modes for %d valid variable modes" % (m, rv.sum(), cv.sum()))
-                if rv.any():
-                    # the systems are block-banded in ell: sparse LU + identity right-hand sides, O(n^2 b) per m
-                    # instead of the O(n^3) dense inverse
-                    import scipy.sparse as sp
-                    import scipy.sparse.linalg as spla
-                    sub = sp.csc_matrix(A[np.ix_(rv, cv)])
-                    inv[np.ix_(cv, rv)] = spla.splu(sub).solve(np.eye(sub.shape[0], dtype=complex))
-            mats.append(inv)
-        return self.ex.make_cgemv_batch(nm, nl, self.R, mats)
+        if self._dinv is None:
+            Ms, Ls, rvs, cvs = [], [], [], []
+            for m in range(nm):
+                ne = max(nl - m, 0)
+                n = self.R * ne
+                if ne > 0:
+                    Ms.append(self._dense(self.M_tl, m))
+                    Ls.append(self._dense(self.L_tl, m))
+                    rv = self.row_valid[:, m, m:].reshape(-1)
+                    cv = self.col_valid[:, m, m:].reshape(-1)
+                    if rv.sum() != cv.sum():
+                        raise ValueError("m = %d: %d valid equation modes for %d valid variable modes" % (m, rv.sum(), cv.sum()))
+                else:
+                    Ms.append(np.zeros((0, 0), dtype=complex))
+                    Ls.append(np.zeros((0, 0), dtype=complex))
+                    rv = cv = np.zeros(0, dtype=bool)
+                rvs.append(rv)
+                cvs.append(cv)
+            self._dinv = self.ex.make_dense_inverse(Ms, Ls, rvs, cvs, complex_=True)
+        return self.ex.make_cgemv_batch_flat(nm, nl, self.R, self._dinv.compute(a, b))
 
     def evaluate_F(self, out):
         ex = self.ex

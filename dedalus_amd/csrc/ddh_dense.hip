@@ -1,0 +1,281 @@
+// Batched dense inversion on the device: (a M + b L)^-1 for every subproblem of the curvilinear solvers.
+//
+// The sphere's per-m and the shell's per-ell subproblem matrices (core/subsystems.py:497-596, built per subproblem
+// by the reference and factorized with SuperLU whenever a0 / b0 or k H_ii change, core/timesteppers.py:172-181,
+// 630-640, libraries/matsolvers.py:126-149) are a few hundred small dense systems here (n <= 768): a M + b L is formed
+// and inverted in place on the device -- Gauss-Jordan with partial pivoting, one workgroup per system -- so a change
+// of the timestep costs no host round trip.  Valid-mode filtering (core/subsystems.py:540-556): rows / columns that
+// carry no mode for a system are paired into unit entries before the elimination and cleared afterwards, which
+// yields exactly the inverse of the valid block embedded in zeros.
+#include "ddh_common.h"
+
+namespace ddh {
+
+template <bool CX> struct DEl;
+template <> struct DEl<false> {
+    typedef double T;
+    static __device__ __forceinline__ T zero() { return 0.0; }
+    static __device__ __forceinline__ T one() { return 1.0; }
+    static __device__ __forceinline__ double abs2(T a) { return a * a; }
+    static __device__ __forceinline__ T mul(T a, T b) { return a * b; }
+    static __device__ __forceinline__ T inv(T a) { return 1.0 / a; }
+    static __device__ __forceinline__ T neg(T a) { return -a; }
+    static __device__ __forceinline__ T fms(T c, T a, T b) { return c - a * b; }
+    static __device__ __forceinline__ T comb(T m, T l, double a, double b) { return a * m + b * l; }
+};
+template <> struct DEl<true> {
+    typedef double2 T;
+    static __device__ __forceinline__ T zero() { return make_double2(0.0, 0.0); }
+    static __device__ __forceinline__ T one() { return make_double2(1.0, 0.0); }
+    static __device__ __forceinline__ double abs2(T a) { return a.x * a.x + a.y * a.y; }
+    static __device__ __forceinline__ T mul(T a, T b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+    static __device__ __forceinline__ T inv(T a) {
+        const double d = 1.0 / (a.x * a.x + a.y * a.y);
+        return make_double2(a.x * d, -a.y * d);
+    }
+    static __device__ __forceinline__ T neg(T a) { return make_double2(-a.x, -a.y); }
+    static __device__ __forceinline__ T fms(T c, T a, T b) {
+        return make_double2(c.x - (a.x * b.x - a.y * b.y), c.y - (a.x * b.y + a.y * b.x));
+    }
+    static __device__ __forceinline__ T comb(T m, T l, double a, double b) {
+        return make_double2(a * m.x + b * l.x, a * m.y + b * l.y);
+    }
+};
+
+constexpr int DI_T = 1024;       // threads per system
+constexpr int DI_NMAX = 1024;    // largest system
+
+struct DenseSys {
+    long off;        // element offset of the n x n row-major matrix in M, L and the output
+    int n;
+    int pair0, npair;   // slice of the (invalid row, invalid column) pair lists
+};
+
+// out = (a M + b L)^-1 on the valid block, zeros elsewhere.  One workgroup per system.
+template <bool CX>
+__global__ void __launch_bounds__(DI_T)
+dense_inverse_kernel(const DenseSys *__restrict__ sys, const void *__restrict__ Mv, const void *__restrict__ Lv,
+                     double a, double b, const unsigned char *__restrict__ row_valid,
+                     const unsigned char *__restrict__ col_valid, const long *__restrict__ valid_off,
+                     const int *__restrict__ pair_r, const int *__restrict__ pair_c, void *__restrict__ outv,
+                     int *__restrict__ flags) {
+    typedef typename DEl<CX>::T E;
+    typedef DEl<CX> O;
+    const DenseSys S = sys[blockIdx.x];
+    const int n = S.n, tid = threadIdx.x;
+    if (n <= 0) return;
+    const E *M = (const E *)Mv + S.off, *L = (const E *)Lv + S.off;
+    E *A = (E *)outv + S.off;
+    const unsigned char *rv = row_valid + valid_off[blockIdx.x], *cv = col_valid + valid_off[blockIdx.x];
+    __shared__ E s_row[DI_NMAX], s_col[DI_NMAX];
+    __shared__ int s_piv[DI_NMAX];
+    __shared__ double s_best[DI_T / 64];
+    __shared__ int s_arg[DI_T / 64];
+    __shared__ int s_p;
+    __shared__ int s_bad;
+    if (tid == 0) s_bad = 0;
+    const long nn = (long)n * n;
+    // ---- assemble: a M + b L on valid rows x valid columns, zero elsewhere, unit entries pairing the invalid ones
+    for (long e = tid; e < nn; e += DI_T) {
+        const int i = (int)(e / n), j = (int)(e - (long)i * n);
+        A[e] = (rv[i] && cv[j]) ? O::comb(M[e], L[e], a, b) : O::zero();
+    }
+    __syncthreads();
+    for (int k = tid; k < S.npair; k += DI_T) A[(long)pair_r[S.pair0 + k] * n + pair_c[S.pair0 + k]] = O::one();
+    __syncthreads();
+    // ---- in-place Gauss-Jordan inversion with partial (row) pivoting
+    for (int k = 0; k < n; ++k) {
+        double best = -1.0;
+        int arg = k;
+        for (int i = k + tid; i < n; i += DI_T) {
+            const double m = O::abs2(A[(long)i * n + k]);
+            if (m > best) { best = m; arg = i; }
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const double ob = __shfl_xor(best, sft, 64);
+            const int oa = __shfl_xor(arg, sft, 64);
+            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+        }
+        if ((tid & 63) == 0) { s_best[tid >> 6] = best; s_arg[tid >> 6] = arg; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < DI_T / 64; ++w)
+                if (s_best[w] > best || (s_best[w] == best && s_arg[w] < arg)) { best = s_best[w]; arg = s_arg[w]; }
+            s_p = arg;
+            s_piv[k] = arg;
+            if (!(best > 0.0)) s_bad = 1;
+        }
+        __syncthreads();
+        const int p = s_p;
+        if (p != k) {
+            for (int j = tid; j < n; j += DI_T) {
+                const E t = A[(long)k * n + j];
+                A[(long)k * n + j] = A[(long)p * n + j];
+                A[(long)p * n + j] = t;
+            }
+        }
+        __syncthreads();
+        E piv = A[(long)k * n + k];
+        if (!(O::abs2(piv) > 0.0)) piv = O::one();
+        const E ip = O::inv(piv);
+        for (int j = tid; j < n; j += DI_T) {
+            s_row[j] = (j == k) ? ip : O::mul(A[(long)k * n + j], ip);
+            s_col[j] = (j == k) ? O::zero() : A[(long)j * n + k];
+        }
+        __syncthreads();
+        for (long e = tid; e < nn; e += DI_T) {
+            const int i = (int)(e / n), j = (int)(e - (long)i * n);
+            if (i == k) {
+                A[e] = s_row[j];
+            } else {
+                const E base = (j == k) ? O::zero() : A[e];
+                A[e] = O::fms(base, s_col[i], s_row[j]);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- undo the row interchanges as column interchanges, in reverse order
+    for (int k = n - 1; k >= 0; --k) {
+        const int p = s_piv[k];
+        if (p != k) {
+            for (int i = tid; i < n; i += DI_T) {
+                const E t = A[(long)i * n + k];
+                A[(long)i * n + k] = A[(long)i * n + p];
+                A[(long)i * n + p] = t;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // ---- the paired unit entries are not part of the inverse
+    for (int k = tid; k < S.npair; k += DI_T) A[(long)pair_c[S.pair0 + k] * n + pair_r[S.pair0 + k]] = O::zero();
+    if (tid == 0 && s_bad) flags[blockIdx.x] = 1;
+}
+
+struct DenseInverse : HandleBase {
+    int nsys = 0, cx = 0;
+    long total = 0;               // elements over all systems
+    void *d_sys = nullptr, *d_M = nullptr, *d_L = nullptr, *d_rv = nullptr, *d_cv = nullptr, *d_voff = nullptr;
+    void *d_pr = nullptr, *d_pc = nullptr, *d_flags = nullptr;
+    ~DenseInverse() override {
+        (void)hipFree(d_sys); (void)hipFree(d_M); (void)hipFree(d_L); (void)hipFree(d_rv); (void)hipFree(d_cv);
+        (void)hipFree(d_voff); (void)hipFree(d_pr); (void)hipFree(d_pc); (void)hipFree(d_flags);
+    }
+};
+
+// [nl][RN][RN] row-major inverses -> EllTerms dense storage [t = co * R + ci][ell][n_in][n_out] (transposed blocks)
+__global__ void __launch_bounds__(256)
+ell_blocks_kernel(const double *__restrict__ inv, double *__restrict__ mats, int nl, int R, int nr) {
+    const long RN = (long)R * nr;
+    const long total = (long)nl * RN * RN;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        // destination-ordered: e = ((t * nl + l) * nr + ni) * nr + no
+        const int no = (int)(e % nr);
+        const int ni = (int)((e / nr) % nr);
+        const int l = (int)((e / ((long)nr * nr)) % nl);
+        const int t = (int)(e / ((long)nr * nr * nl));
+        const int co = t / R, ci = t - co * R;
+        mats[e] = inv[((long)l * RN + (long)co * nr + no) * RN + (long)ci * nr + ni];
+    }
+}
+
+}  // namespace ddh
+
+using namespace ddh;
+
+extern "C" {
+
+int ddh_dense_inverse_create(ddh_handle *h, int nsys, const int *n_h, int is_complex, const double *M_h,
+                             const double *L_h, const unsigned char *row_valid_h, const unsigned char *col_valid_h) {
+    if (!h || nsys < 1) return fail("dense_inverse_create: bad arguments");
+    DenseInverse *p = new DenseInverse();
+    p->kind = H_DENSEINV;
+    p->nsys = nsys;
+    p->cx = is_complex ? 1 : 0;
+    std::vector<DenseSys> sys(nsys);
+    std::vector<long> voff(nsys);
+    std::vector<int> pr, pc;
+    long off = 0, vo = 0;
+    for (int s = 0; s < nsys; ++s) {
+        const int n = n_h[s];
+        if (n < 0 || n > DI_NMAX) { delete p; return fail("dense_inverse_create: system size out of range (0..1024)"); }
+        sys[s].off = off;
+        sys[s].n = n;
+        sys[s].pair0 = (int)pr.size();
+        voff[s] = vo;
+        std::vector<int> br, bc;
+        for (int i = 0; i < n; ++i) {
+            if (!row_valid_h[vo + i]) br.push_back(i);
+            if (!col_valid_h[vo + i]) bc.push_back(i);
+        }
+        if (br.size() != bc.size()) { delete p; return fail("dense_inverse_create: valid rows and columns do not balance"); }
+        for (size_t k = 0; k < br.size(); ++k) { pr.push_back(br[k]); pc.push_back(bc[k]); }
+        sys[s].npair = (int)br.size();
+        off += (long)n * n;
+        vo += n;
+    }
+    p->total = off;
+    const size_t eb = (p->cx ? 2 : 1) * sizeof(double);
+    int st = 0;
+    auto up = [&](void **d, const void *src, size_t bytes) {
+        if (st) return;
+        st = check_hip(hipMalloc(d, bytes + 16), "hipMalloc");
+        if (!st && bytes) st = check_hip(hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice), "hipMemcpy");
+    };
+    up(&p->d_sys, sys.data(), sys.size() * sizeof(DenseSys));
+    up(&p->d_M, M_h, (size_t)off * eb);
+    up(&p->d_L, L_h, (size_t)off * eb);
+    up(&p->d_rv, row_valid_h, (size_t)vo);
+    up(&p->d_cv, col_valid_h, (size_t)vo);
+    up(&p->d_voff, voff.data(), voff.size() * sizeof(long));
+    up(&p->d_pr, pr.data(), pr.size() * sizeof(int));
+    up(&p->d_pc, pc.data(), pc.size() * sizeof(int));
+    if (!st) st = check_hip(hipMalloc(&p->d_flags, (size_t)nsys * sizeof(int)), "hipMalloc");
+    if (st) { delete p; return st; }
+    *h = register_handle(p);
+    return 0;
+}
+
+int ddh_dense_inverse_elements(ddh_handle h, long *count) {
+    DenseInverse *p = (DenseInverse *)lookup_handle(h, H_DENSEINV);
+    if (!p) return -1;
+    *count = p->total * (p->cx ? 2 : 1);
+    return 0;
+}
+
+int ddh_dense_inverse_compute(ddh_handle h, double a, double b, double *out_d, int *nsingular_h, void *stream) {
+    DenseInverse *p = (DenseInverse *)lookup_handle(h, H_DENSEINV);
+    if (!p) return -1;
+    hipStream_t s = as_stream(stream);
+    DDH_HIP(hipMemsetAsync(p->d_flags, 0, (size_t)p->nsys * sizeof(int), s));
+    if (p->cx)
+        hipLaunchKernelGGL(dense_inverse_kernel<true>, dim3((unsigned)p->nsys), dim3(DI_T), 0, s, (const DenseSys *)p->d_sys,
+                           p->d_M, p->d_L, a, b, (const unsigned char *)p->d_rv, (const unsigned char *)p->d_cv,
+                           (const long *)p->d_voff, (const int *)p->d_pr, (const int *)p->d_pc, (void *)out_d,
+                           (int *)p->d_flags);
+    else
+        hipLaunchKernelGGL(dense_inverse_kernel<false>, dim3((unsigned)p->nsys), dim3(DI_T), 0, s, (const DenseSys *)p->d_sys,
+                           p->d_M, p->d_L, a, b, (const unsigned char *)p->d_rv, (const unsigned char *)p->d_cv,
+                           (const long *)p->d_voff, (const int *)p->d_pr, (const int *)p->d_pc, (void *)out_d,
+                           (int *)p->d_flags);
+    DDH_HIP(hipGetLastError());
+    if (nsingular_h) {
+        std::vector<int> f(p->nsys);
+        DDH_HIP(hipMemcpyAsync(f.data(), p->d_flags, (size_t)p->nsys * sizeof(int), hipMemcpyDeviceToHost, s));
+        DDH_HIP(hipStreamSynchronize(s));
+        int c = 0;
+        for (int v : f) c += v ? 1 : 0;
+        *nsingular_h = c;
+    }
+    return 0;
+}
+
+int ddh_ell_blocks_from_dense(const double *inv_d, double *mats_d, int nl, int ncomp, int nr, void *stream) {
+    if (nl < 1 || ncomp < 1 || nr < 1) return fail("ell_blocks_from_dense: bad sizes");
+    hipLaunchKernelGGL(ell_blocks_kernel, dim3(4096), dim3(256), 0, as_stream(stream), inv_d, mats_d, nl, ncomp, nr);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -568,11 +568,68 @@ int ddh_cgemv_batch_create(ddh_handle *h, int nm, int nl, int ncomp, const doubl
     if (check_hip(hipMalloc((void **)&p->d_off, off.size() * sizeof(long)), "hipMalloc") ||
         check_hip(hipMalloc((void **)&p->d_mats, p->bytes ? p->bytes : 16), "hipMalloc") ||
         check_hip(hipMemcpy(p->d_off, off.data(), off.size() * sizeof(long), hipMemcpyHostToDevice), "hipMemcpy") ||
-        (p->bytes && check_hip(hipMemcpy(p->d_mats, mats_h, p->bytes, hipMemcpyHostToDevice), "hipMemcpy"))) {
+        (p->bytes && mats_h && check_hip(hipMemcpy(p->d_mats, mats_h, p->bytes, hipMemcpyHostToDevice), "hipMemcpy"))) {
         delete p;
         return -2;
     }
     *h = register_handle(p);
+    return 0;
+}
+
+int ddh_cgemv_batch_mats(ddh_handle h, double **mats_d) {
+    CgemvBatch *p = (CgemvBatch *)lookup_handle(h, H_CGEMV);
+    if (!p) return -1;
+    *mats_d = (double *)p->d_mats;
+    return 0;
+}
+
+int ddh_ell_terms_create_dense(ddh_handle *h, int nm, int nl, int nr, int ncomp) {
+    if (nm < 1 || nl < 1 || nr < 1 || ncomp < 1) return fail("ell_terms_create_dense: bad sizes");
+    if (nr % EG_K || (ncomp * nr) % EG_M) return fail("ell_terms_create_dense: sizes do not tile the GEMM kernel");
+    EllTerms *p = new EllTerms();
+    p->kind = H_ELLT;
+    p->nm = nm; p->nl = nl; p->nr = nr; p->ncomp_out = ncomp; p->ncomp_in = ncomp; p->nterms = ncomp * ncomp; p->nmat = nl;
+    p->dense = 1;
+    std::vector<int> tmap((size_t)ncomp * ncomp);
+    for (int t = 0; t < ncomp * ncomp; ++t) tmap[t] = t;
+    const size_t mb = (size_t)ncomp * ncomp * nl * nr * nr * sizeof(double);
+    if (check_hip(hipMalloc((void **)&p->d_tmap, tmap.size() * sizeof(int)), "hipMalloc") ||
+        check_hip(hipMemcpy(p->d_tmap, tmap.data(), tmap.size() * sizeof(int), hipMemcpyHostToDevice), "hipMemcpy") ||
+        check_hip(hipMalloc((void **)&p->d_mats, mb), "hipMalloc") || check_hip(hipMemset(p->d_mats, 0, mb), "hipMemset")) {
+        delete p;
+        return -2;
+    }
+    *h = register_handle(p);
+    return 0;
+}
+
+// tmap[t] = t when block t has a non-zero entry for some ell, else -1 (the GEMM skips it); one workgroup per block
+__global__ void __launch_bounds__(256) ell_prune_kernel(const double *__restrict__ mats, int *__restrict__ tmap, long per) {
+    __shared__ int s_any;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    const double *b = mats + (long)blockIdx.x * per;
+    int any = 0;
+    for (long i = threadIdx.x; i < per; i += 256) any |= (b[i] != 0.0);
+    if (any) s_any = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) tmap[blockIdx.x] = s_any ? (int)blockIdx.x : -1;
+}
+
+int ddh_ell_terms_prune(ddh_handle h, void *stream) {
+    EllTerms *p = (EllTerms *)lookup_handle(h, H_ELLT);
+    if (!p) return -1;
+    if (!p->dense || p->nterms != p->ncomp_out * p->ncomp_in) return fail("ell_terms_prune: all-blocks dense handles only");
+    hipLaunchKernelGGL(ell_prune_kernel, dim3((unsigned)p->nterms), dim3(256), 0, as_stream(stream), p->d_mats, p->d_tmap,
+                       (long)p->nmat * p->nr * p->nr);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_ell_terms_mats(ddh_handle h, double **mats_d) {
+    EllTerms *p = (EllTerms *)lookup_handle(h, H_ELLT);
+    if (!p) return -1;
+    *mats_d = p->d_mats;
     return 0;
 }
 

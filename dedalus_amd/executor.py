@@ -281,6 +281,37 @@ class HipExecutor:
         """mats: per m a complex (n_m, n_m) array, n_m = ncomp * max(nl - m, 0)."""
         return CgemvBatch(self, nm, nl, ncomp, mats)
 
+    # ---- device factorization of the curvilinear subproblems (csrc/ddh_dense.hip) ------------------------------------
+    def make_dense_inverse(self, Ms, Ls, row_valid, col_valid, complex_=False):
+        """Ms / Ls: per system the dense matrices of M and L; row_valid / col_valid: per system boolean masks.
+        -> object with compute(a, b): concatenated (a M + b L)^-1 on the valid blocks, on the device."""
+        return DenseInverse(self, Ms, Ls, row_valid, col_valid, complex_)
+
+    def make_cgemv_batch_flat(self, nm, nl, ncomp, flat):
+        """per-m complex matrices given as one concatenated device array (DenseInverse.compute)"""
+        batch = CgemvBatch(self, nm, nl, ncomp, None)
+        dst = C.c_void_p()
+        libhip.call("ddh_cgemv_batch_mats", batch.handle, C.byref(dst))
+        libhip.call("ddh_memcpy_d2d", dst, ptr(flat), int(flat.numel()) * 8, self.dev.stream)
+        batch.nbytes = int(flat.numel()) * 8
+        return batch
+
+    def make_ell_terms_from_dense(self, nm, nl, nr, ncomp, flat, old=None):
+        """Term list of the per-ell dense blocks of `flat` = [nl][ncomp nr][ncomp nr] (device): the per-ell LHS inverses.
+        Sizes that tile the FP64 MFMA GEMM stay on the device end to end (old: a handle of the same shape to refill)."""
+        if nr % 64 == 0 and (ncomp * nr) % 64 == 0:
+            terms = old if isinstance(old, DenseEllTerms) else DenseEllTerms(self, nm, nl, nr, ncomp)
+            terms.fill(flat)
+            return terms
+        inv = self.download(flat).reshape(nl, ncomp * nr, ncomp * nr)
+        blocks = []
+        for co in range(ncomp):
+            for ci in range(ncomp):
+                blk = inv[:, co * nr:(co + 1) * nr, ci * nr:(ci + 1) * nr]
+                if np.any(blk != 0):
+                    blocks.append((co, ci, np.ascontiguousarray(blk)))
+        return self.make_ell_terms(nm, nl, nr, ncomp, blocks)
+
     def make_pack(self, nf, nrows, nx, ny, kx, ky, mx_offset=0):
         pk = PencilPack(self.dev, nf, nrows, nx, ny, kx, ky, mx_offset)
         pk.executor = self
@@ -407,13 +438,81 @@ class EllTerms:
             pass
 
 
+class DenseInverse:
+    """ddh_dense_inverse_*: M and L of every subproblem live on the device; compute(a, b) forms and inverts a M + b L
+    there (no host linear algebra, no host round trip when the timestep changes)."""
+
+    def __init__(self, ex, Ms, Ls, row_valid, col_valid, complex_):
+        self.ex, self.cx = ex, bool(complex_)
+        dt = np.complex128 if self.cx else np.float64
+        n = np.ascontiguousarray([a.shape[0] for a in Ms], dtype=np.int32)
+        cat = lambda mats: np.concatenate([np.ascontiguousarray(a, dtype=dt).ravel() for a in mats] + [np.zeros(0, dtype=dt)])
+        M, L = cat(Ms), cat(Ls)
+        rv = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.uint8).ravel() for v in row_valid] + [np.zeros(0, np.uint8)]))
+        cv = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.uint8).ravel() for v in col_valid] + [np.zeros(0, np.uint8)]))
+        self.handle = C.c_uint64(0)
+        libhip.call("ddh_dense_inverse_create", C.byref(self.handle), len(n), libhip.as_ip(n), int(self.cx),
+                    libhip.as_dp(M.view(np.float64)) if M.size else None, libhip.as_dp(L.view(np.float64)) if L.size else None,
+                    libhip.as_ubp(rv), libhip.as_ubp(cv))
+        cnt = C.c_long(0)
+        libhip.call("ddh_dense_inverse_elements", self.handle, C.byref(cnt))
+        self.count = cnt.value
+        self._out = None
+
+    def compute(self, a, b):
+        if self._out is None:
+            self._out = self.ex.dev.empty((max(self.count, 1),))
+        bad = C.c_int(0)
+        libhip.call("ddh_dense_inverse_compute", self.handle, float(a), float(b), ptr(self._out), C.byref(bad),
+                    self.ex.dev.stream)
+        if bad.value:
+            raise libhip.DdhError("%d subproblem matrices are singular (a = %g, b = %g)" % (bad.value, a, b))
+        return self._out
+
+    def __del__(self):
+        try:
+            libhip.call("ddh_destroy", self.handle)
+        except Exception:
+            pass
+
+
+class DenseEllTerms:
+    """All ncomp x ncomp dense blocks per ell (the shell's LHS inverses) applied as FP64 MFMA GEMMs; filled on the
+    device from DenseInverse.compute (ddh_ell_blocks_from_dense), blocks that vanish for every ell are skipped."""
+    dense_part = None
+
+    def __init__(self, ex, nm, nl, nr, ncomp):
+        self.ex, self.nl, self.nr, self.ncomp = ex, int(nl), int(nr), int(ncomp)
+        self.handle = C.c_uint64(0)
+        libhip.call("ddh_ell_terms_create_dense", C.byref(self.handle), int(nm), int(nl), int(nr), int(ncomp))
+
+    def fill(self, flat):
+        dst = C.c_void_p()
+        libhip.call("ddh_ell_terms_mats", self.handle, C.byref(dst))
+        libhip.call("ddh_ell_blocks_from_dense", ptr(flat), dst, self.nl, self.ncomp, self.nr, self.ex.dev.stream)
+        libhip.call("ddh_ell_terms_prune", self.handle, self.ex.dev.stream)
+
+    def apply(self, x, y):
+        libhip.call("ddh_ell_terms_apply", self.handle, ptr(x), ptr(y), self.ex.dev.stream)
+
+    def __del__(self):
+        try:
+            libhip.call("ddh_destroy", self.handle)
+        except Exception:
+            pass
+
+
 class CgemvBatch:
     def __init__(self, ex, nm, nl, ncomp, mats):
         self.ex = ex
+        self.handle = C.c_uint64(0)
+        if mats is None:                    # storage only: filled on the device (make_cgemv_batch_flat)
+            self.nbytes = 0
+            libhip.call("ddh_cgemv_batch_create", C.byref(self.handle), int(nm), int(nl), int(ncomp), None)
+            return
         flat = np.concatenate([np.ascontiguousarray(a, dtype=np.complex128).ravel() for a in mats] +
                               [np.zeros(0, dtype=np.complex128)])
         self.nbytes = flat.nbytes
-        self.handle = C.c_uint64(0)
         libhip.call("ddh_cgemv_batch_create", C.byref(self.handle), int(nm), int(nl), int(ncomp),
                     libhip.as_dp(flat.view(np.float64)) if flat.size else None)
 

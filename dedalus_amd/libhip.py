@@ -62,6 +62,14 @@ SIGNATURES = {
     "ddh_cgemv_batch_apply": [_h, _vp, _vp, _vp],
     "ddh_ell_terms_create": [_hp, _i, _i, _i, _i, _i, _ip, _ip, _i, _dp, _ip],
     "ddh_ell_terms_apply": [_h, _vp, _vp, _vp],
+    "ddh_dense_inverse_create": [_hp, _i, _ip, _i, _dp, _dp, C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte)],
+    "ddh_dense_inverse_elements": [_h, C.POINTER(_l)],
+    "ddh_dense_inverse_compute": [_h, _d, _d, _vp, _ip, _vp],
+    "ddh_cgemv_batch_mats": [_h, C.POINTER(_vp)],
+    "ddh_ell_terms_create_dense": [_hp, _i, _i, _i, _i],
+    "ddh_ell_terms_mats": [_h, C.POINTER(_vp)],
+    "ddh_ell_terms_prune": [_h, _vp],
+    "ddh_ell_blocks_from_dense": [_vp, _vp, _i, _i, _i, _vp],
     "ddh_ell_terms_apply_acc": [_h, _vp, _vp, _i, _vp],
     "ddh_rfft_forward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward": [_h, _vp, _vp, _l, _l, _vp],

@@ -170,6 +170,29 @@ int ddh_ell_terms_apply(ddh_handle h, const double *x, double *y, void *stream);
  * split into its banded part (first, writes y) and its dense blocks (second, accumulates).              */
 int ddh_ell_terms_apply_acc(ddh_handle h, const double *x, double *y, int accumulate, void *stream);
 
+/* ---- device factorization of the curvilinear subproblems (SURVEY 8a row a9 for configs S and H) ------------------
+ * (a M + b L)^-1 for a batch of small dense systems (n <= 1024), real or complex, formed and inverted ON THE DEVICE
+ * (in-place Gauss-Jordan with partial pivoting, one workgroup per system): replaces the per-subproblem SuperLU
+ * factorizations the reference repeats whenever a0 / b0 or k H_ii change (core/timesteppers.py:172-181, 630-640,
+ * libraries/matsolvers.py:126-149).  M_h / L_h: the nsys row-major n_s x n_s matrices concatenated (complex:
+ * interleaved re, im); row_valid_h / col_valid_h: concatenated per-system 0/1 masks of the equation / variable modes a
+ * system really has (valid-mode filtering, core/subsystems.py:540-556) -- the result is the inverse of the valid block
+ * embedded in zeros.  compute() writes all inverses, concatenated like the inputs, to out_d (device);
+ * nsingular_h (nullable; forces a stream sync) counts systems that hit a zero pivot.                            */
+int ddh_dense_inverse_create(ddh_handle *h, int nsys, const int *n_h, int is_complex, const double *M_h,
+                             const double *L_h, const unsigned char *row_valid_h, const unsigned char *col_valid_h);
+int ddh_dense_inverse_elements(ddh_handle h, long *count_doubles);
+int ddh_dense_inverse_compute(ddh_handle h, double a, double b, double *out_d, int *nsingular_h, void *stream);
+/* Consumers of those inverses.  ddh_cgemv_batch_create accepts mats_h = NULL (storage only); ddh_cgemv_batch_mats gives
+ * the device address of its matrices, the layout ddh_dense_inverse_compute writes for systems ordered by m.
+ * ddh_ell_terms_create_dense makes a term list of all ncomp x ncomp dense blocks (FP64 MFMA GEMM path) without host
+ * data; ddh_ell_blocks_from_dense fills its storage (ddh_ell_terms_mats) from per-ell inverses [nl][ncomp nr][ncomp nr]. */
+int ddh_cgemv_batch_mats(ddh_handle h, double **mats_d);
+int ddh_ell_terms_create_dense(ddh_handle *h, int nm, int nl, int nr, int ncomp);
+int ddh_ell_terms_mats(ddh_handle h, double **mats_d);
+int ddh_ell_blocks_from_dense(const double *inv_d, double *mats_d, int nl, int ncomp, int nr, void *stream);
+int ddh_ell_terms_prune(ddh_handle h, void *stream);      /* drop blocks that are zero for every ell from the GEMM */
+
 /* ---- grid-space and vector kernels -------------------------------- */
 /* y[idx[i]] += vals[i] for n distinct indices (device arrays): the constant right-hand-side entries
  * (e.g. "b(z=0) = Lz", gathered into F by gather_outputs core/timesteppers.py:611-614) touch a handful of

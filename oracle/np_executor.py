@@ -300,5 +300,43 @@ class NumpyExecutor:
                 np_swsh.backward_reduced(c, g, groups, {int(m): a for m, a in zip(ms, bwd_mats)})
         return _Plan()
 
+    def make_dense_inverse(self, Ms, Ls, row_valid, col_valid, complex_=False):
+        """The reference's per-subproblem solver restated as explicit inverses of the valid blocks
+        (libraries/matsolvers.py:126-149 on the matrices of core/subsystems.py:497-596, valid modes :540-556)."""
+        Ms = [np.asarray(a) for a in Ms]
+        Ls = [np.asarray(a) for a in Ls]
+
+        class _Inv:
+            def compute(self_, a, b):
+                outs = []
+                for M, L, rv, cv in zip(Ms, Ls, row_valid, col_valid):
+                    rv, cv = np.asarray(rv, dtype=bool).ravel(), np.asarray(cv, dtype=bool).ravel()
+                    inv = np.zeros(M.shape, dtype=(complex if complex_ else float))
+                    if rv.any():
+                        A = a * M + b * L
+                        if complex_:
+                            import scipy.sparse as sp
+                            import scipy.sparse.linalg as spla
+                            sub = sp.csc_matrix(A[np.ix_(rv, cv)])
+                            inv[np.ix_(cv, rv)] = spla.splu(sub).solve(np.eye(sub.shape[0], dtype=complex))
+                        else:
+                            inv[np.ix_(cv, rv)] = np.linalg.inv(A[np.ix_(rv, cv)])
+                    outs.append(inv)
+                return outs
+        return _Inv()
+
+    def make_cgemv_batch_flat(self, nm, nl, ncomp, mats):
+        return self.make_cgemv_batch(nm, nl, ncomp, mats)
+
+    def make_ell_terms_from_dense(self, nm, nl, nr, ncomp, mats, old=None):
+        inv = np.array(mats)
+        blocks = []
+        for co in range(ncomp):
+            for ci in range(ncomp):
+                blk = inv[:, co * nr:(co + 1) * nr, ci * nr:(ci + 1) * nr]
+                if np.any(blk != 0):
+                    blocks.append((co, ci, np.ascontiguousarray(blk)))
+        return self.make_ell_terms(nm, nl, nr, ncomp, blocks)
+
     def make_pack(self, nf, nrows, nx, ny, kx, ky, mx_offset=0):
         return _NpPack(nf, nrows, nx, ny, kx, ky, mx_offset)

@@ -44,6 +44,20 @@ def run_sphere(name, kw, warm, steps):
     solver.ex.sync()
     el = time.time() - t0
     print("%-28s %8.1f steps/s  (%.3f ms/step, %d steps)" % (name, steps / el, 1e3 * el / steps, steps), flush=True)
+    refactor_time(name, solver, dt, el / steps)
+
+
+def refactor_time(name, solver, dt, step_s):
+    """cost of a timestep change: the LHS of every subproblem is re-formed and re-factored on the device"""
+    ts = []
+    for k in range(3):
+        solver.ex.sync()
+        t0 = time.time()
+        solver.step(dt * (1.0 + 0.01 * (k + 1)))
+        solver.ex.sync()
+        ts.append(time.time() - t0 - step_s)
+    print("%-34s refactorization on a timestep change: %.1f ms (min of 3; step time subtracted)" % (name, 1e3 * min(ts)),
+          flush=True)
 
 
 def run_shell(name, kw, dt, warm, steps):
@@ -74,6 +88,8 @@ def run_shell(name, kw, dt, warm, steps):
     if int(os.environ.get("RANK", "0")) == 0:
         print("%-34s %8.2f steps/s  (%.2f ms/step, %d steps)  |b_c| = %.12f finite=%s" % (
             name, steps / el, 1e3 * el / steps, steps, np.sqrt(nrm2), bool(np.isfinite(b).all())), flush=True)
+    if world == 1:
+        refactor_time(name, solver, dt, el / steps)
 
 
 if __name__ == "__main__":
