@@ -453,6 +453,9 @@ class SolverBase:
         """out = (a M + b L)^-1 rhs  through the recombined band factorization: X = P Y."""
         if self.P_id is None:
             self.pack.solve(lu, rhs, out)
+        elif hasattr(self.pack, "solve_recombined"):
+            Y = self.ex.empty((self.R, self.nx, self.ny))
+            self.pack.solve_recombined(lu, [rhs], [1.0], self.P_id, Y, out)
         else:
             Y = self.ex.empty((self.R, self.nx, self.ny))
             self.pack.solve(lu, rhs, Y)
@@ -474,6 +477,9 @@ class SolverBase:
             return self.solve(lu, rhs, out)
         if self.P_id is None:
             self.pack.solve_lincomb(lu, xs, alphas, out)
+        elif hasattr(self.pack, "solve_recombined"):
+            Y = self.ex.empty((self.R, self.nx, self.ny))
+            self.pack.solve_recombined(lu, xs, alphas, self.P_id, Y, out)
         else:
             Y = self.ex.empty((self.R, self.nx, self.ny))
             self.pack.solve_lincomb(lu, xs, alphas, Y)

@@ -84,7 +84,12 @@ struct LuDev {
     const int *rowperm, *colperm;  // logical -> physical
     const unsigned char *row_axes, *col_axes;   // per logical border row / col: validity bits
     const unsigned char *row_code, *col_code;   // real mode, per logical row / col: bit0 rotate by i, bit1 sign for -kx
+    // column recombination X = P Y fused into the backward sweep (ddh_pencil_solve_recombined): P in logical (graded)
+    // ordering is unit upper banded, pband[j * PBW + d - 1] = P[j, j + d], d = 1..PBW; null = not fused
+    const double *pband;
 };
+
+constexpr int PBW = 12;
 
 struct LuFactor {
     LuDev dev;
@@ -97,6 +102,10 @@ struct LuFactor {
     void *d_flag_cells = nullptr;   // long[nflagcells]
     void *d_inv = nullptr;          // double2 [nflagcells*S][N][N]
     void *d_dense_rhs = nullptr;    // double2 [nflagcells*S][N]
+    std::vector<int> colperm_h;             // logical -> physical columns (host copy)
+    std::vector<unsigned char> ccode_h;     // grading codes of the logical columns (real mode)
+    void *d_pband = nullptr;                // [n][PBW] band of the recombination, see LuDev::pband
+    int pband_mat = -1;                     // matrix id it was built from
 };
 
 struct PencilPack : HandleBase {
@@ -130,6 +139,7 @@ static void free_lu(LuFactor *lu) {
     (void)hipFree(lu->d_flag_cells);
     (void)hipFree(lu->d_inv);
     (void)hipFree(lu->d_dense_rhs);
+    (void)hipFree(lu->d_pband);
     delete lu;
 }
 
@@ -869,7 +879,7 @@ solve_forward_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__restrict_
     }
 }
 
-template <int NF, int WT, bool REAL, bool PREF>
+template <int NF, int WT, bool REAL, bool PREF, bool PFUSE = false>
 __global__ void __launch_bounds__(256)
 solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     typedef typename El<REAL>::T E;
@@ -909,8 +919,7 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         for (int d = 0; d <= WT; ++d)
             if (d <= W) u[d] = Ur[(long)d << 6];
     };
-    auto emit = [&](int j, double2 xj) {
-        double2 v = xj;
+    auto emit = [&](int j, double2 v) {
         if (REAL) {
             const unsigned char code = s_code[j];
             if (code & 1) v = make_double2(-v.y, v.x);
@@ -918,14 +927,23 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         }
         store_sys<NF>(xout, plane, s_perm[j], P, c, s, v);
     };
-    // rows are processed in pairs; the register window is shifted once per pair (by two)
+    // rows are processed in pairs; the register window is shifted once per pair (by two).  With PFUSE the emitted value
+    // is the recombined unknown x_j = y_j + sum_d P[j, j + d] y_(j + d) (the window already holds y_(j+1..)): the
+    // band coefficients are the same for every system -> scalar loads.
     auto row_even = [&](int j, const E *u, double2 y) -> double2 {
         double2 acc = y;
 #pragma unroll
         for (int d = 0; d < WT; ++d)
             if (d < W) El<REAL>::fms2(acc, u[d + 1], win[d]);
         const double2 xj = El<REAL>::mul2(acc, u[0]);   // reciprocal pivot stored on the diagonal
-        emit(j, xj);
+        double2 v = xj;
+        if (PFUSE) {
+            const double *pr = L.pband + (long)j * PBW;
+#pragma unroll
+            for (int d = 0; d < PBW; ++d)
+                if (d < WT) { v.x += pr[d] * win[d].x; v.y += pr[d] * win[d].y; }
+        }
+        emit(j, v);
         return xj;
     };
     auto row_odd = [&](int j, const E *u, double2 y, double2 xprev) {
@@ -935,7 +953,16 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         for (int d = 1; d < WT; ++d)
             if (d < W) El<REAL>::fms2(acc, u[d + 1], win[d - 1]);
         const double2 xj = El<REAL>::mul2(acc, u[0]);
-        emit(j, xj);
+        double2 v = xj;
+        if (PFUSE) {
+            const double *pr = L.pband + (long)j * PBW;
+            v.x += pr[0] * xprev.x;
+            v.y += pr[0] * xprev.y;
+#pragma unroll
+            for (int d = 1; d < PBW; ++d)
+                if (d - 1 < WT) { v.x += pr[d] * win[d - 1].x; v.y += pr[d] * win[d - 1].y; }
+        }
+        emit(j, v);
 #pragma unroll
         for (int d = WT - 1; d > 1; --d) win[d] = win[d - 2];
         win[1] = xprev;
@@ -1269,7 +1296,7 @@ dense_apply_kernel(int N, const double2 *__restrict__ inv, const double2 *__rest
 template <int NF>
 __global__ void __launch_bounds__(256)
 dense_scatter_kernel(PencilDev P, LuDev L, const long *__restrict__ cells, int ncellsf,
-                     const double2 *__restrict__ xin, double *__restrict__ xout) {
+                     const double2 *__restrict__ xin, double *__restrict__ xout, int apply_p) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long per = (long)L.N * P.S;
     if (t >= per * ncellsf) return;
@@ -1277,7 +1304,15 @@ dense_scatter_kernel(PencilDev P, LuDev L, const long *__restrict__ cells, int n
     const int i = (int)((t % per) / P.S);
     const int s = (int)(t % P.S);
     const CellCtx c = cell_ctx(P, cells[f]);
-    store_sys<NF>(xout, P.nx * P.ny, L.colperm[i], P, c, s, xin[(f * P.S + s) * L.N + i]);
+    const double2 *xs = xin + (f * P.S + s) * L.N;
+    double2 v = xs[i];
+    if (apply_p && L.pband && i < L.n) {
+        // (the dense inverse is the plain complex inverse in logical ordering: P is the same real band there)
+        const double *pr = L.pband + (long)i * PBW;
+        for (int d = 1; d <= PBW; ++d)
+            if (i + d < L.n) { v.x += pr[d - 1] * xs[i + d].x; v.y += pr[d - 1] * xs[i + d].y; }
+    }
+    store_sys<NF>(xout, P.nx * P.ny, L.colperm[i], P, c, s, v);
 }
 
 template <typename T>
@@ -1289,7 +1324,7 @@ static int upload_vec(void **dptr, const T *src, size_t count) {
 
 // dense fallback for the flagged pencils (after either sweep variant)
 template <int NF>
-static int finish_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double *x, hipStream_t s) {
+static int finish_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double *x, hipStream_t s, int apply_p) {
     const PencilDev &P = pp->dev;
     const LuDev &d = lu->dev;
     if (lu->nflag) {
@@ -1304,16 +1339,20 @@ static int finish_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
         hipLaunchKernelGGL(dense_apply_kernel, dim3((unsigned)((d.N + 3) / 4), (unsigned)nsys), dim3(256), 0, s, d.N,
                            (const double2 *)lu->d_inv, (const double2 *)drhs, dx);
         hipLaunchKernelGGL(dense_scatter_kernel<NF>, dim3(gb), dim3(256), 0, s, P, d, (const long *)lu->d_flag_cells,
-                           lu->nflag, (const double2 *)dx, x);
+                           lu->nflag, (const double2 *)dx, x, apply_p);
         DDH_HIP(hipGetLastError());
     }
     return 0;
 }
 
+// want_p: the caller asks for x = P y (recombination fused into the backward sweep); *did_p tells whether this launch
+// could do it (one-thread-per-system backward kernel of the real-graded 2-axis path with a band table on file).
 template <int NF>
-static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double *x, hipStream_t s) {
+static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double *x, hipStream_t s, bool want_p = false,
+                        bool *did_p = nullptr) {
     const PencilDev &P = pp->dev;
     const LuDev &d = lu->dev;
+    if (did_p) *did_p = false;
     const unsigned blocks = (unsigned)((P.G + 255) / 256);
     const int W = d.W;
     const size_t lds_f = (size_t)(d.N + d.nb) * 5 + 16, lds_b = (size_t)(d.n > 0 ? d.n : 1) * 5 + 16;
@@ -1395,15 +1434,27 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
             hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
     }
     // (window sizes: few instantiations -- every one is a fully unrolled kernel and this file dominates the build time)
-    if (d.n > 0 && !cb) {
+    bool fuse_p = false;
+    if constexpr (NF == 2) fuse_p = want_p && d.real && d.pband != nullptr && d.n > 0 && !cb && W <= 48;
+#define DDH_SOLVE_P(WTV)                                                                                           \
+    hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false, true>), dim3(blocks), dim3(256), lds_b, s, P, d, x);
+    if (fuse_p) {
+        if constexpr (NF == 2) {
+            if (W <= 32) DDH_SOLVE_P(32)
+            else if (W <= 34) DDH_SOLVE_P(34)
+            else DDH_SOLVE_P(48)
+        }
+    } else if (d.n > 0 && !cb) {
         if (W <= 32) DDH_SOLVE(32)
         else if (W <= 34) DDH_SOLVE(34)
         else if (W <= 48) DDH_SOLVE(48)
         else DDH_SOLVE(64)
     }
+#undef DDH_SOLVE_P
 #undef DDH_SOLVE
     DDH_HIP(hipGetLastError());
-    return finish_solve<NF>(pp, lu, rhs, x, s);
+    if (did_p) *did_p = fuse_p;
+    return finish_solve<NF>(pp, lu, rhs, x, s, fuse_p ? 1 : 0);
 }
 
 
@@ -1686,6 +1737,9 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
         if (!st) st = check_hip(hipMalloc((void **)&d.scratch, szScr), "hipMalloc(scratch)");
         if (!st) st = upload_vec(&lu->d_rowperm, row_perm_h, (size_t)N);
         if (!st) st = upload_vec(&lu->d_colperm, col_perm_h, (size_t)N);
+        lu->colperm_h.assign(col_perm_h, col_perm_h + N);
+        if (real) lu->ccode_h.assign(col_code_h, col_code_h + N);
+        d.pband = nullptr;
         if (!st) st = upload_vec(&lu->d_raxes, row_axes_h + n, (size_t)nb);
         if (!st) st = upload_vec(&lu->d_caxes, col_axes_h + n, (size_t)nb);
         if (!st && real) st = upload_vec(&lu->d_rcode, row_code_h, (size_t)N);
@@ -1829,6 +1883,90 @@ int ddh_pencil_solve_lincomb(ddh_handle pack, int lu_id, int nterms, const doubl
     if (pp->dev.nf == 2) return launch_solve<2>(pp, lu, r, x, s);
     if (pp->dev.nf == 1) return launch_solve<1>(pp, lu, r, x, s);
     return launch_solve<0>(pp, lu, r, x, s);
+}
+
+// band table of the recombination matrix P (a registered constant real matrix) in the logical ordering of an LU;
+// returns 0 and leaves lu->dev.pband null when P cannot be fused (not unit upper banded within PBW, complex or
+// wavenumber-dependent entries, differing grading codes, border columns)
+static int build_pband(PencilPack *pp, LuFactor *lu, int p_mat_id) {
+    LuDev &d = lu->dev;
+    if (lu->pband_mat == p_mat_id && lu->d_pband) { d.pband = (const double *)lu->d_pband; return 0; }
+    d.pband = nullptr;
+    lu->pband_mat = p_mat_id;
+    if (!d.real || d.n <= 0 || lu->colperm_h.empty()) return 0;
+    const Matrix *m = pp->mats[p_mat_id];
+    const int N = d.N, n = d.n;
+    if (m->dev.nrows_out != N) return 0;
+    std::vector<int> cinv(N, -1);
+    for (int i = 0; i < N; ++i) cinv[lu->colperm_h[i]] = i;
+    std::vector<double> band((size_t)n * PBW, 0.0);
+    std::vector<char> diag(N, 0);
+    for (size_t t = 0; t < m->row_h.size(); ++t) {
+        const int r = cinv[m->row_h[t]], c = cinv[m->col_h[t]];
+        const double2 cf = m->coef_h[t];
+        if (m->expo_h[t] != 0 || cf.y != 0.0) return 0;
+        if (r == c) {
+            if (cf.x != 1.0 || diag[r]) return 0;
+            diag[r] = 1;
+            continue;
+        }
+        if (r >= n || c >= n || c < r || c - r > PBW) return 0;
+        if (lu->ccode_h[r] != lu->ccode_h[c]) return 0;
+        band[(size_t)r * PBW + (c - r - 1)] += cf.x;
+    }
+    for (int i = 0; i < N; ++i)
+        if (!diag[i]) return 0;
+    if (!lu->d_pband) DDH_HIP(hipMalloc(&lu->d_pband, band.size() * sizeof(double) + 16));
+    DDH_HIP(hipMemcpy(lu->d_pband, band.data(), band.size() * sizeof(double), hipMemcpyHostToDevice));
+    d.pband = (const double *)lu->d_pband;
+    return 0;
+}
+
+int ddh_pencil_solve_recombined(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h,
+                                const double *alpha_h, int p_mat_id, double *work, double *x, void *stream) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_solve: bad LU id");
+    if (p_mat_id < 0 || p_mat_id >= (int)pp->mats.size()) return fail("pencil_solve_recombined: bad matrix id");
+    if (nterms < 1 || nterms > RHS_MAX) return fail("pencil_solve_recombined: 1 to 8 right-hand-side terms");
+    if (work == x || !work) return fail("pencil_solve_recombined: work and x must be distinct buffers");
+    RhsSrc r;
+    memset(&r, 0, sizeof(r));
+    r.n = nterms;
+    for (int t = 0; t < nterms; ++t) {
+        if (xs_h[t] == x || xs_h[t] == work) return fail("pencil_solve: in-place unsupported");
+        r.p[t] = xs_h[t];
+        r.a[t] = alpha_h[t];
+    }
+    LuFactor *lu = pp->lus[lu_id];
+    hipStream_t s = as_stream(stream);
+    static const bool no_fuse = getenv("DDH_NO_PFUSE") != nullptr;
+    bool did = false;
+    int st;
+    if (pp->dev.nf == 2 && !no_fuse) {
+        if ((st = build_pband(pp, lu, p_mat_id))) return st;
+        // the fused kernel writes x directly; if this launch cannot fuse, the sweeps must write the work vector instead:
+        // decide first (same logic as launch_solve) by a dry query
+        const bool can = lu->dev.pband != nullptr;
+        if (can) {
+            st = launch_solve<2>(pp, lu, r, x, s, true, &did);
+            if (st) return st;
+            if (did) return 0;
+            // not fused (cooperative backward variant chosen): x holds y; move it to work and fall through
+            DDH_HIP(hipMemcpyAsync(work, x, (size_t)pp->dev.nrows * pp->dev.nx * pp->dev.ny * sizeof(double),
+                                   hipMemcpyDeviceToDevice, s));
+            PostSolve none;
+            memset(&none, 0, sizeof(none));
+            return launch_matvec(pp, p_mat_id, work, x, none, stream);
+        }
+    }
+    if (pp->dev.nf == 2) st = launch_solve<2>(pp, lu, r, work, s);
+    else if (pp->dev.nf == 1) st = launch_solve<1>(pp, lu, r, work, s);
+    else st = launch_solve<0>(pp, lu, r, work, s);
+    if (st) return st;
+    PostSolve none;
+    memset(&none, 0, sizeof(none));
+    return launch_matvec(pp, p_mat_id, work, x, none, stream);
 }
 
 int ddh_pencil_lu_row_widths(ddh_handle pack, int lu_id, int *wrow_h) {

@@ -205,6 +205,21 @@ class PencilPack:
         al = np.ascontiguousarray(alphas, dtype=np.float64)
         libhip.call("ddh_pencil_solve_lincomb", self.handle, lu_id, len(xs), arr, libhip.as_dp(al), ptr(x), self.dev.stream)
 
+    def solve_recombined(self, lu_id, xs, alphas, p_mat_id, work, x):
+        """x = P (a M + b L P)^-1 (sum_t alphas[t] xs[t]) (ddh_pencil_solve_recombined): recombination fused into the
+        backward sweep where the kernel variant allows, else through `work` and a mat-vec."""
+        t = self._timer()
+        if t is not None:
+            nb = self.lu_bytes(lu_id) + (sum(v.numel() for v in xs) + x.numel()) * 8
+            return t.run("pencil_solve", nb, self._solve_recombined, lu_id, xs, alphas, p_mat_id, work, x)
+        return self._solve_recombined(lu_id, xs, alphas, p_mat_id, work, x)
+
+    def _solve_recombined(self, lu_id, xs, alphas, p_mat_id, work, x):
+        arr = (C.c_void_p * len(xs))(*[C.c_void_p(v.data_ptr()) for v in xs])
+        al = np.ascontiguousarray(alphas, dtype=np.float64)
+        libhip.call("ddh_pencil_solve_recombined", self.handle, lu_id, len(xs), arr, libhip.as_dp(al), int(p_mat_id),
+                    ptr(work), ptr(x), self.dev.stream)
+
     MAX_RHS_TERMS = 8
 
     def set_solve_variant(self, mode=1, fwd=-1, backward_lanes=-1):

@@ -300,6 +300,14 @@ int ddh_pencil_solve(ddh_handle pack, int lu_id, const double *rhs, double *x, v
  * from HBM.  xs_h: host array of device pointers; none may alias x.                                              */
 int ddh_pencil_solve_lincomb(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h, const double *alpha_h,
                              double *x, void *stream);
+/* x = P (a M + b L P)^-1 rhs: the solve of the column-recombined system (X = P Y makes the
+ * boundary rows sparse) including the recombination.  p_mat_id: the registered constant matrix P.  When P is unit upper
+ * banded in the LU's ordering (the Dirichlet / Neumann recombinations are) and the one-thread-per-system backward
+ * sweep runs, x_j = y_j + sum_d P[j, j+d] y_(j+d) is formed from the sweep's register window and written directly --
+ * neither y nor a separate P.y mat-vec touch HBM; otherwise y goes to `work` and ddh_pencil_matvec(P) follows.
+ * work: a system vector of scratch, distinct from x and the right-hand-side terms.                                */
+int ddh_pencil_solve_recombined(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h,
+                                const double *alpha_h, int p_mat_id, double *work, double *x, void *stream);
 /* Sweep variant used by ddh_pencil_solve (all variants compute the same factorization's solution; they differ in how
  * many lanes share one system).  mode 1 (default): chosen by the number of systems; 0: one
  * thread per system; 2: cooperative (16 lanes) in both sweeps.  fwd = 0 / 1 and backward_lanes = 0 / 4 / 16 override
