@@ -222,6 +222,85 @@ grouped_gemm_kernel(const GroupDev *__restrict__ groups, const double *__restric
     }
 }
 
+
+// ---- FP64 MFMA GEMM for many right-hand-side columns (shell fields: the radial axis rides behind theta) ------------
+// Workgroup = 4 waves, tile = 64 output rows (16 per wave) x 64 columns of ONE (leading index, m part) slice, so the
+// columns are contiguous radial points; contraction in chunks of 32 staged through LDS for the data operand, the
+// matrix operand comes straight from L2 (each element feeds 4 MFMAs; a group's matrix is shared by all its slices'
+// workgroups).  v_mfma_f64_16x16x4: A one f64 per lane (row = lane & 15, k = lane >> 4), B (k = lane >> 4,
+// col = lane & 15), C/D (col = lane & 15, row = (lane >> 4) + 4 r).
+constexpr int GM_M = 64, GM_N = 64, GM_K = 32, GM_LD = GM_N + 1;
+typedef double gm_d4 __attribute__((ext_vector_type(4)));
+
+template <bool FWD>
+__global__ void __launch_bounds__(256)
+grouped_gemm_mfma_kernel(const GroupDev *__restrict__ groups, const double *__restrict__ mats,
+                         const double *__restrict__ in, double *__restrict__ out, GmmtDims d, int xtiles) {
+    __shared__ double sB[GM_K * GM_LD];
+    const GroupDev gr = groups[blockIdx.z];
+    const int nrows = FWD ? gr.n_ell : d.n_grid;
+    const int i0 = blockIdx.y * GM_M;
+    const int slice = blockIdx.x / xtiles, xt = blockIdx.x - slice * xtiles;
+    const long co = slice / gr.count, cj = slice - co * gr.count;      // (leading index, part) of this slice
+    if (co >= d.n0) return;
+    const int x0 = xt * GM_N;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (gr.mat_rows < 0) {                               // |m| > Lmax: forward skips, backward writes zeros
+        if (!FWD) {
+            for (int w = tid; w < GM_M * GM_N; w += 256) {
+                const int r = w / GM_N, x = w - r * GM_N;
+                if (i0 + r < d.n_grid && x0 + x < d.n3) out[g_index(d, co, gr.g_start + cj, i0 + r, x0 + x)] = 0.0;
+            }
+        }
+        return;
+    }
+    if (i0 >= nrows) return;
+    const int K = FWD ? d.n_grid : gr.n_ell;
+    const double *A = mats + (FWD ? gr.off_f : gr.off_b);
+    const int arow = i0 + 16 * wave + (lane & 15);
+    const bool arow_ok = arow < nrows;
+    const double *Arow = A + (long)(arow_ok ? arow : 0) * K;
+    gm_d4 acc[GM_N / 16];
+#pragma unroll
+    for (int jt = 0; jt < GM_N / 16; ++jt) acc[jt] = (gm_d4){0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += GM_K) {
+        __syncthreads();
+        // stage the data operand: rows k0 .. k0 + 31 of this slice, 64 contiguous columns each
+        for (int w = tid; w < GM_K * GM_N; w += 256) {
+            const int kk = w / GM_N, x = w - kk * GM_N, k = k0 + kk;
+            double v = 0.0;
+            if (k < K && x0 + x < d.n3)
+                v = in[FWD ? g_index(d, co, gr.g_start + cj, k, x0 + x)
+                           : c_index(d, co, gr.c_start + cj, gr.ell_start + (long)k * gr.ell_step, x0 + x)];
+            sB[kk * GM_LD + x] = v;
+        }
+        __syncthreads();
+        if (i0 + 16 * wave >= nrows) continue;           // (wave-uniform) no output rows in this wave's 16-row strip
+#pragma unroll
+        for (int k4 = 0; k4 < GM_K; k4 += 4) {
+            const int k = k0 + k4 + (lane >> 4);
+            const double a = (arow_ok && k < K) ? Arow[k] : 0.0;
+            const double *br = sB + (k4 + (lane >> 4)) * GM_LD + (lane & 15);
+#pragma unroll
+            for (int jt = 0; jt < GM_N / 16; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, br[jt * 16], acc[jt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int jt = 0; jt < GM_N / 16; ++jt) {
+        const int x = x0 + jt * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 16 * wave + (lane >> 4) + 4 * r;
+            if (i < nrows && x < d.n3) {
+                const long idx = FWD ? c_index(d, co, gr.c_start + cj, gr.ell_start + (long)i * gr.ell_step, x)
+                                     : g_index(d, co, gr.g_start + cj, i, x);
+                out[idx] = acc[jt][r];
+            }
+        }
+    }
+}
+
 template <bool FWD>
 static int launch_grouped(GmmtPlan *pl, const double *in, double *out, long n0, long n1g, long n1c, long n2c, long n3,
                           void *stream) {
@@ -239,6 +318,7 @@ static int launch_grouped(GmmtPlan *pl, const double *in, double *out, long n0, 
     const double *mats = FWD ? pl->d_fwd : pl->d_bwd;
     if (pl->paired && ncols > GV_COLS)
         return fail("grouped_mmt: paired groups are implemented for the GEMV path (few columns) only");
+    static const bool no_mfma = getenv("DDH_SWSH_NO_MFMA") != nullptr;
     if (ncols <= GV_COLS) {
         dim3 grid((unsigned)((max_rows + 4 * GV_ROWS - 1) / (4 * GV_ROWS)), (unsigned)pl->ngroups);
 #define DDH_GEMV(NC)                                                                                               \
@@ -250,6 +330,11 @@ static int launch_grouped(GmmtPlan *pl, const double *in, double *out, long n0, 
     }
         if (ncols <= 2) DDH_GEMV(2) else if (ncols <= 4) DDH_GEMV(4) else DDH_GEMV(8)
 #undef DDH_GEMV
+    } else if (n3 >= 16 && !no_mfma) {
+        const int xtiles = (int)((n3 + GM_N - 1) / GM_N);
+        dim3 grid((unsigned)(xtiles * n0 * pl->max_count), (unsigned)((max_rows + GM_M - 1) / GM_M), (unsigned)pl->ngroups);
+        if (grid.z > 65535 || grid.y > 65535) return fail("grouped_mmt: too many groups / rows for one launch");
+        hipLaunchKernelGGL(grouped_gemm_mfma_kernel<FWD>, grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, xtiles);
     } else {
         dim3 grid((unsigned)((ncols + GT_X - 1) / GT_X), (unsigned)((max_rows + GT_I - 1) / GT_I), (unsigned)pl->ngroups);
         if (grid.z > 65535 || grid.y > 65535) return fail("grouped_mmt: too many groups / rows for one launch");

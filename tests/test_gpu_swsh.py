@@ -75,3 +75,45 @@ def test_swsh_wide_columns_against_oracle(hex_):
         assert np.array_equal(np.isnan(got), np.isnan(gref))
         mask = ~np.isnan(gref)
         assert rel(got[mask], gref[mask]) < 1e-13
+
+
+@pytest.mark.parametrize("n0,n3", [(1, 16), (3, 40), (2, 192)])
+@pytest.mark.parametrize("s", [0, 1, -2])
+def test_many_columns_mfma_gemm_matches_matrix_products(n0, n3, s):
+    """Shell-like use: the radial axis rides behind theta (n3 columns per slice) -> the FP64 MFMA grouped GEMM
+    (grouped_gemm_mfma_kernel).  Reference: the per-m matrix products of SWSHColatitudeTransform.forward_reduced /
+    backward_reduced (core/transforms.py:1258-1288) in NumPy with the same matrices, folded groups and |m| > Lmax
+    groups included."""
+    from dedalus_amd.core.curvilinear import SWSHColatitudeTransform
+    from dedalus_amd.executor import HipExecutor
+    from dedalus_amd.tools import sphere
+    ex = HipExecutor()
+    Lmax, Nth = 37, 60
+    # groups (m, g_start, c_start, count, ell_start, ell_step, n_ell): plain ones, a folded one (step -1), one beyond Lmax
+    rows = []
+    for m in range(0, Lmax + 1, 3):
+        rows.append((m, 2 * m, 2 * m, 2, m, 1, Lmax + 1 - m))
+    rows.append((5, 2 * (Lmax + 1), 2 * (Lmax + 1), 2, Lmax, -1, Lmax + 1 - 5))
+    rows.append((Lmax + 3, 2 * (Lmax + 2), 2 * (Lmax + 2), 2, 0, 1, 0))
+    rows = np.array(rows, dtype=np.int64)
+    n1 = 2 * (Lmax + 3)
+    plan = SWSHColatitudeTransform(Nth, Lmax, rows, s, executor=ex)
+    rng = np.random.default_rng(5 + n3)
+    g = rng.standard_normal((n0, n1, Nth, n3))
+    c_in = rng.standard_normal((n0, n1, Lmax + 1, n3))
+    c_dev = ex.from_host(np.full((n0, n1, Lmax + 1, n3), 7.0))
+    plan.forward_reduced(ex.from_host(g), c_dev)
+    g_dev = ex.from_host(np.full(g.shape, 7.0))
+    plan.backward_reduced(ex.from_host(c_in), g_dev)
+    c_out, g_out = ex.download(c_dev), ex.download(g_dev)
+    for (m, gs, cs, cnt, l0, step, ne) in rows:
+        if abs(m) > Lmax:
+            assert np.all(c_out[:, cs:cs + cnt] == 7.0)              # forward leaves the slot alone
+            assert np.all(g_out[:, gs:gs + cnt] == 0.0)              # backward zero-fills (transforms.py:1280-1288)
+            continue
+        F, B = sphere.swsh_matrices(Nth, Lmax, int(m), s)
+        ell = l0 + step * np.arange(ne)
+        ref_c = np.einsum("lt,ajtx->ajlx", F, g[:, gs:gs + cnt])
+        assert np.linalg.norm(c_out[:, cs:cs + cnt][:, :, ell] - ref_c) <= 1e-13 * np.linalg.norm(ref_c), (m, "fwd")
+        ref_g = np.einsum("tl,ajlx->ajtx", B, c_in[:, cs:cs + cnt][:, :, ell])
+        assert np.linalg.norm(g_out[:, gs:gs + cnt] - ref_g) <= 1e-13 * np.linalg.norm(ref_g), (m, "bwd")
