@@ -52,7 +52,14 @@ struct DenseSys {
 };
 
 // out = (a M + b L)^-1 on the valid block, zeros elsewhere.  One workgroup per system.
-template <bool CX>
+//
+// Blocked in-place Gauss-Jordan inversion with partial pivoting.  One elimination step k replaces column k by the unit
+// vector e_k and applies a rank-1 update  A <- A - u r^T  (r = row k / pivot with r[k] = 1 / pivot, u = column k with
+// u[k] = pivot - 1).  BS steps are collected before the matrix is touched: inside a block only the current pivot column
+// and pivot row are brought up to date (n BS work each) from the stale matrix and the pending (u, r) pairs kept in LDS,
+// then ONE pass over the matrix applies the rank-BS update -- the matrix streams through memory n / BS times instead
+// of n times (the elimination is bound by that stream: 127 shell systems of 768^2 do not fit the caches).
+template <bool CX, int BS>
 __global__ void __launch_bounds__(DI_T)
 dense_inverse_kernel(const DenseSys *__restrict__ sys, const void *__restrict__ Mv, const void *__restrict__ Lv,
                      double a, double b, const unsigned char *__restrict__ row_valid,
@@ -67,7 +74,10 @@ dense_inverse_kernel(const DenseSys *__restrict__ sys, const void *__restrict__ 
     const E *M = (const E *)Mv + S.off, *L = (const E *)Lv + S.off;
     E *A = (E *)outv + S.off;
     const unsigned char *rv = row_valid + valid_off[blockIdx.x], *cv = col_valid + valid_off[blockIdx.x];
-    __shared__ E s_row[DI_NMAX], s_col[DI_NMAX];
+    extern __shared__ double s_dyn[];
+    E *sU = (E *)s_dyn;                      // [BS][n]
+    E *sR = sU + (size_t)BS * n;             // [BS][n]
+    E *s_col = sR + (size_t)BS * n;          // [n] current pivot column
     __shared__ int s_piv[DI_NMAX];
     __shared__ double s_best[DI_T / 64];
     __shared__ int s_arg[DI_T / 64];
@@ -83,54 +93,87 @@ dense_inverse_kernel(const DenseSys *__restrict__ sys, const void *__restrict__ 
     __syncthreads();
     for (int k = tid; k < S.npair; k += DI_T) A[(long)pair_r[S.pair0 + k] * n + pair_c[S.pair0 + k]] = O::one();
     __syncthreads();
-    // ---- in-place Gauss-Jordan inversion with partial (row) pivoting
-    for (int k = 0; k < n; ++k) {
-        double best = -1.0;
-        int arg = k;
-        for (int i = k + tid; i < n; i += DI_T) {
-            const double m = O::abs2(A[(long)i * n + k]);
-            if (m > best) { best = m; arg = i; }
-        }
-#pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) {
-            const double ob = __shfl_xor(best, sft, 64);
-            const int oa = __shfl_xor(arg, sft, 64);
-            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
-        }
-        if ((tid & 63) == 0) { s_best[tid >> 6] = best; s_arg[tid >> 6] = arg; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < DI_T / 64; ++w)
-                if (s_best[w] > best || (s_best[w] == best && s_arg[w] < arg)) { best = s_best[w]; arg = s_arg[w]; }
-            s_p = arg;
-            s_piv[k] = arg;
-            if (!(best > 0.0)) s_bad = 1;
-        }
-        __syncthreads();
-        const int p = s_p;
-        if (p != k) {
-            for (int j = tid; j < n; j += DI_T) {
-                const E t = A[(long)k * n + j];
-                A[(long)k * n + j] = A[(long)p * n + j];
-                A[(long)p * n + j] = t;
+    for (int k0 = 0; k0 < n; k0 += BS) {
+        const int nb = (n - k0 < BS) ? n - k0 : BS;
+        for (int s = 0; s < nb; ++s) {
+            const int k = k0 + s;
+            // (1) pivot column k, up to date: stale column minus the pending updates
+            for (int i = tid; i < n; i += DI_T) {
+                E v = A[(long)i * n + k];
+                for (int t = 0; t < s; ++t) v = O::fms(v, sU[(size_t)t * n + i], sR[(size_t)t * n + k]);
+                s_col[i] = v;
             }
+            __syncthreads();
+            // (2) pivot search among rows >= k
+            double best = -1.0;
+            int arg = k;
+            for (int i = k + tid; i < n; i += DI_T) {
+                const double m = O::abs2(s_col[i]);
+                if (m > best) { best = m; arg = i; }
+            }
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                const double ob = __shfl_xor(best, sft, 64);
+                const int oa = __shfl_xor(arg, sft, 64);
+                if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+            }
+            if ((tid & 63) == 0) { s_best[tid >> 6] = best; s_arg[tid >> 6] = arg; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < DI_T / 64; ++w)
+                    if (s_best[w] > best || (s_best[w] == best && s_arg[w] < arg)) { best = s_best[w]; arg = s_arg[w]; }
+                s_p = arg;
+                s_piv[k] = arg;
+                if (!(best > 0.0)) s_bad = 1;
+            }
+            __syncthreads();
+            const int p = s_p;
+            // (3) row interchange k <-> p: the stale matrix, the pending u vectors and the current column
+            if (p != k) {
+                for (int j = tid; j < n; j += DI_T) {
+                    const E t = A[(long)k * n + j];
+                    A[(long)k * n + j] = A[(long)p * n + j];
+                    A[(long)p * n + j] = t;
+                }
+                if (tid < s) {
+                    const E t = sU[(size_t)tid * n + k];
+                    sU[(size_t)tid * n + k] = sU[(size_t)tid * n + p];
+                    sU[(size_t)tid * n + p] = t;
+                }
+                if (tid == DI_T - 1) {
+                    const E t = s_col[k];
+                    s_col[k] = s_col[p];
+                    s_col[p] = t;
+                }
+            }
+            __syncthreads();
+            // (4) pivot row k, up to date; columns replaced earlier in this block start from the unit vector's 0
+            E piv = s_col[k];
+            if (!(O::abs2(piv) > 0.0)) piv = O::one();
+            const E ip = O::inv(piv);
+            for (int j = tid; j < n; j += DI_T) {
+                const bool repl = (j >= k0 && j < k);
+                E v = repl ? O::zero() : A[(long)k * n + j];
+                for (int t = repl ? j - k0 : 0; t < s; ++t) v = O::fms(v, sU[(size_t)t * n + k], sR[(size_t)t * n + j]);
+                sR[(size_t)s * n + j] = (j == k) ? ip : O::mul(v, ip);
+                E u = s_col[j];                                   // (n entries as well: same loop, index = row here)
+                if (j == k) { u = piv; u = O::fms(u, O::one(), O::one()); }      // u[k] = pivot - 1
+                sU[(size_t)s * n + j] = u;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        E piv = A[(long)k * n + k];
-        if (!(O::abs2(piv) > 0.0)) piv = O::one();
-        const E ip = O::inv(piv);
+        // ---- one pass over the matrix: rank-nb update; thread = column, pending r values in registers
         for (int j = tid; j < n; j += DI_T) {
-            s_row[j] = (j == k) ? ip : O::mul(A[(long)k * n + j], ip);
-            s_col[j] = (j == k) ? O::zero() : A[(long)j * n + k];
-        }
-        __syncthreads();
-        for (long e = tid; e < nn; e += DI_T) {
-            const int i = (int)(e / n), j = (int)(e - (long)i * n);
-            if (i == k) {
-                A[e] = s_row[j];
-            } else {
-                const E base = (j == k) ? O::zero() : A[e];
-                A[e] = O::fms(base, s_col[i], s_row[j]);
+            const bool repl = (j >= k0 && j < k0 + nb);
+            const int t0 = repl ? j - k0 : 0;
+            E r[BS];
+#pragma unroll
+            for (int t = 0; t < BS; ++t) r[t] = (t >= t0 && t < nb) ? sR[(size_t)t * n + j] : O::zero();
+            for (int i = 0; i < n; ++i) {
+                E v = repl ? ((i == j) ? O::one() : O::zero()) : A[(long)i * n + j];
+#pragma unroll
+                for (int t = 0; t < BS; ++t) v = O::fms(v, sU[(size_t)t * n + i], r[t]);
+                A[(long)i * n + j] = v;
             }
         }
         __syncthreads();
@@ -158,6 +201,7 @@ struct DenseInverse : HandleBase {
     long total = 0;               // elements over all systems
     void *d_sys = nullptr, *d_M = nullptr, *d_L = nullptr, *d_rv = nullptr, *d_cv = nullptr, *d_voff = nullptr;
     void *d_pr = nullptr, *d_pc = nullptr, *d_flags = nullptr;
+    std::vector<int> n_host;
     ~DenseInverse() override {
         (void)hipFree(d_sys); (void)hipFree(d_M); (void)hipFree(d_L); (void)hipFree(d_rv); (void)hipFree(d_cv);
         (void)hipFree(d_voff); (void)hipFree(d_pr); (void)hipFree(d_pc); (void)hipFree(d_flags);
@@ -216,6 +260,7 @@ int ddh_dense_inverse_create(ddh_handle *h, int nsys, const int *n_h, int is_com
         vo += n;
     }
     p->total = off;
+    p->n_host.assign(n_h, n_h + nsys);
     const size_t eb = (p->cx ? 2 : 1) * sizeof(double);
     int st = 0;
     auto up = [&](void **d, const void *src, size_t bytes) {
@@ -249,16 +294,27 @@ int ddh_dense_inverse_compute(ddh_handle h, double a, double b, double *out_d, i
     if (!p) return -1;
     hipStream_t s = as_stream(stream);
     DDH_HIP(hipMemsetAsync(p->d_flags, 0, (size_t)p->nsys * sizeof(int), s));
-    if (p->cx)
-        hipLaunchKernelGGL(dense_inverse_kernel<true>, dim3((unsigned)p->nsys), dim3(DI_T), 0, s, (const DenseSys *)p->d_sys,
+    int nmax = 0;
+    for (int v : p->n_host) nmax = v > nmax ? v : nmax;
+    if (p->cx) {
+        constexpr int BS = 4;
+        const size_t lds = (size_t)(2 * BS + 1) * nmax * sizeof(double2);
+        auto kern = dense_inverse_kernel<true, BS>;
+        DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)p->nsys), dim3(DI_T), lds, s, (const DenseSys *)p->d_sys,
                            p->d_M, p->d_L, a, b, (const unsigned char *)p->d_rv, (const unsigned char *)p->d_cv,
                            (const long *)p->d_voff, (const int *)p->d_pr, (const int *)p->d_pc, (void *)out_d,
                            (int *)p->d_flags);
-    else
-        hipLaunchKernelGGL(dense_inverse_kernel<false>, dim3((unsigned)p->nsys), dim3(DI_T), 0, s, (const DenseSys *)p->d_sys,
+    } else {
+        constexpr int BS = 8;
+        const size_t lds = (size_t)(2 * BS + 1) * nmax * sizeof(double);
+        auto kern = dense_inverse_kernel<false, BS>;
+        DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)p->nsys), dim3(DI_T), lds, s, (const DenseSys *)p->d_sys,
                            p->d_M, p->d_L, a, b, (const unsigned char *)p->d_rv, (const unsigned char *)p->d_cv,
                            (const long *)p->d_voff, (const int *)p->d_pr, (const int *)p->d_pc, (void *)out_d,
                            (int *)p->d_flags);
+    }
     DDH_HIP(hipGetLastError());
     if (nsingular_h) {
         std::vector<int> f(p->nsys);

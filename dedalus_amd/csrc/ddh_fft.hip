@@ -1144,6 +1144,57 @@ mmt_kernel(const double *__restrict__ mat, const double *__restrict__ in, double
     }
 }
 
+// The same product on the matrix cores: v_mfma_f64_16x16x4 (A: row = lane & 15, k = lane >> 4; B: k = lane >> 4,
+// col = lane & 15; C/D: col = lane & 15, row = (lane >> 4) + 4 r).  Workgroup = 4 waves, tile = 64 output rows x 64
+// inner columns, contraction in chunks of 32 through LDS for the data operand, the matrix operand from L2.
+constexpr int MM_M = 64, MM_N = 64, MM_K = 32, MM_LD = MM_N + 1;
+typedef double mm_d4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+mmt_mfma_kernel(const double *__restrict__ mat, const double *__restrict__ in, double *__restrict__ out, int n_out,
+                int n_in, long inner) {
+    __shared__ double sB[MM_K * MM_LD];
+    const long o = blockIdx.z;
+    const int i0 = blockIdx.y * MM_M;
+    const long x0 = (long)blockIdx.x * MM_N;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const double *inb = in + o * (long)n_in * inner;
+    double *ob = out + o * (long)n_out * inner;
+    const int arow = i0 + 16 * wave + (lane & 15);
+    const bool arow_ok = arow < n_out;
+    const double *Arow = mat + (long)(arow_ok ? arow : 0) * n_in;
+    mm_d4 acc[MM_N / 16];
+#pragma unroll
+    for (int jt = 0; jt < MM_N / 16; ++jt) acc[jt] = (mm_d4){0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < n_in; k0 += MM_K) {
+        __syncthreads();
+        for (int w = tid; w < MM_K * MM_N; w += 256) {
+            const int kk = w / MM_N, x = w - kk * MM_N;
+            sB[kk * MM_LD + x] = (k0 + kk < n_in && x0 + x < inner) ? inb[(long)(k0 + kk) * inner + x0 + x] : 0.0;
+        }
+        __syncthreads();
+        if (i0 + 16 * wave >= n_out) continue;
+#pragma unroll
+        for (int k4 = 0; k4 < MM_K; k4 += 4) {
+            const int k = k0 + k4 + (lane >> 4);
+            const double a = (arow_ok && k < n_in) ? Arow[k] : 0.0;
+            const double *br = sB + (k4 + (lane >> 4)) * MM_LD + (lane & 15);
+#pragma unroll
+            for (int jt = 0; jt < MM_N / 16; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, br[jt * 16], acc[jt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int jt = 0; jt < MM_N / 16; ++jt) {
+        const long x = x0 + jt * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 16 * wave + (lane >> 4) + 4 * r;
+            if (i < n_out && x < inner) ob[(long)i * inner + x] = acc[jt][r];
+        }
+    }
+}
+
 }  // namespace ddh
 
 using namespace ddh;
@@ -1322,8 +1373,16 @@ int ddh_mmt_apply(ddh_handle plan, const double *in, double *out, long outer, lo
     if (int st0 = resolve_alias(&in, out, (size_t)pl->n_in * outer * inner, (size_t)pl->n_out * outer * inner,
                                 as_stream(stream)))
         return st0;
-    dim3 grid((unsigned)((inner + MT_X - 1) / MT_X), (unsigned)((pl->n_out + MT_I - 1) / MT_I), (unsigned)outer);
     if (outer > 65535) return fail("ddh_mmt_apply: outer too large");
+    static const bool no_mfma = getenv("DDH_MMT_NO_MFMA") != nullptr;
+    if (inner >= 16 && !no_mfma) {      // enough contiguous columns per row for 16-wide MFMA column tiles
+        dim3 g2((unsigned)((inner + MM_N - 1) / MM_N), (unsigned)((pl->n_out + MM_M - 1) / MM_M), (unsigned)outer);
+        hipLaunchKernelGGL(mmt_mfma_kernel, g2, dim3(256), 0, as_stream(stream), pl->d_mat, in, out, pl->n_out, pl->n_in,
+                           inner);
+        DDH_HIP(hipGetLastError());
+        return 0;
+    }
+    dim3 grid((unsigned)((inner + MT_X - 1) / MT_X), (unsigned)((pl->n_out + MT_I - 1) / MT_I), (unsigned)outer);
     hipLaunchKernelGGL(mmt_kernel, grid, dim3(256), 0, as_stream(stream), pl->d_mat, in, out, pl->n_out, pl->n_in,
                        inner);
     DDH_HIP(hipGetLastError());
