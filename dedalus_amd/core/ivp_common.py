@@ -79,13 +79,76 @@ class IVPLifecycle:
         self._step_wall_time = wall_time
         for hook in self._step_hooks:
             hook(self)
-        self.timestepper.step(dt, wall_time)
+        if not self._graph_replay(dt, wall_time):
+            self.timestepper.step(dt, wall_time)
         # Hermitian symmetry for real variables: for as many iterations as the scheme uses internally, every cadence
         # (core/solvers.py:704-708) -- checked BEFORE the iteration count is advanced, so the first step takes part
         if self.enforce_real_cadence and self.iteration % self.enforce_real_cadence < self.timestepper.steps:
             self.enforce_hermitian_symmetry(self.state)
         self.iteration += 1
         self.dt = dt
+
+    # ---- fixed-timestep steps as one HIP graph ------------------------------------------------------------------------
+    # Small problems are launch bound (2-D Rayleigh-Benard 512 x 256: ~75 % of a step is host time issuing ~100
+    # launches).  With a fixed timestep a Runge-Kutta step is the same launch sequence on the same buffers every time:
+    # it is captured once (torch.cuda.CUDAGraph = hipGraph; every kernel of libdedalus_hip runs on the capturing
+    # stream) and replayed.  Anything that breaks the pattern -- a different dt, state touched through the host or the
+    # grid, several ranks, a scheme that rotates its history buffers -- falls back to normal launches.
+    step_graph = None            # None: decide from DDH_STEP_GRAPH (default off); True / False: forced
+
+    def enable_step_graph(self, on=True):
+        self.step_graph = bool(on)
+        self._graph = None
+
+    def _graph_wanted(self):
+        if self.step_graph is None:
+            import os
+            self.step_graph = os.environ.get("DDH_STEP_GRAPH", "0") == "1"
+        return self.step_graph
+
+    def _state_is_clean(self):
+        for f in self.state:
+            if getattr(f, "_authority", "device") != "device" or getattr(f, "layout", "c") != "c":
+                return False
+        return True
+
+    def _graph_replay(self, dt, wall_time):
+        """-> True when the step was advanced by replaying (or capturing + replaying) the graph"""
+        if not self._graph_wanted() or getattr(self.ex, "name", "") != "hip" or getattr(self.dist, "size", 1) > 1:
+            return False
+        from .timesteppers import RungeKuttaIMEX
+        ts = self.timestepper
+        if not isinstance(ts, RungeKuttaIMEX) or getattr(self.ex, "timer", None) is not None:
+            return False
+        st = getattr(self, "_graph", None)
+        if st is None:
+            st = self._graph = dict(dt=None, seen=0, graph=None, failed=False)
+        if st["failed"] or not self._state_is_clean() or getattr(self, "solve_probe", None) is not None:
+            return False
+        if dt != st["dt"]:                   # (re)start: two ordinary steps with this dt first (factorization, plans, buffers)
+            st.update(dt=dt, seen=0, graph=None)
+        if st["graph"] is None:
+            st["seen"] += 1
+            if st["seen"] <= 2:
+                return False
+            torch = self.ex.torch
+            t0 = self.sim_time
+            try:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    ts.step(dt, wall_time)
+                st["graph"] = g
+            except Exception as e:                      # something in the step is not capturable: never try again
+                st["failed"] = True
+                logger.warning("step graph capture failed (%s): falling back to ordinary launches" % (e,))
+                self.sim_time = t0
+                return False
+            self.sim_time = t0                          # capture only recorded the launches
+        t0 = self.sim_time
+        st["graph"].replay()
+        self.sim_time = t0 + dt
+        return True
 
     def enforce_hermitian_symmetry(self, fields):
         """Grid and back at the dealias scales (core/solvers.py:675-681)."""

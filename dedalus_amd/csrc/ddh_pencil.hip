@@ -104,6 +104,7 @@ struct LuFactor {
     void *d_dense_rhs = nullptr;    // double2 [nflagcells*S][N]
     std::vector<int> colperm_h;             // logical -> physical columns (host copy)
     std::vector<unsigned char> ccode_h;     // grading codes of the logical columns (real mode)
+    void *d_rhs_tmp = nullptr;              // materialised right-hand side for the cooperative forward sweep
     void *d_pband = nullptr;                // [n][PBW] band of the recombination, see LuDev::pband
     int pband_mat = -1;                     // matrix id it was built from
 };
@@ -140,6 +141,7 @@ static void free_lu(LuFactor *lu) {
     (void)hipFree(lu->d_inv);
     (void)hipFree(lu->d_dense_rhs);
     (void)hipFree(lu->d_pband);
+    (void)hipFree(lu->d_rhs_tmp);
     delete lu;
 }
 
@@ -498,15 +500,23 @@ struct RhsSrc {
 template <int NF, int XD = 1>
 __device__ __forceinline__ double2 load_sys(const RhsSrc &r, long plane, int row, const PencilDev &P,
                                             const CellCtx &c, int s) {
-    if (r.n == 1 && r.a[0] == 1.0) return load_sys<NF, XD>(r.p[0], plane, row, P, c, s);
+    // (compile-time indices into the by-value argument struct: a run-time index would push it to scratch memory)
+    if (r.n == 1) {
+        double2 v = load_sys<NF, XD>(r.p[0], plane, row, P, c, s);
+        if (r.a[0] != 1.0) v = make_double2(r.a[0] * v.x, r.a[0] * v.y);
+        return v;
+    }
     const long roff = (long)row * plane;
     if (NF == 2) {
         const long off = roff + (2 * c.mx + s) * P.ny + 2 * c.my;
         double2 mine = make_double2(0.0, 0.0);
-        for (int t = 0; t < r.n; ++t) {
-            const double2 v = *reinterpret_cast<const double2 *>(r.p[t] + off);
-            mine.x += r.a[t] * v.x;
-            mine.y += r.a[t] * v.y;
+#pragma unroll
+        for (int t = 0; t < RHS_MAX; ++t) {
+            if (t < r.n) {
+                const double2 v = *reinterpret_cast<const double2 *>(r.p[t] + off);
+                mine.x += r.a[t] * v.x;
+                mine.y += r.a[t] * v.y;
+            }
         }
         double2 other;
         other.x = __shfl_xor(mine.x, XD);
@@ -515,15 +525,20 @@ __device__ __forceinline__ double2 load_sys(const RhsSrc &r, long plane, int row
                       : make_double2(other.x + mine.y, other.y - mine.x);
     } else if (NF == 1) {
         double2 acc = make_double2(0.0, 0.0);
-        for (int t = 0; t < r.n; ++t) {
-            const double2 v = *reinterpret_cast<const double2 *>(r.p[t] + roff + 2 * c.mx);
-            acc.x += r.a[t] * v.x;
-            acc.y += r.a[t] * v.y;
+#pragma unroll
+        for (int t = 0; t < RHS_MAX; ++t) {
+            if (t < r.n) {
+                const double2 v = *reinterpret_cast<const double2 *>(r.p[t] + roff + 2 * c.mx);
+                acc.x += r.a[t] * v.x;
+                acc.y += r.a[t] * v.y;
+            }
         }
         return acc;
     } else {
         double acc = 0.0;
-        for (int t = 0; t < r.n; ++t) acc += r.a[t] * r.p[t][roff];
+#pragma unroll
+        for (int t = 0; t < RHS_MAX; ++t)
+            if (t < r.n) acc += r.a[t] * r.p[t][roff];
         return make_double2(acc, 0.0);
     }
 }
@@ -1033,7 +1048,7 @@ __device__ __forceinline__ double group_sum(double v) {
 
 template <int NF, bool REAL, int NBT>
 __global__ void __launch_bounds__(256)
-solve_forward_coop_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__restrict__ xout) {
+solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, double *__restrict__ xout) {
     typedef typename El<REAL>::T E;
     extern __shared__ int s_lds[];
     const int N = L.N;
@@ -1345,6 +1360,31 @@ static int finish_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     return 0;
 }
 
+// Sweep variant by the number of systems (measured on MI355X with the 5156-row systems of the 3-D benchmark, solve =
+// both sweeps, ms):
+//   G = 16384: one thread per system 5.79 | fwd coop + bwd 16 lanes 4.24 | + bwd 8 lanes 3.49 | + bwd 4 lanes 3.28
+//   G = 32768: 6.13 | fwd coop 6.5-8.4 | fwd per-thread + bwd 4 lanes 5.75      G = 65536: 6.76 (anything else slower)
+// (these are the per-rank sizes of the 512 x 512 x 256 problem on 8 / 4 / 2 GPUs); 2-D problems (a few hundred
+// systems) were tuned with 16 lanes in both sweeps.  forward: 16 lanes per system (needs kl < 16); backward: 16 or 4
+// lanes per system (fewer lanes = less redundant work per system, more products per lane).
+template <int NF>
+static void choose_variant(const PencilPack *pp, const LuDev &d, int &use_fwd, int &cb) {
+    const PencilDev &P = pp->dev;
+    const int W = d.W;
+    const int coop_mode = pp->coop_mode;
+    const bool coop_auto = coop_mode == 1 && NF > 0;
+    use_fwd = (coop_mode == 2 || (coop_auto && P.G <= 16384)) ? 1 : 0;
+    cb = 0;
+    if (coop_mode == 2 || (coop_auto && P.G <= 1024)) cb = 16;
+    else if (coop_auto && P.G <= 32768) cb = 4;
+    if (pp->coop_fwd >= 0) use_fwd = pp->coop_fwd;
+    if (pp->coop_cb >= 0) cb = pp->coop_cb;
+    if (NF == 0 || d.kl >= CH || d.nb > 8) use_fwd = 0;
+    if (NF == 0 || (cb != 4 && cb != 16)) cb = 0;
+    if (cb && (W + cb - 1) / cb > (cb == 4 ? 12 : 3)) cb = 0;
+    if (d.n <= 0) use_fwd = cb = 0;
+}
+
 // want_p: the caller asks for x = P y (recombination fused into the backward sweep); *did_p tells whether this launch
 // could do it (one-thread-per-system backward kernel of the real-graded 2-axis path with a band table on file).
 template <int NF>
@@ -1357,35 +1397,25 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     const int W = d.W;
     const size_t lds_f = (size_t)(d.N + d.nb) * 5 + 16, lds_b = (size_t)(d.n > 0 ? d.n : 1) * 5 + 16;
     if (lds_f > 64 * 1024) return fail("pencil_solve: system too large for the LDS permutation cache");
-    // few systems: 16 lanes per system (see the cooperative kernels); DDH_SOLVE_COOP = 0 never, 2 always
-    const int coop_mode = pp->coop_mode;
-    // forward: 16 lanes per system (needs kl < 16); backward: 16, 8 or 4 lanes per system (fewer lanes = less redundant
-    // work per system, more products per lane); the choice follows the number of systems, measured on MI355X with
-    // 5156-row systems: G <= 16384 -> both sweeps cooperative.  DDH_COOP_FWD / DDH_COOP_CB override (experiments).
-    // Measured on MI355X (5156-row systems of the 3-D benchmark, solve = both sweeps, ms):
-    //   G = 16384: one thread per system 5.79 | fwd coop + bwd 16 lanes 4.24 | + bwd 8 lanes 3.49 | + bwd 4 lanes 3.28
-    //   G = 32768: 6.13 | fwd coop 6.5-8.4 | fwd per-thread + bwd 4 lanes 5.75      G = 65536: 6.76 (anything else slower)
-    // (these are the per-rank sizes of the 512 x 512 x 256 problem on 8 / 4 / 2 GPUs); 2-D problems (a few hundred
-    // systems) were tuned with 16 lanes in both sweeps.
-    const bool coop_auto = coop_mode == 1 && NF > 0;
-    int use_fwd = (coop_mode == 2 || (coop_auto && P.G <= 16384)) ? 1 : 0;
-    int cb = 0;
-    if (coop_mode == 2 || (coop_auto && P.G <= 1024)) cb = 16;
-    else if (coop_auto && P.G <= 32768) cb = 4;
-    if (pp->coop_fwd >= 0) use_fwd = pp->coop_fwd;
-    if (pp->coop_cb >= 0) cb = pp->coop_cb;
-    if (NF == 0 || d.kl >= CH || d.nb > 8) use_fwd = 0;
-    if (NF == 0 || (cb != 4 && cb != 16)) cb = 0;
-    if (cb && (W + cb - 1) / cb > (cb == 4 ? 12 : 3)) cb = 0;
-    if (d.n <= 0) use_fwd = cb = 0;
+    int use_fwd, cb;
+    choose_variant<NF>(pp, d, use_fwd, cb);
     if (use_fwd) {
         const unsigned cblocks = (unsigned)((P.G + (256 / CH) - 1) / (256 / CH));
+        // the cooperative sweep's deep branch-free prefetch takes ONE right-hand-side vector: a combination is
+        // materialised first (few systems: the extra pass is small next to the latency-bound sweeps)
+        const double *rhs1 = rhs.p[0];
+        if (rhs.n != 1 || rhs.a[0] != 1.0) {
+            const long nel = (long)P.nrows * P.nx * P.ny;
+            if (!lu->d_rhs_tmp) DDH_HIP(hipMalloc(&lu->d_rhs_tmp, (size_t)nel * sizeof(double) + 16));
+            if (int st0 = ddh_lincomb((double *)lu->d_rhs_tmp, rhs.n, rhs.p, rhs.a, nel, (void *)s)) return st0;
+            rhs1 = (const double *)lu->d_rhs_tmp;
+        }
 #define DDH_CFWD(NBTV)                                                                                             \
     {                                                                                                              \
         if (d.real)                                                                                                \
-            hipLaunchKernelGGL((solve_forward_coop_kernel<NF, true, NBTV>), dim3(cblocks), dim3(256), lds_f, s, P, d, rhs, x); \
+            hipLaunchKernelGGL((solve_forward_coop_kernel<NF, true, NBTV>), dim3(cblocks), dim3(256), lds_f, s, P, d, rhs1, x); \
         else                                                                                                       \
-            hipLaunchKernelGGL((solve_forward_coop_kernel<NF, false, NBTV>), dim3(cblocks), dim3(256), lds_f, s, P, d, rhs, x); \
+            hipLaunchKernelGGL((solve_forward_coop_kernel<NF, false, NBTV>), dim3(cblocks), dim3(256), lds_f, s, P, d, rhs1, x); \
     }
         if constexpr (NF > 0) {
             if (d.nb <= 2) DDH_CFWD(2) else DDH_CFWD(8)
@@ -1947,17 +1977,13 @@ int ddh_pencil_solve_recombined(ddh_handle pack, int lu_id, int nterms, const do
         if ((st = build_pband(pp, lu, p_mat_id))) return st;
         // the fused kernel writes x directly; if this launch cannot fuse, the sweeps must write the work vector instead:
         // decide first (same logic as launch_solve) by a dry query
-        const bool can = lu->dev.pband != nullptr;
-        if (can) {
+        int uf, cbv;
+        choose_variant<2>(pp, lu->dev, uf, cbv);
+        if (lu->dev.pband != nullptr && lu->dev.real && !cbv && lu->dev.W <= 48 && lu->dev.n > 0) {
             st = launch_solve<2>(pp, lu, r, x, s, true, &did);
             if (st) return st;
             if (did) return 0;
-            // not fused (cooperative backward variant chosen): x holds y; move it to work and fall through
-            DDH_HIP(hipMemcpyAsync(work, x, (size_t)pp->dev.nrows * pp->dev.nx * pp->dev.ny * sizeof(double),
-                                   hipMemcpyDeviceToDevice, s));
-            PostSolve none;
-            memset(&none, 0, sizeof(none));
-            return launch_matvec(pp, p_mat_id, work, x, none, stream);
+            return fail("pencil_solve_recombined: internal error (fused variant not taken)");
         }
     }
     if (pp->dev.nf == 2) st = launch_solve<2>(pp, lu, r, work, s);

@@ -15,8 +15,11 @@ import problems  # noqa: E402
 import dedalus_amd.public as d3  # noqa: E402
 
 
-def run(name, builder, kw, dt, warm, steps):
+def run(name, builder, kw, dt, warm, steps, graph=False):
     solver, f = builder(d3, **kw)
+    if graph:
+        solver.enable_step_graph(True)
+        name += " [hipGraph]"
     for _ in range(warm):
         solver.step(dt)
     solver.ex.sync()
@@ -99,6 +102,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "r2" in sys.argv[1:]:
         run("R2 rb2d 512x256 RK222", problems.rayleigh_benard_2d, dict(Nx=512, Nz=256), 1e-3, 5, 50)
+        run("R2 rb2d 512x256 RK222", problems.rayleigh_benard_2d, dict(Nx=512, Nz=256), 1e-3, 5, 200, graph=True)
+        run("rb3d 64x64x32 RK222", problems.rayleigh_benard_3d, dict(Nx=64, Ny=64, Nz=32), 1e-3, 5, 100)
+        run("rb3d 64x64x32 RK222", problems.rayleigh_benard_3d, dict(Nx=64, Ny=64, Nz=32), 1e-3, 5, 100, graph=True)
         sys.exit(0)
     if "sphere" in sys.argv[1:]:
         run_sphere("S  shallow water 512x256 RK222", dict(Nphi=512, Ntheta=256), 5, 50)
