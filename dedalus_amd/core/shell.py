@@ -1864,14 +1864,22 @@ class ShellInitialValueSolver(IVPLifecycle, ShellSolverBase):
     def factor(self, a, b, reuse=-1):
         old = self._lus[reuse] if (reuse is not None and reuse >= 0) else None
         inv = self._inverse_terms(a, b, old=old)
+        if not hasattr(self, "_lu_params"):
+            self._lu_params = {}
         if reuse is not None and reuse >= 0:
             self._lus[reuse] = inv
+            self._lu_params[reuse] = (float(a), float(b))
             return reuse
         self._lus.append(inv)
+        self._lu_params[len(self._lus) - 1] = (float(a), float(b))
         return len(self._lus) - 1
 
     def solve(self, lu, rhs, x):
         self._lus[lu].apply(rhs, x)
+        probe = getattr(self, "solve_probe", None)
+        if probe is not None:                        # parity checks: keep (a, b, rhs, x) of every solve
+            a, b = self._lu_params[lu]
+            probe.append(dict(a=a, b=b, rhs=self.ex.download(rhs).copy(), x=self.ex.download(x).copy()))
 
 
 
