@@ -90,6 +90,9 @@ def launch_ranks(n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    if os.environ.get("BENCH_DRY_LAUNCH"):          # (tests: show the launch line instead of running it)
+        print(json.dumps(cmd))
+        sys.exit(0)
     os.execvpe(cmd[0], cmd, env)
 
 

@@ -48,6 +48,8 @@ class Comm:
         the others through the already initialised process group."""
         if self.backend != "nccl" or os.environ.get("DDH_A2A_VIA", "rccl") == "torch":
             return None
+        if self._lib_comm is False:
+            return None
         if self._lib_comm is None:
             import ctypes as C
             from . import libhip
@@ -59,9 +61,45 @@ class Comm:
             self.dist.broadcast(ident, src=0)
             buf = (C.c_ubyte * 128)(*[int(v) for v in ident.cpu().tolist()])
             h = C.c_uint64(0)
-            libhip.call("ddh_comm_create", C.byref(h), self.rank, self.size, buf)
-            self._lib_comm = h
-        return self._lib_comm
+            try:
+                libhip.call("ddh_comm_create", C.byref(h), self.rank, self.size, buf)
+                ok = self._self_check(h)
+            except Exception as e:                   # (an RCCL that cannot initialise here: use the process group)
+                ok = False
+                import logging
+                logging.getLogger(__name__).warning("library RCCL communicator unavailable (%s)" % (e,))
+            # every rank must take the same path
+            flag = t.tensor([1 if ok else 0], dtype=t.int32, device="cuda")
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                import logging
+                logging.getLogger(__name__).warning("pencil transposes fall back to torch.distributed all_to_all_single")
+                self._lib_comm = False
+            else:
+                self._lib_comm = h
+        return self._lib_comm or None
+
+    def _self_check(self, h):
+        """One tiny transpose each way through the library plan against the definition of the two layouts
+        (column-local CL[n0][n1][n2/P][n3], row-local RL[n0][n1/P][n2][n3] of one global array)."""
+        import ctypes as C
+        from . import libhip
+        t, P, r = self.torch, self.size, self.rank
+        n0, n1, n2, n3 = 2, 2 * P, 3 * P, 2
+        A = np.arange(n0 * n1 * n2 * n3, dtype=np.float64).reshape(n0, n1, n2, n3)
+        cl = np.ascontiguousarray(A[:, :, r * (n2 // P):(r + 1) * (n2 // P), :])
+        rl = np.ascontiguousarray(A[:, r * (n1 // P):(r + 1) * (n1 // P), :, :])
+        plan = C.c_uint64(0)
+        libhip.call("ddh_a2a_plan", C.byref(plan), h, n0, n1, n2, n3)
+        d_cl, d_rl = t.from_numpy(cl).cuda(), t.empty(rl.shape, dtype=t.float64, device="cuda")
+        d_back = t.empty(cl.shape, dtype=t.float64, device="cuda")
+        st = C.c_void_p(t.cuda.current_stream().cuda_stream)
+        libhip.call("ddh_a2a_localize_rows", plan, C.c_void_p(d_cl.data_ptr()), C.c_void_p(d_rl.data_ptr()), st)
+        libhip.call("ddh_a2a_localize_columns", plan, C.c_void_p(d_rl.data_ptr()), C.c_void_p(d_back.data_ptr()), st)
+        t.cuda.synchronize()
+        ok = bool(np.array_equal(d_rl.cpu().numpy(), rl) and np.array_equal(d_back.cpu().numpy(), cl))
+        libhip.call("ddh_destroy", plan)
+        return ok
 
     def all_to_all(self, recv, send):
         """Equal-split all-to-all on flat buffers (torch tensors, or numpy arrays for the CPU oracle)."""

@@ -61,3 +61,21 @@ def test_install_registers_plan_classes():
     assert A.transforms["hip"] is bindings.HipRealFFT and B.transforms["hip"] is bindings.HipJacobi
     assert bindings.HipSWSHColatitude._reduced((3, 16, 12, 5), 2) == (3, 16, 12, 5)
     assert bindings.HipSWSHColatitude._reduced((2, 3, 16, 12), 3) == (6, 16, 12, 1)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N ranks on
+    127.0.0.1 (the driver may call it either way); with WORLD_SIZE set it does not"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_DRY_LAUNCH="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")

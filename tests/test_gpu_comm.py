@@ -118,3 +118,32 @@ def test_two_rank_nccl_run_matches_reference(golden_dir):
             ref = gold[case + "__" + key]
             full = np.concatenate([p[key] for p in parts], axis=ref.ndim - 3)
             assert np.linalg.norm(full - ref) / np.linalg.norm(ref) < tol, key
+
+
+def test_comm_bootstrap_through_a_one_rank_nccl_group():
+    """parallel.Comm on a 1-rank `nccl` process group: the RCCL unique id travels through the group, the library
+    communicator is created, self-checked (a transpose each way) and selected for the exchanges"""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d", world_size=1, rank=0)
+from dedalus_amd.parallel import Comm
+from dedalus_amd.executor import HipExecutor
+c = Comm(1)
+assert c.backend == "nccl" and c.library_comm() is not None
+ex = HipExecutor()
+plan = ex.a2a_plan(c, 2, 6, 4, 5)
+a = torch.randn(2, 6, 4, 5, dtype=torch.float64, device="cuda")
+b, d = torch.empty_like(a), torch.empty_like(a)
+ex.a2a_localize_rows(plan, a, b); ex.a2a_localize_columns(plan, b, d)
+torch.cuda.synchronize()
+assert torch.equal(a, b) and torch.equal(a, d)
+assert abs(c.bcast_float(3.25) - 3.25) == 0 and c.allreduce_max(2.0) == 2.0
+dist.destroy_process_group()
+print("OK")
+''' % (ROOT, 29600 + os.getpid() % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
