@@ -38,9 +38,17 @@ class IVPLifecycle:
         """core/solvers.py:603-611: root's clock on every rank"""
         t = time.time()
         pcomm = getattr(self.dist, "pcomm", None)
-        if pcomm is not None and getattr(self.dist, "size", 1) > 1:
+        if pcomm is not None and getattr(self.dist, "size", 1) > 1 and self._clock_decides():
             t = pcomm.bcast_float(t)
         return t
+
+    def _clock_decides(self):
+        """Does any decision depend on the wall clock (stop_wall_time, a handler scheduled by wall_dt)?  Only then is the
+        broadcast worth its price: on the GPUs it synchronises host and device once per step."""
+        if np.isfinite(getattr(self, "stop_wall_time", np.inf)):
+            return True
+        ev = getattr(self, "evaluator", None)
+        return any(getattr(h, "wall_dt", None) for h in getattr(ev, "handlers", ()))
 
     @property
     def wall_time(self):
