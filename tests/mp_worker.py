@@ -44,6 +44,20 @@ def main():
         solver.evaluator.evaluate_handlers([h], iteration=solver.iteration, sim_time=solver.sim_time, timestep=0.05,
                                            wall_time=0.0)
         h.close()
+    elif case == "refpencils":
+        # the sharded solve against the reference's own pencil matrices (tests/pencil_check.py): every rank checks the
+        # sampled pencils it owns
+        import pencil_check
+        ref = pencil_check.ReferencePencils()
+        solver, f = problems.rayleigh_benard_3d(d3, Nx=8, Ny=8, Nz=ref.nz, Lx=4 / ref.stride, Ly=4 / ref.stride,
+                                                dist_kw=dist_kw)
+        lo = solver.dist._mx_offset
+        mine = [g for g in ref.groups if lo <= g[0] < lo + solver.nx // 2]
+        solver.solve_probe = dict(groups=mine, records=[])
+        solver.step(1e-3)
+        out = pencil_check.check_records(ref, solver.solve_probe["records"], mine)
+        res = dict(npencils=np.array(len(mine)), residual=np.array([r["residual"] for r in out]),
+                   solution=np.array([r["solution"] for r in out]), dropped=np.array([r["dropped_max"] for r in out]))
     elif case == "shell_cfl":
         solver, dts, speeds, res = problems.run_shell_cfl_case(d3, dist_kw=dist_kw)
         res = dict(res, dts=np.array(dts), speeds=np.array(speeds))

@@ -102,3 +102,13 @@ def test_m_sharded_shell_cfl_sequence(golden_dir):
             assert np.allclose(p["dts"], gold["shellcfl__dts"], rtol=1e-10, atol=0)
             assert np.allclose(p["speeds"], gold["shellcfl__speeds"], rtol=1e-10, atol=0)
         check_shell_parts(parts, gold, "shellcfl__", ["p", "b", "u"])
+
+
+def test_sharded_solve_against_the_references_pencil_matrices(tmp_path):
+    """2 ranks (kx-sharded pencils, gloo): every solve on the 16 sampled pencils of the Nz = 256 problem against the
+    reference's own M_min / L_min (tests/golden/pencils_nz256.npz) -- the multi-rank twin of
+    tests/test_reference_pencils.py (mode offsets of the local pencils, SolverBase.gather_pencil on a shard)"""
+    parts = _run_worker("refpencils", 2, str(tmp_path))
+    assert sum(int(p["npencils"]) for p in parts) == 16 and all(int(p["npencils"]) == 8 for p in parts)
+    for p in parts:
+        assert p["residual"].max() < 1e-13 and p["solution"].max() < 1e-11 and p["dropped"].max() == 0.0
