@@ -336,6 +336,26 @@ class Transformer:
         else:
             run()
 
+    def backward_dual_step(self, domain, ncomp, src, scales, step, dscale):
+        """Backward step `step` (a RealFourier axis, not the exchange step) applied to data that has seen the steps before
+        it, twice from one read: -> (transform, transform of the derivative along that axis).  None when the executor
+        has no dual kernel."""
+        ex = self.dist.executor
+        if not hasattr(ex, "transform_dual"):
+            return None
+        steps = self._steps(domain, scales)
+        pos, b, spec = steps[step]
+        if spec[0] != "rfft" or (self._needs_exchange(domain) and pos == 0):
+            return None
+        shape = list(self.stage_shape(domain, ncomp, scales, step))
+        ax = self.dist.storage_order[pos]
+        outer = int(np.prod(shape[:pos + 1]))
+        inner = int(np.prod(shape[pos + 2:]))
+        shape[pos + 1] = b.grid_size(scales[ax])
+        out, out_d = ex.empty(tuple(shape)), ex.empty(tuple(shape))
+        ex.transform_dual(spec, b, src, out, out_d, outer, inner, dscale)
+        return out, out_d
+
     def backward_data(self, domain, ncomp, c, g, scales, skip_last=False):
         """coefficient -> grid.  skip_last stops before the last storage axis ("pre-grid" layout)."""
         n = self.nsteps(domain, scales) - (1 if skip_last else 0)

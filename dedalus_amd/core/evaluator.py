@@ -303,7 +303,15 @@ class Evaluator:
             res = leaf.coeff_data().reshape((leaf.ncomp,) + tuple(dom.storage_coeff_shape()))
         else:
             prev = self.eval_stage(leaf, k - 1)
-            res = self.dist.transformer.backward_steps(dom, leaf.ncomp, prev, dom.dealias, k - 1, k)
+            res = None
+            want = getattr(self, "_dual_want", {}).get((id(leaf), k - 1))
+            if want is not None and os.environ.get("DDH_NO_DUAL_FFT") is None:
+                # this field AND its derivative along the axis of step k - 1 are operands: one kernel, one read
+                pair = self.dist.transformer.backward_dual_step(dom, leaf.ncomp, prev, dom.dealias, k - 1, want)
+                if pair is not None:
+                    res, self.cache[("sd", id(leaf), k - 1, want)] = pair
+            if res is None:
+                res = self.dist.transformer.backward_steps(dom, leaf.ncomp, prev, dom.dealias, k - 1, k)
         self.cache[key] = res
         return res
 
@@ -424,6 +432,15 @@ class Evaluator:
                 for co, ci in members:
                     res[co] = (pg, ci, dscale)
                 continue
+            stash = None
+            if step + 1 == n - 1:
+                if getattr(self, "_dual_want", {}).get((lid, step)) == dscale and ("s", lid, step + 1) not in self.cache:
+                    self.eval_stage(leaf, step + 1)     # the field's own transform is needed too: make both now
+                stash = self.cache.get(("sd", lid, step, dscale))
+            if stash is not None:                       # produced together with the field's own transform
+                for co, ci in members:
+                    res[co] = (stash, ci, 0.0)
+                continue
             src = self.eval_stage(leaf, step)
             cis = sorted({ci for _, ci in members})
             if cis == list(range(leaf.ncomp)):
@@ -469,11 +486,43 @@ class Evaluator:
             return None
         return a0, b0, terms, last[0], last[1]
 
+    def _plan_dual_transforms(self, operands):
+        """Fields whose transform along a (non-last) RealFourier step is needed both plain and differentiated -- e.g. u and
+        d/dx u of u.grad(u): eval_stage then produces both from one read (Transformer.backward_dual_step).  The plain
+        transform counts as needed when the field itself or its last-axis derivative (taken from the field's own
+        pre-grid lines) is an operand."""
+        want = getattr(self, "_dual_want", None)
+        if want is None:
+            want = self._dual_want = {}
+        tr = self.dist.transformer
+        plain, derived = set(), {}
+        for x in operands:
+            x = self.canon(x)
+            if isinstance(x, Field):
+                plain.add(id(x))
+                continue
+            d, generic, sub = self._component_plan(x)
+            n = None
+            per = {}
+            for co, (leaf, ci, step, dscale) in d.items():
+                n = tr.nsteps(leaf.domain, leaf.domain.dealias)
+                if step == n - 1:
+                    plain.add(id(leaf))
+                else:
+                    per.setdefault((id(leaf), step, dscale), [leaf, set()])[1].add(ci)
+            for (lid, step, dscale), (leaf, cis) in per.items():
+                if cis == set(range(leaf.ncomp)) and step + 1 == tr.nsteps(leaf.domain, leaf.domain.dealias) - 1:
+                    derived[(lid, step)] = dscale
+        for (lid, step), dscale in derived.items():
+            if lid in plain:
+                want[(lid, step)] = dscale
+
     def eval_fused_products(self, group, outs):
         """One fused launch for product nodes that share their register operand `a`.
         group: [(expr, (a, b, terms, basis, spec))]; outs: pre-grid result arrays [ncomp, ..., M]."""
         a = group[0][1][0]
         basis, spec = group[0][1][3], group[0][1][4]
+        self._plan_dual_transforms([a] + [fp[1] for _, fp in group])
         la = self._operand_lines(a)
         a_list = [par[i] for (par, i, ds) in la]
         a_ds = [ds for (par, i, ds) in la]

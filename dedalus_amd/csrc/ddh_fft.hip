@@ -253,6 +253,15 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     long long t_start = 0, t_loaded = 0, t_fft = 0;
     if (p.prof) t_start = clock64();
 
+    // Dual output (RFFT_BWD only, ddh_rfft_backward_dual): a second pass transforms the SAME coefficient tile again with
+    // another derivative scale into dst2 -- the field and its derivative along the axis from one HBM read of the
+    // coefficients (the second pass re-reads the tile the workgroup has just read: L2 hits).
+    const int npass = (MODE == RFFT_BWD && p.dst2 != nullptr) ? 2 : 1;
+    double *const dst_first = dst;
+    for (int pass = 0; pass < npass; ++pass) {
+    const double dsc = (pass == 0) ? p.dscale : p.dscale2;
+    dst = (pass == 0) ? dst_first : p.dst2;
+    if (pass) __syncthreads();          // the LDS tile of the first pass has been stored
     // ---------------------------------------------------------------- load + pre-process
     if (p.dbg & 4) {
         // timing ablation: no loads
@@ -327,8 +336,8 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                     if (kk[u] < 0) continue;
                     const int k = kk[u], b = bb[u];
                     double2 c = cc[u], s = ss[u];
-                    if (p.dscale != 0.0) {   // d/dx: (cos, msin) -> (-kappa msin, kappa cos)
-                        const double kap = p.dscale * (double)k;
+                    if (dsc != 0.0) {   // d/dx: (cos, msin) -> (-kappa msin, kappa cos)
+                        const double kap = dsc * (double)k;
                         const double2 c2 = make_double2(-kap * s.x, -kap * s.y);
                         s = make_double2(kap * c.x, kap * c.y);
                         c = c2;
@@ -356,8 +365,8 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                     if (2 * (q0 + b) + 1 < io.nlines) vb = *reinterpret_cast<const double2 *>(pa + M);
                     c = make_double2(va.x, vb.x);
                     s = make_double2(va.y, vb.y);
-                    if (p.dscale != 0.0) {
-                        const double kap = p.dscale * (double)k;
+                    if (dsc != 0.0) {
+                        const double kap = dsc * (double)k;
                         const double2 c2 = make_double2(-kap * s.x, -kap * s.y);
                         s = make_double2(kap * c.x, kap * c.y);
                         c = c2;
@@ -657,6 +666,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             *reinterpret_cast<double2 *>(ptr) = buf[b * ld + lpad(j)];
         }
     }
+    }   // pass
     if (p.prof) {
         __syncthreads();
         if (tid == 0) {
@@ -1037,10 +1047,12 @@ static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nba
 
 template <int MODE>
 static int launch(FftPlan *pl, const double *src, double *dst, long outer, long inner, void *stream,
-                  double dscale = 0.0) {
+                  double dscale = 0.0, double *dst2 = nullptr, double dscale2 = 0.0) {
     if (outer <= 0 || inner <= 0) return 0;
     FftDev d = pl->dev;
     d.dscale = dscale;
+    d.dst2 = dst2;
+    d.dscale2 = dscale2;
     const bool is_cfft = (MODE == CFFT_FWD || MODE == CFFT_BWD);
     const bool inner_mode = inner > 1;
     long npairs;
@@ -1251,6 +1263,21 @@ int ddh_rfft_backward_deriv(ddh_handle plan, const double *c, double *g, long ou
                                 as_stream(stream)))
         return st0;
     return launch<RFFT_BWD>(pl, c, g, outer, inner, stream, dscale);
+}
+int ddh_rfft_backward_dual(ddh_handle plan, const double *c, double *g, double *g_deriv, long outer, long inner,
+                           double dscale, void *stream) {
+    FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
+    if (!pl) return -1;
+    if (pl->tkind != K_RFFT) return fail("ddh_rfft_backward_dual: plan is of a different transform kind");
+    if (outer <= 0 || inner <= 0) return 0;
+    if (!g || !g_deriv || g == g_deriv) return fail("ddh_rfft_backward_dual: two distinct outputs required");
+    const size_t nc = (size_t)pl->dev.M * outer * inner, ng = (size_t)pl->dev.N * outer * inner;
+    const char *c0 = (const char *)c, *c1 = c0 + nc * sizeof(double);
+    for (const double *o : {(const double *)g, (const double *)g_deriv}) {
+        const char *o0 = (const char *)o, *o1 = o0 + ng * sizeof(double);
+        if (!(c1 <= o0 || o1 <= c0)) return fail("ddh_rfft_backward_dual: the outputs must not overlap the input");
+    }
+    return launch<RFFT_BWD>(pl, c, g, outer, inner, stream, 0.0, g_deriv, dscale);
 }
 DDH_FFT_ENTRY(ddh_cheb_forward, K_CHEB, CHEB_FWD)
 DDH_FFT_ENTRY(ddh_cheb_backward, K_CHEB, CHEB_BWD)

@@ -48,6 +48,8 @@ struct FftDev {
     const double *bands;   // [nbands][M]
     int B;                 // line pairs per workgroup
     double dscale;         // RFFT_BWD: != 0 differentiates along the axis while loading (2 pi / L)
+    double *dst2;          // RFFT_BWD dual output: second destination (null = single output) ...
+    double dscale2;        // ... transformed with this derivative scale
     int spread_s, spread_c; // strided kernels: workgroup spreading over the address range (see kernel)
     int dbg;               // timing ablations (debug): 1 skip butterfly math, 2 skip FFT passes, 4 skip unpack, 8 skip products
     int rot;               // fused kernel: rotate the butterfly->wave assignment per workgroup

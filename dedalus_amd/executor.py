@@ -189,6 +189,22 @@ class HipExecutor:
         else:
             libhip.call("ddh_%s_%s" % (kind, direction), h, ptr(src), ptr(dst), outer, inner, self.dev.stream)
 
+    def transform_dual(self, spec, basis, src, dst, dst_deriv, outer, inner, dscale):
+        """dst = backward RealFourier transform of src, dst_deriv = the same of d/dx src: one read of the coefficients
+        (ddh_rfft_backward_dual)."""
+        if self.timer is not None:
+            nb = (src.numel() + dst.numel() + dst_deriv.numel()) * 8
+            return self.timer.run("rfft_backward_%s_dual" % ("strided" if inner > 1 else "contig"), nb,
+                                  self._transform_dual, spec, basis, src, dst, dst_deriv, outer, inner, dscale)
+        return self._transform_dual(spec, basis, src, dst, dst_deriv, outer, inner, dscale)
+
+    def _transform_dual(self, spec, basis, src, dst, dst_deriv, outer, inner, dscale):
+        kind, h, _ = self._plan(spec, basis)
+        if kind != "rfft":
+            raise NotImplementedError("dual transform: RealFourier axes only")
+        libhip.call("ddh_rfft_backward_dual", h, ptr(src), ptr(dst), ptr(dst_deriv), outer, inner, float(dscale),
+                    self.dev.stream)
+
     def cfl_max(self, u, ncomp, shape, inv_spacings, comp_axis):
         """max over the grid of sum_c |u_c| / dx_c; inv_spacings: device arrays per component."""
         n = int(np.prod(shape))

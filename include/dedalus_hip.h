@@ -54,6 +54,12 @@ int ddh_rfft_backward(ddh_handle plan, const double *c, double *g, long outer, l
 int ddh_rfft_backward_deriv(ddh_handle plan, const double *c, double *g, long outer, long inner, double dscale,
                             void *stream);
 
+/* Both at once: g = backward transform of c, g_deriv = backward transform of d/dx c, from ONE read of the coefficients
+ * (the nonlinear terms need a field and its derivative along the same axis: core/operators.py gradient components).
+ * g, g_deriv: distinct buffers that do not overlap c.                                                              */
+int ddh_rfft_backward_dual(ddh_handle plan, const double *c, double *g, double *g_deriv, long outer, long inner,
+                           double dscale, void *stream);
+
 /* ComplexFourier: replaces FFTWComplexFFT core/transforms.py:292-330 (resize_coeffs :243-267 fused).
  * Arrays are complex128 stored as interleaved doubles; `inner` counts complex elements.        */
 int ddh_plan_cfft(ddh_handle *plan, int n_grid, int n_coeff);

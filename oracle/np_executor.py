@@ -186,6 +186,11 @@ class NumpyExecutor:
             raise NotImplementedError(kind)
         dst[...] = res.reshape(dst.shape)
 
+    def transform_dual(self, spec, basis, src, dst, dst_deriv, outer, inner, dscale):
+        """The field's backward RealFourier transform and that of its derivative (two plain transforms here)."""
+        self.transform(spec, basis, "backward", src, dst, outer, inner)
+        self.transform(spec, basis, "backward", src, dst_deriv, outer, inner, deriv=dscale)
+
     def cfl_max(self, u, ncomp, shape, inv_spacings, comp_axis):
         """compute_cfl_frequency (core/basis.py:6108-6111) + global max (extras/flow_tools.py:199-204)"""
         ug = np.abs(u.reshape((ncomp,) + tuple(shape)))

@@ -113,6 +113,46 @@ def test_real_fourier_vs_oracle(dev, N, M, shape_kind):
     assert rel(_run(dev, "ddh_rfft_backward", plan, cin, shape, axis), npt.rfft_backward(cin, axis, N)) < TOL
 
 
+@pytest.mark.parametrize("N,M", [(768, 512), (96, 64), (60, 40), (64, 64)])
+@pytest.mark.parametrize("shape_kind", ["contig", "strided_even", "strided_odd"])
+def test_real_fourier_dual_backward(dev, N, M, shape_kind):
+    """ddh_rfft_backward_dual == ddh_rfft_backward and ddh_rfft_backward_deriv of the same coefficients (bit for bit: the
+    passes run the same arithmetic) and both agree with the oracle."""
+    from dedalus_amd import libhip
+    from dedalus_amd.device import ptr
+    from oracle import np_transforms as npt
+    rng = np.random.default_rng(77)
+    shape, axis = {"contig": ((7, N), 1), "strided_even": ((3, N, 10), 1), "strided_odd": ((2, N, 7), 1)}[shape_kind]
+    plan = _plan("ddh_plan_rfft", N, M)
+    cs = list(shape)
+    cs[axis] = M
+    cin = rng.standard_normal(cs)
+    dscale = 2 * np.pi / 4.0
+    outer, inner = int(np.prod(shape[:axis])), int(np.prod(shape[axis + 1:]))
+    d_c = dev.from_host(cin)
+    outs = [dev.empty(shape, np.float64) for _ in range(4)]
+    for o in outs:
+        o.fill_(float("nan"))
+    libhip.call("ddh_rfft_backward_dual", plan, ptr(d_c), ptr(outs[0]), ptr(outs[1]), outer, inner, dscale, dev.stream)
+    libhip.call("ddh_rfft_backward", plan, ptr(d_c), ptr(outs[2]), outer, inner, dev.stream)
+    libhip.call("ddh_rfft_backward_deriv", plan, ptr(d_c), ptr(outs[3]), outer, inner, dscale, dev.stream)
+    dev.sync()
+    g, gd, g1, gd1 = [dev.to_host(o) for o in outs]
+    assert np.array_equal(dev.to_host(d_c), cin)
+    assert np.array_equal(g, g1) and np.array_equal(gd, gd1)
+    k = (dscale * np.arange(M // 2))
+    sh = [1] * len(shape)
+    sh[axis] = -1
+    dc = np.empty_like(cin)
+    ev = [slice(None)] * len(shape)
+    od = list(ev)
+    ev[axis], od[axis] = slice(0, None, 2), slice(1, None, 2)
+    dc[tuple(ev)] = -k.reshape(sh) * cin[tuple(od)]
+    dc[tuple(od)] = k.reshape(sh) * cin[tuple(ev)]
+    assert rel(g, npt.rfft_backward(cin, axis, N)) < TOL
+    assert rel(gd, npt.rfft_backward(dc, axis, N)) < TOL
+
+
 @pytest.mark.parametrize("N,M", [(384, 256), (768, 512), (96, 64), (48, 64), (90, 60)])
 @pytest.mark.parametrize("alpha", [0, 1, 2])
 @pytest.mark.parametrize("shape_kind", ["contig", "strided_even", "strided_odd"])
