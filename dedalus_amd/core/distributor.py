@@ -275,31 +275,7 @@ class Transformer:
                 ex.transform(spec, b, "backward", src, out, outer, inner)
             src = out
             if exchange and pos == 0:
-                # [comp, Gz, nx_loc, ny] -> [comp, Gz/P, nx, ny]
-                P = self.dist.size
-                nc, Gz, nxl = shape[0], shape[1], shape[2]
-                rest = int(np.prod(shape[3:]))
-                shape[1], shape[2] = Gz // P, nxl * P
-                out2 = dst if (last and dst is not None) else ex.empty(tuple(shape))
-                if nc > 1 and _overlap():
-                    # per-component pipeline: the exchange of component c runs (on the communicator's stream) while
-                    # component c + 1 is packed and component c - 1 is unpacked
-                    n1 = int(Gz * nxl * rest)
-                    pend = None
-                    for c in range(nc):
-                        send = ex.empty((n1,))
-                        ex.a2a_pack(src[c:c + 1], send, 1, Gz, nxl, rest, P)
-                        recv = ex.empty((n1,))
-                        work = self.dist.pcomm.all_to_all_start(recv, send)
-                        if pend is not None:
-                            pend[0].wait()
-                            ex.a2a_unpack(pend[1], out2[pend[2]:pend[2] + 1], 1, Gz // P, nxl * P, rest, P)
-                        pend = (work, recv, c, send)
-                    pend[0].wait()
-                    ex.a2a_unpack(pend[1], out2[pend[2]:pend[2] + 1], 1, Gz // P, nxl * P, rest, P)
-                else:
-                    self._exchange(ex, "rows", src, out2, nc, Gz, nxl * P, rest)
-                src = out2
+                src = self._rows_after_z(ex, src, shape, dst if last else None)
         return src
 
     def _exchange(self, ex, which, src, dst, n0, n1, n2, n3):
@@ -335,6 +311,52 @@ class Transformer:
             timer.run("a2a_exchange", 2 * nbytes, run)         # pack read+write, unpack read+write ~ 4x; wire 1x
         else:
             run()
+
+    def _rows_after_z(self, ex, src, shape, dst=None):
+        """The pencil transpose that follows the backward z transform: [comp, Gz, nx_loc, ny] -> [comp, Gz/P, nx, ny]
+        (`shape` is updated in place)."""
+        P = self.dist.size
+        nc, Gz, nxl = shape[0], shape[1], shape[2]
+        rest = int(np.prod(shape[3:]))
+        shape[1], shape[2] = Gz // P, nxl * P
+        out2 = dst if dst is not None else ex.empty(tuple(shape))
+        if nc > 1 and _overlap():
+            # per-component pipeline: the exchange of component c runs (on the communicator's stream) while
+            # component c + 1 is packed and component c - 1 is unpacked
+            n1 = int(Gz * nxl * rest)
+            pend = None
+            for c in range(nc):
+                send = ex.empty((n1,))
+                ex.a2a_pack(src[c:c + 1], send, 1, Gz, nxl, rest, P)
+                recv = ex.empty((n1,))
+                work = self.dist.pcomm.all_to_all_start(recv, send)
+                if pend is not None:
+                    pend[0].wait()
+                    ex.a2a_unpack(pend[1], out2[pend[2]:pend[2] + 1], 1, Gz // P, nxl * P, rest, P)
+                pend = (work, recv, c, send)
+            pend[0].wait()
+            ex.a2a_unpack(pend[1], out2[pend[2]:pend[2] + 1], 1, Gz // P, nxl * P, rest, P)
+        else:
+            self._exchange(ex, "rows", src, out2, nc, Gz, nxl * P, rest)
+        return out2
+
+    def backward_dual_z(self, ldomain, xdomain, ncomp, src, scales, dvec):
+        """The backward Jacobi-axis step (step 0) of a field's coefficients twice from one read: -> (the field's transform,
+        the transform of the one-superdiagonal operator `dvec` (device array) applied to the coefficients, taken in
+        xdomain's basis), each followed by the pencil transpose on several ranks."""
+        ex = self.dist.executor
+        pos, b, spec = self._steps(xdomain, scales)[0]
+        shape = list(self.stage_shape(ldomain, ncomp, scales, 0))
+        ax = self.dist.storage_order[pos]
+        outer = int(np.prod(shape[:pos + 1]))
+        inner = int(np.prod(shape[pos + 2:]))
+        shape[pos + 1] = b.grid_size(scales[ax])
+        out, out_d = ex.empty(tuple(shape)), ex.empty(tuple(shape))
+        ex.transform_dual_z(spec, b, src, out, out_d, dvec, outer, inner)
+        if self._needs_exchange(ldomain) and pos == 0:
+            out = self._rows_after_z(ex, out, list(shape))
+            out_d = self._rows_after_z(ex, out_d, list(shape))
+        return out, out_d
 
     def backward_dual_step(self, domain, ncomp, src, scales, step, dscale):
         """Backward step `step` (a RealFourier axis, not the exchange step) applied to data that has seen the steps before

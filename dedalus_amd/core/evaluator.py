@@ -304,8 +304,12 @@ class Evaluator:
         else:
             prev = self.eval_stage(leaf, k - 1)
             res = None
+            wz = getattr(self, "_dualz_want", {}).get(id(leaf)) if k == 1 else None
+            if wz is not None:
+                self._z_dual(leaf, *wz)                 # the z-derivative is an operand too: both from one read
+                res = self.cache.get(key)
             want = getattr(self, "_dual_want", {}).get((id(leaf), k - 1))
-            if want is not None and os.environ.get("DDH_NO_DUAL_FFT") is None:
+            if res is None and want is not None and os.environ.get("DDH_NO_DUAL_FFT") is None:
                 # this field AND its derivative along the axis of step k - 1 are operands: one kernel, one read
                 pair = self.dist.transformer.backward_dual_step(dom, leaf.ncomp, prev, dom.dealias, k - 1, want)
                 if pair is not None:
@@ -373,6 +377,57 @@ class Evaluator:
             return None
         return (leaf, t.ci, step[0], float(r.real) * 2.0 * np.pi / basis.length)
 
+    def _z_derived_component(self, x, items, steps):
+        """(leaf, ci, dvec) when component `items` of x is a one-superdiagonal operator along the Jacobi axis -- the
+        z-derivative (DifferentiateJacobi, core/basis.py:806-840: T_n -> the (a0+1, b0+1) family, one superdiagonal) -- of
+        one component of a field kept in the family's own basis: its grid data then comes out of the field's own backward
+        z transform, second pass (Transformer.backward_dual_z), instead of a sparse mat-vec and a transform of its own."""
+        if len(items) != 1 or not hasattr(self.dist.executor, "transform_dual_z"):
+            return None
+        leaf, t = items[0]
+        if not isinstance(leaf, Field) or getattr(leaf, "_is_number", False):
+            return None
+        if t.ex or t.ey or t.dx or t.dy or t.dt or t.coef.imag != 0.0:
+            return None
+        ld, xd = leaf.domain, x.domain
+        if ld.dealias != xd.dealias or ld.storage_coeff_shape() != xd.storage_coeff_shape():
+            return None
+        if ld.storage_grid_shape(ld.dealias) != xd.storage_grid_shape(xd.dealias):
+            return None
+        lsteps = self.dist.transformer._steps(ld, ld.dealias)
+        if not steps or not lsteps or steps[0][2][0] != "cheb" or lsteps[0][2][0] != "cheb":
+            return None
+        if steps[0][0] != 0 or lsteps[0][0] != 0 or tuple(steps[0][2][1:3]) != tuple(lsteps[0][2][1:3]):
+            return None
+        bl, bx = lsteps[0][1], steps[0][1]
+        if (bl.a, bl.b) != (bl.a0, bl.b0) or (bx.a, bx.b) == (bx.a0, bx.b0):
+            return None                                 # pass 0 has no conversion solve, pass 1 needs the plan's
+        Z = t.Z.tocoo()
+        M = steps[0][2][2]
+        if Z.shape != (M, M) or Z.nnz == 0 or np.any(Z.col - Z.row != 1):
+            return None
+        dvec = np.zeros(M)
+        np.add.at(dvec, Z.row, Z.data.real * t.coef.real)
+        if np.iscomplexobj(Z.data) and np.abs(Z.data.imag).max() > 0:
+            return None
+        return (leaf, t.ci, dvec)
+
+    def _z_dual(self, leaf, xdomain, dvec):
+        """Stage-1 data (z in grid space) of the z-derivative described by dvec, produced together with the field's own
+        stage-1 data (cache key ("s", id(leaf), 1))."""
+        key = ("sz", id(leaf), dvec.tobytes())
+        if key in self.cache:
+            return self.cache[key]
+        store = self.__dict__.setdefault("_dvec_dev", {})
+        dv = store.get(dvec.tobytes())
+        if dv is None:
+            dv = store[dvec.tobytes()] = self.dist.executor.from_host(dvec)
+        coeff = self.eval_stage(leaf, 0)
+        plain, der = self.dist.transformer.backward_dual_z(leaf.domain, xdomain, leaf.ncomp, coeff, leaf.domain.dealias, dv)
+        self.cache.setdefault(("s", id(leaf), 1), plain)
+        self.cache[key] = der
+        return der
+
     def _component_plan(self, x):
         """Split the components of a linear expression into Fourier-derivative components (see
         _derived_component) and generic ones (evaluated by the batched mat-vec)."""
@@ -388,12 +443,19 @@ class Evaluator:
                 per[t.co].append((leaf, t))
         derived, generic = {}, []
         no_deriv = os.environ.get("DDH_NO_DERIV_AT_LOAD") is not None
+        zder = {}
+        no_zdual = os.environ.get("DDH_NO_DUAL_Z") is not None
         for co in range(x.ncomp):
             d = None if no_deriv else self._derived_component(x, per[co], steps)
             if d is None:
-                generic.append(co)
+                z = None if no_zdual else self._z_derived_component(x, per[co], steps)
+                if z is None:
+                    generic.append(co)
+                else:
+                    zder[co] = z
             else:
                 derived[co] = d
+        x._fuse_zder = zder
         sub = None
         if generic:
             idx = {co: i for i, co in enumerate(generic)}
@@ -422,6 +484,15 @@ class Evaluator:
             arr = self._le_to_grid(sub, x.domain, len(generic), scales, skip_last=True)
             for i, co in enumerate(generic):
                 res[co] = (arr, i, 0.0)
+        zgroups = {}
+        for co, (leaf, ci, dvec) in getattr(x, "_fuse_zder", {}).items():
+            zgroups.setdefault((id(leaf), dvec.tobytes()), [leaf, dvec, []])[2].append((co, ci))
+        for leaf, dvec, members in zgroups.values():
+            der = self._z_dual(leaf, x.domain, dvec)
+            n = tr.nsteps(leaf.domain, scales)
+            out = tr.backward_steps(leaf.domain, leaf.ncomp, der, scales, 1, n - 1) if n - 1 > 1 else der
+            for co, ci in members:
+                res[co] = (out, ci, 0.0)
         groups = {}
         for co, (leaf, ci, step, dscale) in derived.items():
             groups.setdefault((id(leaf), step, dscale), [leaf, []])[1].append((co, ci))
@@ -502,6 +573,9 @@ class Evaluator:
                 plain.add(id(x))
                 continue
             d, generic, sub = self._component_plan(x)
+            zw = self.__dict__.setdefault("_dualz_want", {})
+            for co, (leaf, ci, dvec) in getattr(x, "_fuse_zder", {}).items():
+                zw.setdefault(id(leaf), (x.domain, dvec))
             n = None
             per = {}
             for co, (leaf, ci, step, dscale) in d.items():

@@ -256,7 +256,11 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     // Dual output (RFFT_BWD only, ddh_rfft_backward_dual): a second pass transforms the SAME coefficient tile again with
     // another derivative scale into dst2 -- the field and its derivative along the axis from one HBM read of the
     // coefficients (the second pass re-reads the tile the workgroup has just read: L2 hits).
-    const int npass = (MODE == RFFT_BWD && p.dst2 != nullptr) ? 2 : 1;
+    // CHEB_BWD (ddh_cheb_backward_dual): pass 0 is the plain transform of the coefficients (no conversion solve), pass 1
+    // transforms dvec[k] * c[k + 1] -- the z-derivative, a one-superdiagonal operator into the plan's (a0+1, b0+1) basis --
+    // through the plan's conversion solve.
+    const int npass = ((MODE == RFFT_BWD || MODE == CHEB_BWD) && p.dst2 != nullptr) ? 2 : 1;
+    const bool cheb_plain = (p.nbands == 0);
     double *const dst_first = dst;
     for (int pass = 0; pass < npass; ++pass) {
     const double dsc = (pass == 0) ? p.dscale : p.dscale2;
@@ -400,7 +404,7 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             for (int u = 0; u < LDU; ++u)
                 if (at[u] >= 0) buf[at[u]] = v[u];
         }
-    } else if (MODE == CHEB_BWD && p.nbands == 0) {
+    } else if (MODE == CHEB_BWD && (cheb_plain || (npass == 2 && pass == 0))) {
         // grid basis == coefficient basis: build the DCT-III input straight from global memory
         // (each coefficient is read as k and as N-k; the second read hits L1/L2), no staging buffer
         const int Mk = (M < N) ? M : N;
@@ -440,62 +444,173 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
             }
         }
     } else if (MODE == CHEB_BWD) {
-        for (int w = tid; w < M * B; w += T) {
-            int k, b;
-            split_item<INNER>(w, p.fdB, p.fdM, k, b);
-            double2 v = make_double2(0.0, 0.0);
-            // coefficients beyond the grid size are dropped BEFORE the conversion solve
-            // (transforms.py:878-881)
-            if (q0 + b < npairs && k < N) v = io.load(src, M, k, q0 + b);
-            cbuf[b * M + k] = v;
-        }
-        __syncthreads();
-        if (p.nbands > 0) {
-            // upper-banded back substitution (solve_upper_sparse, transforms.py:876-890):
-            // independent chains k == r (mod gcd_off), both lines of a pair at once.
-            const int g = p.gcd_off;
-            for (int w = tid; w < g * B; w += T) {
-                const int r = w % g, b = w / g;
-                double2 *c = cbuf + b * M;
-                int kstart = M - 1 - ((M - 1 - r) % g);  // largest k < M with k % g == r
-                for (int k = kstart; k >= 0; k -= g) {
-                    double2 acc = c[k];
-                    for (int d = 1; d < p.nbands; ++d) {
-                        const int kk = k + p.boff[d];
-                        if (kk < M) {
-                            const double a = p.bands[d * M + k];
-                            acc.x -= a * c[kk].x;
-                            acc.y -= a * c[kk].y;
-                        }
+        // Coefficients in a basis (a, b) != (a0, b0): conversion solve first.  They are staged IN the transform buffer,
+        // coefficient k at the padded slot of index k, solved in place and then turned into the DCT-III input pairwise
+        // in place (slots k and N - k depend on coefficients k and N - k only): no staging buffer, the tile is as
+        // large as the plain transform's.  Coefficients beyond the grid size are dropped BEFORE the conversion solve
+        // (transforms.py:878-881); with a zero right-hand side there the solve leaves them zero, so it starts at Mk - 1.
+        const int Mk = (M < N) ? M : N;
+        for (int w0 = tid; w0 < Mk * B; w0 += LDU * T) {      // LDU loads in flight per thread
+            double2 vv[LDU];
+            double dk[LDU];
+            int at[LDU];
+#pragma unroll
+            for (int u = 0; u < LDU; ++u) {
+                const int w = w0 + u * T;
+                at[u] = -1;
+                vv[u] = make_double2(0.0, 0.0);
+                dk[u] = 1.0;
+                if (w < Mk * B) {
+                    int k, b;
+                    if (Mk == M) {
+                        split_item<INNER>(w, p.fdB, p.fdM, k, b);
+                    } else {
+                        split_item<INNER>(w, p.fdB, p.fdN, k, b);
                     }
-                    const double inv = 1.0 / p.bands[k];
-                    c[k] = make_double2(acc.x * inv, acc.y * inv);
+                    at[u] = b * ld + lpad(k);
+                    if (npass == 2) {
+                        if (q0 + b < npairs && k + 1 < M) {
+                            vv[u] = io.load(src, M, k + 1, q0 + b);
+                            dk[u] = p.dvec[k];
+                        }
+                    } else if (q0 + b < npairs) {
+                        vv[u] = io.load(src, M, k, q0 + b);
+                    }
                 }
             }
-            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < LDU; ++u)
+                if (at[u] >= 0) buf[at[u]] = make_double2(dk[u] * vv[u].x, dk[u] * vv[u].y);
         }
-        const int Mk = (M < N) ? M : N;
-        for (int w = tid; w < N * B; w += T) {
-            unsigned q, r;
-            p.fdN.divmod((unsigned)w, q, r);
-            const int k = (int)r, b = (int)q;
-            const double2 *c = cbuf + b * M;
+        __syncthreads();
+        {
+            // upper-banded back substitution (solve_upper_sparse, transforms.py:876-890): independent chains
+            // k == r (mod gcd_off), both lines of a pair at once.
+            const int g = p.gcd_off;
+            const int nchain = g * B;
+            const int L = (Mk + g - 1) / g;                 // longest chain
+            const int E = (L + 63) >> 6;                    // chain elements per lane of a wavefront
+            if (p.bsub != nullptr && p.bsub_order == 1 && E <= 8) {
+                // First-order chains x_i = beta_i - alpha_i x_{i-1}: one wavefront per chain, affine-map prefix scan
+                // over the lanes (each lane composes its E consecutive elements, 6 shuffle steps combine the lanes).
+                const int lane = tid & 63, wv = tid >> 6;
+                const double *t0 = p.bsub, *t1 = p.bsub + M;
+                for (int ch = wv; ch < nchain; ch += T / 64) {
+                    const int r = ch % g, b = ch / g;
+                    double2 *c = buf + b * ld;
+                    const int kstart = Mk - 1 - ((Mk - 1 - r) % g);
+                    double2 beta[8];
+                    double alpha[8];
+                    double A = 1.0;
+                    double2 Bv = make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        beta[e] = make_double2(0.0, 0.0);
+                        alpha[e] = 0.0;
+                        const int k = kstart - (lane * E + e) * g;
+                        if (e < E && k >= 0) {
+                            const double2 v = c[lpad(k)];
+                            const double iv = t0[k];
+                            beta[e] = make_double2(v.x * iv, v.y * iv);
+                            alpha[e] = t1[k];
+                        }
+                        if (e < E) {        // elements past the chain end are the map x -> 0 - 0 x: harmless, never stored
+                            Bv = make_double2(beta[e].x - alpha[e] * Bv.x, beta[e].y - alpha[e] * Bv.y);
+                            A = -alpha[e] * A;
+                        }
+                    }
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const double Ap = __shfl_up(A, off, 64);
+                        const double Bx = __shfl_up(Bv.x, off, 64), By = __shfl_up(Bv.y, off, 64);
+                        if (lane >= off) {
+                            Bv = make_double2(Bv.x + A * Bx, Bv.y + A * By);
+                            A = A * Ap;
+                        }
+                    }
+                    double xx = __shfl_up(Bv.x, 1, 64), xy = __shfl_up(Bv.y, 1, 64);
+                    if (lane == 0) xx = xy = 0.0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = kstart - (lane * E + e) * g;
+                        if (e < E && k >= 0) {
+                            xx = beta[e].x - alpha[e] * xx;
+                            xy = beta[e].y - alpha[e] * xy;
+                            c[lpad(k)] = make_double2(xx, xy);
+                        }
+                    }
+                }
+            } else {
+                for (int w = tid; w < nchain; w += T) {
+                    const int r = w % g, b = w / g;
+                    double2 *c = buf + b * ld;
+                    const int kstart = Mk - 1 - ((Mk - 1 - r) % g);  // largest k < Mk with k % g == r
+                    if (p.bsub != nullptr) {
+                        // the two previous unknowns of the chain stay in registers: the loads of c and of the table do
+                        // not depend on the chain, which is then one fused multiply-add pair per step
+                        const double *t0 = p.bsub, *t1 = p.bsub + M, *t2 = p.bsub + 2 * M;
+                        double2 x1 = make_double2(0.0, 0.0), x2 = x1;
+#pragma unroll 4
+                        for (int k = kstart; k >= 0; k -= g) {
+                            const double2 v = c[lpad(k)];
+                            const double iv = t0[k], a1 = t1[k], a2 = t2[k];
+                            double2 x;
+                            x.x = v.x * iv - a1 * x1.x - a2 * x2.x;
+                            x.y = v.y * iv - a1 * x1.y - a2 * x2.y;
+                            c[lpad(k)] = x;
+                            x2 = x1;
+                            x1 = x;
+                        }
+                        continue;
+                    }
+                    for (int k = kstart; k >= 0; k -= g) {
+                        double2 acc = c[lpad(k)];
+                        for (int d = 1; d < p.nbands; ++d) {
+                            const int kk = k + p.boff[d];
+                            if (kk < Mk) {
+                                const double a = p.bands[d * M + k];
+                                acc.x -= a * c[lpad(kk)].x;
+                                acc.y -= a * c[lpad(kk)].y;
+                            }
+                        }
+                        const double inv = 1.0 / p.bands[k];
+                        c[lpad(k)] = make_double2(acc.x * inv, acc.y * inv);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int KH = N / 2 + 1;
+        for (int w = tid; w < KH * B; w += T) {
+            const int b = w / KH, k = w - b * KH;
+            double2 *line = buf + b * ld;
+            const int kr = N - k;
             double2 e = make_double2(0.0, 0.0), f = e;
             if (k < Mk) {
                 const double s = bscale_of(k);
-                e = make_double2(s * c[k].x, s * c[k].y);
+                const double2 v = line[lpad(k)];
+                e = make_double2(s * v.x, s * v.y);
             }
-            const int kr = N - k;
             if (k > 0 && kr < Mk) {
                 const double s = bscale_of(kr);
-                f = make_double2(s * c[kr].x, s * c[kr].y);
+                const double2 v = line[lpad(kr)];
+                f = make_double2(s * v.x, s * v.y);
             }
-            const double2 h = half_of(k);  // exp(-i pi k / 2N); we need its conjugate
-            const double cr = h.x, ci = -h.y;
-            // V^a = (e.x - i f.x)(cr + i ci), V^b likewise with .y ; Z = V^a + i V^b
-            const double var = e.x * cr + f.x * ci, vai = e.x * ci - f.x * cr;
-            const double vbr = e.y * cr + f.y * ci, vbi = e.y * ci - f.y * cr;
-            buf[b * ld + lpad(k)] = make_double2(var - vbi, vai + vbr);
+            {
+                const double2 h = half_of(k);  // exp(-i pi k / 2N); we need its conjugate
+                const double cr = h.x, ci = -h.y;
+                // V^a = (e.x - i f.x)(cr + i ci), V^b likewise with .y ; Z = V^a + i V^b
+                const double var = e.x * cr + f.x * ci, vai = e.x * ci - f.x * cr;
+                const double vbr = e.y * cr + f.y * ci, vbi = e.y * ci - f.y * cr;
+                line[lpad(k)] = make_double2(var - vbi, vai + vbr);
+            }
+            if (k > 0 && kr != k) {            // the partner slot: the roles of e and f swap
+                const double2 h = half_of(kr);
+                const double cr = h.x, ci = -h.y;
+                const double var = f.x * cr + e.x * ci, vai = f.x * ci - e.x * cr;
+                const double vbr = f.y * cr + e.y * ci, vbi = f.y * ci - e.y * cr;
+                line[lpad(kr)] = make_double2(var - vbi, vai + vbr);
+            }
         }
     } else if (MODE == CFFT_FWD) {
         // complex lines, no pairing: "pair" slot = one complex line; load() returns (re, im)
@@ -984,8 +1099,32 @@ static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nba
             }
             d.gcd_off = g > 0 ? g : 1;
             std::vector<double> bv(bands, bands + (size_t)nbands * M);
+            // Back-substitution table for the register-carried solve (kernel, CHEB_BWD): along a chain k, k+g, k+2g, ...
+            //   x[k] = bsub[0][k] c[k] - bsub[1][k] x[k+g] - bsub[2][k] x[k+2g]
+            // (bsub[0] = 1/diag, bsub[j] = band with offset j g over diag); built when no band reaches beyond 2 g.
+            bool ring_ok = true;
+            for (int i = 1; i < nbands; ++i)
+                if (boff[i] / d.gcd_off > 2) ring_ok = false;
+            if (ring_ok) {
+                const size_t base = bv.size();
+                bv.resize(base + (size_t)3 * M, 0.0);
+                for (int k = 0; k < M; ++k) {
+                    const double inv = 1.0 / bands[k];
+                    bv[base + k] = inv;
+                    for (int i = 1; i < nbands; ++i)
+                        if (k + boff[i] < M) bv[base + (size_t)(boff[i] / d.gcd_off) * M + k] += bands[(size_t)i * M + k] * inv;
+                }
+            }
             st = upload(&pl->d_bands, bv);
             d.bands = (const double *)pl->d_bands;
+            d.bsub = ring_ok ? d.bands + (size_t)nbands * M : nullptr;
+            d.bsub_order = 0;
+            if (ring_ok) {
+                const size_t base = (size_t)nbands * M;
+                d.bsub_order = 1;
+                for (int k = 0; k < M; ++k)
+                    if (bv[base + (size_t)2 * M + k] != 0.0) d.bsub_order = 2;
+            }
         }
     }
     if (st) {
@@ -1047,12 +1186,13 @@ static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nba
 
 template <int MODE>
 static int launch(FftPlan *pl, const double *src, double *dst, long outer, long inner, void *stream,
-                  double dscale = 0.0, double *dst2 = nullptr, double dscale2 = 0.0) {
+                  double dscale = 0.0, double *dst2 = nullptr, double dscale2 = 0.0, const double *dvec = nullptr) {
     if (outer <= 0 || inner <= 0) return 0;
     FftDev d = pl->dev;
     d.dscale = dscale;
     d.dst2 = dst2;
     d.dscale2 = dscale2;
+    d.dvec = dvec;
     const bool is_cfft = (MODE == CFFT_FWD || MODE == CFFT_BWD);
     const bool inner_mode = inner > 1;
     long npairs;
@@ -1063,8 +1203,7 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     // lines per workgroup: 64 B of contiguous data per row when strided; bounded by LDS (<= 64 KiB
     // so that at least two workgroups share a CU) and by 12 staged values per thread.
     const int N = d.N, M = d.M;
-    const bool cheb = (MODE == CHEB_FWD || MODE == CHEB_BWD);
-    const size_t per_line = (size_t)(d.ld + ((cheb && d.nbands > 0) ? M : 0)) * sizeof(double2);
+    const size_t per_line = (size_t)(d.ld + ((MODE == CHEB_FWD && d.nbands > 0) ? M : 0)) * sizeof(double2);
     static const int envB = getenv("DDH_FFT_B") ? atoi(getenv("DDH_FFT_B")) : 0;
     static const long lds_cap = getenv("DDH_FFT_LDSCAP") ? atol(getenv("DDH_FFT_LDSCAP")) : 64 * 1024;
     int B = inner_mode ? 8 : 4;      // strided: 128-byte contiguous segments per row when LDS allows
@@ -1278,6 +1417,23 @@ int ddh_rfft_backward_dual(ddh_handle plan, const double *c, double *g, double *
         if (!(c1 <= o0 || o1 <= c0)) return fail("ddh_rfft_backward_dual: the outputs must not overlap the input");
     }
     return launch<RFFT_BWD>(pl, c, g, outer, inner, stream, 0.0, g_deriv, dscale);
+}
+int ddh_cheb_backward_dual(ddh_handle plan, const double *c, double *g, double *g_deriv, const double *dvec, long outer,
+                           long inner, void *stream) {
+    FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
+    if (!pl) return -1;
+    if (pl->tkind != K_CHEB) return fail("ddh_cheb_backward_dual: plan is of a different transform kind");
+    if (pl->dev.nbands == 0)
+        return fail("ddh_cheb_backward_dual: the plan must be that of the derivative's basis (with conversion bands)");
+    if (outer <= 0 || inner <= 0) return 0;
+    if (!g || !g_deriv || g == g_deriv || !dvec) return fail("ddh_cheb_backward_dual: two distinct outputs and dvec required");
+    const size_t nc = (size_t)pl->dev.M * outer * inner, ng = (size_t)pl->dev.N * outer * inner;
+    const char *c0 = (const char *)c, *c1 = c0 + nc * sizeof(double);
+    for (const double *o : {(const double *)g, (const double *)g_deriv}) {
+        const char *o0 = (const char *)o, *o1 = o0 + ng * sizeof(double);
+        if (!(c1 <= o0 || o1 <= c0)) return fail("ddh_cheb_backward_dual: the outputs must not overlap the input");
+    }
+    return launch<CHEB_BWD>(pl, c, g, outer, inner, stream, 0.0, g_deriv, 0.0, dvec);
 }
 DDH_FFT_ENTRY(ddh_cheb_forward, K_CHEB, CHEB_FWD)
 DDH_FFT_ENTRY(ddh_cheb_backward, K_CHEB, CHEB_BWD)

@@ -46,10 +46,13 @@ struct FftDev {
     int gcd_off;           // gcd of the non-zero band offsets (independent back-substitution chains)
     int boff[MAX_BANDS];
     const double *bands;   // [nbands][M]
+    const double *bsub;    // [3][M] back-substitution table (1/diag, bands over diag by chain distance) or null
+    int bsub_order;        // 1: only the nearest chain neighbour enters (first-order recurrence: wavefront scan), 2: two
     int B;                 // line pairs per workgroup
     double dscale;         // RFFT_BWD: != 0 differentiates along the axis while loading (2 pi / L)
     double *dst2;          // RFFT_BWD dual output: second destination (null = single output) ...
     double dscale2;        // ... transformed with this derivative scale
+    const double *dvec;    // CHEB_BWD dual output: [M] superdiagonal of the derivative operator (second pass input = dvec[k] c[k+1])
     int spread_s, spread_c; // strided kernels: workgroup spreading over the address range (see kernel)
     int dbg;               // timing ablations (debug): 1 skip butterfly math, 2 skip FFT passes, 4 skip unpack, 8 skip products
     int rot;               // fused kernel: rotate the butterfly->wave assignment per workgroup

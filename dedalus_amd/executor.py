@@ -205,6 +205,22 @@ class HipExecutor:
         libhip.call("ddh_rfft_backward_dual", h, ptr(src), ptr(dst), ptr(dst_deriv), outer, inner, float(dscale),
                     self.dev.stream)
 
+    def transform_dual_z(self, spec, basis, src, dst, dst_deriv, dvec, outer, inner):
+        """dst = backward Chebyshev transform of src (the family's own basis), dst_deriv = backward transform, in `basis`
+        (the derivative's basis), of the one-superdiagonal operator dvec applied to src (ddh_cheb_backward_dual)."""
+        if self.timer is not None:
+            nb = (src.numel() + dst.numel() + dst_deriv.numel()) * 8
+            return self.timer.run("cheb_backward_%s_dual" % ("strided" if inner > 1 else "contig"), nb,
+                                  self._transform_dual_z, spec, basis, src, dst, dst_deriv, dvec, outer, inner)
+        return self._transform_dual_z(spec, basis, src, dst, dst_deriv, dvec, outer, inner)
+
+    def _transform_dual_z(self, spec, basis, src, dst, dst_deriv, dvec, outer, inner):
+        kind, h, _ = self._plan(spec, basis)
+        if kind != "cheb":
+            raise NotImplementedError("dual z transform: Chebyshev-family axes only")
+        libhip.call("ddh_cheb_backward_dual", h, ptr(src), ptr(dst), ptr(dst_deriv), ptr(dvec), outer, inner,
+                    self.dev.stream)
+
     def cfl_max(self, u, ncomp, shape, inv_spacings, comp_axis):
         """max over the grid of sum_c |u_c| / dx_c; inv_spacings: device arrays per component."""
         n = int(np.prod(shape))

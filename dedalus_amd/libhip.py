@@ -75,6 +75,7 @@ SIGNATURES = {
     "ddh_rfft_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward_deriv": [_h, _vp, _vp, _l, _l, _d, _vp],
     "ddh_rfft_backward_dual": [_h, _vp, _vp, _vp, _l, _l, _d, _vp],
+    "ddh_cheb_backward_dual": [_h, _vp, _vp, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_bilinear_fused": [_h, _i, C.POINTER(_vp), _dp, _i, C.POINTER(_vp), _dp, _i, C.POINTER(_vp), _l, _i,
                                 _ip, _ip, _ip, _dp, _vp],
     "ddh_plan_cfft": [_hp, _i, _i],

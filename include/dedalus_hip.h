@@ -60,6 +60,15 @@ int ddh_rfft_backward_deriv(ddh_handle plan, const double *c, double *g, long ou
 int ddh_rfft_backward_dual(ddh_handle plan, const double *c, double *g, double *g_deriv, long outer, long inner,
                            double dscale, void *stream);
 
+/* Chebyshev counterpart: g = backward transform of the coefficients c (in the family's own basis, no conversion),
+ * g_deriv = backward transform of D c, where D is a one-superdiagonal operator (D c)[k] = dvec[k] c[k+1] into the basis
+ * of `plan` -- the Jacobi derivative d/dz T_n -> (a0+1, b0+1) (DifferentiateJacobi, core/basis.py:806-840; the matrix is
+ * tools/jacobi.py differentiation_matrix scaled by 1/stretch) -- undone by the plan's conversion solve exactly like
+ * ddh_cheb_backward on the stored derivative.  `plan` must be the DERIVATIVE basis's plan (nbands > 0) with the same
+ * (n_grid, n_coeff) as the field's.  dvec: device [n_coeff].  Replaces a sparse mat-vec + a second transform.      */
+int ddh_cheb_backward_dual(ddh_handle plan, const double *c, double *g, double *g_deriv, const double *dvec, long outer,
+                           long inner, void *stream);
+
 /* ComplexFourier: replaces FFTWComplexFFT core/transforms.py:292-330 (resize_coeffs :243-267 fused).
  * Arrays are complex128 stored as interleaved doubles; `inner` counts complex elements.        */
 int ddh_plan_cfft(ddh_handle *plan, int n_grid, int n_coeff);

@@ -191,6 +191,19 @@ class NumpyExecutor:
         self.transform(spec, basis, "backward", src, dst, outer, inner)
         self.transform(spec, basis, "backward", src, dst_deriv, outer, inner, deriv=dscale)
 
+    def transform_dual_z(self, spec, basis, src, dst, dst_deriv, dvec, outer, inner):
+        """Plain Chebyshev backward transform of src, and that of the superdiagonal operator dvec applied to src, taken in
+        `basis` (the derivative's basis: conversion solve first, core/transforms.py:876-890)."""
+        N, M = spec[1], spec[2]
+        n_in = src.size // (outer * inner)
+        s3 = src.reshape(outer, n_in, inner)
+        dst[...] = npt.cheb_backward(s3, 1, N, None).reshape(dst.shape)
+        d3 = np.zeros_like(s3)
+        d3[:, :-1, :] = np.asarray(dvec)[None, :-1, None] * s3[:, 1:, :]
+        from dedalus_amd.tools import jacobi
+        conv = jacobi.conversion_matrix(M, basis.a0, basis.b0, basis.a, basis.b)
+        dst_deriv[...] = npt.cheb_backward(d3, 1, N, conv).reshape(dst_deriv.shape)
+
     def cfl_max(self, u, ncomp, shape, inv_spacings, comp_axis):
         """compute_cfl_frequency (core/basis.py:6108-6111) + global max (extras/flow_tools.py:199-204)"""
         ug = np.abs(u.reshape((ncomp,) + tuple(shape)))

@@ -153,6 +153,47 @@ def test_real_fourier_dual_backward(dev, N, M, shape_kind):
     assert rel(gd, npt.rfft_backward(dc, axis, N)) < TOL
 
 
+@pytest.mark.parametrize("N,M", [(384, 256), (96, 64), (90, 60), (64, 64)])
+@pytest.mark.parametrize("shape_kind", ["contig", "strided_even", "strided_odd"])
+def test_chebyshev_dual_backward(dev, N, M, shape_kind):
+    """ddh_cheb_backward_dual: plain transform + transform of the z-derivative (superdiagonal operator, taken in the
+    (a0+1, b0+1) basis) == the two separate paths (plain plan; derivative applied on the host then the alpha=1 plan)."""
+    from dedalus_amd import libhip
+    from dedalus_amd.device import ptr
+    from dedalus_amd.tools import jacobi
+    from oracle import np_transforms as npt
+    rng = np.random.default_rng(78)
+    shape, axis = {"contig": ((7, N), 1), "strided_even": ((3, N, 10), 1), "strided_odd": ((2, N, 7), 1)}[shape_kind]
+    plan0, _ = _cheb_plan(N, M, 0)
+    plan1, conv = _cheb_plan(N, M, 1)
+    cs = list(shape)
+    cs[axis] = M
+    cin = rng.standard_normal(cs)
+    D = jacobi.differentiation_matrix(M, -0.5, -0.5).toarray() * (2.0 / 1.7)
+    assert np.count_nonzero(D - np.diag(np.diagonal(D, 1), 1)) == 0
+    dvec = np.zeros(M)
+    dvec[:M - 1] = np.diagonal(D, 1)
+    dc = np.moveaxis(np.tensordot(D, np.moveaxis(cin, axis, 0), axes=(1, 0)), 0, axis)
+    outer, inner = int(np.prod(shape[:axis])), int(np.prod(shape[axis + 1:]))
+    d_c, d_dc, d_v = dev.from_host(cin), dev.from_host(np.ascontiguousarray(dc)), dev.from_host(dvec)
+    outs = [dev.empty(shape, np.float64) for _ in range(4)]
+    for o in outs:
+        o.fill_(float("nan"))
+    libhip.call("ddh_cheb_backward_dual", plan1, ptr(d_c), ptr(outs[0]), ptr(outs[1]), ptr(d_v), outer, inner, dev.stream)
+    libhip.call("ddh_cheb_backward", plan0, ptr(d_c), ptr(outs[2]), outer, inner, dev.stream)
+    libhip.call("ddh_cheb_backward", plan1, ptr(d_dc), ptr(outs[3]), outer, inner, dev.stream)
+    dev.sync()
+    g, gd, g1, gd1 = [dev.to_host(o) for o in outs]
+    assert np.array_equal(g, g1)
+    assert rel(gd, gd1) < 1e-14
+    assert rel(g, npt.cheb_backward(cin, axis, N, None)) < TOL
+    assert rel(gd, npt.cheb_backward(dc, axis, N, conv)) < TOL
+    # a plan without conversion bands cannot serve the derivative pass
+    with pytest.raises(Exception):
+        libhip.call("ddh_cheb_backward_dual", plan0, ptr(d_c), ptr(outs[0]), ptr(outs[1]), ptr(d_v), outer, inner,
+                    dev.stream)
+
+
 @pytest.mark.parametrize("N,M", [(384, 256), (768, 512), (96, 64), (48, 64), (90, 60)])
 @pytest.mark.parametrize("alpha", [0, 1, 2])
 @pytest.mark.parametrize("shape_kind", ["contig", "strided_even", "strided_odd"])
