@@ -238,6 +238,80 @@ class SolverBase:
         nb = self.R - self.n_interior
         self.kl, self.ku = kl, max(ku, nb)
         self._build_grading()
+        self._build_pairing()
+
+    def _build_pairing(self):
+        """x <-> y symmetry of the pencil matrices: lambda(ky, kx) = Pi_r lambda(kx, ky) Pi_c with Pi the involutions that
+        swap the components of every tensor variable / equation along the two Fourier axes.  When it holds (equal box
+        lengths and sizes, isotropic equations) the pack solves the pencil (my, mx) with the factorization of (mx, my)
+        (ddh_pencil_set_pairing): half the factorizations, half the factor stream of every solve.  Verified here on the
+        term lists of (a M + b L) P and of P; any mismatch leaves pairing off."""
+        self.pairing = None
+        if not hasattr(self.pack, "set_pairing") or os.environ.get("DDH_PAIR", "1") == "0":
+            return
+        if self.nf != 2 or self.real_grading is None or self.dist.size > 1:
+            return
+        nf, nx, ny, kx, ky = self.evaluator_core.geom()
+        if nx != ny or not np.array_equal(np.asarray(kx), np.asarray(ky)):
+            return
+        sep = self.dist.separable_axes
+
+        def swap_perm(infos, sig_of):
+            perm = np.arange(self.R)
+            for i in infos:
+                sig = sig_of(i)
+                dims = [cs.dim for cs in sig]
+                if (int(np.prod(dims)) if dims else 1) != i["ncomp"]:
+                    return None
+                maps = []
+                for cs in sig:
+                    m = list(range(cs.dim))
+                    idx = {self.dist.coord_axis(c): k for k, c in enumerate(cs.coords)}
+                    if sep[0] in idx and sep[1] in idx:
+                        m[idx[sep[0]]], m[idx[sep[1]]] = idx[sep[1]], idx[sep[0]]
+                    elif sep[0] in idx or sep[1] in idx:
+                        return None
+                    maps.append(m)
+                for comp in range(i["ncomp"]):
+                    multi = np.unravel_index(comp, dims) if dims else ()
+                    image = int(np.ravel_multi_index([maps[k][multi[k]] for k in range(len(dims))], dims)) if dims else 0
+                    r0 = i["row0"] + comp * i["nz"]
+                    perm[r0:r0 + i["nz"]] = i["row0"] + image * i["nz"] + np.arange(i["nz"])
+            return perm
+
+        try:
+            col_swap = swap_perm(self.var_info, lambda i: i["field"].tensorsig)
+            row_swap = swap_perm(self.eq_info, lambda i: i["eq"]["tensorsig"])
+        except (AttributeError, KeyError, ValueError):
+            return
+        if col_swap is None or row_swap is None:
+            return
+        if np.array_equal(col_swap, np.arange(self.R)) and np.array_equal(row_swap, np.arange(self.R)):
+            pass                                            # scalar problem: the swap is the identity, still a symmetry
+
+        def symmetric(tl, rs, cs):
+            if tl is None or tl.nterms == 0:
+                return True
+            a = tl.consolidated()
+            from ..pencilpack import TermList
+            b = TermList(a.nrows, a.ncols, rs[a.row], cs[a.col], a.coef, a.ey, a.ex, a.dy, a.dx).consolidated()
+            if a.nterms != b.nterms:
+                return False
+            same = all(np.array_equal(getattr(a, k), getattr(b, k)) for k in ("row", "col", "ex", "ey", "dx", "dy"))
+            scale = np.abs(a.coef).max()
+            # real operators: coef i^-(ex+ey) real, so that lambda(-kx, -ky) = conj lambda(kx, ky)
+            phase = a.coef * (-1j) ** ((a.ex.astype(int) + a.ey.astype(int)) % 4)
+            return same and np.abs(a.coef - b.coef).max() <= 1e-12 * scale and np.abs(phase.imag).max() <= 1e-12 * scale
+
+        if not (symmetric(self.MP_tl, row_swap, col_swap) and symmetric(self.LP_tl, row_swap, col_swap)
+                and symmetric(self.P_tl, col_swap, col_swap)):
+            return
+        # the swap must respect the band / border split and the validity masks of the ordering
+        if not (np.array_equal(self.row_axes[row_swap], self.row_axes) and np.array_equal(self.col_axes[col_swap], self.col_axes)):
+            return
+        self.pairing = dict(row_swap=row_swap.astype(np.int32), col_swap=col_swap.astype(np.int32))
+        self.pack.set_pairing(self.pairing["row_swap"], self.pairing["col_swap"],
+                              int(os.environ.get("DDH_PAIR_MIN", "65536")))
 
     def _build_grading(self):
         """Z2 gradings that make the pencil matrices real and shared by the +kx / -kx systems.

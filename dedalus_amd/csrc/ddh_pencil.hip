@@ -75,7 +75,8 @@ struct LuDev {
     int n, nb, N, kl, ku, W, BW;   // BW = kl + W + 1, W = ku + kl
     int real;                      // 1: real graded matrix shared by the systems of a cell (see factor_real)
     long GL;                       // number of stored factorizations: G (complex) or ncells (real)
-    long nblk;                     // ceil(GL / 64): factor storage is tiled [row][block of 64][entry][lane]
+    long nblk;                     // ceil(GL / 64): factor storage is tiled [block of 64][row][entry][lane]
+    int rows_aw;                   // max(n, 1) rows per block
     void *Aw;                      // [n][BW][GL]  band rows, LAPACK-style fill space (double2 or double)
     void *Ab;                      // [N][nb][GL]  border rows (multipliers | Schur block inverse)
     unsigned char *piv;            // [n][GL]
@@ -87,6 +88,21 @@ struct LuDev {
     // column recombination X = P Y fused into the backward sweep (ddh_pencil_solve_recombined): P in logical (graded)
     // ordering is unit upper banded, pband[j * PBW + d - 1] = P[j, j + d], d = 1..PBW; null = not fused
     const double *pband;
+    // Partner pencils (ddh_pencil_set_pairing): when the problem is symmetric under the exchange of the two Fourier axes,
+    // lambda(ky, kx) = Pi_r lambda(kx, ky) Pi_c, the cell (my, mx) is solved with the factorization of (mx, my): one
+    // stored factorization ("slot") serves the P, Q systems of both cells, the four threads sit in adjacent lanes and
+    // their factor loads coalesce -- the factor stream, 7/8 of the solve's bytes, halves.
+    //   thread g -> virtual cell v = g / S: vcell[v] = the cell it solves, vslot[v] = 2 * slot + (1 for the partner member);
+    //   the two members of a pair are consecutive virtual cells, the unpaired cells (axes, diagonal) follow with slots of
+    //   their own -- every lane works, the thread count stays ncells * S (one resident round of wavefronts at 512^2)
+    //   partner rows / columns are read and written through rowperm2 / colperm2 (= swap o perm); its Q system is the
+    //   conjugate problem: lambda(kx, -ky) = conj lambda(-kx, ky)  (real operators), so the data are conjugated on the way
+    //   in and out.
+    int pair;
+    const long *vcell;             // [ncells]
+    const int *vslot;              // [ncells]
+    const long *slot_cell;         // [GL] the cell whose matrix a slot holds
+    const int *rowperm2, *colperm2;
 };
 
 constexpr int PBW = 12;
@@ -106,6 +122,9 @@ struct LuFactor {
     std::vector<unsigned char> ccode_h;     // grading codes of the logical columns (real mode)
     void *d_rhs_tmp = nullptr;              // materialised right-hand side for the cooperative forward sweep
     void *d_pband = nullptr;                // [n][PBW] band of the recombination, see LuDev::pband
+    void *d_vcell = nullptr, *d_vslot = nullptr, *d_rowperm2 = nullptr, *d_colperm2 = nullptr;   // partner pencils
+    std::vector<long> slot_cells_h;         // [2 * GL]: the cell of a slot and its partner (-1 = none)
+    void *d_slot_cell = nullptr;
     int pband_mat = -1;                     // matrix id it was built from
 };
 
@@ -121,6 +140,11 @@ struct PencilPack : HandleBase {
     // once from DDH_SOLVE_COOP / DDH_COOP_FWD / DDH_COOP_CB when the pack is created (not per launch);
     // ddh_pencil_set_solve_variant changes them.
     int coop_mode = 1, coop_fwd = -1, coop_cb = -1;
+    // x <-> y symmetry of the problem (ddh_pencil_set_pairing): physical row / column involutions, used by factorizations
+    // of at least pair_min systems
+    std::vector<int> pair_rows, pair_cols;
+    long pair_min = 0;
+    std::vector<double> kx_h, ky_h;
     ~PencilPack() override;
 };
 
@@ -142,6 +166,11 @@ static void free_lu(LuFactor *lu) {
     (void)hipFree(lu->d_dense_rhs);
     (void)hipFree(lu->d_pband);
     (void)hipFree(lu->d_rhs_tmp);
+    (void)hipFree(lu->d_vcell);
+    (void)hipFree(lu->d_vslot);
+    (void)hipFree(lu->d_slot_cell);
+    (void)hipFree(lu->d_rowperm2);
+    (void)hipFree(lu->d_colperm2);
     delete lu;
 }
 
@@ -223,17 +252,16 @@ template <> struct El<true> {
     static __device__ __forceinline__ T scale(T a, double f) { return a * f; }
 };
 
-// Factor storage index.  All entries of one row for one block of 64 factorizations are contiguous
-// ([row][block][entry][lane]): a wave streams one ~BW*512 B chunk per row instead of touching BW
-// different pages (TLB / DRAM-page locality).
+// Factor storage index, [block of 64 factorizations][row][entry][lane]: everything a wave ever reads of one array is one
+// contiguous stream, a row is one BW * 512 B chunk.
 __device__ __forceinline__ long lu_aw(const LuDev &L, long gl, int row, int d) {
-    return ((((long)row * L.nblk + (gl >> 6)) * L.BW + d) << 6) + (gl & 63);
+    return ((((gl >> 6) * (long)L.rows_aw + row) * L.BW + d) << 6) + (gl & 63);
 }
 __device__ __forceinline__ long lu_ab(const LuDev &L, long gl, int col, int rb) {
-    return ((((long)col * L.nblk + (gl >> 6)) * L.nb + rb) << 6) + (gl & 63);
+    return ((((gl >> 6) * (long)L.N + col) * L.nb + rb) << 6) + (gl & 63);
 }
 __device__ __forceinline__ long lu_pv(const LuDev &L, long gl, int row) {
-    return (((long)row * L.nblk + (gl >> 6)) << 6) + (gl & 63);
+    return (((gl >> 6) * (long)L.rows_aw + row) << 6) + (gl & 63);
 }
 
 struct CellCtx {
@@ -255,6 +283,32 @@ __device__ __forceinline__ CellCtx cell_ctx(const PencilDev &P, long cell) {
     c.kx = (P.nf >= 1) ? P.kx[c.mx] : 0.0;
     c.ky = (P.nf == 2) ? P.ky[c.my] : 0.0;
     return c;
+}
+
+// thread of a one-thread-per-system sweep -> the system it solves (see LuDev::pair)
+struct SysId {
+    long cell, gl, G;   // cell (addressing), stored factorization, stride of the scratch vectors
+    int s;
+    bool partner, active, ok;
+};
+template <bool REAL>
+__device__ __forceinline__ SysId sys_id(const PencilDev &P, const LuDev &L, long g) {
+    SysId id;
+    id.partner = false;
+    id.active = true;
+    id.G = P.G;
+    id.ok = g < P.G;                // G is a multiple of S, pairs never straddle the guard
+    id.cell = id.ok ? g / P.S : 0;
+    id.s = (int)(g % P.S);
+    if (L.pair) {
+        const int vs = L.vslot[id.cell];
+        id.gl = vs >> 1;
+        id.partner = (vs & 1) != 0;
+        id.cell = L.vcell[id.cell];
+    } else {
+        id.gl = REAL ? id.cell : g;
+    }
+    return id;
 }
 
 // real factor of a term for the +kx system; the -kx system multiplies by (-1)^ex
@@ -619,7 +673,7 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
     typedef typename El<REAL>::T E;
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;   // index of the stored factorization
     if (g >= L.GL) return;
-    const long cell = REAL ? g : g / P.S;
+    const long cell = REAL ? (L.pair ? L.slot_cell[g] : g) : g / P.S;
     const int s = REAL ? 0 : (int)(g % P.S);
     const CellCtx c = cell_ctx(P, cell);
     const long G = L.GL;
@@ -780,29 +834,35 @@ solve_forward_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__restrict_
     extern __shared__ int s_lds[];
     const int N = L.N;
     int *s_perm = s_lds;                                    // rowperm, then colperm of the border
-    unsigned char *s_code = (unsigned char *)(s_lds + N + L.nb);
+    int *s_perm2 = s_lds + (L.pair ? N + L.nb : 0);         // the partner's (aliases s_perm when unpaired)
+    unsigned char *s_code = (unsigned char *)(s_perm2 + N + L.nb);
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         s_perm[i] = L.rowperm[i];
+        if (L.pair) s_perm2[i] = L.rowperm2[i];
         s_code[i] = REAL ? L.row_code[i] : 0;
     }
     for (int i = threadIdx.x; i < L.nb; i += blockDim.x) {
         s_perm[N + i] = L.colperm[L.n + i];
+        if (L.pair) s_perm2[N + i] = L.colperm2[L.n + i];
         s_code[N + i] = REAL ? L.col_code[L.n + i] : 0;
     }
     __syncthreads();
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= P.G) return;   // G is a multiple of S, pairs never straddle the guard
-    const long cell = g / P.S;
-    const int s = (int)(g % P.S);
-    const CellCtx c = cell_ctx(P, cell);
-    const long G = P.G;
-    const long gl = REAL ? cell : g;
+    const SysId id = sys_id<REAL>(P, L, g);
+    if (!id.ok) return;
+    const int s = id.s;
+    const CellCtx c = cell_ctx(P, id.cell);
+    const long G = id.G;
+    const long gl = id.gl;
+    const int *my_perm = id.partner ? s_perm2 : s_perm;
+    const bool conjq = id.partner && s == 1;
     const E *Aw = (const E *)L.Aw, *Ab = (const E *)L.Ab;
     const long plane = P.nx * P.ny;
     const int n = L.n, nb = L.nb, kl = L.kl;
 
     auto load_row = [&](int i) -> double2 {
-        double2 v = load_sys<NF>(rhs, plane, s_perm[i], P, c, s);
+        double2 v = load_sys<NF>(rhs, plane, my_perm[i], P, c, s);
+        if (conjq) v.y = -v.y;
         if (REAL) {
             const unsigned char code = s_code[i];
             if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
@@ -889,31 +949,37 @@ solve_forward_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__restrict_
                 if (code & 1) v = make_double2(-v.y, v.x);
                 if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
             }
-            store_sys<NF>(xout, plane, s_perm[N + r], P, c, s, v);
+            if (conjq) v.y = -v.y;
+            store_sys<NF>(xout, plane, my_perm[N + r], P, c, s, v, id.active);
         }
     }
 }
 
 template <int NF, int WT, bool REAL, bool PREF, bool PFUSE = false>
 __global__ void __launch_bounds__(256)
-solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
+solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const double *__restrict__ pband) {
     typedef typename El<REAL>::T E;
     extern __shared__ int s_lds[];
     const int n = L.n, nb = L.nb, kl = L.kl, W = L.W;
     int *s_perm = s_lds;
-    unsigned char *s_code = (unsigned char *)(s_lds + n);
+    int *s_perm2 = s_lds + (L.pair ? n : 0);
+    unsigned char *s_code = (unsigned char *)(s_perm2 + n);
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         s_perm[i] = L.colperm[i];
+        if (L.pair) s_perm2[i] = L.colperm2[i];
         s_code[i] = REAL ? L.col_code[i] : 0;
     }
     __syncthreads();
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= P.G) return;
-    const long cell = g / P.S;
-    const int s = (int)(g % P.S);
-    const CellCtx c = cell_ctx(P, cell);
-    const long G = P.G;
-    const long gl = REAL ? cell : g;
+    const SysId id = sys_id<REAL>(P, L, g);
+    if (!id.ok) return;
+    const int s = id.s;
+    const CellCtx c = cell_ctx(P, id.cell);
+    const long G = id.G;
+    const long gl = id.gl;
+    const int *my_perm = id.partner ? s_perm2 : s_perm;
+    const bool conjq = id.partner && s == 1;
+    const bool active = id.active;
     const E *Aw = (const E *)L.Aw;
     const long plane = P.nx * P.ny;
 
@@ -924,15 +990,32 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         if (d < nb) win[d] = L.scratch[(long)(n + d) * G + g];
     }
     E ua[WT + 1], ub[WT + 1];
+    double pa[PBW], pb[PBW];        // the row of the recombination band (PFUSE): uniform, loaded with the factor row
     double2 ya = make_double2(0.0, 0.0), yb = ya;
 #pragma unroll
+    for (int d = 0; d < PBW; ++d) pa[d] = pb[d] = 0.0;
+#pragma unroll
     for (int d = 0; d <= WT; ++d) ua[d] = ub[d] = El<REAL>::zero();
-    auto fetch = [&](int j, E *u, double2 &y) {
-        y = L.scratch[(long)j * G + g];
-        const E *Ur = Aw + lu_aw(L, gl, j, kl);
+    // FULL: every row stores WT + 1 entries from the diagonal on (zero padded beyond the band, factor_impl) -- no guards
+    // in the row loops: every guard was a scalar branch or a select per entry, several times the useful work of a row.
+    constexpr bool FULL = REAL;
+    const E *const ur0 = Aw + lu_aw(L, gl, 0, kl);     // row 0, diagonal; a row further is BW * 64 elements further
+    const long ur_stride = (long)L.BW << 6;
+    const double2 *const y0 = L.scratch + g;
+    auto fetch = [&](int j, E *u, double2 &y, double *pr) {
+        y = y0[(long)j * G];
+        if (PFUSE) {
+            const double *prow = pband + (long)j * PBW;
+#pragma unroll
+            for (int d = 0; d < PBW; ++d) pr[d] = prow[d];
+        }
+        const E *Ur = ur0 + (long)j * ur_stride;
 #pragma unroll
         for (int d = 0; d <= WT; ++d)
-            if (d <= W) u[d] = Ur[(long)d << 6];
+            if (FULL || d <= W) u[d] = Ur[(long)d << 6];
+        // all loads of the row are in flight before the first use: left alone the scheduler trades them for registers
+        // (4 outstanding loads, one memory round trip per group -- 9 per row instead of 1)
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto emit = [&](int j, double2 v) {
         if (REAL) {
@@ -940,20 +1023,20 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
             if (code & 1) v = make_double2(-v.y, v.x);
             if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
         }
-        store_sys<NF>(xout, plane, s_perm[j], P, c, s, v);
+        if (conjq) v.y = -v.y;
+        store_sys<NF>(xout, plane, my_perm[j], P, c, s, v, active);
     };
     // rows are processed in pairs; the register window is shifted once per pair (by two).  With PFUSE the emitted value
     // is the recombined unknown x_j = y_j + sum_d P[j, j + d] y_(j + d) (the window already holds y_(j+1..)): the
     // band coefficients are the same for every system -> scalar loads.
-    auto row_even = [&](int j, const E *u, double2 y) -> double2 {
+    auto row_even = [&](int j, const E *u, double2 y, const double *pr) -> double2 {
         double2 acc = y;
 #pragma unroll
         for (int d = 0; d < WT; ++d)
-            if (d < W) El<REAL>::fms2(acc, u[d + 1], win[d]);
+            if (FULL || d < W) El<REAL>::fms2(acc, u[d + 1], win[d]);
         const double2 xj = El<REAL>::mul2(acc, u[0]);   // reciprocal pivot stored on the diagonal
         double2 v = xj;
         if (PFUSE) {
-            const double *pr = L.pband + (long)j * PBW;
 #pragma unroll
             for (int d = 0; d < PBW; ++d)
                 if (d < WT) { v.x += pr[d] * win[d].x; v.y += pr[d] * win[d].y; }
@@ -961,16 +1044,15 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         emit(j, v);
         return xj;
     };
-    auto row_odd = [&](int j, const E *u, double2 y, double2 xprev) {
+    auto row_odd = [&](int j, const E *u, double2 y, double2 xprev, const double *pr) {
         double2 acc = y;
         El<REAL>::fms2(acc, u[1], xprev);
 #pragma unroll
         for (int d = 1; d < WT; ++d)
-            if (d < W) El<REAL>::fms2(acc, u[d + 1], win[d - 1]);
+            if (FULL || d < W) El<REAL>::fms2(acc, u[d + 1], win[d - 1]);
         const double2 xj = El<REAL>::mul2(acc, u[0]);
         double2 v = xj;
         if (PFUSE) {
-            const double *pr = L.pband + (long)j * PBW;
             v.x += pr[0] * xprev.x;
             v.y += pr[0] * xprev.y;
 #pragma unroll
@@ -985,27 +1067,27 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     };
     int j = n - 1;
     if (PREF) {
-        if (j >= 0) fetch(j, ua, ya);
+        if (j >= 0) fetch(j, ua, ya, pa);
         while (j >= 1) {
-            fetch(j - 1, ub, yb);
-            const double2 xe = row_even(j, ua, ya);
-            if (j - 2 >= 0) fetch(j - 2, ua, ya);
-            row_odd(j - 1, ub, yb, xe);
+            fetch(j - 1, ub, yb, pb);
+            const double2 xe = row_even(j, ua, ya, pa);
+            if (j - 2 >= 0) fetch(j - 2, ua, ya, pa);
+            row_odd(j - 1, ub, yb, xe, pb);
             j -= 2;
         }
-        if (j == 0) row_even(0, ua, ya);
+        if (j == 0) row_even(0, ua, ya, pa);
     } else {
         // no register double-buffering: fewer VGPRs -> two waves per SIMD hide each other's latency
         while (j >= 1) {
-            fetch(j, ua, ya);
-            const double2 xe = row_even(j, ua, ya);
-            fetch(j - 1, ua, ya);
-            row_odd(j - 1, ua, ya, xe);
+            fetch(j, ua, ya, pa);
+            const double2 xe = row_even(j, ua, ya, pa);
+            fetch(j - 1, ua, ya, pa);
+            row_odd(j - 1, ua, ya, xe, pa);
             j -= 2;
         }
         if (j == 0) {
-            fetch(0, ua, ya);
-            row_even(0, ua, ya);
+            fetch(0, ua, ya, pa);
+            row_even(0, ua, ya, pa);
         }
     }
 }
@@ -1100,7 +1182,7 @@ solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, 
     // compiler can wait for exactly the oldest outstanding row (s_waitcnt vmcnt(k)) instead of draining the queue
     // issue() is called for jj = 0, 1, 2, ...: running pointers instead of 64-bit index arithmetic per entry (the
     // address computations were the dominant VALU work of a row)
-    const long aw_rs = (long)L.nblk * L.BW * 64, ab_rs = (long)L.nblk * L.nb * 64, pv_rs = (long)L.nblk * 64;
+    const long aw_rs = (long)L.BW * 64, ab_rs = (long)L.nb * 64, pv_rs = 64;
     const int aw_step = (int)(aw_rs - 64);                   // (row + 1, d - 1) relative to (row, d)
     const unsigned char *pv_ptr = L.piv + lu_pv(L, gl, 0);
     const E *aw_ptr = Aw + lu_aw(L, gl, 0, kl);              // (row jj, diagonal)
@@ -1217,7 +1299,7 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     E pu[COOP_D][TT], pu0[COOP_D];
     double2 py[COOP_D];
     // issue() is called for jj = n - 1, n - 2, ...: running pointers (see the forward kernel)
-    const long aw_rs = (long)L.nblk * L.BW * 64;
+    const long aw_rs = (long)L.BW * 64;
     const E *u_ptr = Aw + lu_aw(L, gl, n - 1, kl);
     const double2 *y_ptr = L.scratch + (long)(n - 1) * G + g;
     auto issue = [&](int jj, int slot) {                  // branch-free
@@ -1367,6 +1449,9 @@ static int finish_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
 // (these are the per-rank sizes of the 512 x 512 x 256 problem on 8 / 4 / 2 GPUs); 2-D problems (a few hundred
 // systems) were tuned with 16 lanes in both sweeps.  forward: 16 lanes per system (needs kl < 16); backward: 16 or 4
 // lanes per system (fewer lanes = less redundant work per system, more products per lane).
+// register window (entries above the diagonal) of the one-thread-per-system backward kernel for an upper bandwidth W
+static int backward_window(int W) { return W <= 32 ? 32 : (W <= 34 ? 34 : (W <= 48 ? 48 : 64)); }
+
 template <int NF>
 static void choose_variant(const PencilPack *pp, const LuDev &d, int &use_fwd, int &cb) {
     const PencilDev &P = pp->dev;
@@ -1395,10 +1480,12 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     if (did_p) *did_p = false;
     const unsigned blocks = (unsigned)((P.G + 255) / 256);
     const int W = d.W;
-    const size_t lds_f = (size_t)(d.N + d.nb) * 5 + 16, lds_b = (size_t)(d.n > 0 ? d.n : 1) * 5 + 16;
+    const size_t per_entry = d.pair ? 9 : 5;    // one (two when paired) int permutations + a code byte per row
+    const size_t lds_f = (size_t)(d.N + d.nb) * per_entry + 16, lds_b = (size_t)(d.n > 0 ? d.n : 1) * per_entry + 16;
     if (lds_f > 64 * 1024) return fail("pencil_solve: system too large for the LDS permutation cache");
     int use_fwd, cb;
     choose_variant<NF>(pp, d, use_fwd, cb);
+    if (d.pair) use_fwd = cb = 0;               // partner pencils: one-thread-per-system sweeps only
     if (use_fwd) {
         const unsigned cblocks = (unsigned)((P.G + (256 / CH) - 1) / (256 / CH));
         // the cooperative sweep's deep branch-free prefetch takes ONE right-hand-side vector: a combination is
@@ -1459,15 +1546,15 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
 #define DDH_SOLVE(WTV)                                                                                             \
     {                                                                                                              \
         if (d.real)                                                                                                \
-            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
+            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband); \
         else                                                                                                       \
-            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x); \
+            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband); \
     }
     // (window sizes: few instantiations -- every one is a fully unrolled kernel and this file dominates the build time)
     bool fuse_p = false;
     if constexpr (NF == 2) fuse_p = want_p && d.real && d.pband != nullptr && d.n > 0 && !cb && W <= 48;
 #define DDH_SOLVE_P(WTV)                                                                                           \
-    hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false, true>), dim3(blocks), dim3(256), lds_b, s, P, d, x);
+    hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false, true>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband);
     if (fuse_p) {
         if constexpr (NF == 2) {
             if (W <= 32) DDH_SOLVE_P(32)
@@ -1548,6 +1635,8 @@ int ddh_pencil_create(ddh_handle *pack, const ddh_pencil_geom *geom) {
     if (st) { delete pp; return st; }
     d.kx = (const double *)pp->d_kx;
     d.ky = (const double *)pp->d_ky;
+    if (d.nf >= 1) pp->kx_h.assign(geom->kx_h, geom->kx_h + d.ncx);
+    if (d.nf == 2) pp->ky_h.assign(geom->ky_h, geom->ky_h + d.ncy);
     if (const char *e = getenv("DDH_SOLVE_COOP")) pp->coop_mode = atoi(e);
     if (const char *e = getenv("DDH_COOP_FWD")) pp->coop_fwd = atoi(e);
     if (const char *e = getenv("DDH_COOP_CB")) pp->coop_cb = atoi(e);
@@ -1564,6 +1653,25 @@ int ddh_pencil_set_solve_variant(ddh_handle pack, int mode, int fwd, int backwar
     pp->coop_mode = mode;
     pp->coop_fwd = fwd < 0 ? -1 : (fwd ? 1 : 0);
     pp->coop_cb = backward_lanes < 0 ? -1 : backward_lanes;
+    return 0;
+}
+
+int ddh_pencil_set_pairing(ddh_handle pack, const int *row_swap_h, const int *col_swap_h, long min_systems) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    pp->pair_rows.clear();
+    pp->pair_cols.clear();
+    if (!row_swap_h || !col_swap_h) return 0;
+    const int N = pp->dev.nrows;
+    if (pp->dev.nf != 2) return fail("pencil_set_pairing: two Fourier axes required");
+    for (int i = 0; i < N; ++i) {
+        const int r = row_swap_h[i], c = col_swap_h[i];
+        if (r < 0 || r >= N || c < 0 || c >= N || row_swap_h[r] != i || col_swap_h[c] != i)
+            return fail("pencil_set_pairing: the row and column maps must be involutions of 0..nrows-1");
+    }
+    pp->pair_rows.assign(row_swap_h, row_swap_h + N);
+    pp->pair_cols.assign(col_swap_h, col_swap_h + N);
+    pp->pair_min = min_systems;
     return 0;
 }
 
@@ -1743,8 +1851,42 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
                        pp->lus[reuse_lu_id]->dev.n == n && pp->lus[reuse_lu_id]->dev.kl == kl &&
                        pp->lus[reuse_lu_id]->dev.ku == ku && (pp->lus[reuse_lu_id]->dev.real != 0) == real;
     hipStream_t s = as_stream(stream);
-    const size_t G = (size_t)P.G;
-    const size_t GL = real ? (size_t)P.ncells : G;
+    // partner pencils: cells (mx, my) and (my, mx), mx != my, both off the axes, share one stored factorization
+    std::vector<long> vcell, slot_cells;
+    std::vector<int> vslot;
+    bool pair = real && P.nf == 2 && !pp->pair_rows.empty() && P.G >= pp->pair_min && P.ncx == P.ncy &&
+                P.mx_offset == 0 && pp->kx_h == pp->ky_h && n > 0;
+    if (reuse && (pp->lus[reuse_lu_id]->dev.pair != 0) != pair) return fail("pencil_factor: pairing changed under a reused LU");
+    if (pair) {
+        // pairs first, in 4 x 4 tiles of cells so that the 16 pairs of a wavefront touch 64-byte runs of the system vectors
+        // in both the cell's and the partner's rows; then the unpaired cells (axes, diagonal) in cell order
+        const long nc = P.ncx, nt = (nc + 3) / 4;
+        auto has_partner = [&](long mx, long my) { return mx > 0 && my > 0 && mx != my; };
+        for (long tx = 0; tx < nt; ++tx)
+            for (long ty = tx; ty < nt; ++ty)
+                for (long mx = 4 * tx; mx < std::min(nc, 4 * tx + 4); ++mx)
+                    for (long my = 4 * ty; my < std::min(nc, 4 * ty + 4); ++my) {
+                        if (!has_partner(mx, my) || mx > my) continue;
+                        const int slot = (int)(slot_cells.size() / 2);
+                        slot_cells.push_back(mx * P.ncy + my);
+                        slot_cells.push_back(my * P.ncy + mx);
+                        vcell.push_back(mx * P.ncy + my);
+                        vslot.push_back(2 * slot);
+                        vcell.push_back(my * P.ncy + mx);
+                        vslot.push_back(2 * slot + 1);
+                    }
+        for (long mx = 0; mx < nc; ++mx)
+            for (long my = 0; my < nc; ++my) {
+                if (has_partner(mx, my)) continue;
+                const int slot = (int)(slot_cells.size() / 2);
+                slot_cells.push_back(mx * P.ncy + my);
+                slot_cells.push_back(-1);
+                vcell.push_back(mx * P.ncy + my);
+                vslot.push_back(2 * slot);
+            }
+    }
+    const size_t G = (size_t)P.G;   // threads of a solve / scratch stride
+    const size_t GL = pair ? slot_cells.size() / 2 : (real ? (size_t)P.ncells : (size_t)P.G);
     const size_t esz = real ? sizeof(double) : sizeof(double2);
     if (reuse) {
         lu = pp->lus[reuse_lu_id];
@@ -1753,9 +1895,13 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
         LuDev &d = lu->dev;
         memset(&d, 0, sizeof(d));
         d.n = n; d.nb = nb; d.N = N; d.kl = kl; d.ku = ku; d.W = W; d.BW = kl + W + 1;
+        // real factors: rows are padded (with zeros) to the register window of the one-thread-per-system backward kernel,
+        // which then runs without per-entry guards (launch_solve picks the same window)
+        if (real) d.BW = kl + backward_window(W) + 1;
         d.real = real ? 1 : 0;
         d.GL = (long)GL;
         d.nblk = (long)((GL + 63) / 64);
+        d.rows_aw = n > 0 ? n : 1;
         const size_t GLp = (size_t)d.nblk * 64;
         const size_t szAw = esz * (size_t)(n > 0 ? n : 1) * d.BW * GLp;
         const size_t szAb = esz * (size_t)N * (nb > 0 ? nb : 1) * GLp;
@@ -1774,6 +1920,27 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
         if (!st) st = upload_vec(&lu->d_caxes, col_axes_h + n, (size_t)nb);
         if (!st && real) st = upload_vec(&lu->d_rcode, row_code_h, (size_t)N);
         if (!st && real) st = upload_vec(&lu->d_ccode, col_code_h, (size_t)N);
+        if (!st && pair) {
+            std::vector<int> rp2(N), cp2(N);
+            for (int i = 0; i < N; ++i) {
+                rp2[i] = pp->pair_rows[row_perm_h[i]];
+                cp2[i] = pp->pair_cols[col_perm_h[i]];
+            }
+            std::vector<long> sc(GL);
+            for (size_t i = 0; i < GL; ++i) sc[i] = slot_cells[2 * i];
+            st = upload_vec(&lu->d_vcell, vcell.data(), vcell.size());
+            if (!st) st = upload_vec(&lu->d_vslot, vslot.data(), vslot.size());
+            if (!st) st = upload_vec(&lu->d_slot_cell, sc.data(), sc.size());
+            if (!st) st = upload_vec(&lu->d_rowperm2, rp2.data(), (size_t)N);
+            if (!st) st = upload_vec(&lu->d_colperm2, cp2.data(), (size_t)N);
+            lu->slot_cells_h = slot_cells;
+            d.pair = 1;
+            d.vcell = (const long *)lu->d_vcell;
+            d.vslot = (const int *)lu->d_vslot;
+            d.slot_cell = (const long *)lu->d_slot_cell;
+            d.rowperm2 = (const int *)lu->d_rowperm2;
+            d.colperm2 = (const int *)lu->d_colperm2;
+        }
         if (st) { free_lu(lu); return st; }
         d.rowperm = (const int *)lu->d_rowperm;
         d.colperm = (const int *)lu->d_colperm;
@@ -1818,10 +1985,19 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
     DDH_HIP(hipMemcpy(flags.data(), d.flag, GL, hipMemcpyDeviceToHost));
     lu->flag_cells.clear();
     const int per = real ? 1 : P.S;
-    for (long cidx = 0; cidx < P.ncells; ++cidx) {
-        bool f = false;
-        for (int sidx = 0; sidx < per; ++sidx) f = f || flags[cidx * per + sidx];
-        if (f) lu->flag_cells.push_back(cidx);
+    if (d.pair) {
+        for (size_t slot = 0; slot < GL; ++slot)
+            if (flags[slot]) {
+                lu->flag_cells.push_back(lu->slot_cells_h[2 * slot]);
+                if (lu->slot_cells_h[2 * slot + 1] >= 0) lu->flag_cells.push_back(lu->slot_cells_h[2 * slot + 1]);
+            }
+        std::sort(lu->flag_cells.begin(), lu->flag_cells.end());
+    } else {
+        for (long cidx = 0; cidx < P.ncells; ++cidx) {
+            bool f = false;
+            for (int sidx = 0; sidx < per; ++sidx) f = f || flags[cidx * per + sidx];
+            if (f) lu->flag_cells.push_back(cidx);
+        }
     }
     lu->nflag = (int)lu->flag_cells.size();
     (void)hipFree(lu->d_flag_cells); lu->d_flag_cells = nullptr;

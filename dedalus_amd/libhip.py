@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdedalus_hip.so")
+# (DDH_LIB: another build of the same library, for A/B timing of kernel variants)
+LIB_PATH = os.environ.get("DDH_LIB") or os.path.join(_HERE, "csrc", "libdedalus_hip.so")
 
 _lib = None
 
@@ -103,6 +104,7 @@ SIGNATURES = {
                                C.POINTER(C.c_ubyte), _i, _ip, _vp],
     "ddh_pencil_solve": [_h, _i, _vp, _vp, _vp],
     "ddh_pencil_set_solve_variant": [_h, _i, _i, _i],
+    "ddh_pencil_set_pairing": [_h, _ip, _ip, _l],
     "ddh_pencil_solve_lincomb": [_h, _i, _i, C.POINTER(_vp), _dp, _vp, _vp],
     "ddh_pencil_solve_recombined": [_h, _i, _i, C.POINTER(_vp), _dp, _i, _vp, _vp, _vp],
     "ddh_pencil_flagged": [_h, _i, _ip, C.POINTER(_l), _i],
@@ -149,6 +151,8 @@ def load(build_if_missing=False):
                            "(there is no CPU fallback)" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
+        if os.environ.get("DDH_LIB") and not hasattr(lib, name):
+            continue                     # an older experimental build: calling a missing entry point raises
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = C.c_int

@@ -227,6 +227,16 @@ class PencilPack:
         fwd (0 / 1) and backward_lanes (0 / 4 / 16) override the two sweeps individually."""
         libhip.call("ddh_pencil_set_solve_variant", self.handle, int(mode), int(fwd), int(backward_lanes))
 
+    def set_pairing(self, row_swap, col_swap, min_systems=0):
+        """Partner pencils (ddh_pencil_set_pairing): (my, mx) is solved with the factorization of (mx, my) through the
+        physical row / column involutions of the x <-> y symmetry.  None, None switches it off."""
+        if row_swap is None or col_swap is None:
+            libhip.call("ddh_pencil_set_pairing", self.handle, None, None, 0)
+            return
+        rs = np.ascontiguousarray(row_swap, dtype=np.int32)
+        cs = np.ascontiguousarray(col_swap, dtype=np.int32)
+        libhip.call("ddh_pencil_set_pairing", self.handle, libhip.as_ip(rs), libhip.as_ip(cs), int(min_systems))
+
     def lu_bytes(self, lu_id):
         n = C.c_size_t(0)
         libhip.call("ddh_pencil_lu_bytes", self.handle, lu_id, C.byref(n))

@@ -329,6 +329,20 @@ int ddh_pencil_solve_recombined(ddh_handle pack, int lu_id, int nterms, const do
  * the forward and backward kernel individually, -1 leaves the choice to `mode`.  The defaults can also be preset with
  * the environment variables DDH_SOLVE_COOP / DDH_COOP_FWD / DDH_COOP_CB, which are read ONCE, by ddh_pencil_create. */
 int ddh_pencil_set_solve_variant(ddh_handle pack, int mode, int fwd, int backward_lanes);
+/* Partner pencils.  For a problem that is symmetric under the exchange of its two Fourier axes (same box length and
+ * size along x and y, isotropic equations: 3-D Rayleigh-Benard is), the pencil matrices obey
+ *     lambda(ky, kx) = Pi_r lambda(kx, ky) Pi_c
+ * with Pi_r / Pi_c the row / column involutions that swap the x and y components of every vector (tensor) equation /
+ * variable.  The pencil (my, mx) is then solved with the factorization of (mx, my): permuted right-hand side in,
+ * permuted solution out (its -kx system through lambda(kx, -ky) = conj lambda(-kx, ky)).  Factorizations made after this
+ * call with at least min_systems systems store one factorization per PAIR of cells (cells on the axes and on the
+ * diagonal keep their own): factor memory, factor time and the solve's factor stream -- 7/8 of its HBM bytes -- halve;
+ * the four systems of a pair sit in adjacent lanes, so the shared loads coalesce in the wavefront.  The reference has no
+ * counterpart (it factors every pencil, core/subsystems.py:497-596); the solutions are those of the same linear systems.
+ * row_swap_h / col_swap_h: PHYSICAL row / column -> its image, involutions of 0..nrows-1 (the caller has verified the
+ * symmetry on its term lists); NULL, NULL switches pairing off.  Needs the real-graded factorization
+ * (ddh_pencil_factor_real), two Fourier axes, a square unsharded cell grid with kx_h == ky_h; otherwise ignored.   */
+int ddh_pencil_set_pairing(ddh_handle pack, const int *row_swap_h, const int *col_swap_h, long min_systems);
 /* Pencils whose band block is singular (e.g. the kx=ky=0 pressure-gauge pencil) are flagged by
  * ddh_pencil_factor and solved with an explicit dense inverse the host supplies: query the flagged
  * cell ids, then upload inverses in logical (permuted) ordering, complex row-major N x N per

@@ -23,6 +23,11 @@ class _NpPack:
         self.lus = []
         self.lu_meta = {}
 
+    def set_pairing(self, row_swap, col_swap, min_systems=0):
+        """The x <-> y symmetry the solver found (dedalus_amd/core/solvers.py _build_pairing).  The oracle keeps one
+        factorization per pencil -- it is the independent check of the shared ones -- and only records the maps."""
+        self.pairing = None if row_swap is None else (np.asarray(row_swap), np.asarray(col_swap))
+
     def add_matrix(self, tl):
         self.mats.append(npp.TermList(tl.nrows, tl.ncols, tl.row, tl.col, tl.coef, tl.ex, tl.ey, tl.dx, tl.dy))
         return len(self.mats) - 1

@@ -33,6 +33,28 @@ def full_size():
     solver.solve_probe = None
 
 
+@pytest.fixture(scope="module")
+def full_size_unpaired():
+    """The same run with one factorization per pencil (DDH_PAIR=0): the cooperative sweep variants need it."""
+    import dedalus_amd.public as d3
+    ref = pencil_check.ReferencePencils()
+    old = os.environ.get("DDH_PAIR")
+    os.environ["DDH_PAIR"] = "0"
+    try:
+        solver, f = problems.rayleigh_benard_3d(d3, Nx=512, Ny=512, Nz=ref.nz, timestepper="RK222")
+    finally:
+        if old is None:
+            del os.environ["DDH_PAIR"]
+        else:
+            os.environ["DDH_PAIR"] = old
+    assert solver.pairing is None
+    solver.solve_probe = dict(groups=[ref.modes(g) for g in ref.groups], records=[])
+    for _ in range(2):
+        solver.step(1e-3)
+    yield solver, f, ref
+    solver.solve_probe = None
+
+
 def test_benchmark_configuration_solves_the_references_matrices(full_size):
     """4 solves (2 RK222 steps) x 16 pencils of the 512 x 512 x 256 run, default kernels (one thread per system)"""
     solver, f, ref = full_size
@@ -48,8 +70,8 @@ def test_benchmark_configuration_solves_the_references_matrices(full_size):
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
-def test_every_sweep_variant_at_full_size(full_size, variant):
-    solver, f, ref = full_size
+def test_every_sweep_variant_at_full_size(full_size_unpaired, full_size, variant):
+    solver, f, ref = full_size_unpaired
     ts = solver.timestepper
     lu = list(ts._lus.values())[0]
     out = solver.ex.empty((solver.R, solver.nx, solver.ny))
@@ -65,6 +87,8 @@ def test_every_sweep_variant_at_full_size(full_size, variant):
     assert summ["max_residual"] < 1e-12 and summ["max_solution_error"] < 1e-10, (variant, summ)
     # and the whole vector agrees with the state the default kernels produced from the same right-hand side
     assert rel(solver.ex.download(out), solver.ex.download(solver.X)) < 1e-12
+    # ... and with the state of the run whose partner pencils share factorizations
+    assert rel(solver.ex.download(out), solver.ex.download(full_size[0].X)) < 1e-11
 
 
 def test_fused_rhs_combination_matches_materialised_rhs(full_size):
@@ -116,3 +140,64 @@ def test_rb2d_512x256_arrays_with_forced_variant(large, variant):
         err = rel(a[..., ::8, :], large["rb2d_512x256__" + k])
         assert err < tol, (variant, k, err)
         assert abs(np.linalg.norm(a) - float(large["rb2d_512x256__" + k + "_norm"])) <= 1e-10 * np.linalg.norm(a)
+
+
+# ---- partner pencils: (my, mx) solved with the factorization of (mx, my) (ddh_pencil_set_pairing) ------------------------
+def test_full_size_run_uses_partner_pencils(full_size):
+    """The 512 x 512 x 256 configuration is symmetric in x <-> y and large enough: its factorizations are shared by
+    partner cells (the sample of the tests above holds both members of the pairs (85, 170) and (170, 85) etc., the
+    diagonal cells and the cells on the axes), and the factor storage is about half of one factorization per cell."""
+    solver, f, ref = full_size
+    assert solver.pairing is not None
+    lu = list(solver.timestepper._lus.values())[0]
+    per_cell = solver.pack.lu_bytes(lu) / (256 * 256)
+    n, bw = solver.n_interior, solver.kl + (solver.kl + solver.ku) + 1
+    assert per_cell < 0.62 * n * bw * 8 + 0.2 * n * bw * 8, per_cell
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 16), (24, 24, 8), (10, 10, 12)])
+def test_partner_pencils_match_unpaired_solves_and_the_oracle(shape, monkeypatch):
+    """Small symmetric 3-D problems with pairing forced on (DDH_PAIR_MIN=0) against pairing off (DDH_PAIR=0) and against
+    the CPU oracle, which factors every pencil on its own."""
+    import dedalus_amd.public as d3
+    from oracle.np_executor import NumpyExecutor
+    kw = dict(Nx=shape[0], Ny=shape[1], Nz=shape[2], timestepper="RK222")
+    monkeypatch.setenv("DDH_PAIR_MIN", "0")
+    s1, f1 = problems.rayleigh_benard_3d(d3, **kw)
+    assert s1.pairing is not None
+    monkeypatch.setenv("DDH_PAIR", "0")
+    s0, f0 = problems.rayleigh_benard_3d(d3, **kw)
+    assert s0.pairing is None
+    monkeypatch.delenv("DDH_PAIR")
+    so, fo = problems.rayleigh_benard_3d(d3, dist_kw=dict(executor=NumpyExecutor()), **kw)
+    for _ in range(4):
+        for s in (s1, s0, so):
+            s.step(1e-3)
+    for k in ("p", "b", "u"):
+        a1, a0, ao = (np.array(f[k]['c']) for f in (f1, f0, fo))
+        assert np.isfinite(a1).all()
+        assert rel(a1, a0) < 1e-11, (k, rel(a1, a0))
+        assert rel(a1, ao) < 1e-9, (k, rel(a1, ao))
+
+
+def test_partner_pencils_reproduce_the_reference_end_state(large, monkeypatch):
+    """rb3d 32^3, 5 steps: the reference's own end state (tests/golden/ivp_large.npz) with pairing forced on."""
+    import dedalus_amd.public as d3
+    monkeypatch.setenv("DDH_PAIR_MIN", "0")
+    solver, f = problems.rayleigh_benard_3d(d3, Nx=32, Ny=32, Nz=32, timestepper="RK222")
+    assert solver.pairing is not None
+    solver.pack.set_solve_variant(0, 0, 0)
+    for _ in range(5):
+        solver.step(1e-3)
+    for k, tol in (("p", 1e-10), ("b", 1e-10), ("u", 1e-9)):
+        got, want = np.array(f[k]['c']), large["rb3d_32__" + k]
+        assert rel(got, want) < tol, (k, rel(got, want))
+
+
+def test_anisotropic_box_is_not_paired(monkeypatch):
+    import dedalus_amd.public as d3
+    monkeypatch.setenv("DDH_PAIR_MIN", "0")
+    solver, f = problems.rayleigh_benard_3d(d3, Nx=8, Ny=8, Nz=8, Lx=4, Ly=2)
+    assert solver.pairing is None
+    solver, f = problems.rayleigh_benard_3d(d3, Nx=8, Ny=12, Nz=8)
+    assert solver.pairing is None
