@@ -76,7 +76,9 @@ struct LuDev {
     int real;                      // 1: real graded matrix shared by the systems of a cell (see factor_real)
     long GL;                       // number of stored factorizations: G (complex) or ncells (real)
     long nblk;                     // ceil(GL / 64): factor storage is tiled [block of 64][row][entry][lane]
-    int rows_aw;                   // max(n, 1) rows per block
+    int rows_aw;                   // rows per block: max(n, 1) (+ kl + kpad zero rows for real factors)
+    int kpad;                      // real factors: zero entries in front of every band row, so that the forward sweep's
+                                   // window of kl + kpad multipliers per column needs no guards (solve_forward_lean_kernel)
     void *Aw;                      // [n][BW][GL]  band rows, LAPACK-style fill space (double2 or double)
     void *Ab;                      // [N][nb][GL]  border rows (multipliers | Schur block inverse)
     unsigned char *piv;            // [n][GL]
@@ -254,8 +256,9 @@ template <> struct El<true> {
 
 // Factor storage index, [block of 64 factorizations][row][entry][lane]: everything a wave ever reads of one array is one
 // contiguous stream, a row is one BW * 512 B chunk.
+// (entry d of a band row: d = kl + (column - row); the row starts with kpad zero entries, see LuDev::kpad)
 __device__ __forceinline__ long lu_aw(const LuDev &L, long gl, int row, int d) {
-    return ((((gl >> 6) * (long)L.rows_aw + row) * L.BW + d) << 6) + (gl & 63);
+    return ((((gl >> 6) * (long)L.rows_aw + row) * L.BW + (d + L.kpad)) << 6) + (gl & 63);
 }
 __device__ __forceinline__ long lu_ab(const LuDev &L, long gl, int col, int rb) {
     return ((((gl >> 6) * (long)L.N + col) * L.nb + rb) << 6) + (gl & 63);
@@ -955,6 +958,184 @@ solve_forward_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward sweep of the real-graded two-axis path, one thread per system, written for the instruction stream: the general
+// kernel above spends ~1500 instructions per row (per-entry guards, 64-bit index arithmetic per load, scalar registers
+// spilled into vector lanes, a select chain for the row interchange) on 38 useful multiply-adds and was bound by
+// instruction issue, not by memory.  Here:
+//  * the factor rows are padded (kpad zero entries in front, KLT zero rows behind): the KLT multipliers of column j are
+//    loaded without guards from awl[j * BW64 + coff[i]] -- one per-lane base pointer, 32-bit uniform offsets;
+//  * the register window holds rows j .. j + KLT: the new row always enters at the top (rows beyond j + kl are not touched
+//    by the elimination until they come within kl of the pivot row: their multipliers are zero);
+//  * the interchange's select chain only runs when some system of the wavefront interchanges at this step;
+//  * two register sets alternate for the prefetched row (no copies), all loads of a row are issued before its first use.
+// Same arithmetic, same order of operations per system as solve_forward_kernel<2, true, ...>.
+// ------------------------------------------------------------------------------------------------
+template <int KLT, int NBT>
+__global__ void __launch_bounds__(256)
+solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__restrict__ xout) {
+    constexpr int NF = 2;
+    extern __shared__ int s_lds[];
+    const int N = L.N, n = L.n, nb = L.nb;
+    int *s_perm = s_lds;                                    // rowperm, then colperm of the border
+    int *s_perm2 = s_lds + (L.pair ? N + nb : 0);           // the partner's (aliases s_perm when unpaired)
+    unsigned char *s_code = (unsigned char *)(s_perm2 + N + nb);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        s_perm[i] = L.rowperm[i];
+        if (L.pair) s_perm2[i] = L.rowperm2[i];
+        s_code[i] = L.row_code[i];
+    }
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+        s_perm[N + i] = L.colperm[n + i];
+        if (L.pair) s_perm2[N + i] = L.colperm2[n + i];
+        s_code[N + i] = L.col_code[n + i];
+    }
+    __syncthreads();
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const SysId id = sys_id<true>(P, L, g);
+    if (!id.ok) return;
+    const int s = id.s;
+    const CellCtx c = cell_ctx(P, id.cell);
+    const long G = id.G;
+    const int *my_perm = id.partner ? s_perm2 : s_perm;
+    const bool conjq = id.partner && s == 1;
+    const long plane = P.nx * P.ny;
+    // running per-lane pointers, advanced by uniform strides once per row:
+    //   mp[i]: multiplier L(j + i + 1, j) = row j + i + 1, entry KLT - i - 1;  abp: border multipliers of column j (nb entries,
+    //   512 B apart: immediate offsets);  pvp: the interchange of step j;  scr: y_j of this system
+    const double *mp[KLT];
+    {
+        const double *const awl = (const double *)L.Aw + lu_aw(L, id.gl, 0, -L.kpad);   // this lane's block, row 0, entry 0
+        const long BW64 = (long)L.BW << 6;
+#pragma unroll
+        for (int i = 0; i < KLT; ++i) mp[i] = awl + (long)(i + 1) * (BW64 - 64) + (long)KLT * 64;
+    }
+    const double *abp = (const double *)L.Ab + lu_ab(L, id.gl, 0, 0);
+    const unsigned char *pvp = L.piv + lu_pv(L, id.gl, 0);
+    double2 *scr = L.scratch + g;
+    const long row_step = (long)L.BW << 6, ab_step = (long)nb << 6;
+
+    auto load_row = [&](int i) -> double2 {
+        double2 v = load_sys<NF>(rhs, plane, my_perm[i], P, c, s);
+        if (conjq) v.y = -v.y;
+        const unsigned char code = s_code[i];
+        if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+        if (code & 1) v = make_double2(v.y, -v.x);
+        return v;
+    };
+
+    // the window (rows 0 .. KLT) and the border rows are shifted in by rolled loops: one inlined copy of the row load each
+    double2 w[KLT + 1];
+#pragma unroll
+    for (int d = 0; d <= KLT; ++d) w[d] = make_double2(0.0, 0.0);
+#pragma unroll 1
+    for (int t = 0; t <= KLT; ++t) {
+        const double2 v = (t < n) ? load_row(t) : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int d = 0; d < KLT; ++d) w[d] = w[d + 1];
+        w[KLT] = v;
+    }
+    double2 gb[NBT];
+#pragma unroll
+    for (int rb = 0; rb < NBT; ++rb) gb[rb] = make_double2(0.0, 0.0);
+#pragma unroll 1
+    for (int t = 0; t < NBT; ++t) {
+        const double2 v = (t < nb) ? load_row(n + t) : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int rb = 0; rb + 1 < NBT; ++rb) gb[rb] = gb[rb + 1];
+        gb[NBT - 1] = v;
+    }
+    double mA[KLT], mB[KLT], abA[NBT], abB[NBT];
+    int pA = 0, pB = 0;
+    double2 rA = make_double2(0.0, 0.0), rB = rA;
+#pragma unroll
+    for (int i = 0; i < KLT; ++i) mA[i] = mB[i] = 0.0;
+#pragma unroll
+    for (int rb = 0; rb < NBT; ++rb) abA[rb] = abB[rb] = 0.0;
+    const bool full_border = (nb == NBT);
+    // loads of the NEXT row (the pointers stand at it); called for rows 0, 1, 2, ... in order
+    int jn = 0;
+    auto prefetch = [&](double *m, double *ab, int &p, double2 &r) {
+        p = *pvp;
+#pragma unroll
+        for (int i = 0; i < KLT; ++i) m[i] = *mp[i];
+        if (full_border) {
+#pragma unroll
+            for (int rb = 0; rb < NBT; ++rb) ab[rb] = abp[rb << 6];
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < NBT; ++rb)
+                if (rb < nb) ab[rb] = abp[rb << 6];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // every factor load of the row is in flight before anything waits
+        // (the right-hand-side row follows: its value is not needed before the end of the next step)
+        const int nxt = jn + KLT + 1;
+        r = make_double2(0.0, 0.0);
+        if (nxt < n) r = load_row(nxt);
+#pragma unroll
+        for (int i = 0; i < KLT; ++i) mp[i] += row_step;
+        abp += ab_step;
+        pvp += 64;
+        ++jn;
+    };
+    auto step = [&](const double *m, const double *ab, int p, double2 rnew) {
+        double2 yj = w[0];
+#pragma unroll
+        for (int d = 1; d <= KLT; ++d) {
+            if (d == p) {
+                yj = w[d];
+                w[d] = w[0];
+            }
+        }
+        *scr = yj;
+        scr += G;
+#pragma unroll
+        for (int i = 1; i <= KLT; ++i) {
+            w[i].x -= m[i - 1] * yj.x;
+            w[i].y -= m[i - 1] * yj.y;
+        }
+#pragma unroll
+        for (int rb = 0; rb < NBT; ++rb) {
+            gb[rb].x -= ab[rb] * yj.x;
+            gb[rb].y -= ab[rb] * yj.y;
+        }
+#pragma unroll
+        for (int d = 0; d < KLT; ++d) w[d] = w[d + 1];
+        w[KLT] = rnew;
+    };
+    // (a second row of loads in flight per system was measured: 4.8 ms instead of 4.4 ms at 512^2 pencils)
+    if (n > 0) prefetch(mB, abB, pB, rB);
+#pragma unroll 1
+    for (int j = 0; j < n; ++j) {
+#pragma unroll
+        for (int i = 0; i < KLT; ++i) mA[i] = mB[i];
+#pragma unroll
+        for (int rb = 0; rb < NBT; ++rb) abA[rb] = abB[rb];
+        pA = pB;
+        rA = rB;
+        if (j + 1 < n) prefetch(mB, abB, pB, rB);
+        step(mA, abA, pA, rA);
+    }
+    // ---- Schur block: z = Sinv * gb ; border unknown r is logical column n + r
+    const double *Ab = (const double *)L.Ab;
+#pragma unroll
+    for (int r = 0; r < NBT; ++r) {
+        if (r < nb) {
+            double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int cidx = 0; cidx < NBT; ++cidx)
+                if (cidx < nb) El<true>::fma2(acc, Ab[lu_ab(L, id.gl, n + cidx, r)], gb[cidx]);
+            L.scratch[(long)(n + r) * G + g] = acc;     // graded value for the backward sweep
+            double2 v = acc;
+            const unsigned char code = s_code[N + r];
+            if (code & 1) v = make_double2(-v.y, v.x);
+            if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+            if (conjq) v.y = -v.y;
+            store_sys<NF>(xout, plane, my_perm[N + r], P, c, s, v, id.active);
+        }
+    }
+}
+
 template <int NF, int WT, bool REAL, bool PREF, bool PFUSE = false>
 __global__ void __launch_bounds__(256)
 solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const double *__restrict__ pband) {
@@ -1449,6 +1630,8 @@ static int finish_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
 // (these are the per-rank sizes of the 512 x 512 x 256 problem on 8 / 4 / 2 GPUs); 2-D problems (a few hundred
 // systems) were tuned with 16 lanes in both sweeps.  forward: 16 lanes per system (needs kl < 16); backward: 16 or 4
 // lanes per system (fewer lanes = less redundant work per system, more products per lane).
+// multipliers per column held by the one-thread-per-system forward kernel for a lower bandwidth kl
+static int forward_window(int kl) { return kl <= 12 ? 12 : 16; }
 // register window (entries above the diagonal) of the one-thread-per-system backward kernel for an upper bandwidth W
 static int backward_window(int W) { return W <= 32 ? 32 : (W <= 34 ? 34 : (W <= 48 ? 48 : 64)); }
 
@@ -1517,7 +1700,24 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
             hipLaunchKernelGGL((solve_forward_kernel<NF, false, KLTV, NBTV>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x); \
     }
     // (few window sizes: every instantiation is a fully unrolled kernel and this file dominates the build time)
-    if (use_fwd) {
+    bool lean_fwd = false;
+    if constexpr (NF == 2) {
+        static const int no_lean = getenv("DDH_FWD_LEAN") ? !atoi(getenv("DDH_FWD_LEAN")) : 0;
+        // (the widest combination, kl > 12 with a border > 2, does not fit two waves per SIMD: general kernel)
+        lean_fwd = !use_fwd && d.real && d.n > 0 && !no_lean && d.kpad + d.kl == forward_window(d.kl) &&
+                   d.rows_aw >= d.n + forward_window(d.kl) && (d.kl <= 12 || d.nb <= 2);
+        if (lean_fwd) {
+#define DDH_LFWD(KLTV, NBTV) \
+    hipLaunchKernelGGL((solve_forward_lean_kernel<KLTV, NBTV>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x);
+            if (d.nb <= 2) {
+                if (d.kl <= 12) DDH_LFWD(12, 2) else DDH_LFWD(16, 2)
+            } else {
+                DDH_LFWD(12, 8)
+            }
+#undef DDH_LFWD
+        }
+    }
+    if (use_fwd || lean_fwd) {
     } else if (d.nb <= 2) {
         if (d.kl <= 12) DDH_FWD(12, 2) else DDH_FWD(16, 2)
     } else {
@@ -1897,18 +2097,21 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
         d.n = n; d.nb = nb; d.N = N; d.kl = kl; d.ku = ku; d.W = W; d.BW = kl + W + 1;
         // real factors: rows are padded (with zeros) to the register window of the one-thread-per-system backward kernel,
         // which then runs without per-entry guards (launch_solve picks the same window)
-        if (real) d.BW = kl + backward_window(W) + 1;
+        if (real) {
+            d.kpad = forward_window(kl) - kl;
+            d.BW = d.kpad + kl + backward_window(W) + 1;
+        }
         d.real = real ? 1 : 0;
         d.GL = (long)GL;
         d.nblk = (long)((GL + 63) / 64);
-        d.rows_aw = n > 0 ? n : 1;
+        d.rows_aw = (n > 0 ? n : 1) + (real ? forward_window(kl) : 0);
         const size_t GLp = (size_t)d.nblk * 64;
-        const size_t szAw = esz * (size_t)(n > 0 ? n : 1) * d.BW * GLp;
+        const size_t szAw = esz * (size_t)d.rows_aw * d.BW * GLp;
         const size_t szAb = esz * (size_t)N * (nb > 0 ? nb : 1) * GLp;
         const size_t szScr = sizeof(double2) * (size_t)std::max(n + nb, nb * nb) * G;
         int st = check_hip(hipMalloc((void **)&d.Aw, szAw), "hipMalloc(band LU)");
         if (!st) st = check_hip(hipMalloc((void **)&d.Ab, szAb), "hipMalloc(border LU)");
-        if (!st) st = check_hip(hipMalloc((void **)&d.piv, (size_t)(n > 0 ? n : 1) * GLp), "hipMalloc(piv)");
+        if (!st) st = check_hip(hipMalloc((void **)&d.piv, (size_t)d.rows_aw * GLp), "hipMalloc(piv)");
         if (!st) st = check_hip(hipMalloc((void **)&d.flag, GL), "hipMalloc(flag)");
         if (!st) st = check_hip(hipMalloc((void **)&d.scratch, szScr), "hipMalloc(scratch)");
         if (!st) st = upload_vec(&lu->d_rowperm, row_perm_h, (size_t)N);
@@ -1957,7 +2160,7 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
             }
     }
     LuDev &d = lu->dev;
-    DDH_HIP(hipMemsetAsync(d.Aw, 0, esz * (size_t)(n > 0 ? n : 1) * d.BW * (size_t)d.nblk * 64, s));
+    DDH_HIP(hipMemsetAsync(d.Aw, 0, esz * (size_t)d.rows_aw * d.BW * (size_t)d.nblk * 64, s));
     DDH_HIP(hipMemsetAsync(d.Ab, 0, esz * (size_t)N * (nb > 0 ? nb : 1) * (size_t)d.nblk * 64, s));
     // inverse permutations (physical -> logical) on the device
     std::vector<int> rowinv(N), colinv(N);
