@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PMC_FAMILY = {   # kernel family in this file -> device kernel name prefixes in profiles/r2_pmc_traffic.json
-    "pencil_solve": ["solve_forward_kernel", "solve_backward_kernel"],
+    "pencil_solve": ["solve_forward_", "solve_backward_"],
     "pencil_matvec": ["matvec_kernel"],
     "rfft_bilinear_fused": ["gw::gridwave_bilinear_kernel", "fused_rfft_bilinear_kernel"],
     "rfft_backward_contig": ["fft_axis_kernel<1, false"],

@@ -27,7 +27,10 @@ def plan(N, M, alpha):
 
 def main():
     dev = Device.get()
-    N, M, nc, inner = 384, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 3, 512 * 512
+    # argv: number of components, inner extent (lines per outer block; the total line count is kept at nc * 512 * 512)
+    N, M, nc = 384, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    inner = int(sys.argv[2]) if len(sys.argv) > 2 else 512 * 512
+    nc = nc * (512 * 512 // inner)
     p0, p1 = plan(N, M, 0), plan(N, M, 1)
     c = torch.randn((nc, M, inner), dtype=torch.float64, device="cuda")
     g0 = torch.empty((nc, N, inner), dtype=torch.float64, device="cuda")
