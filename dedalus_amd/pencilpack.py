@@ -167,6 +167,9 @@ class PencilPack:
                 for s in range(self.S):
                     sign = 1 if s == 0 else -1
                     gmx = mx + self.mx_offset
+                    if s == 1 and kxv == 0.0:
+                        inv[f * self.S + 1] = inv[f * self.S]       # lambda(-kx) == lambda(kx) at kx = 0
+                        continue
                     A = a * M.dense(kxv, kyv, gmx, my, sign) + b * L.dense(kxv, kyv, gmx, my, sign)
                     A = A[np.ix_(row_perm, col_perm)]
                     # identity pairing of rows/columns that do not exist for this pencil
@@ -174,7 +177,8 @@ class PencilPack:
                     bad_c = [i for i in range(N) if not _valid(ca[i], gmx, my, self.nf)]
                     for i, j in zip(bad_r, bad_c):
                         A[i, j] = 1.0
-                    inv[f * self.S + s] = np.linalg.inv(A)
+                    # (the mean-mode pencil of a real operator is a real matrix: a real inversion is 3-4x cheaper)
+                    inv[f * self.S + s] = np.linalg.inv(A.real) if not A.imag.any() else np.linalg.inv(A)
             inv = np.ascontiguousarray(inv)
             libhip.call("ddh_pencil_set_dense_inverse", self.handle, lu_id,
                         inv.view(np.float64).ctypes.data_as(C.POINTER(C.c_double)))

@@ -102,7 +102,9 @@ def test_flow_properties_reduce_on_device():
     assert abs(flow.min("uu") - g.min()) <= 1e-15 * abs(g.max())
     assert abs(flow.grid_average("uu") - g.mean()) <= 1e-13 * abs(g.mean())
     gb = np.asarray(b["g"])
-    assert abs(flow.grid_average("b") - gb.mean()) <= 1e-13 and flow.max("b") == gb.max() and flow.min("b") == gb.min()
+    # (b['g'] may re-transform the field: equal up to the round-off of a transform round trip, not bit for bit)
+    assert abs(flow.grid_average("b") - gb.mean()) <= 1e-13
+    assert abs(flow.max("b") - gb.max()) <= 4e-16 * abs(gb.max()) and abs(flow.min("b") - gb.min()) <= 1e-15
     dev = solver.ex.dev
     rng = np.random.default_rng(0)
     for n in (1, 63, 1025, 300007):
