@@ -170,15 +170,27 @@ class PencilPack:
                     if s == 1 and kxv == 0.0:
                         inv[f * self.S + 1] = inv[f * self.S]       # lambda(-kx) == lambda(kx) at kx = 0
                         continue
-                    A = a * M.dense(kxv, kyv, gmx, my, sign) + b * L.dense(kxv, kyv, gmx, my, sign)
-                    A = A[np.ix_(row_perm, col_perm)]
-                    # identity pairing of rows/columns that do not exist for this pencil
-                    bad_r = [i for i in range(N) if not _valid(ra[i], gmx, my, self.nf)]
-                    bad_c = [i for i in range(N) if not _valid(ca[i], gmx, my, self.nf)]
-                    for i, j in zip(bad_r, bad_c):
-                        A[i, j] = 1.0
+                    # M, L of the pencil in logical ordering and the identity pairing of rows / columns that do not exist
+                    # for it do not depend on (a, b): kept across refactorizations (timestep changes)
+                    key = (matM, matL, cell, s, row_perm.tobytes(), col_perm.tobytes())
+                    cache = self.__dict__.setdefault("_flag_dense", {})
+                    if key not in cache:
+                        Md = M.dense(kxv, kyv, gmx, my, sign)[np.ix_(row_perm, col_perm)]
+                        Ld = L.dense(kxv, kyv, gmx, my, sign)[np.ix_(row_perm, col_perm)]
+                        bad_r = [i for i in range(N) if not _valid(ra[i], gmx, my, self.nf)]
+                        bad_c = [i for i in range(N) if not _valid(ca[i], gmx, my, self.nf)]
+                        npair = min(len(bad_r), len(bad_c))
+                        Id = (np.array(bad_r[:npair], dtype=np.int64), np.array(bad_c[:npair], dtype=np.int64))
+                        if not (Md.imag.any() or Ld.imag.any()):
+                            Md, Ld = Md.real.copy(), Ld.real.copy()
+                        if len(cache) > 8:
+                            cache.clear()
+                        cache[key] = (Md, Ld, Id)
+                    Md, Ld, Id = cache[key]
+                    A = a * Md + b * Ld
+                    A[Id] = 1.0
                     # (the mean-mode pencil of a real operator is a real matrix: a real inversion is 3-4x cheaper)
-                    inv[f * self.S + s] = np.linalg.inv(A.real) if not A.imag.any() else np.linalg.inv(A)
+                    inv[f * self.S + s] = np.linalg.inv(A)
             inv = np.ascontiguousarray(inv)
             libhip.call("ddh_pencil_set_dense_inverse", self.handle, lu_id,
                         inv.view(np.float64).ctypes.data_as(C.POINTER(C.c_double)))
