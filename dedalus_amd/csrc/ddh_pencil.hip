@@ -77,6 +77,7 @@ struct LuDev {
     long GL;                       // number of stored factorizations: G (complex) or ncells (real)
     long nblk;                     // ceil(GL / 64): factor storage is tiled [block of 64][row][entry][lane]
     int rows_aw;                   // rows per block: max(n, 1) (+ kl + kpad zero rows for real factors)
+    int pk;                        // real factors: band entries stored in pairs per lane (lu_eoff)
     int kpad;                      // real factors: zero entries in front of every band row, so that the forward sweep's
                                    // window of kl + kpad multipliers per column needs no guards (solve_forward_lean_kernel)
     void *Aw;                      // [n][BW][GL]  band rows, LAPACK-style fill space (double2 or double)
@@ -257,8 +258,14 @@ template <> struct El<true> {
 // Factor storage index, [block of 64 factorizations][row][entry][lane]: everything a wave ever reads of one array is one
 // contiguous stream, a row is one BW * 512 B chunk.
 // (entry d of a band row: d = kl + (column - row); the row starts with kpad zero entries, see LuDev::kpad)
+// pk (real factors): the entries of a row are stored in PAIRS per lane, [entry / 2][lane][2]: one 16-byte load brings two
+// consecutive band entries of a system.  The sweeps are bound by the number of vector-memory requests in flight, not by
+// bytes (a wave can have 63 outstanding, a row of the backward sweep is 35 entries): half the requests per row.
+__device__ __forceinline__ long lu_eoff(const LuDev &L, int e) {          // raw entry e of a row, relative to raw entry 0
+    return L.pk ? (((long)(e >> 1) << 7) + (e & 1)) : ((long)e << 6);
+}
 __device__ __forceinline__ long lu_aw(const LuDev &L, long gl, int row, int d) {
-    return ((((gl >> 6) * (long)L.rows_aw + row) * L.BW + (d + L.kpad)) << 6) + (gl & 63);
+    return ((((gl >> 6) * (long)L.rows_aw + row) * L.BW) << 6) + lu_eoff(L, d + L.kpad) + ((gl & 63) << (L.pk ? 1 : 0));
 }
 __device__ __forceinline__ long lu_ab(const LuDev &L, long gl, int col, int rb) {
     return ((((gl >> 6) * (long)L.N + col) * L.nb + rb) << 6) + (gl & 63);
@@ -1008,7 +1015,7 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
         const double *const awl = (const double *)L.Aw + lu_aw(L, id.gl, 0, -L.kpad);   // this lane's block, row 0, entry 0
         const long BW64 = (long)L.BW << 6;
 #pragma unroll
-        for (int i = 0; i < KLT; ++i) mp[i] = awl + (long)(i + 1) * (BW64 - 64) + (long)KLT * 64;
+        for (int i = 0; i < KLT; ++i) mp[i] = awl + (long)(i + 1) * BW64 + lu_eoff(L, KLT - i - 1);
     }
     const double *abp = (const double *)L.Ab + lu_ab(L, id.gl, 0, 0);
     const unsigned char *pvp = L.piv + lu_pv(L, id.gl, 0);
@@ -1191,9 +1198,20 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
             for (int d = 0; d < PBW; ++d) pr[d] = prow[d];
         }
         const E *Ur = ur0 + (long)j * ur_stride;
+        if constexpr (REAL) {
+            // pair-packed rows (LuDev::pk; the diagonal sits at an even entry): 16-byte loads, two entries each
+            const double2 *Ur2 = reinterpret_cast<const double2 *>(Ur);
 #pragma unroll
-        for (int d = 0; d <= WT; ++d)
-            if (FULL || d <= W) u[d] = Ur[(long)d << 6];
+            for (int q = 0; 2 * q <= WT; ++q) {
+                const double2 uu = Ur2[(long)q << 6];
+                u[2 * q] = uu.x;
+                if (2 * q + 1 <= WT) u[2 * q + 1] = uu.y;
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d <= WT; ++d)
+                if (FULL || d <= W) u[d] = Ur[(long)d << 6];
+        }
         // all loads of the row are in flight before the first use: left alone the scheduler trades them for registers
         // (4 outstanding loads, one memory round trip per group -- 9 per row instead of 1)
         __builtin_amdgcn_sched_barrier(0);
@@ -1364,7 +1382,8 @@ solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, 
     // issue() is called for jj = 0, 1, 2, ...: running pointers instead of 64-bit index arithmetic per entry (the
     // address computations were the dominant VALU work of a row)
     const long aw_rs = (long)L.BW * 64, ab_rs = (long)L.nb * 64, pv_rs = 64;
-    const int aw_step = (int)(aw_rs - 64);                   // (row + 1, d - 1) relative to (row, d)
+    const int kd = kl + L.kpad;                              // raw entry of the diagonal
+    const long kd_off = lu_eoff(L, kd);
     const unsigned char *pv_ptr = L.piv + lu_pv(L, gl, 0);
     const E *aw_ptr = Aw + lu_aw(L, gl, 0, kl);              // (row jj, diagonal)
     const E *ab_ptr = Ab + lu_ab(L, gl, 0, 0);
@@ -1375,7 +1394,7 @@ solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, 
         pp[slot] = *pv_ptr;
         // raw values only: whether an entry is used is decided when the row is consumed (touching the value here
         // would make the wave wait for the load it has just issued)
-        pm[slot] = aw_ptr[dc * aw_step];
+        pm[slot] = aw_ptr[dc * aw_rs + (lu_eoff(L, kd - dc) - kd_off)];      // (row jj + dc, column jj)
 #pragma unroll
         for (int rb = 0; rb < NBT; ++rb) pab[slot][rb] = ab_ptr[(rb < nb ? rb : 0) << 6];
         const int nxt = jj + kl + 1;
@@ -1481,6 +1500,8 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     double2 py[COOP_D];
     // issue() is called for jj = n - 1, n - 2, ...: running pointers (see the forward kernel)
     const long aw_rs = (long)L.BW * 64;
+    const int kd = kl + L.kpad;
+    const long kd_off = lu_eoff(L, kd);
     const E *u_ptr = Aw + lu_aw(L, gl, n - 1, kl);
     const double2 *y_ptr = L.scratch + (long)(n - 1) * G + g;
     auto issue = [&](int jj, int slot) {                  // branch-free
@@ -1490,7 +1511,7 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             const int d = 1 + e + CB * t;
-            pu[slot][t] = u_ptr[(d <= W ? d : 0) << 6];               // raw; entries beyond the band are dropped at use
+            pu[slot][t] = u_ptr[lu_eoff(L, kd + (d <= W ? d : 0)) - kd_off];   // raw; entries beyond the band are dropped at use
         }
         const bool adv = jj > 0;
         u_ptr -= adv ? aw_rs : 0;
@@ -1788,9 +1809,8 @@ lu_width_kernel(LuDev L, int *__restrict__ wrow) {
     for (int j = 0; j < L.n; ++j) {
         int w = 0;
         if (act) {
-            const E *Ur = Aw + lu_aw(L, gl, j, L.kl);
             for (int d = L.W; d > 0; --d)
-                if (!El<REAL>::is_zero(Ur[(long)d << 6])) { w = d; break; }
+                if (!El<REAL>::is_zero(Aw[lu_aw(L, gl, j, L.kl + d)])) { w = d; break; }
         }
 #pragma unroll
         for (int sft = 32; sft > 0; sft >>= 1) w = max(w, __shfl_xor(w, sft, 64));
@@ -2098,8 +2118,10 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
         // real factors: rows are padded (with zeros) to the register window of the one-thread-per-system backward kernel,
         // which then runs without per-entry guards (launch_solve picks the same window)
         if (real) {
-            d.kpad = forward_window(kl) - kl;
+            d.kpad = forward_window(kl) - kl;                       // the diagonal lands on an even entry (12 or 16)
             d.BW = d.kpad + kl + backward_window(W) + 1;
+            d.BW += d.BW & 1;
+            d.pk = 1;
         }
         d.real = real ? 1 : 0;
         d.GL = (long)GL;
