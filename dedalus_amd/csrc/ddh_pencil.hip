@@ -21,6 +21,11 @@
 // rows < n form a band (kl, ku); the nb border rows are dense and are eliminated without taking
 // part in pivoting; systems whose band block is singular are flagged and solved through an
 // explicit dense inverse supplied by the host (ddh_pencil_set_dense_inverse).
+//
+// Sweep kernels: one thread per system -- solve_forward_lean_kernel (real factors, two Fourier
+// axes), solve_forward_kernel (everything else), solve_backward_kernel (guard-free for real factors) -- or 16 / 4 lanes
+// per system for few systems (solve_*_coop_kernel).  Real factors are stored padded, pair-packed and, for problems
+// symmetric under x <-> y, once per pair of transposed cells (LuDev::kpad, pk, pair).
 #include "ddh_common.h"
 
 #include <algorithm>
@@ -72,7 +77,8 @@ struct Matrix {
 };
 
 struct LuDev {
-    int n, nb, N, kl, ku, W, BW;   // BW = kl + W + 1, W = ku + kl
+    int n, nb, N, kl, ku, W, BW;   // W = ku + kl; BW = entries stored per band row: kl + W + 1 (complex factors), real
+                                   // factors: kpad + kl + (backward register window) + 1, rounded up to even
     int real;                      // 1: real graded matrix shared by the systems of a cell (see factor_real)
     long GL;                       // number of stored factorizations: G (complex) or ncells (real)
     long nblk;                     // ceil(GL / 64): factor storage is tiled [block of 64][row][entry][lane]
@@ -80,7 +86,7 @@ struct LuDev {
     int pk;                        // real factors: band entries stored in pairs per lane (lu_eoff)
     int kpad;                      // real factors: zero entries in front of every band row, so that the forward sweep's
                                    // window of kl + kpad multipliers per column needs no guards (solve_forward_lean_kernel)
-    void *Aw;                      // [n][BW][GL]  band rows, LAPACK-style fill space (double2 or double)
+    void *Aw;                      // [block][rows_aw][BW][lane]  band rows (lu_aw), LAPACK-style fill space (double2 / double)
     void *Ab;                      // [N][nb][GL]  border rows (multipliers | Schur block inverse)
     unsigned char *piv;            // [n][GL]
     unsigned char *flag;           // [GL]
