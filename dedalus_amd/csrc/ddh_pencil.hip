@@ -305,13 +305,12 @@ __device__ __forceinline__ CellCtx cell_ctx(const PencilDev &P, long cell) {
 struct SysId {
     long cell, gl, G;   // cell (addressing), stored factorization, stride of the scratch vectors
     int s;
-    bool partner, active, ok;
+    bool partner, ok;
 };
 template <bool REAL>
 __device__ __forceinline__ SysId sys_id(const PencilDev &P, const LuDev &L, long g) {
     SysId id;
     id.partner = false;
-    id.active = true;
     id.G = P.G;
     id.ok = g < P.G;                // G is a multiple of S, pairs never straddle the guard
     id.cell = id.ok ? g / P.S : 0;
@@ -966,7 +965,7 @@ solve_forward_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__restrict_
                 if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
             }
             if (conjq) v.y = -v.y;
-            store_sys<NF>(xout, plane, my_perm[N + r], P, c, s, v, id.active);
+            store_sys<NF>(xout, plane, my_perm[N + r], P, c, s, v);
         }
     }
 }
@@ -1144,7 +1143,7 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
             if (code & 1) v = make_double2(-v.y, v.x);
             if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
             if (conjq) v.y = -v.y;
-            store_sys<NF>(xout, plane, my_perm[N + r], P, c, s, v, id.active);
+            store_sys<NF>(xout, plane, my_perm[N + r], P, c, s, v);
         }
     }
 }
@@ -1173,7 +1172,6 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
     const long gl = id.gl;
     const int *my_perm = id.partner ? s_perm2 : s_perm;
     const bool conjq = id.partner && s == 1;
-    const bool active = id.active;
     const E *Aw = (const E *)L.Aw;
     const long plane = P.nx * P.ny;
 
@@ -1229,7 +1227,7 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
             if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
         }
         if (conjq) v.y = -v.y;
-        store_sys<NF>(xout, plane, my_perm[j], P, c, s, v, active);
+        store_sys<NF>(xout, plane, my_perm[j], P, c, s, v);
     };
     // rows are processed in pairs; the register window is shifted once per pair (by two).  With PFUSE the emitted value
     // is the recombined unknown x_j = y_j + sum_d P[j, j + d] y_(j + d) (the window already holds y_(j+1..)): the
