@@ -214,7 +214,6 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
     double2 *buf = lds;                 // [B][ld]
     double2 *tw_lo = lds + p.B * p.ld;  // [32]        W^q          (or the full table [N])
     double2 *tw_hi = tw_lo + 32;        // [N/32 + 1]  W^(32 q)
-    double2 *cbuf = tw_lo + tw_entries(p.N, p.twdirect);   // [B][M]   (Chebyshev coefficient staging only)
     load_twiddles(p, tw_lo, tw_hi, threadIdx.x, blockDim.x);
     // Chebyshev normalisation (Appendix A of SURVEY.md; transforms.py:720-724, 737-746, 823-826, 844-860)
     // computed on the fly: forward sgn*sqrt(pi/2)/N (k=0: sqrt(pi)/(2N)), backward sgn/(2 sqrt(pi/2)) (k=0: 1/sqrt(pi))
@@ -720,19 +719,31 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 io.store(dst, M, k, q0 + b, c);
             }
         } else {
-            for (int w = tid; w < M * B; w += T) {
-                unsigned q, r;
-                p.fdM.divmod((unsigned)w, q, r);
-                const int k = (int)r, b = (int)q;
-                double2 c = make_double2(0.0, 0.0);
+            // coefficients in the family's own basis first, IN the transform buffer (slots k and N - k depend on the FFT
+            // outputs k and N - k only: pairwise in place, no staging buffer, the tile is as large as the plain
+            // transform's), then the banded conversion reads them from there.
+            const int KH = N / 2 + 1;
+            for (int w = tid; w < KH * B; w += T) {
+                const int b = w / KH, k = w - b * KH;
+                double2 *line = buf + b * ld;
+                const int kr = N - k;
+                const double2 z1 = line[lpad(k)], z2 = line[lpad((k == 0) ? 0 : kr)];
+                double2 c1 = make_double2(0.0, 0.0), c2 = c1;
                 if (k < Mk) {
-                    const double2 z1 = buf[b * ld + lpad(k)], z2 = buf[b * ld + lpad(((k == 0) ? 0 : N - k))];
                     const double2 h = half_of(k);
                     const double s = fscale_of(k);
-                    c.x = s * ((z1.x + z2.x) * h.x - (z1.y - z2.y) * h.y);
-                    c.y = s * ((z1.y + z2.y) * h.x - (z2.x - z1.x) * h.y);
+                    c1.x = s * ((z1.x + z2.x) * h.x - (z1.y - z2.y) * h.y);
+                    c1.y = s * ((z1.y + z2.y) * h.x - (z2.x - z1.x) * h.y);
                 }
-                cbuf[b * M + k] = c;
+                const bool partner = (k > 0 && kr != k);
+                if (partner && kr < Mk) {                     // the roles of the two FFT outputs swap
+                    const double2 h = half_of(kr);
+                    const double s = fscale_of(kr);
+                    c2.x = s * ((z2.x + z1.x) * h.x - (z2.y - z1.y) * h.y);
+                    c2.y = s * ((z2.y + z1.y) * h.x - (z1.x - z2.x) * h.y);
+                }
+                line[lpad(k)] = c1;
+                if (partner) line[lpad(kr)] = c2;
             }
             __syncthreads();
             // forward_conversion apply (transforms.py:862-874): c'_k = sum_d C[k,k+off_d] c_{k+off_d}
@@ -740,14 +751,15 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 int k, b;
                 split_item<INNER>(w, p.fdB, p.fdM, k, b);
                 if (q0 + b >= npairs) continue;
-                const double2 *c = cbuf + b * M;
+                const double2 *line = buf + b * ld;
                 double2 acc = make_double2(0.0, 0.0);
                 for (int d = 0; d < p.nbands; ++d) {
                     const int kk = k + p.boff[d];
-                    if (kk < M) {
+                    if (kk < Mk) {
                         const double a = p.bands[d * M + k];
-                        acc.x += a * c[kk].x;
-                        acc.y += a * c[kk].y;
+                        const double2 cv = line[lpad(kk)];
+                        acc.x += a * cv.x;
+                        acc.y += a * cv.y;
                     }
                 }
                 io.store(dst, M, k, q0 + b, acc);
@@ -1202,8 +1214,8 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
         npairs = inner_mode ? (inner + 1) / 2 : (outer + 1) / 2;
     // lines per workgroup: 64 B of contiguous data per row when strided; bounded by LDS (<= 64 KiB
     // so that at least two workgroups share a CU) and by 12 staged values per thread.
-    const int N = d.N, M = d.M;
-    const size_t per_line = (size_t)(d.ld + ((MODE == CHEB_FWD && d.nbands > 0) ? M : 0)) * sizeof(double2);
+    const int N = d.N;
+    const size_t per_line = (size_t)d.ld * sizeof(double2);
     static const int envB = getenv("DDH_FFT_B") ? atoi(getenv("DDH_FFT_B")) : 0;
     static const long lds_cap = getenv("DDH_FFT_LDSCAP") ? atol(getenv("DDH_FFT_LDSCAP")) : 64 * 1024;
     int B = inner_mode ? 8 : 4;      // strided: 128-byte contiguous segments per row when LDS allows
