@@ -591,9 +591,10 @@ class Evaluator:
             if lid in plain:
                 want[(lid, step)] = dscale
 
-    def eval_fused_products(self, group, outs):
+    def eval_fused_products(self, group, outs, scales=None):
         """One fused launch for product nodes that share their register operand `a`.
-        group: [(expr, (a, b, terms, basis, spec))]; outs: pre-grid result arrays [ncomp, ..., M]."""
+        group: [(expr, (a, b, terms, basis, spec))]; outs: pre-grid result arrays [ncomp, ..., M]; scales: a factor per
+        product folded into its term coefficients (the sign / constant of the right-hand side it feeds)."""
         a = group[0][1][0]
         basis, spec = group[0][1][3], group[0][1][4]
         self._plan_dual_transforms([a] + [fp[1] for _, fp in group])
@@ -601,7 +602,8 @@ class Evaluator:
         a_list = [par[i] for (par, i, ds) in la]
         a_ds = [ds for (par, i, ds) in la]
         b_list, b_ds, out_list, terms, bpos = [], [], [], [], {}
-        for (expr, (a_, b, tms, _, _)), out in zip(group, outs):
+        for gi, ((expr, (a_, b, tms, _, _)), out) in enumerate(zip(group, outs)):
+            sc = 1.0 if scales is None else float(scales[gi])
             lb = self._operand_lines(b)
             ob = len(out_list)
             out_list.extend(out[i] for i in range(expr.ncomp))
@@ -612,7 +614,7 @@ class Evaluator:
                     bpos[kb] = len(b_list)
                     b_list.append(par[i])
                     b_ds.append(ds)
-                terms.append((ob + ic, ia, bpos[kb], cf))
+                terms.append((ob + ic, ia, bpos[kb], cf * sc))
         if len(b_list) > self.ex.FUSED_LIMITS["nb"]:
             raise RuntimeError("fused grid stage: too many distinct operands")
         M = spec[2]

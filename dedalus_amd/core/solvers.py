@@ -419,8 +419,9 @@ class SolverBase:
                 self.nl_fused.append([(item, fp)])
         nf, nx, ny, kx, ky = ev.geom()
         self.F_nl = None
+        self._plan_direct_F(groups)
         if nl_rows:
-            self.NLbuf = self.ex.zeros((nl_rows, nx, ny))
+            self.NLbuf = None if self.F_direct is not None else self.ex.zeros((nl_rows, nx, ny))
             self.nl_pack = self.ex.make_pack(nf, nl_rows, nx, ny, kx, ky, self.dist._mx_offset)
             self.F_nl = self.nl_pack.add_matrix(flatten(groups["nl"], self.R, nl_rows))
         self.F_x = None
@@ -446,10 +447,93 @@ class SolverBase:
             nz = np.flatnonzero(total)
             self.F_const = self.ex.make_scatter(nz, total.reshape(-1)[nz]) if nz.size else None
 
+    def _plan_direct_F(self, groups):
+        """Right-hand sides that are nothing but fused nonlinear products converted to their equation's basis (times a
+        constant): F_u = -u.grad(u) and the like.  The forward Jacobi-axis transform then writes the equation's rows of the
+        F system vector itself -- the conversion T -> (a, b) of the equation is the transform's own band apply
+        (core/transforms.py:862-874), the constant goes into the product's term coefficients -- and the gather mat-vec
+        (nl_pack / F_nl: read 4, write R row blocks, per stage) never runs.  self.F_direct = [(group index, member index,
+        equation info, scale)] or None when any part of F needs the general path."""
+        self.F_direct = None
+        if os.environ.get("DDH_NO_DIRECT_F") is not None or not self.nl_leaves or self.nl_plain:
+            return
+        if groups["x"] or groups["param"]:
+            return
+        from ..tools import jacobi
+        by_row0 = {}
+        for blk in groups["nl"]:
+            by_row0.setdefault(blk[2], []).append(blk)
+        plan, eq_rows = {}, []
+        for leaf, row0, rows in self.nl_leaves:
+            blks = by_row0.get(row0, [])
+            if len(blks) != 1:
+                return
+            eq_row0, nzo, _, nzi, terms, fx, fy = blks[0]
+            einfo = [e for e in self.eq_info if e["row0"] == eq_row0]
+            if not einfo or fx or fy or nzo != nzi or einfo[0]["ncomp"] != leaf.ncomp or len(terms) != leaf.ncomp:
+                return
+            einfo = einfo[0]
+            jac = [ax for ax in self.dist._jacobi_axes if leaf.domain.by_axis[ax] is not None]
+            if len(jac) != 1:
+                return
+            bl, be = leaf.domain.by_axis[jac[0]], einfo["eq"]["domain"].by_axis[jac[0]]
+            if be is None or (bl.a, bl.b) != (bl.a0, bl.b0) or (be.a0, be.b0) != (bl.a0, bl.b0) or (be.a, be.b) == (bl.a, bl.b):
+                return
+            for ax, b in enumerate(leaf.domain.by_axis):
+                if ax != jac[0] and b is not einfo["eq"]["domain"].by_axis[ax]:
+                    return
+            conv = jacobi.conversion_matrix(nzi, bl.a0, bl.b0, be.a, be.b).tocsr()
+            offs = np.unique((conv.tocoo().col - conv.tocoo().row))
+            if offs.min() < 0 or len(offs) > 4:
+                return
+            scale = None
+            for c, t in enumerate(sorted(terms, key=lambda t: t.co)):
+                if t.co != c or t.ci != c or t.ex or t.ey or t.dx or t.dy or t.dt or t.coef.imag != 0.0:
+                    return
+                Z = t.Z.tocsr() * t.coef.real
+                if Z.shape != conv.shape:
+                    return
+                ratio = Z.diagonal()[0] / conv.diagonal()[0]
+                if scale is None:
+                    scale = ratio
+                diff = abs(Z - scale * conv)
+                if diff.nnz and diff.max() > 1e-13 * abs(scale) * abs(conv).max():
+                    return
+            plan[id(leaf)] = (einfo, float(scale))
+            eq_rows.append((eq_row0, eq_row0 + einfo["rows"]))
+        # constants of F must not fall into rows the transforms overwrite
+        for leaf, blk in groups["const"]:
+            lo, hi = blk[0], blk[0] + blk[1]
+            if any(lo < b and a < hi for a, b in eq_rows):
+                return
+        self.F_direct = plan
+        self._F_zeroed = set()
+
     def evaluate_F(self, out):
         """F system vector for the current state (coefficient space, equation bases)."""
         ev, ex = self.evaluator_core, self.ex
         ev.new_pass()
+        if self.F_direct is not None:
+            tr = self.dist.transformer
+            key = (out.data_ptr() if hasattr(out, "data_ptr") else id(out))
+            if key not in self._F_zeroed:               # rows without right-hand-side terms are zero and stay zero
+                ex.fill_zero(out)
+                self._F_zeroed.add(key)
+            for grp in self.nl_fused:
+                outs = [ex.empty(tr.pregrid_shape(leaf.domain, leaf.ncomp, leaf.domain.dealias))
+                        for (leaf, row0, rows), fp in grp]
+                ev.eval_fused_products([(item[0], fp) for item, fp in grp], outs,
+                                       scales=[self.F_direct[id(item[0])][1] for item, fp in grp])
+                for ((leaf, row0, rows), fp), pg in zip(grp, outs):
+                    einfo = self.F_direct[id(leaf)][0]
+                    edom = einfo["eq"]["domain"]
+                    dst = out[einfo["row0"]:einfo["row0"] + einfo["rows"]].reshape(
+                        (leaf.ncomp,) + tuple(edom.storage_coeff_shape()))
+                    tr.forward_data(edom, leaf.ncomp, pg, edom.dealias, dst, skip_last=True)
+            ev.new_pass()
+            if self.F_const is not None:
+                ex.scatter_set(out, self.F_const)
+            return
         parts = []
 
         def target():

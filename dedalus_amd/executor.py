@@ -96,6 +96,11 @@ class HipExecutor:
         idx, vals = sparse
         libhip.call("ddh_scatter_add", ptr(y), C.c_void_p(idx.data_ptr()), ptr(vals), idx.numel(), self.dev.stream)
 
+    def scatter_set(self, y, sparse):
+        """y[idx] = vals (a handful of entries: constants of the k = 0 pencil)."""
+        idx, vals = sparse
+        y.view(-1).index_copy_(0, idx, vals)
+
     def bilinear(self, out, ncomp_out, a, b, npts, terms):
         if self.timer is not None:
             na = len({t[1] for t in terms}) + len({t[2] for t in terms}) + ncomp_out

@@ -121,6 +121,10 @@ class NumpyExecutor:
         idx, vals = sparse
         y.reshape(-1)[idx] += vals
 
+    def scatter_set(self, y, sparse):
+        idx, vals = sparse
+        y.reshape(-1)[idx] = vals
+
     def bilinear(self, out, ncomp_out, a, b, npts, terms):
         a2, b2 = a.reshape(-1, npts), b.reshape(-1, npts)
         o = np.zeros((ncomp_out, npts))
