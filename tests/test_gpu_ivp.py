@@ -167,3 +167,22 @@ def test_fixed_dt_step_graph_matches_ordinary_launches():
     assert abs(b.sim_time - a.sim_time) < 1e-15 and b.iteration == a.iteration
     for k in ("p", "b", "u"):
         assert rel(np.array(fb[k]["c"]), np.array(fa[k]["c"])) < 1e-13, k
+
+
+def test_direct_right_hand_side_path_on_the_device(monkeypatch):
+    """The forward z transform writing F's equation rows (conversion in its band apply) against the gather mat-vec path
+    (DDH_NO_DIRECT_F=1), 3-D and 2-D Rayleigh-Benard, several steps."""
+    import dedalus_amd.public as d3
+    for builder, kw in ((problems.rayleigh_benard_3d, dict(Nx=16, Ny=24, Nz=16, timestepper="RK222")),
+                        (problems.rayleigh_benard_2d, dict(Nx=64, Nz=32, timestepper="SBDF2"))):
+        monkeypatch.delenv("DDH_NO_DIRECT_F", raising=False)
+        s1, f1 = builder(d3, **kw)
+        monkeypatch.setenv("DDH_NO_DIRECT_F", "1")
+        s0, f0 = builder(d3, **kw)
+        assert s1.F_direct is not None and s0.F_direct is None
+        for _ in range(4):
+            s1.step(1e-3)
+            s0.step(1e-3)
+        for k in ("p", "b", "u"):
+            a1, a0 = np.array(f1[k]['c']), np.array(f0[k]['c'])
+            assert np.isfinite(a1).all() and rel(a1, a0) < 1e-12, (k, rel(a1, a0))

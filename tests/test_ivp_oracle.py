@@ -94,3 +94,28 @@ def test_poisson_lbvp_matches_reference(gold, shape):
         ref = gold["poisson_%dx%d__%s" % (shape + (k,))]
         tol = 1e-10 if k in ("u", "f") else 1e-6          # the tau amplitudes are ~1e-20 (spectrally small residuals)
         assert rel(np.array(f['c']), ref) < tol, (k, rel(np.array(f['c']), ref))
+
+
+def test_direct_right_hand_side_path_matches_the_gather_matvec(monkeypatch):
+    """F made of fused products only (Rayleigh-Benard): the forward Jacobi transform writes the equation rows of F
+    (SolverBase._plan_direct_F); with DDH_NO_DIRECT_F the products go through NLbuf and the gather mat-vec instead.
+    Problems whose F has other parts (shear flow: products of derivatives of two fields + linear pieces) stay general."""
+    import dedalus_amd.public as d3
+    from oracle.np_executor import NumpyExecutor
+
+    def run(case, direct):
+        if direct:
+            monkeypatch.delenv("DDH_NO_DIRECT_F", raising=False)
+        else:
+            monkeypatch.setenv("DDH_NO_DIRECT_F", "1")
+        return problems.run_case(d3, case, dist_kw=dict(executor=NumpyExecutor()))
+
+    for case in ("rb3d_8x12x8_rk222", "rb2d_32x16_sbdf2"):
+        s1, r1 = run(case, True)
+        s0, r0 = run(case, False)
+        assert s1.F_direct is not None and s0.F_direct is None
+        assert s1.NLbuf is None                       # the staging vector of the gather path is not even allocated
+        for k in r1:
+            assert np.linalg.norm(r1[k] - r0[k]) <= 1e-13 * max(np.linalg.norm(r0[k]), 1e-300), (case, k)
+    s, _ = run("kdv64_rk443", True)
+    assert s.F_direct is None
