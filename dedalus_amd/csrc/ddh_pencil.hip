@@ -83,7 +83,7 @@ struct LuDev {
     long GL;                       // number of stored factorizations: G (complex) or ncells (real)
     long nblk;                     // ceil(GL / 64): factor storage is tiled [block of 64][row][entry][lane]
     int rows_aw;                   // rows per block: max(n, 1) (+ kl + kpad zero rows for real factors)
-    int pk;                        // real factors: band entries stored in pairs per lane (lu_eoff)
+    int pk, pk63;                  // real factors: band entries stored in pairs per lane (lu_eoff); pk63 = pk ? 63 : 0
     int kpad;                      // real factors: zero entries in front of every band row, so that the forward sweep's
                                    // window of kl + kpad multipliers per column needs no guards (solve_forward_lean_kernel)
     void *Aw;                      // [block][rows_aw][BW][lane]  band rows (lu_aw), LAPACK-style fill space (double2 / double)
@@ -267,8 +267,9 @@ template <> struct El<true> {
 // pk (real factors): the entries of a row are stored in PAIRS per lane, [entry / 2][lane][2]: one 16-byte load brings two
 // consecutive band entries of a system.  The sweeps are bound by the number of vector-memory requests in flight, not by
 // bytes (a wave can have 63 outstanding, a row of the backward sweep is 35 entries): half the requests per row.
+// (branch-free: pair e / 2 starts at 128 (e / 2), member e & 1 follows it:  64 e - 63 (e & 1);  pk63 = 63 or 0)
 __device__ __forceinline__ long lu_eoff(const LuDev &L, int e) {          // raw entry e of a row, relative to raw entry 0
-    return L.pk ? (((long)(e >> 1) << 7) + (e & 1)) : ((long)e << 6);
+    return ((long)e << 6) - (long)(L.pk63 * (e & 1));
 }
 __device__ __forceinline__ long lu_aw(const LuDev &L, long gl, int row, int d) {
     return ((((gl >> 6) * (long)L.rows_aw + row) * L.BW) << 6) + lu_eoff(L, d + L.kpad) + ((gl & 63) << (L.pk ? 1 : 0));
@@ -1386,8 +1387,8 @@ solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, 
     // issue() is called for jj = 0, 1, 2, ...: running pointers instead of 64-bit index arithmetic per entry (the
     // address computations were the dominant VALU work of a row)
     const long aw_rs = (long)L.BW * 64, ab_rs = (long)L.nb * 64, pv_rs = 64;
-    const int kd = kl + L.kpad;                              // raw entry of the diagonal
-    const long kd_off = lu_eoff(L, kd);
+    const int aw_step = (int)(aw_rs - 64);                   // (row + 1, d - 1) relative to (row, d) ...
+    const int pk63 = L.pk63;                                 // ... minus 63 when d - 1 is the second member of a pair
     const unsigned char *pv_ptr = L.piv + lu_pv(L, gl, 0);
     const E *aw_ptr = Aw + lu_aw(L, gl, 0, kl);              // (row jj, diagonal)
     const E *ab_ptr = Ab + lu_ab(L, gl, 0, 0);
@@ -1398,7 +1399,7 @@ solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, 
         pp[slot] = *pv_ptr;
         // raw values only: whether an entry is used is decided when the row is consumed (touching the value here
         // would make the wave wait for the load it has just issued)
-        pm[slot] = aw_ptr[dc * aw_rs + (lu_eoff(L, kd - dc) - kd_off)];      // (row jj + dc, column jj)
+        pm[slot] = aw_ptr[dc * aw_step - pk63 * (dc & 1)];    // (row jj + dc, column jj); the diagonal's raw entry is even
 #pragma unroll
         for (int rb = 0; rb < NBT; ++rb) pab[slot][rb] = ab_ptr[(rb < nb ? rb : 0) << 6];
         const int nxt = jj + kl + 1;
@@ -1504,8 +1505,7 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     double2 py[COOP_D];
     // issue() is called for jj = n - 1, n - 2, ...: running pointers (see the forward kernel)
     const long aw_rs = (long)L.BW * 64;
-    const int kd = kl + L.kpad;
-    const long kd_off = lu_eoff(L, kd);
+    const int pk63 = L.pk63;
     const E *u_ptr = Aw + lu_aw(L, gl, n - 1, kl);
     const double2 *y_ptr = L.scratch + (long)(n - 1) * G + g;
     auto issue = [&](int jj, int slot) {                  // branch-free
@@ -1515,7 +1515,8 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             const int d = 1 + e + CB * t;
-            pu[slot][t] = u_ptr[lu_eoff(L, kd + (d <= W ? d : 0)) - kd_off];   // raw; entries beyond the band are dropped at use
+            const int dd = (d <= W) ? d : 0;
+            pu[slot][t] = u_ptr[(dd << 6) - pk63 * (dd & 1)];       // raw; entries beyond the band are dropped at use
         }
         const bool adv = jj > 0;
         u_ptr -= adv ? aw_rs : 0;
@@ -2125,7 +2126,8 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
             d.kpad = forward_window(kl) - kl;                       // the diagonal lands on an even entry (12 or 16)
             d.BW = d.kpad + kl + backward_window(W) + 1;
             d.BW += d.BW & 1;
-            d.pk = 1;
+            d.pk = 1;       // (neutral for the cooperative sweeps: 2-D RB 512 x 256 steps at 560 steps/s either way)
+            d.pk63 = 63;
         }
         d.real = real ? 1 : 0;
         d.GL = (long)GL;
