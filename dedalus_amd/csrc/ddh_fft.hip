@@ -719,34 +719,9 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                 io.store(dst, M, k, q0 + b, c);
             }
         } else {
-            // coefficients in the family's own basis first, IN the transform buffer (slots k and N - k depend on the FFT
-            // outputs k and N - k only: pairwise in place, no staging buffer, the tile is as large as the plain
-            // transform's), then the banded conversion reads them from there.
-            const int KH = N / 2 + 1;
-            for (int w = tid; w < KH * B; w += T) {
-                const int b = w / KH, k = w - b * KH;
-                double2 *line = buf + b * ld;
-                const int kr = N - k;
-                const double2 z1 = line[lpad(k)], z2 = line[lpad((k == 0) ? 0 : kr)];
-                double2 c1 = make_double2(0.0, 0.0), c2 = c1;
-                if (k < Mk) {
-                    const double2 h = half_of(k);
-                    const double s = fscale_of(k);
-                    c1.x = s * ((z1.x + z2.x) * h.x - (z1.y - z2.y) * h.y);
-                    c1.y = s * ((z1.y + z2.y) * h.x - (z2.x - z1.x) * h.y);
-                }
-                const bool partner = (k > 0 && kr != k);
-                if (partner && kr < Mk) {                     // the roles of the two FFT outputs swap
-                    const double2 h = half_of(kr);
-                    const double s = fscale_of(kr);
-                    c2.x = s * ((z2.x + z1.x) * h.x - (z2.y - z1.y) * h.y);
-                    c2.y = s * ((z2.y + z1.y) * h.x - (z1.x - z2.x) * h.y);
-                }
-                line[lpad(k)] = c1;
-                if (partner) line[lpad(kr)] = c2;
-            }
-            __syncthreads();
-            // forward_conversion apply (transforms.py:862-874): c'_k = sum_d C[k,k+off_d] c_{k+off_d}
+            // forward_conversion apply (transforms.py:862-874): c'_k = sum_d C[k, k + off_d] c_(k + off_d), with every
+            // coefficient c_j of the family's own basis formed on the fly from the FFT outputs j and N - j (a few more
+            // LDS reads per output instead of a staging pass over the tile and a barrier)
             for (int w = tid; w < M * B; w += T) {
                 int k, b;
                 split_item<INNER>(w, p.fdB, p.fdM, k, b);
@@ -757,9 +732,11 @@ fft_axis_kernel(FftDev p, const double *__restrict__ src, double *__restrict__ d
                     const int kk = k + p.boff[d];
                     if (kk < Mk) {
                         const double a = p.bands[d * M + k];
-                        const double2 cv = line[lpad(kk)];
-                        acc.x += a * cv.x;
-                        acc.y += a * cv.y;
+                        const double2 z1 = line[lpad(kk)], z2 = line[lpad((kk == 0) ? 0 : N - kk)];
+                        const double2 h = half_of(kk);
+                        const double sc = a * fscale_of(kk);
+                        acc.x += sc * ((z1.x + z2.x) * h.x - (z1.y - z2.y) * h.y);
+                        acc.y += sc * ((z1.y + z2.y) * h.x - (z2.x - z1.x) * h.y);
                     }
                 }
                 io.store(dst, M, k, q0 + b, acc);
