@@ -1196,6 +1196,11 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     static const int envB = getenv("DDH_FFT_B") ? atoi(getenv("DDH_FFT_B")) : 0;
     static const long lds_cap = getenv("DDH_FFT_LDSCAP") ? atol(getenv("DDH_FFT_LDSCAP")) : 64 * 1024;
     int B = inner_mode ? 8 : 4;      // strided: 128-byte contiguous segments per row when LDS allows
+    if (!inner_mode) {
+        // contiguous SHORT lines (the shell's radial transforms: 192 <- 128): 4 line pairs are a tile of a few KiB, the
+        // workgroup's fixed costs (twiddle tables, barriers) dominate -- up to 16 pairs while a thread keeps <= 12 items
+        while (B < 16 && (long)N * (2 * B) <= 12L * 256) B *= 2;
+    }
     if (envB > 0) B = envB;
     while (B > 1 && (long)(per_line * B) > lds_cap) B /= 2;
     if ((long)B > npairs) B = (int)npairs;
