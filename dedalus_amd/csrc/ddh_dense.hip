@@ -296,25 +296,31 @@ int ddh_dense_inverse_compute(ddh_handle h, double a, double b, double *out_d, i
     DDH_HIP(hipMemsetAsync(p->d_flags, 0, (size_t)p->nsys * sizeof(int), s));
     int nmax = 0;
     for (int v : p->n_host) nmax = v > nmax ? v : nmax;
-    if (p->cx) {
-        constexpr int BS = 4;
-        const size_t lds = (size_t)(2 * BS + 1) * nmax * sizeof(double2);
-        auto kern = dense_inverse_kernel<true, BS>;
-        DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)p->nsys), dim3(DI_T), lds, s, (const DenseSys *)p->d_sys,
-                           p->d_M, p->d_L, a, b, (const unsigned char *)p->d_rv, (const unsigned char *)p->d_cv,
-                           (const long *)p->d_voff, (const int *)p->d_pr, (const int *)p->d_pc, (void *)out_d,
-                           (int *)p->d_flags);
-    } else {
-        constexpr int BS = 8;
-        const size_t lds = (size_t)(2 * BS + 1) * nmax * sizeof(double);
-        auto kern = dense_inverse_kernel<false, BS>;
-        DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)p->nsys), dim3(DI_T), lds, s, (const DenseSys *)p->d_sys,
-                           p->d_M, p->d_L, a, b, (const unsigned char *)p->d_rv, (const unsigned char *)p->d_cv,
-                           (const long *)p->d_voff, (const int *)p->d_pr, (const int *)p->d_pc, (void *)out_d,
-                           (int *)p->d_flags);
+    // block size: as many pending rank-1 updates as the LDS holds ((2 BS + 1) n elements) -- the matrix streams through
+    // memory n / BS times, and that stream is what a system costs
+#define DDH_DI_LAUNCH(CXV, BSV, ELT)                                                                                   \
+    {                                                                                                                  \
+        const size_t lds = (size_t)(2 * BSV + 1) * nmax * sizeof(ELT);                                                 \
+        auto kern = dense_inverse_kernel<CXV, BSV>;                                                                    \
+        DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+        hipLaunchKernelGGL(kern, dim3((unsigned)p->nsys), dim3(DI_T), lds, s, (const DenseSys *)p->d_sys, p->d_M,      \
+                           p->d_L, a, b, (const unsigned char *)p->d_rv, (const unsigned char *)p->d_cv,               \
+                           (const long *)p->d_voff, (const int *)p->d_pr, (const int *)p->d_pc, (void *)out_d,         \
+                           (int *)p->d_flags);                                                                         \
     }
+    const size_t budget = 150 * 1024;      // of the CU's 160 KiB (the kernel keeps ~5 KiB of static arrays)
+    static const int bs_env = getenv("DDH_DENSE_BS") ? atoi(getenv("DDH_DENSE_BS")) : 0;
+    if (p->cx) {
+        // (5 instead of 4 pending updates fit for n <= 870 and were measured on the sphere's 256 systems: no change,
+        // 195 ms -- there the largest systems, one workgroup each, set the time)
+        DDH_DI_LAUNCH(true, 4, double2)
+    } else {
+        int bs = 8;
+        if ((size_t)(2 * 12 + 1) * nmax * sizeof(double) <= budget) bs = 12;
+        if (bs_env) bs = bs_env;
+        if (bs == 12) DDH_DI_LAUNCH(false, 12, double) else DDH_DI_LAUNCH(false, 8, double)
+    }
+#undef DDH_DI_LAUNCH
     DDH_HIP(hipGetLastError());
     if (nsingular_h) {
         std::vector<int> f(p->nsys);
