@@ -169,7 +169,40 @@ dense_inverse_kernel(const DenseSys *__restrict__ sys, const void *__restrict__ 
             E r[BS];
 #pragma unroll
             for (int t = 0; t < BS; ++t) r[t] = (t >= t0 && t < nb) ? sR[(size_t)t * n + j] : O::zero();
-            for (int i = 0; i < n; ++i) {
+            // Rows in batches of RB, software-pipelined over two register sets: the loads of batch b + 1 are issued BEFORE
+            // batch b is updated and stored.  (Row by row a thread had one load in flight -- a store followed by the next
+            // row's load may alias for all the compiler knows; and loads wait in order behind earlier stores: with the
+            // next batch's loads issued first, waiting for a batch never waits for a store acknowledgement.)  One
+            // workgroup streams its matrix n / BS times: this loop is the cost of a system.
+            constexpr int RB = 8;
+            auto fetch = [&](int i0, E *v) {          // unconditional loads (straight-line code: exact vmcnt waits) ...
+#pragma unroll
+                for (int q = 0; q < RB; ++q) v[q] = A[(long)(i0 + q) * n + j];
+            };
+            auto finish = [&](int i0, E *v) {         // ... the replaced columns start from the unit vector instead
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    if (repl) v[q] = (i0 + q == j) ? O::one() : O::zero();
+#pragma unroll
+                    for (int t = 0; t < BS; ++t) v[q] = O::fms(v[q], sU[(size_t)t * n + i0 + q], r[t]);
+                }
+#pragma unroll
+                for (int q = 0; q < RB; ++q) A[(long)(i0 + q) * n + j] = v[q];
+            };
+            E va[RB], vb[RB];
+            int i = 0;
+            const int nfull = n / RB;            // full batches
+            if (nfull > 0) fetch(0, va);
+            int bidx = 0;
+            for (; bidx + 1 < nfull; bidx += 2) {
+                fetch((bidx + 1) * RB, vb);
+                finish(bidx * RB, va);
+                if (bidx + 2 < nfull) fetch((bidx + 2) * RB, va);
+                finish((bidx + 1) * RB, vb);
+            }
+            if (bidx < nfull) finish(bidx * RB, va);
+            i = nfull * RB;
+            for (; i < n; ++i) {
                 E v = repl ? ((i == j) ? O::one() : O::zero()) : A[(long)i * n + j];
 #pragma unroll
                 for (int t = 0; t < BS; ++t) v = O::fms(v, sU[(size_t)t * n + i], r[t]);
