@@ -565,6 +565,11 @@ class Evaluator:
         want = getattr(self, "_dual_want", None)
         if want is None:
             want = self._dual_want = {}
+        done = self.__dict__.setdefault("_dual_planned", set())
+        gkey = tuple(id(x) for x in operands)
+        if gkey in done:                 # the expression graph is static: planned once per group of operands
+            return
+        done.add(gkey)
         tr = self.dist.transformer
         plain, derived = set(), {}
         for x in operands:
