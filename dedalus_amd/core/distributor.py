@@ -185,12 +185,20 @@ class Transformer:
         self.dist = dist
 
     def _steps(self, domain, scales):
-        """[(storage position, basis, plan_spec)] for axes that carry a basis."""
+        """[(storage position, basis, plan_spec)] for axes that carry a basis (cached: asked dozens of times per step)."""
+        cache = self.__dict__.setdefault("_steps_cache", {})
+        key = (id(domain), tuple(scales))
+        hit = cache.get(key)
+        if hit is not None and hit[0] is domain:
+            return hit[1]
         steps = []
         for pos, ax in enumerate(self.dist.storage_order):
             b = domain.by_axis[ax]
             if b is not None:
                 steps.append((pos, b, b.plan_spec(scales[ax])))
+        if len(cache) > 256:
+            cache.clear()
+        cache[key] = (domain, steps)
         return steps
 
     def backward(self, field, c, g, scales):
