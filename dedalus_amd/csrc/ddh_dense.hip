@@ -22,6 +22,7 @@ template <> struct DEl<false> {
     static __device__ __forceinline__ T neg(T a) { return -a; }
     static __device__ __forceinline__ T fms(T c, T a, T b) { return c - a * b; }
     static __device__ __forceinline__ T comb(T m, T l, double a, double b) { return a * m + b * l; }
+    static __device__ __forceinline__ T lane_value(T x, int l);
 };
 template <> struct DEl<true> {
     typedef double2 T;
@@ -40,7 +41,18 @@ template <> struct DEl<true> {
     static __device__ __forceinline__ T comb(T m, T l, double a, double b) {
         return make_double2(a * m.x + b * l.x, a * m.y + b * l.y);
     }
+    static __device__ __forceinline__ T lane_value(T x, int l);
 };
+
+// the value a given lane of the wavefront holds, through the scalar unit (l uniform)
+__device__ __forceinline__ double lane_double(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
+__device__ __forceinline__ double DEl<false>::lane_value(double x, int l) { return lane_double(x, l); }
+__device__ __forceinline__ double2 DEl<true>::lane_value(double2 x, int l) {
+    return make_double2(lane_double(x.x, l), lane_double(x.y, l));
+}
 
 constexpr int DI_T = 1024;       // threads per system
 constexpr int DI_NMAX = 1024;    // largest system
@@ -162,51 +174,103 @@ dense_inverse_kernel(const DenseSys *__restrict__ sys, const void *__restrict__ 
             }
             __syncthreads();
         }
-        // ---- one pass over the matrix: rank-nb update; thread = column, pending r values in registers
-        for (int j = tid; j < n; j += DI_T) {
-            const bool repl = (j >= k0 && j < k0 + nb);
-            const int t0 = repl ? j - k0 : 0;
-            E r[BS];
-#pragma unroll
-            for (int t = 0; t < BS; ++t) r[t] = (t >= t0 && t < nb) ? sR[(size_t)t * n + j] : O::zero();
-            // Rows in batches of RB, software-pipelined over two register sets: the loads of batch b + 1 are issued BEFORE
-            // batch b is updated and stored.  (Row by row a thread had one load in flight -- a store followed by the next
-            // row's load may alias for all the compiler knows; and loads wait in order behind earlier stores: with the
-            // next batch's loads issued first, waiting for a batch never waits for a store acknowledgement.)  One
-            // workgroup streams its matrix n / BS times: this loop is the cost of a system.
-            constexpr int RB = 8;
-            auto fetch = [&](int i0, E *v) {          // unconditional loads (straight-line code: exact vmcnt waits) ...
-#pragma unroll
-                for (int q = 0; q < RB; ++q) v[q] = A[(long)(i0 + q) * n + j];
-            };
-            auto finish = [&](int i0, E *v) {         // ... the replaced columns start from the unit vector instead
-#pragma unroll
-                for (int q = 0; q < RB; ++q) {
-                    if (repl) v[q] = (i0 + q == j) ? O::one() : O::zero();
-#pragma unroll
-                    for (int t = 0; t < BS; ++t) v[q] = O::fms(v[q], sU[(size_t)t * n + i0 + q], r[t]);
+        if constexpr (CX) {
+            // ---- one pass over the matrix: rank-nb update; thread = column (n <= DI_T), pending r values in registers.
+            // One workgroup streams its matrix n / BS times and does n^2 (row, pending update) steps per thread: this loop is
+            // the cost of a system.  The u value of a step is the same for every thread; read from LDS per step it was
+            // the bottleneck of the COMPLEX systems (765 x 765: 194 ms, 136 ms with 64-bit instead of 128-bit reads, 93 ms now;
+            // real systems read 64-bit values, for them the LDS broadcast is the cheaper way: 11 vs 24 ms at 640 x 640).  Each lane
+            // reads the u values of ONE row of a 64-row chunk instead (conflict free, one read per 64 rows) and the value of a
+            // row is broadcast from that lane's register through the scalar unit (v_readlane).  Rows go in batches of RB whose
+            // loads are issued before the first store of the batch (a store followed by the next row's load may alias for all
+            // the compiler knows: one load in flight per thread otherwise).
+            if ((tid & ~63) < n) {                  // wavefronts without a column leave; the others keep all lanes (readlane)
+                const int j = tid;
+                const bool act = j < n;
+                const int jc = act ? j : n - 1;     // lanes beyond the last column shadow it and never store
+                const bool repl = (jc >= k0 && jc < k0 + nb);
+                const int t0 = repl ? jc - k0 : 0;
+                E r[BS];
+    #pragma unroll
+                for (int t = 0; t < BS; ++t) r[t] = (t >= t0 && t < nb) ? sR[(size_t)t * n + jc] : O::zero();
+                constexpr int RB = 8;
+                const int lane = tid & 63;
+                for (int c0 = 0; c0 < n; c0 += 64) {
+                    E ul[BS];
+    #pragma unroll
+                    for (int t = 0; t < BS; ++t) ul[t] = (c0 + lane < n) ? sU[(size_t)t * n + c0 + lane] : O::zero();
+                    const int rows = (n - c0 < 64) ? n - c0 : 64;
+                    int q0 = 0;
+                    for (; q0 + RB <= rows; q0 += RB) {
+                        E v[RB];
+    #pragma unroll
+                        for (int q = 0; q < RB; ++q) v[q] = A[(long)(c0 + q0 + q) * n + jc];
+    #pragma unroll
+                        for (int q = 0; q < RB; ++q) {
+                            if (repl) v[q] = (c0 + q0 + q == jc) ? O::one() : O::zero();
+    #pragma unroll
+                            for (int t = 0; t < BS; ++t) v[q] = O::fms(v[q], O::lane_value(ul[t], q0 + q), r[t]);
+                        }
+                        if (act) {
+    #pragma unroll
+                            for (int q = 0; q < RB; ++q) A[(long)(c0 + q0 + q) * n + jc] = v[q];
+                        }
+                    }
+                    for (; q0 < rows; ++q0) {
+                        E v = repl ? ((c0 + q0 == jc) ? O::one() : O::zero()) : A[(long)(c0 + q0) * n + jc];
+    #pragma unroll
+                        for (int t = 0; t < BS; ++t) v = O::fms(v, O::lane_value(ul[t], q0), r[t]);
+                        if (act) A[(long)(c0 + q0) * n + jc] = v;
+                    }
                 }
-#pragma unroll
-                for (int q = 0; q < RB; ++q) A[(long)(i0 + q) * n + j] = v[q];
-            };
-            E va[RB], vb[RB];
-            int i = 0;
-            const int nfull = n / RB;            // full batches
-            if (nfull > 0) fetch(0, va);
-            int bidx = 0;
-            for (; bidx + 1 < nfull; bidx += 2) {
-                fetch((bidx + 1) * RB, vb);
-                finish(bidx * RB, va);
-                if (bidx + 2 < nfull) fetch((bidx + 2) * RB, va);
-                finish((bidx + 1) * RB, vb);
             }
-            if (bidx < nfull) finish(bidx * RB, va);
-            i = nfull * RB;
-            for (; i < n; ++i) {
-                E v = repl ? ((i == j) ? O::one() : O::zero()) : A[(long)i * n + j];
-#pragma unroll
-                for (int t = 0; t < BS; ++t) v = O::fms(v, sU[(size_t)t * n + i], r[t]);
-                A[(long)i * n + j] = v;
+        } else {
+            // ---- one pass over the matrix: rank-nb update; thread = column, pending r values in registers
+            for (int j = tid; j < n; j += DI_T) {
+                const bool repl = (j >= k0 && j < k0 + nb);
+                const int t0 = repl ? j - k0 : 0;
+                E r[BS];
+    #pragma unroll
+                for (int t = 0; t < BS; ++t) r[t] = (t >= t0 && t < nb) ? sR[(size_t)t * n + j] : O::zero();
+                // Rows in batches of RB, software-pipelined over two register sets: the loads of batch b + 1 are issued BEFORE
+                // batch b is updated and stored.  (Row by row a thread had one load in flight -- a store followed by the next
+                // row's load may alias for all the compiler knows; and loads wait in order behind earlier stores: with the
+                // next batch's loads issued first, waiting for a batch never waits for a store acknowledgement.)  One
+                // workgroup streams its matrix n / BS times: this loop is the cost of a system.
+                constexpr int RB = 8;
+                auto fetch = [&](int i0, E *v) {          // unconditional loads (straight-line code: exact vmcnt waits) ...
+    #pragma unroll
+                    for (int q = 0; q < RB; ++q) v[q] = A[(long)(i0 + q) * n + j];
+                };
+                auto finish = [&](int i0, E *v) {         // ... the replaced columns start from the unit vector instead
+    #pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+                        if (repl) v[q] = (i0 + q == j) ? O::one() : O::zero();
+    #pragma unroll
+                        for (int t = 0; t < BS; ++t) v[q] = O::fms(v[q], sU[(size_t)t * n + i0 + q], r[t]);
+                    }
+    #pragma unroll
+                    for (int q = 0; q < RB; ++q) A[(long)(i0 + q) * n + j] = v[q];
+                };
+                E va[RB], vb[RB];
+                int i = 0;
+                const int nfull = n / RB;            // full batches
+                if (nfull > 0) fetch(0, va);
+                int bidx = 0;
+                for (; bidx + 1 < nfull; bidx += 2) {
+                    fetch((bidx + 1) * RB, vb);
+                    finish(bidx * RB, va);
+                    if (bidx + 2 < nfull) fetch((bidx + 2) * RB, va);
+                    finish((bidx + 1) * RB, vb);
+                }
+                if (bidx < nfull) finish(bidx * RB, va);
+                i = nfull * RB;
+                for (; i < n; ++i) {
+                    E v = repl ? ((i == j) ? O::one() : O::zero()) : A[(long)i * n + j];
+    #pragma unroll
+                    for (int t = 0; t < BS; ++t) v = O::fms(v, sU[(size_t)t * n + i], r[t]);
+                    A[(long)i * n + j] = v;
+                }
             }
         }
         __syncthreads();
