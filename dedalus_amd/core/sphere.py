@@ -1227,7 +1227,7 @@ class SphereSolverBase:
 
     _dinv = None
 
-    def _inverse_batch(self, a, b):
+    def _inverse_batch(self, a, b, old=None):
         """Per-m inverse of (a M + b L) restricted to the valid modes, embedded with zeros elsewhere: formed and
         inverted on the device (executor.make_dense_inverse; M_m, L_m are uploaded once) and applied as one batched
         complex GEMV."""
@@ -1251,7 +1251,7 @@ class SphereSolverBase:
                 rvs.append(rv)
                 cvs.append(cv)
             self._dinv = self.ex.make_dense_inverse(Ms, Ls, rvs, cvs, complex_=True)
-        return self.ex.make_cgemv_batch_flat(nm, nl, self.R, self._dinv.compute(a, b))
+        return self.ex.make_cgemv_batch_flat(nm, nl, self.R, self._dinv.compute(a, b), old=old)
 
     def evaluate_F(self, out):
         ex = self.ex
@@ -1322,7 +1322,8 @@ class SphereInitialValueSolver(IVPLifecycle, SphereSolverBase):
 
     # interface used by the shared timesteppers ------------------------------------------------------------------
     def factor(self, a, b, reuse=-1):
-        inv = self._inverse_batch(a, b)
+        prev = self._lus[reuse] if (reuse is not None and 0 <= reuse < len(self._lus)) else None
+        inv = self._inverse_batch(a, b, old=prev)
         if not hasattr(self, "_lu_params"):
             self._lu_params = {}
         if reuse is not None and reuse >= 0:

@@ -324,9 +324,12 @@ class HipExecutor:
         -> object with compute(a, b): concatenated (a M + b L)^-1 on the valid blocks, on the device."""
         return DenseInverse(self, Ms, Ls, row_valid, col_valid, complex_)
 
-    def make_cgemv_batch_flat(self, nm, nl, ncomp, flat):
-        """per-m complex matrices given as one concatenated device array (DenseInverse.compute)"""
-        batch = CgemvBatch(self, nm, nl, ncomp, None)
+    def make_cgemv_batch_flat(self, nm, nl, ncomp, flat, old=None):
+        """per-m complex matrices given as one concatenated device array (DenseInverse.compute); old: a batch of the same
+        shape to refill (a change of the timestep then allocates and frees nothing)"""
+        same = isinstance(old, CgemvBatch) and getattr(old, "shape", None) == (nm, nl, ncomp)
+        batch = old if same else CgemvBatch(self, nm, nl, ncomp, None)
+        batch.shape = (nm, nl, ncomp)
         dst = C.c_void_p()
         libhip.call("ddh_cgemv_batch_mats", batch.handle, C.byref(dst))
         libhip.call("ddh_memcpy_d2d", dst, ptr(flat), int(flat.numel()) * 8, self.dev.stream)

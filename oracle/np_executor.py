@@ -352,7 +352,7 @@ class NumpyExecutor:
                 return outs
         return _Inv()
 
-    def make_cgemv_batch_flat(self, nm, nl, ncomp, mats):
+    def make_cgemv_batch_flat(self, nm, nl, ncomp, mats, old=None):
         return self.make_cgemv_batch(nm, nl, ncomp, mats)
 
     def make_ell_terms_from_dense(self, nm, nl, nr, ncomp, mats, old=None):
