@@ -1729,17 +1729,14 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     bool lean_fwd = false;
     if constexpr (NF == 2) {
         static const int no_lean = getenv("DDH_FWD_LEAN") ? !atoi(getenv("DDH_FWD_LEAN")) : 0;
-        // (the widest combination, kl > 12 with a border > 2, does not fit two waves per SIMD: general kernel)
+        // (instantiated and tested for the window of the Rayleigh-Benard pencils: kl <= 12, a border of <= 2; other shapes
+        // take the general kernel -- the wider instantiations fit two waves per SIMD only partly and have no test yet)
         lean_fwd = !use_fwd && d.real && d.n > 0 && !no_lean && d.kpad + d.kl == forward_window(d.kl) &&
-                   d.rows_aw >= d.n + forward_window(d.kl) && (d.kl <= 12 || d.nb <= 2);
+                   d.rows_aw >= d.n + forward_window(d.kl) && d.kl <= 12 && d.nb <= 2;
         if (lean_fwd) {
 #define DDH_LFWD(KLTV, NBTV) \
     hipLaunchKernelGGL((solve_forward_lean_kernel<KLTV, NBTV>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x);
-            if (d.nb <= 2) {
-                if (d.kl <= 12) DDH_LFWD(12, 2) else DDH_LFWD(16, 2)
-            } else {
-                DDH_LFWD(12, 8)
-            }
+            DDH_LFWD(12, 2)
 #undef DDH_LFWD
         }
     }
