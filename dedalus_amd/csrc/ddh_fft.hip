@@ -985,6 +985,9 @@ fused_rfft_bilinear_kernel(FftDev p, FusedArgs f, long nlines, long npairs) {
         for (int i = 0; i < 4; ++i) atomicAdd(&p.prof[i], (unsigned long long)pt[i]);
 }
 
+// ddh_fftwave.hip: wave-per-four-pairs transforms along a strided axis; 0 = launched, 1 = shape not covered, < 0 error
+int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, long outer, long inner, double *dst2,
+                  const double *dvec, hipStream_t st);
 // ddh_gridwave.hip: wave-per-line variant of the fused grid stage for N = 128*C
 bool gridwave_supported(const FftDev &d);
 int launch_gridwave(const FftDev &d, const FusedArgs &f, long nlines, hipStream_t st);
@@ -1184,6 +1187,11 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     d.dvec = dvec;
     const bool is_cfft = (MODE == CFFT_FWD || MODE == CFFT_BWD);
     const bool inner_mode = inner > 1;
+    if ((MODE == CHEB_FWD || MODE == CHEB_BWD) && inner_mode) {
+        // strided axis at an instantiated size: one wavefront per four line pairs (ddh_fftwave.hip)
+        const int wst = wave_axis_try(MODE, d, src, dst, outer, inner, dst2, dvec, as_stream(stream));
+        if (wst <= 0) return wst;
+    }
     long npairs;
     if (is_cfft)
         npairs = inner_mode ? inner : outer;

@@ -1,0 +1,180 @@
+// Strided-axis Chebyshev transforms, one wavefront per four line pairs (ddh_wavefft.h): kernels and launch.
+//
+// A workgroup is 8 independent wavefronts that share the read-only tables in LDS (twiddles, half-angle factors,
+// conversion bands / back-substitution table / derivative vector) and nothing else: no workgroup barrier after the
+// table fill.  At step i the 8 waves of workgroup g work on 8 neighbouring tiles (512 contiguous bytes per row) and a
+// wave requests the coefficient rows of its next tile while it transforms the current one.
+// Replaces core/transforms.py:715-902 for the strided z axis (the reference: scipy DCT + scale / pad / conversion passes).
+#include "ddh_fft_dev.h"
+#include "ddh_wavefft.h"
+
+#include <cstdlib>
+
+namespace ddh {
+
+constexpr int WV_WAVES = 8;
+
+struct WaveArgs {
+    const double *src;
+    double *dst, *dst2;
+    long inner, npairs;
+    FastDiv fd_tpo;          // tiles per outer index
+    unsigned ntiles, tpw;    // tiles in all, tiles per wave
+    int kind;                // backward: 0 plain, 1 dual (plain + derivative pass), 2 conversion solve
+};
+
+template <int KIND, int R, int NL, int CH>      // KIND: 0 backward plain, 1 backward dual, 2 backward conversion, 3 forward
+__global__ void __launch_bounds__(64 * WV_WAVES, 2)
+wave_cheb_kernel(FftDev p, WaveArgs a) {
+    constexpr bool FWD = (KIND == 3);
+    extern __shared__ double2 lds[];
+    constexpr int N = 16 * R;
+    const int M = p.M, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: tile bases live in scalar registers
+    double2 *s_tw = lds, *s_half = lds + N;
+    double *s_d = reinterpret_cast<double *>(lds + 2 * N);
+    // doubles: forward [nbands][M] bands; backward [2][M] back-substitution table, [M] derivative vector
+    const int nd = FWD ? p.nbands * M : 3 * M;
+    double2 *S = reinterpret_cast<double2 *>(s_d + ((nd + 1) & ~1)) + wave * wf::ChebWaveLds<R, NL, CH>::size;
+    for (int i = tid; i < N; i += 64 * WV_WAVES) {
+        s_tw[i] = p.tw[i];
+        s_half[i] = p.half[i];
+    }
+    if (FWD) {
+        for (int i = tid; i < p.nbands * M; i += 64 * WV_WAVES) s_d[i] = p.bands[i];
+    } else {
+        for (int i = tid; i < 2 * M; i += 64 * WV_WAVES) s_d[i] = p.bsub ? p.bsub[i] : 0.0;
+        for (int i = tid; i < M; i += 64 * WV_WAVES) s_d[2 * M + i] = p.dvec ? p.dvec[i] : 0.0;
+    }
+    __syncthreads();                    // the only workgroup barrier
+    wf::ChebTabs T;
+    T.tw = s_tw;
+    T.half = s_half;
+    T.bands = s_d;
+    T.bsub = s_d;
+    T.dvec = s_d + 2 * M;
+    T.M = M;
+    T.Mk = 16 * NL;
+    T.nbands = p.nbands;
+    T.gcd_off = p.gcd_off;
+    { T.boff1 = p.boff[1]; T.boff2 = p.boff[2]; T.boff3 = p.boff[3]; }
+    const double kSqPi = 1.7724538509055160272981674833411, kSqPi2 = 1.2533141373155002512078826424055;
+    T.fs0 = kSqPi / (2.0 * (double)N);
+    T.fs1 = kSqPi2 / (double)N;
+    T.bs0 = 1.0 / kSqPi;
+    T.bs1 = 0.5 / kSqPi2;
+    const wf::Lane L = wf::make_lane(lane);
+    const unsigned g = xcd_swizzle(blockIdx.x, gridDim.x);
+    const long inner = a.inner;
+    const unsigned rsb = (unsigned)(inner * 8);                       // bytes between rows
+    // i-th tile of this wave
+    auto tile_of = [&](unsigned i) -> unsigned { return (g * a.tpw + i) * WV_WAVES + wave; };
+    auto locate = [&](unsigned tile, long &off_c, long &off_g, bool &valid) {
+        unsigned o, tb;
+        a.fd_tpo.divmod(tile, o, tb);
+        const long pair0 = 4L * tb;
+        off_c = ((long)o * M) * inner + 2 * pair0;
+        off_g = ((long)o * N) * inner + 2 * pair0;
+        valid = pair0 + L.p < a.npairs;
+    };
+    if (tile_of(0) >= a.ntiles) return;
+    if (FWD) {
+        for (unsigned i = 0; i < a.tpw; ++i) {
+            const unsigned tile = tile_of(i);
+            if (tile >= a.ntiles) break;
+            long oc, og;
+            bool valid;
+            locate(tile, oc, og, valid);
+            wf::cheb_fwd_tile<R, NL, CH>(a.src + og, a.dst + oc, rsb, valid, S, T, lane);
+        }
+    } else {
+        double2 c[NL];
+        long oc, og;
+        bool valid;
+        locate(tile_of(0), oc, og, valid);
+        wf::cheb_bwd_load<NL>(c, a.src + oc, rsb, valid, L);
+        for (unsigned i = 0; i < a.tpw; ++i) {
+            const unsigned tn = tile_of(i + 1);
+            const bool more = (i + 1 < a.tpw) && (tn < a.ntiles);
+            long ocn = oc, ogn = og;
+            bool validn = valid;
+            if (more) locate(tn, ocn, ogn, validn);
+            const unsigned rsbn = more ? rsb : 0u;
+            if (KIND == 1) {
+                // the plain pass keeps c for the derivative pass
+                wf::cheb_bwd_pass<R, NL, CH, 0, false>(c, S, T, a.dst + og, rsb, valid, lane, a.src + oc, rsb, valid);
+                wf::cheb_bwd_pass<R, NL, CH, 1, true>(c, S, T, a.dst2 + og, rsb, valid, lane, a.src + ocn, rsbn, validn);
+            } else {
+                wf::cheb_bwd_pass<R, NL, CH, (KIND == 2 ? 2 : 0), true>(c, S, T, a.dst + og, rsb, valid, lane, a.src + ocn, rsbn,
+                                                                      validn);
+            }
+            if (!more) break;
+            oc = ocn;
+            og = ogn;
+            valid = validn;
+        }
+    }
+}
+
+template <int KIND, int R, int NL, int CH>
+static int launch_wave_cheb(const FftDev &d, const WaveArgs &a, unsigned nwg, hipStream_t st) {
+    const int N = 16 * R;
+    constexpr bool FWD = (KIND == 3);
+    const int nd = FWD ? d.nbands * d.M : 3 * d.M;
+    const size_t lds = (size_t)2 * N * sizeof(double2) + (size_t)((nd + 1) & ~1) * sizeof(double) +
+                       (size_t)WV_WAVES * wf::ChebWaveLds<R, NL, CH>::size * sizeof(double2);
+    if (lds > 160 * 1024) return 1;
+    auto kern = wave_cheb_kernel<KIND, R, NL, CH>;
+    if (lds > 64 * 1024)
+        DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WV_WAVES), lds, st, d, a);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+// Returns 0 when the transform was launched here, 1 when the shape is not covered (the caller then uses the
+// workgroup-per-tile kernel of ddh_fft.hip), < 0 on error.
+int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, long outer, long inner, double *dst2,
+                  const double *dvec, hipStream_t st) {
+    static const int off = getenv("DDH_FFT_WAVE") ? (atoi(getenv("DDH_FFT_WAVE")) == 0) : 0;
+    static const int env_tpw = getenv("DDH_FFT_TPW") ? atoi(getenv("DDH_FFT_TPW")) : 8;
+    if (off || d.dbg || d.prof) return 1;
+    if (mode != CHEB_FWD && mode != CHEB_BWD) return 1;
+    if (inner < 2 || (inner & 1)) return 1;
+    if (d.N != 384 || d.M != 256) return 1;                     // instantiated sizes (R = 24, 16 rows per lane)
+    const long npairs = inner / 2;
+    const long tpo = (npairs + 3) / 4;
+    const unsigned long ntiles = (unsigned long)tpo * (unsigned long)outer;
+    if (ntiles > 0x7fffffffUL) return 1;
+    if ((unsigned long)d.N * (unsigned long)inner * 8UL >= 0xffffffffUL) return 1;     // 32-bit row offsets inside a tile
+    WaveArgs a;
+    a.src = src;
+    a.dst = dst;
+    a.dst2 = dst2;
+    a.inner = inner;
+    a.npairs = npairs;
+    a.fd_tpo.set((unsigned)tpo);
+    a.ntiles = (unsigned)ntiles;
+    a.kind = 0;
+    FftDev dd = d;
+    dd.dvec = dvec;
+    if (mode == CHEB_BWD) {
+        if (dst2) {
+            if (!(d.bsub && d.bsub_order == 1 && (d.gcd_off == 1 || d.gcd_off == 2) && dvec)) return 1;
+            a.kind = 1;
+        } else if (d.nbands > 0) {
+            if (!(d.bsub && d.bsub_order == 1 && (d.gcd_off == 1 || d.gcd_off == 2))) return 1;
+            a.kind = 2;
+        }
+    }
+    unsigned tpw = (unsigned)(env_tpw > 0 ? env_tpw : 1);
+    while (tpw > 1 && ntiles / ((unsigned long)tpw * WV_WAVES) < 1024) tpw /= 2;   // several rounds of workgroups
+    a.tpw = tpw;
+    const unsigned nwg = (unsigned)((ntiles + (unsigned long)tpw * WV_WAVES - 1) / ((unsigned long)tpw * WV_WAVES));
+    if (mode == CHEB_FWD) return launch_wave_cheb<3, 24, 16, 2>(dd, a, nwg, st);
+    if (a.kind == 1) return launch_wave_cheb<1, 24, 16, 2>(dd, a, nwg, st);
+    if (a.kind == 2) return launch_wave_cheb<2, 24, 16, 2>(dd, a, nwg, st);
+    return launch_wave_cheb<0, 24, 16, 2>(dd, a, nwg, st);
+}
+
+}  // namespace ddh

@@ -1,0 +1,174 @@
+// Host emulation of the wave-level strided transforms (dedalus_amd/csrc/ddh_wavefft.h): the SAME lane code the GPU
+// kernels run, compiled with g++; the 64 lanes of a wavefront are 64 threads, WF_SYNC is a barrier and the LDS is a
+// shared array.  Test infrastructure only (tests/test_host_emu_wavefft.py): checks index maps and arithmetic of the
+// kernels against the numpy oracle without a GPU.
+#define DDH_HOST_EMU
+#include <pthread.h>
+
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../dedalus_amd/csrc/ddh_wavefft.h"
+
+static pthread_barrier_t g_bar;
+static double g_shfl[64];
+
+namespace ddh {
+namespace wf {
+void emu_barrier() { pthread_barrier_wait(&g_bar); }
+double emu_shfl_up(double v, int delta, int lane) {
+    g_shfl[lane] = v;
+    pthread_barrier_wait(&g_bar);
+    const double r = (lane - delta >= 0) ? g_shfl[lane - delta] : v;
+    pthread_barrier_wait(&g_bar);
+    return r;
+}
+}  // namespace wf
+}  // namespace ddh
+
+using namespace ddh;
+using namespace ddh::wf;
+
+struct EmuTabs {
+    const double *tw, *half;      // [N][2]
+    const double *bands;          // [nbands][M]
+    const double *bsub;           // [2][M]
+    const double *dvec;           // [M]
+    int M, nbands, gcd_off;
+    int boff[4];
+};
+
+static ChebTabs make_tabs(const EmuTabs &e, int N, int Mk) {
+    ChebTabs T;
+    T.tw = reinterpret_cast<const double2 *>(e.tw);
+    T.half = reinterpret_cast<const double2 *>(e.half);
+    T.bands = e.bands;
+    T.bsub = e.bsub;
+    T.dvec = e.dvec;
+    T.M = e.M;
+    T.Mk = Mk;
+    T.nbands = e.nbands;
+    T.gcd_off = e.gcd_off;
+    T.boff1 = e.boff[1]; T.boff2 = e.boff[2]; T.boff3 = e.boff[3];
+    const double kSqPi = 1.7724538509055160272981674833411, kSqPi2 = 1.2533141373155002512078826424055;
+    T.fs0 = kSqPi / (2.0 * (double)N);
+    T.fs1 = kSqPi2 / (double)N;
+    T.bs0 = 1.0 / kSqPi;
+    T.bs1 = 0.5 / kSqPi2;
+    return T;
+}
+
+template <typename F>
+static void run_wave(F body) {
+    pthread_barrier_init(&g_bar, nullptr, 64);
+    std::vector<std::thread> th;
+    for (int lane = 0; lane < 64; ++lane) th.emplace_back([=]() { body(lane); });
+    for (auto &t : th) t.join();
+    pthread_barrier_destroy(&g_bar);
+}
+
+template <int R, int NL, int CH>
+static void cheb_bwd(const EmuTabs &e, int kind, const double *src, double *dst, double *dst2, long outer, long inner) {
+    constexpr int N = 16 * R;
+    const ChebTabs T = make_tabs(e, N, 16 * NL);
+    const long npairs = inner / 2, tpo = (npairs + 3) / 4, ntiles = tpo * outer;
+    std::vector<double2> S(ChebWaveLds<R, NL, CH>::size);
+    run_wave([&](int lane) {
+        const Lane L = make_lane(lane);
+        double2 c[NL];
+        auto locate = [&](long tile, long &oc, long &og, bool &valid) {
+            const long o = tile / tpo, tb = tile % tpo;
+            oc = (o * e.M) * inner + 8 * tb;
+            og = (o * N) * inner + 8 * tb;
+            valid = 4 * tb + L.p < npairs;
+        };
+        long oc, og;
+        bool valid;
+        locate(0, oc, og, valid);
+        cheb_bwd_load<NL>(c, src + oc, (unsigned)(inner * 8), valid, L);
+        for (long tile = 0; tile < ntiles; ++tile) {
+            const bool more = tile + 1 < ntiles;
+            long ocn = 0, ogn = 0;
+            bool validn = false;
+            if (more) locate(tile + 1, ocn, ogn, validn);
+            const unsigned rsb = (unsigned)(inner * 8);
+            if (!more) { ocn = oc; ogn = og; validn = valid; }
+            const unsigned rsbn = more ? rsb : 0u;
+            if (kind == 1) {
+                cheb_bwd_pass<R, NL, CH, 0, false>(c, S.data(), T, dst + og, rsb, valid, lane, src + oc, rsb, valid);
+                cheb_bwd_pass<R, NL, CH, 1, true>(c, S.data(), T, dst2 + og, rsb, valid, lane, src + ocn, rsbn, validn);
+            } else if (kind == 2) {
+                cheb_bwd_pass<R, NL, CH, 2, true>(c, S.data(), T, dst + og, rsb, valid, lane, src + ocn, rsbn, validn);
+            } else {
+                cheb_bwd_pass<R, NL, CH, 0, true>(c, S.data(), T, dst + og, rsb, valid, lane, src + ocn, rsbn, validn);
+            }
+            oc = ocn;
+            og = ogn;
+            valid = validn;
+        }
+    });
+}
+
+template <int R, int NL, int CH>
+static void cheb_fwd(const EmuTabs &e, const double *src, double *dst, long outer, long inner) {
+    constexpr int N = 16 * R;
+    const ChebTabs T = make_tabs(e, N, 16 * NL);
+    const long npairs = inner / 2, tpo = (npairs + 3) / 4, ntiles = tpo * outer;
+    std::vector<double2> S(ChebWaveLds<R, NL, CH>::size);
+    run_wave([&](int lane) {
+        const Lane L = make_lane(lane);
+        for (long tile = 0; tile < ntiles; ++tile) {
+            const long o = tile / tpo, tb = tile % tpo;
+            const bool valid = 4 * tb + L.p < npairs;
+            cheb_fwd_tile<R, NL, CH>(src + (o * N) * inner + 8 * tb, dst + (o * e.M) * inner + 8 * tb, (unsigned)(inner * 8), valid, S.data(), T, lane);
+        }
+    });
+}
+
+// plain complex FFT of 4 interleaved lines through wfft: x [N][4][2] -> X [N][4][2]
+template <int R, int SIGN, int CH>
+static void fft4(const double *tw, const double *x, double *X) {
+    constexpr int N = 16 * R, RQ = R / 4;
+    std::vector<double2> xb(WfftBuf<R, CH>::size);
+    const double2 *xin = reinterpret_cast<const double2 *>(x);
+    double2 *xout = reinterpret_cast<double2 *>(X);
+    run_wave([&](int lane) {
+        const Lane L = make_lane(lane);
+        double2 v[R];
+        for (int t = 0; t < R; ++t) v[t] = xin[(L.q + 16 * t) * 4 + L.p];
+        wfft<R, SIGN, CH>(v, xb.data(), reinterpret_cast<const double2 *>(tw), L);
+        for (int a0 = 0; a0 < 4; ++a0)
+            for (int i = 0; i < RQ; ++i) xout[(R * (L.q0 + 4 * a0) + RQ * L.q1 + i) * 4 + L.p] = v[a0 * RQ + i];
+        (void)N;
+    });
+}
+
+extern "C" {
+int emu_fft4(int N, int sign, const double *tw, const double *x, double *X) {
+    if (N == 384 && sign < 0) { fft4<24, -1, 2>(tw, x, X); return 0; }
+    if (N == 384 && sign > 0) { fft4<24, +1, 2>(tw, x, X); return 0; }
+    if (N == 256 && sign < 0) { fft4<16, -1, 2>(tw, x, X); return 0; }
+    if (N == 256 && sign > 0) { fft4<16, +1, 2>(tw, x, X); return 0; }
+    if (N == 192 && sign < 0) { fft4<12, -1, 1>(tw, x, X); return 0; }
+    if (N == 192 && sign > 0) { fft4<12, +1, 1>(tw, x, X); return 0; }
+    return 1;
+}
+int emu_cheb_bwd(int N, int M, int kind, const double *tw, const double *half, const double *bsub, const double *dvec,
+                 int gcd_off, const double *src, double *dst, double *dst2, long outer, long inner) {
+    EmuTabs e;
+    memset(&e, 0, sizeof(e));
+    e.tw = tw; e.half = half; e.bsub = bsub; e.dvec = dvec; e.M = M; e.gcd_off = gcd_off;
+    if (N == 384 && M == 256) { cheb_bwd<24, 16, 2>(e, kind, src, dst, dst2, outer, inner); return 0; }
+    return 1;
+}
+int emu_cheb_fwd(int N, int M, const double *tw, const double *half, int nbands, const int *boff, const double *bands,
+                 const double *src, double *dst, long outer, long inner) {
+    EmuTabs e;
+    memset(&e, 0, sizeof(e));
+    e.tw = tw; e.half = half; e.bands = bands; e.M = M; e.nbands = nbands; e.gcd_off = 1;
+    for (int d = 0; d < nbands && d < 4; ++d) e.boff[d] = boff[d];
+    if (N == 384 && M == 256) { cheb_fwd<24, 16, 2>(e, src, dst, outer, inner); return 0; }
+    return 1;
+}
+}

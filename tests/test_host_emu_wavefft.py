@@ -1,0 +1,109 @@
+"""CPU check of the wave-level strided transforms (dedalus_amd/csrc/ddh_wavefft.h): the lane code of the GPU kernels is
+compiled with g++ (tests/host_emu/emu_wavefft.cpp: 64 threads = 64 lanes, LDS = a shared array) and compared with numpy
+FFTs and with the oracle's Chebyshev transforms (reference: core/transforms.py:715-902).  Index maps, exchanges, the
+conversion solve and the arithmetic are thereby verified without a GPU; the GPU tests re-check the compiled kernels."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import np_transforms as npt
+from dedalus_amd.tools import jacobi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("emu") / "libemu_wavefft.so")
+    src = os.path.join(HERE, "host_emu", "emu_wavefft.cpp")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", out, src], check=True)
+    lib = C.CDLL(out)
+    vp, i, l = C.c_void_p, C.c_int, C.c_long
+    lib.emu_fft4.argtypes = [i, i, vp, vp, vp]
+    lib.emu_cheb_bwd.argtypes = [i, i, i, vp, vp, vp, vp, i, vp, vp, vp, l, l]
+    lib.emu_cheb_fwd.argtypes = [i, i, vp, vp, i, vp, vp, vp, vp, l, l]
+    return lib
+
+
+def dp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def tables(N):
+    q = np.arange(N, dtype=np.longdouble)
+    a = -2 * np.pi * q / N
+    h = -np.longdouble(np.pi) * q / (2 * N)
+    tw = np.ascontiguousarray(np.stack([np.cos(a), np.sin(a)], -1).astype(np.float64))
+    half = np.ascontiguousarray(np.stack([np.cos(h), np.sin(h)], -1).astype(np.float64))
+    return tw, half
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def conv_bands(M, alpha):
+    conv = jacobi.conversion_matrix(M, -0.5, -0.5, alpha - 0.5, alpha - 0.5)
+    dense = conv.toarray()
+    offs = np.array([o for o in range(M) if np.any(np.diagonal(dense, o) != 0)], dtype=np.int32)
+    bands = np.zeros((len(offs), M))
+    for d, o in enumerate(offs):
+        bands[d, :M - o] = np.diagonal(dense, o)
+    return conv, offs, bands
+
+
+@pytest.mark.parametrize("N", [384, 256, 192])
+@pytest.mark.parametrize("sign", [-1, 1])
+def test_wave_fft_of_four_interleaved_lines(emu, N, sign):
+    rng = np.random.default_rng(N + sign)
+    tw, _ = tables(N)
+    x = rng.standard_normal((N, 4, 2))
+    X = np.zeros_like(x)
+    assert emu.emu_fft4(N, sign, dp(tw), dp(x), dp(X)) == 0
+    xc = x[..., 0] + 1j * x[..., 1]
+    ref = np.fft.fft(xc, axis=0) if sign < 0 else np.fft.ifft(xc, axis=0) * N
+    assert rel(X[..., 0] + 1j * X[..., 1], ref) < 1e-14
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 12), (1, 256, 2), (3, 256, 10)])
+def test_wave_chebyshev_matches_the_oracle(emu, shape):
+    """whole and partial tiles (inner = 10: five pairs = one full tile + one pair), several outer indices"""
+    N, M = 384, 256
+    outer, _, inner = shape
+    rng = np.random.default_rng(inner)
+    tw, half = tables(N)
+    zero = np.zeros(3 * M)
+    cin = rng.standard_normal(shape) / (1.0 + np.arange(M).reshape(1, -1, 1)) ** 2
+    gs = (outer, N, inner)
+    g = np.full(gs, np.nan)
+    assert emu.emu_cheb_bwd(N, M, 0, dp(tw), dp(half), dp(zero), dp(zero), 1, dp(cin), dp(g), None, outer, inner) == 0
+    assert rel(g, npt.cheb_backward(cin, 1, N, None)) < 1e-14
+    conv, offs, bands = conv_bands(M, 1)
+    assert list(offs) == [0, 2]
+    bsub = np.zeros((2, M))
+    bsub[0] = 1.0 / bands[0]
+    bsub[1, :M - 2] = bands[1, :M - 2] / bands[0, :M - 2]
+    g2 = np.full(gs, np.nan)
+    emu.emu_cheb_bwd(N, M, 2, dp(tw), dp(half), dp(bsub), dp(zero), 2, dp(cin), dp(g2), None, outer, inner)
+    assert rel(g2, npt.cheb_backward(cin, 1, N, conv)) < 1e-13
+    D = jacobi.differentiation_matrix(M, -0.5, -0.5).toarray() * (2.0 / 1.7)
+    dvec = np.zeros(M)
+    dvec[:M - 1] = np.diagonal(D, 1)
+    dc = np.ascontiguousarray(np.moveaxis(np.tensordot(D, np.moveaxis(cin, 1, 0), axes=(1, 0)), 0, 1))
+    ga, gb = np.full(gs, np.nan), np.full(gs, np.nan)
+    emu.emu_cheb_bwd(N, M, 1, dp(tw), dp(half), dp(bsub), dp(dvec), 2, dp(cin), dp(ga), dp(gb), outer, inner)
+    assert np.array_equal(ga, g)                          # the dual's first pass IS the plain pass
+    assert rel(gb, npt.cheb_backward(dc, 1, N, conv)) < 1e-13
+    gin = rng.standard_normal(gs)
+    for alpha in (0, 1, 2):
+        out = np.full(shape, np.nan)
+        if alpha == 0:
+            emu.emu_cheb_fwd(N, M, dp(tw), dp(half), 0, None, None, dp(gin), dp(out), outer, inner)
+            cv = None
+        else:
+            cv, offs, bands = conv_bands(M, alpha)
+            emu.emu_cheb_fwd(N, M, dp(tw), dp(half), len(offs), dp(offs), dp(bands), dp(gin), dp(out), outer, inner)
+        assert rel(out, npt.cheb_forward(gin, 1, M, cv)) < 1e-14
