@@ -987,7 +987,7 @@ fused_rfft_bilinear_kernel(FftDev p, FusedArgs f, long nlines, long npairs) {
 
 // ddh_fftwave.hip: wave-per-four-pairs transforms along a strided axis; 0 = launched, 1 = shape not covered, < 0 error
 int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, long outer, long inner, double *dst2,
-                  const double *dvec, hipStream_t st);
+                  const double *dvec, double dscale, double dscale2, hipStream_t st);
 // ddh_gridwave.hip: wave-per-line variant of the fused grid stage for N = 128*C
 bool gridwave_supported(const FftDev &d);
 int launch_gridwave(const FftDev &d, const FusedArgs &f, long nlines, hipStream_t st);
@@ -1187,9 +1187,9 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     d.dvec = dvec;
     const bool is_cfft = (MODE == CFFT_FWD || MODE == CFFT_BWD);
     const bool inner_mode = inner > 1;
-    if ((MODE == CHEB_FWD || MODE == CHEB_BWD) && inner_mode) {
+    if (!is_cfft && inner_mode) {
         // strided axis at an instantiated size: one wavefront per four line pairs (ddh_fftwave.hip)
-        const int wst = wave_axis_try(MODE, d, src, dst, outer, inner, dst2, dvec, as_stream(stream));
+        const int wst = wave_axis_try(MODE, d, src, dst, outer, inner, dst2, dvec, dscale, dscale2, as_stream(stream));
         if (wst <= 0) return wst;
     }
     long npairs;

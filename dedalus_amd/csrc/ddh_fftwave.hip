@@ -21,6 +21,7 @@ struct WaveArgs {
     FastDiv fd_tpo;          // tiles per outer index
     unsigned ntiles, tpw;    // tiles in all, tiles per wave
     int kind;                // backward: 0 plain, 1 dual (plain + derivative pass), 2 conversion solve
+    int wsync;               // 1: the waves of a workgroup start every tile together (one s_barrier per tile)
 };
 
 template <int KIND, int R, int NL, int CH>      // KIND: 0 backward plain, 1 backward dual, 2 backward conversion, 3 forward
@@ -77,11 +78,16 @@ wave_cheb_kernel(FftDev p, WaveArgs a) {
         off_g = ((long)o * N) * inner + 2 * pair0;
         valid = pair0 + L.p < a.npairs;
     };
-    if (tile_of(0) >= a.ntiles) return;
+    // The 8 waves of the workgroup take 8 neighbouring tiles per step.  With wsync they enter every step together, so
+    // that their row requests (8 x 64 contiguous bytes per row) reach the memory controllers at the same time.
+    const unsigned step0 = g * a.tpw * WV_WAVES;
+    if (step0 >= a.ntiles) return;
     if (FWD) {
         for (unsigned i = 0; i < a.tpw; ++i) {
+            if (step0 + i * WV_WAVES >= a.ntiles) break;                 // workgroup-uniform
+            if (a.wsync && i > 0) __syncthreads();
             const unsigned tile = tile_of(i);
-            if (tile >= a.ntiles) break;
+            if (tile >= a.ntiles) continue;
             long oc, og;
             bool valid;
             locate(tile, oc, og, valid);
@@ -89,11 +95,17 @@ wave_cheb_kernel(FftDev p, WaveArgs a) {
         }
     } else {
         double2 c[NL];
-        long oc, og;
-        bool valid;
-        locate(tile_of(0), oc, og, valid);
-        wf::cheb_bwd_load<NL>(c, a.src + oc, rsb, valid, L);
+        long oc = 0, og = 0;
+        bool valid = false;
+        const bool have0 = tile_of(0) < a.ntiles;
+        if (have0) {
+            locate(tile_of(0), oc, og, valid);
+            wf::cheb_bwd_load<NL>(c, a.src + oc, rsb, valid, L);
+        }
         for (unsigned i = 0; i < a.tpw; ++i) {
+            if (step0 + i * WV_WAVES >= a.ntiles) break;                 // workgroup-uniform
+            if (a.wsync && i > 0) __syncthreads();
+            if (tile_of(i) >= a.ntiles) continue;                        // this wave has run out of tiles (it still syncs)
             const unsigned tn = tile_of(i + 1);
             const bool more = (i + 1 < a.tpw) && (tn < a.ntiles);
             long ocn = oc, ogn = og;
@@ -108,7 +120,6 @@ wave_cheb_kernel(FftDev p, WaveArgs a) {
                 wf::cheb_bwd_pass<R, NL, CH, (KIND == 2 ? 2 : 0), true>(c, S, T, a.dst + og, rsb, valid, lane, a.src + ocn, rsbn,
                                                                       validn);
             }
-            if (!more) break;
             oc = ocn;
             og = ogn;
             valid = validn;
@@ -132,16 +143,68 @@ static int launch_wave_cheb(const FftDev &d, const WaveArgs &a, unsigned nwg, hi
     return 0;
 }
 
+// ---- real Fourier, 3/2 dealiasing (N = 48 R, M = 32 R): RKIND 0 backward, 1 backward differentiated, 2 backward dual
+// (plain + differentiated), 3 forward
+template <int RKIND, int R>
+__global__ void __launch_bounds__(64 * WV_WAVES, 2)
+wave_rfft_kernel(FftDev p, WaveArgs a) {
+    extern __shared__ double2 lds[];
+    constexpr int N = 48 * R, M = 32 * R;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double2 *s_tw = lds;
+    double2 *S = lds + N + wave * wf::RfftWaveLds<R>::size;
+    for (int i = tid; i < N; i += 64 * WV_WAVES) s_tw[i] = p.tw[i];
+    __syncthreads();                    // the only workgroup barrier
+    const unsigned g = xcd_swizzle(blockIdx.x, gridDim.x);
+    const long inner = a.inner;
+    const unsigned rsb = (unsigned)(inner * 8);
+    const int p4 = lane & 3;
+    for (unsigned i = 0; i < a.tpw; ++i) {
+        if ((g * a.tpw + i) * WV_WAVES >= a.ntiles) break;               // workgroup-uniform
+        if (a.wsync && i > 0) __syncthreads();
+        const unsigned tile = (g * a.tpw + i) * WV_WAVES + wave;
+        if (tile >= a.ntiles) continue;
+        unsigned o, tb;
+        a.fd_tpo.divmod(tile, o, tb);
+        const long pair0 = 4L * tb;
+        const long oc = ((long)o * M) * inner + 2 * pair0, og = ((long)o * N) * inner + 2 * pair0;
+        const bool valid = pair0 + p4 < a.npairs;
+        if (RKIND == 3) wf::rfft_fwd_tile<R>(a.src + og, a.dst + oc, rsb, valid, S, s_tw, lane);
+        else wf::rfft_bwd_tile<R, (RKIND == 3 ? 0 : RKIND)>(a.src + oc, a.dst + og, (RKIND == 2) ? a.dst2 + og : nullptr, rsb, valid,
+                                                            (RKIND == 2) ? p.dscale2 : p.dscale, S, s_tw, lane);
+    }
+}
+
+template <int RKIND, int R>
+static int launch_wave_rfft(const FftDev &d, const WaveArgs &a, unsigned nwg, hipStream_t st) {
+    const size_t lds = ((size_t)48 * R + (size_t)WV_WAVES * wf::RfftWaveLds<R>::size) * sizeof(double2);
+    if (lds > 160 * 1024) return 1;
+    auto kern = wave_rfft_kernel<RKIND, R>;
+    if (lds > 64 * 1024)
+        DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WV_WAVES), lds, st, d, a);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
 // Returns 0 when the transform was launched here, 1 when the shape is not covered (the caller then uses the
 // workgroup-per-tile kernel of ddh_fft.hip), < 0 on error.
 int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, long outer, long inner, double *dst2,
-                  const double *dvec, hipStream_t st) {
-    static const int off = getenv("DDH_FFT_WAVE") ? (atoi(getenv("DDH_FFT_WAVE")) == 0) : 0;
-    static const int env_tpw = getenv("DDH_FFT_TPW") ? atoi(getenv("DDH_FFT_TPW")) : 8;
-    if (off || d.dbg || d.prof) return 1;
-    if (mode != CHEB_FWD && mode != CHEB_BWD) return 1;
+                  const double *dvec, double dscale, double dscale2, hipStream_t st) {
+    static const int mask = getenv("DDH_FFT_WAVE") ? atoi(getenv("DDH_FFT_WAVE")) : 3;     // bit 0: Chebyshev, bit 1: real FFT
+    // tiles per wave / per-tile workgroup sync: measured per kernel at 3 x 256 x 512^2 and 1152 x 512 x 512
+    // (tools/bench_strided.py, profiles/r3_strided_sweep.txt); the environment overrides all of them
+    static const int env_tpw = getenv("DDH_FFT_TPW") ? atoi(getenv("DDH_FFT_TPW")) : 0;
+    static const int env_wsync = getenv("DDH_FFT_WSYNC") ? atoi(getenv("DDH_FFT_WSYNC")) : -1;
+    if (d.dbg || d.prof) return 1;
+    const bool cheb = (mode == CHEB_FWD || mode == CHEB_BWD), rfft = (mode == RFFT_FWD || mode == RFFT_BWD);
+    if (!cheb && !rfft) return 1;
+    if ((cheb && !(mask & 1)) || (rfft && !(mask & 2))) return 1;
     if (inner < 2 || (inner & 1)) return 1;
-    if (d.N != 384 || d.M != 256) return 1;                     // instantiated sizes (R = 24, 16 rows per lane)
+    if (cheb && (d.N != 384 || d.M != 256)) return 1;           // instantiated sizes (R = 24, 16 rows per lane)
+    if (rfft && !((d.N == 768 && d.M == 512) || (d.N == 384 && d.M == 256))) return 1;     // N = 48 R, M = 32 R
+    if (rfft && d.K != d.M / 2 - 1) return 1;
     const long npairs = inner / 2;
     const long tpo = (npairs + 3) / 4;
     const unsigned long ntiles = (unsigned long)tpo * (unsigned long)outer;
@@ -156,8 +219,11 @@ int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, lon
     a.fd_tpo.set((unsigned)tpo);
     a.ntiles = (unsigned)ntiles;
     a.kind = 0;
+    a.wsync = 0;
     FftDev dd = d;
     dd.dvec = dvec;
+    dd.dscale = dscale;
+    dd.dscale2 = dscale2;
     if (mode == CHEB_BWD) {
         if (dst2) {
             if (!(d.bsub && d.bsub_order == 1 && (d.gcd_off == 1 || d.gcd_off == 2) && dvec)) return 1;
@@ -167,10 +233,32 @@ int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, lon
             a.kind = 2;
         }
     }
-    unsigned tpw = (unsigned)(env_tpw > 0 ? env_tpw : 1);
+    int def_tpw = 1, def_wsync = 0;
+    if (mode == CHEB_FWD) {
+        def_tpw = 4;
+        def_wsync = 1;
+    } else if (mode == CHEB_BWD && a.kind != 1) {
+        def_tpw = 2;
+    }
+    a.wsync = env_wsync >= 0 ? env_wsync : def_wsync;
+    unsigned tpw = (unsigned)(env_tpw > 0 ? env_tpw : def_tpw);
     while (tpw > 1 && ntiles / ((unsigned long)tpw * WV_WAVES) < 1024) tpw /= 2;   // several rounds of workgroups
     a.tpw = tpw;
     const unsigned nwg = (unsigned)((ntiles + (unsigned long)tpw * WV_WAVES - 1) / ((unsigned long)tpw * WV_WAVES));
+    if (rfft) {
+        if (dst2 && dscale != 0.0) return 1;                    // the dual entry point transforms plainly into dst
+        const int rk = (mode == RFFT_FWD) ? 3 : (dst2 ? 2 : (dscale != 0.0 ? 1 : 0));
+        if (d.N == 768) {
+            if (rk == 3) return launch_wave_rfft<3, 16>(dd, a, nwg, st);
+            if (rk == 2) return launch_wave_rfft<2, 16>(dd, a, nwg, st);
+            if (rk == 1) return launch_wave_rfft<1, 16>(dd, a, nwg, st);
+            return launch_wave_rfft<0, 16>(dd, a, nwg, st);
+        }
+        if (rk == 3) return launch_wave_rfft<3, 8>(dd, a, nwg, st);
+        if (rk == 2) return launch_wave_rfft<2, 8>(dd, a, nwg, st);
+        if (rk == 1) return launch_wave_rfft<1, 8>(dd, a, nwg, st);
+        return launch_wave_rfft<0, 8>(dd, a, nwg, st);
+    }
     if (mode == CHEB_FWD) return launch_wave_cheb<3, 24, 16, 2>(dd, a, nwg, st);
     if (a.kind == 1) return launch_wave_cheb<1, 24, 16, 2>(dd, a, nwg, st);
     if (a.kind == 2) return launch_wave_cheb<2, 24, 16, 2>(dd, a, nwg, st);

@@ -151,13 +151,17 @@ struct WfftBuf {
 //   out: v[a0 (R/4) + i] = X[R (q0 + 4 a0) + (R/4) q1 + i],   X[n] = sum_k x[k] exp(SIGN 2 pi i n k / N)
 // tw[m] = exp(-2 pi i m / N) (m < N), xb = this wave's exchange buffer (WfftBuf<R, CH>::size elements), exchanged in
 // CH chunks so that the buffer stays small.
-template <int R, int SIGN, int CH>
+// TWS: stride of the twiddle table (tw has TWS * 16 R entries: a sub-transform of a longer FFT uses the long table).
+template <int R, int SIGN, int CH, int TWS = 1>
 DDH_DEV void wfft(double2 (&v)[R], double2 *xb, const double2 *tw, const Lane &L) {
     constexpr int RQ = R / 4, IC = RQ / CH;
     static_assert(R % 4 == 0 && RQ % CH == 0, "R must split into 4 x CH chunks");
     dft_inlane<R>(v, SIGN);
 #pragma unroll
-    for (int b = 1; b < R; ++b) v[b] = cmul(v[b], twid<SIGN>(tw, b * L.q));        // (R - 1) * 15 < 16 R
+    for (int b = 1; b < R; ++b) {
+        v[b] = cmul(v[b], twid<SIGN>(tw, TWS * b * L.q));            // (R - 1) * 15 < 16 R
+        if ((b & 3) == 3) WF_SCHED_FENCE();                           // at most four table reads in flight
+    }
     // exchange 1: lane (q1, q0, p) keeps b in [q1 RQ, (q1 + 1) RQ) and collects it from the four rows
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -176,7 +180,7 @@ DDH_DEV void wfft(double2 (&v)[R], double2 *xb, const double2 *tw, const Lane &L
     for (int i = 0; i < RQ; ++i) dft4_inplace(v[i], v[RQ + i], v[2 * RQ + i], v[3 * RQ + i], SIGN);
 #pragma unroll
     for (int a1 = 1; a1 < 4; ++a1) {
-        const double2 w = twid<SIGN>(tw, R * a1 * L.q0);                             // W16^(a1 q0), 9 R < 16 R
+        const double2 w = twid<SIGN>(tw, TWS * R * a1 * L.q0);                       // W16^(a1 q0), 9 R < 16 R
 #pragma unroll
         for (int i = 0; i < RQ; ++i) v[a1 * RQ + i] = cmul(v[a1 * RQ + i], w);
     }
@@ -306,8 +310,8 @@ DDH_DEV void cheb_solve_chains(double2 *S, const ChebTabs &T, const Lane &L) {
 template <int R>
 DDH_DEV void cheb_bwd_store(const double2 (&v)[R], double *dst_t, unsigned rsb, bool pvalid, const Lane &L) {
     constexpr int N = 16 * R, RQ = R / 4;
+    WF_OPAQUE_U32(rsb);                                              // (outside the divergent region: a scalar register)
     if (!pvalid) return;
-    WF_OPAQUE_U32(rsb);
     const int nl = R * L.q0 + RQ * L.q1;                             // n = nl + 4 R a0 + i
     const unsigned lo = (unsigned)(2 * nl) * rsb + 16u * (unsigned)L.p;                  // row 2 n          (n < N / 2)
     const unsigned hi = (unsigned)(2 * (N - 1 - nl) + 1) * rsb + 16u * (unsigned)L.p;    // row 2 (N - 1 - n) + 1
@@ -449,8 +453,8 @@ DDH_DEV void cheb_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, boo
             acc[t] = o;
         }
     }
+    WF_OPAQUE_U32(rsb);
     if (pvalid) {
-        WF_OPAQUE_U32(rsb);
         const unsigned o0 = (unsigned)L.q * rsb + 16u * (unsigned)L.p;
 #pragma unroll
         for (int t = 0; t < NST; ++t) gstore(dst_t, o0 + (unsigned)(16 * t) * rsb, acc[t]);
@@ -462,6 +466,198 @@ struct ChebWaveLds {
     static constexpr int a = 16 * NL * 4, b = WfftBuf<R, CH>::size, c = 8 * R * 4;
     static constexpr int size = (a > b ? (a > c ? a : c) : (b > c ? b : c));       // double2 elements per wave
 };
+
+
+// ------------------------------------------------------------------------------------------------
+// Real Fourier along a strided axis with 3/2 dealiasing: N = 3 * 16 R grid points, M = 2 * 16 R coefficient rows
+// (cos, msin interleaved; K = 16 R - 1), two real lines per pair (core/transforms.py:469-565,
+// libraries/fftw/fftw_wrappers.pyx:61-214).  A third of the length-N spectrum is the dealiasing gap, so the length-N
+// transform is three length-N/3 transforms of pre-combined inputs (backward: grid rows 3 m + r from
+// u_r[k] = w^(r k) (Z[k] + W3^(2 r) Z[k + 2N/3])) and, forward, three transforms F_r of the rows 3 m + r accumulated
+// into X[k] = sum_r w^(-r k) F_r[k], X[N - k] = sum_r w^(r k) F_r[N/3 - k].
+// ------------------------------------------------------------------------------------------------
+template <int R>
+struct RfftWaveLds {
+    static constexpr int a = 16 * R * 4;                 // natural-order exchange of N/3 values x 4 pairs (forward); half of the
+                                                         // coefficient rows (backward staging: 8 R modes x 2 rows x 4 pairs)
+    static constexpr int b = WfftBuf<R, 2>::size;
+    static constexpr int size = a > b ? a : b;
+};
+
+// Backward.  tw[m] = exp(-2 pi i m / N).  BK: 0 plain transform into dst_t; 1 differentiated (spectrum times i kappa,
+// kappa = dsc * k) into dst_t; 2 both from one read of the coefficients: plain into dst_t, differentiated into dst2_t.
+template <int R, int BK>
+DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, unsigned rsb, bool pvalid, double dsc,
+                           double2 *S, const double2 *tw, int lane) {
+    constexpr int H = 16 * R;                            // N / 3 = modes per pair incl. k = 0
+    WF_OPAQUE_LANE(lane);
+    const Lane L = make_lane(lane);
+    double2 A[R], Zm[R];                                 // Z[k], Z[k + 2H] (= Z[N - (H - k)]) of the lane's modes k = q + 16 t
+    {
+        double2 c[R], s[R];
+        WF_OPAQUE_U32(rsb);
+        const unsigned o0 = (unsigned)(2 * L.q) * rsb + (pvalid ? 16u * (unsigned)L.p : 0u);
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            c[t] = gload(src_t, o0 + (unsigned)(32 * t) * rsb);
+            s[t] = gload(src_t, o0 + (unsigned)(32 * t + 1) * rsb);
+        }
+        // the partner mode H - k sits in another lane: two half exchanges through LDS, [cos | msin][mode][pair]
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            WF_SYNC();
+#pragma unroll
+            for (int t = half * (R / 2); t < (half + 1) * (R / 2); ++t) {
+                const int ml = L.q + 16 * t - half * (H / 2);
+                S[ml * 4 + L.p] = c[t];
+                S[(H / 2 + ml) * 4 + L.p] = s[t];
+            }
+            WF_SYNC();
+            // staged: modes [half H/2, (half + 1) H/2); readers: the lanes' slots of the OTHER half (k = H/2 pairs with
+            // itself and is served by the second half)
+#pragma unroll
+            for (int t = (1 - half) * (R / 2); t < (2 - half) * (R / 2) + half; ++t) {
+                const int k = L.q + 16 * t, km = H - k;
+                const bool in = (k > 0) && (km >= half * (H / 2)) && (km < (half + 1) * (H / 2));
+                const int ml = in ? km - half * (H / 2) : 0;
+                const double2 cm = S[ml * 4 + L.p], sm = S[(H / 2 + ml) * 4 + L.p];
+                const double2 z = make_double2(0.5 * (cm.x + sm.y), 0.5 * (cm.y - sm.x));
+                if (half == 1 && t == R / 2) {           // only lane q = 0 (k = H/2) is served here; the others keep theirs
+                    Zm[t] = make_double2(in ? z.x : Zm[t].x, in ? z.y : Zm[t].y);
+                } else {
+                    Zm[t] = make_double2(in ? z.x : 0.0, in ? z.y : 0.0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const bool k0 = (t == 0 && L.q == 0);        // k = 0: the msin row is no mode
+            A[t] = make_double2(k0 ? c[t].x : 0.5 * (c[t].x - s[t].y), k0 ? c[t].y : 0.5 * (s[t].x + c[t].y));
+        }
+    }
+    const double s3 = 0.86602540378443864676372317075293618;
+#pragma unroll
+    for (int pass = 0; pass < (BK == 2 ? 2 : 1); ++pass) {
+        constexpr bool dummy = false;
+        (void)dummy;
+        const bool deriv = (BK == 1) || (BK == 2 && pass == 1);
+        double *out_t = (BK == 2 && pass == 1) ? dst2_t : dst_t;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double2 v[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const int k = L.q + 16 * t;
+                double2 a = A[t], zm = Zm[t];
+                if (deriv) {                             // compile time
+                    const double ka = dsc * (double)k, km = dsc * (double)(H - k);
+                    a = make_double2(-ka * a.y, ka * a.x);             //  i kappa Z[k]
+                    zm = make_double2(km * zm.y, -km * zm.x);          // -i kappa' Z[N - k']
+                }
+                double2 wz = zm;                         // W3^(2 r) zm
+                if (r == 1) wz = make_double2(-0.5 * zm.x + s3 * zm.y, -0.5 * zm.y - s3 * zm.x);
+                if (r == 2) wz = make_double2(-0.5 * zm.x - s3 * zm.y, -0.5 * zm.y + s3 * zm.x);
+                const double2 u = make_double2(a.x + wz.x, a.y + wz.y);
+                v[t] = (r == 0) ? u : cmul(u, twid<+1>(tw, r * k));
+                if ((t & 3) == 3) WF_SCHED_FENCE();
+            }
+            wfft<R, +1, 2, 3>(v, S, tw, L);
+            WF_OPAQUE_U32(rsb);
+            if (pvalid) {
+                const unsigned o0 = (unsigned)(3 * (R * L.q0 + (R / 4) * L.q1) + r) * rsb + 16u * (unsigned)L.p;
+#pragma unroll
+                for (int a0 = 0; a0 < 4; ++a0)
+#pragma unroll
+                    for (int i = 0; i < R / 4; ++i)
+                        gstore(out_t, o0 + (unsigned)(3 * (4 * R * a0 + i)) * rsb, v[a0 * (R / 4) + i]);
+            }
+        }
+    }
+}
+
+// Forward: grid rows -> (cos, msin) rows 2 k, 2 k + 1 of the lane's modes k = q + 16 t.
+// With T_r[j] = exp(-2 pi i r j / N) F_r[j] (F_r = length-H transform of the rows 3 m + r):
+//     X[j] = sum_r T_r[j],     X[N - (H - j)] = sum_r W3^r T_r[j],   W3 = exp(2 pi i / 3),
+// so both halves of the spectrum accumulate in the lane that owns F_r[j] (the wfft output slot) and one natural-order
+// exchange at the end hands X[k], X[N - k] to the lane that stores mode k.
+template <int R>
+DDH_DEV void rfft_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, bool pvalid, double2 *S, const double2 *tw,
+                           int lane) {
+    constexpr int H = 16 * R, N = 3 * H, RQ = R / 4;
+    static_assert((H & (H - 1)) == 0, "N / 3 must be a power of two here");
+    const double s3 = 0.86602540378443864676372317075293618;
+    double2 P[R], Q[R];                                  // X[j], X[N - (H - j)] at the wfft output slots j
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double2 v[R];
+        WF_SCHED_FENCE();                                // the rows of r are requested after r - 1 has been accumulated
+        int ln = lane;
+        WF_OPAQUE_LANE(ln);                              // addresses are re-derived per r, not kept across the three
+        const Lane Lr = make_lane(ln);
+        {
+            WF_OPAQUE_U32(rsb);
+            const unsigned o0 = (unsigned)(3 * Lr.q + r) * rsb + (pvalid ? 16u * (unsigned)Lr.p : 0u);
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[t] = gload(src_t, o0 + (unsigned)(48 * t) * rsb);
+        }
+        WF_SCHED_FENCE();
+        wfft<R, -1, 2, 3>(v, S, tw, Lr);
+        const double2 *twr = tw + r * (R * Lr.q0 + RQ * Lr.q1);       // exp(-2 pi i r j / N), j = R (q0 + 4 a0) + RQ q1 + i
+#pragma unroll
+        for (int a0 = 0; a0 < 4; ++a0)
+#pragma unroll
+            for (int i = 0; i < RQ; ++i) {
+                const int j = a0 * RQ + i;
+                if (r == 0) {
+                    P[j] = v[j];
+                    Q[j] = v[j];
+                } else {
+                    const double2 T = cmul(v[j], twr[r * (4 * R * a0 + i)]);
+                    P[j] = make_double2(P[j].x + T.x, P[j].y + T.y);
+                    if (r == 1) Q[j] = make_double2(Q[j].x - 0.5 * T.x - s3 * T.y, Q[j].y - 0.5 * T.y + s3 * T.x);
+                    else Q[j] = make_double2(Q[j].x - 0.5 * T.x + s3 * T.y, Q[j].y - 0.5 * T.y - s3 * T.x);
+                }
+                if ((j & 3) == 3) WF_SCHED_FENCE();
+            }
+    }
+    WF_OPAQUE_LANE(lane);
+    const Lane L = make_lane(lane);
+    double2 z1[R];
+    // X[k] = P[k]
+    WF_SYNC();
+#pragma unroll
+    for (int a0 = 0; a0 < 4; ++a0)
+#pragma unroll
+        for (int i = 0; i < RQ; ++i) S[(R * (L.q0 + 4 * a0) + RQ * L.q1 + i) * 4 + L.p] = P[a0 * RQ + i];
+    WF_SYNC();
+#pragma unroll
+    for (int t = 0; t < R; ++t) z1[t] = S[(L.q + 16 * t) * 4 + L.p];
+    // X[N - k] = Q[H - k]:  H - k = (16 - q) + 16 (R - 1 - t)  (k = 0 is not used)
+    WF_SYNC();
+#pragma unroll
+    for (int a0 = 0; a0 < 4; ++a0)
+#pragma unroll
+        for (int i = 0; i < RQ; ++i) S[(R * (L.q0 + 4 * a0) + RQ * L.q1 + i) * 4 + L.p] = Q[a0 * RQ + i];
+    WF_SYNC();
+    WF_OPAQUE_U32(rsb);
+    const double invN = 1.0 / (double)N;
+    const unsigned o0 = (unsigned)(2 * L.q) * rsb + 16u * (unsigned)L.p;
+    const double2 *Sm = S + (16 - L.q) * 4 + L.p;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+        const double2 z2 = (t == 0) ? S[((H - L.q) & (H - 1)) * 4 + L.p] : Sm[16 * (R - 1 - t) * 4];
+        double2 c = make_double2((z1[t].x + z2.x) * invN, (z1[t].y + z2.y) * invN);
+        double2 s = make_double2((z1[t].y - z2.y) * invN, (z2.x - z1[t].x) * invN);
+        if (t == 0 && L.q == 0) {                        // k = 0
+            c = make_double2(z1[t].x * invN, z1[t].y * invN);
+            s = make_double2(0.0, 0.0);
+        }
+        if (pvalid) {
+            gstore(dst_t, o0 + (unsigned)(32 * t) * rsb, c);
+            gstore(dst_t, o0 + (unsigned)(32 * t + 1) * rsb, s);
+        }
+    }
+}
 
 }  // namespace wf
 }  // namespace ddh

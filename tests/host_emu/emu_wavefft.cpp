@@ -172,3 +172,52 @@ int emu_cheb_fwd(int N, int M, const double *tw, const double *half, int nbands,
     return 1;
 }
 }
+
+template <int R>
+static void rfft_bwd(const double *tw, bool dual, double dsc, double dsc2, const double *src, double *dst, double *dst2,
+                     long outer, long inner) {
+    constexpr int H = 16 * R, N = 3 * H, M = 2 * H;
+    const long npairs = inner / 2, tpo = (npairs + 3) / 4, ntiles = tpo * outer;
+    std::vector<double2> S(RfftWaveLds<R>::size);
+    run_wave([&](int lane) {
+        for (long tile = 0; tile < ntiles; ++tile) {
+            const long o = tile / tpo, tb = tile % tpo;
+            const bool valid = 4 * tb + (lane & 3) < npairs;
+            const double *st = src + (o * M) * inner + 8 * tb;
+            double *d1 = dst + (o * N) * inner + 8 * tb, *d2 = dual ? dst2 + (o * N) * inner + 8 * tb : nullptr;
+            const double2 *twp = reinterpret_cast<const double2 *>(tw);
+            if (dual) rfft_bwd_tile<R, 2>(st, d1, d2, (unsigned)(inner * 8), valid, dsc2, S.data(), twp, lane);
+            else if (dsc != 0.0) rfft_bwd_tile<R, 1>(st, d1, d2, (unsigned)(inner * 8), valid, dsc, S.data(), twp, lane);
+            else rfft_bwd_tile<R, 0>(st, d1, d2, (unsigned)(inner * 8), valid, 0.0, S.data(), twp, lane);
+        }
+    });
+}
+
+template <int R>
+static void rfft_fwd(const double *tw, const double *src, double *dst, long outer, long inner) {
+    constexpr int H = 16 * R, N = 3 * H, M = 2 * H;
+    const long npairs = inner / 2, tpo = (npairs + 3) / 4, ntiles = tpo * outer;
+    std::vector<double2> S(RfftWaveLds<R>::size);
+    run_wave([&](int lane) {
+        for (long tile = 0; tile < ntiles; ++tile) {
+            const long o = tile / tpo, tb = tile % tpo;
+            const bool valid = 4 * tb + (lane & 3) < npairs;
+            rfft_fwd_tile<R>(src + (o * N) * inner + 8 * tb, dst + (o * M) * inner + 8 * tb, (unsigned)(inner * 8), valid, S.data(),
+                             reinterpret_cast<const double2 *>(tw), lane);
+        }
+    });
+}
+
+extern "C" {
+int emu_rfft_bwd(int N, int dual, double dsc, double dsc2, const double *tw, const double *src, double *dst, double *dst2,
+                 long outer, long inner) {
+    if (N == 768) { rfft_bwd<16>(tw, dual != 0, dsc, dsc2, src, dst, dst2, outer, inner); return 0; }
+    if (N == 384) { rfft_bwd<8>(tw, dual != 0, dsc, dsc2, src, dst, dst2, outer, inner); return 0; }
+    return 1;
+}
+int emu_rfft_fwd(int N, const double *tw, const double *src, double *dst, long outer, long inner) {
+    if (N == 768) { rfft_fwd<16>(tw, src, dst, outer, inner); return 0; }
+    if (N == 384) { rfft_fwd<8>(tw, src, dst, outer, inner); return 0; }
+    return 1;
+}
+}

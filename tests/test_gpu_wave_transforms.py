@@ -107,3 +107,42 @@ def test_wave_chebyshev_round_trip_full_size(dev):
     dev.sync()
     assert t.equal(ga, g)
     assert float((gb - g2).norm() / g2.norm()) < 1e-13
+
+
+@pytest.mark.parametrize("N,M", [(768, 512), (384, 256)])
+@pytest.mark.parametrize("outer,inner", [(1, 2), (2, 10), (3, 64), (1, 8 * 8 * 4 * 2 + 6), (2, 1024)])
+def test_wave_real_fourier_all_paths(dev, N, M, outer, inner):
+    """wave-per-four-pairs real FFT with 3/2 dealiasing (three length-N/3 transforms): backward, differentiated
+    backward, dual backward (bitwise equal to the two single launches) and forward, vs the oracle
+    (core/transforms.py:469-565)."""
+    from dedalus_amd import libhip
+    from dedalus_amd.device import ptr
+    from oracle import np_transforms as npt
+    rng = np.random.default_rng(N + outer * 1000 + inner)
+    cs, gs = (outer, M, inner), (outer, N, inner)
+    cin = rng.standard_normal(cs)
+    gin = rng.standard_normal(gs)
+    h = C.c_uint64(0)
+    libhip.call("ddh_plan_rfft", C.byref(h), N, M)
+    d_c, d_g = dev.from_host(cin), dev.from_host(gin)
+    dscale = 2 * np.pi / 3.0
+    outs = [dev.empty(gs) for _ in range(4)]
+    for o in outs:
+        o.fill_(float("nan"))
+    libhip.call("ddh_rfft_backward_dual", h, ptr(d_c), ptr(outs[0]), ptr(outs[1]), outer, inner, dscale, dev.stream)
+    libhip.call("ddh_rfft_backward", h, ptr(d_c), ptr(outs[2]), outer, inner, dev.stream)
+    libhip.call("ddh_rfft_backward_deriv", h, ptr(d_c), ptr(outs[3]), outer, inner, dscale, dev.stream)
+    cf = dev.empty(cs)
+    cf.fill_(float("nan"))
+    libhip.call("ddh_rfft_forward", h, ptr(d_g), ptr(cf), outer, inner, dev.stream)
+    dev.sync()
+    g, gd, g1, gd1 = [dev.to_host(o) for o in outs]
+    assert np.array_equal(dev.to_host(d_c), cin)
+    assert np.array_equal(g, g1) and np.array_equal(gd, gd1)
+    k = dscale * np.arange(M // 2)
+    dc = np.empty_like(cin)
+    dc[:, 0::2] = -k.reshape(1, -1, 1) * cin[:, 1::2]
+    dc[:, 1::2] = k.reshape(1, -1, 1) * cin[:, 0::2]
+    assert rel(g, npt.rfft_backward(cin, 1, N)) < 1e-12
+    assert rel(gd, npt.rfft_backward(dc, 1, N)) < 1e-12
+    assert rel(dev.to_host(cf), npt.rfft_forward(gin, 1, M)) < 1e-12

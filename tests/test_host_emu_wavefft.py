@@ -25,6 +25,8 @@ def emu(tmp_path_factory):
     lib.emu_fft4.argtypes = [i, i, vp, vp, vp]
     lib.emu_cheb_bwd.argtypes = [i, i, i, vp, vp, vp, vp, i, vp, vp, vp, l, l]
     lib.emu_cheb_fwd.argtypes = [i, i, vp, vp, i, vp, vp, vp, vp, l, l]
+    lib.emu_rfft_bwd.argtypes = [i, i, C.c_double, C.c_double, vp, vp, vp, vp, l, l]
+    lib.emu_rfft_fwd.argtypes = [i, vp, vp, vp, l, l]
     return lib
 
 
@@ -107,3 +109,31 @@ def test_wave_chebyshev_matches_the_oracle(emu, shape):
             cv, offs, bands = conv_bands(M, alpha)
             emu.emu_cheb_fwd(N, M, dp(tw), dp(half), len(offs), dp(offs), dp(bands), dp(gin), dp(out), outer, inner)
         assert rel(out, npt.cheb_forward(gin, 1, M, cv)) < 1e-14
+
+
+@pytest.mark.parametrize("N", [768, 384])
+@pytest.mark.parametrize("shape_oi", [(2, 10), (1, 8), (3, 2)])
+def test_wave_real_fourier_matches_the_oracle(emu, N, shape_oi):
+    """3/2-dealiased real FFT along a strided axis as three length-N/3 transforms (core/transforms.py:469-565)"""
+    M = 2 * N // 3
+    outer, inner = shape_oi
+    rng = np.random.default_rng(N + inner)
+    tw, _ = tables(N)
+    cs, gs = (outer, M, inner), (outer, N, inner)
+    cin = rng.standard_normal(cs)
+    g, gd, g1, g2 = (np.full(gs, np.nan) for _ in range(4))
+    dscale = 2 * np.pi / 4.0
+    assert emu.emu_rfft_bwd(N, 1, 0.0, dscale, dp(tw), dp(cin), dp(g), dp(gd), outer, inner) == 0
+    emu.emu_rfft_bwd(N, 0, 0.0, 0.0, dp(tw), dp(cin), dp(g1), None, outer, inner)
+    emu.emu_rfft_bwd(N, 0, dscale, 0.0, dp(tw), dp(cin), dp(g2), None, outer, inner)
+    assert np.array_equal(g, g1) and np.array_equal(gd, g2)
+    k = dscale * np.arange(M // 2)
+    dc = np.empty_like(cin)
+    dc[:, 0::2] = -k.reshape(1, -1, 1) * cin[:, 1::2]
+    dc[:, 1::2] = k.reshape(1, -1, 1) * cin[:, 0::2]
+    assert rel(g, npt.rfft_backward(cin, 1, N)) < 1e-14
+    assert rel(gd, npt.rfft_backward(dc, 1, N)) < 1e-14
+    gin = rng.standard_normal(gs)
+    out = np.full(cs, np.nan)
+    emu.emu_rfft_fwd(N, dp(tw), dp(gin), dp(out), outer, inner)
+    assert rel(out, npt.rfft_forward(gin, 1, M)) < 1e-14
