@@ -341,3 +341,89 @@ def install(register_transform, RealFourier=None, ComplexFourier=None, Jacobi=No
                       (SphereBasis, HipSWSHColatitude)):
         if cls is not None:
             register_transform(cls, name)(plan)
+
+
+# ---- B2: matsolver registry (libraries/matsolvers.py:10-13) ---------------------------------------------------------
+class HipBandMatsolver:
+    """`cls(matrix, solver).solve(vector)` of the reference's matsolver interface (libraries/matsolvers.py:16-27;
+    constructed per subproblem in core/solvers.py:95-116, core/timesteppers.py:172-181, 630-640) over the library's
+    pencil engine with ONE pencil (ddh_pencil_create with nfourier = 0):
+
+      * a matrix that is banded as given (lower bandwidth <= 16, kl + ku <= 64 -- the engine's register windows) is
+        factored by the batched band LU with partial pivoting (ddh_pencil_factor) and solved by its sweeps;
+      * anything else (tau columns / boundary rows far from the diagonal, as in the reference's tau-bordered pencils)
+        is flagged by the engine and served by an explicit inverse applied on the device.
+
+    Register it like any matsolver: `matsolvers.add_solver(HipBandMatsolver)`, then `matsolver = 'hipbandmatsolver'`.
+    This is the fine-grained seam, kept for completeness: one launch per pencil is the loop the library exists to
+    remove, the production path factors all pencils at once behind `timestepper.step`.
+    Complex matrices are solved as the interleaved real system of twice the size."""
+
+    sparse = True
+    banded = False
+    config = {}
+
+    def __init__(self, matrix, solver=None):
+        from scipy import sparse
+        from .device import Device
+        from .pencilpack import PencilPack, TermList
+        A = sparse.coo_matrix(matrix)
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("HipBandMatsolver: square matrix expected")
+        self.n = int(A.shape[0])
+        self.cx = bool(np.iscomplexobj(A.data))
+        row, col, val = A.row.astype(np.int64), A.col.astype(np.int64), A.data
+        if self.cx:
+            # (x_re, x_im) interleaved per unknown: [[re, -im], [im, re]] blocks
+            row = np.concatenate([2 * row, 2 * row, 2 * row + 1, 2 * row + 1])
+            col = np.concatenate([2 * col, 2 * col + 1, 2 * col, 2 * col + 1])
+            val = np.concatenate([val.real, -val.imag, val.imag, val.real])
+        N = self.n * (2 if self.cx else 1)
+        keep = val != 0
+        row, col, val = row[keep], col[keep], np.asarray(val[keep], dtype=np.float64)
+        kl = int(max(0, (row - col).max())) if row.size else 0
+        ku = int(max(0, (col - row).max())) if row.size else 0
+        self.band = (kl <= 16 and kl + ku <= 64)
+        self.dev = Device.get()
+        self.pack = PencilPack(self.dev, 0, N, 1, 1, np.zeros(1), np.zeros(1))
+        mat = self.pack.add_matrix(TermList(N, N, row, col, val))
+        perm = np.arange(N, dtype=np.int32)
+        axes = np.full(N, 3, dtype=np.uint8)
+        # (0 * mat + 1 * mat); a band declared as (0, 0) sends a non-banded matrix to the engine's dense path
+        self.lu = self.pack.factor(mat, mat, 0.0, 1.0, perm, perm, N, kl if self.band else 0, ku if self.band else 0, axes, axes)
+        self.N = N
+
+    def solve(self, vector):
+        v = np.asarray(vector)
+        out_dtype = np.result_type(v.dtype, np.complex128 if self.cx else np.float64)
+        cols = v.reshape(self.n, -1)
+        res = np.empty(cols.shape, dtype=out_dtype)
+        for j in range(cols.shape[1]):
+            b = cols[:, j]
+            if self.cx:
+                rb = np.empty(self.N)
+                rb[0::2], rb[1::2] = b.real, np.imag(b)
+                parts = [rb]
+            elif np.iscomplexobj(b):
+                parts = [np.ascontiguousarray(b.real), np.ascontiguousarray(b.imag)]     # a real matrix, twice
+            else:
+                parts = [np.asarray(b, dtype=np.float64)]
+            sols = []
+            for p in parts:
+                d_b = self.dev.from_host(np.ascontiguousarray(p).reshape(self.N, 1, 1))
+                d_x = self.dev.empty((self.N, 1, 1))
+                self.pack.solve(self.lu, d_b, d_x)
+                self.dev.sync()
+                sols.append(self.dev.to_host(d_x).reshape(self.N))
+            if self.cx:
+                res[:, j] = sols[0][0::2] + 1j * sols[0][1::2]
+            elif len(sols) == 2:
+                res[:, j] = sols[0] + 1j * sols[1]
+            else:
+                res[:, j] = sols[0]
+        return res.reshape(v.shape)
+
+
+def install_matsolver(add_solver):
+    """`install_matsolver(dedalus.libraries.matsolvers.add_solver)` -> `matsolvers['hipbandmatsolver']`"""
+    return add_solver(HipBandMatsolver)

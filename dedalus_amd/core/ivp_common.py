@@ -61,14 +61,23 @@ class IVPLifecycle:
         """core/solvers.py:618-630"""
         if self.sim_time >= self.stop_sim_time:
             logger.info("Simulation stop time reached.")
-            return False
+            return self._stopped()
         if self.wall_time >= self.stop_wall_time:
             logger.info("Wall stop time reached.")
-            return False
+            return self._stopped()
         if self.iteration >= self.stop_iteration:
             logger.info("Stop iteration reached.")
-            return False
+            return self._stopped()
         return True
+
+    def _stopped(self):
+        self._flush_outputs()            # staged analysis output reaches its files when the main loop ends
+        return False
+
+    def _flush_outputs(self):
+        ev = getattr(self, "evaluator", None)
+        if ev is not None and hasattr(ev, "flush"):
+            ev.flush()
 
     # ---- one step --------------------------------------------------------------------------------------------------
     def step(self, dt):
@@ -85,6 +94,7 @@ class IVPLifecycle:
         # scheduled analysis sees the pre-step state (the reference's timesteppers call evaluate_scheduled first,
         # core/timesteppers.py:137-139, 578-580), with the same world wall time on every rank
         self._step_wall_time = wall_time
+        self._step_dt = dt
         for hook in self._step_hooks:
             hook(self)
         if not self._graph_replay(dt, wall_time):
@@ -182,11 +192,13 @@ class IVPLifecycle:
             logger.error("Exception raised, triggering end of main loop.")
             raise
         finally:
+            self._flush_outputs()
             self.log_stats()
 
     def log_stats(self, format=".4g"):
         """core/solvers.py:755-778: setup / warm-up / run time and mode-stages per (device-)second."""
         self.ex.sync()
+        self._flush_outputs()
         end = self.world_time
         logger.info("Final iteration: %i" % self.iteration)
         logger.info("Final sim time: %s" % self.sim_time)

@@ -22,6 +22,7 @@ import pathlib
 import re
 import shutil
 import time
+import weakref
 
 import numpy as np
 
@@ -212,6 +213,18 @@ class FileHandler(Handler):
         self._queue = []
         # asynchronous device-to-host staging of the task data (DDH_OUTPUT_SYNC=1: fetch and write immediately)
         self.async_staging = os.environ.get("DDH_OUTPUT_SYNC", "0") != "1"
+        # a script that never closes its handlers still gets its last write: flushed when the main loop ends
+        # (IVPLifecycle) and, as the last resort, when the handler is collected or the interpreter exits
+        self._finalizer = weakref.finalize(self, FileHandler._finalize, self._queue, weakref.ref(self))
+
+    @staticmethod
+    def _finalize(queue, ref):
+        me = ref()
+        if me is not None and queue:
+            try:
+                me.flush()
+            except Exception:                       # the device may already be gone at interpreter exit
+                pass
 
     @property
     def current_file(self):
@@ -362,6 +375,16 @@ class OutputEvaluator:
             h.evaluate()
             h.process(**kw)
 
+    def flush(self):
+        """Write every output that is still staged (asynchronous device-to-host copies) to its file.  Called when a
+        run ends -- `proceed` turning False, `evolve` returning or raising, `log_stats` -- and at interpreter exit, so a
+        reference-style script (`while solver.proceed: solver.step(dt)`) that never closes its handlers loses nothing:
+        the reference writes inside `process()` (core/evaluator.py:366-700)."""
+        for h in self.handlers:
+            fl = getattr(h, "flush", None)
+            if fl is not None:
+                fl()
+
     # hook called by the IVP solvers at the start of every step (pre-step state, as the reference's timesteppers do)
     def step_hook(self, solver):
         if not self.handlers:
@@ -369,8 +392,10 @@ class OutputEvaluator:
         wall = getattr(solver, "_step_wall_time", None)           # the world clock of this step (same on every rank)
         if wall is None:
             wall = time.time() - solver.start_time
+        # the timestep of THIS step (core/timesteppers.py:150, 608), not the previous one's
+        dt = getattr(solver, "_step_dt", None)
         self.evaluate_scheduled(iteration=int(solver.iteration), wall_time=wall,
-                                sim_time=float(solver.sim_time), timestep=float(solver.dt))
+                                sim_time=float(solver.sim_time), timestep=float(solver.dt if dt is None else dt))
 
 
 def load_state(solver, path, index=-1, allow_missing=False):

@@ -1775,7 +1775,7 @@ class ShellSolverBase:
                 self.ex.assign(c[comp:comp + 1], self.X4[sc:sc + 1, :, :, off:off + nr])
             v._set_device_coeff(c)
 
-    def evaluate_F(self, out):
+    def evaluate_F(self, out, persistent=False):
         ex = self.ex
         ex.fill_zero(out)
         out4 = out.reshape(self.R, 2 * self.nm, self.nl, self.Nr)

@@ -509,16 +509,20 @@ class SolverBase:
         self.F_direct = plan
         self._F_zeroed = set()
 
-    def evaluate_F(self, out):
-        """F system vector for the current state (coefficient space, equation bases)."""
+    def evaluate_F(self, out, persistent=False):
+        """F system vector for the current state (coefficient space, equation bases).
+        persistent: `out` is a buffer the caller owns for the life of the solver and nothing else writes to (the
+        timesteppers' F arrays): rows without right-hand-side terms are then zeroed once.  Any other buffer -- a temporary
+        whose address the allocator may hand out again after unrelated data lived there -- is zeroed on every call."""
         ev, ex = self.evaluator_core, self.ex
         ev.new_pass()
         if self.F_direct is not None:
             tr = self.dist.transformer
             key = (out.data_ptr() if hasattr(out, "data_ptr") else id(out))
-            if key not in self._F_zeroed:               # rows without right-hand-side terms are zero and stay zero
+            if not persistent or key not in self._F_zeroed:     # rows without right-hand-side terms are zero and stay zero
                 ex.fill_zero(out)
-                self._F_zeroed.add(key)
+                if persistent:
+                    self._F_zeroed.add(key)
             for grp in self.nl_fused:
                 outs = [ex.empty(tr.pregrid_shape(leaf.domain, leaf.ncomp, leaf.domain.dealias))
                         for (leaf, row0, rows), fp in grp]
@@ -797,7 +801,9 @@ class LinearBoundaryValueSolver(SolverBase):
         """The LHS does not change between calls: it is factored once (the reference factors at build time,
         core/solvers.py:393-406) and re-factored into the same device storage only on request."""
         self.sync_state_to_device()
-        F = self.ex.empty((self.R, self.nx, self.ny))
+        if getattr(self, "_F_lbvp", None) is None:
+            self._F_lbvp = self.ex.empty((self.R, self.nx, self.ny))        # owned by the solver, reused by every solve
+        F = self._F_lbvp
         self.evaluate_F(F)
         if self._lu is None or rebuild_matrices:
             self._lu = self.factor(0.0, 1.0, reuse=(-1 if self._lu is None else self._lu))

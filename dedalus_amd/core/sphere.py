@@ -1253,7 +1253,7 @@ class SphereSolverBase:
             self._dinv = self.ex.make_dense_inverse(Ms, Ls, rvs, cvs, complex_=True)
         return self.ex.make_cgemv_batch_flat(nm, nl, self.R, self._dinv.compute(a, b), old=old)
 
-    def evaluate_F(self, out):
+    def evaluate_F(self, out, persistent=False):
         ex = self.ex
         ex.fill_zero(out)
         self.dist._grid_cache = {}

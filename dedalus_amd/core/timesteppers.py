@@ -125,7 +125,7 @@ class MultistepIMEX(_SolveMixin):
         pack.matvec(s.M_id, s.X, self.MX[0])
         if self._need_lx:
             pack.matvec(s.L_id, s.X, self.LX[0])
-        s.evaluate_F(self.F[0])
+        s.evaluate_F(self.F[0], persistent=True)
         xs, al = [], []
         for j in range(1, len(c)):
             if c[j] != 0.0:
@@ -337,7 +337,7 @@ class RungeKuttaIMEX(_SolveMixin):
                     pack.matvec(s.L_id, s.X, self.LX[j])
                 else:
                     pack.matvec(s.M_id, s.X, self.MX[j])
-            s.evaluate_F(self.F[i - 1])
+            s.evaluate_F(self.F[i - 1], persistent=True)
             # RHS_i as a combination of the stored vectors.  RHS_j of an earlier stage is itself such a combination
             # (it is not kept): -k H_ij L.X_j = -(H_ij / H_jj) (RHS_j - M.X_j) expands into MX0, F_*, MX_* terms.
             comb = {("MX0",): 1.0}

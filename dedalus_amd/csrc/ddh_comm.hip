@@ -105,6 +105,8 @@ using namespace ddh;
 
 extern "C" {
 
+int ddh_comm_probe(void) { return load_rccl(); }
+
 int ddh_comm_unique_id(unsigned char *id_h) {
     if (!id_h) return fail("ddh_comm_unique_id: null buffer");
     if (int s = load_rccl()) return s;

@@ -196,9 +196,13 @@ a2a_unpack_kernel(const double *__restrict__ src, double *__restrict__ dst, long
 // so the result does not depend on scheduling.  out3 = {min, max, sum}.
 constexpr int RED_BLOCKS = 1024;
 
+// NaN-propagating min / max (np.min / np.max semantics: a blown-up field must show up in flow.max(), fmin / fmax drop it)
+__device__ __forceinline__ double nan_min(double x, double y) { return (x != x) ? x : ((y != y) ? y : fmin(x, y)); }
+__device__ __forceinline__ double nan_max(double x, double y) { return (x != x) ? x : ((y != y) ? y : fmax(x, y)); }
+
 __device__ __forceinline__ void red3_combine(double &mn, double &mx, double &sm, double a, double b, double c) {
-    mn = fmin(mn, a);
-    mx = fmax(mx, b);
+    mn = nan_min(mn, a);
+    mx = nan_max(mx, b);
     sm += c;
 }
 
@@ -230,8 +234,8 @@ __global__ void __launch_bounds__(256) reduce3_partial_kernel(const double *__re
     double mn = INFINITY, mx = -INFINITY, sm = 0.0;
     for (long i = lo + threadIdx.x; i < hi; i += 256) {
         const double v = x[i];
-        mn = fmin(mn, v);
-        mx = fmax(mx, v);
+        mn = nan_min(mn, v);
+        mx = nan_max(mx, v);
         sm += v;
     }
     red3_block(mn, mx, sm, part + 3 * blockIdx.x);

@@ -54,20 +54,42 @@ class Comm:
             import ctypes as C
             from . import libhip
             t = self.torch
+            # Rank 0 makes the unique id.  If it cannot (RCCL does not load there), it broadcasts an all-zero id: every
+            # rank then agrees to fall back BEFORE anyone enters ncclCommInitRank, where the others would wait for ever.
             buf = (C.c_ubyte * 128)()
             if self.rank == 0:
-                libhip.call("ddh_comm_unique_id", buf)
+                try:
+                    libhip.call("ddh_comm_unique_id", buf)
+                    if not any(buf):
+                        buf[0] = 1                       # (a valid id is never all zero; keep the convention safe)
+                except Exception as e:
+                    import logging
+                    logging.getLogger(__name__).warning("library RCCL communicator unavailable on rank 0 (%s)" % (e,))
+                    buf = (C.c_ubyte * 128)()
             ident = t.tensor(list(buf), dtype=t.uint8, device="cuda")
             self.dist.broadcast(ident, src=0)
+            have_id = bool(ident.any().item())
             buf = (C.c_ubyte * 128)(*[int(v) for v in ident.cpu().tolist()])
             h = C.c_uint64(0)
-            try:
-                libhip.call("ddh_comm_create", C.byref(h), self.rank, self.size, buf)
-                ok = self._self_check(h)
-            except Exception as e:                   # (an RCCL that cannot initialise here: use the process group)
-                ok = False
-                import logging
-                logging.getLogger(__name__).warning("library RCCL communicator unavailable (%s)" % (e,))
+            ok = False
+            if have_id:
+                # every rank enters ncclCommInitRank together (a rank that cannot load RCCL raises before it and the
+                # others would block): agree first that the library is loadable everywhere
+                try:
+                    libhip.call("ddh_comm_probe")
+                    can = 1
+                except Exception:
+                    can = 0
+                cflag = t.tensor([can], dtype=t.int32, device="cuda")
+                self.dist.all_reduce(cflag, op=self.dist.ReduceOp.MIN)
+                if int(cflag.item()) == 1:
+                    try:
+                        libhip.call("ddh_comm_create", C.byref(h), self.rank, self.size, buf)
+                        ok = self._self_check(h)
+                    except Exception as e:           # (an RCCL that cannot initialise here: use the process group)
+                        ok = False
+                        import logging
+                        logging.getLogger(__name__).warning("library RCCL communicator unavailable (%s)" % (e,))
             # every rank must take the same path
             flag = t.tensor([1 if ok else 0], dtype=t.int32, device="cuda")
             self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)

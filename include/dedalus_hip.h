@@ -360,6 +360,8 @@ int ddh_pencil_lu_row_widths(ddh_handle pack, int lu_id, int *wrow_h);
  * ranks through any out-of-band channel (the launcher's store, a file, MPI_Bcast); then every rank calls
  * ddh_comm_create, collectively.  RCCL is bound at run time (librccl.so.1).  Destroy plans before their communicator. */
 #define DDH_COMM_ID_BYTES 128
+int ddh_comm_probe(void);                                          /* 0 when RCCL can be bound in this process: lets the
+                                                                    * ranks agree BEFORE the collective ddh_comm_create */
 int ddh_comm_unique_id(unsigned char *id_h);                       /* DDH_COMM_ID_BYTES bytes */
 int ddh_comm_create(ddh_handle *comm, int rank, int nranks, const unsigned char *id_h);
 int ddh_comm_info(ddh_handle comm, int *rank, int *nranks);

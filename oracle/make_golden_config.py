@@ -1,0 +1,171 @@
+"""
+TEST INFRASTRUCTURE ONLY.  Config-size goldens of the curvilinear BASELINE configurations, made by the UNMODIFIED
+reference through oracle/refshim (run in the build container; the GPU box has no reference):
+
+  S  ivp_sphere_shallow_water at SphereBasis(512, 256): the reference's own per-m subproblem matrices M_min / L_min
+     (core/subsystems.py:497-596) for sampled m, the order of their unknowns / equations, and the end state of two
+     RK222 steps of the example (sub-sampled arrays + norms).
+  H  ivp_shell_convection at ShellBasis(256, 128, 128): the reference's per-(m, ell) subproblem matrices for sampled
+     ell.  Only those subproblems are BUILT (the reference's build_matrices is called with the sampled list instead of
+     all ~8000 subproblems: building every one takes the reference more than half an hour); the matrix code itself is
+     the reference's.
+
+The order of a subproblem's unknowns is recorded with tags: every variable's coefficient array is filled with its own
+flat indices, `Subproblem.gather_inputs` (core/subsystems.py:340-349) then returns, per unknown, which entry of which
+field it is (pre_right_pinv is a selection); likewise `gather_outputs` on the F fields for the equations.  The tests
+(tests/test_config_matrices.py, tests/test_gpu_sphere.py, tests/test_gpu_shell.py) tag this package's fields the same
+way, so no knowledge of either layout is needed to line the two up.
+
+    python oracle/make_golden_config.py [sphere] [shell]      ->  tests/golden/config_sphere.npz, config_shell.npz
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from oracle import refshim  # noqa: E402
+
+TAG = 2 ** 40
+
+
+def _tag(fields):
+    """fill every field's coefficient array with TAG * index + flat position; returns the saved data"""
+    saved = []
+    for i, f in enumerate(fields):
+        c = np.array(f['c'])
+        saved.append(c)
+        f['c'] = (i * TAG + np.arange(c.size, dtype=np.float64)).reshape(c.shape)
+    return saved
+
+
+def _untag(fields, saved):
+    for f, c in zip(fields, saved):
+        f['c'] = c
+
+
+def _ids(vec):
+    """(unknowns, subsystems) tags -> field index and flat coefficient position, same shape"""
+    v = np.asarray(vec).real
+    v = v.reshape(v.shape[0], -1)
+    ids = np.rint(v).astype(np.int64)
+    assert np.all(ids == v), "a subproblem entry is not a pure selection of one coefficient"
+    return (ids // TAG).astype(np.int32), (ids % TAG).astype(np.int64)
+
+
+def _csr(out, tag, m):
+    m = m.tocsr()
+    m.sort_indices()
+    out[tag + "_indptr"] = m.indptr.astype(np.int32)
+    out[tag + "_indices"] = m.indices.astype(np.int32)
+    out[tag + "_data"] = np.asarray(m.data)
+    out[tag + "_shape"] = np.array(m.shape)
+
+
+def _subproblem(out, tag, solver, sp):
+    for name in ("M_min", "L_min"):
+        _csr(out, tag + name, getattr(sp, name))
+    state, F = list(solver.state), list(solver.F)
+    s1 = _tag(state)
+    iv, ix = _ids(sp.gather_inputs(state).copy())
+    _untag(state, s1)
+    s2 = _tag(F)
+    ov, ox = _ids(sp.gather_outputs(F).copy())
+    _untag(F, s2)
+    out[tag + "in_var"], out[tag + "in_flat"] = iv, ix
+    out[tag + "out_eq"], out[tag + "out_flat"] = ov, ox
+
+
+def config_sphere(Nphi=512, Ntheta=256, ms=(0, 1, 2, 37, 128, 200, 253, 254), steps=2):
+    import problems
+    d3 = refshim.load_reference()
+    t0 = time.time()
+    solver, fields, extra = problems.shallow_water(d3, Nphi=Nphi, Ntheta=Ntheta, timestepper="RK222")
+    print("reference sphere %d x %d built in %.1f s, %d subproblems" % (Nphi, Ntheta, time.time() - t0, len(solver.subproblems)))
+    out = {"shape": np.array([Nphi, Ntheta]), "ms": np.array(ms), "steps": np.array(steps),
+           "variables": np.array([v.name for v in solver.problem.variables])}
+    out["coeff_shapes"] = np.array([len(np.array(f['c']).shape) for f in solver.state])
+    for i, f in enumerate(solver.state):
+        out["cshape_%d" % i] = np.array(np.array(f['c']).shape)
+    for i, f in enumerate(solver.F):
+        out["fshape_%d" % i] = np.array(np.array(f['c']).shape)
+    by_m = {int(sp.group[0]): sp for sp in solver.subproblems}
+    for m in ms:
+        _subproblem(out, "m%d__" % m, solver, by_m[m])
+    out["h_balanced_norm"] = np.array(np.linalg.norm(extra["h_balanced"]))
+    out["h_balanced_sub"] = np.array(extra["h_balanced"])[::16, ::8]
+    t0 = time.time()
+    for _ in range(steps):
+        solver.step(extra["timestep"])
+    print("%d reference steps in %.1f s" % (steps, time.time() - t0))
+    for k, f in fields.items():
+        f.change_scales(1)
+        c = np.array(f['c'])
+        out["end__%s_norm" % k] = np.array(np.linalg.norm(c))
+        out["end__%s_sub" % k] = c[..., ::4, :]                  # every 4th row of the packed azimuthal axis, all ell
+        print(k, c.shape, float(np.linalg.norm(c)))
+    path = os.path.join(GOLD, "config_sphere.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) >> 10, "KiB")
+
+
+def config_shell(shape=(256, 128, 128), ells=(0, 1, 2, 50, 126)):
+    import problems
+    d3 = refshim.load_reference()
+    import dedalus.core.solvers as rsolvers
+    # build only the sampled subproblems' matrices: the reference's build_matrices with a shorter list
+    wanted = {}
+    orig = rsolvers.SolverBase.build_matrices
+
+    def build_some(self, subproblems=None, matrices=None):
+        subs = self.subproblems if subproblems is None else subproblems
+        pick = []
+        for sp in subs:
+            m, ell = sp.group[0], sp.group[1]
+            if ell in ells and (ell not in wanted):
+                wanted[ell] = sp
+                pick.append(sp)
+        print("building %d of %d subproblems: groups %s" % (len(pick), len(subs), [sp.group for sp in pick]), flush=True)
+        from scipy import sparse
+        for sp in subs:
+            if sp not in pick:
+                sp.pre_left = sparse.csr_matrix((1, 1))      # only its shape is read (the solver's mode count)
+        return orig(self, pick, matrices)
+
+    # no step is taken: a do-nothing timestepper keeps the solver constructor from sizing its work arrays on the
+    # subproblems that were not built
+    d3._NoStepper = type("_NoStepper", (), {"__init__": lambda self, solver: None, "steps": 1, "stages": 1})
+    rsolvers.SolverBase.build_matrices = build_some
+    try:
+        t0 = time.time()
+        solver, f = problems.shell_convection(d3, shape=shape, timestepper="_NoStepper")
+        print("reference shell %s: solver object in %.1f s" % (shape, time.time() - t0), flush=True)
+    finally:
+        rsolvers.SolverBase.build_matrices = orig
+    out = {"shape": np.array(shape), "ells": np.array(ells),
+           "variables": np.array([v.name for v in solver.problem.variables])}
+    for i, fld in enumerate(solver.state):
+        out["cshape_%d" % i] = np.array(np.array(fld['c']).shape)
+    for i, fld in enumerate(solver.F):
+        out["fshape_%d" % i] = np.array(np.array(fld['c']).shape)
+    for ell in ells:
+        sp = wanted[ell]
+        out["ell%d__group" % ell] = np.array([-1 if g is None else g for g in sp.group])
+        _subproblem(out, "ell%d__" % ell, solver, sp)
+        print("ell", ell, "group", sp.group, "size", sp.M_min.shape, flush=True)
+    path = os.path.join(GOLD, "config_shell.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) >> 10, "KiB")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["sphere", "shell"]
+    if "sphere" in which:
+        config_sphere()
+    if "shell" in which:
+        config_shell()

@@ -173,3 +173,56 @@ def test_transpose_planner_signature_one_rank():
     plan.localize_columns(b, c)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_matsolver_adapter_vs_superlu():
+    """B2 (libraries/matsolvers.py:10-27): bindings.HipBandMatsolver(matrix, solver).solve(vector) registered through a
+    registry of the reference's shape, against scipy's SuperLU -- a banded matrix (device band LU), a tau-bordered
+    Chebyshev matrix with boundary rows and tau columns (the engine's dense path), and a complex one."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from dedalus_amd import bindings
+    from dedalus_amd.tools import jacobi
+    registry = {}
+
+    def add_solver(cls):                                   # libraries/matsolvers.py:10-13
+        registry[cls.__name__.lower()] = cls
+        return cls
+
+    bindings.install_matsolver(add_solver)
+    cls = registry["hipbandmatsolver"]
+    rng = np.random.default_rng(3)
+    # (1) banded, kl = 3, ku = 5, not symmetric, needs pivoting here and there
+    N = 200
+    A = sp.diags([rng.standard_normal(N - abs(o)) for o in range(-3, 6)], list(range(-3, 6)), format="csr")
+    A = A + sp.diags(0.3 * rng.standard_normal(N), 0)
+    s = cls(A, None)
+    assert s.band
+    b = rng.standard_normal(N)
+    assert rel(s.solve(b), spla.splu(A.tocsc()).solve(b)) < 1e-10
+    B = rng.standard_normal((N, 3))
+    assert rel(s.solve(B), spla.splu(A.tocsc()).solve(B)) < 1e-10
+    # (2) tau-bordered second-order Chebyshev problem u'' - 4 u = f, u(-1) = u(1) = 0 (two tau columns, two dense rows)
+    Nz = 64
+    D1 = jacobi.differentiation_matrix(Nz, -0.5, -0.5)
+    D2 = jacobi.differentiation_matrix(Nz, 0.5, 0.5) @ D1
+    C2 = jacobi.conversion_matrix(Nz, 0.5, 0.5, 1.5, 1.5) @ jacobi.conversion_matrix(Nz, -0.5, -0.5, 0.5, 0.5)
+    Lz = (D2 - 4.0 * C2).tolil()
+    taus = sp.lil_matrix((Nz, 2))
+    taus[Nz - 1, 0] = 1.0
+    taus[Nz - 2, 1] = 1.0
+    left = jacobi.polynomials(Nz, -0.5, -0.5, np.array([-1.0]))[:, 0]
+    right = jacobi.polynomials(Nz, -0.5, -0.5, np.array([1.0]))[:, 0]
+    bc = sp.lil_matrix((2, Nz + 2))
+    bc[0, :Nz] = left
+    bc[1, :Nz] = right
+    T = sp.vstack([bc, sp.hstack([Lz, taus])]).tocsr()
+    s2 = cls(T, None)
+    assert not s2.band
+    f = rng.standard_normal(Nz + 2)
+    assert rel(s2.solve(f), spla.splu(T.tocsc()).solve(f)) < 1e-9
+    # (3) complex banded
+    Ac = (A + 1j * sp.diags(rng.standard_normal(N - 1), 1)).tocsr()
+    s3 = cls(Ac, None)
+    bc_ = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    assert rel(s3.solve(bc_), spla.splu(Ac.tocsc()).solve(bc_)) < 1e-10

@@ -111,6 +111,11 @@ def test_flow_properties_reduce_on_device():
         x = rng.standard_normal(n)
         mn, mx, sm = solver.ex.reduce3(dev.from_host(x))
         assert mn == x.min() and mx == x.max() and abs(sm - x.sum()) <= 1e-12 * np.abs(x).sum()
+    # a blown-up field must be visible: NaN propagates like np.min / np.max (fmin / fmax would drop it)
+    x = rng.standard_normal(70001)
+    x[12345] = np.nan
+    mn, mx, sm = solver.ex.reduce3(dev.from_host(x))
+    assert np.isnan(mn) and np.isnan(mx) and np.isnan(sm)
 
 
 def test_file_output_and_restart_from_device_fields(tmp_path):
@@ -186,3 +191,25 @@ def test_direct_right_hand_side_path_on_the_device(monkeypatch):
         for k in ("p", "b", "u"):
             a1, a0 = np.array(f1[k]['c']), np.array(f0[k]['c'])
             assert np.isfinite(a1).all() and rel(a1, a0) < 1e-12, (k, rel(a1, a0))
+
+
+def test_reference_style_loop_loses_no_output(tmp_path):
+    """A script that never closes its handlers (`while solver.proceed: solver.step(dt)`, the reference's examples) still
+    finds every scheduled write in its file: the asynchronously staged last write is flushed when `proceed` turns False
+    (the reference writes inside process(), core/evaluator.py:366-700), and each write records the timestep of ITS step
+    (core/timesteppers.py:150, 608), not the previous one's."""
+    import dedalus_amd.public as d3
+    from dedalus_amd.tools import h5lite
+    solver, f = problems.rayleigh_benard_2d(d3, Nx=64, Nz=32)
+    snap = solver.evaluator.add_file_handler(str(tmp_path / "snap"), iter=2, max_writes=10)
+    snap.add_task(f["b"], name="b")
+    assert snap.async_staging
+    solver.stop_iteration = 5
+    dts = [1e-3, 2e-3, 3e-3, 4e-3, 5e-3]
+    while solver.proceed:
+        solver.step(dts[solver.iteration])
+    # no close(), no flush() by the script
+    r = h5lite.read(str(tmp_path / "snap" / "snap_s1.h5"))
+    assert np.array_equal(r["scales/iteration"].read(), [0, 2, 4])
+    assert np.allclose(r["scales/timestep"].read(), [dts[0], dts[2], dts[4]], rtol=0, atol=0)
+    assert np.isfinite(r["tasks/b"].read(2)).all()

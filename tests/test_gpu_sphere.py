@@ -106,40 +106,48 @@ def test_shallow_water_vs_reference(ts):
 
 
 def test_shallow_water_config_size():
-    """BASELINE config 4 at its real size, SphereBasis(512, 256) -> Lmax 254, 768 x 384 grid: every implicit solve of
-    two RK222 steps is compared, on sampled azimuthal wavenumbers m, with the oracle -- a direct LAPACK solve of that
-    m's (a M + b L) restricted to its valid modes (the reference's per-subproblem SuperLU solve,
-    libraries/matsolvers.py:126-149) -- plus the properties of the example: mass (the ell = 0 mode of h) is conserved
-    by the flux-form height equation and the fields stay finite."""
+    """BASELINE config 4 at its real size, SphereBasis(512, 256) -> Lmax 254, 768 x 384 grid, against the UNMODIFIED
+    reference at that size (tests/golden/config_sphere.npz, oracle/make_golden_config.py):
+      * the per-m system matrices a M + b L equal the reference's own subproblem matrices M_min / L_min
+        (core/subsystems.py:497-596) on sampled m, entry by entry, and carry nothing outside its valid modes;
+      * every implicit solve of two RK222 steps, gathered in the reference's order, satisfies the REFERENCE's matrix and
+        agrees with a LAPACK solve of it (libraries/matsolvers.py:126-149);
+      * the end state of the two steps equals the reference's (arrays sub-sampled 1:4 along the packed azimuthal axis,
+        and the norms of the full arrays);
+    plus the example's invariant: mass (the ell = 0 mode of h) is conserved by the flux-form height equation."""
     import dedalus_amd.public as d3
+    import config_check as cc
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "config_sphere.npz"))
+    assert tuple(G["shape"]) == (512, 256)
     solver, fields, extra = problems.shallow_water(d3, Nphi=512, Ntheta=256)
     assert solver.basis.Lmax == 254 and solver.basis.nm == 256
+    assert abs(np.linalg.norm(extra["h_balanced"]) - float(G["h_balanced_norm"])) < 1e-9 * float(G["h_balanced_norm"])
+    assert rel(np.array(extra["h_balanced"])[::16, ::8], G["h_balanced_sub"]) < 1e-9
+    Tin, Tout = cc.sphere_tags(solver, d3)
     h = fields["h"]
     h00_before = np.array(h['c'])[0, 0]
     solver.solve_probe = []
-    for _ in range(2):
+    for _ in range(int(G["steps"])):
         solver.step(extra["timestep"])
     recs, solver.solve_probe = solver.solve_probe, None
     assert len(recs) == 4
-    nl, R = solver.basis.nl, solver.R
-    worst = 0.0
-    for rec in recs:
-        rhs = rec["rhs"].reshape(R, 2 * solver.basis.nm, nl)
-        x = rec["x"].reshape(R, 2 * solver.basis.nm, nl)
-        for m in (0, 1, 2, 37, 128, 200, 253, 254):
-            ne = nl - m
-            A = rec["a"] * solver._dense(solver.M_tl, m) + rec["b"] * solver._dense(solver.L_tl, m)
-            rv = solver.row_valid[:, m, m:].reshape(-1)
-            cv = solver.col_valid[:, m, m:].reshape(-1)
-            z = lambda v: (v[:, 2 * m, m:] + 1j * v[:, 2 * m + 1, m:]).reshape(-1)
-            r, got = z(rhs), z(x)
-            ref = np.zeros(R * ne, dtype=complex)
-            ref[cv] = np.linalg.solve(A[np.ix_(rv, cv)], r[rv])
-            err = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-300)
-            worst = max(worst, err)
-            assert err < 1e-10, (m, err)
-            assert np.all(got[~cv] == 0.0)
-    print("sphere 512x256: worst per-m solve error vs LAPACK on sampled m:", worst)
+    worst_m, worst_r, worst_x = 0.0, 0.0, 0.0
+    for m in (int(v) for v in G["ms"]):
+        for rec in recs:
+            A, slots, ign = cc.sphere_group(solver, m, rec["a"], rec["b"])
+            err, maps = cc.compare_group(A, slots, slots, Tin, Tout, G, "m%d__" % m, rec["a"], rec["b"], ignore=ign,
+                                         want_maps=True)
+            assert err < 1e-12, (m, err)
+            res, dx = cc.check_solve(maps, rec["rhs"], rec["x"])
+            worst_m, worst_r, worst_x = max(worst_m, err), max(worst_r, res), max(worst_x, dx)
+            assert res < 1e-11 and dx < 1e-9, (m, res, dx)
+    print("sphere 512x256 vs reference: matrices %.1e, solve residual %.1e, solution vs LAPACK %.1e" % (worst_m, worst_r, worst_x))
+    for k, f in fields.items():
+        f.change_scales(1)
+        c = np.array(f['c'])
+        nref = float(G["end__%s_norm" % k])
+        assert abs(np.linalg.norm(c) - nref) < 1e-9 * nref, k
+        assert rel(c[..., ::4, :], G["end__%s_sub" % k]) < 1e-9, (k, rel(c[..., ::4, :], G["end__%s_sub" % k]))
     h00_after = np.array(h['c'])[0, 0]
     assert abs(h00_after - h00_before) <= 1e-12 * max(1.0, abs(h00_before))
     assert np.all(np.isfinite(np.array(fields["u"]['g'])))
