@@ -77,6 +77,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--cfl", action="store_true",
+                    help="after the fixed-dt measurement (the metric), also time the example's adaptive loop: "
+                         "d3.CFL(cadence=10, threshold=0.05) on an O(1) flow, i.e. with LHS refactorizations; reported "
+                         "as `cfl_mode` beside the fixed-dt value")
+    ap.add_argument("--cfl-steps", type=int, default=40)
     return ap.parse_args()
 
 
@@ -183,6 +188,43 @@ def parity_check(solver, dt):
                 max_invalid_mode=max((r["dropped_max"] for r in res), default=0.0))
 
 
+def adaptive_loop(d3, solver, fields, args, torch):
+    """The reference example's main loop (examples/ivp_2d_rayleigh_benard/rayleigh_benard.py:97-113): the timestep comes
+    from d3.CFL(cadence=10, safety=0.5, threshold=0.05, max_change=1.5, min_change=0.5) and every change re-forms and
+    re-factors every pencil's LHS (core/timesteppers.py:630-640).  The example's initial velocity is zero (the CFL limit
+    never binds), so an O(1) cellular flow is put into u first: the timestep then moves at (nearly) every cadence.
+    Not the metric -- the fixed-dt value is -- but what an adaptive run of the same problem costs."""
+    u = fields["u"]
+    ug = np.array(u["g"])
+    nx, ny, nz = ug.shape[1:]
+    ix, iy, iz = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    sz = np.sin(np.pi * (iz + 0.5) / nz)
+    ug[0] = 0.5 * np.sin(2 * np.pi * ix / nx) * sz * np.cos(2 * np.pi * iy / ny)
+    ug[1] = 0.5 * np.cos(2 * np.pi * ix / nx) * sz * np.sin(2 * np.pi * iy / ny)
+    ug[2] = 0.25 * np.cos(2 * np.pi * ix / nx) * np.cos(2 * np.pi * iy / ny) * sz ** 2
+    u["g"] = ug
+    cfl = d3.CFL(solver, initial_dt=args.dt, cadence=10, safety=0.5, threshold=0.05, max_change=1.5, min_change=0.5,
+                 max_dt=0.125)
+    cfl.add_velocity(u)
+    for _ in range(2):
+        solver.step(cfl.compute_timestep())
+    torch.cuda.synchronize()
+    t0 = time.time()
+    dts = []
+    for _ in range(args.cfl_steps):
+        dt = cfl.compute_timestep()
+        dts.append(float(dt))
+        solver.step(dt)
+    torch.cuda.synchronize()
+    el = time.time() - t0
+    changes = int(sum(1 for a, b in zip(dts[:-1], dts[1:]) if a != b))
+    finite = bool(np.isfinite(np.asarray(fields["b"]["c"])).all())
+    return dict(steps=args.cfl_steps, ms_per_step=1e3 * el / args.cfl_steps, value=args.cfl_steps / el,
+                unit="timesteps/sec", timestep_changes=changes, dt_first=dts[0], dt_last=dts[-1], finite=finite,
+                what="d3.CFL(cadence=10, threshold=0.05, safety=0.5) loop of the reference example on an O(1) flow; every "
+                     "timestep change refactors all pencils (factor kernel + device inversion of the mean-mode pencil)")
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -264,6 +306,7 @@ def main():
         parity["what"] = ("every solve of one extra step on a 4x4 sample of pencils (modes 0, 85, 170, 255) against the "
                           "reference's own M_min/L_min (SuperLU solution and residual); tests/pencil_check.py")
     chk = float(np.sqrt(chk2))
+    cfl_mode = adaptive_loop(d3, solver, fields, args, torch) if (args.cfl and world == 1) else None
 
     if rank == 0:
         steps_per_s = args.steps / el
@@ -299,6 +342,8 @@ def main():
             "build_s": build_s, "checksum_b_c_l2": chk, "parity": parity,
             "ranks_seen": ranks_seen, "dist_backend": backend, "exchange": exch,
         }
+        if cfl_mode is not None:
+            out["cfl_mode"] = cfl_mode
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline((Nx, Ny, Nz))
         print(json.dumps(out))

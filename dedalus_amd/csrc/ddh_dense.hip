@@ -82,7 +82,7 @@ dense_inverse_kernel(const DenseSys *__restrict__ sys, const void *__restrict__ 
     typedef DEl<CX> O;
     const DenseSys S = sys[blockIdx.x];
     const int n = S.n, tid = threadIdx.x;
-    if (n <= 0) return;
+    if (n <= 0 || n > DI_NMAX) return;           // larger systems: the multi-launch path (big_* kernels below)
     const E *M = (const E *)Mv + S.off, *L = (const E *)Lv + S.off;
     E *A = (E *)outv + S.off;
     const unsigned char *rv = row_valid + valid_off[blockIdx.x], *cv = col_valid + valid_off[blockIdx.x];
@@ -293,13 +293,193 @@ dense_inverse_kernel(const DenseSys *__restrict__ sys, const void *__restrict__ 
     if (tid == 0 && s_bad) flags[blockIdx.x] = 1;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Systems larger than one workgroup's reach (n > DI_NMAX; the mean-mode pencil of the 3-D Rayleigh-Benard problem is
+// 1289 x 1289): the same blocked Gauss-Jordan, one system at a time, split over launches -- a single-workgroup PANEL
+// kernel brings the BS pivot columns / rows of a block up to date (steps (1)-(4) above, pending vectors in global
+// memory) and a chip-wide UPDATE kernel applies the rank-BS update to the whole matrix.  The matrix lives in a scratch
+// buffer; a final gather undoes the row interchanges (as a column permutation) into the output slot.
+// ------------------------------------------------------------------------------------------------
+constexpr int BIG_BS = 16;
+constexpr int BIG_RW = 64;      // rows per workgroup of the update kernel
+
+template <bool CX>
+__global__ void __launch_bounds__(256)
+big_assemble_kernel(const void *__restrict__ Mv, const void *__restrict__ Lv, double a, double b,
+                    const unsigned char *__restrict__ rv, const unsigned char *__restrict__ cv, void *__restrict__ Av, int n) {
+    typedef typename DEl<CX>::T E;
+    typedef DEl<CX> O;
+    const E *M = (const E *)Mv, *L = (const E *)Lv;
+    E *A = (E *)Av;
+    const long nn = (long)n * n;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nn; e += (long)gridDim.x * 256) {
+        const int i = (int)(e / n), j = (int)(e - (long)i * n);
+        A[e] = (rv[i] && cv[j]) ? O::comb(M[e], L[e], a, b) : O::zero();
+    }
+}
+
+template <bool CX>
+__global__ void __launch_bounds__(256)
+big_pairs_kernel(void *__restrict__ Av, int n, const int *__restrict__ pr, const int *__restrict__ pc, int npair, int transpose_zero) {
+    typedef typename DEl<CX>::T E;
+    typedef DEl<CX> O;
+    E *A = (E *)Av;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < npair; k += gridDim.x * 256) {
+        if (transpose_zero) A[(long)pc[k] * n + pr[k]] = O::zero();      // after the inversion: not part of the inverse
+        else A[(long)pr[k] * n + pc[k]] = O::one();
+    }
+}
+
+template <bool CX, int BS>
+__global__ void __launch_bounds__(DI_T)
+big_panel_kernel(void *__restrict__ Av, int n, int k0, void *__restrict__ sUv, void *__restrict__ sRv, void *__restrict__ scv,
+                 int *__restrict__ s_piv, int *__restrict__ flag) {
+    typedef typename DEl<CX>::T E;
+    typedef DEl<CX> O;
+    E *A = (E *)Av, *sU = (E *)sUv, *sR = (E *)sRv, *s_col = (E *)scv;
+    const int tid = threadIdx.x;
+    __shared__ double s_best[DI_T / 64];
+    __shared__ int s_arg[DI_T / 64];
+    __shared__ int s_p;
+    const int nb = (n - k0 < BS) ? n - k0 : BS;
+    for (int s = 0; s < nb; ++s) {
+        const int k = k0 + s;
+        for (int i = tid; i < n; i += DI_T) {
+            E v = A[(long)i * n + k];
+            for (int t = 0; t < s; ++t) v = O::fms(v, sU[(size_t)t * n + i], sR[(size_t)t * n + k]);
+            s_col[i] = v;
+        }
+        __syncthreads();
+        double best = -1.0;
+        int arg = k;
+        for (int i = k + tid; i < n; i += DI_T) {
+            const double m = O::abs2(s_col[i]);
+            if (m > best) { best = m; arg = i; }
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+            const double ob = __shfl_xor(best, sft, 64);
+            const int oa = __shfl_xor(arg, sft, 64);
+            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+        }
+        if ((tid & 63) == 0) { s_best[tid >> 6] = best; s_arg[tid >> 6] = arg; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < DI_T / 64; ++w)
+                if (s_best[w] > best || (s_best[w] == best && s_arg[w] < arg)) { best = s_best[w]; arg = s_arg[w]; }
+            s_p = arg;
+            s_piv[k] = arg;
+            if (!(best > 0.0)) *flag = 1;
+        }
+        __syncthreads();
+        const int p = s_p;
+        if (p != k) {
+            for (int j = tid; j < n; j += DI_T) {
+                const E t = A[(long)k * n + j];
+                A[(long)k * n + j] = A[(long)p * n + j];
+                A[(long)p * n + j] = t;
+            }
+            if (tid < s) {
+                const E t = sU[(size_t)tid * n + k];
+                sU[(size_t)tid * n + k] = sU[(size_t)tid * n + p];
+                sU[(size_t)tid * n + p] = t;
+            }
+            if (tid == DI_T - 1) {
+                const E t = s_col[k];
+                s_col[k] = s_col[p];
+                s_col[p] = t;
+            }
+        }
+        __syncthreads();
+        E piv = s_col[k];
+        if (!(O::abs2(piv) > 0.0)) piv = O::one();
+        const E ip = O::inv(piv);
+        for (int j = tid; j < n; j += DI_T) {
+            const bool repl = (j >= k0 && j < k);
+            E v = repl ? O::zero() : A[(long)k * n + j];
+            for (int t = repl ? j - k0 : 0; t < s; ++t) v = O::fms(v, sU[(size_t)t * n + k], sR[(size_t)t * n + j]);
+            sR[(size_t)s * n + j] = (j == k) ? ip : O::mul(v, ip);
+            E u = s_col[j];
+            if (j == k) { u = piv; u = O::fms(u, O::one(), O::one()); }
+            sU[(size_t)s * n + j] = u;
+        }
+        __syncthreads();
+    }
+}
+
+template <bool CX, int BS>
+__global__ void __launch_bounds__(256)
+big_update_kernel(void *__restrict__ Av, int n, int k0, const void *__restrict__ sUv, const void *__restrict__ sRv) {
+    typedef typename DEl<CX>::T E;
+    typedef DEl<CX> O;
+    E *A = (E *)Av;
+    const E *sU = (const E *)sUv, *sR = (const E *)sRv;
+    __shared__ E su[BS][BIG_RW];
+    const int nb = (n - k0 < BS) ? n - k0 : BS;
+    const int i0 = blockIdx.y * BIG_RW;
+    for (int w = threadIdx.x; w < BS * BIG_RW; w += 256) {
+        const int t = w / BIG_RW, q = w - t * BIG_RW;
+        su[t][q] = (t < nb && i0 + q < n) ? sU[(size_t)t * n + i0 + q] : O::zero();
+    }
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const bool repl = (j >= k0 && j < k0 + nb);
+    const int t0 = repl ? j - k0 : 0;
+    E r[BS];
+#pragma unroll
+    for (int t = 0; t < BS; ++t) r[t] = (t >= t0 && t < nb) ? sR[(size_t)t * n + j] : O::zero();
+    const int rows = (n - i0 < BIG_RW) ? n - i0 : BIG_RW;
+    for (int q = 0; q < rows; ++q) {
+        const int i = i0 + q;
+        E v = repl ? ((i == j) ? O::one() : O::zero()) : A[(long)i * n + j];
+#pragma unroll
+        for (int t = 0; t < BS; ++t) v = O::fms(v, su[t][q], r[t]);
+        A[(long)i * n + j] = v;
+    }
+}
+
+// out[i][j] = A[i][src[j]] with src = the column permutation that undoes the row interchanges in reverse order
+template <bool CX>
+__global__ void __launch_bounds__(256)
+big_unpivot_kernel(const void *__restrict__ Av, void *__restrict__ outv, int n, const int *__restrict__ piv) {
+    typedef typename DEl<CX>::T E;
+    const E *A = (const E *)Av;
+    E *out = (E *)outv;
+    extern __shared__ int s_src[];
+    for (int j = threadIdx.x; j < n; j += 256) s_src[j] = j;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // the column swaps (k, piv[k]), k = n - 1 .. 0, applied to A in turn: column j of the result is column s_src[j] of A
+        for (int k = n - 1; k >= 0; --k) {
+            const int p = piv[k];
+            if (p != k) {
+                const int t = s_src[k];
+                s_src[k] = s_src[p];
+                s_src[p] = t;
+            }
+        }
+    }
+    __syncthreads();
+    const int i0 = blockIdx.x * BIG_RW;
+    for (int q = 0; q < BIG_RW && i0 + q < n; ++q) {
+        const long row = (long)(i0 + q) * n;
+        for (int j = threadIdx.x; j < n; j += 256) out[row + j] = A[row + s_src[j]];
+    }
+}
+
 struct DenseInverse : HandleBase {
     int nsys = 0, cx = 0;
     long total = 0;               // elements over all systems
     void *d_sys = nullptr, *d_M = nullptr, *d_L = nullptr, *d_rv = nullptr, *d_cv = nullptr, *d_voff = nullptr;
     void *d_pr = nullptr, *d_pc = nullptr, *d_flags = nullptr;
     std::vector<int> n_host;
+    std::vector<DenseSys> sys_host;
+    std::vector<long> voff_host;
+    void *d_big = nullptr, *d_bU = nullptr, *d_bR = nullptr, *d_bcol = nullptr, *d_bpiv = nullptr;   // n > DI_NMAX systems
     ~DenseInverse() override {
+        (void)hipFree(d_big); (void)hipFree(d_bU); (void)hipFree(d_bR); (void)hipFree(d_bcol); (void)hipFree(d_bpiv);
         (void)hipFree(d_sys); (void)hipFree(d_M); (void)hipFree(d_L); (void)hipFree(d_rv); (void)hipFree(d_cv);
         (void)hipFree(d_voff); (void)hipFree(d_pr); (void)hipFree(d_pc); (void)hipFree(d_flags);
     }
@@ -340,7 +520,7 @@ int ddh_dense_inverse_create(ddh_handle *h, int nsys, const int *n_h, int is_com
     long off = 0, vo = 0;
     for (int s = 0; s < nsys; ++s) {
         const int n = n_h[s];
-        if (n < 0 || n > DI_NMAX) { delete p; return fail("dense_inverse_create: system size out of range (0..1024)"); }
+        if (n < 0 || n > 16384) { delete p; return fail("dense_inverse_create: system size out of range (0..16384)"); }
         sys[s].off = off;
         sys[s].n = n;
         sys[s].pair0 = (int)pr.size();
@@ -358,6 +538,8 @@ int ddh_dense_inverse_create(ddh_handle *h, int nsys, const int *n_h, int is_com
     }
     p->total = off;
     p->n_host.assign(n_h, n_h + nsys);
+    p->sys_host = sys;
+    p->voff_host = voff;
     const size_t eb = (p->cx ? 2 : 1) * sizeof(double);
     int st = 0;
     auto up = [&](void **d, const void *src, size_t bytes) {
@@ -407,18 +589,73 @@ int ddh_dense_inverse_compute(ddh_handle h, double a, double b, double *out_d, i
     }
     const size_t budget = 150 * 1024;      // of the CU's 160 KiB (the kernel keeps ~5 KiB of static arrays)
     static const int bs_env = getenv("DDH_DENSE_BS") ? atoi(getenv("DDH_DENSE_BS")) : 0;
-    if (p->cx) {
-        // (5 instead of 4 pending updates fit for n <= 870 and were measured on the sphere's 256 systems: no change,
-        // 195 ms -- there the largest systems, one workgroup each, set the time)
-        DDH_DI_LAUNCH(true, 4, double2)
-    } else {
-        int bs = 8;
-        if ((size_t)(2 * 12 + 1) * nmax * sizeof(double) <= budget) bs = 12;
-        if (bs_env) bs = bs_env;
-        if (bs == 12) DDH_DI_LAUNCH(false, 12, double) else DDH_DI_LAUNCH(false, 8, double)
+    int nbig = 0, nmax_big = 0;
+    nmax = 0;
+    for (int v : p->n_host) {
+        if (v > DI_NMAX) {
+            ++nbig;
+            nmax_big = v > nmax_big ? v : nmax_big;
+        } else {
+            nmax = v > nmax ? v : nmax;
+        }
+    }
+    if (nmax > 0) {
+        if (p->cx) {
+            // (5 instead of 4 pending updates fit for n <= 870 and were measured on the sphere's 256 systems: no change,
+            // 195 ms -- there the largest systems, one workgroup each, set the time)
+            DDH_DI_LAUNCH(true, 4, double2)
+        } else {
+            int bs = 8;
+            if ((size_t)(2 * 12 + 1) * nmax * sizeof(double) <= budget) bs = 12;
+            if (bs_env) bs = bs_env;
+            if (bs == 12) DDH_DI_LAUNCH(false, 12, double) else DDH_DI_LAUNCH(false, 8, double)
+        }
     }
 #undef DDH_DI_LAUNCH
     DDH_HIP(hipGetLastError());
+    if (nbig) {
+        const size_t eb = (p->cx ? 2 : 1) * sizeof(double);
+        if (!p->d_big) {
+            DDH_HIP(hipMalloc(&p->d_big, (size_t)nmax_big * nmax_big * eb));
+            DDH_HIP(hipMalloc(&p->d_bU, (size_t)BIG_BS * nmax_big * eb));
+            DDH_HIP(hipMalloc(&p->d_bR, (size_t)BIG_BS * nmax_big * eb));
+            DDH_HIP(hipMalloc(&p->d_bcol, (size_t)nmax_big * eb));
+            DDH_HIP(hipMalloc(&p->d_bpiv, (size_t)nmax_big * sizeof(int)));
+        }
+        for (int sidx = 0; sidx < p->nsys; ++sidx) {
+            const DenseSys &S = p->sys_host[sidx];
+            const int n = S.n;
+            if (n <= DI_NMAX) continue;
+            const char *Mp = (const char *)p->d_M + (size_t)S.off * eb, *Lp = (const char *)p->d_L + (size_t)S.off * eb;
+            const unsigned char *rvp = (const unsigned char *)p->d_rv + p->voff_host[sidx];
+            const unsigned char *cvp = (const unsigned char *)p->d_cv + p->voff_host[sidx];
+            const int *prp = (const int *)p->d_pr + S.pair0, *pcp = (const int *)p->d_pc + S.pair0;
+            char *outp = (char *)out_d + (size_t)S.off * eb;
+            int *flagp = (int *)p->d_flags + sidx;
+            const dim3 ugrid((unsigned)((n + 255) / 256), (unsigned)((n + BIG_RW - 1) / BIG_RW));
+#define DDH_BIG(CXV)                                                                                                   \
+    {                                                                                                                  \
+        hipLaunchKernelGGL(big_assemble_kernel<CXV>, dim3(2048), dim3(256), 0, s, Mp, Lp, a, b, rvp, cvp, p->d_big, n); \
+        if (S.npair)                                                                                                   \
+            hipLaunchKernelGGL(big_pairs_kernel<CXV>, dim3((unsigned)((S.npair + 255) / 256)), dim3(256), 0, s,         \
+                               p->d_big, n, prp, pcp, S.npair, 0);                                                     \
+        for (int k0 = 0; k0 < n; k0 += BIG_BS) {                                                                       \
+            hipLaunchKernelGGL((big_panel_kernel<CXV, BIG_BS>), dim3(1), dim3(DI_T), 0, s, p->d_big, n, k0, p->d_bU,    \
+                               p->d_bR, p->d_bcol, (int *)p->d_bpiv, flagp);                                           \
+            hipLaunchKernelGGL((big_update_kernel<CXV, BIG_BS>), ugrid, dim3(256), 0, s, p->d_big, n, k0, p->d_bU,      \
+                               p->d_bR);                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL(big_unpivot_kernel<CXV>, dim3((unsigned)((n + BIG_RW - 1) / BIG_RW)), dim3(256),             \
+                           (size_t)n * sizeof(int), s, p->d_big, (void *)outp, n, (const int *)p->d_bpiv);             \
+        if (S.npair)                                                                                                   \
+            hipLaunchKernelGGL(big_pairs_kernel<CXV>, dim3((unsigned)((S.npair + 255) / 256)), dim3(256), 0, s,         \
+                               (void *)outp, n, prp, pcp, S.npair, 1);                                                 \
+    }
+            if (p->cx) DDH_BIG(true) else DDH_BIG(false)
+#undef DDH_BIG
+        }
+        DDH_HIP(hipGetLastError());
+    }
     if (nsingular_h) {
         std::vector<int> f(p->nsys);
         DDH_HIP(hipMemcpyAsync(f.data(), p->d_flags, (size_t)p->nsys * sizeof(int), hipMemcpyDeviceToHost, s));

@@ -2289,6 +2289,32 @@ int ddh_pencil_set_dense_inverse(ddh_handle pack, int lu_id, const double *inv_h
     return 0;
 }
 
+/* the same from DEVICE memory, one system at a time: inv_d = N x N row-major inverse of system `sys` (= f * S + s in the
+ * order of ddh_pencil_flagged), real (is_complex = 0) or interleaved complex; widened / copied into the pack's storage
+ * on the stream.  With ddh_dense_inverse_* a change of the timestep needs no host linear algebra for flagged pencils. */
+__global__ void __launch_bounds__(256) widen_inverse_kernel(const double *__restrict__ src, double2 *__restrict__ dst, long nn,
+                                                            int cx) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nn; e += (long)gridDim.x * 256)
+        dst[e] = cx ? make_double2(src[2 * e], src[2 * e + 1]) : make_double2(src[e], 0.0);
+}
+
+int ddh_pencil_set_dense_inverse_dev(ddh_handle pack, int lu_id, int sys, const double *inv_d, int is_complex, void *stream) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_set_dense_inverse_dev: bad LU id");
+    LuFactor *lu = pp->lus[lu_id];
+    const size_t N = (size_t)lu->dev.N, nsys = (size_t)lu->nflag * pp->dev.S;
+    if (sys < 0 || (size_t)sys >= nsys) return fail("pencil_set_dense_inverse_dev: system index out of range");
+    if (!lu->d_inv) {
+        DDH_HIP(hipMalloc(&lu->d_inv, nsys * N * N * sizeof(double2)));
+        DDH_HIP(hipMalloc(&lu->d_dense_rhs, 2 * nsys * N * sizeof(double2)));
+    }
+    hipLaunchKernelGGL(widen_inverse_kernel, dim3(2048), dim3(256), 0, as_stream(stream), inv_d,
+                       (double2 *)lu->d_inv + (size_t)sys * N * N, (long)(N * N), is_complex);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
 int ddh_pencil_solve(ddh_handle pack, int lu_id, const double *rhs, double *x, void *stream) {
     PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
     if (!pp) return -1;

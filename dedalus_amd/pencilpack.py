@@ -156,46 +156,74 @@ class PencilPack:
             raise libhip.DdhError("%d pencils have a singular band block: problem structure unsupported by the "
                                   "bordered-band solver" % nflag)
         if nflag:
-            N = self.nrows
-            inv = np.zeros((nflag * self.S, N, N), dtype=np.complex128)
+            self._flagged_inverses(lu_id, matM, matL, a, b, row_perm, col_perm, ra, ca, cells[:nflag])
+        self.lu_meta[lu_id] = dict(nflag=nflag, a=a, b=b)
+        return lu_id
+
+    def _flagged_inverses(self, lu_id, matM, matL, a, b, row_perm, col_perm, ra, ca, cells):
+        """Explicit inverses of the flagged pencils (for Rayleigh-Benard: the mean mode, 1289 x 1289), formed and inverted
+        ON THE DEVICE (ddh_dense_inverse_*: M and L of those pencils are uploaded once, a change of the timestep costs no
+        host linear algebra -- numpy.linalg.inv of that one matrix was 204 of the 334 ms of a refactorization) and handed
+        to the pack with ddh_pencil_set_dense_inverse_dev.  Rows / columns that do not exist for a pencil are masked out
+        (their unknowns are exactly zero), as the reference's valid-mode filtering does (core/subsystems.py:540-556)."""
+        import os
+        N, S = self.nrows, self.S
+        key = (matM, matL, row_perm.tobytes(), col_perm.tobytes(), tuple(int(c) for c in cells))
+        cache = self.__dict__.setdefault("_flag_dinv", {})
+        if key not in cache:
             M, L = self.matrices[matM], self.matrices[matL]
-            for f in range(nflag):
-                cell = int(cells[f])
+            Ms, Ls, rvs, cvs, slots = [], [], [], [], []
+            for f, cell in enumerate(int(c) for c in cells):
                 mx, my = (cell // self.ncy, cell % self.ncy) if self.nf == 2 else (cell, 0)
                 kxv = self.kx[mx] if self.nf >= 1 else 0.0
                 kyv = self.ky[my] if self.nf == 2 else 0.0
-                for s in range(self.S):
-                    sign = 1 if s == 0 else -1
-                    gmx = mx + self.mx_offset
-                    if s == 1 and kxv == 0.0:
-                        inv[f * self.S + 1] = inv[f * self.S]       # lambda(-kx) == lambda(kx) at kx = 0
+                gmx = mx + self.mx_offset
+                rv = np.array([_valid(ra[i], gmx, my, self.nf) for i in range(N)], dtype=bool)
+                cv = np.array([_valid(ca[i], gmx, my, self.nf) for i in range(N)], dtype=bool)
+                for sidx in range(S):
+                    if sidx == 1 and kxv == 0.0:
+                        slots[-1].append(f * S + 1)                  # lambda(-kx) == lambda(kx) at kx = 0
                         continue
-                    # M, L of the pencil in logical ordering and the identity pairing of rows / columns that do not exist
-                    # for it do not depend on (a, b): kept across refactorizations (timestep changes)
-                    key = (matM, matL, cell, s, row_perm.tobytes(), col_perm.tobytes())
-                    cache = self.__dict__.setdefault("_flag_dense", {})
-                    if key not in cache:
-                        Md = M.dense(kxv, kyv, gmx, my, sign)[np.ix_(row_perm, col_perm)]
-                        Ld = L.dense(kxv, kyv, gmx, my, sign)[np.ix_(row_perm, col_perm)]
-                        bad_r = [i for i in range(N) if not _valid(ra[i], gmx, my, self.nf)]
-                        bad_c = [i for i in range(N) if not _valid(ca[i], gmx, my, self.nf)]
-                        npair = min(len(bad_r), len(bad_c))
-                        Id = (np.array(bad_r[:npair], dtype=np.int64), np.array(bad_c[:npair], dtype=np.int64))
-                        if not (Md.imag.any() or Ld.imag.any()):
-                            Md, Ld = Md.real.copy(), Ld.real.copy()
-                        if len(cache) > 8:
-                            cache.clear()
-                        cache[key] = (Md, Ld, Id)
-                    Md, Ld, Id = cache[key]
-                    A = a * Md + b * Ld
-                    A[Id] = 1.0
-                    # (the mean-mode pencil of a real operator is a real matrix: a real inversion is 3-4x cheaper)
-                    inv[f * self.S + s] = np.linalg.inv(A)
+                    sign = 1 if sidx == 0 else -1
+                    Ms.append(M.dense(kxv, kyv, gmx, my, sign)[np.ix_(row_perm, col_perm)])
+                    Ls.append(L.dense(kxv, kyv, gmx, my, sign)[np.ix_(row_perm, col_perm)])
+                    rvs.append(rv)
+                    cvs.append(cv)
+                    slots.append([f * S + sidx])
+            # (the mean-mode pencil of a real operator is a real matrix: a real inversion is 3-4x cheaper)
+            cx = any(m.imag.any() for m in Ms) or any(m.imag.any() for m in Ls)
+            if not cx:
+                Ms, Ls = [m.real.copy() for m in Ms], [m.real.copy() for m in Ls]
+            if os.environ.get("DDH_FLAG_HOST_INV", "0") == "1":        # A/B: the round-2 host inversion
+                cache[key] = ("host", Ms, Ls, rvs, cvs, slots, cx)
+            else:
+                from .executor import DenseInverse, HipExecutor
+                ex = self.executor if self.executor is not None else HipExecutor(self.dev)
+                if len(cache) > 4:
+                    cache.clear()
+                cache[key] = ("dev", DenseInverse(ex, Ms, Ls, rvs, cvs, cx), [m.shape[0] for m in Ms], slots, cx)
+        ent = cache[key]
+        if ent[0] == "host":
+            _, Ms, Ls, rvs, cvs, slots, cx = ent
+            inv = np.zeros((len(cells) * S, N, N), dtype=np.complex128)
+            for Md, Ld, rv, cv, sl in zip(Ms, Ls, rvs, cvs, slots):
+                A = (a * Md + b * Ld)[np.ix_(rv, cv)]
+                full = np.zeros((N, N), dtype=A.dtype)
+                full[np.ix_(cv, rv)] = np.linalg.inv(A)
+                for t in sl:
+                    inv[t] = full
             inv = np.ascontiguousarray(inv)
             libhip.call("ddh_pencil_set_dense_inverse", self.handle, lu_id,
                         inv.view(np.float64).ctypes.data_as(C.POINTER(C.c_double)))
-        self.lu_meta[lu_id] = dict(nflag=nflag, a=a, b=b)
-        return lu_id
+            return
+        _, dinv, sizes, slots, cx = ent
+        flat = dinv.compute(a, b)
+        off = 0
+        for n, sl in zip(sizes, slots):
+            for t in sl:
+                libhip.call("ddh_pencil_set_dense_inverse_dev", self.handle, lu_id, int(t),
+                            C.c_void_p(flat.data_ptr() + off * 8), int(cx), self.dev.stream)
+            off += n * n * (2 if cx else 1)
 
     def solve(self, lu_id, rhs, x):
         t = self._timer()

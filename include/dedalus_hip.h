@@ -349,6 +349,9 @@ int ddh_pencil_set_pairing(ddh_handle pack, const int *row_swap_h, const int *co
  * system, systems ordered (flagged cell, s).                                                      */
 int ddh_pencil_flagged(ddh_handle pack, int lu_id, int *count, long *cells_h, int max_cells);
 int ddh_pencil_set_dense_inverse(ddh_handle pack, int lu_id, const double *inv_h);
+/* the same from device memory, one system (index f * S + s) at a time, real or interleaved complex N x N row-major:
+ * formed by ddh_dense_inverse_compute, so a timestep change costs no host linear algebra for flagged pencils either */
+int ddh_pencil_set_dense_inverse_dev(ddh_handle pack, int lu_id, int sys, const double *inv_d, int is_complex, void *stream);
 int ddh_pencil_lu_bytes(ddh_handle pack, int lu_id, size_t *bytes);
 /* wrow_h[j] (n_interior ints) = max over all factorizations of the last non-zero super-diagonal offset of U row j:
  * how much of the partial-pivoting fill space (kl extra super-diagonals, LAPACK gbtrf storage) is really used.  */

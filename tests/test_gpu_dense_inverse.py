@@ -37,6 +37,38 @@ def test_batched_inverse_matches_numpy(cx):
             assert np.linalg.norm(got - ref) <= 1e-11 * max(np.linalg.norm(ref), 1.0), (n, a, b)
 
 
+@pytest.mark.parametrize("cx,n", [(False, 1289), (True, 1100), (False, 1025)])
+def test_large_system_goes_through_the_multi_launch_path(cx, n):
+    """n > 1024 (the mean-mode pencil of the 3-D Rayleigh-Benard problem is 1289 x 1289): panel + chip-wide rank-16 update
+    launches instead of one workgroup, mixed with small systems in one batch, masks included."""
+    from dedalus_amd.executor import HipExecutor
+    ex = HipExecutor()
+    rng = np.random.default_rng(n + cx)
+    sizes = [40, n, 3]
+    Ms, Ls, rvs, cvs = [], [], [], []
+    for m in sizes:
+        def rnd():
+            a = rng.standard_normal((m, m))
+            return a + 1j * rng.standard_normal((m, m)) if cx else a
+        M = rnd() / np.sqrt(m) + 2.0 * np.eye(m)
+        L = rnd() / np.sqrt(m)
+        rv = rng.random(m) > 0.05
+        cv = np.zeros(m, dtype=bool)
+        cv[rng.permutation(m)[:int(rv.sum())]] = True
+        Ms.append(M); Ls.append(L); rvs.append(rv); cvs.append(cv)
+    inv = ex.make_dense_inverse(Ms, Ls, rvs, cvs, complex_=cx)
+    for (a, b) in ((1.0, 0.37), (0.5, 1.0)):
+        flat = ex.download(inv.compute(a, b))
+        flat = flat.view(np.complex128) if cx else flat
+        pos = 0
+        for m, M, L, rv, cv in zip(sizes, Ms, Ls, rvs, cvs):
+            got = flat[pos:pos + m * m].reshape(m, m)
+            pos += m * m
+            ref = np.zeros((m, m), dtype=got.dtype)
+            ref[np.ix_(cv, rv)] = np.linalg.inv((a * M + b * L)[np.ix_(rv, cv)])
+            assert np.linalg.norm(got - ref) <= 1e-10 * max(np.linalg.norm(ref), 1.0), (m, a, b)
+
+
 def test_singular_system_is_reported():
     from dedalus_amd import libhip
     from dedalus_amd.executor import HipExecutor

@@ -6,7 +6,10 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import problems                                   # noqa: E402
 import dedalus_amd.public as d3                   # noqa: E402
 
