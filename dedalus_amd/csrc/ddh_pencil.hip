@@ -836,6 +836,235 @@ factor_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same factorization with the rows of an elimination step spread over the workgroup (round 3).
+// factor_kernel gives a whole system to one thread: 33 151 systems are 518 wavefronts -- half a wave per SIMD -- each
+// walking 1289 steps of ~450 dependent global read-modify-writes: 135 ms for 512 x 512 x 256, latency from end to end.
+// Here a workgroup is 64 systems (threadIdx.x, the coalescing lane of the factor layout, unchanged) x NT = kl + 1 + nb
+// row threads (threadIdx.y): thread (x, i) owns window row j + i of system x (i <= kl) or border row i - kl - 1.  A step
+// is three phases -- pivot search, row interchange, the kl (+ nb) independent row updates -- with a workgroup barrier in
+// between; the assembly of a M + b L is split over the same threads by physical row.  Same arithmetic in the same
+// order per entry as factor_kernel: the factors are bit-identical.
+// ------------------------------------------------------------------------------------------------
+constexpr int FR_NTMAX = 16;
+
+template <bool REAL>
+__device__ __forceinline__ void scatter_row(const PencilDev &P, const LuDev &L, const MatDev &A, double scale, int r, int i,
+                                            const int *__restrict__ colinv, const CellCtx &c, int s, long g, double &anorm,
+                                            bool &bad) {
+    typedef typename El<REAL>::T E;
+    E *Aw = (E *)L.Aw, *Ab = (E *)L.Ab;
+    if (scale == 0.0 || r >= A.nrows_out) return;
+    const int t1 = A.rowptr[r + 1];
+    for (int t = A.rowptr[r]; t < t1; ++t) {
+        const unsigned e = A.expo[t];
+        double f = term_factor(e, c) * scale;
+        if (s == 1 && (e & 1u)) f = -f;
+        if (f == 0.0) continue;
+        const double2 cf = A.coef[t];
+        const double2 v = make_double2(cf.x * f, cf.y * f);
+        const int cc = colinv[A.col[t]];
+        anorm = fmax(anorm, fabs(v.x) + fabs(v.y));
+        if (i < L.n) {
+            const int d = cc - i + L.kl;
+            if (d < 0 || cc - i > L.ku) {
+                bad = true;
+                continue;
+            }
+            E *p = Aw + lu_aw(L, g, i, d);
+            E o = *p;
+            El<REAL>::add(o, v);
+            *p = o;
+        } else {
+            E *p = Ab + lu_ab(L, g, cc, i - L.n);
+            E o = *p;
+            El<REAL>::add(o, v);
+            *p = o;
+        }
+    }
+}
+
+template <bool REAL>
+__global__ void __launch_bounds__(64 * FR_NTMAX)
+factor_rows_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, const int *__restrict__ rowinv,
+                   const int *__restrict__ colinv) {
+    typedef typename El<REAL>::T E;
+    const int tx = threadIdx.x, ty = threadIdx.y, NT = blockDim.y;
+    // the factor storage is allocated in whole blocks of 64: lanes beyond the last system factor an all-zero matrix in
+    // their own (unused) slot, with the cell data of the last system
+    const long g = (long)blockIdx.x * 64 + tx;
+    const long gc = g < L.GL ? g : L.GL - 1;
+    const long cell = REAL ? (L.pair ? L.slot_cell[gc] : gc) : gc / P.S;
+    const int s = REAL ? 0 : (int)(gc % P.S);
+    const CellCtx c = cell_ctx(P, cell);
+    const long G = L.GL;
+    E *Aw = (E *)L.Aw, *Ab = (E *)L.Ab;
+    const int n = L.n, nb = L.nb, N = L.N, kl = L.kl, W = L.W;
+    __shared__ double s_val[FR_NTMAX][64];
+    __shared__ int s_flag[FR_NTMAX][64];
+    double anorm = 0.0;
+    bool bad = false;
+    if (g < L.GL) {
+        for (int r = ty; r < N; r += NT) {
+            const int i = rowinv[r];
+            scatter_row<REAL>(P, L, M, a, r, i, colinv, c, s, g, anorm, bad);
+            scatter_row<REAL>(P, L, Lm, b, r, i, colinv, c, s, g, anorm, bad);
+        }
+    }
+    s_val[ty][tx] = anorm;
+    s_flag[ty][tx] = bad ? 1 : 0;
+    __syncthreads();
+    for (int t = 0; t < NT; ++t) {
+        anorm = fmax(anorm, s_val[t][tx]);
+        bad = bad || (s_flag[t][tx] != 0);
+    }
+    // border rows / columns that do not exist for this cell are paired into identity entries
+    if (ty == 0) {
+        int cb = 0;
+        for (int rb = 0; rb < nb; ++rb) {
+            if (axes_valid(L.row_axes[rb], c, P.nf)) continue;
+            while (cb < nb && axes_valid(L.col_axes[cb], c, P.nf)) ++cb;
+            if (cb < nb) {
+                Ab[lu_ab(L, g, n + cb, rb)] = El<REAL>::one();
+                ++cb;
+            }
+        }
+    }
+    const double tiny = 1e-13 * anorm;
+    bad = bad || (anorm == 0.0);
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const int imax = (j + kl < n) ? kl : (n - 1 - j);
+        const int wmax = (j + W < N) ? W : (N - 1 - j);   // columns j .. j+wmax
+        // ---- (A) pivot search among rows j .. j + imax
+        s_val[ty < FR_NTMAX ? ty : 0][tx] = (ty <= imax) ? El<REAL>::abs2(Aw[lu_aw(L, g, j + ty, kl - ty)]) : -1.0;
+        __syncthreads();
+        int p = 0;
+        {
+            double best = -1.0;
+            for (int i = 0; i <= imax; ++i) {
+                const double m = s_val[i][tx];
+                if (m > best) {
+                    best = m;
+                    p = i;
+                }
+            }
+        }
+        if (ty == 0) L.piv[lu_pv(L, g, j)] = (unsigned char)p;
+        // ---- (B) row interchange j <-> j + p, the entries dealt out to the row threads
+        if (p != 0) {
+            for (int d = ty; d <= wmax; d += NT) {
+                E *pa = Aw + lu_aw(L, g, j, kl + d);
+                E *pb = Aw + lu_aw(L, g, j + p, (kl - p) + d);
+                const E t = *pa;
+                *pa = *pb;
+                *pb = t;
+            }
+        }
+        __syncthreads();
+        // ---- (C) multipliers and row updates: one window row / border row per thread
+        E piv = Aw[lu_aw(L, g, j, kl)];
+        if (!(El<REAL>::abs2(piv) > tiny * tiny)) {
+            bad = true;
+            piv = El<REAL>::one();
+        }
+        const E ip = El<REAL>::inv(piv);
+        if (ty >= 1 && ty <= imax) {
+            E *pm = Aw + lu_aw(L, g, j + ty, kl - ty);
+            const E m = El<REAL>::mul(*pm, ip);
+            *pm = m;
+            if (!El<REAL>::is_zero(m)) {
+                for (int d = 1; d <= wmax; ++d) {
+                    E *pt = Aw + lu_aw(L, g, j + ty, (kl - ty) + d);
+                    E t = *pt;
+                    El<REAL>::fms(t, m, Aw[lu_aw(L, g, j, kl + d)]);
+                    *pt = t;
+                }
+            }
+        } else if (ty > kl && ty - kl - 1 < nb) {
+            const int rb = ty - kl - 1;
+            E *pm = Ab + lu_ab(L, g, j, rb);
+            const E m = El<REAL>::mul(*pm, ip);
+            *pm = m;
+            if (!El<REAL>::is_zero(m)) {
+                for (int d = 1; d <= wmax; ++d) {
+                    E *pt = Ab + lu_ab(L, g, j + d, rb);
+                    E t = *pt;
+                    El<REAL>::fms(t, m, Aw[lu_aw(L, g, j, kl + d)]);
+                    *pt = t;
+                }
+            }
+        }
+        __syncthreads();
+        // store the reciprocal pivot: the solve multiplies instead of dividing
+        if (ty == 0) Aw[lu_aw(L, g, j, kl)] = ip;
+    }
+    __syncthreads();
+    // ---- Schur block (nb x nb) at Ab[n + c][r]: invert in place by Gauss-Jordan with pivoting (one thread per system)
+    if (ty == 0 && nb > 0 && g < L.GL) {
+        E *Sinv = (E *)L.scratch;   // [nb*nb][GL] workspace
+        const long gs = g;
+        for (int r = 0; r < nb; ++r)
+            for (int cidx = 0; cidx < nb; ++cidx)
+                Sinv[((long)r * nb + cidx) * G + gs] = (r == cidx) ? El<REAL>::one() : El<REAL>::zero();
+        for (int k = 0; k < nb; ++k) {
+            int p = k;
+            double best = -1.0;
+            for (int r = k; r < nb; ++r) {
+                const double m = El<REAL>::abs2(Ab[lu_ab(L, g, n + k, r)]);
+                if (m > best) {
+                    best = m;
+                    p = r;
+                }
+            }
+            if (p != k) {
+                for (int cidx = 0; cidx < nb; ++cidx) {
+                    E *pa = Ab + lu_ab(L, g, n + cidx, k), *pb = Ab + lu_ab(L, g, n + cidx, p);
+                    E t = *pa;
+                    *pa = *pb;
+                    *pb = t;
+                    pa = Sinv + ((long)k * nb + cidx) * G + gs;
+                    pb = Sinv + ((long)p * nb + cidx) * G + gs;
+                    t = *pa;
+                    *pa = *pb;
+                    *pb = t;
+                }
+            }
+            E piv = Ab[lu_ab(L, g, n + k, k)];
+            if (!(El<REAL>::abs2(piv) > tiny * tiny)) {
+                bad = true;
+                piv = El<REAL>::one();
+            }
+            const E ip = El<REAL>::inv(piv);
+            for (int cidx = 0; cidx < nb; ++cidx) {
+                E *pa = Ab + lu_ab(L, g, n + cidx, k);
+                *pa = El<REAL>::mul(*pa, ip);
+                pa = Sinv + ((long)k * nb + cidx) * G + gs;
+                *pa = El<REAL>::mul(*pa, ip);
+            }
+            for (int r = 0; r < nb; ++r) {
+                if (r == k) continue;
+                const E m = Ab[lu_ab(L, g, n + k, r)];
+                if (El<REAL>::is_zero(m)) continue;
+                for (int cidx = 0; cidx < nb; ++cidx) {
+                    E *pt = Ab + lu_ab(L, g, n + cidx, r);
+                    E t = *pt;
+                    El<REAL>::fms(t, m, Ab[lu_ab(L, g, n + cidx, k)]);
+                    *pt = t;
+                    pt = Sinv + ((long)r * nb + cidx) * G + gs;
+                    t = *pt;
+                    El<REAL>::fms(t, m, Sinv[((long)k * nb + cidx) * G + gs]);
+                    *pt = t;
+                }
+            }
+        }
+        for (int r = 0; r < nb; ++r)
+            for (int cidx = 0; cidx < nb; ++cidx)
+                Ab[lu_ab(L, g, n + cidx, r)] = Sinv[((long)r * nb + cidx) * G + gs];
+    }
+    if (ty == 0 && g < L.GL) L.flag[g] = bad ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // solve: forward sweep (row interchanges, band multipliers, border multipliers), Schur block,
 // backward sweep with a register window of the last W solution entries.
 // ------------------------------------------------------------------------------------------------
@@ -2198,7 +2427,18 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
     if (!st) st = upload_vec(&d_colinv, colinv.data(), (size_t)N);
     if (st) { if (!reuse) free_lu(lu); return st; }
     const unsigned blocks = (unsigned)((GL + 63) / 64);
-    if (real)
+    // rows of an elimination step spread over the workgroup (factor_rows_kernel) when kl + 1 + nb row threads fit one;
+    // DDH_FACTOR_ROWS=0: one thread per system (factor_kernel)
+    static const bool rows_off = getenv("DDH_FACTOR_ROWS") && atoi(getenv("DDH_FACTOR_ROWS")) == 0;
+    const int NT = d.kl + 1 + d.nb;
+    if (!rows_off && NT <= FR_NTMAX && GL >= 64) {
+        if (real)
+            hipLaunchKernelGGL(factor_rows_kernel<true>, dim3(blocks), dim3(64, NT), 0, s, P, d, pp->mats[matM_id]->dev,
+                               pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
+        else
+            hipLaunchKernelGGL(factor_rows_kernel<false>, dim3(blocks), dim3(64, NT), 0, s, P, d, pp->mats[matM_id]->dev,
+                               pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
+    } else if (real)
         hipLaunchKernelGGL(factor_kernel<true>, dim3(blocks), dim3(64), 0, s, P, d, pp->mats[matM_id]->dev,
                            pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
     else
