@@ -1065,6 +1065,246 @@ factor_rows_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b
 }
 
 // ------------------------------------------------------------------------------------------------
+// Register-window variant of the row-parallel factorization: a row thread KEEPS its band row in registers for the kl + 1
+// steps the row spends in the elimination window (row r belongs to thread r mod (kl + 1)).  A row is read from the
+// assembled band storage once, when it enters the window, and written once, as a finished U row, when it becomes the
+// pivot row; in between it is updated in registers against the pivot row, which the workgroup shares through LDS (as is
+// the row displaced by an interchange).  factor_rows_kernel re-reads and re-writes the whole (kl + 1) x (W + 1) window
+// from global memory every step: 7.5 MB per system against ~0.9 MB here.  Same operations per entry in the same order:
+// bit-identical factors.
+// ------------------------------------------------------------------------------------------------
+constexpr int FW_WMAX = 36;      // window columns kl + ku + 1 held per thread
+
+template <bool REAL>
+__global__ void __launch_bounds__(64 * FR_NTMAX)
+factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, const int *__restrict__ rowinv,
+                     const int *__restrict__ colinv) {
+    typedef typename El<REAL>::T E;
+    const int tx = threadIdx.x, ty = threadIdx.y, NT = blockDim.y;
+    const long g = (long)blockIdx.x * 64 + tx;
+    const long gc = g < L.GL ? g : L.GL - 1;
+    const long cell = REAL ? (L.pair ? L.slot_cell[gc] : gc) : gc / P.S;
+    const int s = REAL ? 0 : (int)(gc % P.S);
+    const CellCtx c = cell_ctx(P, cell);
+    const long G = L.GL;
+    E *Aw = (E *)L.Aw, *Ab = (E *)L.Ab;
+    const int n = L.n, nb = L.nb, N = L.N, kl = L.kl, W = L.W, KL1 = L.kl + 1;
+    extern __shared__ double s_dyn_fw[];
+    E *s_piv = (E *)s_dyn_fw;                         // [FW_WMAX][64] the pivot row of the step
+    E *s_disp = s_piv + FW_WMAX * 64;                 // [FW_WMAX][64] the row an interchange displaces
+    __shared__ double s_val[FR_NTMAX][64];
+    __shared__ int s_flag[FR_NTMAX][64];
+    double anorm = 0.0;
+    bool bad = false;
+    if (g < L.GL) {
+        for (int r = ty; r < N; r += NT) {
+            const int i = rowinv[r];
+            scatter_row<REAL>(P, L, M, a, r, i, colinv, c, s, g, anorm, bad);
+            scatter_row<REAL>(P, L, Lm, b, r, i, colinv, c, s, g, anorm, bad);
+        }
+    }
+    s_val[ty][tx] = anorm;
+    s_flag[ty][tx] = bad ? 1 : 0;
+    __syncthreads();
+    for (int t = 0; t < NT; ++t) {
+        anorm = fmax(anorm, s_val[t][tx]);
+        bad = bad || (s_flag[t][tx] != 0);
+    }
+    if (ty == 0) {
+        int cb = 0;
+        for (int rb = 0; rb < nb; ++rb) {
+            if (axes_valid(L.row_axes[rb], c, P.nf)) continue;
+            while (cb < nb && axes_valid(L.col_axes[cb], c, P.nf)) ++cb;
+            if (cb < nb) {
+                Ab[lu_ab(L, g, n + cb, rb)] = El<REAL>::one();
+                ++cb;
+            }
+        }
+    }
+    const double tiny = 1e-13 * anorm;
+    bad = bad || (anorm == 0.0);
+    __syncthreads();                                   // the assembled matrix is in global memory, visible to the workgroup
+    const bool interior = ty <= kl;
+    const int rb = ty - kl - 1;                        // border row of a border thread
+    int my_row = ty;                                   // interior: the row this thread holds
+    E reg[FW_WMAX];                                    // reg[w]: the entry of my row in column j + w
+#pragma unroll
+    for (int w = 0; w < FW_WMAX; ++w) {
+        reg[w] = El<REAL>::zero();
+        if (w <= W) {
+            if (interior) {
+                if (my_row < n) reg[w] = Aw[lu_aw(L, g, my_row, kl - my_row + w)];     // column w of row r <= kl
+            } else if (rb < nb && w < N) {
+                reg[w] = Ab[lu_ab(L, g, w, rb)];
+            }
+        }
+    }
+    for (int j = 0; j < n; ++j) {
+        const int imax = (j + kl < n) ? kl : (n - 1 - j);
+        const int wmax = (j + W < N) ? W : (N - 1 - j);
+        const int i = my_row - j;                      // my row's slot in the window (interior threads)
+        const bool live = interior && my_row < n;      // then 0 <= i <= imax
+        // ---- (A) pivot search: candidates in slot order
+        if (interior) s_val[ty][tx] = live ? El<REAL>::abs2(reg[0]) : -1.0;
+        __syncthreads();
+        int p = 0;
+        {
+            double best = -1.0;
+            int t = j % KL1;
+            for (int q = 0; q <= imax; ++q) {
+                const double m = s_val[t][tx];
+                if (m > best) {
+                    best = m;
+                    p = q;
+                }
+                if (++t == KL1) t = 0;
+            }
+        }
+        if (live && i == 0) L.piv[lu_pv(L, g, j)] = (unsigned char)p;
+        // ---- (B) the pivot row (slot p) and the row it displaces (slot 0) go through LDS
+        if (live && i == p) {
+#pragma unroll
+            for (int w = 0; w < FW_WMAX; ++w) {
+                if (w <= W) s_piv[w * 64 + tx] = reg[w];
+                if ((w & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (live && i == 0) {
+#pragma unroll
+            for (int w = 0; w < FW_WMAX; ++w) {
+                if (w <= W) s_disp[w * 64 + tx] = reg[w];
+                if ((w & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        E piv = s_piv[tx];
+        if (!(El<REAL>::abs2(piv) > tiny * tiny)) {
+            bad = true;
+            piv = El<REAL>::one();
+        }
+        const E ip = El<REAL>::inv(piv);
+        if (live && i == p && p != 0) {                // the old row j lives on in slot p
+#pragma unroll
+            for (int w = 0; w < FW_WMAX; ++w) {
+                if (w <= W) reg[w] = s_disp[w * 64 + tx];
+                if ((w & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- (C) multiplier and update of my row (slots 1 .. imax, border rows)
+        const bool upd = (live && i >= 1) || (!interior && rb < nb);
+        if (upd) {
+            const E m = El<REAL>::mul(reg[0], ip);
+            if (interior) Aw[lu_aw(L, g, my_row, kl - i)] = m;
+            else Ab[lu_ab(L, g, j, rb)] = m;
+            if (!El<REAL>::is_zero(m)) {
+#pragma unroll
+                for (int w = 1; w < FW_WMAX; ++w) {
+                    if (w <= wmax) El<REAL>::fms(reg[w], m, s_piv[w * 64 + tx]);
+                    if ((w & 7) == 7) __builtin_amdgcn_sched_barrier(0);       // at most 8 LDS reads in flight (registers)
+                }
+            }
+        }
+        // the finished U row j (reciprocal pivot in front), dealt out to the row threads
+        for (int d = ty; d <= wmax; d += NT) Aw[lu_aw(L, g, j, kl + d)] = (d == 0) ? ip : s_piv[d * 64 + tx];
+        // ---- advance the window
+        if (interior && live && i == 0) {
+            my_row = j + kl + 1;                       // the row entering the window takes this thread
+            {
+                const E *rowp = Aw + lu_aw(L, g, my_row < n ? my_row : 0, 0);         // one base, entry offsets added per load
+#pragma unroll
+                for (int w = 0; w < FW_WMAX; ++w) {
+                    reg[w] = El<REAL>::zero();
+                    if (w <= W && my_row < n) reg[w] = rowp[lu_eoff(L, w + L.kpad) - lu_eoff(L, L.kpad)];
+                    if ((w & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w + 1 < FW_WMAX; ++w) reg[w] = reg[w + 1];
+            reg[FW_WMAX - 1] = El<REAL>::zero();
+            if (!interior && rb < nb) {
+                // the column entering a border row's window
+                const int cn = j + 1 + W;
+#pragma unroll
+                for (int w = 0; w < FW_WMAX; ++w)
+                    if (w == W) reg[w] = (cn < N) ? Ab[lu_ab(L, g, cn, rb)] : El<REAL>::zero();
+            }
+        }
+        // (no barrier: s_val / s_piv / s_disp are rewritten only after the next step's barriers)
+    }
+    // border rows: what is left of their window are the columns n .. N - 1
+    if (!interior && rb < nb) {
+#pragma unroll
+        for (int w = 0; w < FW_WMAX; ++w)
+            if (w < N - n) Ab[lu_ab(L, g, n + w, rb)] = reg[w];
+    }
+    __syncthreads();
+    if (ty == 0 && nb > 0 && g < L.GL) {
+        E *Sinv = (E *)L.scratch;   // [nb*nb][GL] workspace
+        const long gs = g;
+        for (int r = 0; r < nb; ++r)
+            for (int cidx = 0; cidx < nb; ++cidx)
+                Sinv[((long)r * nb + cidx) * G + gs] = (r == cidx) ? El<REAL>::one() : El<REAL>::zero();
+        for (int k = 0; k < nb; ++k) {
+            int p = k;
+            double best = -1.0;
+            for (int r = k; r < nb; ++r) {
+                const double m = El<REAL>::abs2(Ab[lu_ab(L, g, n + k, r)]);
+                if (m > best) {
+                    best = m;
+                    p = r;
+                }
+            }
+            if (p != k) {
+                for (int cidx = 0; cidx < nb; ++cidx) {
+                    E *pa = Ab + lu_ab(L, g, n + cidx, k), *pb = Ab + lu_ab(L, g, n + cidx, p);
+                    E t = *pa;
+                    *pa = *pb;
+                    *pb = t;
+                    pa = Sinv + ((long)k * nb + cidx) * G + gs;
+                    pb = Sinv + ((long)p * nb + cidx) * G + gs;
+                    t = *pa;
+                    *pa = *pb;
+                    *pb = t;
+                }
+            }
+            E piv = Ab[lu_ab(L, g, n + k, k)];
+            if (!(El<REAL>::abs2(piv) > tiny * tiny)) {
+                bad = true;
+                piv = El<REAL>::one();
+            }
+            const E ip = El<REAL>::inv(piv);
+            for (int cidx = 0; cidx < nb; ++cidx) {
+                E *pa = Ab + lu_ab(L, g, n + cidx, k);
+                *pa = El<REAL>::mul(*pa, ip);
+                pa = Sinv + ((long)k * nb + cidx) * G + gs;
+                *pa = El<REAL>::mul(*pa, ip);
+            }
+            for (int r = 0; r < nb; ++r) {
+                if (r == k) continue;
+                const E m = Ab[lu_ab(L, g, n + k, r)];
+                if (El<REAL>::is_zero(m)) continue;
+                for (int cidx = 0; cidx < nb; ++cidx) {
+                    E *pt = Ab + lu_ab(L, g, n + cidx, r);
+                    E t = *pt;
+                    El<REAL>::fms(t, m, Ab[lu_ab(L, g, n + cidx, k)]);
+                    *pt = t;
+                    pt = Sinv + ((long)r * nb + cidx) * G + gs;
+                    t = *pt;
+                    El<REAL>::fms(t, m, Sinv[((long)k * nb + cidx) * G + gs]);
+                    *pt = t;
+                }
+            }
+        }
+        for (int r = 0; r < nb; ++r)
+            for (int cidx = 0; cidx < nb; ++cidx)
+                Ab[lu_ab(L, g, n + cidx, r)] = Sinv[((long)r * nb + cidx) * G + gs];
+    }
+    // (every thread of a system saw the same pivots; the assembly flags were combined above)
+    if (ty == 0 && g < L.GL) L.flag[g] = bad ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // solve: forward sweep (row interchanges, band multipliers, border multipliers), Schur block,
 // backward sweep with a register window of the last W solution entries.
 // ------------------------------------------------------------------------------------------------
@@ -2431,7 +2671,13 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
     // DDH_FACTOR_ROWS=0: one thread per system (factor_kernel)
     static const bool rows_off = getenv("DDH_FACTOR_ROWS") && atoi(getenv("DDH_FACTOR_ROWS")) == 0;
     const int NT = d.kl + 1 + d.nb;
-    if (!rows_off && NT <= FR_NTMAX && GL >= 64) {
+    static const int rows_mode = getenv("DDH_FACTOR_ROWS") ? atoi(getenv("DDH_FACTOR_ROWS")) : 2;   // 2: register window
+    if (!rows_off && rows_mode >= 2 && real && NT <= FR_NTMAX && GL >= 64 && d.W + 1 <= FW_WMAX) {
+        // (real factors: 72 of the 128 registers a 14-wave workgroup allows; the complex window would spill)
+        const size_t lds = 2 * (size_t)FW_WMAX * 64 * esz;
+        hipLaunchKernelGGL(factor_window_kernel<true>, dim3(blocks), dim3(64, NT), lds, s, P, d, pp->mats[matM_id]->dev,
+                           pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
+    } else if (!rows_off && NT <= FR_NTMAX && GL >= 64) {
         if (real)
             hipLaunchKernelGGL(factor_rows_kernel<true>, dim3(blocks), dim3(64, NT), 0, s, P, d, pp->mats[matM_id]->dev,
                                pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
