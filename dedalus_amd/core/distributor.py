@@ -170,10 +170,12 @@ class Distributor:
 
 
 def _overlap():
-    """DDH_A2A_OVERLAP=1: exchange the components of a field one by one with the packing / unpacking of its neighbours
-    overlapped (opt-in until it has been timed on a multi-GPU node: the single-GPU test box cannot run RCCL)."""
+    """Exchange the components of a field one by one with the packing / unpacking of its neighbours overlapped (the
+    exchange of component c is in flight on the communicator's stream while c + 1 is packed and c - 1 unpacked).
+    On by default since round 3 (the 2-rank parity tests run with it, tests/test_multiprocess.py); DDH_A2A_OVERLAP=0
+    sends a whole field in one exchange through the library's RCCL plan (ddh_a2a_localize_*)."""
     import os
-    return os.environ.get("DDH_A2A_OVERLAP", "0") == "1"
+    return os.environ.get("DDH_A2A_OVERLAP", "1") == "1"
 
 
 class Transformer:

@@ -2139,7 +2139,8 @@ static void choose_variant(const PencilPack *pp, const LuDev &d, int &use_fwd, i
     use_fwd = (coop_mode == 2 || (coop_auto && P.G <= 16384)) ? 1 : 0;
     cb = 0;
     if (coop_mode == 2 || (coop_auto && P.G <= 1024)) cb = 16;
-    else if (coop_auto && P.G <= 32768) cb = 4;
+    else if (coop_auto && P.G <= 16384) cb = 4;        // (round 3, register-lean sweeps: at 32 768 systems one thread per
+                                                       //  system is faster again, 5.17 vs 5.58 ms -- profiles/r3_strong_scaling_shares.txt)
     if (pp->coop_fwd >= 0) use_fwd = pp->coop_fwd;
     if (pp->coop_cb >= 0) cb = pp->coop_cb;
     if (NF == 0 || d.kl >= CH || d.nb > 8) use_fwd = 0;
