@@ -169,9 +169,12 @@ __device__ __forceinline__ void build_z(const LineLoads<NT> &ld, double dscale, 
 
 // backward transform from the pre-processed spectrum v: result g[n3] = x[2n] + i x[2n+1],
 // n = (n1 + 8 n2) + 64 n3, lane = n2 + 8 n1
-template <int C>
+// t1r / t2r (TWREG): the lane's 7 + 8 twiddles of the two radix-8 passes held in registers for the whole kernel instead of
+// being read from the LDS tables in every transform (15 of the 53 LDS reads of a backward transform; the kernel is bound
+// by the LDS pipe and runs at 2 waves per SIMD whatever it does with the 60 registers)
+template <int C, bool TWREG = false>
 __device__ __forceinline__ void backward_line(double2 *v, double2 *wb, const double2 *tw, int lane, double2 *g,
-                                              int dbg) {
+                                              int dbg, const double2 *t1r = nullptr, const double2 *t2r = nullptr) {
     using G = GW<C>;
     const int b1 = lane / C, c1 = lane - b1 * C;     // pass 1: butterfly j = lane = b*C + c; pass 2: lr = n1*C + c
     if (lane < G::NB) {
@@ -180,7 +183,7 @@ __device__ __forceinline__ void backward_line(double2 *v, double2 *wb, const dou
         wb[b1 * G::S1 + c1] = v[0];
 #pragma unroll
         for (int n1 = 1; n1 < 8; ++n1) {
-            const double2 w = conj2(tw[G::T_1 + n1 * 8 + b1]);
+            const double2 w = conj2(TWREG ? t1r[n1 - 1] : tw[G::T_1 + n1 * 8 + b1]);
             wb[b1 * G::S1 + n1 * C + c1] = cmul(v[n1], w);
         }
     }
@@ -193,7 +196,7 @@ __device__ __forceinline__ void backward_line(double2 *v, double2 *wb, const dou
         const int n1 = b1, c = c1;
 #pragma unroll
         for (int n2 = 0; n2 < 8; ++n2) {
-            const double2 w = conj2(tw[G::T_2 + n2 * G::STR + lane]);
+            const double2 w = conj2(TWREG ? t2r[n2] : tw[G::T_2 + n2 * G::STR + lane]);
             wb[c * G::S2 + n2 + 8 * n1] = cmul(v[n2], w);
         }
     }
@@ -204,9 +207,9 @@ __device__ __forceinline__ void backward_line(double2 *v, double2 *wb, const dou
 }
 
 // forward transform of the grid values g (same lane/register map) and store of the coefficient line
-template <int C>
+template <int C, bool TWREG = false>
 __device__ __forceinline__ void forward_line(double2 *g, double2 *wb, const double2 *tw, int lane, double *dst,
-                                             int M, int K, int dbg) {
+                                             int M, int K, int dbg, const double2 *t1r = nullptr) {
     using G = GW<C>;
     const int n2L = lane & 7, n1L = lane >> 3;
     if (!(dbg & 1)) butterfly<C>(g, -1);
@@ -228,7 +231,7 @@ __device__ __forceinline__ void forward_line(double2 *g, double2 *wb, const doub
         wb[n1 * G::S1 + c1] = v[0];
 #pragma unroll
         for (int b = 1; b < 8; ++b) {
-            const double2 w = tw[G::T_1 + b * 8 + n1];
+            const double2 w = TWREG ? t1r[b - 1] : tw[G::T_1 + b * 8 + n1];       // (the table is symmetric)
             wb[n1 * G::S1 + b * C + c1] = cmul(v[b], w);
         }
     }
@@ -269,7 +272,7 @@ __device__ __forceinline__ void forward_line(double2 *g, double2 *wb, const doub
 
 // WAVES lines (wavefronts) per workgroup; DBG compiles the timing-ablation switches in (FftDev::dbg bits:
 // 1 no butterfly math, 4 no global loads, 16 no global stores, 32 no forward transforms)
-template <int C, int NT, int WAVES, bool DBG, int OCC>
+template <int C, int NT, int WAVES, bool DBG, int OCC, bool TWREG = false>
 __global__ void __launch_bounds__(64 * WAVES, OCC)
 gridwave_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
     constexpr int GW_T = 64 * WAVES, GW_WAVES = WAVES;
@@ -323,6 +326,14 @@ gridwave_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
     const long off = line * (long)M;
     const int na = f.na, nloads = f.nbatch;              // host builds one load per batch for this kernel
 
+    double2 t1r[7], t2r[8];
+    if (TWREG) {
+        const int lc = lane < G::NB ? lane : 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) t1r[i] = tw[G::T_1 + (i + 1) * 8 + lc / C];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t2r[i] = tw[G::T_2 + i * G::STR + lc];
+    }
     LineLoads<NT> ld;
     if (!(dbg & 4)) issue_loads<NT>(ld, s_src[0] + off, lane, K);
     else
@@ -337,7 +348,7 @@ gridwave_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
         double2 v[8];
         build_z<C, NT>(ld, s_dscale[l], wb, tw, ln, v);
         if (l + 1 < nloads && !(dbg & 4)) issue_loads<NT>(ld, s_src[l + 1] + off, ln, K);
-        backward_line<C>(v, wb, tw, ln, g, dbg);
+        backward_line<C, TWREG>(v, wb, tw, ln, g, dbg, t1r, t2r);
     };
     // the `a` operands stay in registers (twice their grid values, like every transformed operand)
     double2 areg[FUSED_NA][C];
@@ -378,7 +389,7 @@ gridwave_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
         if (oc >= 0 && !(dbg & 32)) {
             int lf = lane;
             asm volatile("" : "+v"(lf));
-            forward_line<C>(acc, wb, tw, lf, s_out[oc] + off, M, K, dbg);
+            forward_line<C, TWREG>(acc, wb, tw, lf, s_out[oc] + off, M, K, dbg, t1r);
 #pragma unroll
             for (int i = 0; i < C; ++i) acc[i] = make_double2(0.0, 0.0);
         }
@@ -394,10 +405,14 @@ int launch_cw(const FftDev &d, const FusedArgs &f_in, long nlines, hipStream_t s
     const size_t lds = ((size_t)G::TW + (size_t)WAVES * G::LDW) * sizeof(double2);
     const dim3 grid((unsigned)nwg), block(64 * WAVES);
     const bool narrow = d.K + 1 <= 64 * NT32;
+    static const bool twreg = getenv("DDH_GW_TWREG") ? atoi(getenv("DDH_GW_TWREG")) != 0 : true;
     FusedArgs f = f_in;
     for (int t = 0; t < FUSED_TERMS; ++t) f.coef[t] *= 0.25;     // both factors of a term arrive doubled
     if (C == 6 && d.dbg && narrow)                         // timing ablations (tools/bench_fused.py)
         hipLaunchKernelGGL((gridwave_bilinear_kernel<C, NT32, WAVES, C == 6, OCC>), grid, block, lds, st, d, f, nlines);
+    else if (narrow && twreg && C == 6 && OCC == 2)
+        hipLaunchKernelGGL((gridwave_bilinear_kernel<C, NT32, WAVES, false, OCC, (C == 6 && OCC == 2)>), grid, block, lds, st, d, f,
+                           nlines);
     else if (narrow)
         hipLaunchKernelGGL((gridwave_bilinear_kernel<C, NT32, WAVES, false, OCC>), grid, block, lds, st, d, f, nlines);
     else
