@@ -9,6 +9,7 @@
 // stream  ->  unpack.  RCCL is bound at run time (dlopen of librccl.so.1: the copy torch already loaded when present),
 // so the library itself has no link-time dependency and loads on boxes without a GPU.
 #include "ddh_common.h"
+#include <vector>
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -78,7 +79,9 @@ struct Comm : HandleBase {
 struct A2aPlan : HandleBase {
     Comm *comm = nullptr;
     long n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-    size_t local = 0;          // doubles per rank
+    size_t local = 0;          // doubles per rank (buffer size)
+    bool even = true;          // both transposed axes divisible by the number of ranks
+    long B1 = 0, B2 = 0;       // block sizes ceil(n1 / P), ceil(n2 / P) of the uneven distribution
     double *send = nullptr, *recv = nullptr;
     ~A2aPlan() override {
         (void)hipFree(send);
@@ -158,17 +161,54 @@ int ddh_comm_allreduce(ddh_handle comm, double *buf, long count, int op, void *s
     return 0;
 }
 
+// uneven blocks: rank p owns [p B, min((p + 1) B, n)) of an axis of length n, B = ceil(n / P) (Layout.local_chunks,
+// core/distributor.py; Alltoallv transposes core/transposes.pyx:287-445)
+static inline long blk_lo(long n, long B, int p) { return (p * B < n) ? p * B : n; }
+static inline long blk_n(long n, long B, int p) {
+    const long lo = blk_lo(n, B, p);
+    return ((lo + B < n) ? lo + B : n) - lo;
+}
+
+// send block p = cnt_s[p] doubles at disp_s[p] of `send`; block q of `recv` = cnt_r[q] doubles at disp_r[q]
+static int exchange_v(A2aPlan *pl, const std::vector<size_t> &cnt_s, const std::vector<size_t> &disp_s,
+                      const std::vector<size_t> &cnt_r, const std::vector<size_t> &disp_r, hipStream_t s) {
+    const Comm *c = pl->comm;
+    const int me = c->rank;
+    if (cnt_s[me] != cnt_r[me]) return fail("a2a: self block sizes differ");
+    if (cnt_s[me])
+        DDH_HIP(hipMemcpyAsync(pl->recv + disp_r[me], pl->send + disp_s[me], cnt_s[me] * sizeof(double),
+                               hipMemcpyDeviceToDevice, s));
+    if (c->nranks == 1) return 0;
+    DDH_NCCL(g_rccl.GroupStart());
+    for (int p = 0; p < c->nranks; ++p) {
+        if (p == me) continue;
+        if (cnt_s[p]) DDH_NCCL(g_rccl.Send(pl->send + disp_s[p], cnt_s[p], ncclDouble, p, c->comm, s));
+        if (cnt_r[p]) DDH_NCCL(g_rccl.Recv(pl->recv + disp_r[p], cnt_r[p], ncclDouble, p, c->comm, s));
+    }
+    DDH_NCCL(g_rccl.GroupEnd());
+    return 0;
+}
+
 int ddh_a2a_plan(ddh_handle *plan, ddh_handle comm, long n0, long n1, long n2, long n3) {
     Comm *c = (Comm *)lookup_handle(comm, H_COMM);
     if (!c) return -1;
     if (!plan || n0 < 1 || n1 < 1 || n2 < 1 || n3 < 1) return fail("ddh_a2a_plan: bad shape");
-    if (n1 % c->nranks || n2 % c->nranks)
-        return fail("ddh_a2a_plan: both transposed axes must be divisible by the number of ranks (equal blocks)");
     A2aPlan *pl = new A2aPlan();
     pl->kind = H_A2A;
     pl->comm = c;
     pl->n0 = n0; pl->n1 = n1; pl->n2 = n2; pl->n3 = n3;
-    pl->local = (size_t)(n0 * n1 * n2 * n3) / (size_t)c->nranks;
+    pl->even = !(n1 % c->nranks || n2 % c->nranks);
+    pl->B1 = (n1 + c->nranks - 1) / c->nranks;
+    pl->B2 = (n2 + c->nranks - 1) / c->nranks;
+    if (pl->even) {
+        pl->local = (size_t)(n0 * n1 * n2 * n3) / (size_t)c->nranks;
+    } else {
+        // the larger of the rank's column-local and row-local arrays
+        const size_t cl = (size_t)(n0 * n1 * blk_n(n2, pl->B2, c->rank) * n3);
+        const size_t rl = (size_t)(n0 * blk_n(n1, pl->B1, c->rank) * n2 * n3);
+        pl->local = cl > rl ? cl : rl;
+        if (pl->local == 0) pl->local = 1;
+    }
     if (check_hip(hipMalloc((void **)&pl->send, pl->local * sizeof(double) + 16), "hipMalloc") ||
         check_hip(hipMalloc((void **)&pl->recv, pl->local * sizeof(double) + 16), "hipMalloc")) {
         delete pl;
@@ -184,6 +224,23 @@ int ddh_a2a_localize_rows(ddh_handle plan, const double *cl, double *rl, void *s
     if (!pl) return -1;
     const int P = pl->comm->nranks;
     if (cl == rl) return fail("ddh_a2a_localize_rows: the two layouts must be different buffers");
+    if (!pl->even) {
+        // CL [N0][N1][n2(me)][N3] -> RL [N0][n1(me)][N2][N3] with uneven blocks
+        const int me = pl->comm->rank;
+        const long n2me = blk_n(pl->n2, pl->B2, me), n1me = blk_n(pl->n1, pl->B1, me);
+        std::vector<size_t> cs(P), ds(P), cr(P), dr(P);
+        for (int p = 0; p < P; ++p) {
+            cs[p] = (size_t)(pl->n0 * blk_n(pl->n1, pl->B1, p) * n2me * pl->n3);
+            ds[p] = (size_t)(pl->n0 * n2me * pl->n3 * blk_lo(pl->n1, pl->B1, p));
+            cr[p] = (size_t)(pl->n0 * n1me * blk_n(pl->n2, pl->B2, p) * pl->n3);
+            dr[p] = (size_t)(pl->n0 * n1me * pl->n3 * blk_lo(pl->n2, pl->B2, p));
+        }
+        if (n2me > 0)
+            if (int s = ddh_a2av_pack(cl, pl->send, pl->n0, pl->n1, n2me * pl->n3, P, stream)) return s;
+        if (int s = exchange_v(pl, cs, ds, cr, dr, as_stream(stream))) return s;
+        if (n1me > 0) return ddh_a2av_unpack(pl->recv, rl, pl->n0 * n1me, pl->n2, pl->n3, P, stream);
+        return 0;
+    }
     // split N1 into P row blocks, exchange, gather the P column blocks along N2
     if (int s = ddh_a2a_pack(cl, pl->send, pl->n0, pl->n1, pl->n2 / P, pl->n3, P, stream)) return s;
     if (int s = exchange(pl, as_stream(stream))) return s;
@@ -196,6 +253,22 @@ int ddh_a2a_localize_columns(ddh_handle plan, const double *rl, double *cl, void
     if (!pl) return -1;
     const int P = pl->comm->nranks;
     if (cl == rl) return fail("ddh_a2a_localize_columns: the two layouts must be different buffers");
+    if (!pl->even) {
+        const int me = pl->comm->rank;
+        const long n2me = blk_n(pl->n2, pl->B2, me), n1me = blk_n(pl->n1, pl->B1, me);
+        std::vector<size_t> cs(P), ds(P), cr(P), dr(P);
+        for (int p = 0; p < P; ++p) {
+            cs[p] = (size_t)(pl->n0 * n1me * blk_n(pl->n2, pl->B2, p) * pl->n3);
+            ds[p] = (size_t)(pl->n0 * n1me * pl->n3 * blk_lo(pl->n2, pl->B2, p));
+            cr[p] = (size_t)(pl->n0 * blk_n(pl->n1, pl->B1, p) * n2me * pl->n3);
+            dr[p] = (size_t)(pl->n0 * n2me * pl->n3 * blk_lo(pl->n1, pl->B1, p));
+        }
+        if (n1me > 0)
+            if (int s = ddh_a2av_pack(rl, pl->send, pl->n0 * n1me, pl->n2, pl->n3, P, stream)) return s;
+        if (int s = exchange_v(pl, cs, ds, cr, dr, as_stream(stream))) return s;
+        if (n2me > 0) return ddh_a2av_unpack(pl->recv, cl, pl->n0, pl->n1, n2me * pl->n3, P, stream);
+        return 0;
+    }
     // split N2 into P column blocks ([N0 N1/P][N2][1][N3] view), exchange, gather the P row blocks along N1
     if (int s = ddh_a2a_pack(rl, pl->send, pl->n0 * (pl->n1 / P), pl->n2, 1, pl->n3, P, stream)) return s;
     if (int s = exchange(pl, as_stream(stream))) return s;

@@ -192,6 +192,37 @@ a2a_unpack_kernel(const double *__restrict__ src, double *__restrict__ dst, long
     }
 }
 
+// Uneven blocks (the reference's Alltoallv transposes, core/transposes.pyx:287-445): an axis of length n is dealt out in
+// blocks of B = ceil(n / P) -- rank p owns [p B, min((p + 1) B, n)), trailing ranks may own nothing (Layout.local_chunks
+// of core/distributor.py).  Block p of the packed buffer starts where the blocks before it end.
+__global__ void __launch_bounds__(256)
+a2av_pack_kernel(const double *__restrict__ src, double *__restrict__ dst, long outer, long na, long row, int P, long B) {
+    const long nseg = outer * P;
+    for (long r = blockIdx.x; r < nseg; r += gridDim.x) {
+        const long o = r / P, p = r % P;
+        const long lo = (p * B < na) ? p * B : na;
+        const long hi = (lo + B < na) ? lo + B : na;
+        const long cnt = (hi - lo) * row;
+        const double *s = src + (o * na + lo) * row;
+        double *d = dst + outer * row * lo + o * cnt;
+        for (long i = threadIdx.x; i < cnt; i += blockDim.x) d[i] = s[i];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+a2av_unpack_kernel(const double *__restrict__ src, double *__restrict__ dst, long outer_na, long nb, long inner, int P, long B) {
+    const long nseg = (long)P * outer_na;
+    for (long r = blockIdx.x; r < nseg; r += gridDim.x) {
+        const long p = r / outer_na, oi = r % outer_na;
+        const long lo = (p * B < nb) ? p * B : nb;
+        const long hi = (lo + B < nb) ? lo + B : nb;
+        const long cnt = (hi - lo) * inner;
+        const double *s = src + outer_na * inner * lo + oi * cnt;
+        double *d = dst + (oi * nb + lo) * inner;
+        for (long i = threadIdx.x; i < cnt; i += blockDim.x) d[i] = s[i];
+    }
+}
+
 // min / max / sum of n doubles: fixed-shape tree (block partials in a fixed order, then one block over the partials),
 // so the result does not depend on scheduling.  out3 = {min, max, sum}.
 constexpr int RED_BLOCKS = 1024;
@@ -393,6 +424,29 @@ int ddh_a2a_unpack(const double *src, double *dst, long outer, long na, long nb,
     if (grid == 0) return 0;
     hipLaunchKernelGGL(a2a_unpack_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, dst, outer, na, nb, inner,
                        nparts);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+/* uneven blocks of B = ceil(n / P) along the split axis (Alltoallv transposes, core/transposes.pyx:287-445) */
+int ddh_a2av_pack(const double *src, double *dst, long outer, long na, long row, int nparts, void *stream) {
+    if (nparts < 1 || na < 1) return fail("ddh_a2av_pack: bad arguments");
+    const long B = (na + nparts - 1) / nparts;
+    const long nseg = outer * nparts;
+    const unsigned grid = (unsigned)(nseg < 8192 ? nseg : 8192);
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL(a2av_pack_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, dst, outer, na, row, nparts, B);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_a2av_unpack(const double *src, double *dst, long outer_na, long nb, long inner, int nparts, void *stream) {
+    if (nparts < 1 || nb < 1) return fail("ddh_a2av_unpack: bad arguments");
+    const long B = (nb + nparts - 1) / nparts;
+    const long nseg = (long)nparts * outer_na;
+    const unsigned grid = (unsigned)(nseg < 8192 ? nseg : 8192);
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL(a2av_unpack_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, dst, outer_na, nb, inner, nparts, B);
     DDH_HIP(hipGetLastError());
     return 0;
 }

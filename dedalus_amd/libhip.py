@@ -124,6 +124,8 @@ SIGNATURES = {
     "ddh_a2a_backward": [_h, _vp, _vp, _vp],
     "ddh_a2a_pack": [_vp, _vp, _l, _l, _l, _l, _i, _vp],
     "ddh_a2a_unpack": [_vp, _vp, _l, _l, _l, _l, _i, _vp],
+    "ddh_a2av_pack": [_vp, _vp, _l, _l, _l, _i, _vp],
+    "ddh_a2av_unpack": [_vp, _vp, _l, _l, _l, _i, _vp],
 }
 
 

@@ -374,7 +374,7 @@ int ddh_comm_allreduce(ddh_handle comm, double *buf, long count, int op, void *s
 
 /* Transpose plan = FFTWTranspose / AlltoallvTranspose (core/transposes.pyx:22-445, planner interface
  * core/distributor.py:696-768): (n0, n1, n2, n3) is the reference's reduced GLOBAL shape (N0, N1, N2, N3) around the
- * transposed axis pair (axis, axis + 1); both transposed axes must be divisible by the number of ranks (equal
+ * transposed axis pair (axis, axis + 1); axes that are not divisible by the number of ranks are dealt out in blocks of ceil(n / P) (uneven
  * blocks).  Local layouts, C order:
  *     column-local CL [n0][n1][n2 / P][n3]      row-local RL [n0][n1 / P][n2][n3]
  * ddh_a2a_localize_rows(plan, CL, RL)     = plan.localize_rows(CL, RL)     (:248-256; Transpose.decrement, forward)
@@ -396,6 +396,12 @@ int ddh_a2a_pack(const double *src, double *dst, long outer, long na, long nb, l
                  int nparts, void *stream);
 int ddh_a2a_unpack(const double *src, double *dst, long outer, long na, long nb, long inner,
                    int nparts, void *stream);
+/* the same with UNEVEN blocks of ceil(n / nparts) along the split axis (the last ranks own less, possibly nothing):
+ * pack [outer][na][row] -> blocks p = [outer][na_p][row] back to back; unpack blocks p = [outer_na][nb_p][inner] ->
+ * [outer_na][nb][inner].  ddh_a2a_plan uses them when an axis is not divisible by the number of ranks (the reference's
+ * Alltoallv transposes, core/transposes.pyx:287-445). */
+int ddh_a2av_pack(const double *src, double *dst, long outer, long na, long row, int nparts, void *stream);
+int ddh_a2av_unpack(const double *src, double *dst, long outer_na, long nb, long inner, int nparts, void *stream);
 
 #ifdef __cplusplus
 }

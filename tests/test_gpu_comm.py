@@ -147,3 +147,80 @@ print("OK")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("P", [2, 3, 4])
+@pytest.mark.parametrize("shape", [(3, 7, 10, 5), (1, 5, 9, 1), (2, 13, 3, 3), (2, 5, 5, 2)])
+def test_uneven_block_transposes_for_P_ranks(P, shape):
+    """Axes that P does not divide (the reference's Alltoallv transposes, core/transposes.pyx:287-445): blocks of
+    ceil(n / P), trailing ranks own less or nothing (n = 5, P = 4 -> 2, 2, 1, 0).  Emulated ranks as above: the pack /
+    unpack kernels ddh_a2a_plan uses for such shapes, with the exchange (counts and displacements of exchange_v) done
+    on the host."""
+    from dedalus_amd import libhip
+    from dedalus_amd.device import Device, ptr
+    dev = Device.get()
+    n0, n1, n2, n3 = shape
+    A = np.random.default_rng(P + n1).standard_normal(shape)
+    B1, B2 = -(-n1 // P), -(-n2 // P)
+    lo1 = [min(p * B1, n1) for p in range(P + 1)]
+    lo2 = [min(p * B2, n2) for p in range(P + 1)]
+    CL = [np.ascontiguousarray(A[:, :, lo2[r]:lo2[r + 1], :]) for r in range(P)]
+    RL = [np.ascontiguousarray(A[:, lo1[r]:lo1[r + 1], :, :]) for r in range(P)]
+
+    def kernel(name, src, nout, *dims):
+        if src.size == 0 or nout == 0:
+            return np.zeros(nout)
+        d_s, d_o = dev.from_host(src.ravel()), dev.empty((max(nout, 1),))
+        d_o.fill_(float("nan"))
+        libhip.call(name, ptr(d_s), ptr(d_o), *dims, P, dev.stream)
+        dev.sync()
+        return dev.to_host(d_o)[:nout]
+
+    # ---- localize_rows: CL_r [n0][n1][n2_r][n3] -> RL_r [n0][n1_r][n2][n3]
+    sends = [kernel("ddh_a2av_pack", CL[r], CL[r].size, n0, n1, CL[r].shape[2] * n3) for r in range(P)]
+    recvs = []
+    for r in range(P):
+        n1r = lo1[r + 1] - lo1[r]
+        parts = []
+        for q in range(P):                                   # what q sends to r: its block r
+            n2q = lo2[q + 1] - lo2[q]
+            disp, cnt = n0 * n2q * n3 * lo1[r], n0 * n1r * n2q * n3
+            parts.append(sends[q][disp:disp + cnt])
+        recvs.append(np.concatenate(parts) if parts else np.zeros(0))
+    for r in range(P):
+        n1r = lo1[r + 1] - lo1[r]
+        got = kernel("ddh_a2av_unpack", recvs[r], RL[r].size, n0 * n1r, n2, n3)
+        assert np.array_equal(got.reshape(RL[r].shape), RL[r]), ("rows", r)
+    # ---- localize_columns: RL_r -> CL_r
+    sends = [kernel("ddh_a2av_pack", RL[r], RL[r].size, n0 * RL[r].shape[1], n2, n3) for r in range(P)]
+    recvs = []
+    for r in range(P):
+        n2r = lo2[r + 1] - lo2[r]
+        parts = []
+        for q in range(P):
+            n1q = lo1[q + 1] - lo1[q]
+            disp, cnt = n0 * n1q * n3 * lo2[r], n0 * n1q * n2r * n3
+            parts.append(sends[q][disp:disp + cnt])
+        recvs.append(np.concatenate(parts) if parts else np.zeros(0))
+    for r in range(P):
+        n2r = lo2[r + 1] - lo2[r]
+        got = kernel("ddh_a2av_unpack", recvs[r], CL[r].size, n0, n1, n2r * n3)
+        assert np.array_equal(got.reshape(CL[r].shape), CL[r]), ("columns", r)
+
+
+def test_one_rank_plan_with_any_shape():
+    """ddh_a2a_plan no longer insists on divisible axes; with one rank every shape is a copy through the plan's buffers"""
+    from dedalus_amd import libhip
+    from dedalus_amd.device import ptr
+    dev, comm = _comm1()
+    rng = np.random.default_rng(8)
+    for shape in [(2, 5, 7, 3), (1, 1, 1, 1)]:
+        plan = C.c_uint64(0)
+        libhip.call("ddh_a2a_plan", C.byref(plan), comm, *shape)
+        a = rng.standard_normal(shape)
+        d_a, d_b = dev.from_host(a), dev.empty(shape)
+        libhip.call("ddh_a2a_localize_rows", plan, ptr(d_a), ptr(d_b), dev.stream)
+        dev.sync()
+        assert np.array_equal(dev.to_host(d_b), a)
+        libhip.call("ddh_destroy", plan)
+    libhip.call("ddh_destroy", comm)
