@@ -312,10 +312,13 @@ class HipTranspose:
         self.global_shape, self.axis, self.comm = gs, int(axis), comm
         self.N0, self.N1, self.N2, self.N3 = math.prod(gs[:axis]), gs[axis], gs[axis + 1], math.prod(gs[axis + 2:])
         cs = [int(v) for v in chunk_shape]
-        if self.N1 % (comm.size * cs[axis]) or self.N2 % (comm.size * cs[axis + 1]):
-            raise ValueError("the transposed axes must split into equal blocks of whole chunks over the ranks")
+        # blocks of whole chunks, as the reference's layouts deal them out (core/distributor.py): equal when the rank
+        # count divides the chunk count, otherwise the last ranks own less (Alltoallv transposes, transposes.pyx:287-445)
+        blk = lambda n, c: c * -(-(-(-n // c)) // comm.size)
+        self.block1, self.block2 = blk(self.N1, max(cs[axis], 1)), blk(self.N2, max(cs[axis + 1], 1))
         self.plan = C.c_uint64(0)
-        libhip.call("ddh_a2a_plan", C.byref(self.plan), comm.handle, self.N0, self.N1, self.N2, self.N3)
+        libhip.call("ddh_a2a_plan_blocks", C.byref(self.plan), comm.handle, self.N0, self.N1, self.N2, self.N3,
+                    self.block1, self.block2)
 
     def localize_rows(self, CL, RL):
         libhip.call("ddh_a2a_localize_rows", self.plan, C.c_void_p(device_pointer(CL)), C.c_void_p(device_pointer(RL)),

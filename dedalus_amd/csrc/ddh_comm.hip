@@ -190,16 +190,22 @@ static int exchange_v(A2aPlan *pl, const std::vector<size_t> &cnt_s, const std::
 }
 
 int ddh_a2a_plan(ddh_handle *plan, ddh_handle comm, long n0, long n1, long n2, long n3) {
+    return ddh_a2a_plan_blocks(plan, comm, n0, n1, n2, n3, 0, 0);
+}
+
+int ddh_a2a_plan_blocks(ddh_handle *plan, ddh_handle comm, long n0, long n1, long n2, long n3, long block1, long block2) {
     Comm *c = (Comm *)lookup_handle(comm, H_COMM);
     if (!c) return -1;
+    if (block1 < 0 || block2 < 0 || (block1 && block1 * c->nranks < n1) || (block2 && block2 * c->nranks < n2))
+        return fail("ddh_a2a_plan_blocks: blocks do not cover the axis");
     if (!plan || n0 < 1 || n1 < 1 || n2 < 1 || n3 < 1) return fail("ddh_a2a_plan: bad shape");
     A2aPlan *pl = new A2aPlan();
     pl->kind = H_A2A;
     pl->comm = c;
     pl->n0 = n0; pl->n1 = n1; pl->n2 = n2; pl->n3 = n3;
-    pl->even = !(n1 % c->nranks || n2 % c->nranks);
-    pl->B1 = (n1 + c->nranks - 1) / c->nranks;
-    pl->B2 = (n2 + c->nranks - 1) / c->nranks;
+    pl->B1 = block1 ? block1 : (n1 + c->nranks - 1) / c->nranks;
+    pl->B2 = block2 ? block2 : (n2 + c->nranks - 1) / c->nranks;
+    pl->even = (pl->B1 * c->nranks == n1) && (pl->B2 * c->nranks == n2);
     if (pl->even) {
         pl->local = (size_t)(n0 * n1 * n2 * n3) / (size_t)c->nranks;
     } else {
@@ -236,9 +242,9 @@ int ddh_a2a_localize_rows(ddh_handle plan, const double *cl, double *rl, void *s
             dr[p] = (size_t)(pl->n0 * n1me * pl->n3 * blk_lo(pl->n2, pl->B2, p));
         }
         if (n2me > 0)
-            if (int s = ddh_a2av_pack(cl, pl->send, pl->n0, pl->n1, n2me * pl->n3, P, stream)) return s;
+            if (int s = ddh_a2av_pack_b(cl, pl->send, pl->n0, pl->n1, n2me * pl->n3, P, pl->B1, stream)) return s;
         if (int s = exchange_v(pl, cs, ds, cr, dr, as_stream(stream))) return s;
-        if (n1me > 0) return ddh_a2av_unpack(pl->recv, rl, pl->n0 * n1me, pl->n2, pl->n3, P, stream);
+        if (n1me > 0) return ddh_a2av_unpack_b(pl->recv, rl, pl->n0 * n1me, pl->n2, pl->n3, P, pl->B2, stream);
         return 0;
     }
     // split N1 into P row blocks, exchange, gather the P column blocks along N2
@@ -264,9 +270,9 @@ int ddh_a2a_localize_columns(ddh_handle plan, const double *rl, double *cl, void
             dr[p] = (size_t)(pl->n0 * n2me * pl->n3 * blk_lo(pl->n1, pl->B1, p));
         }
         if (n1me > 0)
-            if (int s = ddh_a2av_pack(rl, pl->send, pl->n0 * n1me, pl->n2, pl->n3, P, stream)) return s;
+            if (int s = ddh_a2av_pack_b(rl, pl->send, pl->n0 * n1me, pl->n2, pl->n3, P, pl->B2, stream)) return s;
         if (int s = exchange_v(pl, cs, ds, cr, dr, as_stream(stream))) return s;
-        if (n2me > 0) return ddh_a2av_unpack(pl->recv, cl, pl->n0, pl->n1, n2me * pl->n3, P, stream);
+        if (n2me > 0) return ddh_a2av_unpack_b(pl->recv, cl, pl->n0, pl->n1, n2me * pl->n3, P, pl->B1, stream);
         return 0;
     }
     // split N2 into P column blocks ([N0 N1/P][N2][1][N3] view), exchange, gather the P row blocks along N1

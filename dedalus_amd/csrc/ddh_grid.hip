@@ -430,8 +430,15 @@ int ddh_a2a_unpack(const double *src, double *dst, long outer, long na, long nb,
 
 /* uneven blocks of B = ceil(n / P) along the split axis (Alltoallv transposes, core/transposes.pyx:287-445) */
 int ddh_a2av_pack(const double *src, double *dst, long outer, long na, long row, int nparts, void *stream) {
+    return ddh_a2av_pack_b(src, dst, outer, na, row, nparts, 0, stream);
+}
+int ddh_a2av_unpack(const double *src, double *dst, long outer_na, long nb, long inner, int nparts, void *stream) {
+    return ddh_a2av_unpack_b(src, dst, outer_na, nb, inner, nparts, 0, stream);
+}
+
+int ddh_a2av_pack_b(const double *src, double *dst, long outer, long na, long row, int nparts, long block, void *stream) {
     if (nparts < 1 || na < 1) return fail("ddh_a2av_pack: bad arguments");
-    const long B = (na + nparts - 1) / nparts;
+    const long B = block ? block : (na + nparts - 1) / nparts;
     const long nseg = outer * nparts;
     const unsigned grid = (unsigned)(nseg < 8192 ? nseg : 8192);
     if (grid == 0) return 0;
@@ -440,9 +447,9 @@ int ddh_a2av_pack(const double *src, double *dst, long outer, long na, long row,
     return 0;
 }
 
-int ddh_a2av_unpack(const double *src, double *dst, long outer_na, long nb, long inner, int nparts, void *stream) {
+int ddh_a2av_unpack_b(const double *src, double *dst, long outer_na, long nb, long inner, int nparts, long block, void *stream) {
     if (nparts < 1 || nb < 1) return fail("ddh_a2av_unpack: bad arguments");
-    const long B = (nb + nparts - 1) / nparts;
+    const long B = block ? block : (nb + nparts - 1) / nparts;
     const long nseg = (long)nparts * outer_na;
     const unsigned grid = (unsigned)(nseg < 8192 ? nseg : 8192);
     if (grid == 0) return 0;

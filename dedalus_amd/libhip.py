@@ -118,6 +118,7 @@ SIGNATURES = {
     "ddh_comm_info": [_h, _ip, _ip],
     "ddh_comm_allreduce": [_h, _vp, _l, _i, _vp],
     "ddh_a2a_plan": [_hp, _h, _l, _l, _l, _l],
+    "ddh_a2a_plan_blocks": [_hp, _h, _l, _l, _l, _l, _l, _l],
     "ddh_a2a_localize_rows": [_h, _vp, _vp, _vp],
     "ddh_a2a_localize_columns": [_h, _vp, _vp, _vp],
     "ddh_a2a_forward": [_h, _vp, _vp, _vp],
@@ -126,6 +127,8 @@ SIGNATURES = {
     "ddh_a2a_unpack": [_vp, _vp, _l, _l, _l, _l, _i, _vp],
     "ddh_a2av_pack": [_vp, _vp, _l, _l, _l, _i, _vp],
     "ddh_a2av_unpack": [_vp, _vp, _l, _l, _l, _i, _vp],
+    "ddh_a2av_pack_b": [_vp, _vp, _l, _l, _l, _i, _l, _vp],
+    "ddh_a2av_unpack_b": [_vp, _vp, _l, _l, _l, _i, _l, _vp],
 }
 
 

@@ -384,6 +384,8 @@ int ddh_comm_allreduce(ddh_handle comm, double *buf, long count, int op, void *s
  * and destination must be different buffers (the reference's CL/RL views alias one FFTW buffer and are transposed
  * through an internal copy; here the plan owns the two staging buffers). */
 int ddh_a2a_plan(ddh_handle *plan, ddh_handle comm, long n0, long n1, long n2, long n3);
+/* the same with explicit block sizes along the two transposed axes (0 = ceil(n / P)) */
+int ddh_a2a_plan_blocks(ddh_handle *plan, ddh_handle comm, long n0, long n1, long n2, long n3, long block1, long block2);
 int ddh_a2a_localize_rows(ddh_handle plan, const double *cl, double *rl, void *stream);
 int ddh_a2a_localize_columns(ddh_handle plan, const double *rl, double *cl, void *stream);
 int ddh_a2a_forward(ddh_handle plan, const double *cl, double *rl, void *stream);
@@ -402,6 +404,10 @@ int ddh_a2a_unpack(const double *src, double *dst, long outer, long na, long nb,
  * Alltoallv transposes, core/transposes.pyx:287-445). */
 int ddh_a2av_pack(const double *src, double *dst, long outer, long na, long row, int nparts, void *stream);
 int ddh_a2av_unpack(const double *src, double *dst, long outer_na, long nb, long inner, int nparts, void *stream);
+/* ... with an explicit block size (0 = ceil(n / nparts)): the reference's blocks are whole chunks,
+ * chunk * ceil(ceil(n / chunk) / P) (core/distributor.py Layout blocks) */
+int ddh_a2av_pack_b(const double *src, double *dst, long outer, long na, long row, int nparts, long block, void *stream);
+int ddh_a2av_unpack_b(const double *src, double *dst, long outer_na, long nb, long inner, int nparts, long block, void *stream);
 
 #ifdef __cplusplus
 }

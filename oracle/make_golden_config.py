@@ -163,8 +163,34 @@ def config_shell(shape=(256, 128, 128), ells=(0, 1, 2, 50, 126)):
     print("wrote", path, os.path.getsize(path) >> 10, "KiB")
 
 
+def config_cartesian():
+    """K (KdV-Burgers N = 1024, SBDF2, 200 steps of 2e-3) and R2 (2-D Rayleigh-Benard 512 x 256, RK222, 13 steps of 1e-3)
+    end states of the unmodified reference as ARRAYS: every mode of K's u and of R2's b, p and u."""
+    import problems
+    d3 = refshim.load_reference()
+    out = {}
+    solver, f = problems.kdv_burgers(d3, Nx=1024, timestepper="SBDF2")
+    for _ in range(200):
+        solver.step(2e-3)
+    out["kdv1024__u_c"] = np.array(f["u"]["c"])
+    f["u"].change_scales(3 / 2)
+    out["kdv1024__u_g"] = np.array(f["u"]["g"])
+    print("kdv sum u_g^2 =", repr(float(np.sum(out["kdv1024__u_g"] ** 2))))
+    solver, f = problems.rayleigh_benard_2d(d3, Nx=512, Nz=256, timestepper="RK222")
+    for _ in range(13):
+        solver.step(1e-3)
+    for k in ("p", "b", "u"):
+        out["rb2d_512x256__" + k] = np.array(f[k]["c"])
+    print("rb2d |b_c| =", repr(float(np.linalg.norm(out["rb2d_512x256__b"]))))
+    path = os.path.join(GOLD, "config_cartesian.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) >> 10, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sphere", "shell"]
+    which = sys.argv[1:] or ["sphere", "shell", "cartesian"]
+    if "cartesian" in which:
+        config_cartesian()
     if "sphere" in which:
         config_sphere()
     if "shell" in which:

@@ -108,3 +108,40 @@ def test_shell_full_size_transform_projection(rank):
     dist = d3.Distributor(coords, dtype=np.float64)
     basis = d3.ShellBasis(coords, shape=(256, 128, 128), radii=(14, 15), dealias=3 / 2, dtype=np.float64)
     _projection_is_idempotent(d3, dist, coords, basis, rank, 21 + rank)
+
+
+def _gold_cartesian():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_cartesian.npz"))
+
+
+def test_kdv_1024_every_mode_against_the_reference():
+    """BASELINE config 1 at its size: the end state of the unmodified reference (oracle/make_golden_config.py), every
+    coefficient and every grid value -- not one checksum."""
+    import dedalus_amd.public as d3
+    G = _gold_cartesian()
+    solver, f = problems.kdv_burgers(d3, Nx=1024, timestepper="SBDF2")
+    for _ in range(200):
+        solver.step(2e-3)
+    c = np.asarray(f["u"]["c"])
+    assert np.linalg.norm(c - G["kdv1024__u_c"]) < 1e-10 * np.linalg.norm(G["kdv1024__u_c"])
+    assert np.abs(c - G["kdv1024__u_c"]).max() < 1e-10 * np.abs(G["kdv1024__u_c"]).max()
+    f["u"].change_scales(3 / 2)
+    g = np.asarray(f["u"]["g"])
+    assert np.abs(g - G["kdv1024__u_g"]).max() < 1e-10 * np.abs(G["kdv1024__u_g"]).max()
+
+
+def test_rb2d_512x256_every_mode_against_the_reference():
+    """BASELINE config 2: every mode of b, p and u after 13 RK222 steps against the unmodified reference's arrays
+    (tolerances as in tests/test_gpu_ivp.py: u is O(1e-6) of b here and carries the solve's absolute error)."""
+    import dedalus_amd.public as d3
+    G = _gold_cartesian()
+    solver, f = problems.rayleigh_benard_2d(d3, Nx=512, Nz=256, timestepper="RK222")
+    for _ in range(13):
+        solver.step(1e-3)
+    for k, tol in (("b", 1e-12), ("p", 1e-9), ("u", 1e-8)):
+        a, ref = np.asarray(f[k]["c"]), G["rb2d_512x256__" + k]
+        assert a.shape == ref.shape
+        err = np.linalg.norm(a - ref) / np.linalg.norm(ref)
+        worst = np.abs(a - ref).max() / np.abs(ref).max()
+        assert err < tol and worst < 10 * tol, (k, err, worst)
