@@ -1618,7 +1618,7 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     }
 }
 
-template <int NF, int WT, bool REAL, bool PREF, bool PFUSE = false>
+template <int NF, int WT, bool REAL, bool PREF, bool PFUSE = false, int DBG = 0>
 __global__ void __launch_bounds__(256)
 solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const double *__restrict__ pband) {
     typedef typename El<REAL>::T E;
@@ -1665,6 +1665,7 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
     const long ur_stride = (long)L.BW << 6;
     const double2 *const y0 = L.scratch + g;
     auto fetch = [&](int j, E *u, double2 &y, double *pr) {
+        if (DBG & 8) y = make_double2(1.0, 2.0); else
         y = y0[(long)j * G];
         if (PFUSE) {
             const double *prow = pband + (long)j * PBW;
@@ -1677,7 +1678,7 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
             const double2 *Ur2 = reinterpret_cast<const double2 *>(Ur);
 #pragma unroll
             for (int q = 0; 2 * q <= WT; ++q) {
-                const double2 uu = Ur2[(long)q << 6];
+                const double2 uu = ((DBG & 1) && q > 0) ? make_double2(u[0] * 0.5, u[0] * 0.25) : Ur2[(long)q << 6];
                 u[2 * q] = uu.x;
                 if (2 * q + 1 <= WT) u[2 * q + 1] = uu.y;
             }
@@ -1697,6 +1698,8 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
             if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
         }
         if (conjq) v.y = -v.y;
+        if ((DBG & 4) && v.x != 1.2345e300) return;
+        if (DBG & 32) { *reinterpret_cast<double2 *>(xout + (long)j * plane + 2 * g) = v; return; }
         store_sys<NF>(xout, plane, my_perm[j], P, c, s, v);
     };
     // rows are processed in pairs; the register window is shifted once per pair (by two).  With PFUSE the emitted value
@@ -1704,9 +1707,16 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
     // band coefficients are the same for every system -> scalar loads.
     auto row_even = [&](int j, const E *u, double2 y, const double *pr) -> double2 {
         double2 acc = y;
+        if constexpr ((DBG & 2) != 0) {
+            int o = 0;
+#pragma unroll
+            for (int d = 0; d < WT; ++d) o |= __double2loint(u[d + 1]);
+            acc.x += (double)o * win[0].x;
+        } else {
 #pragma unroll
         for (int d = 0; d < WT; ++d)
             if (FULL || d < W) El<REAL>::fms2(acc, u[d + 1], win[d]);
+        }
         const double2 xj = El<REAL>::mul2(acc, u[0]);   // reciprocal pivot stored on the diagonal
         double2 v = xj;
         if (PFUSE) {
@@ -1720,9 +1730,16 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
     auto row_odd = [&](int j, const E *u, double2 y, double2 xprev, const double *pr) {
         double2 acc = y;
         El<REAL>::fms2(acc, u[1], xprev);
+        if constexpr ((DBG & 2) != 0) {
+            int o = 0;
+#pragma unroll
+            for (int d = 1; d < WT; ++d) o |= __double2loint(u[d + 1]);
+            acc.x += (double)o * win[0].x;
+        } else {
 #pragma unroll
         for (int d = 1; d < WT; ++d)
             if (FULL || d < W) El<REAL>::fms2(acc, u[d + 1], win[d - 1]);
+        }
         const double2 xj = El<REAL>::mul2(acc, u[0]);
         double2 v = xj;
         if (PFUSE) {
@@ -1733,9 +1750,11 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
                 if (d - 1 < WT) { v.x += pr[d] * win[d - 1].x; v.y += pr[d] * win[d - 1].y; }
         }
         emit(j, v);
+        if constexpr ((DBG & 16) == 0) {
 #pragma unroll
         for (int d = WT - 1; d > 1; --d) win[d] = win[d - 2];
         win[1] = xprev;
+        }
         win[0] = xj;
     };
     int j = n - 1;
@@ -2251,6 +2270,20 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     if (fuse_p) {
         if constexpr (NF == 2) {
             if (W <= 32) DDH_SOLVE_P(32)
+#ifdef DDH_BWD_ABLATE
+            // timing ablations of the backward sweep (build with -DDDH_BWD_ABLATE; DDH_BWD_DBG = mask: 1 one factor load
+            // per row, 2 no FMAs, 4 no stores, 8 no scratch load, 16 no window shift, 32 stores to lane-contiguous
+            // addresses).  Results are NOT a solve.  Round 3: stores 2.2 ms, factor loads 2.9 ms of
+            // the 4.9 ms sweep, FMAs and window shifts 0.
+            else if (W <= 34 && getenv("DDH_BWD_DBG") && atoi(getenv("DDH_BWD_DBG")) > 0) {
+#define DDH_SOLVE_DBG(V) case V: hipLaunchKernelGGL((solve_backward_kernel<NF, 34, true, false, true, V>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband); break;
+                switch (atoi(getenv("DDH_BWD_DBG"))) {
+                    DDH_SOLVE_DBG(1) DDH_SOLVE_DBG(2) DDH_SOLVE_DBG(4) DDH_SOLVE_DBG(8) DDH_SOLVE_DBG(16) DDH_SOLVE_DBG(32) DDH_SOLVE_DBG(31)
+                    default: DDH_SOLVE_P(34)
+                }
+#undef DDH_SOLVE_DBG
+            }
+#endif
             else if (W <= 34) DDH_SOLVE_P(34)
             else DDH_SOLVE_P(48)
         }
@@ -2551,22 +2584,37 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
     if (reuse && (pp->lus[reuse_lu_id]->dev.pair != 0) != pair) return fail("pencil_factor: pairing changed under a reused LU");
     if (pair) {
         // pairs first, in 4 x 4 tiles of cells so that the 16 pairs of a wavefront touch 64-byte runs of the system vectors
-        // in both the cell's and the partner's rows; then the unpaired cells (axes, diagonal) in cell order
+        // in both the cell's and the partner's rows; the four wavefronts of a workgroup take the 2 x 2 tiles of an 8 x 8
+        // super-tile where all four are full (DDH_PAIR_TILE8, default on), so that the workgroup's accesses cover whole
+        // 128-byte lines in both rows; then the remaining tiles, then the unpaired cells (axes, diagonal) in cell order
         const long nc = P.ncx, nt = (nc + 3) / 4;
+        static const int tile8 = getenv("DDH_PAIR_TILE8") ? atoi(getenv("DDH_PAIR_TILE8")) : 1;
         auto has_partner = [&](long mx, long my) { return mx > 0 && my > 0 && mx != my; };
+        std::vector<char> done((size_t)(nt * nt), 0);
+        auto emit_tile = [&](long tx, long ty) {
+            done[(size_t)(tx * nt + ty)] = 1;
+            for (long mx = 4 * tx; mx < std::min(nc, 4 * tx + 4); ++mx)
+                for (long my = 4 * ty; my < std::min(nc, 4 * ty + 4); ++my) {
+                    if (!has_partner(mx, my) || mx > my) continue;
+                    const int slot = (int)(slot_cells.size() / 2);
+                    slot_cells.push_back(mx * P.ncy + my);
+                    slot_cells.push_back(my * P.ncy + mx);
+                    vcell.push_back(mx * P.ncy + my);
+                    vslot.push_back(2 * slot);
+                    vcell.push_back(my * P.ncy + mx);
+                    vslot.push_back(2 * slot + 1);
+                }
+        };
+        if (tile8 && nc % 8 == 0) {
+            const long ns = nt / 2;
+            for (long sx = 1; sx < ns; ++sx)               // (sx = 0 holds the mx = 0 axis: its tiles are not full)
+                for (long sy = sx + 1; sy < ns; ++sy)
+                    for (long tx = 2 * sx; tx < 2 * sx + 2; ++tx)
+                        for (long ty = 2 * sy; ty < 2 * sy + 2; ++ty) emit_tile(tx, ty);
+        }
         for (long tx = 0; tx < nt; ++tx)
             for (long ty = tx; ty < nt; ++ty)
-                for (long mx = 4 * tx; mx < std::min(nc, 4 * tx + 4); ++mx)
-                    for (long my = 4 * ty; my < std::min(nc, 4 * ty + 4); ++my) {
-                        if (!has_partner(mx, my) || mx > my) continue;
-                        const int slot = (int)(slot_cells.size() / 2);
-                        slot_cells.push_back(mx * P.ncy + my);
-                        slot_cells.push_back(my * P.ncy + mx);
-                        vcell.push_back(mx * P.ncy + my);
-                        vslot.push_back(2 * slot);
-                        vcell.push_back(my * P.ncy + mx);
-                        vslot.push_back(2 * slot + 1);
-                    }
+                if (!done[(size_t)(tx * nt + ty)]) emit_tile(tx, ty);
         for (long mx = 0; mx < nc; ++mx)
             for (long my = 0; my < nc; ++my) {
                 if (has_partner(mx, my)) continue;
