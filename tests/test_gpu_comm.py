@@ -120,6 +120,29 @@ def test_two_rank_nccl_run_matches_reference(golden_dir):
             assert np.linalg.norm(full - ref) / np.linalg.norm(ref) < tol, key
 
 
+def test_two_rank_nccl_bench_at_full_size_matches_the_one_gpu_run():
+    """`bench.py --gpus 2` at the metric's size (512 x 512 x 256 sharded over two GPUs, RCCL exchange) against the 1-GPU run
+    of the same steps: both ranks seen, the library's RCCL plans in use, the pencil parity block green on both shards and
+    the same end-state checksum.  Needs 2 GPUs."""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL: one GPU per rank)")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    lines = {}
+    for n in (1, 2):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+               "--no-cpu-baseline"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines[n] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    one, two = lines[1], lines[2]
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["dist_backend"] == "nccl", two
+    assert two["exchange"]["exchanges_per_step"] > 0
+    assert two["parity"]["max_residual"] < 1e-12 and two["parity"]["max_solution_error"] < 1e-10, two["parity"]
+    assert abs(two["checksum_b_c_l2"] - one["checksum_b_c_l2"]) < 1e-11 * abs(one["checksum_b_c_l2"])
+
+
 def test_comm_bootstrap_through_a_one_rank_nccl_group():
     """parallel.Comm on a 1-rank `nccl` process group: the RCCL unique id travels through the group, the library
     communicator is created, self-checked (a transpose each way) and selected for the exchanges"""
