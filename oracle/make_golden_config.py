@@ -187,11 +187,53 @@ def config_cartesian():
     print("wrote", path, os.path.getsize(path) >> 10, "KiB")
 
 
+def band_limited_state(fields, grids, Lx=4.0, Ly=4.0, Lz=1.0):
+    """A state of few modes, the same FUNCTION at any resolution (used by config_explicit and by the GPU test at the
+    metric's size): products of such fields populate a handful of low modes whose coefficients do not depend on the
+    number of modes carried."""
+    x, y, z = grids
+    kx, ky = 2 * np.pi / Lx, 2 * np.pi / Ly
+    w = z * (Lz - z)
+    b = (Lz - z) + 0.3 * np.sin(kx * x) * np.cos(2 * ky * y) * w + 0.1 * np.cos(2 * kx * x) * z ** 2 + 0 * y
+    ux = 0.5 * np.sin(kx * x) * np.cos(ky * y) * w
+    uy = -0.4 * np.cos(2 * kx * x) * np.sin(ky * y) * z * w
+    uz = 0.25 * np.cos(kx * x) * np.cos(ky * y) * w ** 2
+    fields["b"]["g"] = b
+    u = fields["u"]
+    ug = np.zeros((3,) + b.shape)
+    ug[0], ug[1], ug[2] = ux, uy, uz
+    u["g"] = ug
+
+
+def config_explicit(N=16):
+    """The explicit half of a 3-D Rayleigh-Benard stage -- F = (0, -u.grad(b), -u.grad(u), boundary constants) in the
+    equations' bases -- of the unmodified reference for the band-limited state above at N^3 modes.  The coefficients are
+    those of the same state at ANY resolution (zero beyond the populated modes): tests/test_gpu_baseline_sizes.py
+    compares the 512 x 512 x 256 evaluation of this package (z / x transforms, fused y stage, direct F writes) with them."""
+    import problems
+    d3 = refshim.load_reference()
+    solver, f = problems.rayleigh_benard_3d(d3, Nx=N, Ny=N, Nz=N, timestepper="RK222")
+    dist = solver.dist
+    grids = dist.local_grids(*f["b"].domain.bases)
+    band_limited_state(f, grids)
+    solver.evaluator.evaluate_group("F", iteration=0, wall_time=0.0, sim_time=0.0, timestep=1e-3)
+    out = {"N": np.array(N)}
+    for i, F in enumerate(solver.F):
+        c = np.array(F["c"])
+        out["F%d" % i] = c
+        print("equation", i, c.shape, float(np.abs(c).max()), int(np.sum(np.abs(c) > 1e-14)), "modes above 1e-14")
+    path = os.path.join(GOLD, "config_explicit.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) >> 10, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sphere", "shell", "cartesian"]
+    which = sys.argv[1:] or ["sphere", "shell", "cartesian", "explicit"]
     if "cartesian" in which:
         config_cartesian()
     if "sphere" in which:
         config_sphere()
     if "shell" in which:
         config_shell()
+    if "explicit" in which:
+        config_explicit()
