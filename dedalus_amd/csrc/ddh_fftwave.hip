@@ -13,6 +13,10 @@
 namespace ddh {
 
 constexpr int WV_WAVES = 8;
+#ifndef DDH_WR_WAVES
+#define DDH_WR_WAVES 8
+#endif
+constexpr int WR_WAVES = DDH_WR_WAVES;     // waves per workgroup of the real-FFT kernels
 
 struct WaveArgs {
     const double *src;
@@ -146,7 +150,7 @@ static int launch_wave_cheb(const FftDev &d, const WaveArgs &a, unsigned nwg, hi
 // ---- real Fourier, 3/2 dealiasing (N = 48 R, M = 32 R): RKIND 0 backward, 1 backward differentiated, 2 backward dual
 // (plain + differentiated), 3 forward
 template <int RKIND, int R>
-__global__ void __launch_bounds__(64 * WV_WAVES, 2)
+__global__ void __launch_bounds__(64 * WR_WAVES, 2)
 wave_rfft_kernel(FftDev p, WaveArgs a) {
     extern __shared__ double2 lds[];
     constexpr int N = 48 * R, M = 32 * R;
@@ -154,16 +158,16 @@ wave_rfft_kernel(FftDev p, WaveArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double2 *s_tw = lds;
     double2 *S = lds + N + wave * wf::RfftWaveLds<R>::size;
-    for (int i = tid; i < N; i += 64 * WV_WAVES) s_tw[i] = p.tw[i];
+    for (int i = tid; i < N; i += 64 * WR_WAVES) s_tw[i] = p.tw[i];
     __syncthreads();                    // the only workgroup barrier
     const unsigned g = xcd_swizzle(blockIdx.x, gridDim.x);
     const long inner = a.inner;
     const unsigned rsb = (unsigned)(inner * 8);
     const int p4 = lane & 3;
     for (unsigned i = 0; i < a.tpw; ++i) {
-        if ((g * a.tpw + i) * WV_WAVES >= a.ntiles) break;               // workgroup-uniform
+        if ((g * a.tpw + i) * WR_WAVES >= a.ntiles) break;               // workgroup-uniform
         if (a.wsync && i > 0) __syncthreads();
-        const unsigned tile = (g * a.tpw + i) * WV_WAVES + wave;
+        const unsigned tile = (g * a.tpw + i) * WR_WAVES + wave;
         if (tile >= a.ntiles) continue;
         unsigned o, tb;
         a.fd_tpo.divmod(tile, o, tb);
@@ -178,12 +182,12 @@ wave_rfft_kernel(FftDev p, WaveArgs a) {
 
 template <int RKIND, int R>
 static int launch_wave_rfft(const FftDev &d, const WaveArgs &a, unsigned nwg, hipStream_t st) {
-    const size_t lds = ((size_t)48 * R + (size_t)WV_WAVES * wf::RfftWaveLds<R>::size) * sizeof(double2);
+    const size_t lds = ((size_t)48 * R + (size_t)WR_WAVES * wf::RfftWaveLds<R>::size) * sizeof(double2);
     if (lds > 160 * 1024) return 1;
     auto kern = wave_rfft_kernel<RKIND, R>;
     if (lds > 64 * 1024)
         DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WV_WAVES), lds, st, d, a);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WR_WAVES), lds, st, d, a);
     DDH_HIP(hipGetLastError());
     return 0;
 }
@@ -242,9 +246,10 @@ int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, lon
     }
     a.wsync = env_wsync >= 0 ? env_wsync : def_wsync;
     unsigned tpw = (unsigned)(env_tpw > 0 ? env_tpw : def_tpw);
-    while (tpw > 1 && ntiles / ((unsigned long)tpw * WV_WAVES) < 1024) tpw /= 2;   // several rounds of workgroups
+    const unsigned long wpg = rfft ? WR_WAVES : WV_WAVES;
+    while (tpw > 1 && ntiles / ((unsigned long)tpw * wpg) < 1024) tpw /= 2;   // several rounds of workgroups
     a.tpw = tpw;
-    const unsigned nwg = (unsigned)((ntiles + (unsigned long)tpw * WV_WAVES - 1) / ((unsigned long)tpw * WV_WAVES));
+    const unsigned nwg = (unsigned)((ntiles + (unsigned long)tpw * wpg - 1) / ((unsigned long)tpw * wpg));
     if (rfft) {
         if (dst2 && dscale != 0.0) return 1;                    // the dual entry point transforms plainly into dst
         const int rk = (mode == RFFT_FWD) ? 3 : (dst2 ? 2 : (dscale != 0.0 ? 1 : 0));
