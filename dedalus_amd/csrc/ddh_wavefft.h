@@ -481,7 +481,9 @@ struct RfftWaveLds {
     static constexpr int a = 16 * R * 4;                 // natural-order exchange of N/3 values x 4 pairs (forward); half of the
                                                          // coefficient rows (backward staging: 8 R modes x 2 rows x 4 pairs)
     static constexpr int b = WfftBuf<R, 2>::size;
-    static constexpr int size = a > b ? a : b;
+    static constexpr int park = (R >= 16) ? 128 : 0;     // two more parking slots per lane for the backward tile (see there):
+                                                         // 8 waves x 18 KiB + the 12 KiB table = 156 of the CU's 160 KiB
+    static constexpr int size = (a > b ? a : b) + park;
 };
 
 // Backward.  tw[m] = exp(-2 pi i m / N).  BK: 0 plain transform into dst_t; 1 differentiated (spectrum times i kappa,
@@ -536,22 +538,37 @@ DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, u
         }
     }
     const double s3 = 0.86602540378443864676372317075293618;
-    // differentiated spectrum in place: Z[k] <- i kappa Z[k], Z[N - k'] <- -i kappa' Z[N - k'] (kappa = dsc * k).  For
-    // BK == 2 this happens between the two passes, so that both run the SAME pass body (one copy of the three transforms;
-    // two specialised copies cost 196 bytes of scratch per lane -- 10 % more HBM traffic than the tile's own data).
+    // Register relief: the staging area beyond the FFT's exchange buffer is free from here on, and the last ZL of the
+    // lane's Z[N - k'] values are parked there (lane-contiguous slots, read back once per transform).  With everything
+    // in registers the R = 16 kernels spill (plain 16, differentiated 72, dual 160-196 bytes of scratch per lane -- for
+    // the dual kernel 10 % more HBM traffic than the tile's own data).
+    constexpr int XB = WfftBuf<R, 2>::size;
+    constexpr int ZLmax = (RfftWaveLds<R>::size - XB) / 64;
+    constexpr int ZLwant = (R >= 16) ? (BK == 2 ? 9 : (BK == 1 ? 6 : 4)) : 0;
+    constexpr int ZL = ZLwant < ZLmax ? ZLwant : ZLmax;
+    double2 *ZS = S + XB + lane;
+    if (ZL > 0) {
+        WF_SYNC();                                       // the staged coefficient rows have been read by every lane
+#pragma unroll
+        for (int t = R - ZL; t < R; ++t) ZS[(t - (R - ZL)) * 64] = Zm[t];
+    }
+    // differentiated spectrum: Z[k] <- i kappa Z[k], Z[N - k'] <- -i kappa' Z[N - k'] (kappa = dsc * k): in place for the
+    // register-held values (BK == 2: between the two passes, so that both run the same pass body), when read for the
+    // parked ones.
     auto differentiate = [&]() {
 #pragma unroll
         for (int t = 0; t < R; ++t) {
             const int k = L.q + 16 * t;
             const double ka = dsc * (double)k, km = dsc * (double)(H - k);
             A[t] = make_double2(-ka * A[t].y, ka * A[t].x);
-            Zm[t] = make_double2(km * Zm[t].y, -km * Zm[t].x);
+            if (t < R - ZL) Zm[t] = make_double2(km * Zm[t].y, -km * Zm[t].x);
         }
     };
     if (BK == 1) differentiate();
 #pragma unroll
     for (int pass = 0; pass < (BK == 2 ? 2 : 1); ++pass) {
         double *out_t = dst_t;
+        const bool deriv = (BK == 1) || (BK == 2 && pass == 1);       // compile time (the passes are unrolled)
         if (BK == 2 && pass == 1) {
             differentiate();
             out_t = dst2_t;
@@ -562,7 +579,17 @@ DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, u
 #pragma unroll
             for (int t = 0; t < R; ++t) {
                 const int k = L.q + 16 * t;
-                const double2 a = A[t], zm = Zm[t];
+                const double2 a = A[t];
+                double2 zm;
+                if (t < R - ZL) {
+                    zm = Zm[t];
+                } else {
+                    zm = ZS[(t - (R - ZL)) * 64];
+                    if (deriv) {
+                        const double km = dsc * (double)(H - k);
+                        zm = make_double2(km * zm.y, -km * zm.x);
+                    }
+                }
                 double2 wz = zm;                         // W3^(2 r) zm
                 if (r == 1) wz = make_double2(-0.5 * zm.x + s3 * zm.y, -0.5 * zm.y - s3 * zm.x);
                 if (r == 2) wz = make_double2(-0.5 * zm.x - s3 * zm.y, -0.5 * zm.y + s3 * zm.x);
