@@ -1959,6 +1959,9 @@ template <int NF, int TT, bool REAL, int CB>
 __global__ void __launch_bounds__(256)
 solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     typedef typename El<REAL>::T E;
+    // rows prefetched ahead: 8 for the 16-lane variant (2-3 entries per lane and row); the 4-lane variant holds 9-12
+    // entries per lane and row -- 8 rows of them are 144+ registers and spilled 420-3000 bytes per lane (one wave per SIMD)
+    constexpr int PD = (CB <= 4) ? 4 : COOP_D;
     extern __shared__ int s_lds[];
     const int n = L.n, nb = L.nb, kl = L.kl, W = L.W;
     int *s_perm = s_lds;
@@ -1989,8 +1992,8 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
             xr[t] = (kb < nb) ? L.scratch[(long)(n + kb) * G + g] : make_double2(0.0, 0.0);
         }
     }
-    E pu[COOP_D][TT], pu0[COOP_D];
-    double2 py[COOP_D];
+    E pu[PD][TT], pu0[PD];
+    double2 py[PD];
     // issue() is called for jj = n - 1, n - 2, ...: running pointers (see the forward kernel)
     const long aw_rs = (long)L.BW * 64;
     const int pk63 = L.pk63;
@@ -2011,7 +2014,7 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         y_ptr -= adv ? G : 0;
     };
 #pragma unroll
-    for (int r = 0; r < COOP_D; ++r) issue(n - 1 - r, r);
+    for (int r = 0; r < PD; ++r) issue(n - 1 - r, r);
 #define DDH_COOP_BWD_ROW(r, j)                                                                                     \
     {                                                                                                              \
         E u[TT];                                                                                                   \
@@ -2019,7 +2022,7 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         _Pragma("unroll") for (int t = 0; t < TT; ++t) u[t] = (1 + ej + CB * t <= W) ? pu[r][t] : El<REAL>::zero(); \
         const E u0 = pu0[r];                                                                                       \
         const double2 y = py[r];                                                                                   \
-        issue((j) - COOP_D, r);                                                                                    \
+        issue((j) - PD, r);                                                                                    \
         double2 acc = make_double2(0.0, 0.0);                                                                      \
         _Pragma("unroll") for (int t = 0; t < TT; ++t) El<REAL>::fma2(acc, u[t], xr[t]);                           \
         acc.x = group_sum<CB>(acc.x);                                                                                  \
@@ -2038,12 +2041,12 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         }                                                                                                          \
     }
     int jt0 = 0;
-    for (; jt0 + COOP_D <= n; jt0 += COOP_D) {           // guard-free whole blocks (see the forward kernel)
+    for (; jt0 + PD <= n; jt0 += PD) {           // guard-free whole blocks (see the forward kernel)
 #pragma unroll
-        for (int r = 0; r < COOP_D; ++r) DDH_COOP_BWD_ROW(r, n - 1 - (jt0 + r))
+        for (int r = 0; r < PD; ++r) DDH_COOP_BWD_ROW(r, n - 1 - (jt0 + r))
     }
 #pragma unroll
-    for (int r = 0; r < COOP_D; ++r)
+    for (int r = 0; r < PD; ++r)
         if (jt0 + r < n) DDH_COOP_BWD_ROW(r, n - 1 - (jt0 + r))
 #undef DDH_COOP_BWD_ROW
 }
