@@ -421,7 +421,10 @@ template <int C, int WAVES, int OCC>
 int launch_cw(const FftDev &d, const FusedArgs &f_in, long nlines, hipStream_t st) {
     using G = GW<C>;
     constexpr int NT32 = (2 * C + 2) / 3;                  // 64-pair blocks that hold M/2 = N/3 pairs (3/2 dealiasing)
-    static const int lpw = getenv("DDH_GW_LPW") ? std::max(1, atoi(getenv("DDH_GW_LPW"))) : 8;     // lines per wave
+    // lines per wave: 8 when that still leaves >= 2048 workgroups (8 per CU), fewer for small problems (2-D: a few
+    // hundred lines in all)
+    static const int lpw_env = getenv("DDH_GW_LPW") ? std::max(1, atoi(getenv("DDH_GW_LPW"))) : 0;
+    const long lpw = lpw_env ? lpw_env : std::min<long>(8, std::max<long>(1, nlines / ((long)WAVES * 2048)));
     const long nwg = (nlines + (long)WAVES * lpw - 1) / ((long)WAVES * lpw);
     if ((unsigned long)nwg > 0x7fffffffUL) return fail("rfft_bilinear_fused: grid too large");
     const size_t lds = ((size_t)G::TW + (size_t)WAVES * G::LDW) * sizeof(double2);
