@@ -57,7 +57,13 @@ struct MatDev {
     const double2 *coef;
     const unsigned *expo;  // ex | ey<<8 | dx<<16 | dy<<24
     const int *order;      // optional processing order of the rows (locality of the column accesses), or null
+    // window form (band_matvec_kernel), when every term is a real, wavenumber-independent coefficient and the columns of a
+    // row lie in a window of MV_W consecutive rows of x: band[r * MV_W + d] multiplies x[base[r] + d]; nt[r] = terms of
+    // the row (0: the row of y is zero); null when the matrix does not have that form
+    const double *band;
+    const int *base;
 };
+constexpr int MV_W = 5;
 
 // optional upper-banded back-substitution along the coupled index fused into a mat-vec:
 // rows are (component, kz); y[comp, kz] = (A x)[comp, kz] - sum_{d>=1} band[d][kz] y[comp, kz+off_d]) / band[0][kz]
@@ -74,6 +80,7 @@ struct Matrix {
     std::vector<double2> coef_h;
     std::vector<unsigned> expo_h;
     void *d_rowptr = nullptr, *d_col = nullptr, *d_coef = nullptr, *d_expo = nullptr, *d_order = nullptr;
+    void *d_band = nullptr, *d_base = nullptr;
 };
 
 struct LuDev {
@@ -192,6 +199,8 @@ PencilPack::~PencilPack() {
         (void)hipFree(m->d_coef);
         (void)hipFree(m->d_expo);
         if (m->d_order) (void)hipFree(m->d_order);
+        if (m->d_band) (void)hipFree(m->d_band);
+        if (m->d_base) (void)hipFree(m->d_base);
         delete m;
     }
     for (auto l : lus) free_lu(l);
@@ -444,6 +453,69 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
         } else {
             yr[0] = v0.x;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = A x for matrices in window form (MatDev::band): the mass matrix M of an IVP -- conversions between polynomial
+// bases, a few real coefficients per row, columns within MV_W consecutive rows of the same field.  matvec_kernel reads
+// every x row once per term that uses it (M.X: 6.3 GB read for 2.2 GB of x rows with terms, the re-reads are 2-4 row
+// steps apart and miss the caches); here a thread keeps the MV_W rows around the diagonal in registers and loads each x
+// row once per row chunk.  The arithmetic per term and the order of the terms are those of matvec_kernel (a zero
+// coefficient adds an exact zero), so the two kernels agree bit for bit.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+band_matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, int rows_per_chunk) {
+    const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= P.ncells) return;
+    const CellCtx c = cell_ctx(P, cell);
+    const long plane = P.nx * P.ny;
+    const long off0 = (2 * c.mx) * P.ny + 2 * c.my, off1 = off0 + P.ny;
+    const int rr0 = blockIdx.y * rows_per_chunk;
+    const int rr1 = (rr0 + rows_per_chunk < A.nrows_out) ? rr0 + rows_per_chunk : A.nrows_out;
+    double2 wa[MV_W], wb[MV_W];                  // x rows wbase .. wbase + MV_W - 1: (cc, cs) and (sc, ss)
+#pragma unroll
+    for (int d = 0; d < MV_W; ++d) wa[d] = wb[d] = make_double2(0.0, 0.0);
+    int wbase = -(1 << 30);
+    const int ncol = P.nrows;
+    auto load_row = [&](int col, double2 &a, double2 &b) {
+        const double *xr = x + (long)(col < ncol ? col : ncol - 1) * plane;      // (slots beyond the last row: zero coefficient)
+        a = *reinterpret_cast<const double2 *>(xr + off0);
+        b = *reinterpret_cast<const double2 *>(xr + off1);
+    };
+    for (int r = rr0; r < rr1; ++r) {
+        const int base = A.base[r];              // wave-uniform; < 0: the row has no terms
+        double2 v0 = make_double2(0.0, 0.0), v1 = v0;
+        if (base >= 0) {
+            int adv = base - wbase;
+            if (adv < 0 || adv > MV_W) {         // first row of the chunk / a jump to another field: fill the window
+#pragma unroll
+                for (int d = 0; d < MV_W; ++d) load_row(base + d, wa[d], wb[d]);
+            } else {
+                while (adv-- > 0) {              // one new row per step (the usual case: adv == 1)
+#pragma unroll
+                    for (int d = 0; d + 1 < MV_W; ++d) { wa[d] = wa[d + 1]; wb[d] = wb[d + 1]; }
+                    ++wbase;
+                    load_row(wbase + MV_W - 1, wa[MV_W - 1], wb[MV_W - 1]);
+                }
+            }
+            wbase = base;
+            const double *cf = A.band + (long)r * MV_W;
+            double2 accP = make_double2(0.0, 0.0), accQ = accP;
+#pragma unroll
+            for (int d = 0; d < MV_W; ++d) {
+                const double2 v = make_double2(cf[d], 0.0);
+                const double2 xP = make_double2(wa[d].x - wb[d].y, wa[d].y + wb[d].x);
+                const double2 xQ = make_double2(wa[d].x + wb[d].y, wa[d].y - wb[d].x);
+                cfma(accP, v, xP);
+                cfma(accQ, v, xQ);
+            }
+            v0 = make_double2(0.5 * (accP.x + accQ.x), 0.5 * (accP.y + accQ.y));
+            v1 = make_double2(0.5 * (accP.y - accQ.y), 0.5 * (accQ.x - accP.x));
+        }
+        double *yr = y + (long)r * plane;
+        *reinterpret_cast<double2 *>(yr + off0) = v0;
+        *reinterpret_cast<double2 *>(yr + off1) = v1;
     }
 }
 
@@ -2466,6 +2538,29 @@ int ddh_pencil_add_matrix(ddh_handle pack, const ddh_polymat *mat, int nrows_out
             if (!upload_vec(&m->d_order, ord.data(), ord.size())) m->dev.order = (const int *)m->d_order;
         }
     }
+    // window form for band_matvec_kernel (two Fourier axes only): real, wavenumber-independent coefficients, the columns of
+    // every row strictly ascending and inside MV_W consecutive rows
+    m->dev.band = nullptr;
+    m->dev.base = nullptr;
+    if (pp->dev.nf == 2 && nt > 0 && !getenv("DDH_MV_NOBAND")) {
+        bool ok = true;
+        std::vector<double> band((size_t)nrows_out * MV_W, 0.0);
+        std::vector<int> base(nrows_out, -1);
+        for (int r = 0; r < nrows_out && ok; ++r) {
+            for (int k = rowptr[r]; k < rowptr[r + 1] && ok; ++k) {
+                if (m->expo_h[k] != 0 || m->coef_h[k].y != 0.0) ok = false;
+                if (k > rowptr[r] && m->col_h[k] <= m->col_h[k - 1]) ok = false;
+                if (k == rowptr[r]) base[r] = m->col_h[k];
+                const int d = m->col_h[k] - base[r];
+                if (d < 0 || d >= MV_W) ok = false;
+                else band[(size_t)r * MV_W + d] = m->coef_h[k].x;
+            }
+        }
+        if (ok && !upload_vec(&m->d_band, band.data(), band.size()) && !upload_vec(&m->d_base, base.data(), base.size())) {
+            m->dev.band = (const double *)m->d_band;
+            m->dev.base = (const int *)m->d_base;
+        }
+    }
     pp->mats.push_back(m);
     *mat_id = (int)pp->mats.size() - 1;
     return 0;
@@ -2508,7 +2603,9 @@ static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y,
     const unsigned chunks = (unsigned)((A.nrows_out + rpc - 1) / rpc);
     if (chunks > 65535) return fail("pencil_matvec: too many row chunks");
     const dim3 grid(blocks, chunks ? chunks : 1);
-    if (P.nf == 2)
+    if (P.nf == 2 && A.band && ps.nz == 0 && !A.order && blocks >= 64)
+        hipLaunchKernelGGL(band_matvec_kernel, grid, dim3(256), 0, s, P, A, x, y, rpc);
+    else if (P.nf == 2)
         hipLaunchKernelGGL(matvec_kernel<2>, grid, dim3(256), 0, s, P, A, x, y, ps, rpc);
     else if (P.nf == 1)
         hipLaunchKernelGGL(matvec_kernel<1>, grid, dim3(256), 0, s, P, A, x, y, ps, rpc);
