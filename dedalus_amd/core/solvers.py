@@ -446,6 +446,7 @@ class SolverBase:
                         total[tl.row[t], 0, 0] += (tl.coef[t] * val).real
             nz = np.flatnonzero(total)
             self.F_const = self.ex.make_scatter(nz, total.reshape(-1)[nz]) if nz.size else None
+            self._F_const_rows = np.unique(nz // (nx * ny))
 
     def _plan_direct_F(self, groups):
         """Right-hand sides that are nothing but fused nonlinear products converted to their equation's basis (times a
@@ -629,7 +630,31 @@ class SolverBase:
                                          rhs=[self.gather_pencil(rhs, "equations", gx, gy) for gx, gy in probe["groups"]],
                                          x=[self.gather_pencil(out, "variables", gx, gy) for gx, gy in probe["groups"]]))
 
-    def solve_lincomb(self, lu, xs, alphas, out):
+    def mx_f_zero_rows(self):
+        """Device byte mask over the rows of a system vector: 1 where BOTH M.X and the F vector of `evaluate_F` are
+        structurally zero -- equations without a time derivative and without right-hand side (the continuity equation) --
+        or None when that is not known (F through the general gather path).  A Runge-Kutta right-hand side built from
+        M.X and F vectors only (timesteppers.RungeKuttaIMEX) passes it to the solve, whose forward sweep then does not
+        read those rows (ddh_pencil_solve_recombined_sparse)."""
+        if getattr(self, "_zrows", "unset") != "unset":
+            return self._zrows
+        self._zrows = None
+        if self.F_direct is None or not getattr(self.pack, "supports_zero_rows", False) or self.P_id is None:
+            return None
+        if os.environ.get("DDH_NO_ZERO_ROWS") is not None:
+            return None
+        mask = np.ones(self.R, dtype=np.uint8)
+        mask[np.unique(np.asarray(self.M_tl.row))] = 0
+        for einfo, _scale in self.F_direct.values():
+            mask[einfo["row0"]:einfo["row0"] + einfo["rows"]] = 0
+        if self.F_const is not None:
+            mask[self._F_const_rows] = 0
+        if mask.any():
+            t = self.ex.torch
+            self._zrows = (t.as_tensor(mask, device=self.ex.dev.tdev), float(mask.mean()))
+        return self._zrows
+
+    def solve_lincomb(self, lu, xs, alphas, out, zero_rows=None):
         """out = (a M + b L)^-1 (sum_t alphas[t] xs[t]).  The combination is formed inside the forward sweep of the band
         solve; with a parity probe attached (or more terms than the kernel takes) it is materialised first."""
         if getattr(self, "solve_probe", None) is not None or len(xs) > self.pack.MAX_RHS_TERMS or not hasattr(self.pack, "solve_lincomb"):
@@ -641,7 +666,10 @@ class SolverBase:
             self.pack.solve_lincomb(lu, xs, alphas, out)
         elif hasattr(self.pack, "solve_recombined"):
             Y = self.ex.empty((self.R, self.nx, self.ny))
-            self.pack.solve_recombined(lu, xs, alphas, self.P_id, Y, out)
+            if zero_rows is not None:
+                self.pack.solve_recombined(lu, xs, alphas, self.P_id, Y, out, zero_rows=zero_rows)
+            else:
+                self.pack.solve_recombined(lu, xs, alphas, self.P_id, Y, out)
         else:
             Y = self.ex.empty((self.R, self.nx, self.ny))
             self.pack.solve_lincomb(lu, xs, alphas, Y)

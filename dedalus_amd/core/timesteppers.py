@@ -82,10 +82,13 @@ class _SolveMixin:
             self._RHS = s.ex.zeros((s.R, s.nx, s.ny))
         return self._RHS
 
-    def _solve_combination(self, xs, al, lu):
+    def _solve_combination(self, xs, al, lu, zero_rows=None):
         s = self.solver
         if hasattr(s, "solve_lincomb"):
-            s.solve_lincomb(lu, xs, al, s.X)
+            if zero_rows is not None:
+                s.solve_lincomb(lu, xs, al, s.X, zero_rows=zero_rows)
+            else:
+                s.solve_lincomb(lu, xs, al, s.X)
         else:
             s.ex.lincomb(self.RHS, xs, al)
             s.solve(lu, self.RHS, s.X)
@@ -356,7 +359,11 @@ class RungeKuttaIMEX(_SolveMixin):
             vec = {"MX0": lambda q: self.MX0, "F": lambda q: self.F[q], "LX": lambda q: self.LX[q], "MX": lambda q: self.MX[q]}
             xs = [vec[key[0]](key[1] if len(key) > 1 else None) for key, v in comb.items() if v != 0.0]
             al = [v for v in comb.values() if v != 0.0]
-            self._solve_combination(xs, al, self._lus[float(H[i, i])])
+            # a right-hand side made of M.X and F vectors only: rows that are structurally zero in both are not read
+            zrows = None
+            if not any(key[0] == "LX" and v != 0.0 for key, v in comb.items()) and hasattr(s, "mx_f_zero_rows"):
+                zrows = s.mx_f_zero_rows()
+            self._solve_combination(xs, al, self._lus[float(H[i, i])], zero_rows=zrows)
             s.mark_state_current()
             s.sim_time = t0 + k * c[i]
 

@@ -637,6 +637,7 @@ struct RhsSrc {
     int n;
     const double *p[RHS_MAX];
     double a[RHS_MAX];
+    const unsigned char *zrow;   // optional, per row of the system vectors: 1 = the row is zero in EVERY term (not read)
 };
 
 template <int NF, int XD = 1>
@@ -1534,10 +1535,12 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     int *s_perm = s_lds;                                    // rowperm, then colperm of the border
     int *s_perm2 = s_lds + (L.pair ? N + nb : 0);           // the partner's (aliases s_perm when unpaired)
     unsigned char *s_code = (unsigned char *)(s_perm2 + N + nb);
+    unsigned char *s_zero = s_code + N + nb;                // rows whose right-hand side is zero in every term: not read
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         s_perm[i] = L.rowperm[i];
         if (L.pair) s_perm2[i] = L.rowperm2[i];
         s_code[i] = L.row_code[i];
+        s_zero[i] = rhs.zrow ? (rhs.zrow[L.rowperm[i]] && (!L.pair || rhs.zrow[L.rowperm2[i]])) : 0;
     }
     for (int i = threadIdx.x; i < nb; i += blockDim.x) {
         s_perm[N + i] = L.colperm[n + i];
@@ -1570,6 +1573,7 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     const long row_step = (long)L.BW << 6, ab_step = (long)nb << 6;
 
     auto load_row = [&](int i) -> double2 {
+        if (s_zero[i]) return make_double2(0.0, 0.0);           // wave-uniform
         double2 v = load_sys<NF>(rhs, plane, my_perm[i], P, c, s);
         if (conjq) v.y = -v.y;
         const unsigned char code = s_code[i];
@@ -2254,7 +2258,8 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     const unsigned blocks = (unsigned)((P.G + 255) / 256);
     const int W = d.W;
     const size_t per_entry = d.pair ? 9 : 5;    // one (two when paired) int permutations + a code byte per row
-    const size_t lds_f = (size_t)(d.N + d.nb) * per_entry + 16, lds_b = (size_t)(d.n > 0 ? d.n : 1) * per_entry + 16;
+    const size_t lds_f = (size_t)(d.N + d.nb) * (per_entry + 1) + 16,     // (+ the zero-row flags of the lean sweep)
+ lds_b = (size_t)(d.n > 0 ? d.n : 1) * per_entry + 16;
     if (lds_f > 64 * 1024) return fail("pencil_solve: system too large for the LDS permutation cache");
     int use_fwd, cb;
     choose_variant<NF>(pp, d, use_fwd, cb);
@@ -3019,6 +3024,12 @@ static int build_pband(PencilPack *pp, LuFactor *lu, int p_mat_id) {
 
 int ddh_pencil_solve_recombined(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h,
                                 const double *alpha_h, int p_mat_id, double *work, double *x, void *stream) {
+    return ddh_pencil_solve_recombined_sparse(pack, lu_id, nterms, xs_h, alpha_h, p_mat_id, work, x, nullptr, stream);
+}
+
+int ddh_pencil_solve_recombined_sparse(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h,
+                                       const double *alpha_h, int p_mat_id, double *work, double *x,
+                                       const unsigned char *zero_rows, void *stream) {
     PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
     if (!pp) return -1;
     if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_solve: bad LU id");
@@ -3033,6 +3044,7 @@ int ddh_pencil_solve_recombined(ddh_handle pack, int lu_id, int nterms, const do
         r.p[t] = xs_h[t];
         r.a[t] = alpha_h[t];
     }
+    r.zrow = zero_rows;
     LuFactor *lu = pp->lus[lu_id];
     hipStream_t s = as_stream(stream);
     static const bool no_fuse = getenv("DDH_NO_PFUSE") != nullptr;

@@ -323,6 +323,14 @@ int ddh_pencil_solve_lincomb(ddh_handle pack, int lu_id, int nterms, const doubl
  * work: a system vector of scratch, distinct from x and the right-hand-side terms.                                */
 int ddh_pencil_solve_recombined(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h,
                                 const double *alpha_h, int p_mat_id, double *work, double *x, void *stream);
+/* The same with a row mask: zero_rows[r] != 0 (device array, one byte per row of the system vectors) promises that row r is
+ * zero in EVERY right-hand-side term -- rows of equations without time derivative and without right-hand side (the
+ * continuity equation of core/timesteppers.py:588-623's M.X / F vectors).  The forward sweep then does not read them
+ * (a fifth of the right-hand-side traffic of 3-D Rayleigh-Benard).  Kernels without the shortcut ignore the mask, which
+ * is always correct.  null = ddh_pencil_solve_recombined.                                                          */
+int ddh_pencil_solve_recombined_sparse(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h,
+                                       const double *alpha_h, int p_mat_id, double *work, double *x,
+                                       const unsigned char *zero_rows, void *stream);
 /* Sweep variant used by ddh_pencil_solve (all variants compute the same factorization's solution; they differ in how
  * many lanes share one system).  mode 1 (default): chosen by the number of systems; 0: one
  * thread per system; 2: cooperative (16 lanes) in both sweeps.  fwd = 0 / 1 and backward_lanes = 0 / 4 / 16 override
