@@ -28,14 +28,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PMC_FAMILY = {   # kernel family in this file -> device kernel name prefixes in profiles/r3_pmc_traffic.json
     "pencil_solve": ["solve_forward_", "solve_backward_"],
-    "pencil_matvec": ["matvec_kernel"],
+    "pencil_matvec": ["band_matvec_kernel"],
     "rfft_bilinear_fused": ["gw::gridwave_bilinear_kernel", "fused_rfft_bilinear_kernel"],
     "rfft_backward_contig": ["fft_axis_kernel<1, false"],
-    "rfft_backward_strided": ["fft_axis_kernel<1, true"],
+    "rfft_backward_strided": ["wave_rfft_kernel<0"],
+    "rfft_backward_strided_dual": ["wave_rfft_kernel<2"],
     "rfft_forward_contig": ["fft_axis_kernel<0, false"],
-    "rfft_forward_strided": ["fft_axis_kernel<0, true"],
-    "cheb_forward_strided": ["fft_axis_kernel<2, true"],
-    "cheb_backward_strided": ["fft_axis_kernel<3, true"],
+    "rfft_forward_strided": ["wave_rfft_kernel<3"],
+    "cheb_forward_strided": ["wave_cheb_kernel<3"],
+    "cheb_backward_strided": ["wave_cheb_kernel<0"],
+    "cheb_backward_strided_dual": ["wave_cheb_kernel<1"],
     "grid_bilinear": ["bilinear_kernel"],
     "lincomb": ["lincomb_kernel"],
 }
