@@ -654,7 +654,35 @@ class SolverBase:
             self._zrows = (t.as_tensor(mask, device=self.ex.dev.tdev), float(mask.mean()))
         return self._zrows
 
-    def solve_lincomb(self, lu, xs, alphas, out, zero_rows=None):
+    def intermediate_skip_rows(self):
+        """Device byte mask over the rows of the state vector: 1 for the unknowns that nothing reads between the stages of a
+        Runge-Kutta step -- variables without a column in the mass matrix M that are not operands of any F expression
+        (pressure, tau variables) -- or None.  The solve of an INTERMEDIATE stage then does not store them."""
+        if getattr(self, "_skiprows", "unset") != "unset":
+            return self._skiprows
+        self._skiprows = None
+        if not getattr(self.pack, "supports_zero_rows", False) or self.P_id is None or self.F_direct is None:
+            return None
+        if os.environ.get("DDH_NO_SKIP_ROWS") is not None:
+            return None
+        used = set()
+        for einfo in self.eq_info:
+            F = einfo["eq"]["F"]
+            if F is not None and hasattr(F, "leaves"):
+                used |= {id(f) for f in F.leaves()}
+        mask = np.zeros(self.R, dtype=np.uint8)
+        mcols = np.zeros(self.R, dtype=bool)
+        mcols[np.unique(np.asarray(self.M_tl.col))] = True
+        for info in self.var_info:
+            r0, r1 = info["row0"], info["row0"] + info["rows"]
+            if id(info["field"]) not in used and not mcols[r0:r1].any():
+                mask[r0:r1] = 1
+        if mask.any():
+            t = self.ex.torch
+            self._skiprows = (t.as_tensor(mask, device=self.ex.dev.tdev), float(mask.mean()))
+        return self._skiprows
+
+    def solve_lincomb(self, lu, xs, alphas, out, zero_rows=None, skip_rows=None):
         """out = (a M + b L)^-1 (sum_t alphas[t] xs[t]).  The combination is formed inside the forward sweep of the band
         solve; with a parity probe attached (or more terms than the kernel takes) it is materialised first."""
         if getattr(self, "solve_probe", None) is not None or len(xs) > self.pack.MAX_RHS_TERMS or not hasattr(self.pack, "solve_lincomb"):
@@ -666,8 +694,8 @@ class SolverBase:
             self.pack.solve_lincomb(lu, xs, alphas, out)
         elif hasattr(self.pack, "solve_recombined"):
             Y = self.ex.empty((self.R, self.nx, self.ny))
-            if zero_rows is not None:
-                self.pack.solve_recombined(lu, xs, alphas, self.P_id, Y, out, zero_rows=zero_rows)
+            if zero_rows is not None or skip_rows is not None:
+                self.pack.solve_recombined(lu, xs, alphas, self.P_id, Y, out, zero_rows=zero_rows, skip_rows=skip_rows)
             else:
                 self.pack.solve_recombined(lu, xs, alphas, self.P_id, Y, out)
         else:

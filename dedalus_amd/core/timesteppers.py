@@ -82,11 +82,11 @@ class _SolveMixin:
             self._RHS = s.ex.zeros((s.R, s.nx, s.ny))
         return self._RHS
 
-    def _solve_combination(self, xs, al, lu, zero_rows=None):
+    def _solve_combination(self, xs, al, lu, zero_rows=None, skip_rows=None):
         s = self.solver
         if hasattr(s, "solve_lincomb"):
-            if zero_rows is not None:
-                s.solve_lincomb(lu, xs, al, s.X, zero_rows=zero_rows)
+            if zero_rows is not None or skip_rows is not None:
+                s.solve_lincomb(lu, xs, al, s.X, zero_rows=zero_rows, skip_rows=skip_rows)
             else:
                 s.solve_lincomb(lu, xs, al, s.X)
         else:
@@ -363,7 +363,12 @@ class RungeKuttaIMEX(_SolveMixin):
             zrows = None
             if not any(key[0] == "LX" and v != 0.0 for key, v in comb.items()) and hasattr(s, "mx_f_zero_rows"):
                 zrows = s.mx_f_zero_rows()
-            self._solve_combination(xs, al, self._lus[float(H[i, i])], zero_rows=zrows)
+            # an intermediate stage: unknowns that neither M.X nor F read (pressure, taus) are not stored -- they are final
+            # only after the last stage (not with DDH_RK_DIRECT_LX: L.X_j reads every unknown)
+            skip = None
+            if i < self.stages and not self._direct and hasattr(s, "intermediate_skip_rows"):
+                skip = s.intermediate_skip_rows()
+            self._solve_combination(xs, al, self._lus[float(H[i, i])], zero_rows=zrows, skip_rows=skip)
             s.mark_state_current()
             s.sim_time = t0 + k * c[i]
 

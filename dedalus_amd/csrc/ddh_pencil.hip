@@ -638,6 +638,7 @@ struct RhsSrc {
     const double *p[RHS_MAX];
     double a[RHS_MAX];
     const unsigned char *zrow;   // optional, per row of the system vectors: 1 = the row is zero in EVERY term (not read)
+    const unsigned char *skip;   // optional, per row of the solution: 1 = the caller does not need the row (not written)
 };
 
 template <int NF, int XD = 1>
@@ -1696,17 +1697,20 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
 
 template <int NF, int WT, bool REAL, bool PREF, bool PFUSE = false, int DBG = 0>
 __global__ void __launch_bounds__(256)
-solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const double *__restrict__ pband) {
+solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const double *__restrict__ pband,
+                      const unsigned char *__restrict__ skip) {
     typedef typename El<REAL>::T E;
     extern __shared__ int s_lds[];
     const int n = L.n, nb = L.nb, kl = L.kl, W = L.W;
     int *s_perm = s_lds;
     int *s_perm2 = s_lds + (L.pair ? n : 0);
     unsigned char *s_code = (unsigned char *)(s_perm2 + n);
+    unsigned char *s_skip = s_code + n;                 // unknowns the caller does not need: not stored
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         s_perm[i] = L.colperm[i];
         if (L.pair) s_perm2[i] = L.colperm2[i];
         s_code[i] = REAL ? L.col_code[i] : 0;
+        s_skip[i] = skip ? (skip[L.colperm[i]] && (!L.pair || skip[L.colperm2[i]])) : 0;
     }
     __syncthreads();
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1768,6 +1772,7 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
         __builtin_amdgcn_sched_barrier(0);
     };
     auto emit = [&](int j, double2 v) {
+        if (s_skip[j]) return;                           // wave-uniform
         if (REAL) {
             const unsigned char code = s_code[j];
             if (code & 1) v = make_double2(-v.y, v.x);
@@ -2259,7 +2264,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     const int W = d.W;
     const size_t per_entry = d.pair ? 9 : 5;    // one (two when paired) int permutations + a code byte per row
     const size_t lds_f = (size_t)(d.N + d.nb) * (per_entry + 1) + 16,     // (+ the zero-row flags of the lean sweep)
- lds_b = (size_t)(d.n > 0 ? d.n : 1) * per_entry + 16;
+ lds_b = (size_t)(d.n > 0 ? d.n : 1) * (per_entry + 1) + 16;
     if (lds_f > 64 * 1024) return fail("pencil_solve: system too large for the LDS permutation cache");
     int use_fwd, cb;
     choose_variant<NF>(pp, d, use_fwd, cb);
@@ -2338,15 +2343,15 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
 #define DDH_SOLVE(WTV)                                                                                             \
     {                                                                                                              \
         if (d.real)                                                                                                \
-            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband); \
+            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip); \
         else                                                                                                       \
-            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband); \
+            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip); \
     }
     // (window sizes: few instantiations -- every one is a fully unrolled kernel and this file dominates the build time)
     bool fuse_p = false;
     if constexpr (NF == 2) fuse_p = want_p && d.real && d.pband != nullptr && d.n > 0 && !cb && W <= 48;
 #define DDH_SOLVE_P(WTV)                                                                                           \
-    hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false, true>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband);
+    hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false, true>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
     if (fuse_p) {
         if constexpr (NF == 2) {
             if (W <= 32) DDH_SOLVE_P(32)
@@ -2356,7 +2361,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
             // addresses).  Results are NOT a solve.  Round 3: stores 2.2 ms, factor loads 2.9 ms of
             // the 4.9 ms sweep, FMAs and window shifts 0.
             else if (W <= 34 && getenv("DDH_BWD_DBG") && atoi(getenv("DDH_BWD_DBG")) > 0) {
-#define DDH_SOLVE_DBG(V) case V: hipLaunchKernelGGL((solve_backward_kernel<NF, 34, true, false, true, V>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband); break;
+#define DDH_SOLVE_DBG(V) case V: hipLaunchKernelGGL((solve_backward_kernel<NF, 34, true, false, true, V>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip); break;
                 switch (atoi(getenv("DDH_BWD_DBG"))) {
                     DDH_SOLVE_DBG(1) DDH_SOLVE_DBG(2) DDH_SOLVE_DBG(4) DDH_SOLVE_DBG(8) DDH_SOLVE_DBG(16) DDH_SOLVE_DBG(32) DDH_SOLVE_DBG(31)
                     default: DDH_SOLVE_P(34)
@@ -3024,12 +3029,12 @@ static int build_pband(PencilPack *pp, LuFactor *lu, int p_mat_id) {
 
 int ddh_pencil_solve_recombined(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h,
                                 const double *alpha_h, int p_mat_id, double *work, double *x, void *stream) {
-    return ddh_pencil_solve_recombined_sparse(pack, lu_id, nterms, xs_h, alpha_h, p_mat_id, work, x, nullptr, stream);
+    return ddh_pencil_solve_recombined_sparse(pack, lu_id, nterms, xs_h, alpha_h, p_mat_id, work, x, nullptr, nullptr, stream);
 }
 
 int ddh_pencil_solve_recombined_sparse(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h,
                                        const double *alpha_h, int p_mat_id, double *work, double *x,
-                                       const unsigned char *zero_rows, void *stream) {
+                                       const unsigned char *zero_rows, const unsigned char *skip_rows, void *stream) {
     PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
     if (!pp) return -1;
     if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_solve: bad LU id");
@@ -3045,6 +3050,7 @@ int ddh_pencil_solve_recombined_sparse(ddh_handle pack, int lu_id, int nterms, c
         r.a[t] = alpha_h[t];
     }
     r.zrow = zero_rows;
+    r.skip = skip_rows;
     LuFactor *lu = pp->lus[lu_id];
     hipStream_t s = as_stream(stream);
     static const bool no_fuse = getenv("DDH_NO_PFUSE") != nullptr;

@@ -107,7 +107,7 @@ SIGNATURES = {
     "ddh_pencil_set_pairing": [_h, _ip, _ip, _l],
     "ddh_pencil_solve_lincomb": [_h, _i, _i, C.POINTER(_vp), _dp, _vp, _vp],
     "ddh_pencil_solve_recombined": [_h, _i, _i, C.POINTER(_vp), _dp, _i, _vp, _vp, _vp],
-    "ddh_pencil_solve_recombined_sparse": [_h, _i, _i, C.POINTER(_vp), _dp, _i, _vp, _vp, _vp, _vp],
+    "ddh_pencil_solve_recombined_sparse": [_h, _i, _i, C.POINTER(_vp), _dp, _i, _vp, _vp, _vp, _vp, _vp],
     "ddh_pencil_flagged": [_h, _i, _ip, C.POINTER(_l), _i],
     "ddh_pencil_set_dense_inverse": [_h, _i, _dp],
     "ddh_pencil_set_dense_inverse_dev": [_h, _i, _i, _vp, _i, _vp],

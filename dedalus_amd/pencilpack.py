@@ -251,23 +251,28 @@ class PencilPack:
 
     supports_zero_rows = True
 
-    def solve_recombined(self, lu_id, xs, alphas, p_mat_id, work, x, zero_rows=None):
+    def solve_recombined(self, lu_id, xs, alphas, p_mat_id, work, x, zero_rows=None, skip_rows=None):
         """x = P (a M + b L P)^-1 (sum_t alphas[t] xs[t]) (ddh_pencil_solve_recombined): recombination fused into the
         backward sweep where the kernel variant allows, else through `work` and a mat-vec.
-        zero_rows = (device uint8 mask, fraction set): rows that are zero in every term (ddh_pencil_solve_recombined_sparse)."""
+        zero_rows = (device uint8 mask, fraction set): rows that are zero in every term; skip_rows = (mask, fraction):
+        unknowns the caller does not need (ddh_pencil_solve_recombined_sparse)."""
         t = self._timer()
         if t is not None:
-            read = 1.0 - (zero_rows[1] if zero_rows is not None else 0.0)     # masked rows are not read: not counted
-            nb = self.lu_bytes(lu_id) + (sum(v.numel() for v in xs) * read + x.numel()) * 8
-            return t.run("pencil_solve", nb, self._solve_recombined, lu_id, xs, alphas, p_mat_id, work, x, zero_rows)
-        return self._solve_recombined(lu_id, xs, alphas, p_mat_id, work, x, zero_rows)
+            read = 1.0 - (zero_rows[1] if zero_rows is not None else 0.0)     # masked rows are not read / written:
+            wrote = 1.0 - (skip_rows[1] if skip_rows is not None else 0.0)    # not counted
+            nb = self.lu_bytes(lu_id) + (sum(v.numel() for v in xs) * read + x.numel() * wrote) * 8
+            return t.run("pencil_solve", nb, self._solve_recombined, lu_id, xs, alphas, p_mat_id, work, x, zero_rows,
+                         skip_rows)
+        return self._solve_recombined(lu_id, xs, alphas, p_mat_id, work, x, zero_rows, skip_rows)
 
-    def _solve_recombined(self, lu_id, xs, alphas, p_mat_id, work, x, zero_rows=None):
+    def _solve_recombined(self, lu_id, xs, alphas, p_mat_id, work, x, zero_rows=None, skip_rows=None):
         arr = (C.c_void_p * len(xs))(*[C.c_void_p(v.data_ptr()) for v in xs])
         al = np.ascontiguousarray(alphas, dtype=np.float64)
-        if zero_rows is not None:
+        if zero_rows is not None or skip_rows is not None:
+            zp = C.c_void_p(zero_rows[0].data_ptr()) if zero_rows is not None else None
+            sp = C.c_void_p(skip_rows[0].data_ptr()) if skip_rows is not None else None
             libhip.call("ddh_pencil_solve_recombined_sparse", self.handle, lu_id, len(xs), arr, libhip.as_dp(al),
-                        int(p_mat_id), ptr(work), ptr(x), C.c_void_p(zero_rows[0].data_ptr()), self.dev.stream)
+                        int(p_mat_id), ptr(work), ptr(x), zp, sp, self.dev.stream)
             return
         libhip.call("ddh_pencil_solve_recombined", self.handle, lu_id, len(xs), arr, libhip.as_dp(al), int(p_mat_id),
                     ptr(work), ptr(x), self.dev.stream)

@@ -327,10 +327,12 @@ int ddh_pencil_solve_recombined(ddh_handle pack, int lu_id, int nterms, const do
  * zero in EVERY right-hand-side term -- rows of equations without time derivative and without right-hand side (the
  * continuity equation of core/timesteppers.py:588-623's M.X / F vectors).  The forward sweep then does not read them
  * (a fifth of the right-hand-side traffic of 3-D Rayleigh-Benard).  Kernels without the shortcut ignore the mask, which
- * is always correct.  null = ddh_pencil_solve_recombined.                                                          */
+ * is always correct.  skip_rows[r] != 0 (same shape, rows of the SOLUTION): the caller does not need unknown r of x -- an
+ * intermediate Runge-Kutta stage never reads the pressure and the tau variables (no mass-matrix column, not an operand of F)
+ * -- and the backward sweep does not store it; x keeps whatever it held there.  null masks = ddh_pencil_solve_recombined. */
 int ddh_pencil_solve_recombined_sparse(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h,
                                        const double *alpha_h, int p_mat_id, double *work, double *x,
-                                       const unsigned char *zero_rows, void *stream);
+                                       const unsigned char *zero_rows, const unsigned char *skip_rows, void *stream);
 /* Sweep variant used by ddh_pencil_solve (all variants compute the same factorization's solution; they differ in how
  * many lanes share one system).  mode 1 (default): chosen by the number of systems; 0: one
  * thread per system; 2: cooperative (16 lanes) in both sweeps.  fwd = 0 / 1 and backward_lanes = 0 / 4 / 16 override

@@ -222,10 +222,11 @@ def test_zero_row_mask_of_the_runge_kutta_right_hand_side(monkeypatch):
     import dedalus_amd.public as d3
 
     def run(masked):
-        if not masked:
-            monkeypatch.setenv("DDH_NO_ZERO_ROWS", "1")
-        else:
-            monkeypatch.delenv("DDH_NO_ZERO_ROWS", raising=False)
+        for var in ("DDH_NO_ZERO_ROWS", "DDH_NO_SKIP_ROWS"):
+            if not masked:
+                monkeypatch.setenv(var, "1")
+            else:
+                monkeypatch.delenv(var, raising=False)
         solver, f = problems.rayleigh_benard_3d(d3, Nx=32, Ny=32, Nz=16, timestepper="RK222")
         solver.pack.set_solve_variant(0)                 # one thread per system: the lean forward sweep
         for _ in range(3):
@@ -242,6 +243,14 @@ def test_zero_row_mask_of_the_runge_kutta_right_hand_side(monkeypatch):
     for i in (1, 2):                                      # the b and u equations carry dt and F
         e = s1.eq_info[i]
         assert not mask[e["row0"]:e["row0"] + e["rows"]].any()
+    # intermediate stages do not store what nothing reads before the last stage: the pressure and the tau variables
+    k1, k0 = s1.intermediate_skip_rows(), s0.intermediate_skip_rows()
+    assert k0 is None and k1 is not None
+    skip = k1[0].cpu().numpy()
+    for info in s1.var_info:
+        want = info["field"].name not in ("b", "u")
+        assert skip[info["row0"]:info["row0"] + info["rows"]].all() == want, info["field"].name
+        assert skip[info["row0"]:info["row0"] + info["rows"]].any() == want, info["field"].name
     assert abs(z1[1] - mask.mean()) < 1e-15 and 0.15 < z1[1] < 0.35     # (16 + 8 of 89 rows here, 264 of 1289 at 512 x 512 x 256)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
