@@ -331,7 +331,8 @@ class RungeKuttaIMEX(_SolveMixin):
             self._k = k
         t0 = s.sim_time
         s.sync_state_to_device()
-        pack.matvec(s.M_id, s.X, self.MX0)
+        own = dict(owned=True) if getattr(pack, "supports_zero_rows", False) else {}
+        pack.matvec(s.M_id, s.X, self.MX0, **own)
         combs = {}
         for i in range(1, self.stages + 1):
             j = i - 1                                   # s.X holds X_j
@@ -339,7 +340,7 @@ class RungeKuttaIMEX(_SolveMixin):
                 if self._direct or j == 0:
                     pack.matvec(s.L_id, s.X, self.LX[j])
                 else:
-                    pack.matvec(s.M_id, s.X, self.MX[j])
+                    pack.matvec(s.M_id, s.X, self.MX[j], **own)
             s.evaluate_F(self.F[i - 1], persistent=True)
             # RHS_i as a combination of the stored vectors.  RHS_j of an earlier stage is itself such a combination
             # (it is not kept): -k H_ij L.X_j = -(H_ij / H_jj) (RHS_j - M.X_j) expands into MX0, F_*, MX_* terms.

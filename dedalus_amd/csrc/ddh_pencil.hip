@@ -465,7 +465,7 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
 // coefficient adds an exact zero), so the two kernels agree bit for bit.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-band_matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, int rows_per_chunk) {
+band_matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, int rows_per_chunk, int keep_empty) {
     const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= P.ncells) return;
     const CellCtx c = cell_ctx(P, cell);
@@ -513,6 +513,7 @@ band_matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *
             v0 = make_double2(0.5 * (accP.x + accQ.x), 0.5 * (accP.y + accQ.y));
             v1 = make_double2(0.5 * (accP.y - accQ.y), 0.5 * (accQ.x - accP.x));
         }
+        if (base < 0 && keep_empty) continue;    // ddh_pencil_matvec_update: rows without terms are left as they are
         double *yr = y + (long)r * plane;
         *reinterpret_cast<double2 *>(yr + off0) = v0;
         *reinterpret_cast<double2 *>(yr + off1) = v1;
@@ -2576,7 +2577,8 @@ int ddh_pencil_add_matrix(ddh_handle pack, const ddh_polymat *mat, int nrows_out
     return 0;
 }
 
-static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y, const PostSolve &ps, void *stream) {
+static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y, const PostSolve &ps, void *stream,
+                         int keep_empty = 0) {
     if (mat_id < 0 || mat_id >= (int)pp->mats.size()) return fail("pencil_matvec: bad matrix id");
     if (x == y) return fail("pencil_matvec: in-place unsupported");
     const PencilDev &P = pp->dev;
@@ -2614,7 +2616,7 @@ static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y,
     if (chunks > 65535) return fail("pencil_matvec: too many row chunks");
     const dim3 grid(blocks, chunks ? chunks : 1);
     if (P.nf == 2 && A.band && ps.nz == 0 && !A.order && blocks >= 64)
-        hipLaunchKernelGGL(band_matvec_kernel, grid, dim3(256), 0, s, P, A, x, y, rpc);
+        hipLaunchKernelGGL(band_matvec_kernel, grid, dim3(256), 0, s, P, A, x, y, rpc, keep_empty);
     else if (P.nf == 2)
         hipLaunchKernelGGL(matvec_kernel<2>, grid, dim3(256), 0, s, P, A, x, y, ps, rpc);
     else if (P.nf == 1)
@@ -2631,6 +2633,14 @@ int ddh_pencil_matvec(ddh_handle pack, int mat_id, const double *x, double *y, v
     PostSolve ps;
     memset(&ps, 0, sizeof(ps));
     return launch_matvec(pp, mat_id, x, y, ps, stream);
+}
+
+int ddh_pencil_matvec_update(ddh_handle pack, int mat_id, const double *x, double *y, void *stream) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    PostSolve ps;
+    memset(&ps, 0, sizeof(ps));
+    return launch_matvec(pp, mat_id, x, y, ps, stream, 1);
 }
 
 int ddh_pencil_add_upper_bands(ddh_handle pack, int nz, int nbands, const int *offsets_h, const double *bands_h,

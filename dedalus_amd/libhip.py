@@ -95,6 +95,7 @@ SIGNATURES = {
     "ddh_pencil_create": [_hp, C.POINTER(PencilGeom)],
     "ddh_pencil_add_matrix": [_h, C.POINTER(PolyMat), _i, _ip],
     "ddh_pencil_matvec": [_h, _i, _vp, _vp, _vp],
+    "ddh_pencil_matvec_update": [_h, _i, _vp, _vp, _vp],
     "ddh_pencil_add_upper_bands": [_h, _i, _i, _ip, _dp, _ip],
     "ddh_pencil_matvec_solve": [_h, _i, _i, _vp, _vp, _vp],
     "ddh_pencil_factor": [_h, _i, _i, _d, _d, _ip, _ip, _i, _i, _i,

@@ -96,14 +96,17 @@ class PencilPack:
     def _timer(self):
         return getattr(self.executor, "timer", None) if self.executor is not None else None
 
-    def matvec(self, mat_id, x, y):
+    def matvec(self, mat_id, x, y, owned=False):
+        """y = A x.  owned: y is a zero-initialised buffer that only this product writes (a timestepper's M.X vector): rows
+        without terms may then stay untouched (ddh_pencil_matvec_update)."""
         t = self._timer()
         if t is not None:
-            return t.run("pencil_matvec", (x.numel() + y.numel()) * 8, self._matvec, mat_id, x, y)
-        return self._matvec(mat_id, x, y)
+            return t.run("pencil_matvec", (x.numel() + y.numel()) * 8, self._matvec, mat_id, x, y, owned)
+        return self._matvec(mat_id, x, y, owned)
 
-    def _matvec(self, mat_id, x, y):
-        libhip.call("ddh_pencil_matvec", self.handle, mat_id, ptr(x), ptr(y), self.dev.stream)
+    def _matvec(self, mat_id, x, y, owned=False):
+        libhip.call("ddh_pencil_matvec_update" if owned else "ddh_pencil_matvec", self.handle, mat_id, ptr(x), ptr(y),
+                    self.dev.stream)
 
     def add_upper_bands(self, nz, offsets, bands):
         offs = np.ascontiguousarray(offsets, dtype=np.int32)
