@@ -3079,6 +3079,7 @@ int ddh_pencil_solve_recombined_sparse(ddh_handle pack, int lu_id, int nterms, c
             return fail("pencil_solve_recombined: internal error (fused variant not taken)");
         }
     }
+    r.skip = nullptr;       // (the unfused path recombines from `work` with a mat-vec: every row of it must be written)
     if (pp->dev.nf == 2) st = launch_solve<2>(pp, lu, r, work, s);
     else if (pp->dev.nf == 1) st = launch_solve<1>(pp, lu, r, work, s);
     else st = launch_solve<0>(pp, lu, r, work, s);
