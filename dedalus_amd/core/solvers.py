@@ -630,18 +630,12 @@ class SolverBase:
                                          rhs=[self.gather_pencil(rhs, "equations", gx, gy) for gx, gy in probe["groups"]],
                                          x=[self.gather_pencil(out, "variables", gx, gy) for gx, gy in probe["groups"]]))
 
-    def mx_f_zero_rows(self):
-        """Device byte mask over the rows of a system vector: 1 where BOTH M.X and the F vector of `evaluate_F` are
-        structurally zero -- equations without a time derivative and without right-hand side (the continuity equation) --
-        or None when that is not known (F through the general gather path).  A Runge-Kutta right-hand side built from
-        M.X and F vectors only (timesteppers.RungeKuttaIMEX) passes it to the solve, whose forward sweep then does not
-        read those rows (ddh_pencil_solve_recombined_sparse)."""
-        if getattr(self, "_zrows", "unset") != "unset":
-            return self._zrows
-        self._zrows = None
-        if self.F_direct is None or not getattr(self.pack, "supports_zero_rows", False) or self.P_id is None:
-            return None
-        if os.environ.get("DDH_NO_ZERO_ROWS") is not None:
+    def zero_rows_host(self):
+        """uint8 [R]: 1 where BOTH M.X and the F vector of `evaluate_F` are structurally zero -- rows of equations without a
+        time derivative whose right-hand side is neither written by the direct-F transforms nor a constant (the continuity
+        equation, homogeneous boundary rows); None when F goes through the general gather path (its rows are not known
+        here)."""
+        if self.F_direct is None:
             return None
         mask = np.ones(self.R, dtype=np.uint8)
         mask[np.unique(np.asarray(self.M_tl.row))] = 0
@@ -649,22 +643,11 @@ class SolverBase:
             mask[einfo["row0"]:einfo["row0"] + einfo["rows"]] = 0
         if self.F_const is not None:
             mask[self._F_const_rows] = 0
-        if mask.any():
-            t = self.ex.torch
-            self._zrows = (t.as_tensor(mask, device=self.ex.dev.tdev), float(mask.mean()))
-        return self._zrows
+        return mask
 
-    def intermediate_skip_rows(self):
-        """Device byte mask over the rows of the state vector: 1 for the unknowns that nothing reads between the stages of a
-        Runge-Kutta step -- variables without a column in the mass matrix M that are not operands of any F expression
-        (pressure, tau variables) -- or None.  The solve of an INTERMEDIATE stage then does not store them."""
-        if getattr(self, "_skiprows", "unset") != "unset":
-            return self._skiprows
-        self._skiprows = None
-        if not getattr(self.pack, "supports_zero_rows", False) or self.P_id is None or self.F_direct is None:
-            return None
-        if os.environ.get("DDH_NO_SKIP_ROWS") is not None:
-            return None
+    def skip_rows_host(self):
+        """uint8 [R]: 1 for the unknowns that nothing reads between the stages of a Runge-Kutta step -- variables without a
+        column in the mass matrix M that are not operands of any F expression (pressure, tau variables)."""
         used = set()
         for einfo in self.eq_info:
             F = einfo["eq"]["F"]
@@ -677,9 +660,41 @@ class SolverBase:
             r0, r1 = info["row0"], info["row0"] + info["rows"]
             if id(info["field"]) not in used and not mcols[r0:r1].any():
                 mask[r0:r1] = 1
+        return mask
+
+    def _device_mask(self, mask):
+        t = self.ex.torch
+        return (t.as_tensor(mask, device=self.ex.dev.tdev), float(mask.mean()))
+
+    def mx_f_zero_rows(self):
+        """Device form (byte mask, fraction set) of `zero_rows_host`, or None.  A Runge-Kutta right-hand side built from M.X
+        and F vectors only (timesteppers.RungeKuttaIMEX) passes it to the solve, whose forward sweep then does not read
+        those rows (ddh_pencil_solve_recombined_sparse)."""
+        if getattr(self, "_zrows", "unset") != "unset":
+            return self._zrows
+        self._zrows = None
+        if not getattr(self.pack, "supports_zero_rows", False) or self.P_id is None:
+            return None
+        if os.environ.get("DDH_NO_ZERO_ROWS") is not None:
+            return None
+        mask = self.zero_rows_host()
+        if mask is not None and mask.any():
+            self._zrows = self._device_mask(mask)
+        return self._zrows
+
+    def intermediate_skip_rows(self):
+        """Device form of `skip_rows_host`, or None: the solve of an INTERMEDIATE Runge-Kutta stage does not store these
+        unknowns (they are final only after the last stage)."""
+        if getattr(self, "_skiprows", "unset") != "unset":
+            return self._skiprows
+        self._skiprows = None
+        if not getattr(self.pack, "supports_zero_rows", False) or self.P_id is None or self.F_direct is None:
+            return None
+        if os.environ.get("DDH_NO_SKIP_ROWS") is not None:
+            return None
+        mask = self.skip_rows_host()
         if mask.any():
-            t = self.ex.torch
-            self._skiprows = (t.as_tensor(mask, device=self.ex.dev.tdev), float(mask.mean()))
+            self._skiprows = self._device_mask(mask)
         return self._skiprows
 
     def solve_lincomb(self, lu, xs, alphas, out, zero_rows=None, skip_rows=None):
