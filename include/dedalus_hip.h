@@ -275,7 +275,8 @@ int ddh_pencil_add_matrix(ddh_handle pack, const ddh_polymat *mat, int nrows_out
 /* y[nrows_out][cells] = A x  (apply_sparse tools/array.py:171-203 over all pencils at once;
  * gather/scatter subsystems.py:340-380 are the identity in this layout)                           */
 int ddh_pencil_matvec(ddh_handle pack, int mat_id, const double *x, double *y, void *stream);
-/* The same for a buffer the caller keeps for this product alone (the M.X vectors of a timestepper, zero-initialised): rows of
+/* The same for a buffer the caller keeps for this product alone (the M.X vectors of a timestepper, core/timesteppers.py:588-591
+ * with its CoeffSystem buffers core/system.py:39-60, zero-initialised): rows of
  * y whose matrix row has no terms MAY be left untouched instead of being overwritten with zeros (the window-form kernel
  * skips those stores; a fifth of M.X for an incompressible flow).  Every other row is written as by ddh_pencil_matvec.  */
 int ddh_pencil_matvec_update(ddh_handle pack, int mat_id, const double *x, double *y, void *stream);
