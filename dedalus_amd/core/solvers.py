@@ -85,6 +85,7 @@ class SolverBase:
         # ---- matrices as term lists (physical row / column numbering)
         self.M_tl = self._assemble("M")
         self.L_tl = self._assemble("L")
+        self._decouple_boundary_rows()
         self.pack = self.ex.make_pack(nf, self.R, nx, ny, kx, ky, dist._mx_offset)
         self.M_id = self.pack.add_matrix(self.M_tl)
         self.L_id = self.pack.add_matrix(self.L_tl)
@@ -120,8 +121,24 @@ class SolverBase:
             return inter, edge, special
         return split(self.eq_info), split(self.var_info)
 
-    def _build_recombination(self):
-        """Column recombination X = P Y that makes the boundary-condition rows sparse.
+    def _boundary_rows(self):
+        """Rows of the boundary-condition equations (equations without a coupled basis that exist for every pencil)."""
+        (eq_int, eq_bc, eq_sp), _ = self._classify()
+        return [r for i in eq_bc for r in range(i["row0"], i["row0"] + i["rows"])]
+
+    def _boundary_matrix(self, M_tl, L_tl, bc_rows):
+        """Dense [len(bc_rows)][R] coefficients of the boundary rows (they must not depend on the wavenumber)."""
+        R = np.zeros((len(bc_rows), self.R))
+        rowpos = {r: k for k, r in enumerate(bc_rows)}
+        for tl in (M_tl, L_tl):
+            for t in np.flatnonzero(np.isin(tl.row, bc_rows)):
+                if tl.ex[t] or tl.ey[t] or tl.dx[t] or tl.dy[t] or abs(tl.coef[t].imag) > 0:
+                    raise NotImplementedError("boundary conditions that depend on the wavenumber")
+                R[rowpos[int(tl.row[t])], tl.col[t]] += tl.coef[t].real
+        return R
+
+    def _recombination_matrix(self, M_tl, L_tl):
+        """Column recombination X = P Y that makes the boundary-condition rows sparse (None: nothing to recombine).
 
         The tau-bordered pencil matrices are only well conditioned as a whole: their banded interior
         block alone is exponentially ill conditioned (it is a spectral-space shooting problem), so the
@@ -137,22 +154,10 @@ class SolverBase:
         alternative that this replaces."""
         from scipy import sparse
         (eq_int, eq_bc, eq_sp), (var_int, var_tau, var_sp) = self._classify()
-        self.P_tl = None
-        self.P_id = None
-        self.MP_id, self.LP_id = self.M_id, self.L_id
-        self.MP_tl, self.LP_tl = self.M_tl, self.L_tl
-        bc_rows = [r for i in eq_bc for r in range(i["row0"], i["row0"] + i["rows"])]
+        bc_rows = self._boundary_rows()
         if not bc_rows or not var_int:
-            return
-        R = np.zeros((len(bc_rows), self.R))
-        rowpos = {r: k for k, r in enumerate(bc_rows)}
-        for tl in (self.M_tl, self.L_tl):
-            for t in range(tl.nterms):
-                r = int(tl.row[t])
-                if r in rowpos:
-                    if tl.ex[t] or tl.ey[t] or tl.dx[t] or tl.dy[t] or abs(tl.coef[t].imag) > 0:
-                        raise NotImplementedError("boundary conditions that depend on the wavenumber")
-                    R[rowpos[r], tl.col[t]] += tl.coef[t].real
+            return None
+        R = self._boundary_matrix(M_tl, L_tl, bc_rows)
         P = sparse.identity(self.R, format="lil")
         used = np.zeros(len(bc_rows), dtype=bool)
         for vi in var_int:
@@ -176,7 +181,17 @@ class SolverBase:
                             P[cols[n - s1], cols[n]] = cvec[s1 - 1]
         if not used.all():
             raise NotImplementedError("boundary condition row without interior variable")
-        P = sparse.csr_matrix(P)
+        return sparse.csr_matrix(P)
+
+    def _build_recombination(self):
+        """X = P Y (`_recombination_matrix`) and the recombined term lists (a M + b L) P registered with the pack."""
+        self.P_tl = None
+        self.P_id = None
+        self.MP_id, self.LP_id = self.M_id, self.L_id
+        self.MP_tl, self.LP_tl = self.M_tl, self.L_tl
+        P = self._recombination_matrix(self.M_tl, self.L_tl)
+        if P is None:
+            return
         coo = P.tocoo()
         from ..pencilpack import TermList
         self.P_tl = TermList(self.R, self.R, coo.row, coo.col, coo.data.astype(complex))
@@ -185,6 +200,117 @@ class SolverBase:
         self.P_id = self.pack.add_matrix(self.P_tl)
         self.MP_id = self.pack.add_matrix(self.MP_tl)
         self.LP_id = self.pack.add_matrix(self.LP_tl)
+
+    # ---- independent blocks of the pencil matrix -----------------------------------------------------------------
+    def _band_components(self, MP_tl, LP_tl):
+        """Connected components of the bipartite row / column graph of the band block of (a M + b L) P (every term counts,
+        whatever its wavenumber factor).  Returns (number of components, label per physical row, label per physical
+        column); rows / columns of the small border (gauge conditions) get the label -1."""
+        from scipy import sparse
+        from scipy.sparse.csgraph import connected_components
+        (eq_int, eq_bc, eq_sp), (var_int, var_tau, var_sp) = self._classify()
+        in_rows = np.zeros(self.R, dtype=bool)
+        in_cols = np.zeros(self.R, dtype=bool)
+        for i in eq_int + eq_bc:
+            in_rows[i["row0"]:i["row0"] + i["rows"]] = True
+        for i in var_int + var_tau:
+            in_cols[i["row0"]:i["row0"] + i["rows"]] = True
+        row = np.concatenate([MP_tl.row, LP_tl.row]).astype(np.int64)
+        col = np.concatenate([MP_tl.col, LP_tl.col]).astype(np.int64)
+        keep = in_rows[row] & in_cols[col]
+        row, col = row[keep], col[keep]
+        A = sparse.coo_matrix((np.ones(row.size), (row, col + self.R)), shape=(2 * self.R, 2 * self.R))
+        nc, lab = connected_components(A + A.T, directed=False)
+        lr = np.where(in_rows, lab[:self.R], -1)
+        lc = np.where(in_cols, lab[self.R:], -1)
+        used = np.unique(np.concatenate([lr[lr >= 0], lc[lc >= 0]]))
+        remap = -np.ones(nc + 1, dtype=np.int64)
+        remap[used] = np.arange(used.size)
+        return used.size, remap[lr], remap[lc]
+
+    def _decouple_boundary_rows(self):
+        """Equivalent boundary equations that let the pencil matrix fall apart into independent blocks.
+
+        For problems that are symmetric under a reflection of the coupled axis (constant-coefficient equations between
+        two plates: Rayleigh-Benard, channel flows, ...) even and odd polynomial modes only meet in the boundary
+        conditions: "f(z=0) = a, f(z=Lz) = b" touch both parities.  The m boundary rows of a variable are replaced by the
+        equivalent combinations T (rows) with T = G^-1, G the m x m block of their coefficients on the variable's first m
+        modes: after the column recombination X = P Y each new row touches ONE mode.  If the band block of
+        (a M + b L) P then has several connected components (two for the parity split), `_build_ordering` orders it
+        block by block: a block-diagonal band matrix with half the bandwidth -- half the factor bytes and multiply-adds of
+        every solve, and rows of different blocks are independent.  The equations solved are T (M dt X + L X) = T F:
+        `self.eq_T` multiplies the boundary rows of M, L and of every right-hand-side source (`_eq_transform`,
+        `F_const`); vectors in equation space are handed out un-transformed (`gather_pencil`, `equation_space_to_user`).
+        Nothing changes (eq_T = None) when the split does not happen or DDH_NO_SPLIT is set.
+        The reference solves the coupled matrix per pencil (core/subsystems.py:497-596, libraries/matsolvers.py:126-149)."""
+        from scipy import sparse
+        self.eq_T = self.eq_Tinv = None
+        if os.environ.get("DDH_NO_SPLIT") is not None:
+            return
+        try:
+            bc_rows = self._boundary_rows()
+            (eq_int, eq_bc, eq_sp), (var_int, var_tau, var_sp) = self._classify()
+            if not bc_rows or not var_int:
+                return
+            Rm = self._boundary_matrix(self.M_tl, self.L_tl, bc_rows)
+        except NotImplementedError:
+            return                                      # (reported by _build_recombination)
+        T = np.eye(len(bc_rows))
+        changed = False
+        for vi in var_int:
+            for c in range(vi["ncomp"]):
+                cols = vi["row0"] + c * vi["nz"] + np.arange(vi["nz"])
+                touching = [k for k in range(len(bc_rows)) if np.any(Rm[k, cols] != 0)]
+                m = len(touching)
+                if m < 2 or m > vi["nz"]:
+                    continue
+                G = Rm[np.ix_(touching, cols[:m])]
+                if np.linalg.cond(G) > 1e6:             # (e.g. two Neumann conditions: the constant mode drops out)
+                    continue
+                T[np.ix_(touching, touching)] = np.linalg.inv(G)
+                changed = True
+        if not changed:
+            return
+        Tfull = sparse.identity(self.R, format="lil")
+        for i, ri in enumerate(bc_rows):
+            for j, rj in enumerate(bc_rows):
+                if T[i, j] != 0.0 or i == j:
+                    Tfull[ri, rj] = T[i, j]
+        Tfull = sparse.csr_matrix(Tfull)
+        M2, L2 = _matrix_times_termlist(Tfull, self.M_tl), _matrix_times_termlist(Tfull, self.L_tl)
+        try:
+            P = self._recombination_matrix(M2, L2)
+        except NotImplementedError:
+            return
+        if P is None:
+            return
+        n_old = self._band_components(_termlist_times_matrix(self.M_tl, P), _termlist_times_matrix(self.L_tl, P))[0]
+        n_new, lr, lc = self._band_components(_termlist_times_matrix(M2, P), _termlist_times_matrix(L2, P))
+        if n_new <= n_old or any(np.sum(lr == k) != np.sum(lc == k) for k in range(n_new)):
+            return
+        self.eq_T = Tfull
+        Tinv = sparse.identity(self.R, format="lil")
+        Ti = np.linalg.inv(T)
+        for i, ri in enumerate(bc_rows):
+            for j, rj in enumerate(bc_rows):
+                if abs(Ti[i, j]) > 1e-15 or i == j:
+                    Tinv[ri, rj] = Ti[i, j]
+        self.eq_Tinv = sparse.csr_matrix(Tinv)
+        self._eq_T_rows = np.asarray(bc_rows)
+        self.M_tl, self.L_tl = M2, L2
+
+    def _eq_transform(self, tl):
+        """T applied to the rows of a term list that maps into equation space (right-hand-side sources)."""
+        return tl if self.eq_T is None else _matrix_times_termlist(self.eq_T, tl)
+
+    def equation_space_to_user(self, vec):
+        """Host copy [R][nx][ny] of a vector in equation space (F, M.X, right-hand sides) in the USER's equations: the
+        boundary rows are stored as the equivalent combinations T (rows) of `_decouple_boundary_rows`."""
+        v = np.array(self.ex.download(vec), dtype=float).reshape(self.R, -1)
+        if self.eq_Tinv is not None:
+            rows = self._eq_T_rows
+            v[rows] = self.eq_Tinv[rows][:, rows] @ v[rows]
+        return v.reshape(self.R, self.nx, self.ny)
 
     def _build_ordering(self):
         """Logical ordering for the band LU: boundary-condition rows first, then the interior equations
@@ -209,6 +335,18 @@ class SolverBase:
         if len(rows) != len(cols):
             raise ValueError("band block is not square: %d equation rows vs %d variable columns "
                              "(boundary conditions and tau variables must balance)" % (len(rows), len(cols)))
+        # independent blocks (connected components of the band block, `_decouple_boundary_rows`): block after block, the
+        # order inside a block unchanged -- a block-diagonal band matrix whose bandwidth is that of its widest block
+        self.n_blocks = 1
+        if rows and os.environ.get("DDH_NO_SPLIT") is None:
+            nc, lr, lc = self._band_components(self.MP_tl, self.LP_tl)
+            if nc > 1 and all(np.sum(lr == k) == np.sum(lc == k) for k in range(nc)):
+                rows = [r for k in range(nc) for r in rows if lr[r] == k]
+                cols = [c for k in range(nc) for c in cols if lc[c] == k]
+                self.n_blocks = nc
+                self.block_sizes = [int(np.sum(lr == k)) for k in range(nc)]
+                if len(set(self.block_sizes)) == 1 and hasattr(self.pack, "set_row_blocks"):
+                    self.pack.set_row_blocks(nc)      # (sweeps with one thread per (system, block))
         self.n_interior = len(rows)
         rows += flat(eq_sp)
         cols += flat(var_sp)
@@ -423,15 +561,15 @@ class SolverBase:
         if nl_rows:
             self.NLbuf = None if self.F_direct is not None else self.ex.zeros((nl_rows, nx, ny))
             self.nl_pack = self.ex.make_pack(nf, nl_rows, nx, ny, kx, ky, self.dist._mx_offset)
-            self.F_nl = self.nl_pack.add_matrix(flatten(groups["nl"], self.R, nl_rows))
+            self.F_nl = self.nl_pack.add_matrix(self._eq_transform(flatten(groups["nl"], self.R, nl_rows)))
         self.F_x = None
         if groups["x"]:
-            self.F_x = self.pack.add_matrix(flatten(groups["x"], self.R, self.R))
+            self.F_x = self.pack.add_matrix(self._eq_transform(flatten(groups["x"], self.R, self.R)))
         self.F_params = []
         for key, (leaf, blks) in groups["param"].items():
             rows = leaf.ncomp * self.dist.coupled_size(leaf.domain)
             pk = self.ex.make_pack(nf, rows, nx, ny, kx, ky, self.dist._mx_offset)
-            mid = pk.add_matrix(flatten([tuple(b[:2] + [0] + b[3:]) for b in blks], self.R, rows))
+            mid = pk.add_matrix(self._eq_transform(flatten([tuple(b[:2] + [0] + b[3:]) for b in blks], self.R, rows)))
             self.F_params.append((leaf, pk, mid))
         # constants (e.g. "b(z=0) = Lz"): evaluated once
         self.F_const = None
@@ -444,6 +582,8 @@ class SolverBase:
                     # constants only reach the k=0 pencil, cos-cos part
                     if tl.ex[t] == 0 and tl.ey[t] == 0 and self.dist._mx_offset == 0:
                         total[tl.row[t], 0, 0] += (tl.coef[t] * val).real
+            if self.eq_T is not None:                    # (boundary rows: the equivalent combinations, eq_T)
+                total = (self.eq_T @ total.reshape(self.R, -1)).reshape(total.shape)
             nz = np.flatnonzero(total)
             self.F_const = self.ex.make_scatter(nz, total.reshape(-1)[nz]) if nz.size else None
             self._F_const_rows = np.unique(nz // (nx * ny))
@@ -725,20 +865,29 @@ class SolverBase:
         operands without a Fourier basis belong to group 0 only.  Diagnostics / parity checks: a few KB per call."""
         infos = self.var_info if which == "variables" else self.eq_info
         lx = gx - (self.dist._mx_offset if self.nf >= 1 else 0)
+        # the cell's slab [R][<= 2][<= 2] of the vector comes to the host in one copy
+        cx = slice(2 * lx, 2 * lx + 2) if self.nf >= 1 else slice(0, 1)
+        cy = slice(2 * gy, 2 * gy + 2) if self.nf >= 2 else slice(0, 1)
+        slab = vec.reshape(self.R, self.nx, self.ny)[:, cx, cy]
+        cell = np.array(self.ex.download(slab.contiguous() if hasattr(slab, "contiguous") else slab), dtype=float)
+        cell = cell.reshape(self.R, cell.shape[-2], cell.shape[-1])
+        if which != "variables" and self.eq_Tinv is not None:
+            # boundary rows are stored as the combinations eq_T of the user's equations: hand out the user's
+            rows = self._eq_T_rows
+            cell[rows] = (self.eq_Tinv[rows][:, rows] @ cell[rows].reshape(len(rows), -1)).reshape(cell[rows].shape)
         parts = []
         for info in infos:
             bits = info["bits"]
             if self.nf >= 1:
-                sx = slice(2 * lx, 2 * lx + 2) if (bits & 1) else (slice(0, 1) if gx == 0 else slice(0, 0))
+                sx = slice(0, 2) if (bits & 1) else (slice(0, 1) if gx == 0 else slice(0, 0))
             else:
                 sx = slice(0, 1)
             if self.nf >= 2:
-                sy = slice(2 * gy, 2 * gy + 2) if (bits & 2) else (slice(0, 1) if gy == 0 else slice(0, 0))
+                sy = slice(0, 2) if (bits & 2) else (slice(0, 1) if gy == 0 else slice(0, 0))
             else:
                 sy = slice(0, 1)
-            blk = vec[info["row0"]:info["row0"] + info["rows"]].reshape(info["ncomp"], info["nz"], self.nx, self.ny)
-            blk = self.ex.download(blk[:, :, sx, sy].contiguous() if hasattr(blk, "contiguous") else blk[:, :, sx, sy])
-            blk = np.asarray(blk).transpose(0, 2, 3, 1)
+            blk = cell[info["row0"]:info["row0"] + info["rows"]].reshape(info["ncomp"], info["nz"], cell.shape[1], cell.shape[2])
+            blk = blk[:, :, sx, sy].transpose(0, 2, 3, 1)
             if self.nf < 2:
                 blk = blk[:, :, 0, :] if self.nf == 1 else blk[:, 0, 0, :]
             parts.append(np.ascontiguousarray(blk).ravel())
@@ -797,6 +946,35 @@ def _two_colour(n, row, col, label):
     xr[xr == -1] = 0
     xc[xc == -1] = 0
     return xr, xc
+
+
+def _matrix_times_termlist(T, tl):
+    """(constant sparse matrix) @ (term list): rows mixed by T, monomials unchanged; rows T leaves alone keep their terms
+    bit for bit."""
+    from ..pencilpack import TermList
+    if tl.nterms == 0:
+        return tl
+    T = T.tocsc()
+    ident = np.ones(T.shape[0], dtype=bool)
+    coo = T.tocoo()
+    off = (coo.row != coo.col) | (coo.data != 1.0)
+    ident[coo.row[off]] = False
+    ident[coo.col[off]] = False
+    plain = ident[tl.row]
+    parts = [[tl.row[plain]], [tl.col[plain]], [tl.coef[plain]], [tl.ex[plain]], [tl.ey[plain]], [tl.dx[plain]], [tl.dy[plain]]]
+    for t in np.flatnonzero(~plain):
+        c = T.getcol(int(tl.row[t])).tocoo()
+        n = c.nnz
+        parts[0].append(c.row); parts[1].append(np.full(n, tl.col[t])); parts[2].append(c.data * tl.coef[t])
+        for k, name in enumerate(("ex", "ey", "dx", "dy")):
+            parts[3 + k].append(np.full(n, getattr(tl, name)[t]))
+    out = TermList(tl.nrows, tl.ncols, *[np.concatenate(x) for x in parts])
+    if (~plain).any():
+        out = out.consolidated(0.0)
+        keep = np.abs(out.coef) > 1e-14 * np.abs(out.coef).max()
+        out = TermList(out.nrows, out.ncols, out.row[keep], out.col[keep], out.coef[keep], out.ex[keep], out.ey[keep],
+                       out.dx[keep], out.dy[keep])
+    return out
 
 
 def _termlist_times_matrix(tl, P, cutoff=1e-12):

@@ -114,6 +114,13 @@ struct LuDev {
     //   partner rows / columns are read and written through rowperm2 / colperm2 (= swap o perm); its Q system is the
     //   conjugate problem: lambda(kx, -ky) = conj lambda(-kx, ky)  (real operators), so the data are conjugated on the way
     //   in and out.
+    // Independent diagonal blocks (ddh_pencil_set_row_blocks): the band block is block diagonal with nsplit blocks of nh
+    // rows each (connected components of the pencil matrix, e.g. the two reflection parities of a problem between two
+    // plates).  The one-thread-per-system sweeps of the real-graded path then run one thread per (system, block):
+    // thread t -> block t / Gp, system t % Gp (Gp = G rounded up to the workgroup size); the dependent chain of a sweep is
+    // nh rows instead of n.  nsplit = 1, nh = n otherwise.
+    int nsplit, nh;
+    long Gp;
     int pair;
     const long *vcell;             // [ncells]
     const int *vslot;              // [ncells]
@@ -160,6 +167,7 @@ struct PencilPack : HandleBase {
     // of at least pair_min systems
     std::vector<int> pair_rows, pair_cols;
     long pair_min = 0;
+    int row_blocks = 1;             // ddh_pencil_set_row_blocks: independent diagonal blocks of later factorizations
     std::vector<double> kx_h, ky_h;
     ~PencilPack() override;
 };
@@ -1550,7 +1558,11 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
         s_code[N + i] = L.col_code[n + i];
     }
     __syncthreads();
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // independent diagonal blocks (LuDev::nsplit): this thread sweeps rows row0 .. row1 - 1 of system g
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int blk = L.nsplit > 1 ? (int)(tid / L.Gp) : 0;
+    const long g = tid - (long)blk * L.Gp;
+    const int row0 = blk * L.nh, row1 = row0 + L.nh;
     const SysId id = sys_id<true>(P, L, g);
     if (!id.ok) return;
     const int s = id.s;
@@ -1564,14 +1576,14 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     //   512 B apart: immediate offsets);  pvp: the interchange of step j;  scr: y_j of this system
     const double *mp[KLT];
     {
-        const double *const awl = (const double *)L.Aw + lu_aw(L, id.gl, 0, -L.kpad);   // this lane's block, row 0, entry 0
+        const double *const awl = (const double *)L.Aw + lu_aw(L, id.gl, row0, -L.kpad);   // this lane's block, first row, entry 0
         const long BW64 = (long)L.BW << 6;
 #pragma unroll
         for (int i = 0; i < KLT; ++i) mp[i] = awl + (long)(i + 1) * BW64 + lu_eoff(L, KLT - i - 1);
     }
-    const double *abp = (const double *)L.Ab + lu_ab(L, id.gl, 0, 0);
-    const unsigned char *pvp = L.piv + lu_pv(L, id.gl, 0);
-    double2 *scr = L.scratch + g;
+    const double *abp = (const double *)L.Ab + lu_ab(L, id.gl, row0, 0);
+    const unsigned char *pvp = L.piv + lu_pv(L, id.gl, row0);
+    double2 *scr = L.scratch + (long)row0 * G + g;
     const long row_step = (long)L.BW << 6, ab_step = (long)nb << 6;
 
     auto load_row = [&](int i) -> double2 {
@@ -1590,7 +1602,7 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     for (int d = 0; d <= KLT; ++d) w[d] = make_double2(0.0, 0.0);
 #pragma unroll 1
     for (int t = 0; t <= KLT; ++t) {
-        const double2 v = (t < n) ? load_row(t) : make_double2(0.0, 0.0);
+        const double2 v = (row0 + t < row1) ? load_row(row0 + t) : make_double2(0.0, 0.0);
 #pragma unroll
         for (int d = 0; d < KLT; ++d) w[d] = w[d + 1];
         w[KLT] = v;
@@ -1600,7 +1612,7 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     for (int rb = 0; rb < NBT; ++rb) gb[rb] = make_double2(0.0, 0.0);
 #pragma unroll 1
     for (int t = 0; t < NBT; ++t) {
-        const double2 v = (t < nb) ? load_row(n + t) : make_double2(0.0, 0.0);
+        const double2 v = (t < nb && blk == 0) ? load_row(n + t) : make_double2(0.0, 0.0);   // (block 0 carries the border's right-hand side)
 #pragma unroll
         for (int rb = 0; rb + 1 < NBT; ++rb) gb[rb] = gb[rb + 1];
         gb[NBT - 1] = v;
@@ -1614,7 +1626,7 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     for (int rb = 0; rb < NBT; ++rb) abA[rb] = abB[rb] = 0.0;
     const bool full_border = (nb == NBT);
     // loads of the NEXT row (the pointers stand at it); called for rows 0, 1, 2, ... in order
-    int jn = 0;
+    int jn = row0;
     auto prefetch = [&](double *m, double *ab, int &p, double2 &r) {
         p = *pvp;
 #pragma unroll
@@ -1631,7 +1643,7 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
         // (the right-hand-side row follows: its value is not needed before the end of the next step)
         const int nxt = jn + KLT + 1;
         r = make_double2(0.0, 0.0);
-        if (nxt < n) r = load_row(nxt);
+        if (nxt < row1) r = load_row(nxt);
 #pragma unroll
         for (int i = 0; i < KLT; ++i) mp[i] += row_step;
         abp += ab_step;
@@ -1664,17 +1676,24 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
         w[KLT] = rnew;
     };
     // (a second row of loads in flight per system was measured: 4.8 ms instead of 4.4 ms at 512^2 pencils)
-    if (n > 0) prefetch(mB, abB, pB, rB);
+    if (row1 > row0) prefetch(mB, abB, pB, rB);
 #pragma unroll 1
-    for (int j = 0; j < n; ++j) {
+    for (int j = row0; j < row1; ++j) {
 #pragma unroll
         for (int i = 0; i < KLT; ++i) mA[i] = mB[i];
 #pragma unroll
         for (int rb = 0; rb < NBT; ++rb) abA[rb] = abB[rb];
         pA = pB;
         rA = rB;
-        if (j + 1 < n) prefetch(mB, abB, pB, rB);
+        if (j + 1 < row1) prefetch(mB, abB, pB, rB);
         step(mA, abA, pA, rA);
+    }
+    if (L.nsplit > 1) {
+        // the border rows collect contributions of every block: partial sums, finished by border_finish_kernel
+#pragma unroll
+        for (int r = 0; r < NBT; ++r)
+            if (r < nb) L.scratch[(long)(n + nb + blk * nb + r) * G + g] = gb[r];
+        return;
     }
     // ---- Schur block: z = Sinv * gb ; border unknown r is logical column n + r
     const double *Ab = (const double *)L.Ab;
@@ -1714,7 +1733,11 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
         s_skip[i] = skip ? (skip[L.colperm[i]] && (!L.pair || skip[L.colperm2[i]])) : 0;
     }
     __syncthreads();
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // independent diagonal blocks (LuDev::nsplit; only launched that way for REAL): rows row1 - 1 .. row0 of system g
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int blk = (REAL && L.nsplit > 1) ? (int)(tid / L.Gp) : 0;
+    const long g = tid - (long)blk * L.Gp;
+    const int row0 = (REAL && L.nsplit > 1) ? blk * L.nh : 0, row1 = (REAL && L.nsplit > 1) ? row0 + L.nh : n;
     const SysId id = sys_id<REAL>(P, L, g);
     if (!id.ok) return;
     const int s = id.s;
@@ -1730,7 +1753,7 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
 #pragma unroll
     for (int d = 0; d < WT; ++d) {
         win[d] = make_double2(0.0, 0.0);
-        if (d < nb) win[d] = L.scratch[(long)(n + d) * G + g];
+        if (d < nb && row1 == n) win[d] = L.scratch[(long)(n + d) * G + g];   // border columns follow the LAST band rows
     }
     E ua[WT + 1], ub[WT + 1];
     double pa[PBW], pb[PBW];        // the row of the recombination band (PFUSE): uniform, loaded with the factor row
@@ -1839,31 +1862,70 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
         }
         win[0] = xj;
     };
-    int j = n - 1;
+    int j = row1 - 1;
     if (PREF) {
-        if (j >= 0) fetch(j, ua, ya, pa);
-        while (j >= 1) {
+        if (j >= row0) fetch(j, ua, ya, pa);
+        while (j >= row0 + 1) {
             fetch(j - 1, ub, yb, pb);
             const double2 xe = row_even(j, ua, ya, pa);
-            if (j - 2 >= 0) fetch(j - 2, ua, ya, pa);
+            if (j - 2 >= row0) fetch(j - 2, ua, ya, pa);
             row_odd(j - 1, ub, yb, xe, pb);
             j -= 2;
         }
-        if (j == 0) row_even(0, ua, ya, pa);
+        if (j == row0) row_even(row0, ua, ya, pa);
     } else {
         // no register double-buffering: fewer VGPRs -> two waves per SIMD hide each other's latency
-        while (j >= 1) {
+        while (j >= row0 + 1) {
             fetch(j, ua, ya, pa);
             const double2 xe = row_even(j, ua, ya, pa);
             fetch(j - 1, ua, ya, pa);
             row_odd(j - 1, ua, ya, xe, pa);
             j -= 2;
         }
-        if (j == 0) {
-            fetch(0, ua, ya, pa);
-            row_even(0, ua, ya, pa);
+        if (j == row0) {
+            fetch(row0, ua, ya, pa);
+            row_even(row0, ua, ya, pa);
         }
     }
+}
+
+// Border unknowns of a forward sweep that ran one thread per (system, block) (LuDev::nsplit > 1): the blocks' partial
+// border sums (scratch rows n + nb ...) are added, the Schur block applied, the border unknowns stored -- the tail of
+// solve_forward_lean_kernel, one thread per system.
+template <int NF>
+__global__ void __launch_bounds__(256)
+border_finish_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const SysId id = sys_id<true>(P, L, g);
+    if (!id.ok) return;
+    const int s = id.s, n = L.n, nb = L.nb, N = L.N;
+    const CellCtx c = cell_ctx(P, id.cell);
+    const long G = id.G, plane = P.nx * P.ny;
+    const bool conjq = id.partner && s == 1;
+    const double *Ab = (const double *)L.Ab;
+    double2 gb[NBMAX];
+    for (int r = 0; r < nb; ++r) {
+        double2 acc = make_double2(0.0, 0.0);
+        for (int b = 0; b < L.nsplit; ++b) {
+            const double2 v = L.scratch[(long)(n + nb + b * nb + r) * G + g];
+            acc.x += v.x;
+            acc.y += v.y;
+        }
+        gb[r] = acc;
+    }
+    for (int r = 0; r < nb; ++r) {
+        double2 acc = make_double2(0.0, 0.0);
+        for (int cidx = 0; cidx < nb; ++cidx) El<true>::fma2(acc, Ab[lu_ab(L, id.gl, n + cidx, r)], gb[cidx]);
+        L.scratch[(long)(n + r) * G + g] = acc;
+        double2 v = acc;
+        const unsigned char code = L.col_code[n + r];
+        if (code & 1) v = make_double2(-v.y, v.x);
+        if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+        if (conjq) v.y = -v.y;
+        const int prow = id.partner ? L.colperm2[n + r] : L.colperm[n + r];
+        store_sys<NF>(xout, plane, prow, P, c, s, v);
+    }
+    (void)N;
 }
 
 
@@ -2230,9 +2292,9 @@ static int finish_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
 // systems) were tuned with 16 lanes in both sweeps.  forward: 16 lanes per system (needs kl < 16); backward: 16 or 4
 // lanes per system (fewer lanes = less redundant work per system, more products per lane).
 // multipliers per column held by the one-thread-per-system forward kernel for a lower bandwidth kl
-static int forward_window(int kl) { return kl <= 12 ? 12 : 16; }
+static int forward_window(int kl) { return kl <= 6 ? 6 : (kl <= 12 ? 12 : 16); }
 // register window (entries above the diagonal) of the one-thread-per-system backward kernel for an upper bandwidth W
-static int backward_window(int W) { return W <= 32 ? 32 : (W <= 34 ? 34 : (W <= 48 ? 48 : 64)); }
+static int backward_window(int W) { return W <= 18 ? 18 : (W <= 32 ? 32 : (W <= 34 ? 34 : (W <= 48 ? 48 : 64))); }
 
 template <int NF>
 static void choose_variant(const PencilPack *pp, const LuDev &d, int &use_fwd, int &cb) {
@@ -2302,6 +2364,8 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     }
     // (few window sizes: every instantiation is a fully unrolled kernel and this file dominates the build time)
     bool lean_fwd = false;
+    // one thread per (system, block) where the sweep kernels support it (LuDev::nsplit)
+    const unsigned blocks_split = (unsigned)(((long)d.nsplit * d.Gp + 255) / 256);
     if constexpr (NF == 2) {
         static const int no_lean = getenv("DDH_FWD_LEAN") ? !atoi(getenv("DDH_FWD_LEAN")) : 0;
         // (instantiated and tested for the window of the Rayleigh-Benard pencils: kl <= 12, a border of <= 2; other shapes
@@ -2310,9 +2374,11 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
                    d.rows_aw >= d.n + forward_window(d.kl) && d.kl <= 12 && d.nb <= 2;
         if (lean_fwd) {
 #define DDH_LFWD(KLTV, NBTV) \
-    hipLaunchKernelGGL((solve_forward_lean_kernel<KLTV, NBTV>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x);
-            DDH_LFWD(12, 2)
+    { hipLaunchKernelGGL((solve_forward_lean_kernel<KLTV, NBTV>), dim3(blocks_split), dim3(256), lds_f, s, P, d, rhs, x); }
+            if (forward_window(d.kl) == 6) DDH_LFWD(6, 2) else DDH_LFWD(12, 2)
 #undef DDH_LFWD
+            if (d.nsplit > 1 && d.nb > 0)
+                hipLaunchKernelGGL(border_finish_kernel<NF>, dim3(blocks), dim3(256), 0, s, P, d, x);
         }
     }
     if (use_fwd || lean_fwd) {
@@ -2344,7 +2410,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
 #define DDH_SOLVE(WTV)                                                                                             \
     {                                                                                                              \
         if (d.real)                                                                                                \
-            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip); \
+            hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip); \
         else                                                                                                       \
             hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, false, false>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip); \
     }
@@ -2352,17 +2418,18 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     bool fuse_p = false;
     if constexpr (NF == 2) fuse_p = want_p && d.real && d.pband != nullptr && d.n > 0 && !cb && W <= 48;
 #define DDH_SOLVE_P(WTV)                                                                                           \
-    hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false, true>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
+    { hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false, true>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip); }
     if (fuse_p) {
         if constexpr (NF == 2) {
-            if (W <= 32) DDH_SOLVE_P(32)
+            if (W <= 18) DDH_SOLVE_P(18)
+            else if (W <= 32) DDH_SOLVE_P(32)
 #ifdef DDH_BWD_ABLATE
             // timing ablations of the backward sweep (build with -DDDH_BWD_ABLATE; DDH_BWD_DBG = mask: 1 one factor load
             // per row, 2 no FMAs, 4 no stores, 8 no scratch load, 16 no window shift, 32 stores to lane-contiguous
             // addresses).  Results are NOT a solve.  Round 3: stores 2.2 ms, factor loads 2.9 ms of
             // the 4.9 ms sweep, FMAs and window shifts 0.
             else if (W <= 34 && getenv("DDH_BWD_DBG") && atoi(getenv("DDH_BWD_DBG")) > 0) {
-#define DDH_SOLVE_DBG(V) case V: hipLaunchKernelGGL((solve_backward_kernel<NF, 34, true, false, true, V>), dim3(blocks), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip); break;
+#define DDH_SOLVE_DBG(V) case V: hipLaunchKernelGGL((solve_backward_kernel<NF, 34, true, false, true, V>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip); break;
                 switch (atoi(getenv("DDH_BWD_DBG"))) {
                     DDH_SOLVE_DBG(1) DDH_SOLVE_DBG(2) DDH_SOLVE_DBG(4) DDH_SOLVE_DBG(8) DDH_SOLVE_DBG(16) DDH_SOLVE_DBG(32) DDH_SOLVE_DBG(31)
                     default: DDH_SOLVE_P(34)
@@ -2374,7 +2441,8 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
             else DDH_SOLVE_P(48)
         }
     } else if (d.n > 0 && !cb) {
-        if (W <= 32) DDH_SOLVE(32)
+        if (W <= 18) DDH_SOLVE(18)
+        else if (W <= 32) DDH_SOLVE(32)
         else if (W <= 34) DDH_SOLVE(34)
         else if (W <= 48) DDH_SOLVE(48)
         else DDH_SOLVE(64)
@@ -2483,6 +2551,14 @@ int ddh_pencil_set_pairing(ddh_handle pack, const int *row_swap_h, const int *co
     pp->pair_rows.assign(row_swap_h, row_swap_h + N);
     pp->pair_cols.assign(col_swap_h, col_swap_h + N);
     pp->pair_min = min_systems;
+    return 0;
+}
+
+int ddh_pencil_set_row_blocks(ddh_handle pack, int nblocks) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (nblocks < 1 || nblocks > 8) return fail("pencil_set_row_blocks: 1 .. 8 blocks");
+    pp->row_blocks = nblocks;
     return 0;
 }
 
@@ -2765,13 +2841,21 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
             d.pk63 = 63;
         }
         d.real = real ? 1 : 0;
+        d.nsplit = 1;
+        d.nh = n;
+        d.Gp = (long)((G + 255) / 256) * 256;
+        static const bool no_par = getenv("DDH_SPLIT_THREADS") && atoi(getenv("DDH_SPLIT_THREADS")) == 0;
+        if (real && P.nf == 2 && pp->row_blocks > 1 && n > 0 && n % pp->row_blocks == 0 && !no_par) {
+            d.nsplit = pp->row_blocks;
+            d.nh = n / pp->row_blocks;
+        }
         d.GL = (long)GL;
         d.nblk = (long)((GL + 63) / 64);
         d.rows_aw = (n > 0 ? n : 1) + (real ? forward_window(kl) : 0);
         const size_t GLp = (size_t)d.nblk * 64;
         const size_t szAw = esz * (size_t)d.rows_aw * d.BW * GLp;
         const size_t szAb = esz * (size_t)N * (nb > 0 ? nb : 1) * GLp;
-        const size_t szScr = sizeof(double2) * (size_t)std::max(n + nb, nb * nb) * G;
+        const size_t szScr = sizeof(double2) * (size_t)std::max(n + nb + d.nsplit * nb, nb * nb) * G;
         int st = check_hip(hipMalloc((void **)&d.Aw, szAw), "hipMalloc(band LU)");
         if (!st) st = check_hip(hipMalloc((void **)&d.Ab, szAb), "hipMalloc(border LU)");
         if (!st) st = check_hip(hipMalloc((void **)&d.piv, (size_t)d.rows_aw * GLp), "hipMalloc(piv)");

@@ -106,6 +106,7 @@ SIGNATURES = {
     "ddh_pencil_solve": [_h, _i, _vp, _vp, _vp],
     "ddh_pencil_set_solve_variant": [_h, _i, _i, _i],
     "ddh_pencil_set_pairing": [_h, _ip, _ip, _l],
+    "ddh_pencil_set_row_blocks": [_h, _i],
     "ddh_pencil_solve_lincomb": [_h, _i, _i, C.POINTER(_vp), _dp, _vp, _vp],
     "ddh_pencil_solve_recombined": [_h, _i, _i, C.POINTER(_vp), _dp, _i, _vp, _vp, _vp],
     "ddh_pencil_solve_recombined_sparse": [_h, _i, _i, C.POINTER(_vp), _dp, _i, _vp, _vp, _vp, _vp, _vp],

@@ -297,6 +297,10 @@ class PencilPack:
         cs = np.ascontiguousarray(col_swap, dtype=np.int32)
         libhip.call("ddh_pencil_set_pairing", self.handle, libhip.as_ip(rs), libhip.as_ip(cs), int(min_systems))
 
+    def set_row_blocks(self, nblocks):
+        """Independent diagonal blocks of equal size in the band block of later factorizations (ddh_pencil_set_row_blocks)."""
+        libhip.call("ddh_pencil_set_row_blocks", self.handle, int(nblocks))
+
     def lu_bytes(self, lu_id):
         n = C.c_size_t(0)
         libhip.call("ddh_pencil_lu_bytes", self.handle, lu_id, C.byref(n))

@@ -358,6 +358,18 @@ int ddh_pencil_set_solve_variant(ddh_handle pack, int mode, int fwd, int backwar
  * symmetry on its term lists); NULL, NULL switches pairing off.  Needs the real-graded factorization
  * (ddh_pencil_factor_real), two Fourier axes, a square unsharded cell grid with kx_h == ky_h; otherwise ignored.   */
 int ddh_pencil_set_pairing(ddh_handle pack, const int *row_swap_h, const int *col_swap_h, long min_systems);
+/* Independent diagonal blocks.  When the band block of the ordered pencil matrix (rows / columns < n_interior of
+ * ddh_pencil_factor*) is block diagonal with `nblocks` blocks of EQUAL size -- the connected components of the matrix,
+ * e.g. the two reflection parities of constant-coefficient equations between two plates once the boundary rows are
+ * decoupled (dedalus_amd/core/solvers.py::_decouple_boundary_rows) -- the caller orders it block after block (its
+ * bandwidth is then that of one block) and announces the count here before factoring.  The factorization is the plain
+ * band LU of that matrix (partial pivoting never leaves a block: the candidates of another block are exact zeros); the
+ * one-thread-per-system sweeps of the real-graded two-axis path then run one thread per (system, block), so the chain
+ * of dependent rows of a sweep is n / nblocks long.  Every other sweep variant treats the matrix as the band matrix it
+ * is.  The caller guarantees the structure (no entry couples two blocks).  The reference factors the coupled sparse
+ * matrix per pencil (libraries/matsolvers.py:126-149, core/subsystems.py:497-596); the solutions are those of the same
+ * linear systems.  nblocks = 1 switches it off.                                                                      */
+int ddh_pencil_set_row_blocks(ddh_handle pack, int nblocks);
 /* Pencils whose band block is singular (e.g. the kx=ky=0 pressure-gauge pencil) are flagged by
  * ddh_pencil_factor and solved with an explicit dense inverse the host supplies: query the flagged
  * cell ids, then upload inverses in logical (permuted) ordering, complex row-major N x N per

@@ -1,0 +1,33 @@
+#!/bin/bash
+# One parameterised GPU-box script (replaces the per-experiment r3*.sh files):  gpurun -- 'bash tools/gpu/run.sh STEP [STEP ...]'
+# Every step writes under gpurun_out/<tag>/ (tag = $TAG or "r4").
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${TAG:-r4}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+bench_line() { python - "$1" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r = d["roofline"]
+    print(sys.argv[1], "steps/s %.3f ms %.2f chk %.15g frac %.3f" % (d["value"], d["ms_per_step"], d["checksum_b_c_l2"], r["frac"]))
+    print("   ", {k: (v["avg_ms"], v["GBps"]) for k, v in d["kernels"].items()})
+    print("   parity", d.get("parity"))
+except Exception as e:
+    print(sys.argv[1], "unreadable:", e)
+PY
+}
+for step in "$@"; do
+  case $step in
+    tests)      python -m pytest tests -x -q -m gpu > $OUT/pytest.txt 2>&1; tail -3 $OUT/pytest.txt ;;
+    tests-solve) python -m pytest tests/test_gpu_pencil.py tests/test_gpu_reference_pencils.py tests/test_gpu_ivp.py -x -q -m gpu > $OUT/pytest_solve.txt 2>&1; tail -5 $OUT/pytest_solve.txt ;;
+    smoke)      python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+    bench)      python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; bench_line $OUT/bench.json ;;
+    bench-quick) python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err; bench_line $OUT/bench_quick.json ;;
+    bench-nosplit) DDH_NO_SPLIT=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_nosplit.json 2> $OUT/bench_nosplit.err; bench_line $OUT/bench_nosplit.json ;;
+    bench-cfl)  python bench.py --steps 10 --warmup 3 --cfl --no-cpu-baseline > $OUT/bench_cfl.json 2> $OUT/bench_cfl.err; bench_line $OUT/bench_cfl.json ;;
+    profile)    bash tools/profile_round.sh $TAG > $OUT/profile.log 2>&1; tail -3 $OUT/profile.log ;;
+    configs)    python tools/bench_configs.py all --json > $OUT/configs.json 2> $OUT/configs.err; tail -5 $OUT/configs.json ;;
+    *)          echo "running: $step"; bash -c "$step" ;;
+  esac
+done
