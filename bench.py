@@ -74,15 +74,19 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)     # (the reference's warmup_iterations, core/solvers.py:546)
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="the K timed steps are repeated this many times back to back (each repeat bracketed by its own "
+                         "barrier + synchronize); the line reports the MEDIAN repeat and lists all of them")
     ap.add_argument("--size", type=str, default=os.environ.get("BENCH_SIZE", "512,512,256"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dt", type=float, default=1e-3)
-    ap.add_argument("--cfl", action="store_true",
-                    help="after the fixed-dt measurement (the metric), also time the example's adaptive loop: "
-                         "d3.CFL(cadence=10, threshold=0.05) on an O(1) flow, i.e. with LHS refactorizations; reported "
-                         "as `cfl_mode` beside the fixed-dt value")
+    ap.add_argument("--cfl", action="store_true", help="(kept for old command lines: the adaptive loop now runs by default)")
+    ap.add_argument("--no-cfl", action="store_true",
+                    help="skip the second reported mode: after the fixed-dt measurement (the metric) the example's adaptive "
+                         "loop -- d3.CFL(cadence=10, threshold=0.05) on an O(1) flow, i.e. with LHS refactorizations -- is "
+                         "timed and reported as `cfl_mode` beside the fixed-dt value (one GPU only)")
     ap.add_argument("--cfl-steps", type=int, default=40)
     return ap.parse_args()
 
@@ -122,7 +126,7 @@ def host_info():
 def cpu_baseline(full_shape, budget_s=30.0):
     """The oracle executor ("port": the reference's per-pencil algorithm restated -- scipy CSR + SuperLU per pencil,
     scipy.fft + NumPy pack passes, oracle/np_executor.py) timed on this box's host, ONE core, on bounded samples of
-    the same problem family: 3-D RB 32^3 and 64x64x32 and the 2-D config 512x256.  The metric's size is far beyond
+    the same problem family: 3-D RB 32^3, 64x64x32 and 64^3 and the 2-D config 512x256.  The metric's size is far beyond
     host memory for the reference's algorithm, so `value` extrapolates the largest 3-D sample with the
     reference's own speed figure, mode-stages per cpu-second (core/solvers.py:755-778).  `port_vs_reference` is the
     calibration of this port against the unmodified reference on the build container
@@ -132,8 +136,10 @@ def cpu_baseline(full_shape, budget_s=30.0):
     from oracle.np_executor import NumpyExecutor
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     samples = []
-    cases = [("rb3d", dict(Nx=32, Ny=32, Nz=32), 0.25), ("rb3d", dict(Nx=64, Ny=64, Nz=32), 0.4),
-             ("rb2d", dict(Nx=512, Nz=256), 0.35)]
+    # SURVEY 8(d) asks for 64^3 and 128 x 128 x 64: 64^3 runs (2+ steps); 128 x 128 x 64 (4 x the modes: ~1 min of setup +
+    # ~10 s per step on one core) does not fit the budget of the default bench run and is named in `not_run`
+    cases = [("rb3d", dict(Nx=32, Ny=32, Nz=32), 0.15), ("rb3d", dict(Nx=64, Ny=64, Nz=32), 0.2),
+             ("rb3d", dict(Nx=64, Ny=64, Nz=64), 0.3), ("rb2d", dict(Nx=512, Nz=256), 0.25)]
     for kind, kw, share in cases:
         build = problems.rayleigh_benard_3d if kind == "rb3d" else problems.rayleigh_benard_2d
         t0 = time.time()
@@ -151,7 +157,7 @@ def cpu_baseline(full_shape, budget_s=30.0):
         samples.append(dict(case="%s %s" % (kind, "x".join(str(v) for v in kw.values())), steps=steps, seconds=round(el, 2),
                             setup_s=round(setup, 2), steps_per_s=steps / el, modes=modes,
                             mode_stages_per_cpu_s=modes * 2 * steps / el))
-    ref3d = samples[1]
+    ref3d = samples[2]                          # the largest 3-D sample
     full_modes = 5 * int(np.prod(full_shape))
     value = ref3d["mode_stages_per_cpu_s"] / (2 * full_modes)
     calib = None
@@ -164,9 +170,10 @@ def cpu_baseline(full_shape, budget_s=30.0):
                      source="profiles/r2_cpu_port_vs_reference.json")
     return dict(value=value, unit="timesteps/sec (extrapolated to the metric's size with mode-stages per cpu-second)",
                 cores=1, kind="port", host=host_info(), cores_total=os.cpu_count(),
-                sample="3 bounded samples on 1 core, RK222 dt=1e-3: " + "; ".join(
+                not_run="rb3d 128x128x64 (SURVEY 8d): beyond the ~30 s budget of the default run on one core",
+                sample="4 bounded samples on 1 core, RK222 dt=1e-3: " + "; ".join(
                     "%s: %d steps in %.1f s = %.3f steps/s" % (x["case"], x["steps"], x["seconds"], x["steps_per_s"]) for x in samples)
-                       + "; value = mode-stages/cpu-s of the 64x64x32 sample / (2 stages x %d modes)" % full_modes,
+                       + "; value = mode-stages/cpu-s of the 64x64x64 sample / (2 stages x %d modes)" % full_modes,
                 samples=samples, port_vs_reference=calib,
                 reference_estimate=(value / calib["geomean"]) if calib else None)
 
@@ -184,7 +191,7 @@ def parity_check(solver, dt):
     recs = solver.solve_probe["records"]
     solver.solve_probe = None
     res = pencil_check.check_records(ref, recs, mine) if mine else []
-    return dict(pencils_checked=len(mine), solves=len(recs),
+    return dict(pencils_checked=len(mine), solves=len(recs), solve_paths=sorted({r.get("path") for r in recs}),
                 max_residual=max((r["residual"] for r in res), default=0.0),
                 max_solution_error=max((r["solution"] for r in res), default=0.0),
                 max_invalid_mode=max((r["dropped_max"] for r in res), default=0.0))
@@ -266,19 +273,26 @@ def main():
         torch.distributed.barrier()
     timer = KernelTimer(torch)
     ex.timer = timer
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(args.steps):
-        solver.step(args.dt)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    el = time.time() - t0
+    els = []
+    for _ in range(max(1, args.repeats)):               # every repeat: exactly K steps between barrier + synchronize
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t0 = time.time()
+        for _ in range(args.steps):
+            solver.step(args.dt)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        e = time.time() - t0
+        if world > 1:
+            t = torch.tensor([e], device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            e = float(t.item())
+        els.append(e)
     ex.timer = None
-    if world > 1:
-        t = torch.tensor([el], device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        el = float(t.item())
+    el = float(np.median(els))
+    nrep = len(els)
     summ = timer.summary()
     ranks_seen, backend, exch = 1, None, None
     if world > 1:
@@ -286,9 +300,9 @@ def main():
         backend = torch.distributed.get_backend()
         pc = solver.dist.pcomm
         via = "libdedalus_hip RCCL plan (ddh_a2a_localize_*)" if pc.library_comm() is not None else "torch.distributed all_to_all_single"
-        ex_ms = summ.get("a2a_exchange", {}).get("total_ms", 0.0) / args.steps
-        exch = dict(per_rank_bytes_sent_per_step=pc.stats["bytes_sent"] / (args.warmup + args.steps),
-                    exchanges_per_step=pc.stats["exchanges"] / (args.warmup + args.steps), ms_per_step_rank0=ex_ms, via=via)
+        ex_ms = summ.get("a2a_exchange", {}).get("total_ms", 0.0) / (args.steps * nrep)
+        exch = dict(per_rank_bytes_sent_per_step=pc.stats["bytes_sent"] / (args.warmup + args.steps * nrep),
+                    exchanges_per_step=pc.stats["exchanges"] / (args.warmup + args.steps * nrep), ms_per_step_rank0=ex_ms, via=via)
     chk2 = float(np.sum(np.asarray(fields["b"]["c"]) ** 2))
     if world > 1:
         t = torch.tensor([chk2], device="cuda", dtype=torch.float64)
@@ -305,10 +319,13 @@ def main():
             torch.distributed.all_reduce(cnt)
             parity.update(max_residual=float(vals[0]), max_solution_error=float(vals[1]),
                           max_invalid_mode=float(vals[2]), pencils_checked=int(cnt.item()))
-        parity["what"] = ("every solve of one extra step on a 4x4 sample of pencils (modes 0, 85, 170, 255) against the "
-                          "reference's own M_min/L_min (SuperLU solution and residual); tests/pencil_check.py")
+        parity["what"] = ("every solve of one extra step -- issued through the SAME fused, masked entry point the timed steps "
+                          "use (solve_paths) -- on a 4x4 sample of pencils (modes 0, 85, 170, 255) against the reference's own "
+                          "M_min/L_min (SuperLU solution and residual); the right-hand side of the check is formed "
+                          "independently (unmasked lincomb); an intermediate stage is checked on the unknowns it stores; "
+                          "tests/pencil_check.py")
     chk = float(np.sqrt(chk2))
-    cfl_mode = adaptive_loop(d3, solver, fields, args, torch) if (args.cfl and world == 1) else None
+    cfl_mode = adaptive_loop(d3, solver, fields, args, torch) if (not args.no_cfl and world == 1) else None
 
     if rank == 0:
         steps_per_s = args.steps / el
@@ -330,14 +347,15 @@ def main():
             "metric": "timesteps/sec, 3D Rayleigh-Benard %dx%dx%d (Fourier x Fourier x Chebyshev, RK222)" % (Nx, Ny, Nz),
             "value": steps_per_s, "unit": "timesteps/sec", "n_gpus": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+            "repeats": {"n": nrep, "steps_per_s": [args.steps / e for e in els], "reported": "median"},
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "3-D Rayleigh-Benard IVP %dx%dx%d, dealias 3/2, RK222, fixed dt=%g, Ra=2e6 Pr=1, "
                                    "example-script initial condition (fill_random seed 42)" % (Nx, Ny, Nz, args.dt),
                        "pencils": (Nx // 2) * (Ny // 2), "rows_per_pencil_real": 4 * solver.R,
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs, pencils sharded on kx, RCCL all-to-all" % world},
             "roofline": roof,
-            "whole_step": {"algorithmic_GB_per_step": total_bytes / args.steps / 1e9,
-                           "kernel_ms_per_step": total_kernel_ms / args.steps,
+            "whole_step": {"algorithmic_GB_per_step": total_bytes / (args.steps * nrep) / 1e9,
+                           "kernel_ms_per_step": total_kernel_ms / (args.steps * nrep),
                            "achieved_GBps_all_kernels": (total_bytes / 1e9) / (total_kernel_ms / 1e3) if total_kernel_ms else None},
             "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4), "GBps": round(v["gbps"], 1),
                             "total_ms": round(v["total_ms"], 2)} for k, v in sorted(summ.items())},

@@ -320,11 +320,29 @@ class HipTranspose:
         libhip.call("ddh_a2a_plan_blocks", C.byref(self.plan), comm.handle, self.N0, self.N1, self.N2, self.N3,
                     self.block1, self.block2)
 
+    def _local(self, n, block):
+        """Entries of an axis of length n this rank owns when it is dealt out in blocks of `block`."""
+        return max(0, min(block, n - self.comm.rank * block))
+
+    def _check(self, CL, RL):
+        """The plan reads / writes exactly these many elements: a caller with another chunk convention must hear about it
+        here, not through an out-of-bounds access on the device."""
+        want_cl = self.N0 * self.N1 * self._local(self.N2, self.block2) * self.N3
+        want_rl = self.N0 * self._local(self.N1, self.block1) * self.N2 * self.N3
+        for name, arr, want in (("column-local", CL, want_cl), ("row-local", RL, want_rl)):
+            have = int(arr.numel()) if hasattr(arr, "numel") else int(np.prod(arr.shape))
+            if have != want:
+                raise ValueError("HipTranspose: the %s array holds %d elements, the plan's block of rank %d has %d "
+                                 "(global %s, axis %d, blocks %d / %d)" % (name, have, self.comm.rank, want, self.global_shape,
+                                                                          self.axis, self.block1, self.block2))
+
     def localize_rows(self, CL, RL):
+        self._check(CL, RL)
         libhip.call("ddh_a2a_localize_rows", self.plan, C.c_void_p(device_pointer(CL)), C.c_void_p(device_pointer(RL)),
                     self.stream)
 
     def localize_columns(self, RL, CL):
+        self._check(CL, RL)
         libhip.call("ddh_a2a_localize_columns", self.plan, C.c_void_p(device_pointer(RL)),
                     C.c_void_p(device_pointer(CL)), self.stream)
 

@@ -214,17 +214,17 @@ class FileHandler(Handler):
         # asynchronous device-to-host staging of the task data (DDH_OUTPUT_SYNC=1: fetch and write immediately)
         self.async_staging = os.environ.get("DDH_OUTPUT_SYNC", "0") != "1"
         # a script that never closes its handlers still gets its last write: flushed when the main loop ends
-        # (IVPLifecycle) and, as the last resort, when the handler is collected or the interpreter exits
-        self._finalizer = weakref.finalize(self, FileHandler._finalize, self._queue, weakref.ref(self))
+        # (IVPLifecycle) and, as the last resort, at interpreter exit: atexit holds the handler itself (a finalizer of the
+        # handler could not work -- by the time it runs the handler and its staged outputs are gone -- and a handler that
+        # a script drops must still write what it staged), and the exit path CLOSES the set (flush + close of the file)
+        import atexit
+        atexit.register(self._at_exit)
 
-    @staticmethod
-    def _finalize(queue, ref):
-        me = ref()
-        if me is not None and queue:
-            try:
-                me.flush()
-            except Exception:                       # the device may already be gone at interpreter exit
-                pass
+    def _at_exit(self):
+        try:
+            self.close()
+        except Exception:                           # the device may already be gone at interpreter exit
+            pass
 
     @property
     def current_file(self):

@@ -763,12 +763,21 @@ class SolverBase:
             Y = self.ex.empty((self.R, self.nx, self.ny))
             self.pack.solve(lu, rhs, Y)
             self.pack.matvec(self.P_id, Y, out)
-        probe = getattr(self, "solve_probe", None)
-        if probe is not None:
-            a, b = self._lu_params[lu]
-            probe["records"].append(dict(a=a, b=b,
-                                         rhs=[self.gather_pencil(rhs, "equations", gx, gy) for gx, gy in probe["groups"]],
-                                         x=[self.gather_pencil(out, "variables", gx, gy) for gx, gy in probe["groups"]]))
+        if getattr(self, "solve_probe", None) is not None:
+            self._probe_record(lu, rhs, out, path="ddh_pencil_solve_recombined (one materialised right-hand side)")
+
+    def _probe_record(self, lu, rhs, out, path, skip_rows=None, terms=1, zero_rows=None):
+        """Parity probe (tests, bench.py `parity`): the right-hand side and the solution of the solve that just ran, on the
+        probe's pencils, in the reference's gathered order.  `skip_rows` (host uint8 [R] or None): unknowns this solve did
+        not store -- their entries of `x` are stale by design and the record says which."""
+        probe = self.solve_probe
+        a, b = self._lu_params[lu]
+        rec = dict(a=a, b=b, path=path, terms=int(terms), zero_rows=bool(zero_rows), skip_rows=skip_rows is not None,
+                   rhs=[self.gather_pencil(rhs, "equations", gx, gy) for gx, gy in probe["groups"]],
+                   x=[self.gather_pencil(out, "variables", gx, gy) for gx, gy in probe["groups"]])
+        if skip_rows is not None:
+            rec["skipped"] = [self.gather_rows_mask(skip_rows, "variables", gx, gy) for gx, gy in probe["groups"]]
+        probe["records"].append(rec)
 
     def zero_rows_host(self):
         """uint8 [R]: 1 where BOTH M.X and the F vector of `evaluate_F` are structurally zero -- rows of equations without a
@@ -840,30 +849,54 @@ class SolverBase:
     def solve_lincomb(self, lu, xs, alphas, out, zero_rows=None, skip_rows=None):
         """out = (a M + b L)^-1 (sum_t alphas[t] xs[t]).  The combination is formed inside the forward sweep of the band
         solve; with a parity probe attached (or more terms than the kernel takes) it is materialised first."""
-        if getattr(self, "solve_probe", None) is not None or len(xs) > self.pack.MAX_RHS_TERMS or not hasattr(self.pack, "solve_lincomb"):
+        probe = getattr(self, "solve_probe", None)
+        if len(xs) > self.pack.MAX_RHS_TERMS or not hasattr(self.pack, "solve_lincomb"):
             rhs = self.ex.empty((self.R, self.nx, self.ny))
             self.ex.lincomb(rhs, xs, alphas)
             self._last_rhs = rhs                       # (kept for the parity tests)
             return self.solve(lu, rhs, out)
+        rhs_rec = None
+        if probe is not None:
+            # The probe must certify the kernels that are TIMED: the same fused call runs below, with the same terms and
+            # masks; the record's right-hand side is formed independently (a plain lincomb of the same vectors, every row),
+            # so a mask that hid a non-zero row would show up as a residual.  (`out` may alias a term: formed first.)
+            rhs_rec = self.ex.empty((self.R, self.nx, self.ny))
+            self.ex.lincomb(rhs_rec, xs, alphas)
+            self._last_rhs = rhs_rec
+        path = "ddh_pencil_solve_lincomb"
         if self.P_id is None:
             self.pack.solve_lincomb(lu, xs, alphas, out)
         elif hasattr(self.pack, "solve_recombined"):
             Y = self.ex.empty((self.R, self.nx, self.ny))
             if zero_rows is not None or skip_rows is not None:
                 self.pack.solve_recombined(lu, xs, alphas, self.P_id, Y, out, zero_rows=zero_rows, skip_rows=skip_rows)
+                path = "ddh_pencil_solve_recombined_sparse"
             else:
                 self.pack.solve_recombined(lu, xs, alphas, self.P_id, Y, out)
+                path = "ddh_pencil_solve_recombined"
         else:
             Y = self.ex.empty((self.R, self.nx, self.ny))
             self.pack.solve_lincomb(lu, xs, alphas, Y)
             self.pack.matvec(self.P_id, Y, out)
+        if probe is not None:
+            skip_h = None
+            if skip_rows is not None:
+                skip_h = np.asarray(skip_rows[0].cpu().numpy() if hasattr(skip_rows[0], "cpu") else skip_rows[0], dtype=np.uint8)
+            self._probe_record(lu, rhs_rec, out, path + " (%d fused terms%s%s)" % (
+                len(xs), ", zero_rows" if zero_rows is not None else "", ", skip_rows" if skip_rows is not None else ""),
+                skip_rows=skip_h, terms=len(xs), zero_rows=zero_rows is not None)
+        if skip_rows is not None and os.environ.get("DDH_POISON_SKIPPED") is not None:
+            # debug aid: the unknowns an intermediate stage does not store must not be consumed before the last stage
+            # stores them -- poison them and a consumer shows up as NaN in the end state (tests/test_gpu_ivp.py)
+            t = self.ex.torch
+            idx = t.nonzero(skip_rows[0]).flatten()
+            out.reshape(self.R, -1)[idx] = float("nan")
 
     def gather_pencil(self, vec, which, gx, gy=0):
         """One pencil of a system vector in the reference's gathered order (Subproblem.gather_inputs /
         gather_outputs before pre_right_pinv / pre_left, core/subsystems.py:302-365): for every variable (or equation)
         in problem order its slice [component..., 2 modes of x group gx, 2 modes of y group gy, all z], C order;
         operands without a Fourier basis belong to group 0 only.  Diagnostics / parity checks: a few KB per call."""
-        infos = self.var_info if which == "variables" else self.eq_info
         lx = gx - (self.dist._mx_offset if self.nf >= 1 else 0)
         # the cell's slab [R][<= 2][<= 2] of the vector comes to the host in one copy
         cx = slice(2 * lx, 2 * lx + 2) if self.nf >= 1 else slice(0, 1)
@@ -875,6 +908,17 @@ class SolverBase:
             # boundary rows are stored as the combinations eq_T of the user's equations: hand out the user's
             rows = self._eq_T_rows
             cell[rows] = (self.eq_Tinv[rows][:, rows] @ cell[rows].reshape(len(rows), -1)).reshape(cell[rows].shape)
+        return self._gather_cell(cell, which, gx, gy)
+
+    def gather_rows_mask(self, mask, which, gx, gy=0):
+        """A per-row flag [R] in the gathered order of `gather_pencil` (one entry per gathered mode)."""
+        wx = 2 if self.nf >= 1 else 1
+        wy = 2 if self.nf >= 2 else 1
+        cell = np.broadcast_to(np.asarray(mask, dtype=float)[:, None, None], (self.R, wx, wy))
+        return self._gather_cell(cell, which, gx, gy) != 0
+
+    def _gather_cell(self, cell, which, gx, gy):
+        infos = self.var_info if which == "variables" else self.eq_info
         parts = []
         for info in infos:
             bits = info["bits"]

@@ -103,6 +103,8 @@ class MultistepIMEX(_SolveMixin):
         self.dt = deque([0.0] * self.steps)
         self.MX = deque(ex.zeros(shape) for _ in range(self.amax))
         self.F = deque(ex.zeros(shape) for _ in range(self.cmax))
+        if hasattr(solver, "_F_zeroed"):
+            solver._F_zeroed = set()            # (addresses of an earlier timestepper's buffers may be handed out again)
         self._iteration = 0
         self._LHS_params = None
         self._lu = -1
@@ -298,6 +300,8 @@ class RungeKuttaIMEX(_SolveMixin):
         H = self.H
         self.MX0 = ex.zeros(shape)
         self.F = [ex.zeros(shape) for _ in range(self.stages)]
+        if hasattr(solver, "_F_zeroed"):
+            solver._F_zeroed = set()            # (addresses of an earlier timestepper's buffers may be handed out again)
         # Which L.X_j enter a later stage?  (the first column of H is zero in the registered schemes)
         self._need_lx = [any(H[m, j] != 0.0 for m in range(j + 1, self.stages + 1)) for j in range(self.stages + 1)]
         # L.X_j of a solved stage j >= 1 is not formed by a mat-vec: the stage equation (M + k H_jj L) X_j = RHS_j

@@ -512,6 +512,9 @@ band_matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *
             double2 accP = make_double2(0.0, 0.0), accQ = accP;
 #pragma unroll
             for (int d = 0; d < MV_W; ++d) {
+                // (wave-uniform) window slots without a term are SKIPPED, not multiplied by zero: 0 * NaN / 0 * Inf of an
+                // unrelated row of x must not reach y -- the term-list kernel never reads those rows
+                if (cf[d] == 0.0) continue;
                 const double2 v = make_double2(cf[d], 0.0);
                 const double2 xP = make_double2(wa[d].x - wb[d].y, wa[d].y + wb[d].x);
                 const double2 xQ = make_double2(wa[d].x + wb[d].y, wa[d].y - wb[d].x);
@@ -1536,8 +1539,8 @@ solve_forward_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__restrict_
 //  * two register sets alternate for the prefetched row (no copies), all loads of a row are issued before its first use.
 // Same arithmetic, same order of operations per system as solve_forward_kernel<2, true, ...>.
 // ------------------------------------------------------------------------------------------------
-template <int KLT, int NBT>
-__global__ void __launch_bounds__(256)
+template <int KLT, int NBT, int MINW = 1>
+__global__ void __launch_bounds__(256, MINW)
 solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__restrict__ xout) {
     constexpr int NF = 2;
     extern __shared__ int s_lds[];
@@ -1715,8 +1718,8 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     }
 }
 
-template <int NF, int WT, bool REAL, bool PREF, bool PFUSE = false, int DBG = 0>
-__global__ void __launch_bounds__(256)
+template <int NF, int WT, bool REAL, bool PREF, bool PFUSE = false, int DBG = 0, int MINW = 1>
+__global__ void __launch_bounds__(256, MINW)
 solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const double *__restrict__ pband,
                       const unsigned char *__restrict__ skip) {
     typedef typename El<REAL>::T E;
@@ -2315,6 +2318,15 @@ static void choose_variant(const PencilPack *pp, const LuDev &d, int &use_fwd, i
     if (d.n <= 0) use_fwd = cb = 0;
 }
 
+// The lean forward sweep (real-graded factors, two Fourier axes) is instantiated and tested for the windows of the
+// Rayleigh-Benard pencils: kl <= 12, a border of <= 2; other shapes take the general kernel (the wider instantiations fit
+// two waves per SIMD only partly and have no test yet).
+static bool lean_forward_ok(const LuDev &d) {
+    static const int no_lean = getenv("DDH_FWD_LEAN") ? !atoi(getenv("DDH_FWD_LEAN")) : 0;
+    return d.real && d.n > 0 && !no_lean && d.kpad + d.kl == forward_window(d.kl) &&
+           d.rows_aw >= d.n + forward_window(d.kl) && d.kl <= 12 && d.nb <= 2;
+}
+
 // want_p: the caller asks for x = P y (recombination fused into the backward sweep); *did_p tells whether this launch
 // could do it (one-thread-per-system backward kernel of the real-graded 2-axis path with a band table on file).
 template <int NF>
@@ -2367,15 +2379,15 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     // one thread per (system, block) where the sweep kernels support it (LuDev::nsplit)
     const unsigned blocks_split = (unsigned)(((long)d.nsplit * d.Gp + 255) / 256);
     if constexpr (NF == 2) {
-        static const int no_lean = getenv("DDH_FWD_LEAN") ? !atoi(getenv("DDH_FWD_LEAN")) : 0;
-        // (instantiated and tested for the window of the Rayleigh-Benard pencils: kl <= 12, a border of <= 2; other shapes
-        // take the general kernel -- the wider instantiations fit two waves per SIMD only partly and have no test yet)
-        lean_fwd = !use_fwd && d.real && d.n > 0 && !no_lean && d.kpad + d.kl == forward_window(d.kl) &&
-                   d.rows_aw >= d.n + forward_window(d.kl) && d.kl <= 12 && d.nb <= 2;
+        lean_fwd = !use_fwd && lean_forward_ok(d);
         if (lean_fwd) {
 #define DDH_LFWD(KLTV, NBTV) \
     { hipLaunchKernelGGL((solve_forward_lean_kernel<KLTV, NBTV>), dim3(blocks_split), dim3(256), lds_f, s, P, d, rhs, x); }
-            if (forward_window(d.kl) == 6) DDH_LFWD(6, 2) else DDH_LFWD(12, 2)
+            // (block-parallel sweeps double the thread count: 4 waves per SIMD keep every thread resident, DDH_SWEEP_OCC=4)
+            static const int occ4 = getenv("DDH_SWEEP_OCC") ? atoi(getenv("DDH_SWEEP_OCC")) == 4 : 1;
+            if (forward_window(d.kl) == 6 && d.nsplit > 1 && occ4)
+                hipLaunchKernelGGL((solve_forward_lean_kernel<6, 2, 4>), dim3(blocks_split), dim3(256), lds_f, s, P, d, rhs, x);
+            else if (forward_window(d.kl) == 6) DDH_LFWD(6, 2) else DDH_LFWD(12, 2)
 #undef DDH_LFWD
             if (d.nsplit > 1 && d.nb > 0)
                 hipLaunchKernelGGL(border_finish_kernel<NF>, dim3(blocks), dim3(256), 0, s, P, d, x);
@@ -2421,7 +2433,10 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     { hipLaunchKernelGGL((solve_backward_kernel<NF, WTV, true, false, true>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip); }
     if (fuse_p) {
         if constexpr (NF == 2) {
-            if (W <= 18) DDH_SOLVE_P(18)
+            static const int occ4 = getenv("DDH_SWEEP_OCC") ? atoi(getenv("DDH_SWEEP_OCC")) == 4 : 1;
+            if (W <= 18 && d.nsplit > 1 && occ4)
+                hipLaunchKernelGGL((solve_backward_kernel<NF, 18, true, false, true, 0, 4>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
+            else if (W <= 18) DDH_SOLVE_P(18)
             else if (W <= 32) DDH_SOLVE_P(32)
 #ifdef DDH_BWD_ABLATE
             // timing ablations of the backward sweep (build with -DDDH_BWD_ABLATE; DDH_BWD_DBG = mask: 1 one factor load
@@ -3044,9 +3059,19 @@ int ddh_pencil_set_dense_inverse_dev(ddh_handle pack, int lu_id, int sys, const 
     LuFactor *lu = pp->lus[lu_id];
     const size_t N = (size_t)lu->dev.N, nsys = (size_t)lu->nflag * pp->dev.S;
     if (sys < 0 || (size_t)sys >= nsys) return fail("pencil_set_dense_inverse_dev: system index out of range");
-    if (!lu->d_inv) {
-        DDH_HIP(hipMalloc(&lu->d_inv, nsys * N * N * sizeof(double2)));
-        DDH_HIP(hipMalloc(&lu->d_dense_rhs, 2 * nsys * N * sizeof(double2)));
+    if (!lu->d_inv || !lu->d_dense_rhs) {
+        // both or neither: a solve that finds d_inv expects its right-hand-side buffer too
+        (void)hipFree(lu->d_inv); lu->d_inv = nullptr;
+        (void)hipFree(lu->d_dense_rhs); lu->d_dense_rhs = nullptr;
+        void *inv = nullptr, *rhs = nullptr;
+        int st = check_hip(hipMalloc(&inv, nsys * N * N * sizeof(double2)), "hipMalloc(dense inverse)");
+        if (!st) st = check_hip(hipMalloc(&rhs, 2 * nsys * N * sizeof(double2)), "hipMalloc(dense rhs)");
+        if (st) {
+            (void)hipFree(inv);
+            return st;
+        }
+        lu->d_inv = inv;
+        lu->d_dense_rhs = rhs;
     }
     hipLaunchKernelGGL(widen_inverse_kernel, dim3(2048), dim3(256), 0, as_stream(stream), inv_d,
                        (double2 *)lu->d_inv + (size_t)sys * N * N, (long)(N * N), is_complex);
@@ -3188,6 +3213,24 @@ int ddh_pencil_lu_row_widths(ddh_handle pack, int lu_id, int *wrow_h) {
     DDH_HIP(hipGetLastError());
     DDH_HIP(hipMemcpy(wrow_h, dw, d.n * sizeof(int), hipMemcpyDeviceToHost));
     (void)hipFree(dw);
+    return 0;
+}
+
+int ddh_pencil_lu_info(ddh_handle pack, int lu_id, int *info_h) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_lu_info: bad LU id");
+    const LuDev &d = pp->lus[lu_id]->dev;
+    int use_fwd = 0, cb = 0;
+    switch (pp->dev.nf) {
+        case 0: choose_variant<0>(pp, d, use_fwd, cb); break;
+        case 1: choose_variant<1>(pp, d, use_fwd, cb); break;
+        default: choose_variant<2>(pp, d, use_fwd, cb); break;
+    }
+    if (d.pair) use_fwd = cb = 0;
+    const bool lean = pp->dev.nf == 2 && !use_fwd && lean_forward_ok(d);
+    const int v[12] = {d.n, d.nb, d.kl, d.ku, d.W, d.BW, d.nsplit, d.nh, use_fwd ? 2 : (lean ? 1 : 0), cb, d.pair, d.real};
+    for (int i = 0; i < 12; ++i) info_h[i] = v[i];
     return 0;
 }
 

@@ -261,8 +261,9 @@ class PencilPack:
         unknowns the caller does not need (ddh_pencil_solve_recombined_sparse)."""
         t = self._timer()
         if t is not None:
-            read = 1.0 - (zero_rows[1] if zero_rows is not None else 0.0)     # masked rows are not read / written:
-            wrote = 1.0 - (skip_rows[1] if skip_rows is not None else 0.0)    # not counted
+            info = self.lu_info(lu_id)          # masked rows are not read / written -- by the kernels that honour the masks
+            read = 1.0 - (zero_rows[1] if (zero_rows is not None and info["forward"] == "lean") else 0.0)
+            wrote = 1.0 - (skip_rows[1] if (skip_rows is not None and info["backward_lanes"] == 0 and info["real"]) else 0.0)
             nb = self.lu_bytes(lu_id) + (sum(v.numel() for v in xs) * read + x.numel() * wrote) * 8
             return t.run("pencil_solve", nb, self._solve_recombined, lu_id, xs, alphas, p_mat_id, work, x, zero_rows,
                          skip_rows)
@@ -300,6 +301,15 @@ class PencilPack:
     def set_row_blocks(self, nblocks):
         """Independent diagonal blocks of equal size in the band block of later factorizations (ddh_pencil_set_row_blocks)."""
         libhip.call("ddh_pencil_set_row_blocks", self.handle, int(nblocks))
+
+    def lu_info(self, lu_id):
+        """Shape of a factorization and the sweep variant its solves launch (ddh_pencil_lu_info); cached per id and variant."""
+        v = np.zeros(12, dtype=np.int32)
+        libhip.call("ddh_pencil_lu_info", self.handle, lu_id, libhip.as_ip(v))
+        keys = ("n", "nb", "kl", "ku", "W", "BW", "nsplit", "rows_per_block", "forward", "backward_lanes", "pair", "real")
+        d = dict(zip(keys, (int(x) for x in v)))
+        d["forward"] = ("general", "lean", "cooperative")[d["forward"]]
+        return d
 
     def lu_bytes(self, lu_id):
         n = C.c_size_t(0)

@@ -380,6 +380,14 @@ int ddh_pencil_set_dense_inverse(ddh_handle pack, int lu_id, const double *inv_h
  * formed by ddh_dense_inverse_compute, so a timestep change costs no host linear algebra for flagged pencils either */
 int ddh_pencil_set_dense_inverse_dev(ddh_handle pack, int lu_id, int sys, const double *inv_d, int is_complex, void *stream);
 int ddh_pencil_lu_bytes(ddh_handle pack, int lu_id, size_t *bytes);
+/* Shape of a factorization and the sweep kernels ddh_pencil_solve* will launch for it (diagnostics, byte accounting,
+ * tests): info_h[12] = { n (band rows), nb (border), kl, ku, W = kl + ku, BW (stored entries per band row), nsplit
+ * (independent diagonal blocks swept by separate threads, ddh_pencil_set_row_blocks), rows per block, forward sweep
+ * (0 general one-thread-per-system, 1 lean one-thread-per-system -- the one that honours zero_rows --, 2 cooperative),
+ * backward lanes per system (0 = one thread per system -- the one that honours skip_rows and fuses x = P y --, 4, 16),
+ * partner pencils (0 / 1), real-graded (0 / 1) }.  No reference counterpart (SuperLU objects are opaque,
+ * libraries/matsolvers.py:126-149).                                                                                  */
+int ddh_pencil_lu_info(ddh_handle pack, int lu_id, int *info_h);
 /* wrow_h[j] (n_interior ints) = max over all factorizations of the last non-zero super-diagonal offset of U row j:
  * how much of the partial-pivoting fill space (kl extra super-diagonals, LAPACK gbtrf storage) is really used.  */
 int ddh_pencil_lu_row_widths(ddh_handle pack, int lu_id, int *wrow_h);

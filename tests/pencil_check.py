@@ -42,17 +42,32 @@ class ReferencePencils:
         """(mx, my) mode-group indices of sample g in the problem with Lx = Ly = 4"""
         return g[0] * self.stride, g[1] * self.stride
 
-    def check(self, g, a, b, rhs_gathered, x_gathered, solve=True):
+    def check(self, g, a, b, rhs_gathered, x_gathered, solve=True, skipped=None):
+        """skipped (bool per gathered unknown, or None): unknowns the solve did NOT store (intermediate Runge-Kutta stages
+        leave out what nothing reads before the last stage, ddh_pencil_solve_recombined_sparse): the stored ones are
+        compared with the reference's SuperLU solution, and the residual is that of the stored unknowns completed by the
+        reference's values for the others."""
         m = self.data[g]
         assert rhs_gathered.size == m["n_out"], (g, rhs_gathered.size, m["n_out"])
         assert x_gathered.size == m["n_in"], (g, x_gathered.size, m["n_in"])
         rhs = rhs_gathered[m["pre_left"]]
         x = x_gathered[m["pre_right_pinv"]]
         A = (a * m["M_min"] + b * m["L_min"]).tocsc()
-        out = dict(group=g, residual=float(np.linalg.norm(A @ x - rhs) / max(np.linalg.norm(rhs), 1e-300)))
-        # modes the reference does not keep must be empty in the product's vectors
         drop = np.ones(x_gathered.size, dtype=bool)
         drop[m["pre_right_pinv"]] = False
+        if skipped is not None and np.any(skipped):
+            sk = np.asarray(skipped, dtype=bool)[m["pre_right_pinv"]]
+            xr = spla.splu(A).solve(rhs)
+            xh = np.where(sk, xr, x)
+            out = dict(group=g, residual=float(np.linalg.norm(A @ xh - rhs) / max(np.linalg.norm(rhs), 1e-300)),
+                       skipped_unknowns=int(sk.sum()))
+            keep_drop = drop & ~np.asarray(skipped, dtype=bool)
+            out["dropped_max"] = float(np.abs(x_gathered[keep_drop]).max()) if keep_drop.any() else 0.0
+            out["solution"] = float(np.linalg.norm((x - xr)[~sk]) / max(np.linalg.norm(xr[~sk]), 1e-300))
+            out["superlu_residual"] = float(np.linalg.norm(A @ xr - rhs) / max(np.linalg.norm(rhs), 1e-300))
+            return out
+        out = dict(group=g, residual=float(np.linalg.norm(A @ x - rhs) / max(np.linalg.norm(rhs), 1e-300)))
+        # modes the reference does not keep must be empty in the product's vectors
         out["dropped_max"] = float(np.abs(x_gathered[drop]).max()) if drop.any() else 0.0
         if solve:
             xr = spla.splu(A).solve(rhs)
@@ -65,8 +80,11 @@ def check_records(ref, records, groups, solve=True):
     """records: solver.solve_probe['records'] -> flat list of per-(solve, pencil) results"""
     res = []
     for rec in records:
-        for g, r, x in zip(groups, rec["rhs"], rec["x"]):
-            res.append(ref.check(g, rec["a"], rec["b"], r, x, solve=solve))
+        sk = rec.get("skipped") or [None] * len(groups)
+        for g, r, x, k in zip(groups, rec["rhs"], rec["x"], sk):
+            out = ref.check(g, rec["a"], rec["b"], r, x, solve=solve, skipped=k)
+            out["path"] = rec.get("path")
+            res.append(out)
     return res
 
 

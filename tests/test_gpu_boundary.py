@@ -173,6 +173,11 @@ def test_transpose_planner_signature_one_rank():
     plan.localize_columns(b, c)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(a, c)
+    # a buffer of another chunk convention is refused on the host (not read out of bounds on the device)
+    with pytest.raises(ValueError, match="elements"):
+        plan.localize_rows(a[:, :4].contiguous(), b)
+    with pytest.raises(ValueError, match="elements"):
+        plan.localize_columns(b, c[:, :, :3].contiguous())
 
 
 def test_matsolver_adapter_vs_superlu():

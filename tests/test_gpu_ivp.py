@@ -254,3 +254,27 @@ def test_zero_row_mask_of_the_runge_kutta_right_hand_side(monkeypatch):
     assert abs(z1[1] - mask.mean()) < 1e-15 and 0.15 < z1[1] < 0.35     # (16 + 8 of 89 rows here, 264 of 1289 at 512 x 512 x 256)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_unknowns_skipped_by_intermediate_stages_are_never_consumed(monkeypatch):
+    """An intermediate Runge-Kutta stage does not store the unknowns nothing reads before the last stage (skip_rows).
+    DDH_POISON_SKIPPED overwrites exactly those rows of the state with NaN after every such solve: if anything -- F, M.X,
+    a transform, a hook -- consumed them, the end state would not be finite; it is bit-identical to the ordinary run."""
+    import dedalus_amd.public as d3
+
+    def run(poison):
+        if poison:
+            monkeypatch.setenv("DDH_POISON_SKIPPED", "1")
+        else:
+            monkeypatch.delenv("DDH_POISON_SKIPPED", raising=False)
+        solver, f = problems.rayleigh_benard_3d(d3, Nx=32, Ny=32, Nz=16, timestepper="RK222")
+        solver.pack.set_solve_variant(0)
+        assert solver.intermediate_skip_rows() is not None
+        for _ in range(3):
+            solver.step(1e-3)
+        return {k: np.array(f[k]["c"]) for k in ("p", "b", "u")}
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), k
