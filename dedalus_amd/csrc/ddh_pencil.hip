@@ -278,6 +278,36 @@ template <> struct El<true> {
     static __device__ __forceinline__ T scale(T a, double f) { return a * f; }
 };
 
+// Wave-uniform buffer addressing for the streams of the sweeps: resource = (address of the wave's FIRST lane, 4 GiB
+// range), a lane's address = resource + 32-bit lane offset (one vector register) + a uniform 32-bit row offset (scalar
+// register) + the instruction's immediate.  A 64-bit vector pointer per stream (plus one per out-of-range immediate) and
+// its two-instruction carry chains per load group are gone -- registers are what keeps these kernels from one more
+// resident wave per SIMD.  The first lane's address must be the smallest of the wave (factor slots and systems ascend
+// with the lane) and the wave must span < 4 GiB.
+typedef unsigned ddh_u4v __attribute__((ext_vector_type(4)));
+typedef unsigned ddh_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rsrc(const void *first_lane_ptr) {
+    const unsigned long long a = (unsigned long long)first_lane_ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void *base = (void *)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ unsigned wave_lane_off(const void *lane_ptr) {      // byte distance to the wave's first lane
+    const unsigned long long a = (unsigned long long)lane_ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (unsigned)(a - (((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double2 bload16(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uni_off) {
+    const ddh_u4v q = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uni_off, 0);
+    return make_double2(__hiloint2double((int)q.y, (int)q.x), __hiloint2double((int)q.w, (int)q.z));
+}
+__device__ __forceinline__ double bload8(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uni_off) {
+    const ddh_u2v q = __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, uni_off, 0);
+    return __hiloint2double((int)q.y, (int)q.x);
+}
+
 // Factor storage index, [block of 64 factorizations][row][entry][lane]: everything a wave ever reads of one array is one
 // contiguous stream, a row is one BW * 512 B chunk.
 // (entry d of a band row: d = kl + (column - row); the row starts with kpad zero entries, see LuDev::kpad)
@@ -1562,9 +1592,10 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     }
     __syncthreads();
     // independent diagonal blocks (LuDev::nsplit): this thread sweeps rows row0 .. row1 - 1 of system g
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int blk = L.nsplit > 1 ? (int)(tid / L.Gp) : 0;
-    const long g = tid - (long)blk * L.Gp;
+    // (Gp is a multiple of the workgroup size: the block index is uniform over the workgroup -- computed from blockIdx
+    // alone so that the row counters and everything indexed by them stay in scalar registers)
+    const int blk = L.nsplit > 1 ? __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x) / L.Gp)) : 0;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x - (long)blk * L.Gp;
     const int row0 = blk * L.nh, row1 = row0 + L.nh;
     const SysId id = sys_id<true>(P, L, g);
     if (!id.ok) return;
@@ -1577,17 +1608,20 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     // running per-lane pointers, advanced by uniform strides once per row:
     //   mp[i]: multiplier L(j + i + 1, j) = row j + i + 1, entry KLT - i - 1;  abp: border multipliers of column j (nb entries,
     //   512 B apart: immediate offsets);  pvp: the interchange of step j;  scr: y_j of this system
-    const double *mp[KLT];
+    // (one per-lane base + a running 32-bit byte offset + KLT wave-uniform deltas: 3 vector registers instead of 2 KLT)
+    const char *const awl = (const char *)((const double *)L.Aw + lu_aw(L, id.gl, row0, -L.kpad));   // this lane's block, first row, entry 0
+    unsigned mo = 0;
+    unsigned md[KLT];
     {
-        const double *const awl = (const double *)L.Aw + lu_aw(L, id.gl, row0, -L.kpad);   // this lane's block, first row, entry 0
         const long BW64 = (long)L.BW << 6;
 #pragma unroll
-        for (int i = 0; i < KLT; ++i) mp[i] = awl + (long)(i + 1) * BW64 + lu_eoff(L, KLT - i - 1);
+        for (int i = 0; i < KLT; ++i) md[i] = (unsigned)(((long)(i + 1) * BW64 + lu_eoff(L, KLT - i - 1)) * 8);
     }
     const double *abp = (const double *)L.Ab + lu_ab(L, id.gl, row0, 0);
     const unsigned char *pvp = L.piv + lu_pv(L, id.gl, row0);
     double2 *scr = L.scratch + (long)row0 * G + g;
-    const long row_step = (long)L.BW << 6, ab_step = (long)nb << 6;
+    const unsigned row_step8 = (unsigned)L.BW << 9;              // bytes between band rows of a block (32-bit: a block is < 4 GB)
+    const long ab_step = (long)nb << 6;
 
     auto load_row = [&](int i) -> double2 {
         if (s_zero[i]) return make_double2(0.0, 0.0);           // wave-uniform
@@ -1633,7 +1667,7 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     auto prefetch = [&](double *m, double *ab, int &p, double2 &r) {
         p = *pvp;
 #pragma unroll
-        for (int i = 0; i < KLT; ++i) m[i] = *mp[i];
+        for (int i = 0; i < KLT; ++i) m[i] = *reinterpret_cast<const double *>(awl + (mo + md[i]));
         if (full_border) {
 #pragma unroll
             for (int rb = 0; rb < NBT; ++rb) ab[rb] = abp[rb << 6];
@@ -1647,8 +1681,7 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
         const int nxt = jn + KLT + 1;
         r = make_double2(0.0, 0.0);
         if (nxt < row1) r = load_row(nxt);
-#pragma unroll
-        for (int i = 0; i < KLT; ++i) mp[i] += row_step;
+        mo += row_step8;
         abp += ab_step;
         pvp += 64;
         ++jn;
@@ -1737,9 +1770,9 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
     }
     __syncthreads();
     // independent diagonal blocks (LuDev::nsplit; only launched that way for REAL): rows row1 - 1 .. row0 of system g
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int blk = (REAL && L.nsplit > 1) ? (int)(tid / L.Gp) : 0;
-    const long g = tid - (long)blk * L.Gp;
+    // (uniform over the workgroup: from blockIdx alone, so that the row counter stays in scalar registers)
+    const int blk = (REAL && L.nsplit > 1) ? __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x) / L.Gp)) : 0;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x - (long)blk * L.Gp;
     const int row0 = (REAL && L.nsplit > 1) ? blk * L.nh : 0, row1 = (REAL && L.nsplit > 1) ? row0 + L.nh : n;
     const SysId id = sys_id<REAL>(P, L, g);
     if (!id.ok) return;
@@ -1771,9 +1804,21 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
     const E *const ur0 = Aw + lu_aw(L, gl, 0, kl);     // row 0, diagonal; a row further is BW * 64 elements further
     const long ur_stride = (long)L.BW << 6;
     const double2 *const y0 = L.scratch + g;
+    // Real factors: the wave's addresses are  (uniform base of the row) + (32-bit byte offset of the lane): one vector
+    // register instead of a 64-bit pointer per array and per out-of-range immediate offset.  The factorizations of a
+    // wave's lanes are consecutive (sys_id), i.e. at most two adjacent 64-blocks of the storage: the first lane's
+    // address is the smallest and the others lie within 2 * rows_aw * BW * 512 bytes of it (checked at factor time).
+    // real factors: wave-uniform buffer addressing (wave_rsrc) of the U rows and of the scratch vector; the uniform
+    // offsets are row * (bytes per row): < 4 GiB for both (rows_aw * BW * 512 per block, (n + nb) * G * 16)
+    const __amdgpu_buffer_rsrc_t ur_rs = wave_rsrc(ur0);
+    const unsigned ur_lane = wave_lane_off(ur0);
+    const __amdgpu_buffer_rsrc_t y_rs = wave_rsrc(y0);
+    const unsigned y_lane = wave_lane_off(y0);
+    const unsigned ur_row8 = (unsigned)L.BW << 9, y_row16 = (unsigned)(G * (long)sizeof(double2));
     auto fetch = [&](int j, E *u, double2 &y, double *pr) {
-        if (DBG & 8) y = make_double2(1.0, 2.0); else
-        y = y0[(long)j * G];
+        if (DBG & 8) y = make_double2(1.0, 2.0);
+        else if constexpr (REAL) y = bload16(y_rs, y_lane, (unsigned)j * y_row16);
+        else y = y0[(long)j * G];
         if (PFUSE) {
             const double *prow = pband + (long)j * PBW;
 #pragma unroll
@@ -1782,10 +1827,11 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
         const E *Ur = ur0 + (long)j * ur_stride;
         if constexpr (REAL) {
             // pair-packed rows (LuDev::pk; the diagonal sits at an even entry): 16-byte loads, two entries each
-            const double2 *Ur2 = reinterpret_cast<const double2 *>(Ur);
+            const unsigned urow = (unsigned)j * ur_row8;                                 // uniform
 #pragma unroll
             for (int q = 0; 2 * q <= WT; ++q) {
-                const double2 uu = ((DBG & 1) && q > 0) ? make_double2(u[0] * 0.5, u[0] * 0.25) : Ur2[(long)q << 6];
+                const double2 uu = ((DBG & 1) && q > 0) ? make_double2(u[0] * 0.5, u[0] * 0.25)
+                                                        : bload16(ur_rs, ur_lane, urow + (unsigned)(q << 10));
                 u[2 * q] = uu.x;
                 if (2 * q + 1 <= WT) u[2 * q + 1] = uu.y;
             }
@@ -2297,7 +2343,7 @@ static int finish_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
 // multipliers per column held by the one-thread-per-system forward kernel for a lower bandwidth kl
 static int forward_window(int kl) { return kl <= 6 ? 6 : (kl <= 12 ? 12 : 16); }
 // register window (entries above the diagonal) of the one-thread-per-system backward kernel for an upper bandwidth W
-static int backward_window(int W) { return W <= 18 ? 18 : (W <= 32 ? 32 : (W <= 34 ? 34 : (W <= 48 ? 48 : 64))); }
+static int backward_window(int W) { return W <= 17 ? 17 : (W <= 32 ? 32 : (W <= 34 ? 34 : (W <= 48 ? 48 : 64))); }
 
 template <int NF>
 static void choose_variant(const PencilPack *pp, const LuDev &d, int &use_fwd, int &cb) {
@@ -2310,6 +2356,14 @@ static void choose_variant(const PencilPack *pp, const LuDev &d, int &use_fwd, i
     if (coop_mode == 2 || (coop_auto && P.G <= 1024)) cb = 16;
     else if (coop_auto && P.G <= 16384) cb = 4;        // (round 3, register-lean sweeps: at 32 768 systems one thread per
                                                        //  system is faster again, 5.17 vs 5.58 ms -- profiles/r3_strong_scaling_shares.txt)
+    // independent diagonal blocks swept by separate threads (LuDev::nsplit): the one-thread-per-(system, block) forward
+    // sweep beats the cooperative one from a few thousand systems on (round 4, gpurun_out/r4e, solve ms per launch at the
+    // per-rank shares of 512 x 512 x 256: 16 384 systems fwd coop + cb 4: 4.32 | per-thread + cb 4: 2.24 | per-thread
+    // both: 2.57;  32 768: per-thread both 2.76 | + cb 4: 3.15;  65 536: 3.86 | 5.26)
+    if (coop_auto && d.nsplit > 1 && P.G > 4096) {
+        use_fwd = 0;
+        cb = (P.G <= 16384) ? 4 : 0;
+    }
     if (pp->coop_fwd >= 0) use_fwd = pp->coop_fwd;
     if (pp->coop_cb >= 0) cb = pp->coop_cb;
     if (NF == 0 || d.kl >= CH || d.nb > 8) use_fwd = 0;
@@ -2385,8 +2439,9 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     { hipLaunchKernelGGL((solve_forward_lean_kernel<KLTV, NBTV>), dim3(blocks_split), dim3(256), lds_f, s, P, d, rhs, x); }
             // (block-parallel sweeps double the thread count: 4 waves per SIMD keep every thread resident, DDH_SWEEP_OCC=4)
             static const int occ4 = getenv("DDH_SWEEP_OCC") ? atoi(getenv("DDH_SWEEP_OCC")) == 4 : 1;
-            if (forward_window(d.kl) == 6 && d.nsplit > 1 && occ4)
-                hipLaunchKernelGGL((solve_forward_lean_kernel<6, 2, 4>), dim3(blocks_split), dim3(256), lds_f, s, P, d, rhs, x);
+            if (forward_window(d.kl) == 6 && d.nsplit > 1 && occ4 && d.nb <= 1)
+                hipLaunchKernelGGL((solve_forward_lean_kernel<6, 1, 4>), dim3(blocks_split), dim3(256), lds_f, s, P, d, rhs, x);
+            else if (forward_window(d.kl) == 6 && d.nb <= 1) DDH_LFWD(6, 1)
             else if (forward_window(d.kl) == 6) DDH_LFWD(6, 2) else DDH_LFWD(12, 2)
 #undef DDH_LFWD
             if (d.nsplit > 1 && d.nb > 0)
@@ -2434,9 +2489,9 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     if (fuse_p) {
         if constexpr (NF == 2) {
             static const int occ4 = getenv("DDH_SWEEP_OCC") ? atoi(getenv("DDH_SWEEP_OCC")) == 4 : 1;
-            if (W <= 18 && d.nsplit > 1 && occ4)
-                hipLaunchKernelGGL((solve_backward_kernel<NF, 18, true, false, true, 0, 4>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
-            else if (W <= 18) DDH_SOLVE_P(18)
+            if (W <= 17 && d.nsplit > 1 && occ4)
+                hipLaunchKernelGGL((solve_backward_kernel<NF, 17, true, false, true, 0, 4>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
+            else if (W <= 17) DDH_SOLVE_P(17)
             else if (W <= 32) DDH_SOLVE_P(32)
 #ifdef DDH_BWD_ABLATE
             // timing ablations of the backward sweep (build with -DDDH_BWD_ABLATE; DDH_BWD_DBG = mask: 1 one factor load
@@ -2456,7 +2511,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
             else DDH_SOLVE_P(48)
         }
     } else if (d.n > 0 && !cb) {
-        if (W <= 18) DDH_SOLVE(18)
+        if (W <= 17) DDH_SOLVE(17)
         else if (W <= 32) DDH_SOLVE(32)
         else if (W <= 34) DDH_SOLVE(34)
         else if (W <= 48) DDH_SOLVE(48)

@@ -28,6 +28,23 @@ for step in "$@"; do
     bench-cfl)  python bench.py --steps 10 --warmup 3 --cfl --no-cpu-baseline > $OUT/bench_cfl.json 2> $OUT/bench_cfl.err; bench_line $OUT/bench_cfl.json ;;
     profile)    bash tools/profile_round.sh $TAG > $OUT/profile.log 2>&1; tail -3 $OUT/profile.log ;;
     configs)    python tools/bench_configs.py all --json > $OUT/configs.json 2> $OUT/configs.err; tail -5 $OUT/configs.json ;;
+    shares)     # per-rank shares of the strong-scaled problem on one GPU, sweep variants A/B (profiles/*_strong_scaling_shares.txt)
+                for sz in 256,512,256 128,512,256 64,512,256; do
+                  for var in "default:" "per-thread:DDH_SOLVE_COOP=0" "per-thread-unsplit:DDH_SOLVE_COOP=0 DDH_SPLIT_THREADS=0" "coop-fwd+cb4:DDH_COOP_FWD=1 DDH_COOP_CB=4" "cb4:DDH_COOP_FWD=0 DDH_COOP_CB=4"; do
+                    name=${var%%:*}; envs=${var#*:}
+                    env $envs python bench.py --size $sz --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-parity --no-cfl > $OUT/share_${sz//,/x}_$name.json 2>/dev/null
+                    python - $OUT/share_${sz//,/x}_$name.json "$sz $name" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    k = d["kernels"]
+    print("%-34s ms/step %6.2f  solve %5.2f  fused-y %5.2f  others %5.2f" % (sys.argv[2], d["ms_per_step"], k["pencil_solve"]["avg_ms"],
+          k.get("rfft_bilinear_fused", {}).get("avg_ms", 0.0), d["ms_per_step"] - 2 * k["pencil_solve"]["avg_ms"] - 2 * k.get("rfft_bilinear_fused", {}).get("avg_ms", 0.0)))
+except Exception as e:
+    print(sys.argv[2], "failed:", e)
+PY
+                  done
+                done ;;
     *)          echo "running: $step"; bash -c "$step" ;;
   esac
 done
