@@ -391,11 +391,22 @@ class GroupedMmt:
         self.handle = C.c_uint64(0)
         libhip.call("ddh_plan_grouped_mmt", C.byref(self.handle), self.n_grid, len(groups), C.cast(arr, C.c_void_p),
                     len(fw), libhip.as_ip(rows), pf, pb)
+        # algorithmic work of one application (libhip.note_cost): every group multiplies its [n_ell][n_grid] matrix with
+        # `count` right-hand-side slices of n3 columns; every distinct matrix is streamed once
+        self._madds = sum(int(r[6]) * self.n_grid * int(r[3]) for r in groups if index.get(int(r[0]), -1) >= 0)
+        self._mat_bytes = sum(a.nbytes for a in fw)
+        self._pairs = 0
 
     def set_pairs(self, pair_g, pair_c, pair_mode, parity):
         """second right-hand-side set per group served by the same matrices (ddh_grouped_mmt_set_pairs)"""
         a = [np.ascontiguousarray(v, dtype=np.int32) for v in (pair_g, pair_c, pair_mode, parity)]
         libhip.call("ddh_grouped_mmt_set_pairs", self.handle, len(a[0]), *[libhip.as_ip(v) for v in a])
+        self._pairs = int(np.count_nonzero(np.asarray(pair_g) >= 0))
+
+    def _cost(self, name, g, c):
+        n0, n3 = int(g.shape[0]), int(g.shape[3])
+        madds = self._madds * (2 if self._pairs else 1) * n0 * n3          # (a paired group serves two right-hand-side sets)
+        libhip.note_cost(name, 2.0 * madds, self._mat_bytes + (g.numel() + c.numel()) * 8)
 
     def _dims(self, g, c):
         n0, n1g, nt, n3 = [int(x) for x in g.shape]
@@ -405,9 +416,11 @@ class GroupedMmt:
         return n0, n1g, n1c, n2c, n3
 
     def forward(self, g, c):
+        self._cost("ddh_grouped_mmt_forward", g, c)
         libhip.call("ddh_grouped_mmt_forward", self.handle, ptr(g), ptr(c), *self._dims(g, c), self.ex.dev.stream)
 
     def backward(self, c, g):
+        self._cost("ddh_grouped_mmt_backward", g, c)
         libhip.call("ddh_grouped_mmt_backward", self.handle, ptr(c), ptr(g), *self._dims(g, c), self.ex.dev.stream)
 
 
@@ -465,10 +478,17 @@ class EllTerms:
         self.handle = C.c_uint64(0)
         libhip.call("ddh_ell_terms_create", C.byref(self.handle), int(nm), int(nl), int(nr), int(ncomp_out), len(terms),
                     libhip.as_ip(co), libhip.as_ip(ci), nmat, libhip.as_dp(mats), libhip.as_ip(sm))
+        # algorithmic work of one application: every non-zero of A[mat] times the slots that use that matrix
+        uses = np.bincount(sm[sm >= 0].ravel(), minlength=nmat)[:nmat] if nmat else np.zeros(0)
+        nnz = np.count_nonzero(mats.reshape(mats.shape[0], nmat, -1), axis=2).sum(axis=0) if terms else np.zeros(nmat)
+        self._madds = float(np.dot(nnz, uses))
+        self._mat_bytes = float(np.count_nonzero(mats)) * 8
 
     def apply(self, x, y):
+        libhip.note_cost("ddh_ell_terms_apply", 2.0 * self._madds, self._mat_bytes + (x.numel() + y.numel()) * 8)
         libhip.call("ddh_ell_terms_apply", self.handle, ptr(x), ptr(y), self.ex.dev.stream)
         if self.dense_part is not None:
+            libhip.note_cost("ddh_ell_terms_apply_acc", 2.0 * self.dense_part._madds, self.dense_part._mat_bytes + (x.numel() + y.numel()) * 8)
             libhip.call("ddh_ell_terms_apply_acc", self.dense_part.handle, ptr(x), ptr(y), 1, self.ex.dev.stream)
 
     def __del__(self):
@@ -531,8 +551,17 @@ class DenseEllTerms:
         libhip.call("ddh_ell_terms_mats", self.handle, C.byref(dst))
         libhip.call("ddh_ell_blocks_from_dense", ptr(flat), dst, self.nl, self.ncomp, self.nr, self.ex.dev.stream)
         libhip.call("ddh_ell_terms_prune", self.handle, self.ex.dev.stream)
+        self._blocks = None
+        if libhip.cost_log is not None:          # (measurement runs only) blocks that survive the pruning
+            nz = (flat.reshape(self.nl, self.ncomp, self.nr, self.ncomp, self.nr) != 0).any(dim=4).any(dim=2).any(dim=0)
+            self._blocks = int(nz.sum().item())
 
     def apply(self, x, y):
+        if libhip.cost_log is not None:
+            blocks = self._blocks if self._blocks is not None else self.ncomp * self.ncomp
+            slots = sum(2 * (min(l, x.shape[1] // 2 - 1) + 1) for l in range(self.nl))      # (m, part) slots with m <= ell
+            libhip.note_cost("ddh_ell_terms_apply", 2.0 * blocks * self.nr * self.nr * slots,
+                             blocks * self.nl * self.nr * self.nr * 8 + (x.numel() + y.numel()) * 8)
         libhip.call("ddh_ell_terms_apply", self.handle, ptr(x), ptr(y), self.ex.dev.stream)
 
     def __del__(self):
@@ -557,6 +586,7 @@ class CgemvBatch:
                     libhip.as_dp(flat.view(np.float64)) if flat.size else None)
 
     def apply(self, x, y):
+        libhip.note_cost("ddh_cgemv_batch_apply", 8.0 * self.nbytes / 16, self.nbytes + (x.numel() + y.numel()) * 8)
         libhip.call("ddh_cgemv_batch_apply", self.handle, ptr(x), ptr(y), self.ex.dev.stream)
 
     def __del__(self):

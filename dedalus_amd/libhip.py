@@ -179,9 +179,24 @@ def check(status, what=""):
         raise DdhError("%s failed (status %d): %s" % (what or "libdedalus_hip call", status, msg))
 
 
+# Optional measurement hooks (tools/bench_configs.py): `profiler(name, fn, args) -> status` wraps every entry point
+# (HIP events per call), `cost_log(name, flops, bytes)` receives the ALGORITHMIC work a wrapper hands to an entry point
+# (dedalus_amd/executor.py::note_cost).  Both are None in ordinary runs: one attribute test per call.
+profiler = None
+cost_log = None
+
+
 def call(name, *args):
     lib = load()
+    if profiler is not None:
+        check(profiler(name, getattr(lib, name), args), name)
+        return
     check(getattr(lib, name)(*args), name)
+
+
+def note_cost(name, flops, nbytes):
+    if cost_log is not None:
+        cost_log(name, float(flops), float(nbytes))
 
 
 def as_dp(a):

@@ -227,8 +227,33 @@ def config_explicit(N=16):
     print("wrote", path, os.path.getsize(path) >> 10, "KiB")
 
 
+def config_shell_explicit(shape=(32, 16, 16)):
+    """The explicit half of a shell-convection step -- F_b = -u.grad(b), F_u = -u.grad(u) in the equations' bases,
+    evaluated by the unmodified reference's solver (evaluate_group("F"), core/solvers.py:683-711 -> operators.py:3136-3175,
+    basis.py:4474-4508) -- for the band-limited state of tests/problems.py::shell_band_limited_state at a SMALL shell.
+    The table {(equation, component, m, part, ell, n): value}, labelled with the reference's own group arrays, holds the
+    coefficients of the same functions at ANY resolution: tests/explicit_check.py::check_shell compares this package's
+    evaluation at ShellBasis(256, 128, 128) with it (every other mode must vanish)."""
+    import problems
+    d3 = refshim.load_reference()
+
+    def labels(F):
+        g = F.dist.coeff_layout.local_group_arrays(F.domain, scales=1)
+        return tuple(np.ma.filled(a, -1) for a in g)
+
+    tab = problems.shell_explicit_results(d3, shape, labels)
+    keys = np.array(sorted(tab), dtype=np.int64)
+    vals = np.array([tab[tuple(k)] for k in keys])
+    print("shell explicit half at", shape, ":", len(keys), "modes; max ell", int(keys[:, 4].max()), "max n", int(keys[:, 5].max()))
+    path = os.path.join(GOLD, "config_shell_explicit.npz")
+    np.savez_compressed(path, shape=np.array(shape), keys=keys, values=vals)
+    print("wrote", path, os.path.getsize(path) >> 10, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sphere", "shell", "cartesian", "explicit"]
+    which = sys.argv[1:] or ["sphere", "shell", "cartesian", "explicit", "shell_explicit"]
+    if "shell_explicit" in which:
+        config_shell_explicit()
     if "cartesian" in which:
         config_cartesian()
     if "sphere" in which:

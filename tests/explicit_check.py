@@ -43,3 +43,43 @@ def check(solver, fields, tol=1e-13):
         worst = max(worst, err)
         assert err < tol, ("equation %d" % i, err, Ns)
     return worst
+
+
+SHELL_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_shell_explicit.npz")
+
+
+def shell_labels(F):
+    """(m, ell, n) of every element of a shell field's coefficient array in this package's user layout (the reference's
+    packed layout: SphereBasis.packed_groups restates core/basis.py:2868-2889)."""
+    m, ell = F.basis.sphere.packed_groups()
+    Nr = np.asarray(F["c"]).shape[-1]
+    shp = m.shape + (Nr,)
+    return (np.broadcast_to(m[:, :, None], shp), np.broadcast_to(ell[:, :, None], shp),
+            np.broadcast_to(np.arange(Nr)[None, None, :], shp))
+
+
+def check_shell(d3, shape, dist_kw=None, tol=1e-12):
+    """The explicit half of a shell-convection step at `shape` against the reference's table for the band-limited state
+    (oracle/make_golden_config.py::config_shell_explicit): every listed mode within tol of the largest coefficient of its
+    equation, every unlisted mode below tol."""
+    import problems
+    gold = np.load(SHELL_GOLD)
+    ref = {tuple(int(v) for v in k): float(x) for k, x in zip(gold["keys"], gold["values"])}
+    tab = problems.shell_explicit_results(d3, shape, shell_labels, dist_kw=dist_kw)
+    mine_eqs = {k[0] for k in tab}
+    scale = {}
+    for k, v in ref.items():
+        scale[k[0]] = max(scale.get(k[0], 0.0), abs(v))
+    worst, checked = 0.0, 0
+    for k, v in ref.items():
+        if k[0] not in mine_eqs:
+            continue                                  # (a constant right-hand side: a number here, not an expression)
+        err = abs(tab.get(k, 0.0) - v) / scale[k[0]]
+        worst = max(worst, err)
+        checked += 1
+        assert err < tol, (k, tab.get(k), v)
+    for k, v in tab.items():
+        if k not in ref:
+            assert abs(v) < tol * scale.get(k[0], 1.0), ("mode absent from the reference's table", k, v)
+    assert checked > 100 and {1, 2} <= mine_eqs
+    return worst

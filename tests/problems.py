@@ -449,6 +449,61 @@ def shell_convection(d3, shape=(16, 12, 8), timestepper="SBDF2", dist_kw=None):
     return solver, dict(p=p, b=b, u=u, tau_p=tau_p, tau_b1=tau_b1, tau_b2=tau_b2, tau_u1=tau_u1, tau_u2=tau_u2)
 
 
+def shell_band_limited_state(fields, grids):
+    """A state of few modes for the shell-convection problem, the same FUNCTION at any resolution: Cartesian polynomials
+    restricted to the shell (angular degree <= 3, polynomial in r), the velocity given through its spherical components.
+    The explicit right-hand sides -u.grad(b), -u.grad(u) of such a state populate a handful of low (m, ell, n) modes whose
+    coefficients do not depend on the number of modes carried (radial dependence of the 1/r factors: resolved to round-off
+    by ~12 radial modes in the example's thin shell, radii 14 .. 15)."""
+    phi, theta, r = grids
+    st, ct, sp, cp = np.sin(theta), np.cos(theta), np.sin(phi), np.cos(phi)
+    x, y, z = r * st * cp, r * st * sp, r * ct + 0 * phi
+    s = 1.0 / 15.0                                      # (coordinates are O(15) in the example's shell: keep values O(1))
+    x, y, z = s * x, s * y, s * z
+    fields["b"]["g"] = 0.4 + 0.3 * x * y + 0.2 * z * z * x - 0.5 * y + 0.1 * x * x * z
+    U = (0.5 * y * z - 0.2 * x, -0.4 * x * z + 0.3 * y * y, 0.25 * x * y + 0.1 * z)          # Cartesian components
+    e_phi = (-sp + 0 * theta, cp + 0 * theta, 0 * phi + 0 * theta)
+    e_theta = (ct * cp, ct * sp, -st + 0 * phi)
+    e_r = (st * cp, st * sp, ct + 0 * phi)
+    u = fields["u"]
+    ug = np.zeros((3,) + np.broadcast(phi, theta, r).shape)
+    for c, e in enumerate((e_phi, e_theta, e_r)):
+        ug[c] = sum(U[k] * e[k] for k in range(3))
+    u["g"] = ug
+
+
+def shell_explicit_results(d3, shape, labels, dist_kw=None):
+    """F of the shell-convection problem (the explicit half of a step: -u.grad(b), -u.grad(u), boundary constants) for the
+    band-limited state above, evaluated through the SOLVER's right-hand-side path, as a resolution-independent table
+    {(equation, component, m, part, ell, n): value} of the coefficients above 1e-13 of the largest.
+    labels(field) -> (m, ell, n) integer arrays of the field's coefficient layout (the reference's
+    local_group_arrays; this package's packed_groups)."""
+    solver, f = shell_convection(d3, shape=shape, timestepper="SBDF2", dist_kw=dist_kw)
+    b = f["b"]
+    basis = b.domain.bases[0] if hasattr(b, "domain") else b.basis
+    shell_band_limited_state(f, b.dist.local_grids(basis))
+    if hasattr(solver, "evaluator") and hasattr(solver, "F") and not hasattr(solver, "evaluate_F"):
+        solver.evaluator.evaluate_group("F", iteration=0, wall_time=0.0, sim_time=0.0, timestep=1.0)      # the reference
+        Fs = list(solver.F)
+    else:
+        Fs = [(eq["F"].evaluate() if hasattr(eq["F"], "evaluate") else None) for eq in solver.problem.equations]
+    table = {}
+    for i, F in enumerate(Fs):
+        if F is None or isinstance(F, (int, float)):
+            continue
+        c = np.array(F["c"])
+        if c.size == 0 or not np.abs(c).max() > 0:
+            continue
+        m, ell, n = labels(F)
+        c = c.reshape((-1,) + c.shape[-3:])
+        scale = np.abs(c).max()
+        for idx in zip(*np.nonzero(np.abs(c) > 1e-13 * scale)):
+            comp, a, b_, k = (int(v) for v in idx)
+            key = (i, comp, int(m[a, b_, k]), a % 2, int(ell[a, b_, k]), int(n[a, b_, k]))
+            table[key] = float(c[idx])
+    return table
+
+
 def run_shell_convection(d3, steps=4, dt=0.05, **kw):
     solver, fields = shell_convection(d3, **kw)
     for _ in range(steps):

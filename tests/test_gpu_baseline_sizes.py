@@ -161,3 +161,16 @@ def test_explicit_half_against_the_reference_at_full_size(shape, tol):
     if shape[0] == 512:
         assert solver.F_direct is not None      # the fused path with direct F writes is what ran
     print("explicit half %s: max error / max |F| = %.2e" % (shape, worst))
+
+
+def test_shell_explicit_half_against_the_reference_at_config_size():
+    """BASELINE config 5 at its size, ShellBasis(256, 128, 128): the explicit half of a convection step -- backward radial /
+    colatitude / azimuth transforms of u and b, the operator term lists of grad, the grid products u.grad(b), u.grad(u),
+    forward transforms into the equations' bases -- against the table the UNMODIFIED reference produces for the same
+    band-limited functions at a small shell (tests/golden/config_shell_explicit.npz, oracle/make_golden_config.py):
+    every populated (m, ell, n) mode equal, every other mode empty."""
+    import dedalus_amd.public as d3
+    import explicit_check
+    worst = explicit_check.check_shell(d3, (256, 128, 128), tol=1e-11)
+    print("shell explicit half at 256 x 128 x 128: max error", worst)
+    assert worst < 1e-11

@@ -95,7 +95,125 @@ def run_shell(name, kw, dt, warm, steps):
         refactor_time(name, solver, dt, el / steps)
 
 
+# ---- --json: steps/s + where the step goes + roofline of the dominant entry point, per secondary configuration -------------
+FP64_MFMA_PEAK_TFLOPS = 78.6        # MI355X FP64 matrix peak (AMD spec; v_mfma_f64_16x16x4: 256 flop / clk / CU at 2.4 GHz)
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured copy)
+
+
+class EventProfiler:
+    """libhip.profiler: HIP events around every C-ABI entry point (torch's current stream = the library's launch stream)."""
+
+    def __init__(self, torch):
+        self.torch, self.rec = torch, {}
+
+    def __call__(self, name, fn, args):
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        e0.record()
+        st = fn(*args)
+        e1.record()
+        self.rec.setdefault(name, []).append((e0, e1))
+        return st
+
+    def summary(self):
+        self.torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.rec.items()}
+
+
+def measure_json(tag, make, step, warm, steps, repeats=3):
+    """make() -> solver; step(solver) advances one timestep.  Clean timing first (median of `repeats`), then one more pass
+    with the entry-point profiler and the wrappers' algorithmic cost notes attached."""
+    import json
+    import torch
+    from dedalus_amd import libhip
+    from dedalus_amd.executor import KernelTimer
+    solver = make()
+    for _ in range(warm):
+        step(solver)
+    rates = []
+    for _ in range(repeats):
+        solver.ex.sync()
+        t0 = time.time()
+        for _ in range(steps):
+            step(solver)
+        solver.ex.sync()
+        rates.append(steps / (time.time() - t0))
+    prof, costs = EventProfiler(torch), {}
+
+    def cost_log(name, flops, nbytes):
+        c = costs.setdefault(name, [0.0, 0.0])
+        c[0] += flops
+        c[1] += nbytes
+    libhip.profiler, libhip.cost_log = prof, cost_log
+    timer = KernelTimer(torch)
+    solver.ex.timer = timer                         # (Cartesian executors: algorithmic bytes per kernel family)
+    try:
+        for _ in range(steps):
+            step(solver)
+        ents = prof.summary()
+        fam = timer.summary()
+    finally:
+        libhip.profiler = libhip.cost_log = None
+        solver.ex.timer = None
+    table = {}
+    for name, (n, ms) in sorted(ents.items(), key=lambda kv: -kv[1][1]):
+        if ms / steps < 1e-3:
+            continue
+        row = dict(launches_per_step=n / steps, ms_per_step=ms / steps, ms_per_launch=ms / n)
+        if name in costs and n:
+            fl, by = costs[name][0] / n, costs[name][1] / n
+            row.update(algorithmic_GFLOP_per_launch=fl / 1e9, algorithmic_GB_per_launch=by / 1e9)
+            sec = ms / n / 1e3
+            if by > 0 and fl / by >= FP64_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+                row.update(bound="mfma", achieved=fl / sec / 1e12, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s")
+            elif by > 0:
+                row.update(bound="hbm", achieved=by / sec / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+            if "achieved" in row:
+                row["frac"] = row["achieved"] / row["peak"]
+        table[name] = row
+    out = dict(config=tag, steps_per_s=float(np.median(rates)), ms_per_step=1e3 / float(np.median(rates)),
+               repeats=rates, steps=steps, launches_per_step=sum(n for n, _ in ents.values()) / steps,
+               entry_point_ms_per_step=sum(ms for _, ms in ents.values()) / steps, entry_points=table)
+    if fam:
+        out["kernel_families"] = {k: dict(launches_per_step=v["launches"] / steps, ms_per_launch=v["avg_ms"],
+                                          algorithmic_GB_per_launch=v["bytes_per_launch"] / 1e9, GBps=v["gbps"],
+                                          frac_of_hbm_peak=v["gbps"] / HBM_PEAK_GBS) for k, v in fam.items()}
+    rated = [(k, v) for k, v in table.items() if "frac" in v]
+    if rated:
+        k, v = max(rated, key=lambda kv: kv[1]["ms_per_step"])
+        out["dominant"] = dict(entry_point=k, **v)
+        out["roofline"] = dict(bound=v["bound"], kernel=k, achieved=v["achieved"], peak=v["peak"], unit=v["unit"], frac=v["frac"])
+    elif fam:
+        k, v = max(fam.items(), key=lambda kv: kv[1]["total_ms"])
+        out["roofline"] = dict(bound="hbm", kernel=k, achieved=v["gbps"], peak=HBM_PEAK_GBS, unit="GB/s", frac=v["gbps"] / HBM_PEAK_GBS)
+    print(json.dumps(out), flush=True)
+    return out
+
+
+def all_json():
+    def k_make():
+        return problems.kdv_burgers(d3, Nx=1024, timestepper="SBDF2")[0]
+    measure_json("K kdv_burgers N=1024 SBDF2", k_make, lambda s: s.step(2e-3), 20, 200)
+
+    def r2_make():
+        return problems.rayleigh_benard_2d(d3, Nx=512, Nz=256)[0]
+    measure_json("R2 rayleigh_benard 2-D 512x256 RK222", r2_make, lambda s: s.step(1e-3), 5, 100)
+    sw = {}
+
+    def s_make():
+        solver, f, extra = problems.shallow_water(d3, Nphi=512, Ntheta=256)
+        sw["dt"] = extra["timestep"]
+        return solver
+    measure_json("S shallow_water SphereBasis(512,256) RK222", s_make, lambda s: s.step(sw["dt"]), 5, 50)
+
+    def h_make():
+        return problems.shell_convection(d3, shape=(256, 128, 128), timestepper="SBDF2")[0]
+    measure_json("H shell_convection ShellBasis(256,128,128) SBDF2", h_make, lambda s: s.step(0.05), 3, 10)
+
+
 if __name__ == "__main__":
+    if "--json" in sys.argv[1:]:
+        all_json()
+        sys.exit(0)
     if "shell" in sys.argv[1:]:
         shape = tuple(int(x) for x in os.environ.get("SHELL_SHAPE", "256,128,128").split(","))
         run_shell("H  shell convection %dx%dx%d SBDF2" % shape, dict(shape=shape, timestepper="SBDF2"), 0.05, 3, 10)

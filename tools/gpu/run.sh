@@ -27,7 +27,7 @@ for step in "$@"; do
     bench-nosplit) DDH_NO_SPLIT=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_nosplit.json 2> $OUT/bench_nosplit.err; bench_line $OUT/bench_nosplit.json ;;
     bench-cfl)  python bench.py --steps 10 --warmup 3 --cfl --no-cpu-baseline > $OUT/bench_cfl.json 2> $OUT/bench_cfl.err; bench_line $OUT/bench_cfl.json ;;
     profile)    bash tools/profile_round.sh $TAG > $OUT/profile.log 2>&1; tail -3 $OUT/profile.log ;;
-    configs)    python tools/bench_configs.py all --json > $OUT/configs.json 2> $OUT/configs.err; tail -5 $OUT/configs.json ;;
+    configs)    python tools/bench_configs.py --json > $OUT/configs.json 2> $OUT/configs.err; tail -5 $OUT/configs.json ;;
     shares)     # per-rank shares of the strong-scaled problem on one GPU, sweep variants A/B (profiles/*_strong_scaling_shares.txt)
                 for sz in 256,512,256 128,512,256 64,512,256; do
                   for var in "default:" "per-thread:DDH_SOLVE_COOP=0" "per-thread-unsplit:DDH_SOLVE_COOP=0 DDH_SPLIT_THREADS=0" "coop-fwd+cb4:DDH_COOP_FWD=1 DDH_COOP_CB=4" "cb4:DDH_COOP_FWD=0 DDH_COOP_CB=4"; do
