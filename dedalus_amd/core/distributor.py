@@ -396,7 +396,9 @@ class Transformer:
             return
         self.backward_steps(domain, ncomp, c, scales, 0, n, dst=g)
 
-    def forward_data(self, domain, ncomp, g, scales, c, skip_last=False):
+    def forward_data(self, domain, ncomp, g, scales, c, skip_last=False, tiled_row=0):
+        """tiled_row: the coefficient rows (the last transform's output, `c`) are written tile-major, rows of
+        nx * tiled_row doubles (Executor.transform; only where `tiled_forward_ok` said so)."""
         ex = self.dist.executor
         steps = self._steps(domain, scales)
         shape = [ncomp] + list(domain.storage_grid_shape(scales))
@@ -438,6 +440,10 @@ class Transformer:
             outer = int(np.prod(shape[:pos + 1]))
             inner = int(np.prod(shape[pos + 2:]))
             shape[pos + 1] = b.coeff_size
-            dst = c if i == len(rsteps) - 1 else ex.empty(tuple(shape))
-            ex.transform(spec, b, "forward", src, dst, outer, inner)
+            last = i == len(rsteps) - 1
+            dst = c if last else ex.empty(tuple(shape))
+            if last and tiled_row:
+                ex.transform(spec, b, "forward", src, dst, outer, inner, tiled_row=tiled_row)
+            else:
+                ex.transform(spec, b, "forward", src, dst, outer, inner)
             src = dst

@@ -585,6 +585,7 @@ class SolverBase:
             if self.eq_T is not None:                    # (boundary rows: the equivalent combinations, eq_T)
                 total = (self.eq_T @ total.reshape(self.R, -1)).reshape(total.shape)
             nz = np.flatnonzero(total)
+            self._F_const_index = nz
             self.F_const = self.ex.make_scatter(nz, total.reshape(-1)[nz]) if nz.size else None
             self._F_const_rows = np.unique(nz // (nx * ny))
 
@@ -650,13 +651,15 @@ class SolverBase:
         self.F_direct = plan
         self._F_zeroed = set()
 
-    def evaluate_F(self, out, persistent=False):
+    def evaluate_F(self, out, persistent=False, tiled_row=0):
         """F system vector for the current state (coefficient space, equation bases).
         persistent: `out` is a buffer the caller owns for the life of the solver and nothing else writes to (the
         timesteppers' F arrays): rows without right-hand-side terms are then zeroed once.  Any other buffer -- a temporary
         whose address the allocator may hand out again after unrelated data lived there -- is zeroed on every call."""
         ev, ex = self.evaluator_core, self.ex
         ev.new_pass()
+        if tiled_row and self.F_direct is None:
+            raise RuntimeError("tile-major right-hand sides need the direct-F plan")
         if self.F_direct is not None:
             tr = self.dist.transformer
             key = (out.data_ptr() if hasattr(out, "data_ptr") else id(out))
@@ -674,11 +677,11 @@ class SolverBase:
                     edom = einfo["eq"]["domain"]
                     dst = out[einfo["row0"]:einfo["row0"] + einfo["rows"]].reshape(
                         (leaf.ncomp,) + tuple(edom.storage_coeff_shape()))
-                    tr.forward_data(edom, leaf.ncomp, pg, edom.dealias, dst, skip_last=True)
+                    tr.forward_data(edom, leaf.ncomp, pg, edom.dealias, dst, skip_last=True, tiled_row=tiled_row)
             ev.new_pass()
             if self.F_const is not None:
-                ex.scatter_set(out, self.F_const)
-            return
+                ex.scatter_set(out, self.F_const)       # (entries of the kx = ky = 0 cos-cos mode: offset 0 of a row in
+            return                                       #  the natural and in the tile-major layout alike)
         parts = []
 
         def target():
@@ -751,6 +754,42 @@ class SolverBase:
         for info in self.var_info:
             info["field"].require_coeff_space()
         self.push_unaliased()
+
+    def rhs_tiling(self, lu):
+        """Row length ny when the solver-internal right-hand-side vectors (the timestepper's M.X and F buffers) can use
+        the TILE-MAJOR layout [kx/8][ky/8][kx%8][ky%8] the sweeps read contiguously (ddh_pencil_solve_recombined_tiled,
+        include/dedalus_hip.h), else 0.  Needs: two Fourier axes with sizes that are multiples of 8, right-hand sides
+        written by the forward transforms themselves (direct F) through the strided-axis wave kernel, the window-form M.X
+        product, the lean forward sweep for this factorization.  DDH_NO_RHS_TILING=1 switches it off (A/B)."""
+        if getattr(self, "_rhs_tiling", None) is not None:
+            return self._rhs_tiling
+        self._rhs_tiling = 0
+        ex = self.ex
+        if (os.environ.get("DDH_NO_RHS_TILING") is not None or not getattr(self.pack, "supports_tiled_rhs", False)
+                or self.nf != 2 or self.nx % 8 or self.ny % 8 or self.F_direct is None or self.P_id is None
+                or self.real_grading is None or self.nx * self.ny < 4 * 16384 or not hasattr(ex, "tiled_forward_ok")):
+            return 0
+        if self.F_const is not None and np.any(np.asarray(self._F_const_index) % (self.nx * self.ny) != 0):
+            return 0
+        tr = self.dist.transformer
+        for einfo, _scale in self.F_direct.values():
+            edom = einfo["eq"]["domain"]
+            pos, b, spec = tr._steps(edom, edom.dealias)[0]
+            if pos != 0 or not ex.tiled_forward_ok(spec, b, self.nx * self.ny, self.ny):
+                return 0
+        info = self.pack.lu_info(lu)
+        if info["forward"] != "lean" or not info["real"]:
+            return 0
+        self._rhs_tiling = int(self.ny)
+        return self._rhs_tiling
+
+    def untile_rows(self, vec):
+        """Natural-layout copy [R][nx][ny] of a tile-major system vector (diagnostics / parity probes only)."""
+        R, nx, ny = self.R, self.nx, self.ny
+        v = vec.reshape(R, nx // 8, ny // 8, 8, 8)
+        if hasattr(v, "permute"):
+            return v.permute(0, 1, 3, 2, 4).contiguous().reshape(R, nx, ny)
+        return np.ascontiguousarray(np.transpose(v, (0, 1, 3, 2, 4))).reshape(R, nx, ny)
 
     def solve(self, lu, rhs, out):
         """out = (a M + b L)^-1 rhs  through the recombined band factorization: X = P Y."""
@@ -846,10 +885,12 @@ class SolverBase:
             self._skiprows = self._device_mask(mask)
         return self._skiprows
 
-    def solve_lincomb(self, lu, xs, alphas, out, zero_rows=None, skip_rows=None):
+    def solve_lincomb(self, lu, xs, alphas, out, zero_rows=None, skip_rows=None, tiled=False):
         """out = (a M + b L)^-1 (sum_t alphas[t] xs[t]).  The combination is formed inside the forward sweep of the band
         solve; with a parity probe attached (or more terms than the kernel takes) it is materialised first."""
         probe = getattr(self, "solve_probe", None)
+        if tiled and (self.P_id is None or not hasattr(self.pack, "solve_recombined") or len(xs) > self.pack.MAX_RHS_TERMS):
+            raise RuntimeError("tile-major right-hand sides need the fused recombined solve")
         if len(xs) > self.pack.MAX_RHS_TERMS or not hasattr(self.pack, "solve_lincomb"):
             rhs = self.ex.empty((self.R, self.nx, self.ny))
             self.ex.lincomb(rhs, xs, alphas)
@@ -862,13 +903,19 @@ class SolverBase:
             # so a mask that hid a non-zero row would show up as a residual.  (`out` may alias a term: formed first.)
             rhs_rec = self.ex.empty((self.R, self.nx, self.ny))
             self.ex.lincomb(rhs_rec, xs, alphas)
+            if tiled:
+                rhs_rec = self.untile_rows(rhs_rec)          # (the record and the tests' re-solves use the natural layout)
             self._last_rhs = rhs_rec
         path = "ddh_pencil_solve_lincomb"
         if self.P_id is None:
             self.pack.solve_lincomb(lu, xs, alphas, out)
         elif hasattr(self.pack, "solve_recombined"):
             Y = self.ex.empty((self.R, self.nx, self.ny))
-            if zero_rows is not None or skip_rows is not None:
+            if tiled:
+                self.pack.solve_recombined(lu, xs, alphas, self.P_id, Y, out, zero_rows=zero_rows, skip_rows=skip_rows,
+                                           tiled=True)
+                path = "ddh_pencil_solve_recombined_tiled"
+            elif zero_rows is not None or skip_rows is not None:
                 self.pack.solve_recombined(lu, xs, alphas, self.P_id, Y, out, zero_rows=zero_rows, skip_rows=skip_rows)
                 path = "ddh_pencil_solve_recombined_sparse"
             else:

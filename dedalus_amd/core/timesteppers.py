@@ -82,10 +82,12 @@ class _SolveMixin:
             self._RHS = s.ex.zeros((s.R, s.nx, s.ny))
         return self._RHS
 
-    def _solve_combination(self, xs, al, lu, zero_rows=None, skip_rows=None):
+    def _solve_combination(self, xs, al, lu, zero_rows=None, skip_rows=None, tiled=False):
         s = self.solver
         if hasattr(s, "solve_lincomb"):
-            if zero_rows is not None or skip_rows is not None:
+            if tiled:
+                s.solve_lincomb(lu, xs, al, s.X, zero_rows=zero_rows, skip_rows=skip_rows, tiled=True)
+            elif zero_rows is not None or skip_rows is not None:
                 s.solve_lincomb(lu, xs, al, s.X, zero_rows=zero_rows, skip_rows=skip_rows)
             else:
                 s.solve_lincomb(lu, xs, al, s.X)
@@ -336,6 +338,15 @@ class RungeKuttaIMEX(_SolveMixin):
         t0 = s.sim_time
         s.sync_state_to_device()
         own = dict(owned=True) if getattr(pack, "supports_zero_rows", False) else {}
+        # the M.X and F buffers of this timestepper in the tile-major layout the sweeps read contiguously (decided once,
+        # after the first factorization, while the buffers still hold zeros; SolverBase.rhs_tiling)
+        if getattr(self, "_tiled", None) is None:
+            self._tiled = 0
+            if own and not self._direct and not any(v is not None for v in self.LX) and hasattr(s, "rhs_tiling"):
+                self._tiled = s.rhs_tiling(next(iter(self._lus.values())))
+        tiled = self._tiled
+        if tiled:
+            own = dict(owned=True, tiled=True)
         pack.matvec(s.M_id, s.X, self.MX0, **own)
         combs = {}
         for i in range(1, self.stages + 1):
@@ -345,7 +356,10 @@ class RungeKuttaIMEX(_SolveMixin):
                     pack.matvec(s.L_id, s.X, self.LX[j])
                 else:
                     pack.matvec(s.M_id, s.X, self.MX[j], **own)
-            s.evaluate_F(self.F[i - 1], persistent=True)
+            if tiled:
+                s.evaluate_F(self.F[i - 1], persistent=True, tiled_row=tiled)
+            else:
+                s.evaluate_F(self.F[i - 1], persistent=True)
             # RHS_i as a combination of the stored vectors.  RHS_j of an earlier stage is itself such a combination
             # (it is not kept): -k H_ij L.X_j = -(H_ij / H_jj) (RHS_j - M.X_j) expands into MX0, F_*, MX_* terms.
             comb = {("MX0",): 1.0}
@@ -373,7 +387,7 @@ class RungeKuttaIMEX(_SolveMixin):
             skip = None
             if i < self.stages and not self._direct and hasattr(s, "intermediate_skip_rows"):
                 skip = s.intermediate_skip_rows()
-            self._solve_combination(xs, al, self._lus[float(H[i, i])], zero_rows=zrows, skip_rows=skip)
+            self._solve_combination(xs, al, self._lus[float(H[i, i])], zero_rows=zrows, skip_rows=skip, tiled=bool(tiled))
             s.mark_state_current()
             s.sim_time = t0 + k * c[i]
 

@@ -1192,6 +1192,8 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
         const int wst = wave_axis_try(MODE, d, src, dst, outer, inner, dst2, dvec, dscale, dscale2, as_stream(stream));
         if (wst <= 0) return wst;
     }
+    if (d.ctile_nseg) return fail("cheb_forward_tiled: only the wave-per-four-pairs kernel (N = 384, M = 256, strided axis) "
+                                  "writes the tile-major coefficient layout");
     long npairs;
     if (is_cfft)
         npairs = inner_mode ? inner : outer;
@@ -1438,6 +1440,20 @@ int ddh_cheb_backward_dual(ddh_handle plan, const double *c, double *g, double *
     return launch<CHEB_BWD>(pl, c, g, outer, inner, stream, 0.0, g_deriv, 0.0, dvec);
 }
 DDH_FFT_ENTRY(ddh_cheb_forward, K_CHEB, CHEB_FWD)
+int ddh_cheb_forward_tiled(ddh_handle plan, const double *g, double *c, long outer, long inner, long row_len, void *stream) {
+    FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
+    if (!pl) return -1;
+    if (pl->tkind != K_CHEB) return fail("ddh_cheb_forward_tiled: plan is of a different transform kind");
+    if (row_len < 8 || (row_len & 7) || inner % row_len || (inner / row_len) % 8)
+        return fail("ddh_cheb_forward_tiled: inner = nx * ny with nx and ny = row_len multiples of 8");
+    if (g == c) return fail("ddh_cheb_forward_tiled: in-place unsupported");
+    if (outer <= 0 || inner <= 0) return 0;
+    const unsigned saved = pl->dev.ctile_nseg;
+    pl->dev.ctile_nseg = (unsigned)(row_len / 8);
+    const int st = launch<CHEB_FWD>(pl, g, c, outer, inner, stream);
+    pl->dev.ctile_nseg = saved;
+    return st;
+}
 DDH_FFT_ENTRY(ddh_cheb_backward, K_CHEB, CHEB_BWD)
 DDH_FFT_ENTRY(ddh_cfft_forward, K_CFFT, CFFT_FWD)
 DDH_FFT_ENTRY(ddh_cfft_backward, K_CFFT, CFFT_BWD)

@@ -78,7 +78,12 @@ wave_cheb_kernel(FftDev p, WaveArgs a) {
         unsigned o, tb;
         a.fd_tpo.divmod(tile, o, tb);
         const long pair0 = 4L * tb;
-        off_c = ((long)o * M) * inner + 2 * pair0;
+        long seg = tb;                       // 64-byte segment of the coefficient row [nx][ny] ...
+        if (FWD && p.ctile_nseg) {           // ... tile-major: [kx / 8][ky / 8][kx % 8] (ddh_cheb_forward_tiled, tile_offset)
+            const unsigned kxrow = tb / p.ctile_nseg, sg = tb - kxrow * p.ctile_nseg;
+            seg = ((long)(kxrow >> 3) * p.ctile_nseg + sg) * 8 + (kxrow & 7);
+        }
+        off_c = ((long)o * M) * inner + 8 * seg;
         off_g = ((long)o * N) * inner + 2 * pair0;
         valid = pair0 + L.p < a.npairs;
     };
@@ -202,6 +207,7 @@ int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, lon
     static const int env_tpw = getenv("DDH_FFT_TPW") ? atoi(getenv("DDH_FFT_TPW")) : 0;
     static const int env_wsync = getenv("DDH_FFT_WSYNC") ? atoi(getenv("DDH_FFT_WSYNC")) : -1;
     if (d.dbg || d.prof) return 1;
+    if (d.ctile_nseg && (mode != CHEB_FWD || inner % (8L * d.ctile_nseg) || (inner / (8L * d.ctile_nseg)) % 8)) return 1;
     const bool cheb = (mode == CHEB_FWD || mode == CHEB_BWD), rfft = (mode == RFFT_FWD || mode == RFFT_BWD);
     if (!cheb && !rfft) return 1;
     if ((cheb && !(mask & 1)) || (rfft && !(mask & 2))) return 1;

@@ -390,6 +390,16 @@ __device__ __forceinline__ bool axes_valid(unsigned char bits, const CellCtx &c,
     return true;
 }
 
+// Tile-major layout of a row [nx][ny] of a system vector (two Fourier axes; nx, ny multiples of 8): the 64-byte segments
+// (one storage row kx, four cells = 8 doubles along ky) of a tile of 4 x 4 cells -- 8 storage rows x 1 segment -- are
+// contiguous: [kx / 8][ky / 8][kx % 8][ky % 8].  The sweeps give a wavefront the cells of one tile and of its transposed
+// partner tile: in this layout its 64 16-byte accesses to a row are two contiguous 512-byte runs instead of sixteen
+// 64-byte runs spread over eight storage rows (natural layout [kx][ky]).  Used for the solver-internal right-hand-side
+// vectors (M.X, F); the state X keeps the natural layout its other consumers read.
+__device__ __forceinline__ long tile_offset(long kxrow, long ky, long ny) {
+    return (((kxrow >> 3) * (ny >> 3) + (ky >> 3)) << 6) + ((kxrow & 7) << 3) + (ky & 7);
+}
+
 // ------------------------------------------------------------------------------------------------
 // y = A x for every cell (apply_sparse over all pencils; M.X and L.X of timesteppers.py:588-604)
 // ------------------------------------------------------------------------------------------------
@@ -503,12 +513,16 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
 // coefficient adds an exact zero), so the two kernels agree bit for bit.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-band_matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, int rows_per_chunk, int keep_empty) {
+band_matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, int rows_per_chunk, int keep_empty,
+                   int out_tiled) {
     const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= P.ncells) return;
     const CellCtx c = cell_ctx(P, cell);
     const long plane = P.nx * P.ny;
     const long off0 = (2 * c.mx) * P.ny + 2 * c.my, off1 = off0 + P.ny;
+    // (y tile-major: ddh_pencil_matvec_update_tiled)
+    const long yoff0 = out_tiled ? tile_offset(2 * c.mx, 2 * c.my, P.ny) : off0;
+    const long yoff1 = out_tiled ? tile_offset(2 * c.mx + 1, 2 * c.my, P.ny) : off1;
     const int rr0 = blockIdx.y * rows_per_chunk;
     const int rr1 = (rr0 + rows_per_chunk < A.nrows_out) ? rr0 + rows_per_chunk : A.nrows_out;
     double2 wa[MV_W], wb[MV_W];                  // x rows wbase .. wbase + MV_W - 1: (cc, cs) and (sc, ss)
@@ -556,8 +570,8 @@ band_matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *
         }
         if (base < 0 && keep_empty) continue;    // ddh_pencil_matvec_update: rows without terms are left as they are
         double *yr = y + (long)r * plane;
-        *reinterpret_cast<double2 *>(yr + off0) = v0;
-        *reinterpret_cast<double2 *>(yr + off1) = v1;
+        *reinterpret_cast<double2 *>(yr + yoff0) = v0;
+        *reinterpret_cast<double2 *>(yr + yoff1) = v1;
     }
 }
 
@@ -681,20 +695,25 @@ struct RhsSrc {
     double a[RHS_MAX];
     const unsigned char *zrow;   // optional, per row of the system vectors: 1 = the row is zero in EVERY term (not read)
     const unsigned char *skip;   // optional, per row of the solution: 1 = the caller does not need the row (not written)
+    int tiled;                   // 1: the term vectors are stored tile-major (tile_offset), see ddh_pencil_solve_recombined_tiled
+#ifdef DDH_SWEEP_ABLATE
+    int abl;                     // timing ablations (results are NOT a solve): DDH_ABL bit mask, see launch_solve
+#endif
 };
 
 template <int NF, int XD = 1>
 __device__ __forceinline__ double2 load_sys(const RhsSrc &r, long plane, int row, const PencilDev &P,
                                             const CellCtx &c, int s) {
     // (compile-time indices into the by-value argument struct: a run-time index would push it to scratch memory)
-    if (r.n == 1) {
+    if (r.n == 1 && !r.tiled) {
         double2 v = load_sys<NF, XD>(r.p[0], plane, row, P, c, s);
         if (r.a[0] != 1.0) v = make_double2(r.a[0] * v.x, r.a[0] * v.y);
         return v;
     }
     const long roff = (long)row * plane;
     if (NF == 2) {
-        const long off = roff + (2 * c.mx + s) * P.ny + 2 * c.my;
+        // (r.tiled: tile-major term vectors, see tile_offset; uniform, the offset is loop-invariant per thread)
+        const long off = roff + (r.tiled ? tile_offset(2 * c.mx + s, 2 * c.my, P.ny) : (2 * c.mx + s) * P.ny + 2 * c.my);
         double2 mine = make_double2(0.0, 0.0);
 #pragma unroll
         for (int t = 0; t < RHS_MAX; ++t) {
@@ -1625,6 +1644,19 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
 
     auto load_row = [&](int i) -> double2 {
         if (s_zero[i]) return make_double2(0.0, 0.0);           // wave-uniform
+#ifdef DDH_SWEEP_ABLATE
+        if (rhs.abl & 1) {                                      // right-hand-side terms from lane-contiguous addresses
+            double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int t = 0; t < RHS_MAX; ++t)
+                if (t < rhs.n) {
+                    const double2 q = *reinterpret_cast<const double2 *>(rhs.p[t] + (long)i * plane + 2 * g);
+                    acc.x += rhs.a[t] * q.x;
+                    acc.y += rhs.a[t] * q.y;
+                }
+            return acc;
+        }
+#endif
         double2 v = load_sys<NF>(rhs, plane, my_perm[i], P, c, s);
         if (conjq) v.y = -v.y;
         const unsigned char code = s_code[i];
@@ -1668,6 +1700,12 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
         p = *pvp;
 #pragma unroll
         for (int i = 0; i < KLT; ++i) m[i] = *reinterpret_cast<const double *>(awl + (mo + md[i]));
+#ifdef DDH_SWEEP_ABLATE
+        if (rhs.abl & 4) {                                      // one multiplier load per row
+#pragma unroll
+            for (int i = 1; i < KLT; ++i) m[i] = m[0] * 0.5;
+        }
+#endif
         if (full_border) {
 #pragma unroll
             for (int rb = 0; rb < NBT; ++rb) ab[rb] = abp[rb << 6];
@@ -1751,6 +1789,9 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     }
 }
 
+#ifdef DDH_SWEEP_ABLATE
+__constant__ int c_abl;          // timing ablations of the backward sweep (DDH_ABL): 2 lane-contiguous stores, 8 one factor load per row
+#endif
 template <int NF, int WT, bool REAL, bool PREF, bool PFUSE = false, int DBG = 0, int MINW = 1>
 __global__ void __launch_bounds__(256, MINW)
 solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const double *__restrict__ pband,
@@ -1830,8 +1871,13 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
             const unsigned urow = (unsigned)j * ur_row8;                                 // uniform
 #pragma unroll
             for (int q = 0; 2 * q <= WT; ++q) {
-                const double2 uu = ((DBG & 1) && q > 0) ? make_double2(u[0] * 0.5, u[0] * 0.25)
-                                                        : bload16(ur_rs, ur_lane, urow + (unsigned)(q << 10));
+#ifdef DDH_SWEEP_ABLATE
+                const bool one = (c_abl & 8) && q > 0;
+#else
+                constexpr bool one = false;
+#endif
+                const double2 uu = (((DBG & 1) && q > 0) || one) ? make_double2(u[0] * 0.5, u[0] * 0.25)
+                                                                 : bload16(ur_rs, ur_lane, urow + (unsigned)(q << 10));
                 u[2 * q] = uu.x;
                 if (2 * q + 1 <= WT) u[2 * q + 1] = uu.y;
             }
@@ -1854,6 +1900,9 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
         if (conjq) v.y = -v.y;
         if ((DBG & 4) && v.x != 1.2345e300) return;
         if (DBG & 32) { *reinterpret_cast<double2 *>(xout + (long)j * plane + 2 * g) = v; return; }
+#ifdef DDH_SWEEP_ABLATE
+        if (c_abl & 2) { *reinterpret_cast<double2 *>(xout + (long)j * plane + 2 * g) = v; return; }
+#endif
         store_sys<NF>(xout, plane, my_perm[j], P, c, s, v);
     };
     // rows are processed in pairs; the register window is shifted once per pair (by two).  With PFUSE the emitted value
@@ -2429,6 +2478,16 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
             hipLaunchKernelGGL((solve_forward_kernel<NF, false, KLTV, NBTV>), dim3(blocks), dim3(256), lds_f, s, P, d, rhs, x); \
     }
     // (few window sizes: every instantiation is a fully unrolled kernel and this file dominates the build time)
+#ifdef DDH_SWEEP_ABLATE
+    // timing ablations (build with -DDDH_SWEEP_ABLATE, select with DDH_ABL = bit mask; results are NOT a solve):
+    //   1 forward: right-hand-side terms from lane-contiguous addresses   2 backward: lane-contiguous stores
+    //   4 forward: one multiplier load per row                            8 backward: one factor load per row
+    // Round 4, 512 x 512 x 256, solve ms per launch (gpurun_out/r4i): 0: 6.77 | 1: 5.36 | 2: 6.04 | 4: 6.77 | 8: 5.62 | all: 3.30
+    static const int abl = getenv("DDH_ABL") ? atoi(getenv("DDH_ABL")) : 0;
+    const_cast<RhsSrc &>(rhs).abl = abl;
+    static bool abl_set = false;
+    if (!abl_set) { (void)hipMemcpyToSymbol(HIP_SYMBOL(c_abl), &abl, sizeof(int)); abl_set = true; }
+#endif
     bool lean_fwd = false;
     // one thread per (system, block) where the sweep kernels support it (LuDev::nsplit)
     const unsigned blocks_split = (unsigned)(((long)d.nsplit * d.Gp + 255) / 256);
@@ -2724,7 +2783,7 @@ int ddh_pencil_add_matrix(ddh_handle pack, const ddh_polymat *mat, int nrows_out
 }
 
 static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y, const PostSolve &ps, void *stream,
-                         int keep_empty = 0) {
+                         int keep_empty = 0, int out_tiled = 0) {
     if (mat_id < 0 || mat_id >= (int)pp->mats.size()) return fail("pencil_matvec: bad matrix id");
     if (x == y) return fail("pencil_matvec: in-place unsupported");
     const PencilDev &P = pp->dev;
@@ -2762,7 +2821,10 @@ static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y,
     if (chunks > 65535) return fail("pencil_matvec: too many row chunks");
     const dim3 grid(blocks, chunks ? chunks : 1);
     if (P.nf == 2 && A.band && ps.nz == 0 && !A.order && blocks >= 64)
-        hipLaunchKernelGGL(band_matvec_kernel, grid, dim3(256), 0, s, P, A, x, y, rpc, keep_empty);
+        hipLaunchKernelGGL(band_matvec_kernel, grid, dim3(256), 0, s, P, A, x, y, rpc, keep_empty, out_tiled);
+    else if (out_tiled)
+        return fail("pencil_matvec_update_tiled: only the window-form mat-vec (real, wavenumber-independent bands; two Fourier "
+                    "axes, >= 16384 cells) writes the tile-major layout");
     else if (P.nf == 2)
         hipLaunchKernelGGL(matvec_kernel<2>, grid, dim3(256), 0, s, P, A, x, y, ps, rpc);
     else if (P.nf == 1)
@@ -2787,6 +2849,16 @@ int ddh_pencil_matvec_update(ddh_handle pack, int mat_id, const double *x, doubl
     PostSolve ps;
     memset(&ps, 0, sizeof(ps));
     return launch_matvec(pp, mat_id, x, y, ps, stream, 1);
+}
+
+int ddh_pencil_matvec_update_tiled(ddh_handle pack, int mat_id, const double *x, double *y, void *stream) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (pp->dev.nf != 2 || (pp->dev.nx & 7) || (pp->dev.ny & 7))
+        return fail("pencil_matvec_update_tiled: two Fourier axes with storage sizes that are multiples of 8");
+    PostSolve ps;
+    memset(&ps, 0, sizeof(ps));
+    return launch_matvec(pp, mat_id, x, y, ps, stream, 1, 1);
 }
 
 int ddh_pencil_add_upper_bands(ddh_handle pack, int nz, int nbands, const int *offsets_h, const double *bands_h,
@@ -3206,9 +3278,38 @@ int ddh_pencil_solve_recombined(ddh_handle pack, int lu_id, int nterms, const do
     return ddh_pencil_solve_recombined_sparse(pack, lu_id, nterms, xs_h, alpha_h, p_mat_id, work, x, nullptr, nullptr, stream);
 }
 
+static int solve_recombined_impl(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h, const double *alpha_h,
+                                 int p_mat_id, double *work, double *x, const unsigned char *zero_rows,
+                                 const unsigned char *skip_rows, int terms_tiled, void *stream);
+
 int ddh_pencil_solve_recombined_sparse(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h,
                                        const double *alpha_h, int p_mat_id, double *work, double *x,
                                        const unsigned char *zero_rows, const unsigned char *skip_rows, void *stream) {
+    return solve_recombined_impl(pack, lu_id, nterms, xs_h, alpha_h, p_mat_id, work, x, zero_rows, skip_rows, 0, stream);
+}
+
+int ddh_pencil_solve_recombined_tiled(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h,
+                                      const double *alpha_h, int p_mat_id, double *work, double *x,
+                                      const unsigned char *zero_rows, const unsigned char *skip_rows, void *stream) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_solve: bad LU id");
+    if (pp->dev.nf != 2 || (pp->dev.nx & 7) || (pp->dev.ny & 7))
+        return fail("pencil_solve_recombined_tiled: two Fourier axes with storage sizes that are multiples of 8");
+    {
+        int uf, cbv;
+        choose_variant<2>(pp, pp->lus[lu_id]->dev, uf, cbv);
+        if (pp->lus[lu_id]->dev.pair) uf = 0;
+        if (uf || !lean_forward_ok(pp->lus[lu_id]->dev))
+            return fail("pencil_solve_recombined_tiled: this factorization does not run the lean forward sweep, the only one "
+                        "that reads tile-major terms (ddh_pencil_lu_info)");
+    }
+    return solve_recombined_impl(pack, lu_id, nterms, xs_h, alpha_h, p_mat_id, work, x, zero_rows, skip_rows, 1, stream);
+}
+
+static int solve_recombined_impl(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h, const double *alpha_h,
+                                 int p_mat_id, double *work, double *x, const unsigned char *zero_rows,
+                                 const unsigned char *skip_rows, int terms_tiled, void *stream) {
     PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
     if (!pp) return -1;
     if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_solve: bad LU id");
@@ -3225,6 +3326,7 @@ int ddh_pencil_solve_recombined_sparse(ddh_handle pack, int lu_id, int nterms, c
     }
     r.zrow = zero_rows;
     r.skip = skip_rows;
+    r.tiled = terms_tiled;
     LuFactor *lu = pp->lus[lu_id];
     hipStream_t s = as_stream(stream);
     static const bool no_fuse = getenv("DDH_NO_PFUSE") != nullptr;

@@ -175,15 +175,27 @@ class HipExecutor:
                 raise NotImplementedError(kind)
         return self._plans[spec]
 
-    def transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0):
+    def transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0, tiled_row=0):
+        """tiled_row (forward Chebyshev only): dst rows of `inner` = nx * tiled_row doubles are written tile-major
+        (ddh_cheb_forward_tiled)."""
         if self.timer is not None:
             name = "%s_%s_%s" % (spec[0], direction, "strided" if inner > 1 else "contig")
             return self.timer.run(name, (src.numel() + dst.numel()) * 8, self._transform, spec, basis, direction,
-                                  src, dst, outer, inner, deriv)
-        return self._transform(spec, basis, direction, src, dst, outer, inner, deriv)
+                                  src, dst, outer, inner, deriv, tiled_row)
+        return self._transform(spec, basis, direction, src, dst, outer, inner, deriv, tiled_row)
 
-    def _transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0):
+    def tiled_forward_ok(self, spec, basis, inner, row_len):
+        """Can `transform(..., "forward", tiled_row=row_len)` run?  (the strided-axis wave kernel's sizes)"""
+        return (spec[0] == "cheb" and int(spec[1]) == 384 and int(spec[2]) == 256 and inner > 1
+                and row_len % 8 == 0 and inner % row_len == 0 and (inner // row_len) % 8 == 0)
+
+    def _transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0, tiled_row=0):
         kind, h, h2 = self._plan(spec, basis)
+        if tiled_row:
+            if kind != "cheb" or direction != "forward":
+                raise NotImplementedError("tile-major output: forward Chebyshev transforms only")
+            libhip.call("ddh_cheb_forward_tiled", h, ptr(src), ptr(dst), outer, inner, int(tiled_row), self.dev.stream)
+            return
         if deriv:
             if kind != "rfft" or direction != "backward":
                 raise NotImplementedError("derivative at load: RealFourier backward transforms only")

@@ -84,6 +84,7 @@ SIGNATURES = {
     "ddh_cfft_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_plan_cheb": [_hp, _i, _i, _i, _ip, _dp],
     "ddh_cheb_forward": [_h, _vp, _vp, _l, _l, _vp],
+    "ddh_cheb_forward_tiled": [_h, _vp, _vp, _l, _l, _l, _vp],
     "ddh_cheb_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_plan_mmt": [_hp, _i, _i, _dp],
     "ddh_mmt_apply": [_h, _vp, _vp, _l, _l, _vp],
@@ -110,6 +111,8 @@ SIGNATURES = {
     "ddh_pencil_solve_lincomb": [_h, _i, _i, C.POINTER(_vp), _dp, _vp, _vp],
     "ddh_pencil_solve_recombined": [_h, _i, _i, C.POINTER(_vp), _dp, _i, _vp, _vp, _vp],
     "ddh_pencil_solve_recombined_sparse": [_h, _i, _i, C.POINTER(_vp), _dp, _i, _vp, _vp, _vp, _vp, _vp],
+    "ddh_pencil_solve_recombined_tiled": [_h, _i, _i, C.POINTER(_vp), _dp, _i, _vp, _vp, _vp, _vp, _vp],
+    "ddh_pencil_matvec_update_tiled": [_h, _i, _vp, _vp, _vp],
     "ddh_pencil_flagged": [_h, _i, _ip, C.POINTER(_l), _i],
     "ddh_pencil_set_dense_inverse": [_h, _i, _dp],
     "ddh_pencil_set_dense_inverse_dev": [_h, _i, _i, _vp, _i, _vp],

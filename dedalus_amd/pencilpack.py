@@ -96,17 +96,23 @@ class PencilPack:
     def _timer(self):
         return getattr(self.executor, "timer", None) if self.executor is not None else None
 
-    def matvec(self, mat_id, x, y, owned=False):
+    def matvec(self, mat_id, x, y, owned=False, tiled=False):
         """y = A x.  owned: y is a zero-initialised buffer that only this product writes (a timestepper's M.X vector): rows
-        without terms may then stay untouched (ddh_pencil_matvec_update)."""
+        without terms may then stay untouched (ddh_pencil_matvec_update).  tiled (with owned): y is written in the
+        tile-major layout the sweeps read contiguously (ddh_pencil_matvec_update_tiled)."""
         t = self._timer()
         if t is not None:
-            return t.run("pencil_matvec", (x.numel() + y.numel()) * 8, self._matvec, mat_id, x, y, owned)
-        return self._matvec(mat_id, x, y, owned)
+            return t.run("pencil_matvec", (x.numel() + y.numel()) * 8, self._matvec, mat_id, x, y, owned, tiled)
+        return self._matvec(mat_id, x, y, owned, tiled)
 
-    def _matvec(self, mat_id, x, y, owned=False):
+    def _matvec(self, mat_id, x, y, owned=False, tiled=False):
+        if tiled:
+            libhip.call("ddh_pencil_matvec_update_tiled", self.handle, mat_id, ptr(x), ptr(y), self.dev.stream)
+            return
         libhip.call("ddh_pencil_matvec_update" if owned else "ddh_pencil_matvec", self.handle, mat_id, ptr(x), ptr(y),
                     self.dev.stream)
+
+    supports_tiled_rhs = True
 
     def add_upper_bands(self, nz, offsets, bands):
         offs = np.ascontiguousarray(offsets, dtype=np.int32)
@@ -254,7 +260,7 @@ class PencilPack:
 
     supports_zero_rows = True
 
-    def solve_recombined(self, lu_id, xs, alphas, p_mat_id, work, x, zero_rows=None, skip_rows=None):
+    def solve_recombined(self, lu_id, xs, alphas, p_mat_id, work, x, zero_rows=None, skip_rows=None, tiled=False):
         """x = P (a M + b L P)^-1 (sum_t alphas[t] xs[t]) (ddh_pencil_solve_recombined): recombination fused into the
         backward sweep where the kernel variant allows, else through `work` and a mat-vec.
         zero_rows = (device uint8 mask, fraction set): rows that are zero in every term; skip_rows = (mask, fraction):
@@ -266,17 +272,17 @@ class PencilPack:
             wrote = 1.0 - (skip_rows[1] if (skip_rows is not None and info["backward_lanes"] == 0 and info["real"]) else 0.0)
             nb = self.lu_bytes(lu_id) + (sum(v.numel() for v in xs) * read + x.numel() * wrote) * 8
             return t.run("pencil_solve", nb, self._solve_recombined, lu_id, xs, alphas, p_mat_id, work, x, zero_rows,
-                         skip_rows)
-        return self._solve_recombined(lu_id, xs, alphas, p_mat_id, work, x, zero_rows, skip_rows)
+                         skip_rows, tiled)
+        return self._solve_recombined(lu_id, xs, alphas, p_mat_id, work, x, zero_rows, skip_rows, tiled)
 
-    def _solve_recombined(self, lu_id, xs, alphas, p_mat_id, work, x, zero_rows=None, skip_rows=None):
+    def _solve_recombined(self, lu_id, xs, alphas, p_mat_id, work, x, zero_rows=None, skip_rows=None, tiled=False):
         arr = (C.c_void_p * len(xs))(*[C.c_void_p(v.data_ptr()) for v in xs])
         al = np.ascontiguousarray(alphas, dtype=np.float64)
-        if zero_rows is not None or skip_rows is not None:
+        if zero_rows is not None or skip_rows is not None or tiled:
             zp = C.c_void_p(zero_rows[0].data_ptr()) if zero_rows is not None else None
             sp = C.c_void_p(skip_rows[0].data_ptr()) if skip_rows is not None else None
-            libhip.call("ddh_pencil_solve_recombined_sparse", self.handle, lu_id, len(xs), arr, libhip.as_dp(al),
-                        int(p_mat_id), ptr(work), ptr(x), zp, sp, self.dev.stream)
+            libhip.call("ddh_pencil_solve_recombined_tiled" if tiled else "ddh_pencil_solve_recombined_sparse", self.handle,
+                        lu_id, len(xs), arr, libhip.as_dp(al), int(p_mat_id), ptr(work), ptr(x), zp, sp, self.dev.stream)
             return
         libhip.call("ddh_pencil_solve_recombined", self.handle, lu_id, len(xs), arr, libhip.as_dp(al), int(p_mat_id),
                     ptr(work), ptr(x), self.dev.stream)

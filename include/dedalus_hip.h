@@ -99,6 +99,14 @@ int ddh_rfft_bilinear_fused(ddh_handle plan, int na, const double *const *a_h, c
 int ddh_plan_cheb(ddh_handle *plan, int n_grid, int n_coeff, int nbands,
                   const int *band_offsets_h, const double *bands_h);
 int ddh_cheb_forward(ddh_handle plan, const double *g, double *c, long outer, long inner, void *stream);
+/* The same transform with the coefficient rows written TILE-MAJOR: a row of `inner` = nx * row_len doubles is stored as
+ * [kx / 8][ky / 8][kx % 8][ky % 8] (64-byte segments of a tile of 8 storage rows x 8 doubles contiguous) instead of
+ * [kx][ky].  It is the layout the pencil sweeps read with two contiguous 512-byte runs per wavefront and row
+ * (ddh_pencil_solve_recombined_tiled); the forward transform of a right-hand-side product writes the equation rows of the
+ * solver's F vector directly in it.  Values are those of ddh_cheb_forward (core/transforms.py:801-902), only their
+ * addresses differ.  nx and row_len multiples of 8; strided-axis wave kernel sizes only (N = 384, M = 256), an error
+ * otherwise; not in place.                                                                                            */
+int ddh_cheb_forward_tiled(ddh_handle plan, const double *g, double *c, long outer, long inner, long row_len, void *stream);
 int ddh_cheb_backward(ddh_handle plan, const double *c, double *g, long outer, long inner, void *stream);
 
 /* Dense matrix-multiply transform along an axis (JacobiMMT core/transforms.py:114-158 via
@@ -358,6 +366,21 @@ int ddh_pencil_set_solve_variant(ddh_handle pack, int mode, int fwd, int backwar
  * symmetry on its term lists); NULL, NULL switches pairing off.  Needs the real-graded factorization
  * (ddh_pencil_factor_real), two Fourier axes, a square unsharded cell grid with kx_h == ky_h; otherwise ignored.   */
 int ddh_pencil_set_pairing(ddh_handle pack, const int *row_swap_h, const int *col_swap_h, long min_systems);
+/* Tile-major right-hand-side vectors (two Fourier axes, nx and ny multiples of 8).  The sweeps hand a wavefront the 16
+ * cells of a 4 x 4 tile and of its transposed partner tile; in the natural row layout [nx][ny] its 64 accesses to a row
+ * of a system vector are sixteen 64-byte runs in eight storage rows, in the tile-major layout [kx/8][ky/8][kx%8][ky%8]
+ * two contiguous 512-byte runs (measured: -1.4 ms of a 6.8 ms solve at 512 x 512 x 256 with contiguous term reads).
+ *   ddh_pencil_matvec_update_tiled      y = A x like ddh_pencil_matvec_update, y written tile-major (window-form
+ *                                       matrices only: the timesteppers' M.X products); x in the natural layout
+ *   ddh_pencil_solve_recombined_tiled   ddh_pencil_solve_recombined_sparse whose term vectors xs_h are ALL tile-major;
+ *                                       x (the state) and work keep the natural layout.  Needs the lean forward sweep
+ *                                       (ddh_pencil_lu_info), an error otherwise.
+ * The reference gathers every pencil's right-hand side into a dense buffer (core/subsystems.py:340-380); the values and
+ * the linear systems are the same, only the addresses of the solver-internal vectors differ.                          */
+int ddh_pencil_matvec_update_tiled(ddh_handle pack, int mat_id, const double *x, double *y, void *stream);
+int ddh_pencil_solve_recombined_tiled(ddh_handle pack, int lu_id, int nterms, const double *const *xs_h,
+                                      const double *alpha_h, int p_mat_id, double *work, double *x,
+                                      const unsigned char *zero_rows, const unsigned char *skip_rows, void *stream);
 /* Independent diagonal blocks.  When the band block of the ordered pencil matrix (rows / columns < n_interior of
  * ddh_pencil_factor*) is block diagonal with `nblocks` blocks of EQUAL size -- the connected components of the matrix,
  * e.g. the two reflection parities of constant-coefficient equations between two plates once the boundary rows are

@@ -278,3 +278,29 @@ def test_unknowns_skipped_by_intermediate_stages_are_never_consumed(monkeypatch)
     for k in a:
         assert np.isfinite(a[k]).all(), k
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_tile_major_right_hand_sides_change_addresses_not_values(monkeypatch):
+    """The timestepper's M.X and F buffers in the tile-major layout (ddh_pencil_matvec_update_tiled,
+    ddh_cheb_forward_tiled, ddh_pencil_solve_recombined_tiled) against the natural layout (DDH_NO_RHS_TILING): the same
+    values are summed in the same order, so the end states agree bit for bit.  256 x 256 x 256: the smallest size at which
+    every tiled producer runs (window mat-vec, strided wave transform, lean sweep)."""
+    import dedalus_amd.public as d3
+
+    def run(tiled):
+        if tiled:
+            monkeypatch.delenv("DDH_NO_RHS_TILING", raising=False)
+        else:
+            monkeypatch.setenv("DDH_NO_RHS_TILING", "1")
+        solver, f = problems.rayleigh_benard_3d(d3, Nx=256, Ny=256, Nz=256, timestepper="RK222")
+        for _ in range(2):
+            solver.step(1e-3)
+        assert bool(solver.timestepper._tiled) == tiled
+        out = {k: np.array(f[k]["c"]) for k in ("p", "b", "u")}
+        del solver, f
+        return out
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), k

@@ -63,7 +63,7 @@ def test_benchmark_configuration_solves_the_references_matrices(full_size):
     # the probe rides on the kernels the benchmark times: fused right-hand-side terms, structural-zero mask, and -- on the
     # intermediate stage -- the unknowns nothing reads left unstored (checked there on the stored unknowns)
     for k, rec in enumerate(recs):
-        assert "ddh_pencil_solve_recombined_sparse" in rec["path"], rec["path"]
+        assert "ddh_pencil_solve_recombined_tiled" in rec["path"], rec["path"]      # (masked + tile-major terms)
         assert rec["terms"] == (2 if k % 2 == 0 else 4) and rec["zero_rows"]
         assert rec["skip_rows"] == (k % 2 == 0)
     summ = pencil_check.summarize(pencil_check.check_records(ref, recs, ref.groups))
