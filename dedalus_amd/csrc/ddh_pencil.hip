@@ -2080,8 +2080,11 @@ solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, 
     }
     __syncthreads();
     const int h = threadIdx.x & (CH - 1);
-    const long g = (long)blockIdx.x * (256 / CH) + (threadIdx.x / CH);
+    // independent diagonal blocks (LuDev::nsplit, real factors): this lane group sweeps rows row0 .. row1 - 1 of system g
+    const int blk = (REAL && L.nsplit > 1) ? __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * (256 / CH)) / L.Gp)) : 0;
+    const long g = (long)blockIdx.x * (256 / CH) + (threadIdx.x / CH) - (long)blk * L.Gp;
     if (g >= P.G) return;   // whole lane groups leave together; P/Q partner groups are adjacent and leave together
+    const int row0 = (REAL && L.nsplit > 1) ? blk * L.nh : 0, row1 = (REAL && L.nsplit > 1) ? row0 + L.nh : L.n;
     const long cell = g / P.S;
     const int s = (int)(g % P.S);
     const CellCtx c = cell_ctx(P, cell);
@@ -2102,12 +2105,15 @@ solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, 
     };
 
     double2 wv = make_double2(0.0, 0.0);          // window row i = h (mod CH), i in [j, j + kl]
-    if (h <= kl && h < n) wv = load_row(h);
+    {
+        const int i0 = row0 + ((h - row0) & (CH - 1));
+        if (i0 - row0 <= kl && i0 < row1) wv = load_row(i0);
+    }
     double2 gb[NBT];
 #pragma unroll
     for (int rb = 0; rb < NBT; ++rb) {
         gb[rb] = make_double2(0.0, 0.0);
-        if (rb < nb) gb[rb] = load_row(n + rb);
+        if (rb < nb && blk == 0) gb[rb] = load_row(n + rb);       // (block 0 carries the border's right-hand side)
     }
     int pp[COOP_D];
     E pm[COOP_D], pab[COOP_D][NBT];
@@ -2119,12 +2125,12 @@ solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, 
     const long aw_rs = (long)L.BW * 64, ab_rs = (long)L.nb * 64, pv_rs = 64;
     const int aw_step = (int)(aw_rs - 64);                   // (row + 1, d - 1) relative to (row, d) ...
     const int pk63 = L.pk63;                                 // ... minus 63 when d - 1 is the second member of a pair
-    const unsigned char *pv_ptr = L.piv + lu_pv(L, gl, 0);
-    const E *aw_ptr = Aw + lu_aw(L, gl, 0, kl);              // (row jj, diagonal)
-    const E *ab_ptr = Ab + lu_ab(L, gl, 0, 0);
+    const unsigned char *pv_ptr = L.piv + lu_pv(L, gl, row0);
+    const E *aw_ptr = Aw + lu_aw(L, gl, row0, kl);           // (row jj, diagonal)
+    const E *ab_ptr = Ab + lu_ab(L, gl, row0, 0);
     auto issue = [&](int jj, int slot) {
         const int dl = (h - jj) & (CH - 1);
-        const bool live = dl >= 1 && dl <= kl && jj + dl < n;
+        const bool live = dl >= 1 && dl <= kl && jj + dl < row1;
         const int dc = live ? dl : 0;                       // the diagonal itself is always a valid entry
         pp[slot] = *pv_ptr;
         // raw values only: whether an entry is used is decided when the row is consumed (touching the value here
@@ -2133,15 +2139,15 @@ solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, 
 #pragma unroll
         for (int rb = 0; rb < NBT; ++rb) pab[slot][rb] = ab_ptr[(rb < nb ? rb : 0) << 6];
         const int nxt = jj + kl + 1;
-        pr[slot] = load_row(nxt < n ? nxt : n - 1);          // every lane of the group reads the same row
-        const bool adv = jj < n - 1;                         // past the end the last row is re-read (and never used)
+        pr[slot] = load_row(nxt < row1 ? nxt : row1 - 1);    // every lane of the group reads the same row
+        const bool adv = jj < row1 - 1;                      // past the end the last row is re-read (and never used)
         pv_ptr += adv ? pv_rs : 0;
         aw_ptr += adv ? aw_rs : 0;
         ab_ptr += adv ? ab_rs : 0;
     };
-    double2 *sc_ptr = L.scratch + g;
+    double2 *sc_ptr = L.scratch + (long)row0 * G + g;
 #pragma unroll
-    for (int r = 0; r < COOP_D; ++r) issue(r, r);
+    for (int r = 0; r < COOP_D; ++r) issue(row0 + r, r);
     // One row.  The main loop runs whole blocks of COOP_D rows without any guard: straight-line code lets the compiler
     // wait for exactly the oldest outstanding prefetch (vmcnt(k)); a guard per row merges control-flow paths with
     // different numbers of issued loads and degrades every wait to "almost everything".
@@ -2163,20 +2169,29 @@ solve_forward_coop_kernel(PencilDev P, LuDev L, const double *__restrict__ rhs, 
         *sc_ptr = yj; /* row j of the scratch (all lanes of the group store the same value) */                     \
         sc_ptr += G;                                                                                               \
         const int dl = (h - (j)) & (CH - 1);                                                                       \
-        if (dl >= 1 && dl <= kl && (j) + dl < n) El<REAL>::fms2(wv, m, yj);                                        \
+        if (dl >= 1 && dl <= kl && (j) + dl < row1) El<REAL>::fms2(wv, m, yj);                                     \
         _Pragma("unroll") for (int rb = 0; rb < NBT; ++rb) if (rb < nb) El<REAL>::fms2(gb[rb], ab[rb], yj);        \
         const int nxt = (j) + kl + 1;                                                                              \
-        if (nxt < n && (nxt & (CH - 1)) == h) wv = rnew;                                                           \
+        if (nxt < row1 && (nxt & (CH - 1)) == h) wv = rnew;                                                        \
     }
-    int j0 = 0;
-    for (; j0 + COOP_D <= n; j0 += COOP_D) {
+    int j0 = row0;
+    for (; j0 + COOP_D <= row1; j0 += COOP_D) {
 #pragma unroll
         for (int r = 0; r < COOP_D; ++r) DDH_COOP_FWD_ROW(r, j0 + r)
     }
 #pragma unroll
     for (int r = 0; r < COOP_D; ++r)
-        if (j0 + r < n) DDH_COOP_FWD_ROW(r, j0 + r)
+        if (j0 + r < row1) DDH_COOP_FWD_ROW(r, j0 + r)
 #undef DDH_COOP_FWD_ROW
+    if (REAL && L.nsplit > 1) {
+        // the border rows collect contributions of every block: partial sums, finished by border_finish_kernel
+        if (h == 0) {
+#pragma unroll
+            for (int r = 0; r < NBT; ++r)
+                if (r < nb) L.scratch[(long)(n + nb + blk * nb + r) * G + g] = gb[r];
+        }
+        return;
+    }
     // ---- Schur block (every lane of the group computes it; lane 0 stores)
 #pragma unroll
     for (int r = 0; r < NBT; ++r) {
@@ -2214,8 +2229,11 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     }
     __syncthreads();
     const int h = threadIdx.x & (CB - 1);
-    const long g = (long)blockIdx.x * (256 / CB) + (threadIdx.x / CB);
+    // independent diagonal blocks (LuDev::nsplit, real factors): rows row1 - 1 .. row0 of system g
+    const int blk = (REAL && L.nsplit > 1) ? __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * (256 / CB)) / L.Gp)) : 0;
+    const long g = (long)blockIdx.x * (256 / CB) + (threadIdx.x / CB) - (long)blk * L.Gp;
     if (g >= P.G) return;
+    const int row0 = (REAL && L.nsplit > 1) ? blk * L.nh : 0, row1 = (REAL && L.nsplit > 1) ? row0 + L.nh : n;
     const long cell = g / P.S;
     const int s = (int)(g % P.S);
     const CellCtx c = cell_ctx(P, cell);
@@ -2227,11 +2245,11 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     // xr[t] = x[k_t]: the entries k = h (mod CB) above the current row, k_t = j + 1 + e + CB t, e = (h - j - 1) mod CB
     double2 xr[TT];
     {
-        const int e = (h - n) & (CB - 1);              // row j = n - 1
+        const int e = (h - row1) & (CB - 1);           // row j = row1 - 1
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            const int kb = e + CB * t;                 // k - n
-            xr[t] = (kb < nb) ? L.scratch[(long)(n + kb) * G + g] : make_double2(0.0, 0.0);
+            const int kb = e + CB * t;                 // k - row1 (border columns follow the LAST band rows)
+            xr[t] = (kb < nb && row1 == n) ? L.scratch[(long)(n + kb) * G + g] : make_double2(0.0, 0.0);
         }
     }
     E pu[PD][TT], pu0[PD];
@@ -2239,8 +2257,8 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
     // issue() is called for jj = n - 1, n - 2, ...: running pointers (see the forward kernel)
     const long aw_rs = (long)L.BW * 64;
     const int pk63 = L.pk63;
-    const E *u_ptr = Aw + lu_aw(L, gl, n - 1, kl);
-    const double2 *y_ptr = L.scratch + (long)(n - 1) * G + g;
+    const E *u_ptr = Aw + lu_aw(L, gl, row1 - 1, kl);
+    const double2 *y_ptr = L.scratch + (long)(row1 - 1) * G + g;
     auto issue = [&](int jj, int slot) {                  // branch-free
         py[slot] = *y_ptr;
         pu0[slot] = u_ptr[0];
@@ -2251,12 +2269,12 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
             const int dd = (d <= W) ? d : 0;
             pu[slot][t] = u_ptr[(dd << 6) - pk63 * (dd & 1)];       // raw; entries beyond the band are dropped at use
         }
-        const bool adv = jj > 0;
+        const bool adv = jj > row0;
         u_ptr -= adv ? aw_rs : 0;
         y_ptr -= adv ? G : 0;
     };
 #pragma unroll
-    for (int r = 0; r < PD; ++r) issue(n - 1 - r, r);
+    for (int r = 0; r < PD; ++r) issue(row1 - 1 - r, r);
 #define DDH_COOP_BWD_ROW(r, j)                                                                                     \
     {                                                                                                              \
         E u[TT];                                                                                                   \
@@ -2283,13 +2301,14 @@ solve_backward_coop_kernel(PencilDev P, LuDev L, double *__restrict__ xout) {
         }                                                                                                          \
     }
     int jt0 = 0;
-    for (; jt0 + PD <= n; jt0 += PD) {           // guard-free whole blocks (see the forward kernel)
+    const int nrows = row1 - row0;
+    for (; jt0 + PD <= nrows; jt0 += PD) {       // guard-free whole blocks (see the forward kernel)
 #pragma unroll
-        for (int r = 0; r < PD; ++r) DDH_COOP_BWD_ROW(r, n - 1 - (jt0 + r))
+        for (int r = 0; r < PD; ++r) DDH_COOP_BWD_ROW(r, row1 - 1 - (jt0 + r))
     }
 #pragma unroll
     for (int r = 0; r < PD; ++r)
-        if (jt0 + r < n) DDH_COOP_BWD_ROW(r, n - 1 - (jt0 + r))
+        if (jt0 + r < nrows) DDH_COOP_BWD_ROW(r, row1 - 1 - (jt0 + r))
 #undef DDH_COOP_BWD_ROW
 }
 
@@ -2448,7 +2467,8 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     choose_variant<NF>(pp, d, use_fwd, cb);
     if (d.pair) use_fwd = cb = 0;               // partner pencils: one-thread-per-system sweeps only
     if (use_fwd) {
-        const unsigned cblocks = (unsigned)((P.G + (256 / CH) - 1) / (256 / CH));
+        const unsigned cblocks = (d.real && d.nsplit > 1) ? (unsigned)(((long)d.nsplit * d.Gp) / (256 / CH))
+                                                          : (unsigned)((P.G + (256 / CH) - 1) / (256 / CH));
         // the cooperative sweep's deep branch-free prefetch takes ONE right-hand-side vector: a combination is
         // materialised first (few systems: the extra pass is small next to the latency-bound sweeps)
         const double *rhs1 = rhs.p[0];
@@ -2467,6 +2487,8 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     }
         if constexpr (NF > 0) {
             if (d.nb <= 2) DDH_CFWD(2) else DDH_CFWD(8)
+            if (d.real && d.nsplit > 1 && d.nb > 0)
+                hipLaunchKernelGGL(border_finish_kernel<NF>, dim3(blocks), dim3(256), 0, s, P, d, x);
         }
 #undef DDH_CFWD
     }
@@ -2517,7 +2539,8 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     if (cb) {
 #define DDH_CBWD(TTV, CBV)                                                                                         \
     {                                                                                                              \
-        const unsigned cblocks = (unsigned)((P.G + (256 / CBV) - 1) / (256 / CBV));                                \
+        const unsigned cblocks = (d.real && d.nsplit > 1) ? (unsigned)(((long)d.nsplit * d.Gp) / (256 / CBV))      \
+                                                          : (unsigned)((P.G + (256 / CBV) - 1) / (256 / CBV));     \
         if (d.real)                                                                                                \
             hipLaunchKernelGGL((solve_backward_coop_kernel<NF, TTV, true, CBV>), dim3(cblocks), dim3(256), lds_b, s, P, d, x); \
         else                                                                                                       \
@@ -2987,7 +3010,7 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
         d.nh = n;
         d.Gp = (long)((G + 255) / 256) * 256;
         static const bool no_par = getenv("DDH_SPLIT_THREADS") && atoi(getenv("DDH_SPLIT_THREADS")) == 0;
-        if (real && P.nf == 2 && pp->row_blocks > 1 && n > 0 && n % pp->row_blocks == 0 && !no_par) {
+        if (real && P.nf >= 1 && pp->row_blocks > 1 && n > 0 && n % pp->row_blocks == 0 && !no_par) {
             d.nsplit = pp->row_blocks;
             d.nh = n / pp->row_blocks;
         }
