@@ -2424,14 +2424,11 @@ static void choose_variant(const PencilPack *pp, const LuDev &d, int &use_fwd, i
     if (coop_mode == 2 || (coop_auto && P.G <= 1024)) cb = 16;
     else if (coop_auto && P.G <= 16384) cb = 4;        // (round 3, register-lean sweeps: at 32 768 systems one thread per
                                                        //  system is faster again, 5.17 vs 5.58 ms -- profiles/r3_strong_scaling_shares.txt)
-    // independent diagonal blocks swept by separate threads (LuDev::nsplit): the one-thread-per-(system, block) forward
-    // sweep beats the cooperative one from a few thousand systems on (round 4, gpurun_out/r4e, solve ms per launch at the
-    // per-rank shares of 512 x 512 x 256: 16 384 systems fwd coop + cb 4: 4.32 | per-thread + cb 4: 2.24 | per-thread
-    // both: 2.57;  32 768: per-thread both 2.76 | + cb 4: 3.15;  65 536: 3.86 | 5.26)
-    if (coop_auto && d.nsplit > 1 && P.G > 4096) {
-        use_fwd = 0;
-        cb = (P.G <= 16384) ? 4 : 0;
-    }
+    // independent diagonal blocks swept by separate threads (LuDev::nsplit): one thread per (system, block) in both sweeps
+    // beats the cooperative variants from a few thousand systems on (round 4, profiles/r4_strong_scaling_shares.txt, solve
+    // ms per launch at the per-rank shares of 512 x 512 x 256: 16 384 systems: per-thread both 1.97 | per-thread + cb 4:
+    // 2.15 | fwd coop + cb 4: 4.36;  32 768: 2.24 | 3.12 | 8.72;  65 536: 3.28 | 5.03 | 17.3)
+    if (coop_auto && d.nsplit > 1 && P.G > 4096) use_fwd = cb = 0;
     if (pp->coop_fwd >= 0) use_fwd = pp->coop_fwd;
     if (pp->coop_cb >= 0) cb = pp->coop_cb;
     if (NF == 0 || d.kl >= CH || d.nb > 8) use_fwd = 0;
