@@ -435,8 +435,8 @@ int ddh_comm_allreduce(ddh_handle comm, double *buf, long count, int op, void *s
  * transposed axis pair (axis, axis + 1); axes that are not divisible by the number of ranks are dealt out in blocks of ceil(n / P) (uneven
  * blocks).  Local layouts, C order:
  *     column-local CL [n0][n1][n2 / P][n3]      row-local RL [n0][n1 / P][n2][n3]
- * ddh_a2a_localize_rows(plan, CL, RL)     = plan.localize_rows(CL, RL)     (:248-256; Transpose.decrement, forward)
- * ddh_a2a_localize_columns(plan, RL, CL)  = plan.localize_columns(RL, CL)  (:258-266; Transpose.increment, backward)
+ * ddh_a2a_localize_rows(plan, CL, RL)     = plan.localize_rows(CL, RL)     (FFTWTranspose :211-220, AlltoallvTranspose :329-342; Transpose.decrement, forward)
+ * ddh_a2a_localize_columns(plan, RL, CL)  = plan.localize_columns(RL, CL)  (:237-246 / :344-358; Transpose.increment, backward)
  * ddh_a2a_forward / ddh_a2a_backward are the same two calls under the transform-direction names.
  * Each is pack kernel -> grouped ncclSend/ncclRecv to every peer -> unpack kernel, asynchronous on `stream`; source
  * and destination must be different buffers (the reference's CL/RL views alias one FFTW buffer and are transposed
