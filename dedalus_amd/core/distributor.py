@@ -5,6 +5,8 @@ dedalus/core/distributor.py:36-175, 311-517, 588-661 (one rank per GPU; the penc
 :696-924 become RCCL all-to-alls, see parallel.py).
 """
 
+import os
+
 import numpy as np
 
 from .coords import CartesianCoordinates, Coordinate
@@ -259,6 +261,31 @@ class Transformer:
                 shape[1], shape[2] = shape[1] // P, shape[2] * P
         return tuple(shape)
 
+    def stage_xb(self, domain, scales):
+        """(ny, gz) when the array between the z and the x transforms of `domain` at `scales` -- "stage 1": after backward
+        step 0, before forward step 0 -- is stored x-blocked, [comp][kx / 64][z][kx % 64][ky] (include/dedalus_hip.h,
+        ddh_fft_set_stage_layout), else None.  A RULE, not a property of an array: every producer and consumer of a stage-1
+        array asks it with the same arguments.  One rank (the exchange between the two transforms reads the natural
+        layout), a domain with bases on all three axes, both transforms on the strided wave kernels.  DDH_NO_STAGE_XB=1
+        switches it off."""
+        cache = self.__dict__.setdefault("_xb_cache", {})
+        key = (id(domain), tuple(scales))
+        hit = cache.get(key)
+        if hit is not None and hit[0] is domain:
+            return hit[1]
+        res = None
+        ex = self.dist.executor
+        steps = self._steps(domain, scales)
+        if (os.environ.get("DDH_NO_STAGE_XB") is None and self.dist.size == 1 and len(steps) == 3
+                and hasattr(ex, "stage_layout_ok") and [p for p, _, _ in steps] == [0, 1, 2]):
+            (_, bz, zspec), (_, bx, xspec), (_, by, _) = steps
+            shape = domain.storage_coeff_shape()
+            nx, ny = int(shape[1]), int(shape[2])
+            if ex.stage_layout_ok(zspec, xspec, nx, ny):
+                res = (ny, int(bz.grid_size(scales[self.dist.storage_order[0]])))
+        cache[key] = (domain, res)
+        return res
+
     def backward_steps(self, domain, ncomp, src, scales, i0, i1, dst=None, deriv=None):
         """Apply backward steps i0 .. i1-1 to data that has seen steps < i0 (z transform first, then the
         all-to-all (-> z-sharded, kx local), then the Fourier transforms).  deriv = (step, 2 pi / L)
@@ -277,12 +304,14 @@ class Transformer:
             shape[pos + 1] = n_out
             last = (i == i1 - 1)
             out = dst if (last and dst is not None and not (exchange and pos == 0)) else ex.empty(tuple(shape))
+            xb = self.stage_xb(domain, scales) if i <= 1 else None
+            xbv = dict(xb=xb[i]) if xb is not None else {}      # step 0 writes, step 1 reads the stage-1 array
             if deriv is not None and deriv[0] == i:
                 if spec[0] != "rfft":
                     raise NotImplementedError("derivative at load along a non-Fourier axis")
-                ex.transform(spec, b, "backward", src, out, outer, inner, deriv=deriv[1])
+                ex.transform(spec, b, "backward", src, out, outer, inner, deriv=deriv[1], **xbv)
             else:
-                ex.transform(spec, b, "backward", src, out, outer, inner)
+                ex.transform(spec, b, "backward", src, out, outer, inner, **xbv)
             src = out
             if exchange and pos == 0:
                 src = self._rows_after_z(ex, src, shape, dst if last else None)
@@ -362,7 +391,10 @@ class Transformer:
         inner = int(np.prod(shape[pos + 2:]))
         shape[pos + 1] = b.grid_size(scales[ax])
         out, out_d = ex.empty(tuple(shape)), ex.empty(tuple(shape))
-        ex.transform_dual_z(spec, b, src, out, out_d, dvec, outer, inner)
+        xb = self.stage_xb(ldomain, scales)
+        if xb is not None and self.stage_xb(xdomain, scales) != xb:
+            raise RuntimeError("dual z transform: the two domains disagree about the stage layout")
+        ex.transform_dual_z(spec, b, src, out, out_d, dvec, outer, inner, **(dict(xb=xb[0]) if xb is not None else {}))
         if self._needs_exchange(ldomain) and pos == 0:
             out = self._rows_after_z(ex, out, list(shape))
             out_d = self._rows_after_z(ex, out_d, list(shape))
@@ -385,7 +417,8 @@ class Transformer:
         inner = int(np.prod(shape[pos + 2:]))
         shape[pos + 1] = b.grid_size(scales[ax])
         out, out_d = ex.empty(tuple(shape)), ex.empty(tuple(shape))
-        ex.transform_dual(spec, b, src, out, out_d, outer, inner, dscale)
+        xb = self.stage_xb(domain, scales) if step == 1 else None
+        ex.transform_dual(spec, b, src, out, out_d, outer, inner, dscale, **(dict(xb=xb[1]) if xb is not None else {}))
         return out, out_d
 
     def backward_data(self, domain, ncomp, c, g, scales, skip_last=False):
@@ -442,8 +475,9 @@ class Transformer:
             shape[pos + 1] = b.coeff_size
             last = i == len(rsteps) - 1
             dst = c if last else ex.empty(tuple(shape))
+            xb = self.stage_xb(domain, scales) if pos <= 1 else None
+            kw = dict(xb=xb[pos]) if xb is not None else {}      # step 1 (x) writes, step 0 (z) reads the stage-1 array
             if last and tiled_row:
-                ex.transform(spec, b, "forward", src, dst, outer, inner, tiled_row=tiled_row)
-            else:
-                ex.transform(spec, b, "forward", src, dst, outer, inner)
+                kw["tiled_row"] = tiled_row
+            ex.transform(spec, b, "forward", src, dst, outer, inner, **kw)
             src = dst

@@ -1192,6 +1192,8 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
         const int wst = wave_axis_try(MODE, d, src, dst, outer, inner, dst2, dvec, dscale, dscale2, as_stream(stream));
         if (wst <= 0) return wst;
     }
+    if (d.xb && inner_mode) return fail("x-blocked stage layout (ddh_fft_set_stage_layout): only the strided-axis wave kernels at their "
+                          "instantiated sizes read / write it -- this transform would have used another kernel");
     if (d.ctile_nseg) return fail("cheb_forward_tiled: only the wave-per-four-pairs kernel (N = 384, M = 256, strided axis) "
                                   "writes the tile-major coefficient layout");
     long npairs;
@@ -1440,6 +1442,15 @@ int ddh_cheb_backward_dual(ddh_handle plan, const double *c, double *g, double *
     return launch<CHEB_BWD>(pl, c, g, outer, inner, stream, 0.0, g_deriv, 0.0, dvec);
 }
 DDH_FFT_ENTRY(ddh_cheb_forward, K_CHEB, CHEB_FWD)
+int ddh_fft_set_stage_layout(ddh_handle plan, long value) {
+    FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
+    if (!pl) return -1;
+    if (pl->tkind != K_CHEB && pl->tkind != K_RFFT) return fail("ddh_fft_set_stage_layout: Chebyshev or real-Fourier plans");
+    if (value < 0 || value > 0x7fffffffL) return fail("ddh_fft_set_stage_layout: bad value");
+    pl->dev.xb = (unsigned)value;
+    return 0;
+}
+
 int ddh_cheb_forward_tiled(ddh_handle plan, const double *g, double *c, long outer, long inner, long row_len, void *stream) {
     FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
     if (!pl) return -1;

@@ -60,6 +60,8 @@ struct FftDev {
     int twdirect;          // 1: full twiddle table in LDS (N entries) instead of the two-level table
     int ld;                // LDS leading dimension of the FFT buffer (>= N)
     unsigned long long *prof;   // optional phase timing (debug): [load, fft, store, count]
+    unsigned xb;                // != 0: x-blocked stage layout on the INTERMEDIATE side of a strided wave transform
+                                // (ddh_fft_set_stage_layout): Chebyshev plans: row length ny; real-FFT plans: z planes gz
     unsigned ctile_nseg;        // != 0: the coefficient rows [nx][ny] are written tile-major, ctile_nseg = ny / 8 64-byte
                                 // segments per storage row (ddh_cheb_forward_tiled; wave kernel only)
 };

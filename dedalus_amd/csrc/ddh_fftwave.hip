@@ -71,7 +71,10 @@ wave_cheb_kernel(FftDev p, WaveArgs a) {
     const wf::Lane L = wf::make_lane(lane);
     const unsigned g = xcd_swizzle(blockIdx.x, gridDim.x);
     const long inner = a.inner;
-    const unsigned rsb = (unsigned)(inner * 8);                       // bytes between rows
+    const unsigned rsb = (unsigned)(inner * 8);                       // bytes between coefficient rows
+    // grid side (the stage array between the z and the x transforms): natural [z][kx][ky], or x-blocked
+    // [kx / 64][z][kx % 64][ky] (p.xb = ny): rows 64 ny doubles apart (256 KiB at ny = 512, not one 2 MiB page per row)
+    const unsigned rsg = p.xb ? (unsigned)(64u * p.xb * 8u) : rsb;
     // i-th tile of this wave
     auto tile_of = [&](unsigned i) -> unsigned { return (g * a.tpw + i) * WV_WAVES + wave; };
     auto locate = [&](unsigned tile, long &off_c, long &off_g, bool &valid) {
@@ -85,6 +88,10 @@ wave_cheb_kernel(FftDev p, WaveArgs a) {
         }
         off_c = ((long)o * M) * inner + 8 * seg;
         off_g = ((long)o * N) * inner + 2 * pair0;
+        if (p.xb) {
+            const unsigned nsg = p.xb >> 3, kxrow = tb / nsg, sg = tb - kxrow * nsg;
+            off_g = ((long)o * N) * inner + ((long)(kxrow >> 6) * N * 64 + (kxrow & 63)) * p.xb + 8L * sg;
+        }
         valid = pair0 + L.p < a.npairs;
     };
     // The 8 waves of the workgroup take 8 neighbouring tiles per step.  With wsync they enter every step together, so
@@ -100,7 +107,7 @@ wave_cheb_kernel(FftDev p, WaveArgs a) {
             long oc, og;
             bool valid;
             locate(tile, oc, og, valid);
-            wf::cheb_fwd_tile<R, NL, CH>(a.src + og, a.dst + oc, rsb, valid, S, T, lane);
+            wf::cheb_fwd_tile<R, NL, CH>(a.src + og, a.dst + oc, rsg, rsb, valid, S, T, lane);
         }
     } else {
         double2 c[NL];
@@ -123,10 +130,10 @@ wave_cheb_kernel(FftDev p, WaveArgs a) {
             const unsigned rsbn = more ? rsb : 0u;
             if (KIND == 1) {
                 // the plain pass keeps c for the derivative pass
-                wf::cheb_bwd_pass<R, NL, CH, 0, false>(c, S, T, a.dst + og, rsb, valid, lane, a.src + oc, rsb, valid);
-                wf::cheb_bwd_pass<R, NL, CH, 1, true>(c, S, T, a.dst2 + og, rsb, valid, lane, a.src + ocn, rsbn, validn);
+                wf::cheb_bwd_pass<R, NL, CH, 0, false>(c, S, T, a.dst + og, rsg, valid, lane, a.src + oc, rsb, valid);
+                wf::cheb_bwd_pass<R, NL, CH, 1, true>(c, S, T, a.dst2 + og, rsg, valid, lane, a.src + ocn, rsbn, validn);
             } else {
-                wf::cheb_bwd_pass<R, NL, CH, (KIND == 2 ? 2 : 0), true>(c, S, T, a.dst + og, rsb, valid, lane, a.src + ocn, rsbn,
+                wf::cheb_bwd_pass<R, NL, CH, (KIND == 2 ? 2 : 0), true>(c, S, T, a.dst + og, rsg, valid, lane, a.src + ocn, rsbn,
                                                                       validn);
             }
             oc = ocn;
@@ -177,10 +184,18 @@ wave_rfft_kernel(FftDev p, WaveArgs a) {
         unsigned o, tb;
         a.fd_tpo.divmod(tile, o, tb);
         const long pair0 = 4L * tb;
-        const long oc = ((long)o * M) * inner + 2 * pair0, og = ((long)o * N) * inner + 2 * pair0;
+        long oc = ((long)o * M) * inner + 2 * pair0;
+        const long og = ((long)o * N) * inner + 2 * pair0;
+        unsigned rsb64 = 64u * rsb;
+        if (p.xb) {
+            // coefficient side = the stage array [comp][kx / 64][z][kx % 64][ky], o = comp * gz + z (p.xb = gz)
+            const unsigned comp = o / p.xb, z = o - comp * p.xb;
+            oc = ((long)comp * M * p.xb + 64L * z) * inner + 2 * pair0;
+            rsb64 = (unsigned)(64u * p.xb) * rsb;
+        }
         const bool valid = pair0 + p4 < a.npairs;
-        if (RKIND == 3) wf::rfft_fwd_tile<R>(a.src + og, a.dst + oc, rsb, valid, S, s_tw, lane);
-        else wf::rfft_bwd_tile<R, (RKIND == 3 ? 0 : RKIND)>(a.src + oc, a.dst + og, (RKIND == 2) ? a.dst2 + og : nullptr, rsb, valid,
+        if (RKIND == 3) wf::rfft_fwd_tile<R>(a.src + og, a.dst + oc, rsb, rsb64, valid, S, s_tw, lane);
+        else wf::rfft_bwd_tile<R, (RKIND == 3 ? 0 : RKIND)>(a.src + oc, a.dst + og, (RKIND == 2) ? a.dst2 + og : nullptr, rsb, rsb64, valid,
                                                             (RKIND == 2) ? p.dscale2 : p.dscale, S, s_tw, lane);
     }
 }
@@ -207,6 +222,16 @@ int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, lon
     static const int env_tpw = getenv("DDH_FFT_TPW") ? atoi(getenv("DDH_FFT_TPW")) : 0;
     static const int env_wsync = getenv("DDH_FFT_WSYNC") ? atoi(getenv("DDH_FFT_WSYNC")) : -1;
     if (d.dbg || d.prof) return 1;
+    if (d.xb) {
+        // x-blocked stage layout: shapes it is defined for (the caller falls back to an error, never to another layout)
+        if (mode == CHEB_FWD || mode == CHEB_BWD) {
+            if ((d.xb & 7) || inner % d.xb || (inner / d.xb) % 64) return 1;
+        } else if (mode == RFFT_FWD || mode == RFFT_BWD) {
+            if (outer % d.xb || d.M % 64 || (unsigned long)d.xb * 64UL * (unsigned long)inner * 8UL * (unsigned long)(d.M / 64) >= 0xffffffffUL) return 1;
+        } else {
+            return 1;
+        }
+    }
     if (d.ctile_nseg && (mode != CHEB_FWD || inner % (8L * d.ctile_nseg) || (inner / (8L * d.ctile_nseg)) % 8)) return 1;
     const bool cheb = (mode == CHEB_FWD || mode == CHEB_BWD), rfft = (mode == RFFT_FWD || mode == RFFT_BWD);
     if (!cheb && !rfft) return 1;

@@ -371,8 +371,8 @@ DDH_DEV void cheb_bwd_pass(double2 (&c)[NLC], double2 *S, const ChebTabs &T, dou
 // Forward: grid rows -> coefficients k = q + 16 t, t < NST (Mk = 16 NST), optional conversion bands.
 // S: max(8 R * 4, 16 NST * 4, WfftBuf size) elements.
 template <int R, int NST, int CH>
-DDH_DEV void cheb_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, bool pvalid, double2 *S, const ChebTabs &T,
-                           int lane) {
+DDH_DEV void cheb_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, unsigned rsbd, bool pvalid, double2 *S,
+                           const ChebTabs &T, int lane) {      // rsb: bytes between grid rows (src), rsbd: coefficient rows (dst)
     constexpr int N = 16 * R, RQ = R / 4, Mk = 16 * NST, H8 = 8 * R;
     WF_OPAQUE_LANE(lane);
     const Lane L = make_lane(lane);
@@ -453,11 +453,11 @@ DDH_DEV void cheb_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, boo
             acc[t] = o;
         }
     }
-    WF_OPAQUE_U32(rsb);
+    WF_OPAQUE_U32(rsbd);
     if (pvalid) {
-        const unsigned o0 = (unsigned)L.q * rsb + 16u * (unsigned)L.p;
+        const unsigned o0 = (unsigned)L.q * rsbd + 16u * (unsigned)L.p;
 #pragma unroll
-        for (int t = 0; t < NST; ++t) gstore(dst_t, o0 + (unsigned)(16 * t) * rsb, acc[t]);
+        for (int t = 0; t < NST; ++t) gstore(dst_t, o0 + (unsigned)(16 * t) * rsbd, acc[t]);
     }
 }
 
@@ -489,8 +489,11 @@ struct RfftWaveLds {
 // Backward.  tw[m] = exp(-2 pi i m / N).  BK: 0 plain transform into dst_t; 1 differentiated (spectrum times i kappa,
 // kappa = dsc * k) into dst_t; 2 both from one read of the coefficients: plain into dst_t, differentiated into dst2_t.
 template <int R, int BK>
-DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, unsigned rsb, bool pvalid, double dsc,
-                           double2 *S, const double2 *tw, int lane) {
+// Coefficient rows k of a tile sit at (k / 64) * rsb64 + (k % 64) * rsb bytes: rsb64 = 64 rsb is the natural layout
+// [kx][ky]; the x-blocked stage layout [kx / 64][z][kx % 64][ky] (ddh_fft_set_stage_layout) has the z planes of a block
+// of 64 rows in between.  The lane's rows are 2 q + 32 t (+ 1), q < 16: block t / 2, row 32 (t % 2) + 2 q (+ 1) inside it.
+DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, unsigned rsb, unsigned rsb64, bool pvalid,
+                           double dsc, double2 *S, const double2 *tw, int lane) {
     constexpr int H = 16 * R;                            // N / 3 = modes per pair incl. k = 0
     WF_OPAQUE_LANE(lane);
     const Lane L = make_lane(lane);
@@ -498,11 +501,13 @@ DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, u
     {
         double2 c[R], s[R];
         WF_OPAQUE_U32(rsb);
+        WF_OPAQUE_U32(rsb64);
         const unsigned o0 = (unsigned)(2 * L.q) * rsb + (pvalid ? 16u * (unsigned)L.p : 0u);
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-            c[t] = gload(src_t, o0 + (unsigned)(32 * t) * rsb);
-            s[t] = gload(src_t, o0 + (unsigned)(32 * t + 1) * rsb);
+            const unsigned ob = (unsigned)(t >> 1) * rsb64 + (unsigned)(32 * (t & 1)) * rsb;
+            c[t] = gload(src_t, o0 + ob);
+            s[t] = gload(src_t, o0 + ob + rsb);
         }
         // the partner mode H - k sits in another lane: two half exchanges through LDS, [cos | msin][mode][pair]
 #pragma unroll
@@ -617,8 +622,8 @@ DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, u
 // so both halves of the spectrum accumulate in the lane that owns F_r[j] (the wfft output slot) and one natural-order
 // exchange at the end hands X[k], X[N - k] to the lane that stores mode k.
 template <int R>
-DDH_DEV void rfft_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, bool pvalid, double2 *S, const double2 *tw,
-                           int lane) {
+DDH_DEV void rfft_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, unsigned rsb64, bool pvalid, double2 *S,
+                           const double2 *tw, int lane) {      // rsb64: see rfft_bwd_tile (coefficient side = dst here)
     constexpr int H = 16 * R, N = 3 * H, RQ = R / 4;
     static_assert((H & (H - 1)) == 0, "N / 3 must be a power of two here");
     const double s3 = 0.86602540378443864676372317075293618;
@@ -676,6 +681,7 @@ DDH_DEV void rfft_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, boo
         for (int i = 0; i < RQ; ++i) S[(R * (L.q0 + 4 * a0) + RQ * L.q1 + i) * 4 + L.p] = Q[a0 * RQ + i];
     WF_SYNC();
     WF_OPAQUE_U32(rsb);
+    WF_OPAQUE_U32(rsb64);
     const double invN = 1.0 / (double)N;
     const unsigned o0 = (unsigned)(2 * L.q) * rsb + 16u * (unsigned)L.p;
     const double2 *Sm = S + (16 - L.q) * 4 + L.p;
@@ -689,8 +695,9 @@ DDH_DEV void rfft_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, boo
             s = make_double2(0.0, 0.0);
         }
         if (pvalid) {
-            gstore(dst_t, o0 + (unsigned)(32 * t) * rsb, c);
-            gstore(dst_t, o0 + (unsigned)(32 * t + 1) * rsb, s);
+            const unsigned ob = (unsigned)(t >> 1) * rsb64 + (unsigned)(32 * (t & 1)) * rsb;
+            gstore(dst_t, o0 + ob, c);
+            gstore(dst_t, o0 + ob + rsb, s);
         }
     }
 }

@@ -175,22 +175,40 @@ class HipExecutor:
                 raise NotImplementedError(kind)
         return self._plans[spec]
 
-    def transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0, tiled_row=0):
+    def transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0, tiled_row=0, xb=0):
         """tiled_row (forward Chebyshev only): dst rows of `inner` = nx * tiled_row doubles are written tile-major
-        (ddh_cheb_forward_tiled)."""
+        (ddh_cheb_forward_tiled).  xb: the stage array of this transform (grid side of a Chebyshev, coefficient side of a
+        real-Fourier transform) is x-blocked: row length ny / z planes gz (ddh_fft_set_stage_layout), 0 = natural."""
         if self.timer is not None:
             name = "%s_%s_%s" % (spec[0], direction, "strided" if inner > 1 else "contig")
             return self.timer.run(name, (src.numel() + dst.numel()) * 8, self._transform, spec, basis, direction,
-                                  src, dst, outer, inner, deriv, tiled_row)
-        return self._transform(spec, basis, direction, src, dst, outer, inner, deriv, tiled_row)
+                                  src, dst, outer, inner, deriv, tiled_row, xb)
+        return self._transform(spec, basis, direction, src, dst, outer, inner, deriv, tiled_row, xb)
+
+    def _stage_layout(self, h, value):
+        """x-blocked stage layout of a plan (ddh_fft_set_stage_layout); the library call only when the value changes."""
+        cur = self.__dict__.setdefault("_layouts", {})
+        if cur.get(h.value, 0) != int(value):
+            libhip.call("ddh_fft_set_stage_layout", h, int(value))
+            cur[h.value] = int(value)
+
+    def stage_layout_ok(self, zspec, xspec, nx, ny):
+        """Can the array between the z and the x transforms be x-blocked?  (both run as strided wave kernels)"""
+        return (zspec[0] == "cheb" and (int(zspec[1]), int(zspec[2])) == (384, 256) and xspec[0] == "rfft"
+                and (int(xspec[1]), int(xspec[2])) in ((768, 512), (384, 256)) and nx % 64 == 0 and ny % 8 == 0
+                and int(xspec[2]) == nx)
 
     def tiled_forward_ok(self, spec, basis, inner, row_len):
         """Can `transform(..., "forward", tiled_row=row_len)` run?  (the strided-axis wave kernel's sizes)"""
         return (spec[0] == "cheb" and int(spec[1]) == 384 and int(spec[2]) == 256 and inner > 1
                 and row_len % 8 == 0 and inner % row_len == 0 and (inner // row_len) % 8 == 0)
 
-    def _transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0, tiled_row=0):
+    def _transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0, tiled_row=0, xb=0):
         kind, h, h2 = self._plan(spec, basis)
+        if kind in ("cheb", "rfft") and inner > 1:
+            self._stage_layout(h, xb)
+        elif xb:
+            raise NotImplementedError("x-blocked stage layout: strided Chebyshev / real-Fourier transforms only")
         if tiled_row:
             if kind != "cheb" or direction != "forward":
                 raise NotImplementedError("tile-major output: forward Chebyshev transforms only")
@@ -206,35 +224,39 @@ class HipExecutor:
         else:
             libhip.call("ddh_%s_%s" % (kind, direction), h, ptr(src), ptr(dst), outer, inner, self.dev.stream)
 
-    def transform_dual(self, spec, basis, src, dst, dst_deriv, outer, inner, dscale):
+    def transform_dual(self, spec, basis, src, dst, dst_deriv, outer, inner, dscale, xb=0):
         """dst = backward RealFourier transform of src, dst_deriv = the same of d/dx src: one read of the coefficients
         (ddh_rfft_backward_dual)."""
         if self.timer is not None:
             nb = (src.numel() + dst.numel() + dst_deriv.numel()) * 8
             return self.timer.run("rfft_backward_%s_dual" % ("strided" if inner > 1 else "contig"), nb,
-                                  self._transform_dual, spec, basis, src, dst, dst_deriv, outer, inner, dscale)
-        return self._transform_dual(spec, basis, src, dst, dst_deriv, outer, inner, dscale)
+                                  self._transform_dual, spec, basis, src, dst, dst_deriv, outer, inner, dscale, xb)
+        return self._transform_dual(spec, basis, src, dst, dst_deriv, outer, inner, dscale, xb)
 
-    def _transform_dual(self, spec, basis, src, dst, dst_deriv, outer, inner, dscale):
+    def _transform_dual(self, spec, basis, src, dst, dst_deriv, outer, inner, dscale, xb=0):
         kind, h, _ = self._plan(spec, basis)
         if kind != "rfft":
             raise NotImplementedError("dual transform: RealFourier axes only")
+        if inner > 1:
+            self._stage_layout(h, xb)
         libhip.call("ddh_rfft_backward_dual", h, ptr(src), ptr(dst), ptr(dst_deriv), outer, inner, float(dscale),
                     self.dev.stream)
 
-    def transform_dual_z(self, spec, basis, src, dst, dst_deriv, dvec, outer, inner):
+    def transform_dual_z(self, spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb=0):
         """dst = backward Chebyshev transform of src (the family's own basis), dst_deriv = backward transform, in `basis`
         (the derivative's basis), of the one-superdiagonal operator dvec applied to src (ddh_cheb_backward_dual)."""
         if self.timer is not None:
             nb = (src.numel() + dst.numel() + dst_deriv.numel()) * 8
             return self.timer.run("cheb_backward_%s_dual" % ("strided" if inner > 1 else "contig"), nb,
-                                  self._transform_dual_z, spec, basis, src, dst, dst_deriv, dvec, outer, inner)
-        return self._transform_dual_z(spec, basis, src, dst, dst_deriv, dvec, outer, inner)
+                                  self._transform_dual_z, spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb)
+        return self._transform_dual_z(spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb)
 
-    def _transform_dual_z(self, spec, basis, src, dst, dst_deriv, dvec, outer, inner):
+    def _transform_dual_z(self, spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb=0):
         kind, h, _ = self._plan(spec, basis)
         if kind != "cheb":
             raise NotImplementedError("dual z transform: Chebyshev-family axes only")
+        if inner > 1:
+            self._stage_layout(h, xb)
         libhip.call("ddh_cheb_backward_dual", h, ptr(src), ptr(dst), ptr(dst_deriv), ptr(dvec), outer, inner,
                     self.dev.stream)
 

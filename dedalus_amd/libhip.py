@@ -85,6 +85,7 @@ SIGNATURES = {
     "ddh_plan_cheb": [_hp, _i, _i, _i, _ip, _dp],
     "ddh_cheb_forward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_cheb_forward_tiled": [_h, _vp, _vp, _l, _l, _l, _vp],
+    "ddh_fft_set_stage_layout": [_h, _l],
     "ddh_cheb_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_plan_mmt": [_hp, _i, _i, _dp],
     "ddh_mmt_apply": [_h, _vp, _vp, _l, _l, _vp],

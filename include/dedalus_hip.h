@@ -107,6 +107,21 @@ int ddh_cheb_forward(ddh_handle plan, const double *g, double *c, long outer, lo
  * addresses differ.  nx and row_len multiples of 8; strided-axis wave kernel sizes only (N = 384, M = 256), an error
  * otherwise; not in place.                                                                                            */
 int ddh_cheb_forward_tiled(ddh_handle plan, const double *g, double *c, long outer, long inner, long row_len, void *stream);
+/* x-blocked STAGE layout.  On a three-axis problem the array between the z (Chebyshev) and the x (real Fourier) transforms
+ * is [comp][z][kx][ky] in the natural layout: consecutive rows of a z line are a whole [kx][ky] plane (2 MiB at 512 x 512)
+ * apart, one page per 64-byte row segment.  In the x-blocked layout [comp][kx / 64][z][kx % 64][ky] they are 64 ky-rows
+ * (256 KiB) apart, and the rows of an x line are 64 contiguous rows per block.  It exists only between two transforms:
+ *   Chebyshev plan,    value = ny (row length in doubles): the GRID side of every strided transform of the plan
+ *                      (output of ddh_cheb_backward / _dual, input of ddh_cheb_forward / _tiled) is x-blocked
+ *   real-Fourier plan, value = gz (z planes per component): the COEFFICIENT side of every strided transform of the plan
+ *                      (input of ddh_rfft_backward / _deriv / _dual, output of ddh_rfft_forward) is x-blocked;
+ *                      outer = components * gz
+ *   value = 0 restores the natural layout.  The setting stays until changed and applies to STRIDED-axis transforms only
+ * (a contiguous-axis transform of the same plan -- the y axis of a cubic box shares the x axis' plan -- ignores it);
+ * strided transforms that cannot honour it (sizes the wave kernels are not instantiated for) return an error instead of
+ * using another layout.  Values are
+ * those of the plain transforms (core/transforms.py:469-565, 801-902), only addresses differ.                        */
+int ddh_fft_set_stage_layout(ddh_handle plan, long value);
 int ddh_cheb_backward(ddh_handle plan, const double *c, double *g, long outer, long inner, void *stream);
 
 /* Dense matrix-multiply transform along an axis (JacobiMMT core/transforms.py:114-158 via

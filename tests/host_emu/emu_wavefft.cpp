@@ -121,7 +121,7 @@ static void cheb_fwd(const EmuTabs &e, const double *src, double *dst, long oute
         for (long tile = 0; tile < ntiles; ++tile) {
             const long o = tile / tpo, tb = tile % tpo;
             const bool valid = 4 * tb + L.p < npairs;
-            cheb_fwd_tile<R, NL, CH>(src + (o * N) * inner + 8 * tb, dst + (o * e.M) * inner + 8 * tb, (unsigned)(inner * 8), valid, S.data(), T, lane);
+            cheb_fwd_tile<R, NL, CH>(src + (o * N) * inner + 8 * tb, dst + (o * e.M) * inner + 8 * tb, (unsigned)(inner * 8), (unsigned)(inner * 8), valid, S.data(), T, lane);
         }
     });
 }
@@ -186,9 +186,9 @@ static void rfft_bwd(const double *tw, bool dual, double dsc, double dsc2, const
             const double *st = src + (o * M) * inner + 8 * tb;
             double *d1 = dst + (o * N) * inner + 8 * tb, *d2 = dual ? dst2 + (o * N) * inner + 8 * tb : nullptr;
             const double2 *twp = reinterpret_cast<const double2 *>(tw);
-            if (dual) rfft_bwd_tile<R, 2>(st, d1, d2, (unsigned)(inner * 8), valid, dsc2, S.data(), twp, lane);
-            else if (dsc != 0.0) rfft_bwd_tile<R, 1>(st, d1, d2, (unsigned)(inner * 8), valid, dsc, S.data(), twp, lane);
-            else rfft_bwd_tile<R, 0>(st, d1, d2, (unsigned)(inner * 8), valid, 0.0, S.data(), twp, lane);
+            if (dual) rfft_bwd_tile<R, 2>(st, d1, d2, (unsigned)(inner * 8), (unsigned)(inner * 8 * 64), valid, dsc2, S.data(), twp, lane);
+            else if (dsc != 0.0) rfft_bwd_tile<R, 1>(st, d1, d2, (unsigned)(inner * 8), (unsigned)(inner * 8 * 64), valid, dsc, S.data(), twp, lane);
+            else rfft_bwd_tile<R, 0>(st, d1, d2, (unsigned)(inner * 8), (unsigned)(inner * 8 * 64), valid, 0.0, S.data(), twp, lane);
         }
     });
 }
@@ -202,7 +202,7 @@ static void rfft_fwd(const double *tw, const double *src, double *dst, long oute
         for (long tile = 0; tile < ntiles; ++tile) {
             const long o = tile / tpo, tb = tile % tpo;
             const bool valid = 4 * tb + (lane & 3) < npairs;
-            rfft_fwd_tile<R>(src + (o * N) * inner + 8 * tb, dst + (o * M) * inner + 8 * tb, (unsigned)(inner * 8), valid, S.data(),
+            rfft_fwd_tile<R>(src + (o * N) * inner + 8 * tb, dst + (o * M) * inner + 8 * tb, (unsigned)(inner * 8), (unsigned)(inner * 8 * 64), valid, S.data(),
                              reinterpret_cast<const double2 *>(tw), lane);
         }
     });

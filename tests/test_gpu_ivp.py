@@ -304,3 +304,31 @@ def test_tile_major_right_hand_sides_change_addresses_not_values(monkeypatch):
     for k in a:
         assert np.isfinite(a[k]).all(), k
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_x_blocked_stage_layout_changes_addresses_not_values(monkeypatch):
+    """The arrays between the z and the x transforms stored [kx / 64][z][kx % 64][ky] (ddh_fft_set_stage_layout,
+    Transformer.stage_xb) against the natural layout (DDH_NO_STAGE_XB): same arithmetic, bit-identical end states; the
+    Hermitian-symmetry round trip of the first steps and a full-grid read-back go through the same stage arrays."""
+    import dedalus_amd.public as d3
+
+    def run(xb):
+        if xb:
+            monkeypatch.delenv("DDH_NO_STAGE_XB", raising=False)
+        else:
+            monkeypatch.setenv("DDH_NO_STAGE_XB", "1")
+        solver, f = problems.rayleigh_benard_3d(d3, Nx=256, Ny=256, Nz=256, timestepper="RK222")
+        dom = f["b"].domain
+        assert (solver.dist.transformer.stage_xb(dom, dom.dealias) is not None) == xb
+        for _ in range(2):
+            solver.step(1e-3)
+        out = {k: np.array(f[k]["c"]) for k in ("p", "b", "u")}
+        f["b"].change_scales(1.5)
+        out["b_grid"] = np.array(f["b"]["g"])
+        del solver, f
+        return out
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), k
