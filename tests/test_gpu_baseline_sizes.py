@@ -174,3 +174,48 @@ def test_shell_explicit_half_against_the_reference_at_config_size():
     worst = explicit_check.check_shell(d3, (256, 128, 128), tol=1e-11)
     print("shell explicit half at 256 x 128 x 128: max error", worst)
     assert worst < 1e-11
+
+
+def test_full_spectrum_transforms_at_the_metric_size_against_the_series():
+    """512 x 512 x 256 with EVERY mode populated (the band-limited explicit-half check fills 16^3 of them): the backward
+    transforms (z Chebyshev, x and y real Fourier, 3/2 padding) of seeded random coefficients, compared at sampled grid
+    points with the direct summation of the series -- the reference's matrix definitions of the transforms
+    (core/transforms.py:114-158, 387-424, restated in oracle/np_transforms.py and pinned to the reference's goldens) --
+    and the forward transforms through the round trip of the same full-spectrum data.  A vector field exercises the
+    dual / multi-component launches."""
+    import dedalus_amd.public as d3
+    from oracle import np_transforms as T
+    N = (512, 512, 256)
+    coords = d3.CartesianCoordinates('x', 'y', 'z')
+    dist = d3.Distributor(coords, dtype=np.float64)
+    bases = (d3.RealFourier(coords['x'], size=N[0], bounds=(0, 4), dealias=3 / 2),
+             d3.RealFourier(coords['y'], size=N[1], bounds=(0, 4), dealias=3 / 2),
+             d3.ChebyshevT(coords['z'], size=N[2], bounds=(0, 1), dealias=3 / 2))
+    u = dist.VectorField(coords, name='u', bases=bases)
+    rng = np.random.default_rng(20)
+    c = rng.standard_normal((3,) + N)
+    c[:, 1, :, :] = 0.0                    # the msin parts of k = 0 are not modes of a real field
+    c[:, :, 1, :] = 0.0
+    u["c"] = c
+    u.change_scales(3 / 2)
+    g = np.array(u["g"])                   # [3][768][768][384]
+    assert g.shape == (3, 768, 768, 384)
+    Bx = T.real_fourier_mmt_matrices(768, 512)[1]
+    By = T.real_fourier_mmt_matrices(768, 512)[1]
+    Bz = T.chebyshev_mmt_matrices(384, 256)[1]
+    scale = np.abs(g).max()
+    worst = 0.0
+    for comp in range(3):
+        for k in rng.choice(384, size=3, replace=False):
+            plane = c[comp] @ Bz[k]                                   # [512][512]: the series summed along z
+            for i, j in zip(rng.choice(768, size=6), rng.choice(768, size=6)):
+                want = Bx[i] @ plane @ By[j]
+                worst = max(worst, abs(g[comp, i, j, k] - want) / scale)
+    print("full-spectrum backward transforms at 512 x 512 x 256 vs the series: max error", worst)
+    assert worst < 1e-12, worst
+    # forward: grid -> coefficients returns the full spectrum
+    u["g"] = g
+    c2 = np.array(u["c"])
+    err = np.abs(c2 - c).max() / np.abs(c).max()
+    print("round trip of the full spectrum:", err)
+    assert err < 1e-12, err
