@@ -11,6 +11,9 @@ LIB = os.path.join(CSRC, "libdedalus_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
+# the band sweeps of ddh_ellband.hip keep their sliding windows in registers: that needs the row loops fully unrolled
+# (up to 96 rows x ~110 multiply-adds), past the default size limit of "#pragma unroll"
+FILE_FLAGS = {"ddh_ellband.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 
 
 def _hipcc():
@@ -46,7 +49,7 @@ def build_library(force=False, verbose=False):
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-6000:]))

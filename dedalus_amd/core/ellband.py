@@ -1,0 +1,227 @@
+"""
+Band structure of per-group LHS systems given as explicit matrices (the shell's per-ell systems).
+
+The reference solves every subproblem with a sparse LU of the matrices it assembles (core/subsystems.py:481-600,
+libraries/matsolvers.py:129-160).  The dense inverses this package used for the curvilinear solvers cost O(n^3) per
+change of the timestep and O(n^2) storage per system; this module finds, ONCE at solver build time, the permutation /
+recombination that turns a M + b L of every group into a narrow band matrix, so that the device factors it with a
+partial-pivoting band LU (csrc/ddh_ellband.hip) in O(n kl (kl + ku)) and sweeps it in O(n (kl + ku)) per right-hand side:
+
+  * boundary rows ("single-point" equations packed along n) couple every radial mode of a variable.  The columns of the
+    variables they touch (components coupled by the same rows form one group, ordered n-major) are recombined,
+    X = P Y with column q of P = e_q + sum_s c_s e_(q-s), so that every boundary row vanishes on the recombined columns;
+    the boundary rows themselves are replaced by the equivalent combinations T = G0^-1 that pick one unknown each.
+  * rows and columns are ordered n-major, every tau column placed where its first entry is (the lift taus meet the
+    last rows of their equations, a constant tau the n = 0 row of its equation);
+  * what remains is measured: kl / ku of the permuted matrix, and the band of P in the permuted order.
+
+Groups whose matrices do not fit the band limits (the ell = 0 system of a shell problem with a pressure gauge: one
+dense row) are left to the dense path; the caller combines both.
+
+Everything here is setup-time host analysis on small matrices (like the assembly of the matrices themselves); the
+per-timestep work -- forming a M + b L, the factorization and the sweeps -- runs on the device.
+"""
+
+import numpy as np
+
+
+class EllBandPlan:
+    """Attributes (nl groups, nmax = largest system, all arrays padded):
+        n[g]               system size (0: no valid modes, or a dense group)
+        dense_groups       groups left to the dense path
+        kl, ku, mp, nbc    band limits over the banded groups: sub / super diagonals of the permuted matrix, super
+                           diagonals of P, boundary rows
+        row_index[g][i]    flat (component * Nr + n) index of permuted row i (-1: padding), col_index likewise
+        T[g]               (nbc, nbc) combination of the boundary rows (identity where there are none)
+        P[g][i][s]         P_perm[i, i + 1 + s], s < mp
+        MB, LB[g][i][d]    permuted, recombined M / L: entry (i, i - kl + d), d < kl + ku + 1
+    """
+
+    def __init__(self, M_of, L_of, row_valid, col_valid, packed_rows, packed_cols, Nr, groups, kl_max=32, w_max=96,
+                 cutoff=1e-12):
+        self.Nr = int(Nr)
+        self.nl = len(row_valid)
+        self.kl_max, self.w_max = int(kl_max), int(w_max)
+        self.cutoff = cutoff
+        per = {}
+        self.dense_groups = []
+        self.why_dense = {}
+        for g in groups:
+            rv, cv = np.asarray(row_valid[g]).reshape(-1), np.asarray(col_valid[g]).reshape(-1)
+            if not rv.any():
+                continue
+            res = self._analyse(M_of(g), L_of(g), rv, cv, packed_rows, packed_cols)
+            if isinstance(res, str):
+                self.dense_groups.append(g)
+                self.why_dense[g] = res
+            else:
+                per[g] = res
+        # a few groups much wider than the rest (the ell = 0 system with its gauge row) would widen the windows of
+        # every group: they go to the dense path as well
+        if per:
+            wmed = np.median([r["kl"] + r["ku"] for r in per.values()])
+            for g in [g for g, r in per.items() if r["kl"] + r["ku"] > 1.5 * wmed]:
+                self.why_dense[g] = "band much wider than the median (kl %d, ku %d)" % (per[g]["kl"], per[g]["ku"])
+                self.dense_groups.append(g)
+                del per[g]
+            self.dense_groups.sort()
+        self.per = per
+        self.n = np.zeros(self.nl, dtype=np.int32)
+        if not per:
+            self.kl = self.ku = self.mp = self.nbc = self.nmax = 0
+            return
+        self.kl = max(r["kl"] for r in per.values())
+        self.ku = max(r["ku"] for r in per.values())
+        self.mp = max(r["mp"] for r in per.values())
+        self.nbc = max(r["T"].shape[0] for r in per.values())
+        self.nmax = max(r["n"] for r in per.values())
+        nl, nmax, W = self.nl, self.nmax, self.kl + self.ku + 1
+        self.row_index = np.full((nl, nmax), -1, dtype=np.int64)
+        self.col_index = np.full((nl, nmax), -1, dtype=np.int64)
+        self.T = np.zeros((nl, max(self.nbc, 1), max(self.nbc, 1)))
+        self.nbc_of = np.zeros(nl, dtype=np.int32)
+        self.P = np.zeros((nl, nmax, max(self.mp, 1)))
+        self.MB = np.zeros((nl, nmax, W))
+        self.LB = np.zeros((nl, nmax, W))
+        for g, r in per.items():
+            n = r["n"]
+            self.n[g] = n
+            self.row_index[g, :n] = r["rows"]
+            self.col_index[g, :n] = r["cols"]
+            k = r["T"].shape[0]
+            self.nbc_of[g] = k
+            self.T[g, :k, :k] = r["T"]
+            for name, dst in (("Mp", self.MB), ("Lp", self.LB)):
+                i, j = np.nonzero(r[name])
+                dst[g, i, j - i + self.kl] = r[name][i, j]
+            i, j = np.nonzero(np.triu(r["Pp"], 1))
+            self.P[g, i, j - i - 1] = r["Pp"][i, j]
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _analyse(self, M, L, rv, cv, packed_rows, packed_cols):
+        Nr = self.Nr
+        ridx, cidx = np.flatnonzero(rv), np.flatnonzero(cv)
+        n = len(ridx)
+        if len(cidx) != n:
+            return "not square"
+        M = M[np.ix_(ridx, cidx)]
+        L = L[np.ix_(ridx, cidx)]
+        rcomp, rn, ccomp, cn = ridx // Nr, ridx % Nr, cidx // Nr, cidx % Nr
+        bc = np.flatnonzero(np.isin(rcomp, packed_rows))
+        tau = np.flatnonzero(np.isin(ccomp, packed_cols))
+        inter_r = np.flatnonzero(~np.isin(rcomp, packed_rows))
+        inter_c = np.flatnonzero(~np.isin(ccomp, packed_cols))
+        if np.any(M[bc] != 0):
+            return "boundary rows with time derivatives"
+        Rb = L[bc]
+        if np.any(Rb[:, tau] != 0):
+            return "boundary rows touch tau columns"
+        # components coupled by boundary rows -> groups of variables that are recombined together
+        comps = sorted(set(ccomp[inter_c].tolist()))
+        parent = {c: c for c in comps}
+
+        def find(c):
+            while parent[c] != c:
+                c = parent[c]
+            return c
+        for k in range(len(bc)):
+            cs = sorted(set(ccomp[np.flatnonzero(Rb[k] != 0)].tolist()))
+            for c in cs[1:]:
+                parent[find(c)] = find(cs[0])
+        groups = {}
+        for c in comps:
+            groups.setdefault(find(c), []).append(c)
+        P = np.eye(n)
+        T = np.eye(len(bc))
+        bc_order, bc_target = [], []                   # boundary rows in the order of the unknowns they end up picking
+        for _, cs in sorted(groups.items()):
+            cols = np.flatnonzero(np.isin(ccomp, cs))
+            cols = cols[np.lexsort((ccomp[cols], cn[cols]))]           # n-major
+            touching = [k for k in range(len(bc)) if np.any(Rb[k, cols] != 0)]
+            m = len(touching)
+            if m == 0:
+                continue
+            if m > len(cols):
+                return "more boundary rows than unknowns"
+            Rv = Rb[np.ix_(touching, cols)]
+            G0 = Rv[:, :m]
+            if np.linalg.cond(G0) > 1e10:
+                return "boundary rows not independent on the leading modes"
+            for q in range(m, len(cols)):
+                G = Rv[:, q - m:q][:, ::-1]                             # columns q-1 ... q-m
+                if np.linalg.cond(G) > 1e10:
+                    return "recombination singular"
+                c = np.linalg.solve(G, -Rv[:, q])
+                P[cols[q - 1 - np.arange(m)], cols[q]] = c
+            T[np.ix_(touching, touching)] = np.linalg.inv(G0)
+            bc_order += touching
+            bc_target += cols[:m].tolist()
+        if sorted(bc_order) != list(range(len(bc))):
+            return "boundary rows without unknowns"
+        Mp, Lp = M @ P, L @ P
+        Lp[bc] = T @ Lp[bc]
+        # by construction the transformed boundary rows are unit rows: set them exactly
+        unit = np.zeros((len(bc), n))
+        unit[bc_order, bc_target] = 1.0
+        if len(bc) and np.abs(Lp[bc] - unit).max() > 1e-8 * max(1.0, np.abs(unit).max()):
+            return "boundary rows do not reduce to unit rows"
+        Lp[bc] = unit
+        for A in (Mp, Lp):                                             # entry_cutoff (core/subsystems.py:536)
+            A[np.abs(A) < self.cutoff] = 0.0
+        # permutation: boundary rows first, then equations n-major; unknowns n-major, tau columns last
+        ri = inter_r[np.lexsort((rcomp[inter_r], rn[inter_r]))]
+        ci = inter_c[np.lexsort((ccomp[inter_c], cn[inter_c]))]
+        # tau columns sit where their entries are: after the unknowns of the first equation row they enter (the lift
+        # taus meet the last rows of their equations; a constant tau, e.g. tau_p, the n = 0 row of its equation)
+        if len(tau):
+            coupled = (Mp[np.ix_(inter_r, tau)] != 0) | (Lp[np.ix_(inter_r, tau)] != 0)
+            first_n = np.array([rn[inter_r][coupled[:, t]].min() if coupled[:, t].any() else Nr for t in range(len(tau))])
+            first_n = np.where(first_n < Nr // 2, first_n, Nr)          # (late ones: simply last)
+            key_n = np.concatenate([cn[ci] + 0.0, first_n + 0.5])
+            order = np.argsort(key_n, kind="stable")
+            cols_all = np.concatenate([ci, tau])[order]
+        else:
+            cols_all = ci
+        pos = {int(c): i for i, c in enumerate(cols_all)}
+        order_k = sorted(range(len(bc)), key=lambda k: pos[int(bc_target[bc_order.index(k)])])
+        rows = np.concatenate([bc[order_k].astype(int), ri])
+        cols = cols_all
+        Tperm = T[np.ix_(order_k, order_k)]
+        Mq, Lq, Pq = Mp[np.ix_(rows, cols)], Lp[np.ix_(rows, cols)], P[np.ix_(cols, cols)]
+        i, j = np.nonzero((Mq != 0) | (Lq != 0))
+        kl, ku = int(max((i - j).max(), 0)), int(max((j - i).max(), 0))
+        i, j = np.nonzero(np.triu(Pq, 1))
+        mp = int((j - i).max()) if len(i) else 0
+        if np.any(np.tril(Pq, -1) != 0):
+            return "recombination not upper triangular in the permuted order"
+        if kl > self.kl_max or kl + ku > self.w_max or mp > kl + ku:
+            return "band too wide (kl %d, ku %d)" % (kl, ku)
+        return dict(n=n, rows=ridx[rows], cols=cidx[cols], T=Tperm, Mp=Mq, Lp=Lq, Pp=Pq, kl=kl, ku=ku, mp=mp)
+
+    # ---- host restatement of what the device does with the plan (tests) --------------------------------------------------
+    def reference_solve(self, g, a, b, rhs_flat):
+        """rhs_flat: (R Nr, nrhs) equation-space right-hand side of group g -> (R Nr, nrhs) solution, through the band
+        path with LAPACK's gbtrf / gbtrs standing in for the device kernels."""
+        from scipy.linalg import lapack
+        n, kl, ku = int(self.n[g]), self.kl, self.ku
+        W = kl + ku + 1
+        A = a * self.MB[g, :n] + b * self.LB[g, :n]                    # [i][d] = entry (i, i - kl + d)
+        ab = np.zeros((2 * kl + ku + 1, n))
+        for d in range(W):
+            i = np.arange(n)
+            j = i - kl + d
+            ok = (j >= 0) & (j < n)
+            ab[kl + ku + i[ok] - j[ok], j[ok]] = A[i[ok], d]
+        lu, piv, info = lapack.dgbtrf(ab, kl, ku)
+        if info:
+            raise np.linalg.LinAlgError("gbtrf info %d" % info)
+        r = rhs_flat[self.row_index[g, :n]].astype(float)
+        k = int(self.nbc_of[g])
+        r[:k] = self.T[g, :k, :k] @ r[:k]
+        y, info = lapack.dgbtrs(lu, kl, ku, r, piv)
+        z = y.copy()
+        for s in range(self.mp):
+            z[:n - 1 - s] += self.P[g, :n - 1 - s, s, None] * y[1 + s:]
+        out = np.zeros_like(rhs_flat, dtype=float)
+        out[self.col_index[g, :n]] = z
+        return out

@@ -1861,9 +1861,52 @@ class ShellInitialValueSolver(IVPLifecycle, ShellSolverBase):
             f.require_grid_space(f.basis.dealias)
             f.require_coeff_space()
 
+    # ---- LHS systems: band LU per ell where the matrices allow it, dense inverses for the rest ---------------------------
+    _band = None                 # None: undecided; False: dense inverses only; dict: the band path
+
+    def _band_setup(self):
+        """Decide once how a M + b L is solved.  core/ellband.py finds the permutation / recombination that makes the
+        per-ell matrices narrow bands; the groups it covers are factorized and swept by csrc/ddh_ellband.hip, the others
+        (the ell = 0 system with its dense gauge row) keep a dense inverse.  DDH_SHELL_DENSE=1: dense inverses for all."""
+        if self._band is None:
+            self._band = False
+            import os
+            if hasattr(self.ex, "make_ell_band") and os.environ.get("DDH_SHELL_DENSE", "0") != "1":
+                from .ellband import EllBandPlan
+                prow = sorted({sc for m in self.emap for (sc, off, nr) in m if nr != self.Nr})
+                pcol = sorted({sc for m in self.vmap for (sc, off, nr) in m if nr != self.Nr})
+                ells = [ell for ell in range(self.nl) if ell >= self.m0]
+                plan = EllBandPlan(lambda g: self._dense(self.M_tl, g), lambda g: self._dense(self.L_tl, g),
+                                   [self.row_valid[:, g, :] for g in range(self.nl)],
+                                   [self.col_valid[:, g, :] for g in range(self.nl)], prow, pcol, self.Nr, ells)
+                if plan.per and plan.nbc <= 8 and plan.mp <= 16:
+                    limit = [2 * min(max(g - self.m0 + 1, 0), self.nm) for g in range(self.nl)]
+                    dev = self.ex.make_ell_band(plan, self.R, 2 * self.nm, self.nl, self.Nr, limit)
+                    dinv = None
+                    if plan.dense_groups:
+                        gs = plan.dense_groups
+                        dinv = self.ex.make_dense_inverse([self._dense(self.M_tl, g) for g in gs],
+                                                          [self._dense(self.L_tl, g) for g in gs],
+                                                          [self.row_valid[:, g, :].reshape(-1) for g in gs],
+                                                          [self.col_valid[:, g, :].reshape(-1) for g in gs], complex_=False)
+                    self._band = dict(plan=plan, dev=dev, dinv=dinv)
+                    logger.info("shell LHS: band LU for %d of %d ell (kl %d, ku %d); dense inverse for ell in %s" % (
+                        len(plan.per), len(ells), plan.kl, plan.ku, plan.dense_groups))
+        return self._band
+
     def factor(self, a, b, reuse=-1):
         old = self._lus[reuse] if (reuse is not None and reuse >= 0) else None
-        inv = self._inverse_terms(a, b, old=old)
+        band = self._band_setup()
+        if band:
+            index = band["dev"].factor(a, b, index=old["index"] if isinstance(old, dict) else None)
+            dense = None
+            if band["dinv"] is not None:
+                flat = band["dinv"].compute(a, b)
+                dense = old["dense"] if isinstance(old, dict) else self.ex.empty(tuple(flat.shape))
+                self.ex.assign(dense, flat)
+            inv = dict(index=index, dense=dense)
+        else:
+            inv = self._inverse_terms(a, b, old=old)
         if not hasattr(self, "_lu_params"):
             self._lu_params = {}
         if reuse is not None and reuse >= 0:
@@ -1875,7 +1918,18 @@ class ShellInitialValueSolver(IVPLifecycle, ShellSolverBase):
         return len(self._lus) - 1
 
     def solve(self, lu, rhs, x):
-        self._lus[lu].apply(rhs, x)
+        inv = self._lus[lu]
+        if isinstance(inv, dict):
+            band = self._band
+            self.ex.fill_zero(x)
+            band["dev"].solve(inv["index"], rhs, x)
+            if inv["dense"] is not None:
+                shape = (self.R, 2 * self.nm, self.nl, self.Nr)
+                n2 = (self.R * self.Nr) ** 2
+                for k, g in enumerate(band["plan"].dense_groups):
+                    self.ex.dense_group_solve(inv["dense"][k * n2:(k + 1) * n2], rhs.reshape(shape), x.reshape(shape), g)
+        else:
+            inv.apply(rhs, x)
         probe = getattr(self, "solve_probe", None)
         if probe is not None:                        # parity checks: keep (a, b, rhs, x) of every solve
             a, b = self._lu_params[lu]

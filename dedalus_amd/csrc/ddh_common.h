@@ -22,7 +22,7 @@ int check_hip(hipError_t e, const char *what);    // 0 or negative
     } while (0)
 
 enum HandleKind : uint32_t { H_FFT = 1, H_MMT = 2, H_PENCIL = 3, H_GMMT = 4, H_STERMS = 5, H_CGEMV = 6, H_ELLT = 7,
-                             H_COMM = 8, H_A2A = 9, H_DENSEINV = 10 };
+                             H_COMM = 8, H_A2A = 9, H_DENSEINV = 10, H_ELLBAND = 11 };
 
 struct HandleBase {
     HandleKind kind;

@@ -358,6 +358,17 @@ class HipExecutor:
         -> object with compute(a, b): concatenated (a M + b L)^-1 on the valid blocks, on the device."""
         return DenseInverse(self, Ms, Ls, row_valid, col_valid, complex_)
 
+    def make_ell_band(self, plan, ncomp, nslots, nl, nr, slot_limit):
+        """Band LU of per-ell systems laid out by core/ellband.py::EllBandPlan (system vectors [ncomp][nslots][nl][nr];
+        slot_limit[g]: leading slots that can hold modes of group g)."""
+        return EllBand(self, plan, ncomp, nslots, nl, nr, slot_limit)
+
+    def dense_group_solve(self, inv, rhs4, x4, g):
+        """x4[:, :, g, :] = inv @ rhs4[:, :, g, :] for one group kept on the dense path (inv: (ncomp nr)^2, device)"""
+        R, S, _, nr = rhs4.shape
+        v = rhs4[:, :, g, :].permute(0, 2, 1).reshape(R * nr, S)
+        x4[:, :, g, :] = (inv.reshape(R * nr, R * nr) @ v).reshape(R, nr, S).permute(0, 2, 1)
+
     def make_cgemv_batch_flat(self, nm, nl, ncomp, flat, old=None):
         """per-m complex matrices given as one concatenated device array (DenseInverse.compute); old: a batch of the same
         shape to refill (a change of the timestep then allocates and frees nothing)"""
@@ -562,6 +573,60 @@ class DenseInverse:
         if bad.value:
             raise libhip.DdhError("%d subproblem matrices are singular (a = %g, b = %g)" % (bad.value, a, b))
         return self._out
+
+    def __del__(self):
+        try:
+            libhip.call("ddh_destroy", self.handle)
+        except Exception:
+            pass
+
+
+class EllBand:
+    """ddh_ellband_*: device band LU + sweeps of the per-ell systems (csrc/ddh_ellband.hip)."""
+
+    def __init__(self, ex, plan, ncomp, nslots, nl, nr, slot_limit):
+        self.ex, self.plan = ex, plan
+        self.shape = (int(ncomp), int(nslots), int(nl), int(nr))
+        comp_stride = nslots * nl * nr
+        g = np.arange(nl)[:, None]
+
+        def offsets(idx):
+            off = (idx // nr) * comp_stride + g * nr + idx % nr
+            return np.ascontiguousarray(np.where(idx >= 0, off, 0), dtype=np.int64)
+        rowoff, coloff = offsets(plan.row_index), offsets(plan.col_index)
+        c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+        self.handle = C.c_uint64(0)
+        lp = lambda a: a.ctypes.data_as(C.POINTER(C.c_long))
+        libhip.call("ddh_ellband_create", C.byref(self.handle), int(nl), int(plan.nmax), int(plan.kl), int(plan.ku),
+                    int(plan.mp), int(plan.nbc), int(nslots), int(nl * nr), libhip.as_ip(c(plan.n, np.int32)),
+                    libhip.as_ip(c(plan.nbc_of, np.int32)), libhip.as_ip(c(slot_limit, np.int32)), lp(rowoff), lp(coloff),
+                    libhip.as_dp(c(plan.T, np.float64)), libhip.as_dp(c(plan.P, np.float64)),
+                    libhip.as_dp(c(plan.MB, np.float64)), libhip.as_dp(c(plan.LB, np.float64)))
+        self.count = 0
+        # algorithmic cost of one solve (every (group, slot) column that can hold modes)
+        cols = float(np.dot(plan.n.astype(np.float64), np.minimum(np.asarray(slot_limit), nslots)))
+        self._flops = 2.0 * (2 * plan.kl + plan.ku + plan.mp) * cols
+        self._bytes = 16.0 * cols + float(plan.n.sum()) * 8 * (2 * plan.kl + plan.ku + 1 + plan.mp)
+
+    def factor(self, a, b, index=None):
+        """-> index of the factorization (index: one to overwrite)"""
+        if index is None:
+            index = self.count
+        bad = C.c_int(0)
+        libhip.call("ddh_ellband_factor", self.handle, int(index), float(a), float(b), C.byref(bad), self.ex.dev.stream)
+        if bad.value:
+            raise libhip.DdhError("%d zero pivots in the band LU (a = %g, b = %g)" % (bad.value, a, b))
+        self.count = max(self.count, index + 1)
+        return index
+
+    def solve(self, index, rhs, x):
+        libhip.note_cost("ddh_ellband_solve", self._flops, self._bytes)
+        libhip.call("ddh_ellband_solve", self.handle, int(index), ptr(rhs), ptr(x), self.ex.dev.stream)
+
+    def info(self):
+        nw, wt, nb = C.c_int(0), C.c_int(0), C.c_long(0)
+        libhip.call("ddh_ellband_info", self.handle, C.byref(nw), C.byref(wt), C.byref(nb))
+        return dict(nw=nw.value, wt=wt.value, factor_bytes=nb.value)
 
     def __del__(self):
         try:

@@ -72,6 +72,10 @@ SIGNATURES = {
     "ddh_ell_terms_prune": [_h, _vp],
     "ddh_ell_blocks_from_dense": [_vp, _vp, _i, _i, _i, _vp],
     "ddh_ell_terms_apply_acc": [_h, _vp, _vp, _i, _vp],
+    "ddh_ellband_create": [_hp, _i, _i, _i, _i, _i, _i, _i, _l, _ip, _ip, _ip, C.POINTER(_l), C.POINTER(_l), _dp, _dp, _dp, _dp],
+    "ddh_ellband_factor": [_h, _i, _d, _d, _ip, _vp],
+    "ddh_ellband_solve": [_h, _i, _vp, _vp, _vp],
+    "ddh_ellband_info": [_h, _ip, _ip, C.POINTER(_l)],
     "ddh_rfft_forward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward_deriv": [_h, _vp, _vp, _l, _l, _d, _vp],

@@ -231,6 +231,27 @@ int ddh_ell_terms_mats(ddh_handle h, double **mats_d);
 int ddh_ell_blocks_from_dense(const double *inv_d, double *mats_d, int nl, int ncomp, int nr, void *stream);
 int ddh_ell_terms_prune(ddh_handle h, void *stream);      /* drop blocks that are zero for every ell from the GEMM */
 
+/* ---- band LU of the curvilinear subproblems (SURVEY 8a row a9 for config H; VERDICT r3 "block-banded LU") ---------
+ * The per-group (shell: per-ell) matrices a M + b L, permuted and column-recombined once on the host
+ * (dedalus_amd/core/ellband.py) into bands of kl sub / ku super diagonals, are formed, factorized (partial pivoting,
+ * gbtrf-shaped) and swept on the device: replaces the reference's per-subproblem sparse LU + solve
+ * (core/timesteppers.py:172-181, 630-640; libraries/matsolvers.py:129-160) at O(n kl (kl + ku)) per factorization and
+ * O(n (kl + ku)) per right-hand side instead of the dense inverse's O(n^3) / O(n^2).
+ * create: nl groups of n_h[g] <= nmax unknowns (0: skipped); rowoff_h / coloff_h [nl][nmax]: element offset of permuted
+ * row / column i inside one slot of the [component][slot][group][n] system vectors (slot_stride elements apart);
+ * slot_limit_h[g]: leading slots that can hold modes of group g; nbc_h[g] <= 8 boundary rows with their combination
+ * T_h [nl][max(nbc,1)]^2; P_h [nl][nmax][max(mp,1)]: super diagonals of the recombination in the permuted order
+ * (mp <= 16); MB_h / LB_h [nl][nmax][kl + ku + 1]: row i holds columns i - kl .. i + ku.
+ * factor: factorization number `index` (== count so far: a new one) of a M + b L; nsingular_h (nullable; syncs) counts
+ * zero pivots.  solve: x = (a M + b L)^-1 rhs on the valid modes of the banded groups (x cleared by the caller). */
+int ddh_ellband_create(ddh_handle *h, int nl, int nmax, int kl, int ku, int mp, int nbc, int nslots, long slot_stride,
+                       const int *n_h, const int *nbc_h, const int *slot_limit_h, const long *rowoff_h,
+                       const long *coloff_h, const double *T_h, const double *P_h, const double *MB_h,
+                       const double *LB_h);
+int ddh_ellband_factor(ddh_handle h, int index, double a, double b, int *nsingular_h, void *stream);
+int ddh_ellband_solve(ddh_handle h, int index, const double *rhs_d, double *x_d, void *stream);
+int ddh_ellband_info(ddh_handle h, int *nw, int *wt, long *factor_bytes);
+
 /* ---- grid-space and vector kernels -------------------------------- */
 /* y[idx[i]] += vals[i] for n distinct indices (device arrays): the constant right-hand-side entries
  * (e.g. "b(z=0) = Lz", gathered into F by gather_outputs core/timesteppers.py:611-614) touch a handful of
