@@ -60,7 +60,7 @@ constexpr int EB_FT = 256;
 __global__ void __launch_bounds__(EB_FT)
 ellband_factor_kernel(const int *__restrict__ n_d, const double *__restrict__ MB, const double *__restrict__ LB, double a,
                       double b, double *__restrict__ Lm, double *__restrict__ U, int *__restrict__ flag, int nmax, int np,
-                      int kl, int ku, int lrow, int wt, int urow) {
+                      int kl, int ku, int lrow, int nmul, int wt, int urow) {
     const int g = blockIdx.x, tid = threadIdx.x;
     const int n = n_d[g];
     if (n == 0) return;
@@ -116,7 +116,7 @@ ellband_factor_kernel(const int *__restrict__ n_d, const double *__restrict__ MB
         }
         const double pv = win[jr * WC + jc];
         const double ipv = pv != 0.0 ? 1.0 / pv : 0.0;
-        if (tid < lrow - 1) {
+        if (tid < nmul) {
             double l = 0.0;
             if (tid < nrows) {
                 int r = jr + 1 + tid;
@@ -166,7 +166,8 @@ ellband_factor_kernel(const int *__restrict__ n_d, const double *__restrict__ MB
 // (two coefficients per LDS instruction, every lane the same address).  A single wave per workgroup is in flight, so
 // the sweep time is its instruction count: the scalar unit's loads would serialize a round trip per row, v_readlane
 // costs two VALU slots per coefficient.
-constexpr int EB_D = 4;          // rows of factor data in flight
+// rows of factor data in flight: a divisor of the window (compile-time ring slots), as deep as the window allows
+constexpr int eb_depth(int) { return 4; }
 constexpr int EB_FLW = 64;       // doubles per forward factor row: [0] pivot offset, [1 .. nw-1] multipliers
 
 // Row tables and factor rows are padded with EB_PAD zero rows per group, so the unrolled row loops run whole blocks
@@ -181,7 +182,8 @@ ellband_forward_kernel(const int *__restrict__ n_d, const int *__restrict__ nbc_
                        const long *__restrict__ rowoff, const double *__restrict__ T, const double *__restrict__ FL,
                        const double *__restrict__ rhs, double *__restrict__ work, int np, int nslots, int nslots_pad,
                        long slot_stride, int nbcmax) {
-    static_assert(NW % EB_D == 0 && NW % 2 == 0 && NW <= EB_FLW, "window: a multiple of the prefetch depth");
+    constexpr int EB_D = eb_depth(NW);
+    static_assert(NW % EB_D == 0 && NW % 2 == 0 && NW + 2 <= EB_FLW, "window: a multiple of the prefetch depth");
     __shared__ double2 ring[EB_FLW / 2];
     const int g = blockIdx.y;
     const int n = n_d[g];
@@ -196,7 +198,7 @@ ellband_forward_kernel(const int *__restrict__ n_d, const int *__restrict__ nbc_
     double *wk = work + (size_t)g * np * nslots_pad + s;
     double *ring_w = reinterpret_cast<double *>(&ring[0]) + lane;
     double bw[NW], fr[EB_D];
-    double2 cf[2][NW / 2];                                      // coefficients of the current / the next row
+    double2 cf[2][NW / 2 + 1];                                  // coefficients of the current / the next row (+ row offset)
     ring_w[0] = Fg[0];
 #pragma unroll
     for (int q = 0; q < EB_D; ++q) fr[q] = Fg[(size_t)(q + 1) * EB_FLW];                 // rows 1 .. EB_D
@@ -206,7 +208,7 @@ ellband_forward_kernel(const int *__restrict__ n_d, const int *__restrict__ nbc_
         bw[q] = (q < n && live) ? v : 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < NW / 2; ++q) cf[0][q] = ring[q];
+    for (int q = 0; q < NW / 2 + 1; ++q) cf[0][q] = ring[q];
     // boundary rows (the first nbc of the permuted order): the combinations T that pick one unknown each
     const int nbc = nbc_d[g];
     if (nbc > 0) {
@@ -230,20 +232,31 @@ ellband_forward_kernel(const int *__restrict__ n_d, const int *__restrict__ nbc_
             const int j = j0 + u;
             const double2 *c = cf[u & 1];
             const int d = __builtin_amdgcn_readfirstlane((int)c[0].x);
-            double y = bw[u];
-            if (d != 0) {                                       // (the one branch of a row: pivot rows are the exception)
+            // Row interchange bw[u] <-> bw[(u + d) % NW], wave-uniform d: pivot rows are the rule in these systems (~80 % of
+            // the columns, offsets up to ~12), so the offset is resolved in two levels of scalar branches (groups of four)
+            // instead of a chain of NW; the empty asm keeps them branches -- as selects they cost 4 NW VALU slots per row.
+            if (d != 0) {
+                asm volatile("");
 #pragma unroll
-                for (int r = 1; r < NW; ++r)
-                    if (d == r) {
-                        y = bw[(u + r) % NW];
-                        bw[(u + r) % NW] = bw[u];
+                for (int gq = 0; gq < (NW + 3) / 4; ++gq)
+                    if ((d >> 2) == gq) {
+                        asm volatile("");
+#pragma unroll
+                        for (int r = 4 * gq; r < 4 * gq + 4; ++r)
+                            if (r >= 1 && r < NW && d == r) {
+                                asm volatile("");
+                                const double tmp = bw[u];
+                                bw[u] = bw[(u + r) % NW];
+                                bw[(u + r) % NW] = tmp;
+                            }
                     }
             }
+            const double y = bw[u];
             // row j + 1: memory -> LDS -> the other coefficient set, while this row's multiply-adds run
             ring_w[0] = fr[u % EB_D];
             fr[u % EB_D] = Fg[(size_t)(j + 1 + EB_D) * EB_FLW];
 #pragma unroll
-            for (int q = 0; q < NW / 2; ++q) cf[(u + 1) & 1][q] = ring[q];
+            for (int q = 0; q < NW / 2 + 1; ++q) cf[(u + 1) & 1][q] = ring[q];
             wk[(size_t)j * nslots_pad] = y;
             bw[(u + 1) % NW] -= c[0].y * y;
 #pragma unroll
@@ -251,14 +264,15 @@ ellband_forward_kernel(const int *__restrict__ n_d, const int *__restrict__ nbc_
                 bw[(u + r) % NW] -= c[r / 2].x * y;
                 if (r + 1 < NW) bw[(u + r + 1) % NW] -= c[r / 2].y * y;
             }
-            const int jn = j + NW;
-            const double v = src[ro[jn]];
-            bw[u] = (jn < n && live) ? v : 0.0;
+            // the row that enters the window: its offset rides in entry NW of this factor row (no scalar load in the loop)
+            const long off = __double_as_longlong(c[NW / 2].x);
+            const double v = src[off];
+            bw[u] = (j + NW < n && live) ? v : 0.0;
         }
     }
 }
 
-// WT: solved unknowns kept (kl + ku <= WT, a multiple of EB_D); a backward factor row is WT + 1 entries of U
+// WT: solved unknowns kept (kl + ku <= WT, even); a backward factor row is WT + 1 entries of U
 // (1 / diagonal first) followed by the EB_MP super diagonals of the recombination, padded to NV * 64 doubles.
 // The sweep starts `pad` rows past the end (zero factor rows, results to the dump word) so that it ends on row 0
 // with whole blocks.
@@ -267,9 +281,11 @@ __global__ void __launch_bounds__(64)
 ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slot_limit, const long *__restrict__ coloff,
                         const double *__restrict__ FU, const double *__restrict__ work, double *__restrict__ x,
                         double *__restrict__ dump, int np, int nslots, int nslots_pad, long slot_stride) {
+    constexpr int EB_D = eb_depth(WT);
     static_assert(WT % EB_D == 0 && WT % 2 == 0, "window: a multiple of the prefetch depth");
-    constexpr int NV = (WT + 1 + EB_MP + 63) / 64;
+    constexpr int NV = (WT + 1 + EB_MP + 2 + 63) / 64;
     constexpr int RW = NV * 64;
+    constexpr int NC = (WT + 1 + EB_MP + 1) / 2 + 1;          // double2 pairs of a row in use: U, recombination, column offset
     __shared__ double2 ring[2][RW / 2];
     const int g = blockIdx.y;
     const int n = n_d[g];
@@ -278,9 +294,9 @@ ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slo
     const int lane = threadIdx.x;
     const int s = blockIdx.x * 64 + lane;
     const bool own = s < nslots;                               // lanes past the last slot write to the dump word
-    double *dst = own ? x + (size_t)s * slot_stride : dump + lane;
-    double *dmp = dump + lane;
-    const long *co = coloff + (size_t)g * np;
+    const unsigned long long dmp_a = reinterpret_cast<unsigned long long>(dump + lane);
+    const unsigned long long dst_a = own ? reinterpret_cast<unsigned long long>(x + (size_t)s * slot_stride) : dmp_a;
+    const long ownm = own ? -1L : 0L;
     const double *Fg = FU + (size_t)g * np * RW + lane;
     const double *wk = work + (size_t)g * np * nslots_pad + s;
     double *ring_w = reinterpret_cast<double *>(&ring[0][0]) + lane;
@@ -303,6 +319,7 @@ ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slo
         for (int u = 0; u < WT; ++u) {
             const int i = top - (b * WT + u);
             // row t + 1 -> the other half of the ring; row t + 1 + EB_D and the right-hand side of t + EB_D leave memory
+            const double2 *row = ring[u & 1];
 #pragma unroll
             for (int v = 0; v < NV; ++v) ring_w[((u + 1) & 1) * RW + v * 64] = fr[u % EB_D][v];
             const double w = wr[u % EB_D];
@@ -312,7 +329,6 @@ ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slo
                 for (int v = 0; v < NV; ++v) fr[u % EB_D][v] = Fg[(size_t)ip * RW + v * 64];
                 wr[u % EB_D] = wk[(size_t)max(i - EB_D, 0) * nslots_pad];
             }
-            const double2 *row = ring[u & 1];
             // oldest unknowns first: only the last multiply-add of a row waits for the row before it
             double a0 = i < n ? w : 0.0, a1 = 0.0;
 #pragma unroll
@@ -333,26 +349,35 @@ ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slo
                 z1 += c.x * yw[(u - s1 + 2 * WT) % WT];
             }
             z0 += row[WT / 2].y * yw[(u - 1 + 2 * WT) % WT];
-            double *to = i < n ? dst + (own ? co[i] : 0) : dmp;
-            *to = (z0 + z1) + y;
+            // column offset: the entry after the recombination band (no scalar load in the loop); integer selects, a
+            // conditional store would put a branch into every row
+            const long off = __double_as_longlong(row[NC - 1].x);
+            const long keep = -(long)(i < n);
+            const unsigned long long to = dmp_a + ((dst_a - dmp_a + (unsigned long long)((off & ownm) << 3)) & (unsigned long long)keep);
+            *reinterpret_cast<double *>(to) = (z0 + z1) + y;
             yw[u] = y;
         }
     }
 }
 
-// recombination band -> the tail of the backward factor rows (once per factorization storage)
-__global__ void ellband_fill_p_kernel(const double *__restrict__ P, double *__restrict__ FU, long rows, int wt, int nv) {
+// Once per factorization storage: the recombination band and the column offset of row i behind its U entries; the
+// offset of the row that enters the forward window (j + nw) behind the multipliers of column j.
+__global__ void ellband_fill_rows_kernel(const double *__restrict__ P, const long *__restrict__ rowoff,
+                                         const long *__restrict__ coloff, double *__restrict__ FL, double *__restrict__ FU,
+                                         int nl, int np, int nw, int wt, int nv, int nc) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= rows * EB_MP) return;
-    const long r = e / EB_MP;
-    const int sidx = (int)(e % EB_MP);
-    FU[r * (nv * 64) + wt + 1 + sidx] = P[r * EB_MP + sidx];
+    if (e >= (long)nl * np) return;
+    const int i = (int)(e % np);
+    for (int sd = 0; sd < EB_MP; ++sd) FU[e * (nv * 64) + wt + 1 + sd] = P[e * EB_MP + sd];
+    FU[e * (nv * 64) + 2 * (nc - 1)] = __longlong_as_double(coloff[e]);
+    FL[e * EB_FLW + nw] = __longlong_as_double(i + nw < np ? rowoff[e + nw] : 0L);
 }
 
 struct EbVariant { int nw, wt; };
 static const EbVariant eb_variants[] = {{12, 24}, {20, 40}, {28, 56}, {36, 64}, {36, 96}};
 
-static inline int eb_nv(int wt) { return (wt + 1 + EB_MP + 63) / 64; }
+static inline int eb_nv(int wt) { return (wt + 1 + EB_MP + 2 + 63) / 64; }
+static inline int eb_nc(int wt) { return (wt + 1 + EB_MP + 1) / 2 + 1; }
 
 #ifdef DDH_EB_ABLATE      // measurement builds: DDH_EB_ABL bit 0 / 1 = coalesced (wrong) addressing of the gather / scatter
 static int eb_abl() { const char *e = getenv("DDH_EB_ABL"); return e ? atoi(e) : 0; }
@@ -442,8 +467,9 @@ int ddh_ellband_factor(ddh_handle h, int index, double a, double b, int *nsingul
         DDH_HIP(hipMalloc((void **)&lu.U, sizeof(double) * rows * eb_nv(p->wt) * 64));
         DDH_HIP(hipMemsetAsync(lu.Lm, 0, sizeof(double) * rows * EB_FLW, as_stream(stream)));
         DDH_HIP(hipMemsetAsync(lu.U, 0, sizeof(double) * rows * eb_nv(p->wt) * 64, as_stream(stream)));
-        hipLaunchKernelGGL(ellband_fill_p_kernel, dim3((unsigned)((rows * EB_MP + 255) / 256)), dim3(256), 0,
-                           as_stream(stream), p->P_d, lu.U, (long)rows, p->wt, eb_nv(p->wt));
+        hipLaunchKernelGGL(ellband_fill_rows_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream),
+                           p->P_d, p->rowoff_d, p->coloff_d, lu.Lm, lu.U, p->nl, p->np, p->nw, p->wt, eb_nv(p->wt),
+                           eb_nc(p->wt));
         p->lus.push_back(lu);
     }
     const EllBandLu &lu = p->lus[index];
@@ -451,7 +477,7 @@ int ddh_ellband_factor(ddh_handle h, int index, double a, double b, int *nsingul
     DDH_HIP(hipMemsetAsync(p->flag_d, 0, sizeof(int), st));
     const size_t lds = sizeof(double) * ((size_t)(p->kl + 1) * (p->kl + p->ku + 1) + p->kl + 1);
     hipLaunchKernelGGL(ellband_factor_kernel, dim3(p->nl), dim3(EB_FT), lds, st, p->n_d, p->MB_d, p->LB_d, a, b, lu.Lm, lu.U,
-                       p->flag_d, p->nmax, p->np, p->kl, p->ku, EB_FLW, p->wt, eb_nv(p->wt) * 64);
+                       p->flag_d, p->nmax, p->np, p->kl, p->ku, EB_FLW, p->nw - 1, p->wt, eb_nv(p->wt) * 64);
     DDH_HIP(hipGetLastError());
     if (nsingular_h) {
         DDH_HIP(hipMemcpyAsync(nsingular_h, p->flag_d, sizeof(int), hipMemcpyDeviceToHost, st));
