@@ -23,6 +23,7 @@ per-timestep work -- forming a M + b L, the factorization and the sweeps -- runs
 """
 
 import numpy as np
+from scipy import sparse
 
 
 class EllBandPlan:
@@ -44,6 +45,7 @@ class EllBandPlan:
         self.kl_max, self.w_max = int(kl_max), int(w_max)
         self.cutoff = cutoff
         per = {}
+        self._rec_cache = {}
         self.dense_groups = []
         self.why_dense = {}
         for g in groups:
@@ -66,6 +68,7 @@ class EllBandPlan:
                 del per[g]
             self.dense_groups.sort()
         self.per = per
+        self._rec_cache = None
         self.n = np.zeros(self.nl, dtype=np.int32)
         if not per:
             self.kl = self.ku = self.mp = self.nbc = self.nmax = 0
@@ -92,10 +95,10 @@ class EllBandPlan:
             self.nbc_of[g] = k
             self.T[g, :k, :k] = r["T"]
             for name, dst in (("Mp", self.MB), ("Lp", self.LB)):
-                i, j = np.nonzero(r[name])
-                dst[g, i, j - i + self.kl] = r[name][i, j]
-            i, j = np.nonzero(np.triu(r["Pp"], 1))
-            self.P[g, i, j - i - 1] = r["Pp"][i, j]
+                i, j, v = r[name]
+                dst[g, i, j - i + self.kl] = v
+            i, j, v = r["Pp"]
+            self.P[g, i, j - i - 1] = v
 
     # ------------------------------------------------------------------------------------------------------------------
     def _analyse(self, M, L, rv, cv, packed_rows, packed_cols):
@@ -131,13 +134,79 @@ class EllBandPlan:
         groups = {}
         for c in comps:
             groups.setdefault(find(c), []).append(c)
-        P = np.eye(n)
-        T = np.eye(len(bc))
-        bc_order, bc_target = [], []                   # boundary rows in the order of the unknowns they end up picking
+        # the boundary rows (and with them the recombination) are the same for most groups: worked out once per pattern
+        key = (cidx.tobytes(), bc.tobytes(), Rb.tobytes())
+        rec = self._rec_cache.get(key)
+        if rec is None:
+            rec = self._rec_cache[key] = self._recombination(n, Rb, ccomp, cn, groups)
+        if isinstance(rec, str):
+            return rec
+        P, T, bc_order, bc_target = rec
+        Ms, Ls = sparse.csr_matrix(M), sparse.csr_matrix(L)
+        Mp, Lp = (Ms @ P).tolil(), (Ls @ P).tolil()
+        if len(bc):
+            TL = T @ Lp[bc].toarray()
+            # by construction the transformed boundary rows are unit rows: set them exactly
+            unit = np.zeros((len(bc), n))
+            unit[bc_order, bc_target] = 1.0
+            if np.abs(TL - unit).max() > 1e-8:
+                return "boundary rows do not reduce to unit rows"
+            Lp[bc] = unit
+        Mp, Lp = Mp.tocoo(), Lp.tocoo()
+        keep = lambda A: np.abs(A.data) >= self.cutoff                 # entry_cutoff (core/subsystems.py:536)
+        Mi, Mj, Mv = (a[keep(Mp)] for a in (Mp.row, Mp.col, Mp.data))
+        Li, Lj, Lv = (a[keep(Lp)] for a in (Lp.row, Lp.col, Lp.data))
+        # permutation: boundary rows first, then equations n-major; unknowns n-major, tau columns last
+        ri = inter_r[np.lexsort((rcomp[inter_r], rn[inter_r]))]
+        ci = inter_c[np.lexsort((ccomp[inter_c], cn[inter_c]))]
+        # tau columns sit where their entries are: after the unknowns of the first equation row they enter (the lift
+        # taus meet the last rows of their equations; a constant tau, e.g. tau_p, the n = 0 row of its equation)
+        if len(tau):
+            is_bc = np.zeros(n, dtype=bool)
+            is_bc[bc] = True
+            first_n = np.full(len(tau), Nr)
+            for t, col in enumerate(tau):
+                rr = np.concatenate([Mi[Mj == col], Li[Lj == col]])
+                rr = rr[~is_bc[rr]]
+                if len(rr):
+                    first_n[t] = rn[rr].min()
+            first_n = np.where(first_n < Nr // 2, first_n, Nr)          # (late ones: simply last)
+            key_n = np.concatenate([cn[ci] + 0.0, first_n + 0.5])
+            order = np.argsort(key_n, kind="stable")
+            cols = np.concatenate([ci, tau])[order]
+        else:
+            cols = ci
+        pos = np.empty(n, dtype=np.int64)
+        pos[cols] = np.arange(n)
+        order_k = sorted(range(len(bc)), key=lambda k: pos[int(bc_target[bc_order.index(k)])])
+        rows = np.concatenate([bc[order_k].astype(int), ri])
+        rpos = np.empty(n, dtype=np.int64)
+        rpos[rows] = np.arange(n)
+        Tperm = T[np.ix_(order_k, order_k)]
+        Mq = (rpos[Mi], pos[Mj], Mv)
+        Lq = (rpos[Li], pos[Lj], Lv)
+        Pc = P.tocoo()
+        off = Pc.row != Pc.col
+        Pq = (pos[Pc.row[off]], pos[Pc.col[off]], Pc.data[off])
+        d = np.concatenate([Mq[0] - Mq[1], Lq[0] - Lq[1]])
+        kl, ku = int(max(d.max(), 0)), int(max((-d).max(), 0))
+        mp = int((Pq[1] - Pq[0]).max()) if len(Pq[0]) else 0
+        if len(Pq[0]) and (Pq[1] - Pq[0]).min() < 1:
+            return "recombination not upper triangular in the permuted order"
+        if kl > self.kl_max or kl + ku > self.w_max or mp > kl + ku:
+            return "band too wide (kl %d, ku %d)" % (kl, ku)
+        return dict(n=n, rows=ridx[rows], cols=cidx[cols], T=Tperm, Mp=Mq, Lp=Lq, Pp=Pq, kl=kl, ku=ku, mp=mp)
+
+    @staticmethod
+    def _recombination(n, Rb, ccomp, cn, groups):
+        """-> (P sparse, T, boundary rows in the order of the unknowns they pick, those unknowns) or a reason"""
+        rows_p, cols_p, vals_p = [np.arange(n)], [np.arange(n)], [np.ones(n)]
+        T = np.eye(Rb.shape[0])
+        bc_order, bc_target = [], []
         for _, cs in sorted(groups.items()):
             cols = np.flatnonzero(np.isin(ccomp, cs))
             cols = cols[np.lexsort((ccomp[cols], cn[cols]))]           # n-major
-            touching = [k for k in range(len(bc)) if np.any(Rb[k, cols] != 0)]
+            touching = [k for k in range(Rb.shape[0]) if np.any(Rb[k, cols] != 0)]
             m = len(touching)
             if m == 0:
                 continue
@@ -147,56 +216,23 @@ class EllBandPlan:
             G0 = Rv[:, :m]
             if np.linalg.cond(G0) > 1e10:
                 return "boundary rows not independent on the leading modes"
-            for q in range(m, len(cols)):
-                G = Rv[:, q - m:q][:, ::-1]                             # columns q-1 ... q-m
-                if np.linalg.cond(G) > 1e10:
+            qs = np.arange(m, len(cols))
+            if len(qs):
+                # column q = e_q + sum_s c_s e_(q-s): G c = -R[:, q] with G = columns q-1 ... q-m, all q at once
+                Gs = Rv[:, qs[:, None] - 1 - np.arange(m)[None, :]].transpose(1, 0, 2)          # (nq, m, m)
+                if np.linalg.cond(Gs).max() > 1e10:
                     return "recombination singular"
-                c = np.linalg.solve(G, -Rv[:, q])
-                P[cols[q - 1 - np.arange(m)], cols[q]] = c
+                c = np.linalg.solve(Gs, -Rv[:, qs].T[:, :, None])[:, :, 0]                       # (nq, m)
+                rows_p.append(cols[qs[:, None] - 1 - np.arange(m)[None, :]].ravel())
+                cols_p.append(np.repeat(cols[qs], m))
+                vals_p.append(c.ravel())
             T[np.ix_(touching, touching)] = np.linalg.inv(G0)
             bc_order += touching
             bc_target += cols[:m].tolist()
-        if sorted(bc_order) != list(range(len(bc))):
+        if sorted(bc_order) != list(range(Rb.shape[0])):
             return "boundary rows without unknowns"
-        Mp, Lp = M @ P, L @ P
-        Lp[bc] = T @ Lp[bc]
-        # by construction the transformed boundary rows are unit rows: set them exactly
-        unit = np.zeros((len(bc), n))
-        unit[bc_order, bc_target] = 1.0
-        if len(bc) and np.abs(Lp[bc] - unit).max() > 1e-8 * max(1.0, np.abs(unit).max()):
-            return "boundary rows do not reduce to unit rows"
-        Lp[bc] = unit
-        for A in (Mp, Lp):                                             # entry_cutoff (core/subsystems.py:536)
-            A[np.abs(A) < self.cutoff] = 0.0
-        # permutation: boundary rows first, then equations n-major; unknowns n-major, tau columns last
-        ri = inter_r[np.lexsort((rcomp[inter_r], rn[inter_r]))]
-        ci = inter_c[np.lexsort((ccomp[inter_c], cn[inter_c]))]
-        # tau columns sit where their entries are: after the unknowns of the first equation row they enter (the lift
-        # taus meet the last rows of their equations; a constant tau, e.g. tau_p, the n = 0 row of its equation)
-        if len(tau):
-            coupled = (Mp[np.ix_(inter_r, tau)] != 0) | (Lp[np.ix_(inter_r, tau)] != 0)
-            first_n = np.array([rn[inter_r][coupled[:, t]].min() if coupled[:, t].any() else Nr for t in range(len(tau))])
-            first_n = np.where(first_n < Nr // 2, first_n, Nr)          # (late ones: simply last)
-            key_n = np.concatenate([cn[ci] + 0.0, first_n + 0.5])
-            order = np.argsort(key_n, kind="stable")
-            cols_all = np.concatenate([ci, tau])[order]
-        else:
-            cols_all = ci
-        pos = {int(c): i for i, c in enumerate(cols_all)}
-        order_k = sorted(range(len(bc)), key=lambda k: pos[int(bc_target[bc_order.index(k)])])
-        rows = np.concatenate([bc[order_k].astype(int), ri])
-        cols = cols_all
-        Tperm = T[np.ix_(order_k, order_k)]
-        Mq, Lq, Pq = Mp[np.ix_(rows, cols)], Lp[np.ix_(rows, cols)], P[np.ix_(cols, cols)]
-        i, j = np.nonzero((Mq != 0) | (Lq != 0))
-        kl, ku = int(max((i - j).max(), 0)), int(max((j - i).max(), 0))
-        i, j = np.nonzero(np.triu(Pq, 1))
-        mp = int((j - i).max()) if len(i) else 0
-        if np.any(np.tril(Pq, -1) != 0):
-            return "recombination not upper triangular in the permuted order"
-        if kl > self.kl_max or kl + ku > self.w_max or mp > kl + ku:
-            return "band too wide (kl %d, ku %d)" % (kl, ku)
-        return dict(n=n, rows=ridx[rows], cols=cidx[cols], T=Tperm, Mp=Mq, Lp=Lq, Pp=Pq, kl=kl, ku=ku, mp=mp)
+        P = sparse.csr_matrix((np.concatenate(vals_p), (np.concatenate(rows_p), np.concatenate(cols_p))), shape=(n, n))
+        return P, T, bc_order, bc_target
 
     # ---- host restatement of what the device does with the plan (tests) --------------------------------------------------
     def reference_solve(self, g, a, b, rhs_flat):

@@ -21,6 +21,10 @@ namespace ddh {
 
 constexpr int EB_NBC = 8;        // boundary rows per group
 constexpr int EB_MP = 16;        // super diagonals of the recombination in the permuted order
+// backward factor rows (layout: see ellband_backward_kernel)
+constexpr int EB_RW = 128;       // doubles per backward factor row
+__host__ __device__ constexpr int eb_qw(int wt) { return wt / 4 + EB_MP / 4; }
+__host__ __device__ constexpr int eb_u_index(int wt, int s1) { return s1 == 0 ? 4 * eb_qw(wt) : ((s1 - 1) % 4) * eb_qw(wt) + (s1 - 1) / 4; }
 
 struct EllBandLu {
     double *Lm = nullptr;        // [nl][nmax][64]       column j: pivot row offset (as a double), then the multipliers of
@@ -140,19 +144,15 @@ ellband_factor_kernel(const int *__restrict__ n_d, const double *__restrict__ MB
         __syncthreads();
         // pivot row -> U; row j + kl + 1 enters in its place (its columns j+1 .. j+WC map onto the same slots)
         const int inew = j + kl + 1;
-        for (int c1 = tid; c1 <= wt; c1 += EB_FT) {
-            if (c1 < WC) {
-                int c = jc + c1;
-                if (c >= WC) c -= WC;
-                const double u = win[jr * WC + c];
-                Ug[(size_t)j * urow + c1] = c1 == 0 ? ipv : u;
-                const int d = c1 == 0 ? WC - 1 : c1 - 1;
-                double v = 0.0;
-                if (inew < n) v = a * Mg[(size_t)inew * WC + d] + b * Lg[(size_t)inew * WC + d];
-                win[jr * WC + c] = v;
-            } else {
-                Ug[(size_t)j * urow + c1] = 0.0;
-            }
+        for (int c1 = tid; c1 < WC; c1 += EB_FT) {          // (entries past the band stay zero from the allocation)
+            int c = jc + c1;
+            if (c >= WC) c -= WC;
+            const double u = win[jr * WC + c];
+            Ug[(size_t)j * urow + eb_u_index(wt, c1)] = c1 == 0 ? ipv : u;
+            const int d = c1 == 0 ? WC - 1 : c1 - 1;
+            double v = 0.0;
+            if (inew < n) v = a * Mg[(size_t)inew * WC + d] + b * Lg[(size_t)inew * WC + d];
+            win[jr * WC + c] = v;
         }
         if (++jr == NR) jr = 0;
         if (++jc == WC) jc = 0;
@@ -167,7 +167,7 @@ ellband_factor_kernel(const int *__restrict__ n_d, const double *__restrict__ MB
 // the sweep time is its instruction count: the scalar unit's loads would serialize a round trip per row, v_readlane
 // costs two VALU slots per coefficient.
 // rows of factor data in flight: a divisor of the window (compile-time ring slots), as deep as the window allows
-constexpr int eb_depth(int) { return 4; }
+constexpr int eb_depth(int w) { return w % 8 == 0 ? 8 : 4; }
 constexpr int EB_FLW = 64;       // doubles per forward factor row: [0] pivot offset, [1 .. nw-1] multipliers
 
 // Row tables and factor rows are padded with EB_PAD zero rows per group, so the unrolled row loops run whole blocks
@@ -272,90 +272,114 @@ ellband_forward_kernel(const int *__restrict__ n_d, const int *__restrict__ nbc_
     }
 }
 
-// WT: solved unknowns kept (kl + ku <= WT, even); a backward factor row is WT + 1 entries of U
-// (1 / diagonal first) followed by the EB_MP super diagonals of the recombination, padded to NV * 64 doubles.
-// The sweep starts `pad` rows past the end (zero factor rows, results to the dump word) so that it ends on row 0
-// with whole blocks.
+// Sum over the four 16-lane quads of a wave, result in every lane: gfx950's v_permlane16_swap / v_permlane32_swap
+// exchange 16- / 32-lane halves between two registers in the VALU (a ds_bpermute round trip per step would sit on the
+// row-to-row dependency chain of the sweep).
+__device__ __forceinline__ double eb_quad_sum(double a) {
+    unsigned lo = __double2loint(a), hi = __double2hiint(a);
+    const auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double x = __hiloint2double(h16[0], l16[0]) + __hiloint2double(h16[1], l16[1]);
+    lo = __double2loint(x);
+    hi = __double2hiint(x);
+    const auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(h32[0], l32[0]) + __hiloint2double(h32[1], l32[1]);
+}
+
+// WT: solved unknowns kept (kl + ku <= WT, a multiple of 4).  Backward sweep: one wavefront per (group, 16 slots); the
+// four 16-lane quads of the wave split the dot product of a row -- quad q takes the super diagonals s1 = 4k + q + 1 --
+// and an xor all-reduce over the quads (two steps) completes it.  A lone wave per SIMD is bound by its instruction
+// count: this cuts the multiply-adds per lane to a quarter and makes four times as many waves (the machine has ~3x more
+// SIMDs than a 64-slot split has waves).  Every lane keeps the whole window, rotated by its quad: the solved y of step
+// t sits at slot (t + q + 1) mod WT, so the unknown quad q needs for its k-th coefficient, step t - 4k - q - 1, is at
+// slot (t - 4k) mod WT -- a compile-time register for every quad.
+// A factor row (128 doubles): quad q's [q QW, (q + 1) QW): WT / 4 entries of U then EB_MP / 4 of the recombination;
+// [4 QW] = 1 / diagonal, [4 QW + 1] = column offset of the row.  The sweep starts past the end (zero rows, results to
+// the dump word) so that it ends on row 0 with whole blocks.
+
 template <int WT>
 __global__ void __launch_bounds__(64)
-ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slot_limit, const long *__restrict__ coloff,
-                        const double *__restrict__ FU, const double *__restrict__ work, double *__restrict__ x,
-                        double *__restrict__ dump, int np, int nslots, int nslots_pad, long slot_stride) {
+ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slot_limit, const double *__restrict__ FU,
+                        const double *__restrict__ work, double *__restrict__ x, double *__restrict__ dump, int np,
+                        int nslots, int nslots_pad, long slot_stride, int abl) {
     constexpr int EB_D = eb_depth(WT);
-    static_assert(WT % EB_D == 0 && WT % 2 == 0, "window: a multiple of the prefetch depth");
-    constexpr int NV = (WT + 1 + EB_MP + 2 + 63) / 64;
-    constexpr int RW = NV * 64;
-    constexpr int NC = (WT + 1 + EB_MP + 1) / 2 + 1;          // double2 pairs of a row in use: U, recombination, column offset
+    constexpr int KU = WT / 4, KP = EB_MP / 4, QW = KU + KP, RW = EB_RW;
+    static_assert(WT % 4 == 0 && WT % EB_D == 0 && QW % 2 == 0 && KU % 2 == 0 && 4 * QW + 2 <= RW, "row layout");
     __shared__ double2 ring[2][RW / 2];
     const int g = blockIdx.y;
     const int n = n_d[g];
     const int lim = slot_limit[g];
-    if (n == 0 || (int)blockIdx.x * 64 >= lim) return;
-    const int lane = threadIdx.x;
-    const int s = blockIdx.x * 64 + lane;
-    const bool own = s < nslots;                               // lanes past the last slot write to the dump word
+    if (n == 0 || (int)blockIdx.x * 16 >= lim) return;
+    const int lane = threadIdx.x, q = lane >> 4;
+    const int s = blockIdx.x * 16 + (lane & 15);
+    const bool own = q == 0 && s < nslots;                     // the quad that stores; the others write to the dump word
     const unsigned long long dmp_a = reinterpret_cast<unsigned long long>(dump + lane);
     const unsigned long long dst_a = own ? reinterpret_cast<unsigned long long>(x + (size_t)s * slot_stride) : dmp_a;
     const long ownm = own ? -1L : 0L;
     const double *Fg = FU + (size_t)g * np * RW + lane;
-    const double *wk = work + (size_t)g * np * nslots_pad + s;
+    const double *wk = work + (size_t)g * np * nslots_pad + (s < nslots_pad ? s : 0);
     double *ring_w = reinterpret_cast<double *>(&ring[0][0]) + lane;
+    // (measurement builds only: abl bit 2 = results to the dump word, 3 = one right-hand-side row, 4 = one factor row)
+    const long keepm = (abl & 4) ? 0L : -1L;
+    const size_t wrow = (abl & 8) ? 0 : (size_t)nslots_pad;
+    const size_t frow = (abl & 16) ? 0 : (size_t)RW;
     const int nblk = (n + WT - 1) / WT;
     const int top = nblk * WT - 1;                              // first row of the sweep (>= n - 1: padding rows)
-    double yw[WT];                        // y of the rows below: y_(i+s1) sits at slot (t - s1) mod WT, t = top - i
-    double fr[EB_D][NV], wr[EB_D];
+    double yw[WT];
+    double fr[EB_D][2], wr[EB_D];
 #pragma unroll
-    for (int q = 0; q < WT; ++q) yw[q] = 0.0;
+    for (int k = 0; k < WT; ++k) yw[k] = 0.0;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) ring_w[v * 64] = Fg[(size_t)top * RW + v * 64];             // t = 0
+    for (int v = 0; v < 2; ++v) ring_w[v * 64] = Fg[(size_t)top * frow + v * 64];              // t = 0
 #pragma unroll
-    for (int q = 0; q < EB_D; ++q) {
+    for (int k = 0; k < EB_D; ++k) {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) fr[q][v] = Fg[(size_t)max(top - 1 - q, 0) * RW + v * 64];      // t = 1 .. EB_D
-        wr[q] = wk[(size_t)max(top - q, 0) * nslots_pad];                                    // t = 0 .. EB_D - 1
+        for (int v = 0; v < 2; ++v) fr[k][v] = Fg[(size_t)max(top - 1 - k, 0) * frow + v * 64];       // t = 1 .. EB_D
+        wr[k] = wk[(size_t)max(top - k, 0) * wrow];                                    // t = 0 .. EB_D - 1
     }
     for (int b = 0; b < nblk; ++b) {
 #pragma unroll
         for (int u = 0; u < WT; ++u) {
             const int i = top - (b * WT + u);
+            const double2 *rq = ring[u & 1] + q * (QW / 2);          // this quad's coefficients
+            const double2 sh = ring[u & 1][2 * QW];                  // (1 / diagonal, column offset)
             // row t + 1 -> the other half of the ring; row t + 1 + EB_D and the right-hand side of t + EB_D leave memory
-            const double2 *row = ring[u & 1];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) ring_w[((u + 1) & 1) * RW + v * 64] = fr[u % EB_D][v];
+            for (int v = 0; v < 2; ++v) ring_w[((u + 1) & 1) * RW + v * 64] = fr[u % EB_D][v];
             const double w = wr[u % EB_D];
             {
                 const int ip = max(i - 1 - EB_D, 0);
 #pragma unroll
-                for (int v = 0; v < NV; ++v) fr[u % EB_D][v] = Fg[(size_t)ip * RW + v * 64];
-                wr[u % EB_D] = wk[(size_t)max(i - EB_D, 0) * nslots_pad];
+                for (int v = 0; v < 2; ++v) fr[u % EB_D][v] = Fg[(size_t)ip * frow + v * 64];
+                wr[u % EB_D] = wk[(size_t)max(i - EB_D, 0) * wrow];
             }
             // oldest unknowns first: only the last multiply-add of a row waits for the row before it
-            double a0 = i < n ? w : 0.0, a1 = 0.0;
+            double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int s1 = WT; s1 >= 2; s1 -= 2) {
-                const double2 c = row[s1 / 2];
-                if (s1 + 1 <= WT) a0 -= c.y * yw[(u - s1 - 1 + 2 * WT) % WT];
-                a1 -= c.x * yw[(u - s1 + 2 * WT) % WT];
+            for (int k = KU - 2; k >= 0; k -= 2) {
+                const double2 c = rq[k / 2];
+                a1 -= c.y * yw[(u - 4 * (k + 1) + 2 * WT) % WT];
+                a0 -= c.x * yw[(u - 4 * k + 2 * WT) % WT];
             }
-            const double2 c0 = row[0];                  // (1 / diagonal, first super diagonal)
-            a0 -= c0.y * yw[(u - 1 + 2 * WT) % WT];
-            const double y = (a0 + a1) * c0.x;
-            // recombination: entries WT + 1 .. WT + EB_MP of the row (WT even: the first one is the .y of a pair)
-            double z0 = 0.0, z1 = 0.0;
+            double z0 = 0.0;
 #pragma unroll
-            for (int s1 = (EB_MP < WT ? EB_MP : WT) & ~1; s1 >= 2; s1 -= 2) {
-                const double2 c = row[(WT + s1) / 2];
-                if (s1 + 1 <= EB_MP && s1 + 1 <= WT) z0 += c.y * yw[(u - s1 - 1 + 2 * WT) % WT];
-                z1 += c.x * yw[(u - s1 + 2 * WT) % WT];
+            for (int k = KP - 2; k >= 0; k -= 2) {
+                const double2 c = rq[(KU + k) / 2];
+                z0 += c.y * yw[(u - 4 * (k + 1) + 2 * WT) % WT];
+                z0 += c.x * yw[(u - 4 * k + 2 * WT) % WT];
             }
-            z0 += row[WT / 2].y * yw[(u - 1 + 2 * WT) % WT];
-            // column offset: the entry after the recombination band (no scalar load in the loop); integer selects, a
-            // conditional store would put a branch into every row
-            const long off = __double_as_longlong(row[NC - 1].x);
-            const long keep = -(long)(i < n);
+            const double a = eb_quad_sum(a0 + a1);
+            z0 = eb_quad_sum(z0);
+            const double y = ((i < n ? w : 0.0) + a) * sh.x;
+            // integer selects: a conditional store would put a branch into every row
+            const long off = __double_as_longlong(sh.y);
+            const long keep = -(long)(i < n) & keepm;
             const unsigned long long to = dmp_a + ((dst_a - dmp_a + (unsigned long long)((off & ownm) << 3)) & (unsigned long long)keep);
-            *reinterpret_cast<double *>(to) = (z0 + z1) + y;
-            yw[u] = y;
+            *reinterpret_cast<__attribute__((address_space(1))) double *>(to) = z0 + y;      // (global, not flat: keeps lgkmcnt for the LDS)
+            // y of this step -> slot (u + 1 + q) mod WT
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) yw[(u + 1 + qq) % WT] = (q == qq) ? y : yw[(u + 1 + qq) % WT];
         }
     }
 }
@@ -364,20 +388,19 @@ ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slo
 // offset of the row that enters the forward window (j + nw) behind the multipliers of column j.
 __global__ void ellband_fill_rows_kernel(const double *__restrict__ P, const long *__restrict__ rowoff,
                                          const long *__restrict__ coloff, double *__restrict__ FL, double *__restrict__ FU,
-                                         int nl, int np, int nw, int wt, int nv, int nc) {
+                                         int nl, int np, int nw, int wt) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (long)nl * np) return;
     const int i = (int)(e % np);
-    for (int sd = 0; sd < EB_MP; ++sd) FU[e * (nv * 64) + wt + 1 + sd] = P[e * EB_MP + sd];
-    FU[e * (nv * 64) + 2 * (nc - 1)] = __longlong_as_double(coloff[e]);
+    const int qw = eb_qw(wt);
+    for (int sd = 0; sd < EB_MP; ++sd) FU[e * EB_RW + (sd % 4) * qw + wt / 4 + sd / 4] = P[e * EB_MP + sd];
+    FU[e * EB_RW + 4 * qw + 1] = __longlong_as_double(coloff[e]);
     FL[e * EB_FLW + nw] = __longlong_as_double(i + nw < np ? rowoff[e + nw] : 0L);
 }
 
 struct EbVariant { int nw, wt; };
 static const EbVariant eb_variants[] = {{12, 24}, {20, 40}, {28, 56}, {36, 64}, {36, 96}};
 
-static inline int eb_nv(int wt) { return (wt + 1 + EB_MP + 2 + 63) / 64; }
-static inline int eb_nc(int wt) { return (wt + 1 + EB_MP + 1) / 2 + 1; }
 
 #ifdef DDH_EB_ABLATE      // measurement builds: DDH_EB_ABL bit 0 / 1 = coalesced (wrong) addressing of the gather / scatter
 static int eb_abl() { const char *e = getenv("DDH_EB_ABL"); return e ? atoi(e) : 0; }
@@ -392,8 +415,9 @@ static void launch_forward(EllBand *p, const EllBandLu &lu, const double *rhs, d
 }
 template <int WT>
 static void launch_backward(EllBand *p, const EllBandLu &lu, double *x, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL(ellband_backward_kernel<WT>, grid, dim3(64), 0, st, p->n_d, p->slot_limit_d, p->coloff_d, lu.U,
-                       p->work_d, x, p->dump_d, p->np, p->nslots, p->nslots_pad, (eb_abl() & 2) ? 1L : p->slot_stride);
+    hipLaunchKernelGGL(ellband_backward_kernel<WT>, dim3((p->nslots + 15) / 16, grid.y), dim3(64), 0, st, p->n_d,
+                       p->slot_limit_d, lu.U, p->work_d, x, p->dump_d, p->np, p->nslots, p->nslots_pad,
+                       (eb_abl() & 2) ? 1L : p->slot_stride, eb_abl());
 }
 
 }  // namespace ddh
@@ -464,12 +488,11 @@ int ddh_ellband_factor(ddh_handle h, int index, double a, double b, int *nsingul
         EllBandLu lu;
         const size_t rows = (size_t)p->nl * p->np;
         DDH_HIP(hipMalloc((void **)&lu.Lm, sizeof(double) * rows * EB_FLW));
-        DDH_HIP(hipMalloc((void **)&lu.U, sizeof(double) * rows * eb_nv(p->wt) * 64));
+        DDH_HIP(hipMalloc((void **)&lu.U, sizeof(double) * rows * EB_RW));
         DDH_HIP(hipMemsetAsync(lu.Lm, 0, sizeof(double) * rows * EB_FLW, as_stream(stream)));
-        DDH_HIP(hipMemsetAsync(lu.U, 0, sizeof(double) * rows * eb_nv(p->wt) * 64, as_stream(stream)));
+        DDH_HIP(hipMemsetAsync(lu.U, 0, sizeof(double) * rows * EB_RW, as_stream(stream)));
         hipLaunchKernelGGL(ellband_fill_rows_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream),
-                           p->P_d, p->rowoff_d, p->coloff_d, lu.Lm, lu.U, p->nl, p->np, p->nw, p->wt, eb_nv(p->wt),
-                           eb_nc(p->wt));
+                           p->P_d, p->rowoff_d, p->coloff_d, lu.Lm, lu.U, p->nl, p->np, p->nw, p->wt);
         p->lus.push_back(lu);
     }
     const EllBandLu &lu = p->lus[index];
@@ -477,7 +500,7 @@ int ddh_ellband_factor(ddh_handle h, int index, double a, double b, int *nsingul
     DDH_HIP(hipMemsetAsync(p->flag_d, 0, sizeof(int), st));
     const size_t lds = sizeof(double) * ((size_t)(p->kl + 1) * (p->kl + p->ku + 1) + p->kl + 1);
     hipLaunchKernelGGL(ellband_factor_kernel, dim3(p->nl), dim3(EB_FT), lds, st, p->n_d, p->MB_d, p->LB_d, a, b, lu.Lm, lu.U,
-                       p->flag_d, p->nmax, p->np, p->kl, p->ku, EB_FLW, p->nw - 1, p->wt, eb_nv(p->wt) * 64);
+                       p->flag_d, p->nmax, p->np, p->kl, p->ku, EB_FLW, p->nw - 1, p->wt, EB_RW);
     DDH_HIP(hipGetLastError());
     if (nsingular_h) {
         DDH_HIP(hipMemcpyAsync(nsingular_h, p->flag_d, sizeof(int), hipMemcpyDeviceToHost, st));
