@@ -26,7 +26,12 @@ for step in "$@"; do
     bench-quick) python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err; bench_line $OUT/bench_quick.json ;;
     bench-nosplit) DDH_NO_SPLIT=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_nosplit.json 2> $OUT/bench_nosplit.err; bench_line $OUT/bench_nosplit.json ;;
     bench-cfl)  python bench.py --steps 10 --warmup 3 --cfl --no-cpu-baseline > $OUT/bench_cfl.json 2> $OUT/bench_cfl.err; bench_line $OUT/bench_cfl.json ;;
-    profile)    bash tools/profile_round.sh $TAG > $OUT/profile.log 2>&1; tail -3 $OUT/profile.log ;;
+    profile)    timeout 900 bash tools/profile_round.sh $TAG > $OUT/profile.log 2>&1; tail -3 $OUT/profile.log ;;
+    ellband)    # shell LHS at config H: band LU against the dense inverses (solve / factorization device time, per-kernel table)
+                export TMPDIR=/tmp
+                timeout 200 rocprofv3 --kernel-trace -d /tmp/prof_eb -o eb -- python tools/gpu/ellband_time.py > $OUT/ellband_band.log 2>&1
+                grep -E "^(build|plan|solve|factor)" $OUT/ellband_band.log; python tools/gpu/db_stats.py /tmp/prof_eb/eb_results.db 4 | tee $OUT/ellband_kernels.txt
+                DDH_SHELL_DENSE=1 timeout 200 python tools/gpu/ellband_time.py 2>&1 | grep -E "^(build|solve|factor)" | tee $OUT/ellband_dense.log ;;
     configs)    python tools/bench_configs.py --json > $OUT/configs.json 2> $OUT/configs.err; tail -5 $OUT/configs.json ;;
     shares)     # per-rank shares of the strong-scaled problem on one GPU, sweep variants A/B (profiles/*_strong_scaling_shares.txt)
                 for sz in 256,512,256 128,512,256 64,512,256; do
