@@ -184,7 +184,7 @@ ellband_forward_kernel(const int *__restrict__ n_d, const int *__restrict__ nbc_
                        long slot_stride, int nbcmax) {
     constexpr int EB_D = eb_depth(NW);
     static_assert(NW % EB_D == 0 && NW % 2 == 0 && NW + 2 <= EB_FLW, "window: a multiple of the prefetch depth");
-    __shared__ double2 ring[EB_FLW / 2];
+    __shared__ double2 ring[2][EB_FLW / 2];
     const int g = blockIdx.y;
     const int n = n_d[g];
     const int lim = slot_limit[g];
@@ -196,19 +196,20 @@ ellband_forward_kernel(const int *__restrict__ n_d, const int *__restrict__ nbc_
     const long *ro = rowoff + (size_t)g * np;
     const double *Fg = FL + (size_t)g * np * EB_FLW + lane;
     double *wk = work + (size_t)g * np * nslots_pad + s;
-    double *ring_w = reinterpret_cast<double *>(&ring[0]) + lane;
+    double *ring_w = reinterpret_cast<double *>(&ring[0][0]) + lane;
     double bw[NW], fr[EB_D];
     double2 cf[2][NW / 2 + 1];                                  // coefficients of the current / the next row (+ row offset)
-    ring_w[0] = Fg[0];
+    ring_w[0] = Fg[0];                                          // rows 0, 1 -> the ring
+    ring_w[EB_FLW] = Fg[EB_FLW];
 #pragma unroll
-    for (int q = 0; q < EB_D; ++q) fr[q] = Fg[(size_t)(q + 1) * EB_FLW];                 // rows 1 .. EB_D
+    for (int q = 0; q < EB_D; ++q) fr[q] = Fg[(size_t)(q + 2) * EB_FLW];                 // rows 2 .. EB_D + 1
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
         const double v = src[ro[q]];
         bw[q] = (q < n && live) ? v : 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < NW / 2 + 1; ++q) cf[0][q] = ring[q];
+    for (int q = 0; q < NW / 2 + 1; ++q) cf[0][q] = ring[0][q];
     // boundary rows (the first nbc of the permuted order): the combinations T that pick one unknown each
     const int nbc = nbc_d[g];
     if (nbc > 0) {
@@ -232,31 +233,35 @@ ellband_forward_kernel(const int *__restrict__ n_d, const int *__restrict__ nbc_
             const int j = j0 + u;
             const double2 *c = cf[u & 1];
             const int d = __builtin_amdgcn_readfirstlane((int)c[0].x);
-            // Row interchange bw[u] <-> bw[(u + d) % NW], wave-uniform d: pivot rows are the rule in these systems (~80 % of
-            // the columns, offsets up to ~12), so the offset is resolved in two levels of scalar branches (groups of four)
-            // instead of a chain of NW; the empty asm keeps them branches -- as selects they cost 4 NW VALU slots per row.
+            // coefficients of row j + 1 (in the ring since row j - 1) -> the other register set: a whole row of work ahead of
+            // their use, the lone wave of the workgroup has nothing else to hide the LDS latency behind
+#pragma unroll
+            for (int q = 0; q < NW / 2 + 1; ++q) cf[(u + 1) & 1][q] = ring[(u + 1) & 1][q];
+            // Row interchange, wave-uniform offset d = 4 a + b: y = bw[u + d], and the row it displaces takes that place.
+            // Pivot rows are the rule in these systems (~80 % of the columns, offsets up to ~12): one scalar branch per
+            // group of four window rows (a), selects inside (b) -- a chain of NW branches or of NW selects costs several
+            // times the multiply-adds of the row.
             if (d != 0) {
                 asm volatile("");
+                const int ga = d >> 2, gb = d & 3;
 #pragma unroll
-                for (int gq = 0; gq < (NW + 3) / 4; ++gq)
-                    if ((d >> 2) == gq) {
+                for (int a = 0; a < NW / 4; ++a)
+                    if (ga == a) {
                         asm volatile("");
+                        const double old = bw[u];
+                        double ysel = bw[(u + 4 * a) % NW];
 #pragma unroll
-                        for (int r = 4 * gq; r < 4 * gq + 4; ++r)
-                            if (r >= 1 && r < NW && d == r) {
-                                asm volatile("");
-                                const double tmp = bw[u];
-                                bw[u] = bw[(u + r) % NW];
-                                bw[(u + r) % NW] = tmp;
-                            }
+                        for (int bb = 1; bb < 4; ++bb) ysel = (gb == bb) ? bw[(u + 4 * a + bb) % NW] : ysel;
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb)
+                            if (4 * a + bb >= 1) bw[(u + 4 * a + bb) % NW] = (gb == bb) ? old : bw[(u + 4 * a + bb) % NW];
+                        bw[u] = ysel;
                     }
             }
             const double y = bw[u];
-            // row j + 1: memory -> LDS -> the other coefficient set, while this row's multiply-adds run
-            ring_w[0] = fr[u % EB_D];
-            fr[u % EB_D] = Fg[(size_t)(j + 1 + EB_D) * EB_FLW];
-#pragma unroll
-            for (int q = 0; q < NW / 2 + 1; ++q) cf[(u + 1) & 1][q] = ring[q];
+            // row j + 2: memory -> the ring slot row j has left; row j + 2 + EB_D leaves memory
+            ring_w[(u & 1) * EB_FLW] = fr[u % EB_D];
+            fr[u % EB_D] = Fg[(size_t)(j + 2 + EB_D) * EB_FLW];
             wk[(size_t)j * nslots_pad] = y;
             bw[(u + 1) % NW] -= c[0].y * y;
 #pragma unroll
@@ -320,10 +325,15 @@ ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slo
     const double *Fg = FU + (size_t)g * np * RW + lane;
     const double *wk = work + (size_t)g * np * nslots_pad + (s < nslots_pad ? s : 0);
     double *ring_w = reinterpret_cast<double *>(&ring[0][0]) + lane;
-    // (measurement builds only: abl bit 2 = results to the dump word, 3 = one right-hand-side row, 4 = one factor row)
+#ifdef DDH_EB_ABLATE      // measurement builds only: abl bit 2 = results to the dump word, 3 = one right-hand-side row, 4 = one factor row
     const long keepm = (abl & 4) ? 0L : -1L;
     const size_t wrow = (abl & 8) ? 0 : (size_t)nslots_pad;
     const size_t frow = (abl & 16) ? 0 : (size_t)RW;
+#else
+    constexpr long keepm = -1L;
+    const size_t wrow = (size_t)nslots_pad;
+    constexpr size_t frow = (size_t)RW;
+#endif
     const int nblk = (n + WT - 1) / WT;
     const int top = nblk * WT - 1;                              // first row of the sweep (>= n - 1: padding rows)
     double yw[WT];
