@@ -22,8 +22,10 @@ namespace ddh {
 constexpr int EB_NBC = 8;        // boundary rows per group
 constexpr int EB_MP = 16;        // super diagonals of the recombination in the permuted order
 // backward factor rows (layout: see ellband_backward_kernel)
-constexpr int EB_RW = 128;       // doubles per backward factor row
+constexpr int EB_RING = 128;     // doubles per LDS ring slot of the backward sweep (two 64-lane stores per row)
 __host__ __device__ constexpr int eb_qw(int wt) { return wt / 4 + EB_MP / 4; }
+// doubles per backward factor row in memory: the four quads' entries, 1 / diagonal, column offset -- rounded to 128 B
+__host__ __device__ constexpr int eb_rw(int wt) { return (4 * eb_qw(wt) + 2 + 15) / 16 * 16; }
 __host__ __device__ constexpr int eb_u_index(int wt, int s1) { return s1 == 0 ? 4 * eb_qw(wt) : ((s1 - 1) % 4) * eb_qw(wt) + (s1 - 1) / 4; }
 
 struct EllBandLu {
@@ -168,7 +170,10 @@ ellband_factor_kernel(const int *__restrict__ n_d, const double *__restrict__ MB
 // costs two VALU slots per coefficient.
 // rows of factor data in flight: a divisor of the window (compile-time ring slots), as deep as the window allows
 constexpr int eb_depth(int w) { return w % 8 == 0 ? 8 : 4; }
-constexpr int EB_FLW = 64;       // doubles per forward factor row: [0] pivot offset, [1 .. nw-1] multipliers
+constexpr int EB_FLW = 64;       // doubles per LDS ring slot of the forward sweep (one 64-lane store per row)
+// doubles per forward factor row in memory: [0] pivot offset, [1 .. nw-1] multipliers, [nw] offset of the row that enters
+// the window, rounded to 128 B
+__host__ __device__ constexpr int eb_flw(int nw) { return (nw + 1 + 15) / 16 * 16; }
 
 // Row tables and factor rows are padded with EB_PAD zero rows per group, so the unrolled row loops run whole blocks
 // without per-row branches (a branch per row would end the scheduling region: every row would then pay its own LDS and
@@ -194,15 +199,16 @@ ellband_forward_kernel(const int *__restrict__ n_d, const int *__restrict__ nbc_
     const bool live = s < lim;                                  // slots past the limit carry zeros
     const double *src = rhs + (size_t)(s < nslots ? s : 0) * slot_stride;
     const long *ro = rowoff + (size_t)g * np;
-    const double *Fg = FL + (size_t)g * np * EB_FLW + lane;
+    constexpr int FW = eb_flw(NW);
+    const double *Fg = FL + (size_t)g * np * FW + min(lane, FW - 1);
     double *wk = work + (size_t)g * np * nslots_pad + s;
     double *ring_w = reinterpret_cast<double *>(&ring[0][0]) + lane;
     double bw[NW], fr[EB_D];
     double2 cf[2][NW / 2 + 1];                                  // coefficients of the current / the next row (+ row offset)
     ring_w[0] = Fg[0];                                          // rows 0, 1 -> the ring
-    ring_w[EB_FLW] = Fg[EB_FLW];
+    ring_w[EB_FLW] = Fg[FW];
 #pragma unroll
-    for (int q = 0; q < EB_D; ++q) fr[q] = Fg[(size_t)(q + 2) * EB_FLW];                 // rows 2 .. EB_D + 1
+    for (int q = 0; q < EB_D; ++q) fr[q] = Fg[(size_t)(q + 2) * FW];                 // rows 2 .. EB_D + 1
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
         const double v = src[ro[q]];
@@ -261,7 +267,7 @@ ellband_forward_kernel(const int *__restrict__ n_d, const int *__restrict__ nbc_
             const double y = bw[u];
             // row j + 2: memory -> the ring slot row j has left; row j + 2 + EB_D leaves memory
             ring_w[(u & 1) * EB_FLW] = fr[u % EB_D];
-            fr[u % EB_D] = Fg[(size_t)(j + 2 + EB_D) * EB_FLW];
+            fr[u % EB_D] = Fg[(size_t)(j + 2 + EB_D) * FW];
             wk[(size_t)j * nslots_pad] = y;
             bw[(u + 1) % NW] -= c[0].y * y;
 #pragma unroll
@@ -299,7 +305,7 @@ __device__ __forceinline__ double eb_quad_sum(double a) {
 // SIMDs than a 64-slot split has waves).  Every lane keeps the whole window, rotated by its quad: the solved y of step
 // t sits at slot (t + q + 1) mod WT, so the unknown quad q needs for its k-th coefficient, step t - 4k - q - 1, is at
 // slot (t - 4k) mod WT -- a compile-time register for every quad.
-// A factor row (128 doubles): quad q's [q QW, (q + 1) QW): WT / 4 entries of U then EB_MP / 4 of the recombination;
+// A factor row (eb_rw(WT) doubles, 80 for WT = 56): quad q's [q QW, (q + 1) QW): WT / 4 entries of U then EB_MP / 4 of the recombination;
 // [4 QW] = 1 / diagonal, [4 QW + 1] = column offset of the row.  The sweep starts past the end (zero rows, results to
 // the dump word) so that it ends on row 0 with whole blocks.
 
@@ -309,9 +315,9 @@ ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slo
                         const double *__restrict__ work, double *__restrict__ x, double *__restrict__ dump, int np,
                         int nslots, int nslots_pad, long slot_stride, int abl) {
     constexpr int EB_D = eb_depth(WT);
-    constexpr int KU = WT / 4, KP = EB_MP / 4, QW = KU + KP, RW = EB_RW;
-    static_assert(WT % 4 == 0 && WT % EB_D == 0 && QW % 2 == 0 && KU % 2 == 0 && 4 * QW + 2 <= RW, "row layout");
-    __shared__ double2 ring[2][RW / 2];
+    constexpr int KU = WT / 4, KP = EB_MP / 4, QW = KU + KP, RW = eb_rw(WT), RG = EB_RING;
+    static_assert(WT % 4 == 0 && WT % EB_D == 0 && QW % 2 == 0 && KU % 2 == 0 && RW <= RG, "row layout");
+    __shared__ double2 ring[2][RG / 2];
     const int g = blockIdx.y;
     const int n = n_d[g];
     const int lim = slot_limit[g];
@@ -322,7 +328,8 @@ ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slo
     const unsigned long long dmp_a = reinterpret_cast<unsigned long long>(dump + lane);
     const unsigned long long dst_a = own ? reinterpret_cast<unsigned long long>(x + (size_t)s * slot_stride) : dmp_a;
     const long ownm = own ? -1L : 0L;
-    const double *Fg = FU + (size_t)g * np * RW + lane;
+    const double *Fg = FU + (size_t)g * np * RW;
+    const int fl[2] = {min(lane, RW - 1), min(64 + lane, RW - 1)};      // the row's entries this lane fetches
     const double *wk = work + (size_t)g * np * nslots_pad + (s < nslots_pad ? s : 0);
     double *ring_w = reinterpret_cast<double *>(&ring[0][0]) + lane;
 #ifdef DDH_EB_ABLATE      // measurement builds only: abl bit 2 = results to the dump word, 3 = one right-hand-side row, 4 = one factor row
@@ -341,11 +348,11 @@ ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slo
 #pragma unroll
     for (int k = 0; k < WT; ++k) yw[k] = 0.0;
 #pragma unroll
-    for (int v = 0; v < 2; ++v) ring_w[v * 64] = Fg[(size_t)top * frow + v * 64];              // t = 0
+    for (int v = 0; v < 2; ++v) ring_w[v * 64] = Fg[(size_t)top * frow + fl[v]];              // t = 0
 #pragma unroll
     for (int k = 0; k < EB_D; ++k) {
 #pragma unroll
-        for (int v = 0; v < 2; ++v) fr[k][v] = Fg[(size_t)max(top - 1 - k, 0) * frow + v * 64];       // t = 1 .. EB_D
+        for (int v = 0; v < 2; ++v) fr[k][v] = Fg[(size_t)max(top - 1 - k, 0) * frow + fl[v]];       // t = 1 .. EB_D
         wr[k] = wk[(size_t)max(top - k, 0) * wrow];                                    // t = 0 .. EB_D - 1
     }
     for (int b = 0; b < nblk; ++b) {
@@ -356,12 +363,12 @@ ellband_backward_kernel(const int *__restrict__ n_d, const int *__restrict__ slo
             const double2 sh = ring[u & 1][2 * QW];                  // (1 / diagonal, column offset)
             // row t + 1 -> the other half of the ring; row t + 1 + EB_D and the right-hand side of t + EB_D leave memory
 #pragma unroll
-            for (int v = 0; v < 2; ++v) ring_w[((u + 1) & 1) * RW + v * 64] = fr[u % EB_D][v];
+            for (int v = 0; v < 2; ++v) ring_w[((u + 1) & 1) * RG + v * 64] = fr[u % EB_D][v];
             const double w = wr[u % EB_D];
             {
                 const int ip = max(i - 1 - EB_D, 0);
 #pragma unroll
-                for (int v = 0; v < 2; ++v) fr[u % EB_D][v] = Fg[(size_t)ip * frow + v * 64];
+                for (int v = 0; v < 2; ++v) fr[u % EB_D][v] = Fg[(size_t)ip * frow + fl[v]];
                 wr[u % EB_D] = wk[(size_t)max(i - EB_D, 0) * wrow];
             }
             // oldest unknowns first: only the last multiply-add of a row waits for the row before it
@@ -403,9 +410,9 @@ __global__ void ellband_fill_rows_kernel(const double *__restrict__ P, const lon
     if (e >= (long)nl * np) return;
     const int i = (int)(e % np);
     const int qw = eb_qw(wt);
-    for (int sd = 0; sd < EB_MP; ++sd) FU[e * EB_RW + (sd % 4) * qw + wt / 4 + sd / 4] = P[e * EB_MP + sd];
-    FU[e * EB_RW + 4 * qw + 1] = __longlong_as_double(coloff[e]);
-    FL[e * EB_FLW + nw] = __longlong_as_double(i + nw < np ? rowoff[e + nw] : 0L);
+    for (int sd = 0; sd < EB_MP; ++sd) FU[e * eb_rw(wt) + (sd % 4) * qw + wt / 4 + sd / 4] = P[e * EB_MP + sd];
+    FU[e * eb_rw(wt) + 4 * qw + 1] = __longlong_as_double(coloff[e]);
+    FL[e * eb_flw(nw) + nw] = __longlong_as_double(i + nw < np ? rowoff[e + nw] : 0L);
 }
 
 struct EbVariant { int nw, wt; };
@@ -497,10 +504,10 @@ int ddh_ellband_factor(ddh_handle h, int index, double a, double b, int *nsingul
     if (index == (int)p->lus.size()) {
         EllBandLu lu;
         const size_t rows = (size_t)p->nl * p->np;
-        DDH_HIP(hipMalloc((void **)&lu.Lm, sizeof(double) * rows * EB_FLW));
-        DDH_HIP(hipMalloc((void **)&lu.U, sizeof(double) * rows * EB_RW));
-        DDH_HIP(hipMemsetAsync(lu.Lm, 0, sizeof(double) * rows * EB_FLW, as_stream(stream)));
-        DDH_HIP(hipMemsetAsync(lu.U, 0, sizeof(double) * rows * EB_RW, as_stream(stream)));
+        DDH_HIP(hipMalloc((void **)&lu.Lm, sizeof(double) * rows * eb_flw(p->nw)));
+        DDH_HIP(hipMalloc((void **)&lu.U, sizeof(double) * rows * eb_rw(p->wt)));
+        DDH_HIP(hipMemsetAsync(lu.Lm, 0, sizeof(double) * rows * eb_flw(p->nw), as_stream(stream)));
+        DDH_HIP(hipMemsetAsync(lu.U, 0, sizeof(double) * rows * eb_rw(p->wt), as_stream(stream)));
         hipLaunchKernelGGL(ellband_fill_rows_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream),
                            p->P_d, p->rowoff_d, p->coloff_d, lu.Lm, lu.U, p->nl, p->np, p->nw, p->wt);
         p->lus.push_back(lu);
@@ -510,7 +517,7 @@ int ddh_ellband_factor(ddh_handle h, int index, double a, double b, int *nsingul
     DDH_HIP(hipMemsetAsync(p->flag_d, 0, sizeof(int), st));
     const size_t lds = sizeof(double) * ((size_t)(p->kl + 1) * (p->kl + p->ku + 1) + p->kl + 1);
     hipLaunchKernelGGL(ellband_factor_kernel, dim3(p->nl), dim3(EB_FT), lds, st, p->n_d, p->MB_d, p->LB_d, a, b, lu.Lm, lu.U,
-                       p->flag_d, p->nmax, p->np, p->kl, p->ku, EB_FLW, p->nw - 1, p->wt, EB_RW);
+                       p->flag_d, p->nmax, p->np, p->kl, p->ku, eb_flw(p->nw), p->nw - 1, p->wt, eb_rw(p->wt));
     DDH_HIP(hipGetLastError());
     if (nsingular_h) {
         DDH_HIP(hipMemcpyAsync(nsingular_h, p->flag_d, sizeof(int), hipMemcpyDeviceToHost, st));
