@@ -107,14 +107,17 @@ def test_device_band_lu_of_the_shell_systems_against_dense_solves(shape):
 
 
 @pytest.mark.gpu
-def test_band_and_dense_paths_take_the_same_steps(monkeypatch):
+@pytest.mark.parametrize("ts", ["SBDF2", "RK443"])
+def test_band_and_dense_paths_take_the_same_steps(monkeypatch, ts):
+    """multistep (one factorization, refilled when the timestep changes) and Runge-Kutta (one factorization per distinct
+    diagonal entry of H, all alive at once)"""
     import dedalus_amd.public as d3
     states = []
     for dense in ("0", "1"):
         monkeypatch.setenv("DDH_SHELL_DENSE", dense)
-        s, fields = problems.shell_convection(d3, shape=(16, 8, 16))
-        for _ in range(5):
-            s.step(0.02)
+        s, fields = problems.shell_convection(d3, shape=(16, 8, 16), timestepper=ts)
+        for k in range(5):
+            s.step(0.02 if k < 3 else 0.015)
         assert bool(s._band) == (dense == "0")
         states.append({f.name: np.array(f["c"]) for f in s.state if hasattr(f, "basis")})
     worst = {}
