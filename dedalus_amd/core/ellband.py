@@ -107,16 +107,17 @@ class EllBandPlan:
         n = len(ridx)
         if len(cidx) != n:
             return "not square"
-        M = M[np.ix_(ridx, cidx)]
-        L = L[np.ix_(ridx, cidx)]
+        # (dense or scipy.sparse matrices of the full (component, n) index space; sparse from here on)
+        Ms = sparse.csr_matrix(M)[ridx][:, cidx].tocsr()
+        Ls = sparse.csr_matrix(L)[ridx][:, cidx].tocsr()
         rcomp, rn, ccomp, cn = ridx // Nr, ridx % Nr, cidx // Nr, cidx % Nr
         bc = np.flatnonzero(np.isin(rcomp, packed_rows))
         tau = np.flatnonzero(np.isin(ccomp, packed_cols))
         inter_r = np.flatnonzero(~np.isin(rcomp, packed_rows))
         inter_c = np.flatnonzero(~np.isin(ccomp, packed_cols))
-        if np.any(M[bc] != 0):
+        if len(bc) and Ms[bc].count_nonzero():
             return "boundary rows with time derivatives"
-        Rb = L[bc]
+        Rb = Ls[bc].toarray() if len(bc) else np.zeros((0, n))
         if np.any(Rb[:, tau] != 0):
             return "boundary rows touch tau columns"
         # components coupled by boundary rows -> groups of variables that are recombined together
@@ -142,7 +143,6 @@ class EllBandPlan:
         if isinstance(rec, str):
             return rec
         P, T, bc_order, bc_target = rec
-        Ms, Ls = sparse.csr_matrix(M), sparse.csr_matrix(L)
         Mp, Lp = (Ms @ P).tolil(), (Ls @ P).tolil()
         if len(bc):
             TL = T @ Lp[bc].toarray()

@@ -1227,11 +1227,78 @@ class SphereSolverBase:
 
     _dinv = None
 
+    # ---- inverses through the band LU -----------------------------------------------------------------------------------
+    # A sphere system has ONE right-hand side per step, so its solve stays a dense-inverse GEMV (a banded sweep of 765
+    # dependent rows cannot be hidden behind 256 systems: measured in round 2).  But the inverse itself need not cost
+    # O(n^3): the per-m matrices are block-tridiagonal in ell, so  (a M + b L)_m^-1  is obtained row by row from unit
+    # solves against the band LU of the transposed system -- the machinery of the shell (core/ellband.py,
+    # csrc/ddh_ellband.hip), fed with the REAL form of the complex matrices (components 2c / 2c + 1 = re / im).
+    _sband = None
+
+    def _real_form_transposed(self, tl, m):
+        """scipy.sparse real form, index (2c + part) nl + ell, of the TRANSPOSE of the complex term-list matrix at m"""
+        from scipy import sparse
+        nl = self.basis.nl
+        ell = np.arange(m, nl)
+        rows, cols, vals = [], [], []
+        for (co, ci, d, cf) in tl.terms:
+            src = ell + d
+            ok = (src >= m) & (src < nl)
+            v = cf[m, ell[ok]]
+            # A[(co, l), (ci, l + d)] = v  ->  A^T[(ci, l + d), (co, l)] = v;  z -> v z in real form: [[vr, -vi], [vi, vr]]
+            r0, r1 = (2 * ci) * nl + src[ok], (2 * ci + 1) * nl + src[ok]
+            c0, c1 = (2 * co) * nl + ell[ok], (2 * co + 1) * nl + ell[ok]
+            rows += [r0, r0, r1, r1]
+            cols += [c0, c1, c0, c1]
+            vals += [v.real, -v.imag, v.imag, v.real]
+        n = 2 * self.R * nl
+        if not rows:
+            return sparse.csr_matrix((n, n))
+        return sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+
+    def _band_inverse_setup(self):
+        """-> dict of the band path, or False (executor without it, DDH_SPHERE_DENSE=1, matrices that are no bands)"""
+        if self._sband is None:
+            self._sband = False
+            import os
+            nm, nl, R = self.basis.nm, self.basis.nl, self.R
+            if hasattr(self.ex, "make_ell_band") and os.environ.get("DDH_SPHERE_DENSE", "0") != "1" and \
+                    getattr(self.dist, "size", 1) == 1:
+                from .ellband import EllBandPlan
+                above = lambda m: (np.arange(nl) >= m)[None, :]
+                rv = [np.repeat(self.row_valid[:, m, :] * above(m), 2, axis=0) for m in range(nm)]
+                cv = [np.repeat(self.col_valid[:, m, :] * above(m), 2, axis=0) for m in range(nm)]
+                # (transposed systems: equation modes are the columns)
+                plan = EllBandPlan(lambda m: self._real_form_transposed(self.M_tl, m),
+                                   lambda m: self._real_form_transposed(self.L_tl, m), cv, rv, [], [], nl, range(nm))
+                if plan.per and not plan.dense_groups and plan.nbc == 0 and plan.mp == 0:
+                    nslots = R * nl
+                    limit = [R * max(nl - m, 0) for m in range(nm)]          # slots (nl - 1 - ell) R + c with ell >= m
+                    dev = self.ex.make_ell_band(plan, 2 * R, nslots, nm, nl, limit)
+                    rhs = np.zeros((2 * R, nslots, nm, nl))
+                    for m in range(nm):
+                        for c in range(R):
+                            ell = np.flatnonzero(self.col_valid[c, m, :] * (np.arange(nl) >= m))     # (unknown (c, ell): a row of A^T)
+                            rhs[2 * c, (nl - 1 - ell) * R + c, m, ell] = 1.0
+                    off = np.concatenate([[0], np.cumsum([(R * max(nl - m, 0)) ** 2 for m in range(nm)])]).astype(np.int64)
+                    self._sband = dict(plan=plan, dev=dev, rhs=self.ex.from_host(rhs), x=self.ex.zeros((2 * R, nslots, nm, nl)),
+                                       off=self.ex.from_host_int64(off), count=int(off[-1]), nslots=nslots)
+                    logger.info("sphere LHS: inverses from the band LU of the real-form systems (kl %d, ku %d, %d unknowns at m = 0)"
+                                % (plan.kl, plan.ku, plan.nmax))
+        return self._sband
+
     def _inverse_batch(self, a, b, old=None):
-        """Per-m inverse of (a M + b L) restricted to the valid modes, embedded with zeros elsewhere: formed and
-        inverted on the device (executor.make_dense_inverse; M_m, L_m are uploaded once) and applied as one batched
-        complex GEMV."""
+        """Per-m inverse of (a M + b L) restricted to the valid modes, embedded with zeros elsewhere, applied as one
+        batched complex GEMV.  Formed on the device: from unit solves against the band LU of the transposed real-form
+        systems (see above) where the matrices allow it, else by the dense Gauss-Jordan kernel
+        (executor.make_dense_inverse; M_m, L_m are uploaded once)."""
         nm, nl = self.basis.nm, self.basis.nl
+        band = self._band_inverse_setup()
+        if band:
+            band["dev"].factor(a, b, index=0)
+            band["dev"].solve(0, band["rhs"], band["x"])
+            flat = self.ex.gather_complex_inverse(band["x"], band["off"], band["count"], self.R, nl, nm, band["nslots"])
+            return self.ex.make_cgemv_batch_flat(nm, nl, self.R, flat, old=old)
         if self._dinv is None:
             Ms, Ls, rvs, cvs = [], [], [], []
             for m in range(nm):

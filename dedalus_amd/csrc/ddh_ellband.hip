@@ -16,6 +16,7 @@
 // Algorithmic cost per solve: 2 (kl + W + mp) n flops and 16 n bytes per (group, slot) -- against 2 n^2 for the dense
 // inverse -- and the factorization is O(n kl W) per group instead of O(n^3).
 #include "ddh_common.h"
+#include <algorithm>
 
 namespace ddh {
 
@@ -415,6 +416,30 @@ __global__ void ellband_fill_rows_kernel(const double *__restrict__ P, const lon
     FL[e * eb_flw(nw) + nw] = __longlong_as_double(i + nw < np ? rowoff[e + nw] : 0L);
 }
 
+// Complex inverses from unit solves of the real-form, transposed systems (the sphere's per-m systems, which have ONE
+// right-hand side per step and therefore keep their dense-inverse GEMV -- but no longer an O(n^3) inversion): system
+// vectors x [2 R][slot][m][ell], components 2c / 2c + 1 = real / imaginary part of component c, slot
+// s(c, ell) = (nl - 1 - ell) R + c holding  (a M + b L)_m^-T e_(c, ell)  = row (c, ell) of the inverse.  out: per m the
+// row-major (R (nl - m))^2 complex matrix, unknown j = c (nl - m) + (ell - m), at complex offset off[m]
+// (the layout of ddh_dense_inverse_compute / ddh_cgemv_batch_mats).
+__global__ void __launch_bounds__(256)
+ellband_gather_cinv_kernel(const double *__restrict__ x, double2 *__restrict__ out, const long *__restrict__ off, int R,
+                           int nl, int nm, int nslots) {
+    const int m = blockIdx.y;
+    const int ne = nl - m;
+    if (ne <= 0) return;
+    const long n = (long)R * ne;
+    const size_t plane = (size_t)nslots * nm * nl;
+    double2 *o = out + off[m];
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n * n; e += (long)gridDim.x * 256) {
+        const int j = (int)(e / n), jp = (int)(e - (long)j * n);
+        const int c = j / ne, el = j - c * ne, cp = jp / ne, elp = jp - cp * ne;
+        const int sl = (nl - 1 - (m + el)) * R + c;
+        const size_t base = ((size_t)(2 * cp) * nslots + sl) * nm * nl + (size_t)m * nl + (m + elp);
+        o[e] = make_double2(x[base], x[base + plane]);
+    }
+}
+
 struct EbVariant { int nw, wt; };
 static const EbVariant eb_variants[] = {{12, 24}, {20, 40}, {28, 56}, {36, 64}, {36, 96}};
 
@@ -548,6 +573,18 @@ int ddh_ellband_solve(ddh_handle h, int index, const double *rhs_d, double *x_d,
         case 64: launch_backward<64>(p, lu, x_d, grid, st); break;
         default: launch_backward<96>(p, lu, x_d, grid, st); break;
     }
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+int ddh_ellband_gather_complex_inverse(const double *x_d, double *out_d, const long *off_d, int ncomp, int nl, int nm,
+                                       int nslots, void *stream) {
+    if (!x_d || !out_d || !off_d || ncomp < 1 || nl < 1 || nm < 1 || nslots < ncomp * nl)
+        return fail("ellband_gather_complex_inverse: bad arguments");
+    const long nmax = (long)ncomp * nl;
+    const unsigned bx = (unsigned)std::min<long>((nmax * nmax + 255) / 256, 4096);
+    hipLaunchKernelGGL(ellband_gather_cinv_kernel, dim3(bx, nm), dim3(256), 0, as_stream(stream), x_d, (double2 *)out_d, off_d,
+                       ncomp, nl, nm, nslots);
     DDH_HIP(hipGetLastError());
     return 0;
 }

@@ -363,6 +363,18 @@ class HipExecutor:
         slot_limit[g]: leading slots that can hold modes of group g)."""
         return EllBand(self, plan, ncomp, nslots, nl, nr, slot_limit)
 
+    def from_host_int64(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.int64), device=self.dev.tdev)
+
+    def gather_complex_inverse(self, x, off, count, ncomp, nl, nm, nslots):
+        """ddh_ellband_gather_complex_inverse: per-m complex inverses (count complex numbers, offsets off[m]) from the unit
+        solves x [2 ncomp][nslots][nm][nl] of the real-form transposed systems"""
+        if getattr(self, "_cinv_out", None) is None or self._cinv_out.numel() != 2 * count:
+            self._cinv_out = self.dev.empty((2 * max(count, 1),))
+        libhip.call("ddh_ellband_gather_complex_inverse", ptr(x), ptr(self._cinv_out), ptr(off), int(ncomp), int(nl), int(nm),
+                    int(nslots), self.dev.stream)
+        return self._cinv_out
+
     def dense_group_solve(self, inv, rhs4, x4, g):
         """x4[:, :, g, :] = inv @ rhs4[:, :, g, :] for one group kept on the dense path (inv: (ncomp nr)^2, device)"""
         R, S, _, nr = rhs4.shape

@@ -251,6 +251,12 @@ int ddh_ellband_create(ddh_handle *h, int nl, int nmax, int kl, int ku, int mp, 
 int ddh_ellband_factor(ddh_handle h, int index, double a, double b, int *nsingular_h, void *stream);
 int ddh_ellband_solve(ddh_handle h, int index, const double *rhs_d, double *x_d, void *stream);
 int ddh_ellband_info(ddh_handle h, int *nw, int *wt, long *factor_bytes);
+/* Complex per-m inverses (the layout of ddh_dense_inverse_compute / ddh_cgemv_batch_mats, complex offsets off_d[m]) from
+ * unit solves of the real-form transposed systems: x_d [2 ncomp][nslots][nm][nl], components 2c / 2c + 1 = real / imaginary
+ * part, slot (nl - 1 - ell) ncomp + c = the solve with the unit right-hand side of unknown (c, ell), i.e. row (c, ell) of
+ * the inverse.  The sphere's timestep change: O(n b^2 + n^2 b) per m instead of the O(n^3) Gauss-Jordan inversion. */
+int ddh_ellband_gather_complex_inverse(const double *x_d, double *out_d, const long *off_d, int ncomp, int nl, int nm,
+                                       int nslots, void *stream);
 
 /* ---- grid-space and vector kernels -------------------------------- */
 /* y[idx[i]] += vals[i] for n distinct indices (device arrays): the constant right-hand-side entries

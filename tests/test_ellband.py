@@ -128,3 +128,54 @@ def test_band_and_dense_paths_take_the_same_steps(monkeypatch, ts):
     # between two summation orders of the SAME dense inverse); buoyancy and velocity agree to rounding
     assert worst["b"] <= 1e-10 and worst["u"] <= 1e-10, worst
     assert max(worst.values()) <= 1e-6, worst
+
+
+def test_sphere_inverses_from_the_band_plan_of_the_real_form_transposed_systems():
+    """(a M + b L)_m^-1 row by row from unit solves of the real-form TRANSPOSED band systems (LAPACK standing in for the
+    device kernels) against numpy's inverse of the complex matrices"""
+    import dedalus_amd.public as d3
+    from oracle.np_executor import NumpyExecutor
+    from dedalus_amd.core.ellband import EllBandPlan
+    s, _, _ = problems.shallow_water(d3, Nphi=32, Ntheta=16, dist_kw=dict(executor=NumpyExecutor()))
+    R, nl, nm = s.R, s.basis.nl, s.basis.nm
+    above = lambda m: (np.arange(nl) >= m)[None, :]
+    rv = [np.repeat(s.row_valid[:, m, :] * above(m), 2, axis=0) for m in range(nm)]
+    cv = [np.repeat(s.col_valid[:, m, :] * above(m), 2, axis=0) for m in range(nm)]
+    plan = EllBandPlan(lambda m: s._real_form_transposed(s.M_tl, m), lambda m: s._real_form_transposed(s.L_tl, m),
+                       cv, rv, [], [], nl, range(nm))
+    assert not plan.dense_groups and plan.nbc == 0 and plan.mp == 0 and plan.kl <= 11 and plan.ku <= 11
+    a, b = 1.0, 0.37
+    for m in (0, 1, nm // 2, nm - 2):
+        ne = nl - m
+        if ne <= 0 or plan.n[m] == 0:
+            continue
+        A = a * s._dense(s.M_tl, m) + b * s._dense(s.L_tl, m)
+        rvm, cvm = s.row_valid[:, m, m:].reshape(-1), s.col_valid[:, m, m:].reshape(-1)
+        B = np.zeros_like(A)
+        B[np.ix_(cvm, rvm)] = np.linalg.inv(A[np.ix_(rvm, cvm)])
+        rhs = np.zeros((2 * R * nl, R * ne))
+        for c in range(R):
+            for e in range(ne):
+                rhs[(2 * c) * nl + m + e, c * ne + e] = 1.0
+        X = plan.reference_solve(m, a, b, rhs)                   # column j: A^-T e_j = row j of the inverse
+        got = np.zeros_like(B)
+        for cp in range(R):
+            got[:, cp * ne:(cp + 1) * ne] = (X[(2 * cp) * nl + m:(2 * cp) * nl + nl] + 1j * X[(2 * cp + 1) * nl + m:(2 * cp + 1) * nl + nl]).T
+        assert np.abs(got - B).max() <= 1e-13 * np.abs(B).max(), m
+
+
+@pytest.mark.gpu
+def test_sphere_band_and_dense_inverses_take_the_same_steps(monkeypatch):
+    import dedalus_amd.public as d3
+    states = []
+    for dense in ("0", "1"):
+        monkeypatch.setenv("DDH_SPHERE_DENSE", dense)
+        s, fields, extra = problems.shallow_water(d3, Nphi=64, Ntheta=32)
+        dt = extra["timestep"]
+        for k in range(6):
+            s.step(dt if k < 3 else 0.7 * dt)                   # (a timestep change: the inverses are formed again)
+        assert bool(s._sband) == (dense == "0")
+        states.append({f.name: np.array(f["c"]) for f in s.state})
+    for name in states[0]:
+        x, y = states[0][name], states[1][name]
+        assert np.abs(x - y).max() <= 1e-12 * max(np.abs(y).max(), 1e-12), name
