@@ -8,13 +8,16 @@
 //     applied to the trailing columns only, multipliers kept per column) -- one workgroup per group, the kl + 1 active
 //     rows live in LDS and slide down the band;
 //   * ddh_ellband_solve sweeps all right-hand sides: the factors of a group are the same for every (m, part) slot, so a
-//     lane owns a slot, the factor rows are fetched once per wavefront and broadcast through v_readlane, and the sliding windows (kl + 1 right-hand side
-//     rows forward, kl + ku solved unknowns backward) stay in registers.  The forward sweep gathers the permuted rows
-//     straight from the solver's [component][slot][group][n] right-hand side and applies the boundary-row combination
-//     T; the backward sweep undoes the column recombination (X = P Y, a short upper band in the permuted order) and
-//     scatters into the state layout.
-// Algorithmic cost per solve: 2 (kl + W + mp) n flops and 16 n bytes per (group, slot) -- against 2 n^2 for the dense
-// inverse -- and the factorization is O(n kl W) per group instead of O(n^3).
+//     lane owns a slot, the factor row of a step is fetched once per wavefront, parked in LDS and read back as broadcast
+//     loads, and the sliding windows (kl + 1 right-hand-side rows forward, kl + ku solved unknowns backward) stay in
+//     registers.  The forward sweep gathers the permuted rows straight from the solver's [component][slot][group][n]
+//     right-hand side and applies the boundary-row combination T; the backward sweep (16 slots per wave, the dot product
+//     of a row split over the four lane quads) undoes the column recombination (X = P Y, a short upper band in the
+//     permuted order) and scatters into the state layout.
+// The sphere uses the same kernels to FORM its per-m dense inverses: unit right-hand sides against the band LU of the
+// real-form transposed systems, then ddh_ellband_gather_complex_inverse (core/sphere.py::_inverse_batch).
+// Algorithmic cost per solve: 2 (2 kl + ku + mp) n flops and 16 n bytes per (group, slot) -- against 2 n^2 for the dense
+// inverse -- and the factorization is O(n kl (kl + ku)) per group instead of O(n^3).
 #include "ddh_common.h"
 #include <algorithm>
 
@@ -30,10 +33,10 @@ __host__ __device__ constexpr int eb_rw(int wt) { return (4 * eb_qw(wt) + 2 + 15
 __host__ __device__ constexpr int eb_u_index(int wt, int s1) { return s1 == 0 ? 4 * eb_qw(wt) : ((s1 - 1) % 4) * eb_qw(wt) + (s1 - 1) / 4; }
 
 struct EllBandLu {
-    double *Lm = nullptr;        // [nl][nmax][64]       column j: pivot row offset (as a double), then the multipliers of
-                                 //                      rows j+1 .., zero padded
-    double *U = nullptr;         // [nl][nmax][nv * 64]  row i: 1 / diagonal, the kl + ku super diagonals zero padded to wt,
-                                 //                      then the recombination's super diagonals of that row
+    double *Lm = nullptr;        // [nl][np][eb_flw(nw)]  column j: pivot row offset (as a double), the multipliers of rows
+                                 //                       j+1 .., zero padded to nw - 1, the offset of the row entering the window
+    double *U = nullptr;         // [nl][np][eb_rw(wt)]   row i in the quad layout of ellband_backward_kernel: super diagonals,
+                                 //                       recombination, 1 / diagonal, column offset
 };
 
 struct EllBand : HandleBase {
