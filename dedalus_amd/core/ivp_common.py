@@ -128,24 +128,34 @@ class IVPLifecycle:
         for f in self.state:
             if getattr(f, "_authority", "device") != "device" or getattr(f, "layout", "c") != "c":
                 return False
+            if getattr(f, "_host_dirty", False):         # (a constant the user has looked at or set: uploaded by an ordinary step)
+                return False
         return True
 
     def _graph_replay(self, dt, wall_time):
-        """-> True when the step was advanced by replaying (or capturing + replaying) the graph"""
+        """-> True when the step was advanced by replaying (or capturing + replaying) a graph"""
         if not self._graph_wanted() or getattr(self.ex, "name", "") != "hip" or getattr(self.dist, "size", 1) > 1:
             return False
-        from .timesteppers import RungeKuttaIMEX
+        from .timesteppers import RungeKuttaIMEX, MultistepIMEX
         ts = self.timestepper
-        if not isinstance(ts, RungeKuttaIMEX) or getattr(self.ex, "timer", None) is not None:
+        if not isinstance(ts, (RungeKuttaIMEX, MultistepIMEX)) or getattr(self.ex, "timer", None) is not None:
             return False
         st = getattr(self, "_graph", None)
         if st is None:
-            st = self._graph = dict(dt=None, seen=0, graph=None, failed=False)
+            st = self._graph = dict(dt=None, seen=0, graphs={}, failed=False)
         if st["failed"] or not self._state_is_clean() or getattr(self, "solve_probe", None) is not None:
             return False
         if dt != st["dt"]:                   # (re)start: two ordinary steps with this dt first (factorization, plans, buffers)
-            st.update(dt=dt, seen=0, graph=None)
-        if st["graph"] is None:
+            st.update(dt=dt, seen=0, graphs={})
+        # Runge-Kutta: one graph.  Multistep: the history buffers rotate, one graph per phase of the rotation -- and only
+        # once the start-up orders are over and the whole timestep history equals dt (the coefficients are constant then)
+        phase = (1, 0)
+        if isinstance(ts, MultistepIMEX):
+            phase = ts.graph_phase(dt)
+            if phase is None:
+                return False
+        g = st["graphs"].get(phase[1])
+        if g is None:
             st["seen"] += 1
             if st["seen"] <= 2:
                 return False
@@ -156,15 +166,20 @@ class IVPLifecycle:
                 torch.cuda.synchronize()
                 with torch.cuda.graph(g):
                     ts.step(dt, wall_time)
-                st["graph"] = g
+                st["graphs"][phase[1]] = g
             except Exception as e:                      # something in the step is not capturable: never try again
                 st["failed"] = True
                 logger.warning("step graph capture failed (%s): falling back to ordinary launches" % (e,))
                 self.sim_time = t0
                 return False
-            self.sim_time = t0                          # capture only recorded the launches
+            self.sim_time = t0                          # capture only recorded the launches (the host side of the step ran)
+            g.replay()
+            self.sim_time = t0 + dt
+            return True
         t0 = self.sim_time
-        st["graph"].replay()
+        g.replay()
+        if isinstance(ts, MultistepIMEX):
+            ts.graph_advance(dt)
         self.sim_time = t0 + dt
         return True
 

@@ -1177,17 +1177,32 @@ class ConstField(ShOperand):
 
     def __init__(self, dist, name=None):
         self.dist, self.name, self.basis, self.rank = dist, name, None, 0
-        self.value = np.zeros((1, 1, 1))
+        self._value = np.zeros((1, 1, 1))
+        self._host_dirty = True          # the host copy has to reach the solver's state vector before the next step
+        self._pull = None                # set by the solver after a step: fetches the solved value when somebody asks
         self.args = ()
 
     def __repr__(self):
         return self.name or "<ConstField %d>" % id(self)
 
+    @property
+    def value(self):
+        """The number, as a (1, 1, 1) array.  While a solver steps, the solved value stays on the device (no host round
+        trip per step); it is fetched here, on demand -- and since the caller may write into the array it gets, the
+        host copy counts as modified from then on (one small upload before the next step)."""
+        if self._pull is not None:
+            pull, self._pull = self._pull, None
+            self._value[...] = pull()
+        self._host_dirty = True
+        return self._value
+
     def __getitem__(self, key):
         return self.value
 
     def __setitem__(self, key, data):
-        self.value[...] = data
+        self._pull = None
+        self._value[...] = data
+        self._host_dirty = True
 
     def change_scales(self, scales):
         pass
@@ -1751,11 +1766,14 @@ class ShellSolverBase:
     def sync_state_to_device(self):
         for v, m in zip(self.variables, self.vmap):
             if isinstance(v, ConstField):
+                if not v._host_dirty:                      # untouched since the last step: the state vector holds it
+                    continue
                 sc, off, nr = m[0]
                 col = np.zeros((1, 2 * self.nm, self.nl, 1))
                 if self.m0 == 0:                           # the (m = 0, ell = 0) slot lives on the first rank
                     col[0, 0, 0, 0] = float(v.value.reshape(-1)[0])
                 self.ex.assign(self.X4[sc:sc + 1, :, :, off:off + 1], self.ex.from_host(col))
+                v._host_dirty = False
                 continue
             c = v.require_coeff_space()
             for comp, (sc, off, nr) in enumerate(m):
@@ -1765,12 +1783,21 @@ class ShellSolverBase:
         for v, m in zip(self.variables, self.vmap):
             if isinstance(v, ConstField):
                 sc, off, nr = m[0]
-                val = float(np.asarray(self.ex.download(self.X4[sc:sc + 1, 0:1, 0:1, off:off + 1])).reshape(-1)[0])
-                if self.dist.size > 1:
-                    val = self.dist.pcomm.allreduce_sum(val if self.m0 == 0 else 0.0)
-                v.value[...] = val
+
+                def pull(sc=sc, off=off):                  # (on demand: a download per step would serialize host and device)
+                    val = float(np.asarray(self.ex.download(self.X4[sc:sc + 1, 0:1, 0:1, off:off + 1])).reshape(-1)[0])
+                    if self.dist.size > 1:
+                        val = self.dist.pcomm.allreduce_sum(val if self.m0 == 0 else 0.0)
+                    return val
+                v._pull = pull
+                v._host_dirty = False
                 continue
-            c = self.ex.empty(v._cshape())
+            # one coefficient buffer per variable for the life of the solver: a step graph (core/ivp_common.py) replays the
+            # copies into the very tensors the fields hold, whichever rotation phase of a multistep scheme recorded them
+            bufs = self.__dict__.setdefault("_coeff_bufs", {})
+            c = bufs.get(id(v))
+            if c is None:
+                c = bufs[id(v)] = self.ex.empty(v._cshape())
             for comp, (sc, off, nr) in enumerate(m):
                 self.ex.assign(c[comp:comp + 1], self.X4[sc:sc + 1, :, :, off:off + nr])
             v._set_device_coeff(c)
@@ -1788,11 +1815,15 @@ class ShellSolverBase:
                 if eq["rank"] != 0:
                     raise NotImplementedError("constant right-hand side of a tensor equation")
                 sc, off, nr = m[0]
-                col = np.zeros((1, 2 * self.nm, self.nl, nr))
-                if self.m0 == 0:
-                    col[0, 0, 0, 0] = F / SphereBasis.constant_mode_value * \
-                        (1.0 if isinstance(eq["basis"], SurfaceBasis) else 1.0 / self._radial_constant(eq["basis"]))
-                ex.assign(out4[sc:sc + 1, :, :, off:off + nr], ex.from_host(col))
+                cache = self.__dict__.setdefault("_const_F_cols", {})
+                key = (id(eq), sc, off, nr)
+                if key not in cache:                       # (uploaded once: no host-to-device copy inside a step)
+                    col = np.zeros((1, 2 * self.nm, self.nl, nr))
+                    if self.m0 == 0:
+                        col[0, 0, 0, 0] = F / SphereBasis.constant_mode_value * \
+                            (1.0 if isinstance(eq["basis"], SurfaceBasis) else 1.0 / self._radial_constant(eq["basis"]))
+                    cache[key] = ex.from_host(col)
+                ex.assign(out4[sc:sc + 1, :, :, off:off + nr], cache[key])
             else:
                 c = F.eval_c()
                 for comp, (sc, off, nr) in enumerate(m):

@@ -118,6 +118,26 @@ class MultistepIMEX(_SolveMixin):
             self._need_lx = self._need_lx or bool(np.any(np.asarray(b)[1:] != 0.0))
         self.LX = deque((ex.zeros(shape) if self._need_lx else None) for _ in range(self.bmax))
 
+    # ---- fixed-timestep steps as HIP graphs (core/ivp_common.py::_graph_replay) -------------------------------------------
+    # A multistep step is the same launch sequence every time once the start-up orders are over and the timestep history
+    # is constant -- except that the history buffers rotate: the pattern of buffer addresses repeats with the period
+    # below, so one graph per phase is captured and the phases are replayed in turn.
+    def graph_phase(self, dt):
+        """-> (period, phase) of the step about to be taken, or None while the step still differs from its successors"""
+        if self._iteration < self.steps + 1 or any(h != dt for h in self.dt):
+            return None
+        period = int(np.lcm.reduce([len(self.MX), len(self.LX), len(self.F)]))
+        return period, self._iteration % period
+
+    def graph_advance(self, dt):
+        """the host-side part of a step whose launches were replayed from a graph"""
+        self.dt.rotate()
+        self.dt[0] = dt
+        self._iteration += 1
+        self.MX.rotate()
+        self.LX.rotate()
+        self.F.rotate()
+
     def step(self, dt, wall_time=None):
         s = self.solver
         ex, pack = s.ex, s.pack

@@ -105,3 +105,27 @@ def test_shell_convection_config_size_sampled_ell_systems():
           % (worst_m, worst_r, worst_x))
     b = np.asarray(f["b"]["c"])
     assert np.isfinite(b).all()
+
+
+@pytest.mark.gpu
+def test_multistep_step_graphs_reproduce_ordinary_steps():
+    """SBDF2 with a fixed timestep replayed from HIP graphs (one per phase of the history-buffer rotation,
+    core/ivp_common.py::_graph_replay) against ordinary launches; the constant tau_p stays on the device between steps
+    and is fetched on demand"""
+    import problems
+    import dedalus_amd.public as d3
+    out = []
+    for graph in (False, True):
+        s, f = problems.shell_convection(d3, shape=(16, 8, 16), timestepper="SBDF2")
+        if graph:
+            s.enable_step_graph(True)
+        for _ in range(12):
+            s.step(0.02)
+        if graph:
+            assert len(s._graph["graphs"]) == 2 and not s._graph["failed"]       # both phases captured and replayed
+        out.append({v.name: np.array(v["c"]) for v in s.state})
+        s.step(0.01)                                                             # a new timestep: ordinary launches again
+        s.step(0.01)
+        out[-1]["after"] = np.array(f["b"]["c"])
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k

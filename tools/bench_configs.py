@@ -63,7 +63,7 @@ def refactor_time(name, solver, dt, step_s):
           flush=True)
 
 
-def run_shell(name, kw, dt, warm, steps):
+def run_shell(name, kw, dt, warm, steps, graph=False):
     """Under torch.distributed.run (one rank per GPU) the azimuthal wavenumbers are sharded over the ranks
     (mesh = (WORLD_SIZE,)): `python -m torch.distributed.run --nproc-per-node 4 ... tools/bench_configs.py shell`."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,6 +72,9 @@ def run_shell(name, kw, dt, warm, steps):
         name += " x%d ranks" % world
     t0 = time.time()
     solver, f = problems.shell_convection(d3, **kw)
+    if graph:
+        solver.enable_step_graph(True)
+        name += " [hipGraph]"
     solver.step(dt)
     solver.ex.sync()
     print("%-34s setup + first step: %.1f s" % (name, time.time() - t0), flush=True)
@@ -217,6 +220,8 @@ if __name__ == "__main__":
     if "shell" in sys.argv[1:]:
         shape = tuple(int(x) for x in os.environ.get("SHELL_SHAPE", "256,128,128").split(","))
         run_shell("H  shell convection %dx%dx%d SBDF2" % shape, dict(shape=shape, timestepper="SBDF2"), 0.05, 3, 10)
+        if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+            run_shell("H  shell convection %dx%dx%d SBDF2" % shape, dict(shape=shape, timestepper="SBDF2"), 0.05, 8, 20, graph=True)
         sys.exit(0)
     if "r2" in sys.argv[1:]:
         run("R2 rb2d 512x256 RK222", problems.rayleigh_benard_2d, dict(Nx=512, Nz=256), 1e-3, 5, 50)
