@@ -168,10 +168,34 @@ def test_fixed_dt_step_graph_matches_ordinary_launches():
         b.step(dt)
         if i == 10:
             assert rel(np.array(fb["b"]["c"]), np.array(fa["b"]["c"])) < 1e-13      # host access: state not clean next step
-    assert b._graph["graph"] is not None and not b._graph["failed"]
+    assert b._graph["graphs"] and not b._graph["failed"]
     assert abs(b.sim_time - a.sim_time) < 1e-15 and b.iteration == a.iteration
     for k in ("p", "b", "u"):
         assert rel(np.array(fb[k]["c"]), np.array(fa[k]["c"])) < 1e-13, k
+
+
+@pytest.mark.parametrize("case", ["kdv_SBDF2", "rb2d_SBDF2", "kdv_CNAB2"])
+def test_multistep_step_graphs_match_ordinary_launches(case):
+    """Multistep schemes rotate their history buffers: one HIP graph per phase of the rotation, replayed in turn
+    (core/ivp_common.py::_graph_replay, MultistepIMEX.graph_phase); a timestep change falls back to ordinary launches
+    through the start-up of the new history and captures again."""
+    import dedalus_amd.public as d3
+    name, ts = case.split("_")
+    make = (lambda: problems.kdv_burgers(d3, Nx=256, timestepper=ts)) if name == "kdv" else \
+        (lambda: problems.rayleigh_benard_2d(d3, Nx=64, Nz=32, timestepper=ts))
+    a, fa = make()
+    b, fb = make()
+    b.enable_step_graph(True)
+    dt = 2e-3 if name == "kdv" else 1e-3
+    for i, h in enumerate([dt] * 11 + [0.5 * dt] * 9):
+        a.step(h)
+        b.step(h)
+        if i == 10:
+            assert len(b._graph["graphs"]) >= 2 and not b._graph["failed"]
+    assert len(b._graph["graphs"]) >= 2 and not b._graph["failed"]
+    assert abs(b.sim_time - a.sim_time) < 1e-15 and b.iteration == a.iteration
+    for k in fa:
+        assert np.array_equal(np.array(fb[k]["c"]), np.array(fa[k]["c"])), k
 
 
 def test_direct_right_hand_side_path_on_the_device(monkeypatch):

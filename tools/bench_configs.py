@@ -232,6 +232,14 @@ if __name__ == "__main__":
     if "sphere" in sys.argv[1:]:
         run_sphere("S  shallow water 512x256 RK222", dict(Nphi=512, Ntheta=256), 5, 50)
         sys.exit(0)
+    if "graphs" in sys.argv[1:]:         # launch-bound configurations with the fixed-timestep steps replayed from HIP graphs
+        run("K  kdv N=1024 SBDF2", problems.kdv_burgers, dict(Nx=1024, timestepper="SBDF2"), 2e-3, 20, 2000)
+        run("K  kdv N=1024 SBDF2", problems.kdv_burgers, dict(Nx=1024, timestepper="SBDF2"), 2e-3, 20, 2000, graph=True)
+        run("R2 rb2d 512x256 RK222", problems.rayleigh_benard_2d, dict(Nx=512, Nz=256), 1e-3, 5, 200)
+        run("R2 rb2d 512x256 RK222", problems.rayleigh_benard_2d, dict(Nx=512, Nz=256), 1e-3, 5, 200, graph=True)
+        os.environ["DDH_STEP_GRAPH"] = "1"
+        run_sphere("S  shallow water 512x256 RK222 [hipGraph]", dict(Nphi=512, Ntheta=256), 5, 200)
+        sys.exit(0)
     run("K  kdv N=1024 SBDF2", problems.kdv_burgers, dict(Nx=1024, timestepper="SBDF2"), 2e-3, 20, 200)
     run("R2 rb2d 512x256 RK222", problems.rayleigh_benard_2d, dict(Nx=512, Nz=256), 1e-3, 5, 50)
     run("rb3d 128x128x64 RK222", problems.rayleigh_benard_3d, dict(Nx=128, Ny=128, Nz=64), 1e-3, 3, 20)
