@@ -161,6 +161,7 @@ class IVPLifecycle:
                 return False
             torch = self.ex.torch
             t0 = self.sim_time
+            snap = ts.graph_snapshot() if hasattr(ts, "graph_snapshot") else None
             try:
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
@@ -171,6 +172,8 @@ class IVPLifecycle:
                 st["failed"] = True
                 logger.warning("step graph capture failed (%s): falling back to ordinary launches" % (e,))
                 self.sim_time = t0
+                if snap is not None:                    # the aborted capture rotated the history without running a kernel
+                    ts.graph_rollback(snap)
                 return False
             self.sim_time = t0                          # capture only recorded the launches (the host side of the step ran)
             g.replay()

@@ -129,6 +129,15 @@ class MultistepIMEX(_SolveMixin):
         period = int(np.lcm.reduce([len(self.MX), len(self.LX), len(self.F)]))
         return period, self._iteration % period
 
+    def graph_snapshot(self):
+        """host state a step mutates (taken before a capture: the capture runs the host side of step() without
+        executing a kernel, so a capture that fails must be undone before the step is taken by ordinary launches)"""
+        return (list(self.dt), self._iteration, list(self.MX), list(self.LX), list(self.F), self._LHS_params, self._lu)
+
+    def graph_rollback(self, snap):
+        dts, self._iteration, mx, lx, f, self._LHS_params, self._lu = snap
+        self.dt, self.MX, self.LX, self.F = deque(dts), deque(mx), deque(lx), deque(f)
+
     def graph_advance(self, dt):
         """the host-side part of a step whose launches were replayed from a graph"""
         self.dt.rotate()

@@ -268,6 +268,24 @@ def golden_ivp():
     print("wrote ivp.npz")
 
 
+def golden_schemes():
+    """End states of the reference for EVERY registered IMEX scheme (core/timesteppers.py:190-725) on the forced heat
+    problem of its own timestepper test (tests/test_ivp.py:20-49), KdV-Burgers, and the tau-bordered 2-D
+    Rayleigh-Benard problem with constant and with varying timesteps (tests/problems.py::SCHEME_CASES)."""
+    d3 = refshim.load_reference()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import problems
+    out = {}
+    for name in problems.SCHEME_CASES:
+        solver, res = problems.run_scheme_case(d3, name)
+        out[name + "__sim_time"] = np.array(solver.sim_time)
+        for k, v in res.items():
+            out[name + "__" + k] = v
+        print(name, {k: float(np.linalg.norm(v)) for k, v in res.items()})
+    np.savez_compressed(os.path.join(GOLD, "ivp_schemes.npz"), **out)
+    print("wrote ivp_schemes.npz", os.path.getsize(os.path.join(GOLD, "ivp_schemes.npz")) >> 10, "KiB")
+
+
 def golden_pencils():
     """The reference's OWN pencil matrices (Subproblem.build_matrices, core/subsystems.py:497-596: M_min, L_min and
     the pre_left / pre_right_pinv selections) of the 3-D Rayleigh-Benard problem at the BASELINE coupled size Nz = 256

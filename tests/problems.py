@@ -177,6 +177,59 @@ IVP_CASES = {
 }
 
 
+def heat_forced(d3, N=16, timestepper="SBDF2", dist_kw=None):
+    """The reference's timestepper test problem (tests/test_ivp.py:20-49: forced 1-D heat equation, analytic solution
+    (1 - exp(-t)) sin x) on the real Fourier basis, plus a second forced mode so that both parities carry data."""
+    c = d3.Coordinate('x')
+    dist = d3.Distributor(c, dtype=np.float64, **(dist_kw or {}))
+    b = d3.RealFourier(c, size=N, bounds=(0, 2 * np.pi), dealias=1)
+    x = dist.local_grid(b, scale=1)
+    u = dist.Field(name='u', bases=b)
+    F = dist.Field(name='F', bases=b)
+    F['g'] = np.sin(x) + 0.5 * np.cos(3 * x)
+    dx = lambda A: d3.Differentiate(A, c)
+    problem = d3.IVP([u], namespace=locals())
+    problem.add_equation("dt(u) - dx(dx(u)) = F")
+    solver = problem.build_solver(getattr(d3, timestepper))
+    return solver, dict(u=u)
+
+
+ALL_SCHEMES = ("CNAB1", "SBDF1", "CNAB2", "MCNAB2", "SBDF2", "CNLF2", "SBDF3", "SBDF4", "RK111", "RK222", "RK443", "RKSMR")
+
+# Every registered scheme stepped end to end (the reference pins all of them, tests/test_ivp.py:20-49).  A timestep
+# SEQUENCE per case: the constant ones reach the steady coefficients past the start-up ramp of SBDF3 / SBDF4 / CNLF2,
+# the varying ones exercise the variable-step coefficient formulas and the refactorization on every change.
+SCHEME_CASES = {}
+for _ts in ALL_SCHEMES:
+    SCHEME_CASES["heat16_" + _ts] = (heat_forced, dict(N=16, timestepper=_ts), [1e-3] * 12)
+    SCHEME_CASES["kdv64_" + _ts] = (kdv_burgers, dict(Nx=64, timestepper=_ts), [2e-3] * 10)
+    SCHEME_CASES["rb2d_32x16_" + _ts] = (rayleigh_benard_2d, dict(Nx=32, Nz=16, timestepper=_ts), [1e-3] * 7)
+    SCHEME_CASES["rb2d_32x16_vardt_" + _ts] = (rayleigh_benard_2d, dict(Nx=32, Nz=16, timestepper=_ts),
+                                               [1e-3, 1e-3, 1.5e-3, 1.5e-3, 0.8e-3, 1.2e-3, 1.2e-3, 1.2e-3])
+
+
+# Tolerances of the scheme cases: rel-L2, except that the Crank-Nicolson family (CNAB1/2, CNLF2) leaves the pressure and
+# tau amplitudes of the index-2 constraints undamped -- they alternate from step to step in the reference too and pass
+# through ~0 (|p| = 7.6e-8 where the damped schemes have 0.325) -- so their error is measured against the amplitude these
+# fields have in the damped schemes (SCHEME_FLOOR) when their own norm is smaller.
+SCHEME_TOL = {"p": 1e-10, "b": 1e-10, "u": 1e-9, "tau_b1": 1e-5, "tau_b2": 1e-5, "tau_u1": 1e-8, "tau_u2": 1e-8}
+SCHEME_FLOOR = {"p": 0.325, "tau_b1": 7.6e-4, "tau_b2": 1.6e-4, "tau_u1": 2.4e-5, "tau_u2": 3.7e-5}
+
+
+def scheme_error(key, v, ref):
+    return np.linalg.norm(v - ref) / max(np.linalg.norm(ref), SCHEME_FLOOR.get(key, 1e-300))
+
+
+def run_scheme_case(d3, name, dist_kw=None, before_step=None):
+    builder, kw, dts = SCHEME_CASES[name]
+    solver, fields = builder(d3, dist_kw=dist_kw, **kw)
+    for i, dt in enumerate(dts):
+        if before_step is not None:
+            before_step(solver, i)
+        solver.step(dt)
+    return solver, {k: np.array(f['c']) for k, f in fields.items()}
+
+
 def run_case(d3, name, dist_kw=None):
     builder, kw, dt, nsteps = IVP_CASES[name]
     solver, fields = builder(d3, dist_kw=dist_kw, **kw)

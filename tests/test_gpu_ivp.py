@@ -174,6 +174,77 @@ def test_fixed_dt_step_graph_matches_ordinary_launches():
         assert rel(np.array(fb[k]["c"]), np.array(fa[k]["c"])) < 1e-13, k
 
 
+@pytest.fixture(scope="module")
+def gold_schemes(golden_dir):
+    return np.load(os.path.join(golden_dir, "ivp_schemes.npz"))
+
+
+@pytest.mark.parametrize("name", list(problems.SCHEME_CASES))
+def test_every_scheme_on_the_device_matches_reference(gold_schemes, name):
+    """All 12 registered IMEX schemes stepped by the HIP path against the reference's own end states
+    (tests/golden/ivp_schemes.npz <- oracle/make_golden.py::golden_schemes; reference: tests/test_ivp.py:20-49,
+    core/timesteppers.py:190-725): forced heat equation, KdV-Burgers, tau-bordered 2-D Rayleigh-Benard with constant
+    and with varying timesteps.  float64, rel-L2 (problems.SCHEME_TOL)."""
+    import dedalus_amd.public as d3
+    solver, res = problems.run_scheme_case(d3, name)
+    assert solver.ex.name == "hip"
+    assert abs(solver.sim_time - float(gold_schemes[name + "__sim_time"])) < 1e-15
+    for k, v in res.items():
+        assert np.isfinite(v).all()
+        err = problems.scheme_error(k, v, gold_schemes[name + "__" + k])
+        assert err < problems.SCHEME_TOL.get(k, 1e-10), (name, k, err)
+
+
+@pytest.mark.parametrize("scheme", problems.ALL_SCHEMES)
+def test_every_scheme_replayed_from_step_graphs(gold_schemes, scheme):
+    """The same reference end states with the steps replayed from HIP graphs wherever the pattern allows (after the
+    start-up orders, constant timestep), and bit-identity with ordinary launches over a longer run that visits every
+    phase of the history rotation."""
+    import dedalus_amd.public as d3
+    for case in ("kdv64_", "rb2d_32x16_"):
+        name = case + scheme
+        solver, res = problems.run_scheme_case(d3, name, before_step=lambda s, i: s.enable_step_graph(True) if i == 0 else None)
+        if scheme not in ("SBDF4",) or case == "kdv64_":
+            assert solver._graph["graphs"] and not solver._graph["failed"], name
+        for k, v in res.items():
+            err = problems.scheme_error(k, v, gold_schemes[name + "__" + k])
+            assert err < problems.SCHEME_TOL.get(k, 1e-10), (name, k, err)
+    a, fa = problems.kdv_burgers(d3, Nx=128, timestepper=scheme)
+    b, fb = problems.kdv_burgers(d3, Nx=128, timestepper=scheme)
+    b.enable_step_graph(True)
+    for h in [2e-3] * 16 + [1e-3] * 12:
+        a.step(h)
+        b.step(h)
+    assert b._graph["graphs"] and not b._graph["failed"]
+    assert abs(b.sim_time - a.sim_time) < 1e-15 and b.iteration == a.iteration
+    assert np.array_equal(np.array(fb["u"]["c"]), np.array(fa["u"]["c"]))
+
+
+@pytest.mark.parametrize("scheme", ["SBDF2", "SBDF3", "CNAB2", "RK222"])
+def test_failed_graph_capture_leaves_the_history_intact(scheme):
+    """A capture runs the host side of step() (history rotation, iteration count) without executing a kernel: when
+    it fails the timestepper's host state is rolled back before the step is taken by ordinary launches
+    (MultistepIMEX.graph_snapshot / graph_rollback) -- the run equals one that never tried."""
+    import torch
+    import dedalus_amd.public as d3
+    a, fa = problems.kdv_burgers(d3, Nx=128, timestepper=scheme)
+    b, fb = problems.kdv_burgers(d3, Nx=128, timestepper=scheme)
+    b.enable_step_graph(True)
+    real = b.timestepper.step
+
+    def flaky(dt, wall_time=None):
+        real(dt, wall_time)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("forced capture failure")
+    b.timestepper.step = flaky
+    for h in [2e-3] * 12:
+        a.step(h)
+        b.step(h)
+    assert b._graph["failed"] and not b._graph["graphs"]
+    assert abs(b.sim_time - a.sim_time) < 1e-15 and b.iteration == a.iteration
+    assert np.array_equal(np.array(fb["u"]["c"]), np.array(fa["u"]["c"]))
+
+
 @pytest.mark.parametrize("case", ["kdv_SBDF2", "rb2d_SBDF2", "kdv_CNAB2"])
 def test_multistep_step_graphs_match_ordinary_launches(case):
     """Multistep schemes rotate their history buffers: one HIP graph per phase of the rotation, replayed in turn

@@ -119,3 +119,24 @@ def test_direct_right_hand_side_path_matches_the_gather_matvec(monkeypatch):
             assert np.linalg.norm(r1[k] - r0[k]) <= 1e-13 * max(np.linalg.norm(r0[k]), 1e-300), (case, k)
     s, _ = run("kdv64_rk443", True)
     assert s.F_direct is None
+
+
+@pytest.fixture(scope="module")
+def gold_schemes(golden_dir):
+    return np.load(os.path.join(golden_dir, "ivp_schemes.npz"))
+
+
+@pytest.mark.parametrize("name", list(problems.SCHEME_CASES))
+def test_every_scheme_steps_like_the_reference(gold_schemes, name):
+    """All 12 registered IMEX schemes end to end (reference: tests/test_ivp.py:20-49 steps every entry of
+    timesteppers.schemes): start-up order ramps of SBDF3 / SBDF4, the leap-frog history of CNLF2, variable-step
+    coefficients, against the reference's own end states (oracle/make_golden.py::golden_schemes)."""
+    import dedalus_amd.public as d3
+    from oracle.np_executor import NumpyExecutor
+    solver, res = problems.run_scheme_case(d3, name, dist_kw=dict(executor=NumpyExecutor()))
+    assert abs(solver.sim_time - float(gold_schemes[name + "__sim_time"])) < 1e-15
+    for k, v in res.items():
+        ref = gold_schemes[name + "__" + k]
+        assert v.shape == ref.shape
+        err = problems.scheme_error(k, v, ref)
+        assert err < problems.SCHEME_TOL.get(k, 1e-10), (name, k, err)

@@ -2,7 +2,7 @@
 # One parameterised GPU-box script (replaces the per-experiment r3*.sh files):  gpurun -- 'bash tools/gpu/run.sh STEP [STEP ...]'
 # Every step writes under gpurun_out/<tag>/ (tag = $TAG or "r4").
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${TAG:-r4}
+TAG=${TAG:-r5}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 bench_line() { python - "$1" <<'PY'
