@@ -81,6 +81,13 @@ def parse():
     ap.add_argument("--size", type=str, default=os.environ.get("BENCH_SIZE", "512,512,256"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=30.0,
+                    help="seconds of one-core CPU work for the cpu_baseline samples (default 30; >= 240 adds 128x128x64)")
+    ap.add_argument("--cpu-replicas", type=int, default=None,
+                    help="one-core replicas of the 64^3 sample run at once (default: min(32, usable cores / 2))")
+    ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker-seconds", type=float, default=5.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker-which", type=str, default="port", help=argparse.SUPPRESS)
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--cfl", action="store_true", help="(kept for old command lines: the adaptive loop now runs by default)")
     ap.add_argument("--no-cfl", action="store_true",
@@ -123,57 +130,135 @@ def host_info():
     return dict(cpu_model=model, cores_total=os.cpu_count(), cores_usable=usable)
 
 
-def cpu_baseline(full_shape, budget_s=30.0):
-    """The oracle executor ("port": the reference's per-pencil algorithm restated -- scipy CSR + SuperLU per pencil,
-    scipy.fft + NumPy pack passes, oracle/np_executor.py) timed on this box's host, ONE core, on bounded samples of
-    the same problem family: 3-D RB 32^3, 64x64x32 and 64^3 and the 2-D config 512x256.  The metric's size is far beyond
-    host memory for the reference's algorithm, so `value` extrapolates the largest 3-D sample with the
-    reference's own speed figure, mode-stages per cpu-second (core/solvers.py:755-778).  `port_vs_reference` is the
-    calibration of this port against the unmodified reference on the build container
-    (profiles/r2_cpu_port_vs_reference.json, tools/cpu_calibration.py)."""
+CPU_CASES = {   # name -> (kind, size kwargs, share of the budget)
+    "rb3d 32x32x32": ("rb3d", dict(Nx=32, Ny=32, Nz=32), 0.15),
+    "rb3d 64x64x32": ("rb3d", dict(Nx=64, Ny=64, Nz=32), 0.2),
+    "rb3d 64x64x64": ("rb3d", dict(Nx=64, Ny=64, Nz=64), 0.3),
+    "rb2d 512x256": ("rb2d", dict(Nx=512, Nz=256), 0.25),
+    "rb3d 128x128x64": ("rb3d", dict(Nx=128, Ny=128, Nz=64), 1.0),       # SURVEY 8(d); only with --cpu-budget >= 240
+}
+
+
+def cpu_sample(name, seconds, which="port"):
+    """One bounded CPU sample on ONE core: build, first step (factorizations), then >= 2 timed RK222 steps for about
+    `seconds`.  which = "port": the oracle executor (oracle/np_executor.py: the reference's per-pencil algorithm restated
+    -- scipy CSR + SuperLU per pencil, scipy.fft + NumPy pack passes); "reference": the UNMODIFIED reference through
+    oracle/refshim (only where /root/reference exists, i.e. never on the GPU box)."""
     import problems
-    import dedalus_amd.public as d3
-    from oracle.np_executor import NumpyExecutor
     os.environ.setdefault("OMP_NUM_THREADS", "1")
-    samples = []
-    # SURVEY 8(d) asks for 64^3 and 128 x 128 x 64: 64^3 runs (2+ steps); 128 x 128 x 64 (4 x the modes: ~1 min of setup +
-    # ~10 s per step on one core) does not fit the budget of the default bench run and is named in `not_run`
-    cases = [("rb3d", dict(Nx=32, Ny=32, Nz=32), 0.15), ("rb3d", dict(Nx=64, Ny=64, Nz=32), 0.2),
-             ("rb3d", dict(Nx=64, Ny=64, Nz=64), 0.3), ("rb2d", dict(Nx=512, Nz=256), 0.25)]
-    for kind, kw, share in cases:
-        build = problems.rayleigh_benard_3d if kind == "rb3d" else problems.rayleigh_benard_2d
-        t0 = time.time()
-        solver, fields = build(d3, timestepper="RK222", dist_kw=dict(executor=NumpyExecutor()), **kw)
-        solver.step(1e-3)                      # factorizations happen here
-        setup = time.time() - t0
-        t0 = time.time()
-        steps = 0
-        while steps < 2 or (time.time() - t0 < share * budget_s * 0.5 and steps < 100):
-            solver.step(1e-3)
-            steps += 1
-        el = time.time() - t0
-        nvar = 5 if kind == "rb3d" else 4
-        modes = nvar * int(np.prod(list(kw.values())))
-        samples.append(dict(case="%s %s" % (kind, "x".join(str(v) for v in kw.values())), steps=steps, seconds=round(el, 2),
-                            setup_s=round(setup, 2), steps_per_s=steps / el, modes=modes,
-                            mode_stages_per_cpu_s=modes * 2 * steps / el))
-    ref3d = samples[2]                          # the largest 3-D sample
+    kind, kw, _ = CPU_CASES[name]
+    if which == "reference":
+        from oracle import refshim
+        d3 = refshim.load_reference()
+        dist_kw = None
+    else:
+        import dedalus_amd.public as d3
+        from oracle.np_executor import NumpyExecutor
+        dist_kw = dict(executor=NumpyExecutor())
+    build = problems.rayleigh_benard_3d if kind == "rb3d" else problems.rayleigh_benard_2d
+    t0 = time.time()
+    solver, fields = build(d3, timestepper="RK222", dist_kw=dist_kw, **kw)
+    solver.step(1e-3)                      # factorizations happen here
+    setup = time.time() - t0
+    t0 = time.time()
+    steps = 0
+    while steps < 2 or (time.time() - t0 < seconds and steps < 100):
+        solver.step(1e-3)
+        steps += 1
+    el = time.time() - t0
+    nvar = 5 if kind == "rb3d" else 4
+    modes = nvar * int(np.prod(list(kw.values())))
+    return dict(case=name, which=which, steps=steps, seconds=round(el, 2), setup_s=round(setup, 2), steps_per_s=steps / el,
+                modes=modes, mode_stages_per_cpu_s=modes * 2 * steps / el,
+                norm_b=float(np.linalg.norm(np.asarray(fields["b"]["c"]))))
+
+
+def cpu_replicas(name, seconds, n, which="port"):
+    """n independent one-core replicas of a sample running AT THE SAME TIME (one process each, `python bench.py
+    --cpu-worker`): what n cores of this host deliver together on the reference's algorithm when nothing is
+    communicated -- an upper bound for an n-rank MPI run of the reference, and the measure of the memory-bandwidth
+    contention a single-core sample hides."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", name, "--cpu-worker-seconds",
+                               str(seconds), "--cpu-worker-which", which], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                              text=True, env=env) for _ in range(n)]
+    res = []
+    for p in procs:
+        out, _ = p.communicate()
+        try:
+            res.append(json.loads(out.strip().splitlines()[-1]))
+        except Exception:
+            pass
+    return res
+
+
+def cpu_baseline(full_shape, budget_s=30.0, replicas=None):
+    """CPU baseline on this box's host cores (rank 0, N = 1 only), bounded samples of the same problem family -- 3-D RB
+    32^3, 64x64x32, 64^3, the 2-D config 512x256, and 128x128x64 when --cpu-budget allows:
+      * one core, one sample after the other ("port"; plus the unmodified reference on the same samples wherever
+        /root/reference exists: `reference_here`);
+      * `replicas`: n one-core copies of the 64^3 sample at once -> aggregate mode-stages per second of n cores.
+    The metric's size is far beyond host memory for the reference's algorithm, so `value` extrapolates the
+    n-core aggregate of the largest 3-D sample with the reference's own speed figure, mode-stages per cpu-second
+    (core/solvers.py:755-778).  `port_vs_reference` is the calibration of this port against the unmodified reference
+    (profiles/r5_cpu_port_vs_reference.json, tools/cpu_calibration.py: same machine, same samples, one core)."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    host = host_info()
+    names = ["rb3d 32x32x32", "rb3d 64x64x32", "rb3d 64x64x64", "rb2d 512x256"]
+    not_run = None
+    if budget_s >= 240:
+        names.append("rb3d 128x128x64")
+    else:
+        not_run = ("rb3d 128x128x64 (SURVEY 8d): ~1 min of setup + ~10 s per step on one core, beyond the default "
+                   "--cpu-budget of %g s; run `python bench.py --cpu-budget 300`; measured on the build container in "
+                   "profiles/r5_cpu_port_vs_reference.json" % budget_s)
+    base = min(budget_s, 30.0)
+    samples = [cpu_sample(n, CPU_CASES[n][2] * base * 0.5) for n in names]
+    big = [x for x in samples if x["case"].startswith("rb3d")][-1]           # the largest 3-D sample
     full_modes = 5 * int(np.prod(full_shape))
-    value = ref3d["mode_stages_per_cpu_s"] / (2 * full_modes)
+    one_core = big["mode_stages_per_cpu_s"] / (2 * full_modes)
+    # the reference itself, where it exists (the build container; the GPU box has no /root/reference)
+    reference_here = None
+    try:
+        from oracle import refshim
+        if refshim.available():
+            reference_here = [cpu_sample(n, CPU_CASES[n][2] * base * 0.5, which="reference")
+                              for n in ("rb3d 32x32x32", "rb3d 64x64x64")]     # (its setup alone is ~80 s at 64^3)
+    except Exception as e:                                   # noqa: BLE001 -- a checker that fails must not fail the bench
+        reference_here = "failed: %s" % (e,)
+    # n replicas at once
+    if replicas is None:
+        replicas = max(1, min(32, host["cores_usable"] // 2))
+    rep = None
+    cores, value, kind = 1, one_core, "port"
+    if replicas > 1:
+        rs = cpu_replicas("rb3d 64x64x64", CPU_CASES["rb3d 64x64x64"][2] * base * 0.5, replicas)
+        if rs:
+            agg = sum(r["mode_stages_per_cpu_s"] for r in rs)
+            rep = dict(case="rb3d 64x64x64", replicas_started=replicas, replicas_finished=len(rs),
+                       per_replica_steps_per_s=[round(r["steps_per_s"], 4) for r in rs],
+                       aggregate_mode_stages_per_s=agg,
+                       per_core_vs_alone=(agg / len(rs)) / samples[2]["mode_stages_per_cpu_s"])
+            cores, value = len(rs), agg / (2 * full_modes)
     calib = None
-    cpath = os.path.join(ROOT, "profiles", "r2_cpu_port_vs_reference.json")
-    if os.path.exists(cpath):
-        cj = json.load(open(cpath))
-        calib = dict(geomean=cj["port_vs_reference_geomean"], measured_on=cj["host"]["cpu_model"],
-                     per_case={"%s %s" % (c["case"], "x".join(str(v) for v in c["size"].values())): round(c["port_vs_reference"], 3)
-                               for c in cj["cases"]},
-                     source="profiles/r2_cpu_port_vs_reference.json")
+    for tag in ("r5", "r2"):
+        cpath = os.path.join(ROOT, "profiles", "%s_cpu_port_vs_reference.json" % tag)
+        if os.path.exists(cpath):
+            cj = json.load(open(cpath))
+            calib = dict(geomean=cj["port_vs_reference_geomean"], measured_on=cj["host"]["cpu_model"],
+                         per_case={"%s %s" % (c["case"], "x".join(str(v) for v in c["size"].values())): round(c["port_vs_reference"], 3)
+                                   for c in cj["cases"]},
+                         source="profiles/%s_cpu_port_vs_reference.json" % tag)
+            break
     return dict(value=value, unit="timesteps/sec (extrapolated to the metric's size with mode-stages per cpu-second)",
-                cores=1, kind="port", host=host_info(), cores_total=os.cpu_count(),
-                not_run="rb3d 128x128x64 (SURVEY 8d): beyond the ~30 s budget of the default run on one core",
-                sample="4 bounded samples on 1 core, RK222 dt=1e-3: " + "; ".join(
+                cores=cores, kind=kind, host=host, cores_total=os.cpu_count(), one_core_value=one_core,
+                replicas=rep, not_run=not_run, reference_here=reference_here,
+                sample="%d bounded samples on 1 core, RK222 dt=1e-3: " % len(samples) + "; ".join(
                     "%s: %d steps in %.1f s = %.3f steps/s" % (x["case"], x["steps"], x["seconds"], x["steps_per_s"]) for x in samples)
-                       + "; value = mode-stages/cpu-s of the 64x64x64 sample / (2 stages x %d modes)" % full_modes,
+                       + ("; then %d one-core replicas of 64x64x64 at once" % cores if rep else "")
+                       + "; value = aggregate mode-stages/s of the %d core(s) on the %s sample / (2 stages x %d modes)"
+                       % (cores, big["case"] if not rep else "rb3d 64x64x64", full_modes),
                 samples=samples, port_vs_reference=calib,
                 reference_estimate=(value / calib["geomean"]) if calib else None)
 
@@ -236,6 +321,9 @@ def adaptive_loop(d3, solver, fields, args, torch):
 
 def main():
     args = parse()
+    if args.cpu_worker:                          # one replica of cpu_replicas(): no GPU, no torch
+        print(json.dumps(cpu_sample(args.cpu_worker, args.cpu_worker_seconds, args.cpu_worker_which)))
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)                   # does not return
     import torch
@@ -273,6 +361,9 @@ def main():
         torch.distributed.barrier()
     timer = KernelTimer(torch)
     ex.timer = timer
+    if world > 1:
+        solver.dist.pcomm.via = {}
+        solver.dist.pcomm.wire_events = []
     els = []
     for _ in range(max(1, args.repeats)):               # every repeat: exactly K steps between barrier + synchronize
         torch.cuda.synchronize()
@@ -291,6 +382,10 @@ def main():
             e = float(t.item())
         els.append(e)
     ex.timer = None
+    if world > 1:
+        wire_events = solver.dist.pcomm.wire_events            # (later steps -- parity probe -- add no events)
+        solver.dist.pcomm.wire_events = None
+        via_counts = {k: list(v) for k, v in solver.dist.pcomm.via.items()}
     el = float(np.median(els))
     nrep = len(els)
     summ = timer.summary()
@@ -299,10 +394,24 @@ def main():
         ranks_seen = torch.distributed.get_world_size()
         backend = torch.distributed.get_backend()
         pc = solver.dist.pcomm
-        via = "libdedalus_hip RCCL plan (ddh_a2a_localize_*)" if pc.library_comm() is not None else "torch.distributed all_to_all_single"
-        ex_ms = summ.get("a2a_exchange", {}).get("total_ms", 0.0) / (args.steps * nrep)
-        exch = dict(per_rank_bytes_sent_per_step=pc.stats["bytes_sent"] / (args.warmup + args.steps * nrep),
-                    exchanges_per_step=pc.stats["exchanges"] / (args.warmup + args.steps * nrep), ms_per_step_rank0=ex_ms, via=via)
+        nst = args.steps * nrep                       # (the per-path counters were reset after the warm-up)
+        # the code path every exchange of the timed steps really took (parallel.Comm.via), not what could have been used
+        via = {k: dict(exchanges_per_step=v[0] / nst, wire_MB_per_rank_per_step=v[1] / nst / 1e6) for k, v in via_counts.items()}
+        wire_bytes = sum(v[1] for v in via_counts.values()) / nst
+        wire_ms = None
+        if wire_events:
+            wire_ms = sum(a.elapsed_time(b) for a, b in wire_events) / nst
+        kern_ms = sum(v["total_ms"] for k, v in summ.items()) / nst
+        step_ms = 1e3 * el / args.steps
+        overlap = None
+        if wire_ms:
+            overlap = max(0.0, min(1.0, (kern_ms + wire_ms - step_ms) / wire_ms))
+        exch = dict(via=via, per_rank_wire_bytes_per_step=wire_bytes, exchanges_per_step=sum(v[0] for v in via_counts.values()) / nst,
+                    wire_ms_per_step_side_stream_rank0=wire_ms, timed_kernel_ms_per_step_rank0=kern_ms,
+                    overlap_fraction=overlap,
+                    overlap_note="(timed kernels + side-stream exchange time - step time) / exchange time on rank 0, clamped to "
+                                 "[0, 1]; the exchange time is HIP events around ddh_comm_alltoall on the side stream",
+                    per_link_GBps=(wire_bytes / max(world - 1, 1) / 1e9) / (wire_ms / 1e3) if wire_ms else None)
     chk2 = float(np.sum(np.asarray(fields["b"]["c"]) ** 2))
     if world > 1:
         t = torch.tensor([chk2], device="cuda", dtype=torch.float64)
@@ -365,7 +474,7 @@ def main():
         if cfl_mode is not None:
             out["cfl_mode"] = cfl_mode
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline((Nx, Ny, Nz))
+            out["cpu_baseline"] = cpu_baseline((Nx, Ny, Nz), args.cpu_budget, args.cpu_replicas)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

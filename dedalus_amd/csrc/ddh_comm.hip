@@ -161,6 +161,28 @@ int ddh_comm_allreduce(ddh_handle comm, double *buf, long count, int op, void *s
     return 0;
 }
 
+// Equal-split all-to-all on caller-owned buffers: block p (`chunk` doubles) of `send` goes to rank p, block q of `recv`
+// comes from rank q; asynchronous on `stream` (the caller orders it against its pack / unpack kernels with events).
+int ddh_comm_alltoall(ddh_handle comm, const double *send, double *recv, long chunk, void *stream) {
+    Comm *c = (Comm *)lookup_handle(comm, H_COMM);
+    if (!c) return -1;
+    if (!send || !recv || chunk < 0) return fail("ddh_comm_alltoall: bad argument");
+    if (send == recv) return fail("ddh_comm_alltoall: send and receive buffers must differ");
+    hipStream_t s = as_stream(stream);
+    if (chunk == 0) return 0;
+    DDH_HIP(hipMemcpyAsync(recv + (size_t)c->rank * chunk, send + (size_t)c->rank * chunk, (size_t)chunk * sizeof(double),
+                           hipMemcpyDeviceToDevice, s));
+    if (c->nranks == 1) return 0;
+    DDH_NCCL(g_rccl.GroupStart());
+    for (int p = 0; p < c->nranks; ++p) {
+        if (p == c->rank) continue;
+        DDH_NCCL(g_rccl.Send(send + (size_t)p * chunk, (size_t)chunk, ncclDouble, p, c->comm, s));
+        DDH_NCCL(g_rccl.Recv(recv + (size_t)p * chunk, (size_t)chunk, ncclDouble, p, c->comm, s));
+    }
+    DDH_NCCL(g_rccl.GroupEnd());
+    return 0;
+}
+
 // uneven blocks: rank p owns [p B, min((p + 1) B, n)) of an axis of length n, B = ceil(n / P) (Layout.local_chunks,
 // core/distributor.py; Alltoallv transposes core/transposes.pyx:287-445)
 static inline long blk_lo(long n, long B, int p) { return (p * B < n) ? p * B : n; }

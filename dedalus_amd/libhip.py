@@ -130,6 +130,7 @@ SIGNATURES = {
     "ddh_comm_create": [_hp, _i, _i, C.POINTER(C.c_ubyte)],
     "ddh_comm_info": [_h, _ip, _ip],
     "ddh_comm_allreduce": [_h, _vp, _l, _i, _vp],
+    "ddh_comm_alltoall": [_h, _vp, _vp, _l, _vp],
     "ddh_a2a_plan": [_hp, _h, _l, _l, _l, _l],
     "ddh_a2a_plan_blocks": [_hp, _h, _l, _l, _l, _l, _l, _l],
     "ddh_a2a_localize_rows": [_h, _vp, _vp, _vp],

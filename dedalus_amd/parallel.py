@@ -24,6 +24,19 @@ class _Done:
         return True
 
 
+class _StreamWork:
+    """An exchange issued on the communicator's side stream: wait() makes the CURRENT stream wait for it (no host
+    synchronisation), like the Work object of an asynchronous torch.distributed collective."""
+
+    def __init__(self, torch, event, keep):
+        self.torch, self.event, self.keep = torch, event, keep
+
+    def wait(self):
+        self.torch.cuda.current_stream().wait_event(self.event)
+        self.keep = None
+        return True
+
+
 class Comm:
     def __init__(self, size):
         import torch
@@ -40,6 +53,13 @@ class Comm:
         self.backend = dist.get_backend()
         self._lib_comm = None
         self.stats = dict(exchanges=0, bytes_sent=0)      # per rank, device exchanges only (bench.py reads it)
+        # which code path carried how many exchanges / wire bytes (bench.py prints it as exchange.via):
+        #   "ddh_a2a_localize (library RCCL plan)"       whole-field transposes, core/distributor.py::_exchange
+        #   "ddh_comm_alltoall (library RCCL, side stream)"  the per-component pipeline
+        #   "torch.distributed.all_to_all_single"         gloo test configurations, DDH_A2A_VIA=torch, fallback
+        self.via = {}
+        self._side = None
+        self.wire_events = None        # bench.py: list collecting (start, end) events of the side-stream exchanges
 
     # ---- RCCL communicator owned by libdedalus_hip (ddh_comm_*): the production exchange path on the GPUs ----------
     def library_comm(self):
@@ -123,9 +143,16 @@ class Comm:
         libhip.call("ddh_destroy", plan)
         return ok
 
+    def note_via(self, path, nbytes):
+        v = self.via.setdefault(path, [0, 0])
+        v[0] += 1
+        v[1] += int(nbytes)
+
     def all_to_all(self, recv, send):
         """Equal-split all-to-all on flat buffers (torch tensors, or numpy arrays for the CPU oracle)."""
         t = self.torch
+        self.note_via("torch.distributed.all_to_all_single (%s)" % self.backend,
+                      (send.size if isinstance(send, np.ndarray) else send.numel()) * 8 * (self.size - 1) // self.size)
         if isinstance(send, np.ndarray):
             s = t.from_numpy(np.ascontiguousarray(send).reshape(-1))
             r = t.empty_like(s)
@@ -149,6 +176,34 @@ class Comm:
         if isinstance(send, np.ndarray) or (send.is_cuda and self.dist.get_backend() == "gloo"):
             self.all_to_all(recv, send)
             return _Done()
+        h = self.library_comm()
+        if h is not None:
+            # the library's own communicator (grouped ncclSend / ncclRecv, ddh_comm_alltoall) on a side stream: ordered
+            # after the packing kernel by an event, the unpacking kernel waits for its completion event
+            import ctypes as C
+            from . import libhip
+            if self._side is None:
+                self._side = t.cuda.Stream()
+            cur = t.cuda.current_stream()
+            ready = t.cuda.Event()
+            ready.record(cur)
+            self._side.wait_event(ready)
+            send.record_stream(self._side)
+            recv.record_stream(self._side)
+            timed = self.wire_events is not None
+            if timed:
+                e0 = t.cuda.Event(enable_timing=True)
+                e0.record(self._side)
+            libhip.call("ddh_comm_alltoall", h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
+                        send.numel() // self.size, C.c_void_p(self._side.cuda_stream))
+            done = t.cuda.Event(enable_timing=timed)
+            done.record(self._side)
+            if timed:
+                self.wire_events.append((e0, done))
+            self.note_via("ddh_comm_alltoall (library RCCL, side stream)", send.numel() * 8 * (self.size - 1) // self.size)
+            return _StreamWork(t, done, (send, recv))
+        self.note_via("torch.distributed.all_to_all_single (%s, async)" % self.backend,
+                      send.numel() * 8 * (self.size - 1) // self.size)
         return self.dist.all_to_all_single(recv.reshape(-1), send.reshape(-1), async_op=True)
 
     def all_gather_host(self, a, axis=0):

@@ -471,6 +471,11 @@ int ddh_comm_info(ddh_handle comm, int *rank, int *nranks);
 /* in-place all-reduce of `count` doubles: op 0 sum, 1 max, 2 min (the MPI Allreduce of GlobalArrayReducer,
  * extras/flow_tools.py:9-47, and of the CFL frequency) */
 int ddh_comm_allreduce(ddh_handle comm, double *buf, long count, int op, void *stream);
+/* equal-split all-to-all on caller-owned device buffers (the MPI Alltoall of the transposes, core/transposes.pyx:329-358,
+ * for callers that pipeline pack / exchange / unpack themselves, e.g. one field component at a time on a side stream):
+ * block p (`chunk` doubles) of `send` goes to rank p, block q of `recv` comes from rank q; grouped ncclSend / ncclRecv,
+ * the rank's own block as a device copy; asynchronous on `stream` */
+int ddh_comm_alltoall(ddh_handle comm, const double *send, double *recv, long chunk, void *stream);
 
 /* Transpose plan = FFTWTranspose / AlltoallvTranspose (core/transposes.pyx:22-445, planner interface
  * core/distributor.py:696-768): (n0, n1, n2, n3) is the reference's reduced GLOBAL shape (N0, N1, N2, N3) around the

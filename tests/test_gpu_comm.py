@@ -61,8 +61,8 @@ def test_one_rank_rccl_communicator_transposes_and_allreduce():
     libhip.call("ddh_destroy", comm)
 
 
-@pytest.mark.parametrize("P", [2, 4])
-@pytest.mark.parametrize("shape", [(3, 8, 12, 5), (1, 4, 8, 1), (2, 12, 4, 3)])
+@pytest.mark.parametrize("P,shape", [(P, sh) for P in (2, 4) for sh in [(3, 8, 12, 5), (1, 4, 8, 1), (2, 12, 4, 3)]]
+                         + [(8, (3, 8, 16, 5)), (8, (1, 24, 8, 2))])          # 8 = the target node's rank count
 def test_transpose_index_logic_for_P_ranks(P, shape):
     """Emulated ranks: CL_r = A[:, :, block r of N2, :], RL_r = A[:, block r of N1, :, :] of one global array A."""
     from dedalus_amd import libhip
@@ -164,6 +164,21 @@ ex.a2a_localize_rows(plan, a, b); ex.a2a_localize_columns(plan, b, d)
 torch.cuda.synchronize()
 assert torch.equal(a, b) and torch.equal(a, d)
 assert abs(c.bcast_float(3.25) - 3.25) == 0 and c.allreduce_max(2.0) == 2.0
+# the per-component pipeline's exchange (core/distributor.py::_rows_after_z): ddh_comm_alltoall of the library's own
+# communicator on the side stream, ordered against the producer / consumer kernels by events only
+c.wire_events = []
+works = []
+for k in range(4):
+    send = torch.randn(1 << 16, dtype=torch.float64, device="cuda") * (k + 1)
+    recv = torch.zeros_like(send)
+    works.append((c.all_to_all_start(recv, send), send, recv))
+for w, send, recv in works:
+    w.wait()
+    out = recv * 2.0                      # consumer on the current stream, after the wait
+    assert torch.equal(out, send * 2.0)
+torch.cuda.synchronize()
+assert list(c.via) == ["ddh_comm_alltoall (library RCCL, side stream)"] and c.via["ddh_comm_alltoall (library RCCL, side stream)"][0] == 4
+assert len(c.wire_events) == 4 and all(a.elapsed_time(b) >= 0 for a, b in c.wire_events)
 dist.destroy_process_group()
 print("OK")
 ''' % (ROOT, 29600 + os.getpid() % 2000)
@@ -172,7 +187,25 @@ print("OK")
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("P", [2, 3, 4])
+def test_two_rank_bench_line_names_the_exchange_paths_taken():
+    """`bench.py --gpus 2` with both ranks on the one GPU of the test box (gloo, host-staged exchange): the `exchange`
+    block lists the code path every exchange of the timed steps really took, with wire bytes per rank and step."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS="1", DDH_DIST_BACKEND="gloo", DDH_FORCE_DEVICE="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "32,32,16", "--steps", "2", "--warmup", "1",
+           "--repeats", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    ex = line["exchange"]
+    assert line["n_gpus"] == 2 and line["dist_backend"] == "gloo"
+    assert ex["via"] and all(k.startswith("torch.distributed.all_to_all_single (gloo") for k in ex["via"]), ex["via"]
+    # 8 + 4 components cross per stage, backward + forward; wire bytes = half of a rank's share at P = 2
+    assert ex["exchanges_per_step"] > 0 and ex["per_rank_wire_bytes_per_step"] > 0
+    assert abs(sum(v["wire_MB_per_rank_per_step"] for v in ex["via"].values()) * 1e6 - ex["per_rank_wire_bytes_per_step"]) < 1
+
+
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
 @pytest.mark.parametrize("shape", [(3, 7, 10, 5), (1, 5, 9, 1), (2, 13, 3, 3), (2, 5, 5, 2)])
 def test_uneven_block_transposes_for_P_ranks(P, shape):
     """Axes that P does not divide (the reference's Alltoallv transposes, core/transposes.pyx:287-445): blocks of

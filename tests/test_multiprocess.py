@@ -19,9 +19,11 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("case,world,overlap", [("rb3d_8x12x8_rk222", 2, "0"), ("rb2d_32x16_rk222", 2, "0"),
-                                                ("rb3d_8x12x8_rk222", 2, "1"), ("rb3d_8x12x8_rk222", 4, "1")])
+                                                ("rb3d_8x12x8_rk222", 2, "1"), ("rb3d_8x12x8_rk222", 4, "1"),
+                                                ("rb3d_16x16x16_rk222", 8, "1")])
 def test_sharded_run_matches_reference(golden_dir, case, world, overlap, monkeypatch):
-    # overlap = "1": the per-component exchange pipeline (DDH_A2A_OVERLAP, the default); 4 ranks: one kx group per rank
+    # overlap = "1": the per-component exchange pipeline (DDH_A2A_OVERLAP, the default); 4 ranks / 8 ranks (the target
+    # node's rank count): one kx group per rank, 3 z grid planes per rank at 8
     monkeypatch.setenv("DDH_A2A_OVERLAP", overlap)
     gold = np.load(os.path.join(golden_dir, "ivp.npz"))
     with tempfile.TemporaryDirectory() as tmp:

@@ -20,7 +20,7 @@ import numpy as np  # noqa: E402
 import problems  # noqa: E402
 
 CASES = [("rb3d", dict(Nx=32, Ny=32, Nz=32)), ("rb3d", dict(Nx=64, Ny=64, Nz=32)), ("rb3d", dict(Nx=64, Ny=64, Nz=64)),
-         ("rb2d", dict(Nx=512, Nz=256))]
+         ("rb2d", dict(Nx=512, Nz=256)), ("rb3d", dict(Nx=128, Ny=128, Nz=64))]      # (the last one: SURVEY 8d)
 
 
 def host():
@@ -53,7 +53,7 @@ def time_case(d3, kind, kw, dist_kw=None, budget=15.0, max_steps=40):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
     import dedalus_amd.public as d3p
     from oracle.np_executor import NumpyExecutor
     from oracle import refshim
