@@ -261,3 +261,28 @@ class EllBandPlan:
         out = np.zeros_like(rhs_flat, dtype=float)
         out[self.col_index[g, :n]] = z
         return out
+
+
+class BandBlockPlan:
+    """One explicit band system (no boundary rows, no recombination) in the attribute layout EllBandPlan hands to
+    executor.EllBand: M / L given densely in the order they are to be factored in.  Used for the band block of a
+    Cartesian solver's k = 0 pencil (dedalus_amd/pencilpack.py::_flagged_inverses)."""
+
+    def __init__(self, M, L, cutoff=0.0):
+        M, L = np.asarray(M, dtype=np.float64), np.asarray(L, dtype=np.float64)
+        n = M.shape[0]
+        i, j = np.nonzero((np.abs(M) > cutoff) | (np.abs(L) > cutoff))
+        self.kl = int(max((i - j).max(), 0)) if len(i) else 0
+        self.ku = int(max((j - i).max(), 0)) if len(i) else 0
+        W = self.kl + self.ku + 1
+        self.nl, self.nmax, self.mp, self.nbc = 1, n, 0, 0
+        self.n = np.array([n], dtype=np.int32)
+        self.nbc_of = np.zeros(1, dtype=np.int32)
+        self.T = np.zeros((1, 1, 1))
+        self.P = np.zeros((1, n, 1))
+        self.MB = np.zeros((1, n, W))
+        self.LB = np.zeros((1, n, W))
+        self.MB[0, i, j - i + self.kl] = M[i, j]
+        self.LB[0, i, j - i + self.kl] = L[i, j]
+        self.row_index = self.col_index = None           # (the caller gives element offsets directly)
+        self.per, self.dense_groups = {0: None}, []

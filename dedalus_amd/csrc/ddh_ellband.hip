@@ -465,11 +465,51 @@ static void launch_backward(EllBand *p, const EllBandLu &lu, double *x, dim3 gri
                        (eb_abl() & 2) ? 1L : p->slot_stride, eb_abl());
 }
 
+
+// ---- inverse of a bordered system whose band block has one zero column -------------------------------------------------
+// The k = 0 pencil of a Cartesian problem with a pressure gauge (core/subsystems.py: the subproblem that holds tau_p and
+// "integ(p) = 0"):  A = [[B, c], [r^T, e]] in the solver's permuted order, B the n x n band block, singular ONLY because
+// the column of the constant pressure mode (j0) vanishes, c the gauge variable's column, r the gauge row.  With the two
+// columns exchanged, A2 = [[B2, 0], [w^T, d]] (B2 = B with column j0 replaced by c: a band again, w = r with e at j0,
+// d = r[j0]) is block triangular, so A^-1 follows from X = B2^-1 (n unit solves of the band LU) and one weighted
+// column sum:   rows j != j0 of A^-1 = (X[j][:], 0);  row n (the gauge variable) = (X[j0][:], 0);
+//               row j0 = (-(w^T X) / d, 1 / d).        out: (n + 1) x (n + 1), row-major.
+__global__ void __launch_bounds__(256)
+bordered_inverse_kernel(const double *__restrict__ X, int n, int j0, const double *__restrict__ wM,
+                        const double *__restrict__ wL, double a, double b, double d, double *__restrict__ out) {
+    const int s = blockIdx.x * 256 + threadIdx.x;              // column of the inverse = equation (right-hand side) index
+    const int N = n + 1;
+    if (s >= N) return;
+    if (blockIdx.y == 0) {                                      // row j0: the weighted column sum
+        double v = 0.0;
+        if (s < n)
+            for (int i = 0; i < n; ++i) v += (a * wM[i] + b * wL[i]) * X[(size_t)i * n + s];
+        out[(size_t)j0 * N + s] = s < n ? -v / d : 1.0 / d;
+        return;
+    }
+    for (int j = blockIdx.y - 1; j < N; j += gridDim.y - 1) {   // the other rows: copies
+        if (j == j0) continue;
+        const int src = j < n ? j : j0;
+        out[(size_t)j * N + s] = s < n ? X[(size_t)src * n + s] : 0.0;
+    }
+}
+
 }  // namespace ddh
 
 using namespace ddh;
 
 extern "C" {
+
+int ddh_ellband_bordered_inverse(const double *X_d, int n, int j0, const double *wM_d, const double *wL_d, double dM,
+                                 double dL, double a, double b, double *out_d, void *stream) {
+    if (!X_d || !wM_d || !wL_d || !out_d || n < 1 || j0 < 0 || j0 >= n) return fail("ellband_bordered_inverse: bad arguments");
+    const double d = a * dM + b * dL;
+    if (d == 0.0) return fail("ellband_bordered_inverse: the gauge row does not see the free mode");
+    hipLaunchKernelGGL(bordered_inverse_kernel, dim3((unsigned)((n + 1 + 255) / 256), 65), dim3(256), 0, as_stream(stream), X_d, n,
+                       j0, wM_d, wL_d, a, b, d, out_d);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
 
 int ddh_ellband_create(ddh_handle *h, int nl, int nmax, int kl, int ku, int mp, int nbc, int nslots, long slot_stride,
                        const int *n_h, const int *nbc_h, const int *slot_limit_h, const long *rowoff_h,

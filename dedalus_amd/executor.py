@@ -358,10 +358,10 @@ class HipExecutor:
         -> object with compute(a, b): concatenated (a M + b L)^-1 on the valid blocks, on the device."""
         return DenseInverse(self, Ms, Ls, row_valid, col_valid, complex_)
 
-    def make_ell_band(self, plan, ncomp, nslots, nl, nr, slot_limit):
+    def make_ell_band(self, plan, ncomp, nslots, nl, nr, slot_limit, offsets=None):
         """Band LU of per-ell systems laid out by core/ellband.py::EllBandPlan (system vectors [ncomp][nslots][nl][nr];
         slot_limit[g]: leading slots that can hold modes of group g)."""
-        return EllBand(self, plan, ncomp, nslots, nl, nr, slot_limit)
+        return EllBand(self, plan, ncomp, nslots, nl, nr, slot_limit, offsets=offsets)
 
     def from_host_int64(self, a):
         return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.int64), device=self.dev.tdev)
@@ -596,21 +596,27 @@ class DenseInverse:
 class EllBand:
     """ddh_ellband_*: device band LU + sweeps of the per-ell systems (csrc/ddh_ellband.hip)."""
 
-    def __init__(self, ex, plan, ncomp, nslots, nl, nr, slot_limit):
+    def __init__(self, ex, plan, ncomp, nslots, nl, nr, slot_limit, offsets=None):
+        """offsets = (rowoff [nl][nmax], coloff [nl][nmax], slot_stride): element offsets of the permuted rows / columns
+        inside one slot and the distance between slots, for system vectors that are not [component][slot][group][n]."""
         self.ex, self.plan = ex, plan
         self.shape = (int(ncomp), int(nslots), int(nl), int(nr))
         comp_stride = nslots * nl * nr
         g = np.arange(nl)[:, None]
 
-        def offsets(idx):
+        def _offsets(idx):
             off = (idx // nr) * comp_stride + g * nr + idx % nr
             return np.ascontiguousarray(np.where(idx >= 0, off, 0), dtype=np.int64)
-        rowoff, coloff = offsets(plan.row_index), offsets(plan.col_index)
+        if offsets is None:
+            rowoff, coloff, slot_stride = _offsets(plan.row_index), _offsets(plan.col_index), nl * nr
+        else:
+            rowoff, coloff = (np.ascontiguousarray(a, dtype=np.int64).reshape(nl, plan.nmax) for a in offsets[:2])
+            slot_stride = int(offsets[2])
         c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
         self.handle = C.c_uint64(0)
         lp = lambda a: a.ctypes.data_as(C.POINTER(C.c_long))
         libhip.call("ddh_ellband_create", C.byref(self.handle), int(nl), int(plan.nmax), int(plan.kl), int(plan.ku),
-                    int(plan.mp), int(plan.nbc), int(nslots), int(nl * nr), libhip.as_ip(c(plan.n, np.int32)),
+                    int(plan.mp), int(plan.nbc), int(nslots), int(slot_stride), libhip.as_ip(c(plan.n, np.int32)),
                     libhip.as_ip(c(plan.nbc_of, np.int32)), libhip.as_ip(c(slot_limit, np.int32)), lp(rowoff), lp(coloff),
                     libhip.as_dp(c(plan.T, np.float64)), libhip.as_dp(c(plan.P, np.float64)),
                     libhip.as_dp(c(plan.MB, np.float64)), libhip.as_dp(c(plan.LB, np.float64)))
@@ -645,6 +651,46 @@ class EllBand:
             libhip.call("ddh_destroy", self.handle)
         except Exception:
             pass
+
+
+class BorderedBandInverse:
+    """Inverse of a real bordered pencil [[B, c], [r^T, e]] whose n x n band block B is singular only through one vanishing
+    column j0 (the k = 0 pencil of a Cartesian problem with a pressure gauge), formed on the device at the cost of a band
+    factorization and n unit solves instead of an O(n^3) dense inversion: with columns j0 and n exchanged the matrix is
+    block triangular around B2 = B with column j0 replaced by c -- a band again -- so that A^-1 follows from X = B2^-1 (the
+    band LU + sweeps of csrc/ddh_ellband.hip on an n x n identity, unit solve s in lane s) and one weighted column sum
+    (ddh_ellband_bordered_inverse).  Replaces the reference's sparse LU of that subproblem at every change of the timestep
+    (core/timesteppers.py:630-640, libraries/matsolvers.py:126-149)."""
+
+    def __init__(self, ex, Md, Ld, n, j0):
+        from .core.ellband import BandBlockPlan
+        self.ex, self.n, self.j0 = ex, int(n), int(j0)
+        N = n + 1
+        M2, L2 = np.array(Md[:n, :n], dtype=np.float64), np.array(Ld[:n, :n], dtype=np.float64)
+        M2[:, j0], L2[:, j0] = Md[:n, n], Ld[:n, n]
+        plan = BandBlockPlan(M2, L2)
+        self.kl, self.ku = plan.kl, plan.ku
+        # system vectors [row][slot]: slot = right-hand side s in the lanes (stride 1), row / column i at i * nslots
+        off = np.arange(n, dtype=np.int64)[None, :] * n
+        self.band = EllBand(ex, plan, 1, n, 1, n, [n], offsets=(off, off, 1))
+        self.rhs = ex.from_host(np.eye(n))
+        self.x = ex.zeros((n, n))
+        wM, wL = np.array(Md[n, :n], dtype=np.float64), np.array(Ld[n, :n], dtype=np.float64)
+        self.dM, self.dL = float(wM[j0]), float(wL[j0])
+        wM[j0], wL[j0] = Md[n, n], Ld[n, n]
+        self.wM, self.wL = ex.from_host(wM), ex.from_host(wL)
+        self.out = ex.zeros((N, N))
+
+    def compute(self, a, b):
+        """-> device array (n + 1)^2, the inverse of a M + b L in the permuted order; None after a zero pivot"""
+        try:
+            self.band.factor(a, b, index=0)
+        except libhip.DdhError:
+            return None
+        self.band.solve(0, self.rhs, self.x)
+        libhip.call("ddh_ellband_bordered_inverse", ptr(self.x), self.n, self.j0, ptr(self.wM), ptr(self.wL), self.dM, self.dL,
+                    float(a), float(b), ptr(self.out), self.ex.dev.stream)
+        return self.out
 
 
 class DenseEllTerms:

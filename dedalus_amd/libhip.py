@@ -77,6 +77,7 @@ SIGNATURES = {
     "ddh_ellband_solve": [_h, _i, _vp, _vp, _vp],
     "ddh_ellband_info": [_h, _ip, _ip, C.POINTER(_l)],
     "ddh_ellband_gather_complex_inverse": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ddh_ellband_bordered_inverse": [_vp, _i, _i, _vp, _vp, _d, _d, _d, _d, _vp, _vp],
     "ddh_rfft_forward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_rfft_backward_deriv": [_h, _vp, _vp, _l, _l, _d, _vp],

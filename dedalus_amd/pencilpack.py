@@ -165,11 +165,32 @@ class PencilPack:
             raise libhip.DdhError("%d pencils have a singular band block: problem structure unsupported by the "
                                   "bordered-band solver" % nflag)
         if nflag:
-            self._flagged_inverses(lu_id, matM, matL, a, b, row_perm, col_perm, ra, ca, cells[:nflag])
+            self._flagged_inverses(lu_id, matM, matL, a, b, row_perm, col_perm, ra, ca, cells[:nflag], n_interior)
         self.lu_meta[lu_id] = dict(nflag=nflag, a=a, b=b)
         return lu_id
 
-    def _flagged_inverses(self, lu_id, matM, matL, a, b, row_perm, col_perm, ra, ca, cells):
+    def _bordered_band(self, Md, Ld, n_interior):
+        """-> BorderedBandInverse for a real pencil matrix (permuted order) whose band block is singular only through ONE
+        vanishing column and that has a 1 x 1 border (the k = 0 pencil of a problem with a pressure gauge: the constant
+        pressure mode drops out of every interior equation and `integ(p) = 0` / tau_p close the system), else None."""
+        N, n = Md.shape[0], int(n_interior)
+        if N - n != 1 or n < 2:
+            return None
+        absB = np.abs(Md[:n, :n]) + np.abs(Ld[:n, :n])
+        zc = np.flatnonzero(absB.sum(axis=0) == 0.0)
+        if len(zc) != 1:
+            return None
+        j0 = int(zc[0])
+        if Md[n, j0] == 0.0 and Ld[n, j0] == 0.0:
+            return None                                   # the gauge row does not see the free mode
+        from .executor import BorderedBandInverse, HipExecutor
+        ex = self.executor if self.executor is not None else HipExecutor(self.dev)
+        try:
+            return BorderedBandInverse(ex, Md, Ld, n, j0)
+        except libhip.DdhError:
+            return None                                   # (band wider than the compiled windows)
+
+    def _flagged_inverses(self, lu_id, matM, matL, a, b, row_perm, col_perm, ra, ca, cells, n_interior=None):
         """Explicit inverses of the flagged pencils (for Rayleigh-Benard: the mean mode, 1289 x 1289), formed and inverted
         ON THE DEVICE (ddh_dense_inverse_*: M and L of those pencils are uploaded once, a change of the timestep costs no
         host linear algebra -- numpy.linalg.inv of that one matrix was 204 of the 334 ms of a refactorization) and handed
@@ -177,6 +198,8 @@ class PencilPack:
         (their unknowns are exactly zero), as the reference's valid-mode filtering does (core/subsystems.py:540-556)."""
         import os
         N, S = self.nrows, self.S
+        if n_interior is None:
+            n_interior = N
         key = (matM, matL, row_perm.tobytes(), col_perm.tobytes(), tuple(int(c) for c in cells))
         cache = self.__dict__.setdefault("_flag_dinv", {})
         if key not in cache:
@@ -203,8 +226,13 @@ class PencilPack:
             cx = any(m.imag.any() for m in Ms) or any(m.imag.any() for m in Ls)
             if not cx:
                 Ms, Ls = [m.real.copy() for m in Ms], [m.real.copy() for m in Ls]
-            if os.environ.get("DDH_FLAG_HOST_INV", "0") == "1":        # A/B: the round-2 host inversion
-                cache[key] = ("host", Ms, Ls, rvs, cvs, slots, cx)
+            band = None
+            if not cx and os.environ.get("DDH_FLAG_DENSE", "0") != "1" and all(rv.all() and cv.all() for rv, cv in zip(rvs, cvs)):
+                band = [self._bordered_band(Md, Ld, n_interior) for Md, Ld in zip(Ms, Ls)]
+                if any(bd is None for bd in band):
+                    band = None
+            if band is not None:
+                cache[key] = ("band", band, slots)
             else:
                 from .executor import DenseInverse, HipExecutor
                 ex = self.executor if self.executor is not None else HipExecutor(self.dev)
@@ -212,18 +240,16 @@ class PencilPack:
                     cache.clear()
                 cache[key] = ("dev", DenseInverse(ex, Ms, Ls, rvs, cvs, cx), [m.shape[0] for m in Ms], slots, cx)
         ent = cache[key]
-        if ent[0] == "host":
-            _, Ms, Ls, rvs, cvs, slots, cx = ent
-            inv = np.zeros((len(cells) * S, N, N), dtype=np.complex128)
-            for Md, Ld, rv, cv, sl in zip(Ms, Ls, rvs, cvs, slots):
-                A = (a * Md + b * Ld)[np.ix_(rv, cv)]
-                full = np.zeros((N, N), dtype=A.dtype)
-                full[np.ix_(cv, rv)] = np.linalg.inv(A)
+        if ent[0] == "band":
+            for bd, sl in zip(ent[1], ent[2]):
+                inv = bd.compute(a, b)
+                if inv is None:                      # (a zero pivot: never seen; the dense path takes over for good)
+                    os.environ["DDH_FLAG_DENSE"] = "1"
+                    cache.pop(key)
+                    return self._flagged_inverses(lu_id, matM, matL, a, b, row_perm, col_perm, ra, ca, cells, n_interior)
                 for t in sl:
-                    inv[t] = full
-            inv = np.ascontiguousarray(inv)
-            libhip.call("ddh_pencil_set_dense_inverse", self.handle, lu_id,
-                        inv.view(np.float64).ctypes.data_as(C.POINTER(C.c_double)))
+                    libhip.call("ddh_pencil_set_dense_inverse_dev", self.handle, lu_id, int(t), C.c_void_p(inv.data_ptr()), 0,
+                                self.dev.stream)
             return
         _, dinv, sizes, slots, cx = ent
         flat = dinv.compute(a, b)

@@ -258,6 +258,16 @@ int ddh_ellband_info(ddh_handle h, int *nw, int *wt, long *factor_bytes);
 int ddh_ellband_gather_complex_inverse(const double *x_d, double *out_d, const long *off_d, int ncomp, int nl, int nm,
                                        int nslots, void *stream);
 
+/* Inverse of a bordered pencil whose band block B (n x n, permuted order) is singular only through ONE vanishing column
+ * j0 -- the k = 0 subproblem of a Cartesian problem with a pressure gauge (tau_p, "integ(p) = 0"; the reference factors
+ * it like every other subproblem, libraries/matsolvers.py:126-149, core/timesteppers.py:630-640) -- from X_d = B2^-1
+ * ([n][n] row-major: n unit solves of the band LU of B2 = B with column j0 replaced by the gauge variable's column):
+ * wM_d / wL_d [n] = the M / L parts of the gauge row over the columns of B2 (its corner entry at j0), dM / dL = its entry
+ * in the free mode's column.  out_d: the (n + 1)^2 inverse, row-major (rows = unknowns, the gauge variable last).
+ * Replaces the O(n^3) dense inversion of that one pencil at every change of the timestep. */
+int ddh_ellband_bordered_inverse(const double *X_d, int n, int j0, const double *wM_d, const double *wL_d, double dM,
+                                 double dL, double a, double b, double *out_d, void *stream);
+
 /* ---- grid-space and vector kernels -------------------------------- */
 /* y[idx[i]] += vals[i] for n distinct indices (device arrays): the constant right-hand-side entries
  * (e.g. "b(z=0) = Lz", gathered into F by gather_outputs core/timesteppers.py:611-614) touch a handful of

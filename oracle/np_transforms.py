@@ -2,8 +2,8 @@
 TEST INFRASTRUCTURE ONLY -- CPU restatement (numpy / scipy.fft) of the reference's spectral
 transform plans.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
 
-Pinned (tests/test_oracle_golden.py) against fixtures produced by running the reference itself
-through oracle/refshim (tests/golden/transforms_*.npz) and against the reference's own
+Pinned (tests/test_oracle_transforms.py) against fixtures produced by running the reference itself
+through oracle/refshim (tests/golden/transforms.npz, transforms_extra.npz) and against the reference's own
 matrix-multiply definitions restated in *_mmt_matrices below.
 
 Each function names the reference code it follows (paths under /root/reference/dedalus).

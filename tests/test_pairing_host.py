@@ -51,3 +51,45 @@ def test_two_dimensional_problems_are_left_alone():
 def test_switch(monkeypatch):
     monkeypatch.setenv("DDH_PAIR", "0")
     assert _solver(Nx=8, Ny=8, Nz=8).pairing is None
+
+
+def test_bordered_band_inverse_of_the_mean_mode_pencil():
+    """Host restatement of ddh_ellband_bordered_inverse (csrc/ddh_ellband.hip) on the solver's own k = 0 pencil of 3-D
+    Rayleigh-Benard: the band block is singular only through the vanishing column of the constant pressure mode; with
+    that column exchanged for tau_p's the matrix is block triangular around a band, and the inverse assembled from the
+    band block's inverse equals the dense inverse."""
+    import problems
+    import dedalus_amd.public as d3
+    from dedalus_amd.pencilpack import TermList
+    from dedalus_amd.core.ellband import BandBlockPlan
+    from oracle.np_executor import NumpyExecutor
+    s, _ = problems.rayleigh_benard_3d(d3, Nx=8, Ny=8, Nz=24, dist_kw=dict(executor=NumpyExecutor()))
+    mats = []
+    for mid in (s.MP_id, s.LP_id):
+        t = s.pack.mats[mid]
+        A = TermList(t.nrows, t.ncols, t.row, t.col, t.coef, t.ex, t.ey, t.dx, t.dy).dense(0.0, 0.0, 0, 0, 1)
+        assert np.abs(A.imag).max() == 0.0
+        mats.append(A.real[np.ix_(s.row_perm, s.col_perm)])
+    Md, Ld = mats
+    n, N = s.n_interior, s.R
+    assert N - n == 1
+    zc = np.flatnonzero((np.abs(Md[:n, :n]) + np.abs(Ld[:n, :n])).sum(axis=0) == 0.0)
+    assert len(zc) == 1
+    j0 = int(zc[0])
+    M2, L2 = Md[:n, :n].copy(), Ld[:n, :n].copy()
+    M2[:, j0], L2[:, j0] = Md[:n, n], Ld[:n, n]
+    plan = BandBlockPlan(M2, L2)
+    assert plan.kl <= s.kl + 2 and plan.ku <= s.ku + 2          # still the solver's narrow band
+    for (a, b) in ((1.0, 1e-3), (1.0, 0.25e-3), (1.5, 2e-3)):
+        A = a * Md + b * Ld
+        X = np.linalg.inv(a * M2 + b * L2)
+        w = A[n, :n].copy()
+        d = w[j0]
+        w[j0] = A[n, n]
+        inv = np.zeros((N, N))
+        inv[:n, :n] = X
+        inv[n, :n] = X[j0]
+        inv[j0, :n] = -(w @ X) / d
+        inv[j0, n] = 1.0 / d
+        ref = np.linalg.inv(A)
+        assert np.abs(inv - ref).max() <= 1e-9 * np.abs(ref).max()
