@@ -467,8 +467,12 @@ bool gridwave_supported(const FftDev &d) {
     return C == 2 || C == 3 || C == 4 || C == 6 || C == 8;
 }
 
+bool gridwave2_supported(const FftDev &d);                                       // ddh_gridwave2.hip
+int launch_gridwave2(const FftDev &d, const FusedArgs &f, long nlines, hipStream_t st);
+
 // f must have been built with one load per batch
 int launch_gridwave(const FftDev &d, const FusedArgs &f, long nlines, hipStream_t st) {
+    if (!d.dbg && gridwave2_supported(d)) return launch_gridwave2(d, f, nlines, st);
     switch (d.N / 128) {
         case 2: return launch_c<2>(d, f, nlines, st);
         case 3: return launch_c<3>(d, f, nlines, st);

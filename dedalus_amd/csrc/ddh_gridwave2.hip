@@ -1,0 +1,212 @@
+// Second-generation wave-per-line fused grid stage along the contiguous real-Fourier axis (gfx950):
+//
+//     out[ic] = forward_rfft( sum_t coef_t * backward_rfft(a[ia_t]) * backward_rfft(b[ib_t]) )
+//
+// Same contract, argument block and launch shape as gw::gridwave_bilinear_kernel (ddh_gridwave.hip); the transforms are
+// the H = C x 8 x 8 decomposition of ddh_gridwave2.h: spectrum values built from direct + lane-reversed global loads (no
+// LDS staging), the radix-C pass on the coefficient side, 34 % fewer LDS stores per line.  The grid-point <-> (lane,
+// register) map is the same for every operand, which is all the point-wise products need.
+//
+// Replaces the reference's backward transforms + DotProduct / MultiplyFields + forward transform along the last axis
+// (core/transforms.py:469-565, core/arithmetic.py:666-674, 855-866).
+#include "ddh_fft_dev.h"
+#include "ddh_gridwave2.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace ddh {
+
+namespace gw2 {
+
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) d2v *gptr;
+
+__device__ __forceinline__ void gstore16(double *p, double2 v) {
+    d2v r;
+    r.x = v.x;
+    r.y = v.y;
+    *(gptr)(p) = r;
+}
+
+// Buffer descriptor of one coefficient line, valid for the retained wavenumbers k <= K only: loads of anything beyond
+// return zero from the hardware range check, every load address is a lane offset plus an instruction immediate.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t line_rsrc(const double *line, int K) {
+    const unsigned long long a = (unsigned long long)line;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void *base = (void *)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (K + 1) * 16, 0x00020000);
+}
+__device__ __forceinline__ double2 bload16(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const u4v q = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    double2 v;
+    v.x = __hiloint2double((int)q.y, (int)q.x);
+    v.y = __hiloint2double((int)q.w, (int)q.z);
+    return v;
+}
+
+// the loads of one operand line: 2 x NT wave instructions of 1 KiB, the second set lane-reversed (the mirror pairs)
+template <int NT>
+__device__ __forceinline__ void issue_loads(Loads<NT> &ld, const double *line, int lane, int K) {
+    const __amdgpu_buffer_rsrc_t r = line_rsrc(line, K);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ld.d[t] = bload16(r, 16 * lane + 1024 * t);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ld.m[t] = bload16(r, 16 * (64 - lane) + 1024 * t);
+}
+
+// WAVES lines (wavefronts) per workgroup
+template <int C, int NT, int WAVES, bool TWREG>
+__global__ void __launch_bounds__(64 * WAVES, 2)
+gridwave2_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
+    constexpr int GW_T = 64 * WAVES;
+    using G = G2<C>;
+    extern __shared__ double2 lds[];
+    double2 *tw = lds;                                   // twiddle tables (G2<C>::T_*)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double2 *wb = lds + G::TW + wave * G::LDW;          // this wave's exchange buffer
+    for (int i = tid; i < G::TW; i += GW_T) tw[i] = p.tw[G::table_q(i)];
+    // kernel arguments indexed at run time go through LDS
+    __shared__ const double *s_src[FUSED_LOADS];
+    __shared__ double s_dscale[FUSED_LOADS];
+    __shared__ double *s_out[FUSED_NC];
+    __shared__ double s_coef[FUSED_TERMS];
+    __shared__ short s_tbeg[FUSED_LOADS + 1];
+    __shared__ signed char s_flush[FUSED_LOADS], s_ia[FUSED_TERMS];
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < FUSED_LOADS; ++i) {
+            s_src[i] = f.src[i];
+            s_dscale[i] = f.dscale[i];
+            s_tbeg[i] = f.tbeg[i];
+            s_flush[i] = f.flush[i];
+        }
+        s_tbeg[FUSED_LOADS] = f.tbeg[FUSED_LOADS];
+#pragma unroll
+        for (int i = 0; i < FUSED_TERMS; ++i) {
+            s_coef[i] = f.coef[i];
+            s_ia[i] = f.ia[i];
+        }
+#pragma unroll
+        for (int i = 0; i < FUSED_NC; ++i) s_out[i] = f.out[i];
+    }
+    __syncthreads();                                     // the only workgroup barrier
+    const int M = p.M, K = p.K;
+    const int na = f.na, nloads = f.nbatch;              // host builds one load per batch for this kernel
+    double2 t64r[7];
+    if (TWREG) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) t64r[i] = tw[G::T_64 + (lane & 7) * (i + 1)];
+    }
+#pragma unroll 1
+  for (long line = (long)blockIdx.x * WAVES + wave; line < nlines; line += (long)gridDim.x * WAVES) {
+    const long off = line * (long)M;
+
+    Loads<NT> ld;
+    issue_loads<NT>(ld, s_src[0] + off, lane, K);
+    // One backward transform: operand l (already staged in ld) -> grid values g; prefetches operand l + 1.
+    auto backward = [&](int l, double2 *g) {
+        int ln = lane;
+        WF_OPAQUE_LANE(ln);
+        double2 z[C];
+        const double ds = s_dscale[l];
+        if (ds != 0.0) build_z<C, NT, true>(ld, ds, tw, ln, z);      // wave-uniform branch
+        else build_z<C, NT, false>(ld, ds, tw, ln, z);
+        if (l + 1 < nloads) issue_loads<NT>(ld, s_src[l + 1] + off, ln, K);
+        backward_line<C, TWREG>(z, wb, tw, ln, g, t64r);
+    };
+    // the `a` operands stay in registers (twice their grid values, like every transformed operand)
+    double2 areg[FUSED_NA][8];
+#pragma unroll
+    for (int ia = 0; ia < FUSED_NA; ++ia) {
+        if (ia < na) {
+            backward(ia, areg[ia]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) areg[ia][i] = make_double2(0.0, 0.0);
+        }
+    }
+    double2 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = make_double2(0.0, 0.0);
+#pragma unroll 1
+    for (int l = na; l < nloads; ++l) {
+        double2 g[8];
+        backward(l, g);
+        const int t1 = s_tbeg[l + 1];
+#pragma unroll 1
+        for (int t = s_tbeg[l]; t < t1; ++t) {
+            const double cf = s_coef[t];                 // includes the 1/4 of the two doubled operands
+            const int tia = s_ia[t];                     // wave-uniform
+#pragma unroll
+            for (int ia = 0; ia < FUSED_NA; ++ia) {
+                if (tia == ia) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        // packed even/odd samples: real parts multiply real parts, imaginary parts imaginary parts
+                        acc[i].x += (cf * g[i].x) * areg[ia][i].x;
+                        acc[i].y += (cf * g[i].y) * areg[ia][i].y;
+                    }
+                }
+            }
+        }
+        const int oc = s_flush[l];
+        if (oc >= 0) {
+            int lf = lane;
+            WF_OPAQUE_LANE(lf);
+            double *dst = s_out[oc] + off;
+            forward_line<C, NT, TWREG>(acc, wb, tw, lf, M, K, t64r, [&](int k, double2 v) { gstore16(dst + 2 * k, v); });
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = make_double2(0.0, 0.0);
+        }
+    }
+  }
+}
+
+template <int C>
+int launch_c(const FftDev &d, const FusedArgs &f_in, long nlines, hipStream_t st) {
+    using G = G2<C>;
+    constexpr int WAVES = 4;
+    constexpr int NT32 = (2 * C + 2) / 3;                  // 64-pair blocks that hold M/2 = N/3 pairs (3/2 dealiasing)
+    static const int lpw_env = getenv("DDH_GW_LPW") ? std::max(1, atoi(getenv("DDH_GW_LPW"))) : 0;
+    const long lpw = lpw_env ? lpw_env : std::min<long>(8, std::max<long>(1, nlines / ((long)WAVES * 2048)));
+    const long nwg = (nlines + (long)WAVES * lpw - 1) / ((long)WAVES * lpw);
+    if ((unsigned long)nwg > 0x7fffffffUL) return fail("rfft_bilinear_fused: grid too large");
+    const size_t lds = ((size_t)G::TW + (size_t)WAVES * G::LDW) * sizeof(double2);
+    const dim3 grid((unsigned)nwg), block(64 * WAVES);
+    static const bool twreg = getenv("DDH_GW_TWREG") ? atoi(getenv("DDH_GW_TWREG")) != 0 : true;
+    FusedArgs f = f_in;
+    for (int t = 0; t < FUSED_TERMS; ++t) f.coef[t] *= 0.25;     // both factors of a term arrive doubled
+    if (twreg)
+        hipLaunchKernelGGL((gridwave2_bilinear_kernel<C, NT32, WAVES, true>), grid, block, lds, st, d, f, nlines);
+    else
+        hipLaunchKernelGGL((gridwave2_bilinear_kernel<C, NT32, WAVES, false>), grid, block, lds, st, d, f, nlines);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gw2
+
+// the second-generation kernel takes the sizes it is instantiated for when the spectrum is 3/2-padded (K + 1 pairs fit
+// the 64-pair blocks that hold N / 3 pairs); DDH_GW_V1=1 keeps the first generation (A/B)
+bool gridwave2_supported(const FftDev &d) {
+    static const bool off = getenv("DDH_GW_V1") != nullptr && atoi(getenv("DDH_GW_V1")) != 0;
+    if (off) return false;
+    if (d.N % 128 != 0 || (d.M & 1) || d.M < 2 || d.M > d.N) return false;
+    const int C = d.N / 128;
+    if (!(C == 3 || C == 6)) return false;
+    const int NT32 = (2 * C + 2) / 3;
+    return d.K + 1 <= 64 * NT32 && NT32 < C;
+}
+
+int launch_gridwave2(const FftDev &d, const FusedArgs &f, long nlines, hipStream_t st) {
+    switch (d.N / 128) {
+        case 3: return gw2::launch_c<3>(d, f, nlines, st);
+        case 6: return gw2::launch_c<6>(d, f, nlines, st);
+    }
+    return fail("gridwave2: unsupported size");
+}
+
+}  // namespace ddh

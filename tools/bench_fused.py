@@ -22,9 +22,16 @@ def main():
     oo = dev.empty((4, nl, Ny))
     terms = [(0, j, j, 1.0) for j in range(3)] + [(1 + c, j, 3 + 3 * j + c, 1.0) for c in range(3) for j in range(3)]
 
+    # FUSED_DERIV=1: four of the operands differentiated at load, as in the step (d/dy of u and b)
+    bds = None
+    if os.environ.get("FUSED_DERIV", "0") == "1":
+        bds = [0.0] * 12
+        for i in (1, 6, 7, 8):
+            bds[i] = 1.5707963267948966
+
     def run():
         hx.rfft_bilinear_fused(("rfft", Gy, Ny), None, [a[i] for i in range(3)], [bb[i] for i in range(12)],
-                               [oo[i] for i in range(4)], nl, terms)
+                               [oo[i] for i in range(4)], nl, terms, b_dscale=bds)
     run()
     dev.sync()
     e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
@@ -36,9 +43,11 @@ def main():
     dev.sync()
     ms = e0.elapsed_time(e1) / reps
     nbytes = 19 * nl * Ny * 8
-    print("fused grid stage %d lines  dbg=%s waves=%s old=%s: %.3f ms  %.0f GB/s" % (
+    chk = [float(oo[i].abs().sum().item()) for i in range(4)]
+    print("fused grid stage %d lines  dbg=%s waves=%s old=%s v1=%s twreg=%s lpw=%s: %.3f ms  %.0f GB/s  checksums %s" % (
         nl, os.environ.get("DDH_FFT_DBG", "0"), os.environ.get("DDH_GW_WAVES", "4"),
-        os.environ.get("DDH_FUSED_OLD", "0"), ms, nbytes / ms / 1e6), flush=True)
+        os.environ.get("DDH_FUSED_OLD", "0"), os.environ.get("DDH_GW_V1", "0"), os.environ.get("DDH_GW_TWREG", "1"),
+        os.environ.get("DDH_GW_LPW", "-"), ms, nbytes / ms / 1e6, " ".join("%.15e" % c for c in chk)), flush=True)
 
 
 if __name__ == "__main__":
