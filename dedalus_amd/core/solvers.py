@@ -1107,6 +1107,16 @@ class InitialValueSolver(IVPLifecycle, SolverBase):
         self.timestepper = timestepper(self)
         self.setup_time = time.time() - t0
         self.total_modes = self.R * self.nx * self.ny
+        # launch-bound problems replay their fixed-timestep steps from HIP graphs by default (core/ivp_common.py) -- but only
+        # when every right-hand side is built from the state alone: a parameter field (a forcing the script may rewrite
+        # between steps, the time field `t`) is uploaded by ordinary launches, which a replayed graph would not see
+        state_ids = {id(v) for v in self.variables}
+        rhs_fields = set()
+        for eq in self.equations:
+            if eq["F"] is not None and hasattr(eq["F"], "leaves"):
+                rhs_fields |= {id(f) for f in eq["F"].leaves() if not getattr(f, "_is_number", False)}
+        if rhs_fields <= state_ids:
+            self.step_graph_auto_modes = 1 << 22
         self.handlers = []
         from .output import OutputEvaluator
         self.evaluator = OutputEvaluator(self)       # analysis handlers: evaluated at the start of a step

@@ -176,7 +176,7 @@ int launch_c(const FftDev &d, const FusedArgs &f_in, long nlines, hipStream_t st
     if ((unsigned long)nwg > 0x7fffffffUL) return fail("rfft_bilinear_fused: grid too large");
     const size_t lds = ((size_t)G::TW + (size_t)WAVES * G::LDW) * sizeof(double2);
     const dim3 grid((unsigned)nwg), block(64 * WAVES);
-    static const bool twreg = getenv("DDH_GW_TWREG") ? atoi(getenv("DDH_GW_TWREG")) != 0 : true;
+    static const bool twreg = getenv("DDH_GW_TWREG") ? atoi(getenv("DDH_GW_TWREG")) != 0 : false;   // (spills: see below)
     FusedArgs f = f_in;
     for (int t = 0; t < FUSED_TERMS; ++t) f.coef[t] *= 0.25;     // both factors of a term arrive doubled
     if (twreg)
@@ -189,11 +189,14 @@ int launch_c(const FftDev &d, const FusedArgs &f_in, long nlines, hipStream_t st
 
 }  // namespace gw2
 
-// the second-generation kernel takes the sizes it is instantiated for when the spectrum is 3/2-padded (K + 1 pairs fit
-// the 64-pair blocks that hold N / 3 pairs); DDH_GW_V1=1 keeps the first generation (A/B)
+// Opt-in (DDH_GW_V2=1): measured on MI355X at 768 x 384 lines of 768 points (tools/bench_fused.py, round 5) the second
+// generation runs at 6.95 ms without register twiddles -- the first generation takes 7.46 ms without and 6.82 ms with them --
+// but its 8 C x 8 register map (96 + 32 + 32 registers of operands / accumulator / work values) leaves no room for the 28
+// twiddle registers: with them the kernel spills (256 VGPRs + 44 B of scratch, 8.19 ms).  A third fewer LDS cycles did
+// not move the time: the LDS pipe is ~13 % of a wave's cycles, FP64 issue 30 %, waits 29 %.
 bool gridwave2_supported(const FftDev &d) {
-    static const bool off = getenv("DDH_GW_V1") != nullptr && atoi(getenv("DDH_GW_V1")) != 0;
-    if (off) return false;
+    static const bool on = getenv("DDH_GW_V2") != nullptr && atoi(getenv("DDH_GW_V2")) != 0;
+    if (!on) return false;
     if (d.N % 128 != 0 || (d.M & 1) || d.M < 2 || d.M > d.N) return false;
     const int C = d.N / 128;
     if (!(C == 3 || C == 6)) return false;

@@ -163,6 +163,35 @@ def config_shell(shape=(256, 128, 128), ells=(0, 1, 2, 50, 126)):
     print("wrote", path, os.path.getsize(path) >> 10, "KiB")
 
 
+def config_shell_endstate(shape=(256, 128, 128), steps=2, dt=0.05):
+    """H end state at configuration size: the UNMODIFIED reference builds all subproblems of ShellBasis(256, 128, 128)
+    (hours of host time: that is why config_shell only samples matrices) and takes `steps` SBDF2 steps of the example
+    from its seeded initial condition; stored: norms and sub-sampled coefficient arrays of every state field."""
+    import problems
+    d3 = refshim.load_reference()
+    t0 = time.time()
+    solver, fields = problems.shell_convection(d3, shape=shape, timestepper="SBDF2")
+    t_build = time.time() - t0
+    print("reference shell %s built in %.1f s, %d subproblems" % (shape, t_build, len(solver.subproblems)), flush=True)
+    out = {"shape": np.array(shape), "steps": np.array(steps), "dt": np.array(dt), "build_seconds": np.array(t_build)}
+    t0 = time.time()
+    for i in range(steps):
+        solver.step(dt)
+        print("step", i, "done after %.1f s" % (time.time() - t0), flush=True)
+    out["step_seconds"] = np.array(time.time() - t0)
+    for k, f in fields.items():
+        f.change_scales(1)
+        c = np.array(f['c'])
+        out["end__%s_norm" % k] = np.array(np.linalg.norm(c))
+        if c.ndim >= 3 and c.shape[-3] >= 8:
+            c = c[..., ::8, :, :]                       # every 8th row of the packed azimuthal axis, all ell, all n
+        out["end__%s_sub" % k] = c
+        print(k, np.array(f['c']).shape, float(out["end__%s_norm" % k]), flush=True)
+    path = os.path.join(GOLD, "config_shell_endstate.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) >> 10, "KiB")
+
+
 def config_cartesian():
     """K (KdV-Burgers N = 1024, SBDF2, 200 steps of 2e-3) and R2 (2-D Rayleigh-Benard 512 x 256, RK222, 13 steps of 1e-3)
     end states of the unmodified reference as ARRAYS: every mode of K's u and of R2's b, p and u."""
@@ -262,3 +291,5 @@ if __name__ == "__main__":
         config_shell()
     if "explicit" in which:
         config_explicit()
+    if "shell_endstate" in which:
+        config_shell_endstate()

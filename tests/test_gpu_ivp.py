@@ -161,6 +161,7 @@ def test_fixed_dt_step_graph_matches_ordinary_launches():
     import dedalus_amd.public as d3
     a, fa = problems.rayleigh_benard_2d(d3, Nx=64, Nz=32)
     b, fb = problems.rayleigh_benard_2d(d3, Nx=64, Nz=32)
+    a.enable_step_graph(False)              # (small problems replay by default)
     b.enable_step_graph(True)
     seq = [1e-3] * 8 + [2e-3] * 6
     for i, dt in enumerate(seq):
@@ -211,6 +212,7 @@ def test_every_scheme_replayed_from_step_graphs(gold_schemes, scheme):
             assert err < problems.SCHEME_TOL.get(k, 1e-10), (name, k, err)
     a, fa = problems.kdv_burgers(d3, Nx=128, timestepper=scheme)
     b, fb = problems.kdv_burgers(d3, Nx=128, timestepper=scheme)
+    a.enable_step_graph(False)              # (small problems replay by default)
     b.enable_step_graph(True)
     for h in [2e-3] * 16 + [1e-3] * 12:
         a.step(h)
@@ -229,6 +231,7 @@ def test_failed_graph_capture_leaves_the_history_intact(scheme):
     import dedalus_amd.public as d3
     a, fa = problems.kdv_burgers(d3, Nx=128, timestepper=scheme)
     b, fb = problems.kdv_burgers(d3, Nx=128, timestepper=scheme)
+    a.enable_step_graph(False)              # (small problems replay by default)
     b.enable_step_graph(True)
     real = b.timestepper.step
 
@@ -256,6 +259,7 @@ def test_multistep_step_graphs_match_ordinary_launches(case):
         (lambda: problems.rayleigh_benard_2d(d3, Nx=64, Nz=32, timestepper=ts))
     a, fa = make()
     b, fb = make()
+    a.enable_step_graph(False)              # (small problems replay by default)
     b.enable_step_graph(True)
     dt = 2e-3 if name == "kdv" else 1e-3
     for i, h in enumerate([dt] * 11 + [0.5 * dt] * 9):

@@ -2,6 +2,7 @@
 numpy oracle (reference: core/transforms.py:715-902): whole / partial tiles, several outer indices, enough tiles that
 every wave of several workgroups walks more than one tile (the prefetch path), alpha = 0, 1, 2 and the dual backward."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -146,3 +147,18 @@ def test_wave_real_fourier_all_paths(dev, N, M, outer, inner):
     assert rel(g, npt.rfft_backward(cin, 1, N)) < 1e-12
     assert rel(gd, npt.rfft_backward(dc, 1, N)) < 1e-12
     assert rel(dev.to_host(cf), npt.rfft_forward(gin, 1, M)) < 1e-12
+
+
+def test_second_generation_fused_grid_stage_opt_in():
+    """DDH_GW_V2=1 selects gw2::gridwave2_bilinear_kernel (csrc/ddh_gridwave2.hip: C x 8 x 8 with mirror loads; its lane
+    code is also checked on the CPU, tests/test_host_emu_gridwave2.py) for 3/2-padded lines of 768 / 384 points: the same
+    oracle comparison as the default kernel, in a subprocess (the switch is read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DDH_GW_V2="1")
+    sel = "test_fused_grid_stage and (768-512 or 384-256 or 768-40)"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_transforms.py"), "-q", "-m", "gpu",
+                        "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
