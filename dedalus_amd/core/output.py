@@ -217,8 +217,7 @@ class FileHandler(Handler):
         # (IVPLifecycle) and, as the last resort, at interpreter exit: atexit holds the handler itself (a finalizer of the
         # handler could not work -- by the time it runs the handler and its staged outputs are gone -- and a handler that
         # a script drops must still write what it staged), and the exit path CLOSES the set (flush + close of the file)
-        import atexit
-        atexit.register(self._at_exit)
+        self._exit_hook = False                      # registered while outputs may be pending (process), dropped by close()
 
     def _at_exit(self):
         try:
@@ -297,6 +296,10 @@ class FileHandler(Handler):
         return lambda: res
 
     def process(self, iteration=0, wall_time=0.0, sim_time=0.0, timestep=0.0, **kw):
+        if not self._exit_hook:
+            import atexit
+            atexit.register(self._at_exit)
+            self._exit_hook = True
         self.flush()                                   # the previous write: its copies had a whole output interval
         self.total_write_num += 1
         meta = dict(sim_time=sim_time, wall_time=wall_time, timestep=timestep, iteration=iteration,
@@ -336,6 +339,10 @@ class FileHandler(Handler):
     def close(self):
         self.flush()
         self._close_file()
+        if self._exit_hook:                          # nothing pending any more: do not pin the handler (solver, device
+            import atexit                            # buffers) until interpreter exit
+            atexit.unregister(self._at_exit)
+            self._exit_hook = False
 
     def _close_file(self):
         if self._file is not None:

@@ -1784,11 +1784,15 @@ class ShellSolverBase:
             if isinstance(v, ConstField):
                 sc, off, nr = m[0]
 
-                def pull(sc=sc, off=off):                  # (on demand: a download per step would serialize host and device)
-                    val = float(np.asarray(self.ex.download(self.X4[sc:sc + 1, 0:1, 0:1, off:off + 1])).reshape(-1)[0])
-                    if self.dist.size > 1:
-                        val = self.dist.pcomm.allreduce_sum(val if self.m0 == 0 else 0.0)
-                    return val
+                src = self.X4[sc:sc + 1, 0:1, 0:1, off:off + 1]
+                if self.dist.size > 1:
+                    # every rank gets the value INSIDE the step (all ranks are here together): a later read by one rank
+                    # alone -- `if rank == 0: print(tau_p['g'])` -- then needs no collective, as in the reference, where a
+                    # constant field's data is replicated
+                    src = self.dist.pcomm.bcast_scalar(src, self.ex, src_rank=0)
+
+                def pull(src=src):                         # (on demand: a download per step would serialize host and device)
+                    return float(np.asarray(self.ex.download(src)).reshape(-1)[0])
                 v._pull = pull
                 v._host_dirty = False
                 continue

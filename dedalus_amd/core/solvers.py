@@ -257,6 +257,7 @@ class SolverBase:
             return                                      # (reported by _build_recombination)
         T = np.eye(len(bc_rows))
         changed = False
+        claimed = set()                                  # boundary rows already combined for another component
         for vi in var_int:
             for c in range(vi["ncomp"]):
                 cols = vi["row0"] + c * vi["nz"] + np.arange(vi["nz"])
@@ -264,12 +265,17 @@ class SolverBase:
                 m = len(touching)
                 if m < 2 or m > vi["nz"]:
                     continue
+                if claimed & set(touching):
+                    # a boundary row that couples two variables (a Robin / coupled condition) belongs to two such sets: the
+                    # second block would overwrite part of the first.  No equivalent rows for this problem.
+                    return
                 G = Rm[np.ix_(touching, cols[:m])]
                 if np.linalg.cond(G) > 1e6:             # (e.g. two Neumann conditions: the constant mode drops out)
                     continue
                 T[np.ix_(touching, touching)] = np.linalg.inv(G)
+                claimed |= set(touching)
                 changed = True
-        if not changed:
+        if not changed or np.linalg.cond(T) > 1e8:
             return
         Tfull = sparse.identity(self.R, format="lil")
         for i, ri in enumerate(bc_rows):
@@ -1062,7 +1068,11 @@ def _matrix_times_termlist(T, tl):
     out = TermList(tl.nrows, tl.ncols, *[np.concatenate(x) for x in parts])
     if (~plain).any():
         out = out.consolidated(0.0)
-        keep = np.abs(out.coef) > 1e-14 * np.abs(out.coef).max()
+        # cancellation residue of the combinations: only in the rows T mixes, relative to each row's own largest entry (the
+        # rows T leaves alone keep every term, however small against the rest of the matrix)
+        rowmax = np.zeros(tl.nrows)
+        np.maximum.at(rowmax, out.row, np.abs(out.coef))
+        keep = ident[out.row] | (np.abs(out.coef) > 1e-14 * rowmax[out.row])
         out = TermList(out.nrows, out.ncols, out.row[keep], out.col[keep], out.coef[keep], out.ex[keep], out.ey[keep],
                        out.dx[keep], out.dy[keep])
     return out

@@ -239,5 +239,19 @@ class Comm:
         self.dist.broadcast(x, src=src)
         return float(x.item())
 
+    def bcast_scalar(self, view, ex, src_rank=0):
+        """a one-element array (device tensor or numpy) holding rank `src_rank`'s value of `view` on every rank: an
+        asynchronous RCCL broadcast on the device (no host synchronisation), host-staged in the gloo test configurations"""
+        t = self.torch
+        if isinstance(view, np.ndarray):
+            out = np.array([self.bcast_float(float(view.reshape(-1)[0]), src=src_rank)])
+            return out
+        buf = view.reshape(-1)[:1].clone()
+        if self.backend == "nccl":
+            self.dist.broadcast(buf, src=src_rank)
+        else:
+            buf.fill_(self.bcast_float(float(buf.cpu()[0]), src=src_rank))
+        return buf
+
     def barrier(self):
         self.dist.barrier()
