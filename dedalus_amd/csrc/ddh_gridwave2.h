@@ -118,6 +118,19 @@ DDH_DEV void build_z(const Loads<NT> &ld, double dscale, const double2 *tw, int 
     }
 }
 
+// The same from an LDS staging area filled by LDS-DMA loads (buffer_load ... lds: no destination registers while the
+// next operand's pairs are in flight): st[t * 64 + lane] = pair lane + 64 t, st[(NT + t) * 64 + lane] = pair (64 - lane) + 64 t
+template <int C, int NT, bool DERIV>
+DDH_DEV void build_z_staged(const double2 *st, double dscale, const double2 *tw, int lane, double2 *z) {
+    Loads<NT> ld;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        ld.d[t] = st[t * 64 + lane];
+        ld.m[t] = st[(NT + t) * 64 + lane];
+    }
+    build_z<C, NT, DERIV>(ld, dscale, tw, lane, z);
+}
+
 // Backward transform of the pre-processed spectrum z[c] = 2 Z[lane + 64 c]:
 //     g[q] = 2 (x[2 m] + i x[2 m + 1]),  m = mc + C (p + 8 q),  lane = 8 mc + p < 8 C   (other lanes: copies of mc = 0)
 // t64r: exp(-2 pi i (lane % 8) (i + 1) / 64), i < 7, in registers (TWREG) or null (LDS table)

@@ -57,16 +57,53 @@ __device__ __forceinline__ void issue_loads(Loads<NT> &ld, const double *line, i
     for (int t = 0; t < NT; ++t) ld.m[t] = bload16(r, 16 * (64 - lane) + 1024 * t);
 }
 
-// WAVES lines (wavefronts) per workgroup
-template <int C, int NT, int WAVES, bool TWREG>
+// the same loads as LDS-DMA (buffer_load_dwordx4 ... lds): lane l's 16 bytes land at st + 64 * t + l, no destination
+// registers; the data are valid for ds_read after the wave's own s_waitcnt vmcnt(0)
+typedef __attribute__((address_space(3))) void *ldsptr;
+// Hand-issued (inline asm): the compiler orders every LDS read behind an LDS-DMA load it knows about (s_waitcnt vmcnt(0)
+// before the first ds_read that follows, whatever it addresses), which would expose the whole HBM latency of the prefetch;
+// these loads are invisible to its counters and are waited for explicitly (s_waitcnt vmcnt(0) before build_z_staged).
+// Its own vmcnt waits stay safe: memory operations retire in order, an uncounted load can only make a wait longer.
+template <int NT>
+__device__ __forceinline__ void issue_loads_dma(double2 *st, const double *line, int lane, int K) {
+    const unsigned long long a = (unsigned long long)line;
+    u4v rs;
+    rs.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    rs.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    rs.z = (unsigned)((K + 1) * 16);
+    rs.w = 0x00020000u;
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(ldsptr)st);   // wave-uniform LDS address
+    const int vd = 16 * lane, vm = 16 * (64 - lane);
+#pragma unroll
+    for (int t = 0; t < 2 * NT; ++t) {
+        unsigned keep;
+        const unsigned dst = base + 1024u * t, soff = 1024u * (t % NT);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(t < NT ? vd : vm), "s"(rs), "s"(dst), "s"(soff)
+                     : "memory");
+    }
+}
+
+// WAVES lines (wavefronts) per workgroup.  DMA: operand pairs staged in LDS by LDS-DMA instead of in registers (frees the
+// 8 NT prefetch registers for the register twiddles; needs every stored pair in range, K + 1 == 64 NT)
+template <int C, int NT, int WAVES, bool TWREG, bool DMA = false>
 __global__ void __launch_bounds__(64 * WAVES, 2)
 gridwave2_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
     constexpr int GW_T = 64 * WAVES;
     using G = G2<C>;
+    constexpr int STG = DMA ? 2 * NT * 64 : 1;          // staging area per wave (double2)
     extern __shared__ double2 lds[];
+    __shared__ double2 s_stage[WAVES][STG];
     double2 *tw = lds;                                   // twiddle tables (G2<C>::T_*)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double2 *wb = lds + G::TW + wave * G::LDW;          // this wave's exchange buffer
+    double2 *st = s_stage[__builtin_amdgcn_readfirstlane(wave)];     // ... and its staging area
+    if (DMA) {
+        // the one pair the loads never bring (lane 0's mirror of block NT - 1 = pair 64 NT: beyond the line) reads as zero
+        // whether the range check of an LDS-DMA load writes a zero or nothing at all
+        for (int i = lane; i < STG; i += 64) st[i] = make_double2(0.0, 0.0);
+    }
     for (int i = tid; i < G::TW; i += GW_T) tw[i] = p.tw[G::table_q(i)];
     // kernel arguments indexed at run time go through LDS
     __shared__ const double *s_src[FUSED_LOADS];
@@ -104,17 +141,32 @@ gridwave2_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
   for (long line = (long)blockIdx.x * WAVES + wave; line < nlines; line += (long)gridDim.x * WAVES) {
     const long off = line * (long)M;
 
-    Loads<NT> ld;
-    issue_loads<NT>(ld, s_src[0] + off, lane, K);
-    // One backward transform: operand l (already staged in ld) -> grid values g; prefetches operand l + 1.
+    Loads<DMA ? 1 : NT> ld;
+    if constexpr (DMA) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the staging area's last readers are done)
+        issue_loads_dma<NT>(st, s_src[0] + off, lane, K);
+    } else {
+        issue_loads<NT>(ld, s_src[0] + off, lane, K);
+    }
+    // One backward transform: operand l (already staged) -> grid values g; prefetches operand l + 1.
     auto backward = [&](int l, double2 *g) {
         int ln = lane;
         WF_OPAQUE_LANE(ln);
         double2 z[C];
         const double ds = s_dscale[l];
-        if (ds != 0.0) build_z<C, NT, true>(ld, ds, tw, ln, z);      // wave-uniform branch
-        else build_z<C, NT, false>(ld, ds, tw, ln, z);
-        if (l + 1 < nloads) issue_loads<NT>(ld, s_src[l + 1] + off, ln, K);
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the LDS-DMA loads of this operand have landed
+            WF_SYNC();
+            if (ds != 0.0) build_z_staged<C, NT, true>(st, ds, tw, ln, z);
+            else build_z_staged<C, NT, false>(st, ds, tw, ln, z);
+            WF_SYNC();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // ... and have been read: the area is free again
+            if (l + 1 < nloads) issue_loads_dma<NT>(st, s_src[l + 1] + off, ln, K);
+        } else {
+            if (ds != 0.0) build_z<C, NT, true>(ld, ds, tw, ln, z);  // wave-uniform branch
+            else build_z<C, NT, false>(ld, ds, tw, ln, z);
+            if (l + 1 < nloads) issue_loads<NT>(ld, s_src[l + 1] + off, ln, K);
+        }
         backward_line<C, TWREG>(z, wb, tw, ln, g, t64r);
     };
     // the `a` operands stay in registers (twice their grid values, like every transformed operand)
@@ -177,9 +229,15 @@ int launch_c(const FftDev &d, const FusedArgs &f_in, long nlines, hipStream_t st
     const size_t lds = ((size_t)G::TW + (size_t)WAVES * G::LDW) * sizeof(double2);
     const dim3 grid((unsigned)nwg), block(64 * WAVES);
     static const bool twreg = getenv("DDH_GW_TWREG") ? atoi(getenv("DDH_GW_TWREG")) != 0 : false;   // (spills: see below)
+    static const int dma = getenv("DDH_GW_DMA") ? atoi(getenv("DDH_GW_DMA")) : 0;     // 1: LDS-DMA staging + register twiddles, 2: without
     FusedArgs f = f_in;
     for (int t = 0; t < FUSED_TERMS; ++t) f.coef[t] *= 0.25;     // both factors of a term arrive doubled
-    if (twreg)
+    if (dma && d.K + 1 == 64 * NT32) {
+        if (dma == 1)
+            hipLaunchKernelGGL((gridwave2_bilinear_kernel<C, NT32, WAVES, true, true>), grid, block, lds, st, d, f, nlines);
+        else
+            hipLaunchKernelGGL((gridwave2_bilinear_kernel<C, NT32, WAVES, false, true>), grid, block, lds, st, d, f, nlines);
+    } else if (twreg)
         hipLaunchKernelGGL((gridwave2_bilinear_kernel<C, NT32, WAVES, true>), grid, block, lds, st, d, f, nlines);
     else
         hipLaunchKernelGGL((gridwave2_bilinear_kernel<C, NT32, WAVES, false>), grid, block, lds, st, d, f, nlines);

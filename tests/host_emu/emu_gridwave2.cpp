@@ -54,22 +54,29 @@ static double2 pair_at(const double *line, int k, int K) {
 }
 
 template <int C, bool TWREG>
-static void backward(int K, double dscale, const double *line, const double *plan_tw, double *grid) {
+static void backward(int K, double dscale, const double *line, const double *plan_tw, double *grid, bool staged) {
     using G = G2<C>;
     constexpr int NT = (2 * C + 2) / 3;
     const std::vector<double2> tw = make_tables<C>(plan_tw);
-    std::vector<double2> wb(G::LDW);
+    std::vector<double2> wb(G::LDW), st(2 * NT * 64);
     run_wave([&](int lane) {
         Loads<NT> ld;
         for (int t = 0; t < NT; ++t) {
             ld.d[t] = pair_at(line, lane + 64 * t, K);
             ld.m[t] = pair_at(line, 64 - lane + 64 * t, K);
+            // (the LDS-DMA loads of the device: lane l's 16 bytes land at st + 64 t + l)
+            st[t * 64 + lane] = ld.d[t];
+            st[(NT + t) * 64 + lane] = ld.m[t];
         }
+        WF_SYNC();
         double2 t64r[7];
         for (int i = 0; i < 7; ++i) t64r[i] = tw[G::T_64 + (lane & 7) * (i + 1)];
         double2 z[C], g[8];
         for (int i = 0; i < 8; ++i) g[i] = make_double2(0.0, 0.0);
-        if (dscale != 0.0) build_z<C, NT, true>(ld, dscale, tw.data(), lane, z);
+        if (staged) {
+            if (dscale != 0.0) build_z_staged<C, NT, true>(st.data(), dscale, tw.data(), lane, z);
+            else build_z_staged<C, NT, false>(st.data(), dscale, tw.data(), lane, z);
+        } else if (dscale != 0.0) build_z<C, NT, true>(ld, dscale, tw.data(), lane, z);
         else build_z<C, NT, false>(ld, dscale, tw.data(), lane, z);
         backward_line<C, TWREG>(z, wb.data(), tw.data(), lane, g, t64r);
         if (lane < G::NB) {
@@ -113,8 +120,10 @@ extern "C" {
 // grid (N = 128 C doubles) = TWICE the c2r transform of the (cos, msin) pairs of `line` (derivative applied when
 // dscale != 0); returns -1 for sizes that are not instantiated
 int emu_gw2_backward(int C, int twreg, int K, double dscale, const double *line, const double *plan_tw, double *grid) {
-    if (C == 6) { twreg ? backward<6, true>(K, dscale, line, plan_tw, grid) : backward<6, false>(K, dscale, line, plan_tw, grid); return 0; }
-    if (C == 3) { twreg ? backward<3, true>(K, dscale, line, plan_tw, grid) : backward<3, false>(K, dscale, line, plan_tw, grid); return 0; }
+    const bool staged = (twreg & 2) != 0;      // bit 1: pairs through the LDS staging area (the LDS-DMA variant)
+    twreg &= 1;
+    if (C == 6) { twreg ? backward<6, true>(K, dscale, line, plan_tw, grid, staged) : backward<6, false>(K, dscale, line, plan_tw, grid, staged); return 0; }
+    if (C == 3) { twreg ? backward<3, true>(K, dscale, line, plan_tw, grid, staged) : backward<3, false>(K, dscale, line, plan_tw, grid, staged); return 0; }
     return -1;
 }
 int emu_gw2_forward(int C, int twreg, int K, int M, const double *grid, const double *plan_tw, double *line) {

@@ -156,9 +156,12 @@ def test_second_generation_fused_grid_stage_opt_in():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DDH_GW_V2="1")
     sel = "test_fused_grid_stage and (768-512 or 384-256 or 768-40)"
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_transforms.py"), "-q", "-m", "gpu",
-                        "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    # DDH_GW_DMA=1 / 2: operand pairs staged by LDS-DMA loads (with / without register twiddles) where every stored pair is in
+    # range (768-512, 384-256; 768-40 keeps the register loads)
+    for extra in ({}, {"DDH_GW_DMA": "1"}, {"DDH_GW_DMA": "2"}):
+        env = dict(os.environ, DDH_GW_V2="1", **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_transforms.py"), "-q", "-m", "gpu",
+                            "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, (extra, r.stdout[-3000:] + r.stderr[-2000:])
+        assert " passed" in r.stdout and "failed" not in r.stdout

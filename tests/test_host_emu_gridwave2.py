@@ -60,7 +60,7 @@ def r2c(x, M):
 
 
 @pytest.mark.parametrize("C_", [6, 3])
-@pytest.mark.parametrize("twreg", [1, 0])
+@pytest.mark.parametrize("twreg", [1, 0, 3])                   # 3: register twiddles + pairs through the LDS staging area
 @pytest.mark.parametrize("dscale", [0.0, 1.7])
 def test_backward_line(emu, C_, twreg, dscale):
     N = 128 * C_
