@@ -119,14 +119,19 @@ DDH_DEV void build_z(const Loads<NT> &ld, double dscale, const double2 *tw, int 
 }
 
 // The same from an LDS staging area filled by LDS-DMA loads (buffer_load ... lds: no destination registers while the
-// next operand's pairs are in flight): st[t * 64 + lane] = pair lane + 64 t, st[(NT + t) * 64 + lane] = pair (64 - lane) + 64 t
+// pairs of the next operands are in flight): st[k] = pair k for k < 64 NT, st[64 NT] = 0.  The mirror pairs are the same
+// blocks read lane-reversed: pair (64 - lane) + 64 t = st[64 t + 64 - lane] (lane 0: the first pair of the next block).
+template <int NT>
+struct Staging {
+    static constexpr int SIZE = 64 * NT + 8;       // double2 per buffer (the pad keeps the second buffer 128-byte aligned)
+};
 template <int C, int NT, bool DERIV>
 DDH_DEV void build_z_staged(const double2 *st, double dscale, const double2 *tw, int lane, double2 *z) {
     Loads<NT> ld;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         ld.d[t] = st[t * 64 + lane];
-        ld.m[t] = st[(NT + t) * 64 + lane];
+        ld.m[t] = st[t * 64 + 64 - lane];
     }
     build_z<C, NT, DERIV>(ld, dscale, tw, lane, z);
 }

@@ -73,16 +73,23 @@ __device__ __forceinline__ void issue_loads_dma(double2 *st, const double *line,
     rs.z = (unsigned)((K + 1) * 16);
     rs.w = 0x00020000u;
     const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(ldsptr)st);   // wave-uniform LDS address
-    const int vd = 16 * lane, vm = 16 * (64 - lane);
+    const int vd = 16 * lane;
 #pragma unroll
-    for (int t = 0; t < 2 * NT; ++t) {
+    for (int t = 0; t < NT; ++t) {
         unsigned keep;
-        const unsigned dst = base + 1024u * t, soff = 1024u * (t % NT);
+        const unsigned dst = base + 1024u * t, soff = 1024u * t;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "v"(t < NT ? vd : vm), "s"(rs), "s"(dst), "s"(soff)
+                     : "v"(vd), "s"(rs), "s"(dst), "s"(soff)
                      : "memory");
     }
+}
+// wait until at most the NT loads of the NEWEST operand are outstanding / until nothing is
+template <int NT>
+__device__ __forceinline__ void wait_older_loads() {
+    static_assert(NT == 2 || NT == 4, "vmcnt immediates of the instantiated sizes");
+    if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 }
 
 // WAVES lines (wavefronts) per workgroup.  DMA: operand pairs staged in LDS by LDS-DMA instead of in registers (frees the
@@ -92,7 +99,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2)
 gridwave2_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
     constexpr int GW_T = 64 * WAVES;
     using G = G2<C>;
-    constexpr int STG = DMA ? 2 * NT * 64 : 1;          // staging area per wave (double2)
+    constexpr int STGB = Staging<NT>::SIZE;             // one staging buffer (double2); two per wave: the pairs of the next
+    constexpr int STG = DMA ? 2 * STGB : 1;             // TWO operands are in flight while one is transformed
     extern __shared__ double2 lds[];
     __shared__ double2 s_stage[WAVES][STG];
     double2 *tw = lds;                                   // twiddle tables (G2<C>::T_*)
@@ -100,8 +108,7 @@ gridwave2_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
     double2 *wb = lds + G::TW + wave * G::LDW;          // this wave's exchange buffer
     double2 *st = s_stage[__builtin_amdgcn_readfirstlane(wave)];     // ... and its staging area
     if (DMA) {
-        // the one pair the loads never bring (lane 0's mirror of block NT - 1 = pair 64 NT: beyond the line) reads as zero
-        // whether the range check of an LDS-DMA load writes a zero or nothing at all
+        // the pair the loads never bring (st[64 NT] = pair 64 NT, lane 0's mirror of the last block: beyond the line) is zero
         for (int i = lane; i < STG; i += 64) st[i] = make_double2(0.0, 0.0);
     }
     for (int i = tid; i < G::TW; i += GW_T) tw[i] = p.tw[G::table_q(i)];
@@ -137,31 +144,53 @@ gridwave2_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
 #pragma unroll
         for (int i = 0; i < 7; ++i) t64r[i] = tw[G::T_64 + (lane & 7) * (i + 1)];
     }
+    // LDS-DMA pipeline (DMA): the operand sequence of this wave -- every operand of every line it takes -- is fetched two
+    // operands ahead into two alternating staging buffers, across line boundaries
+    const long line0 = (long)blockIdx.x * WAVES + wave, lstride = (long)gridDim.x * WAVES;
+    long pf_line = line0;
+    int pf_l = 0, cur_buf = 0;
+    bool pf_newer = false, st_pending = false;
+    auto prefetch = [&](int buf) -> bool {
+        const bool live = pf_line < nlines;
+        if (live) issue_loads_dma<NT>(st + buf * STGB, s_src[pf_l] + pf_line * (long)M, lane, K);
+        if (++pf_l == nloads) {
+            pf_l = 0;
+            pf_line += lstride;
+        }
+        return live;
+    };
+    if constexpr (DMA) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the zero fill of the staging buffers)
+        prefetch(0);
+        pf_newer = prefetch(1);
+    }
 #pragma unroll 1
-  for (long line = (long)blockIdx.x * WAVES + wave; line < nlines; line += (long)gridDim.x * WAVES) {
+  for (long line = line0; line < nlines; line += lstride) {
     const long off = line * (long)M;
 
     Loads<DMA ? 1 : NT> ld;
-    if constexpr (DMA) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the staging area's last readers are done)
-        issue_loads_dma<NT>(st, s_src[0] + off, lane, K);
-    } else {
-        issue_loads<NT>(ld, s_src[0] + off, lane, K);
-    }
-    // One backward transform: operand l (already staged) -> grid values g; prefetches operand l + 1.
+    if constexpr (!DMA) issue_loads<NT>(ld, s_src[0] + off, lane, K);
+    // One backward transform: operand l (already staged) -> grid values g; prefetches the next operand(s).
     auto backward = [&](int l, double2 *g) {
         int ln = lane;
         WF_OPAQUE_LANE(ln);
         double2 z[C];
         const double ds = s_dscale[l];
         if constexpr (DMA) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the LDS-DMA loads of this operand have landed
+            // The loads of this operand were issued two transforms ago, those of the next one a transform ago: wait for
+            // the older set only.  Stores retire out of order with loads (one counter): after a forward transform, and when
+            // no newer set was issued (the last operand of the wave), wait for everything.
+            if (pf_newer && !st_pending) wait_older_loads<NT>();
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_pending = false;
             WF_SYNC();
-            if (ds != 0.0) build_z_staged<C, NT, true>(st, ds, tw, ln, z);
-            else build_z_staged<C, NT, false>(st, ds, tw, ln, z);
+            const double2 *cur = st + cur_buf * STGB;
+            if (ds != 0.0) build_z_staged<C, NT, true>(cur, ds, tw, ln, z);
+            else build_z_staged<C, NT, false>(cur, ds, tw, ln, z);
             WF_SYNC();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // ... and have been read: the area is free again
-            if (l + 1 < nloads) issue_loads_dma<NT>(st, s_src[l + 1] + off, ln, K);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // ... and have been read: the buffer is free again
+            pf_newer = prefetch(cur_buf);                            // operand + 2 into the buffer just read; at the next
+            cur_buf ^= 1;                                            // transform it is the newer of the two sets in flight
         } else {
             if (ds != 0.0) build_z<C, NT, true>(ld, ds, tw, ln, z);  // wave-uniform branch
             else build_z<C, NT, false>(ld, ds, tw, ln, z);
@@ -210,6 +239,7 @@ gridwave2_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
             WF_OPAQUE_LANE(lf);
             double *dst = s_out[oc] + off;
             forward_line<C, NT, TWREG>(acc, wb, tw, lf, M, K, t64r, [&](int k, double2 v) { gstore16(dst + 2 * k, v); });
+            st_pending = true;
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = make_double2(0.0, 0.0);
         }

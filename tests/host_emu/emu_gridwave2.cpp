@@ -58,7 +58,7 @@ static void backward(int K, double dscale, const double *line, const double *pla
     using G = G2<C>;
     constexpr int NT = (2 * C + 2) / 3;
     const std::vector<double2> tw = make_tables<C>(plan_tw);
-    std::vector<double2> wb(G::LDW), st(2 * NT * 64);
+    std::vector<double2> wb(G::LDW), st(Staging<NT>::SIZE, make_double2(0.0, 0.0));
     run_wave([&](int lane) {
         Loads<NT> ld;
         for (int t = 0; t < NT; ++t) {
@@ -66,7 +66,6 @@ static void backward(int K, double dscale, const double *line, const double *pla
             ld.m[t] = pair_at(line, 64 - lane + 64 * t, K);
             // (the LDS-DMA loads of the device: lane l's 16 bytes land at st + 64 t + l)
             st[t * 64 + lane] = ld.d[t];
-            st[(NT + t) * 64 + lane] = ld.m[t];
         }
         WF_SYNC();
         double2 t64r[7];
