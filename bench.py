@@ -26,10 +26,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-PMC_FAMILY = {   # kernel family in this file -> device kernel name prefixes in profiles/r4_pmc_traffic.json
+PMC_FAMILY = {   # kernel family in this file -> device kernel name prefixes in profiles/r5_pmc_traffic.json
     "pencil_solve": ["solve_forward_", "solve_backward_"],
     "pencil_matvec": ["band_matvec_kernel"],
-    "rfft_bilinear_fused": ["gw::gridwave_bilinear_kernel", "fused_rfft_bilinear_kernel"],
+    "rfft_bilinear_fused": ["gw2::gridwave2_bilinear_kernel", "gw::gridwave_bilinear_kernel", "fused_rfft_bilinear_kernel"],
     "rfft_backward_contig": ["fft_axis_kernel<1, false"],
     "rfft_backward_strided": ["wave_rfft_kernel<0"],
     "rfft_backward_strided_dual": ["wave_rfft_kernel<2"],
@@ -45,10 +45,12 @@ PMC_FAMILY = {   # kernel family in this file -> device kernel name prefixes in 
 
 def pmc_traffic(family):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes
-    (profiles/r4_pmc_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes,
+    (profiles/r5_pmc_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes,
     full-size run; a family made of several kernels per call sums their per-launch means).
     Returns None when no measurement is on file."""
-    path = os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r5_pmc_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")
     if not os.path.exists(path) or family not in PMC_FAMILY:
         return None
     data = json.load(open(path))
@@ -447,7 +449,7 @@ def main():
                         frac=dom[1]["gbps"] / HBM_PEAK_GBS,
                         traffic=(pmc_traffic(dom[0]) if (Nx, Ny, Nz) == (512, 512, 256) and world == 1 else None),
                         traffic_note="bytes per launch from rocprofv3 PMC passes committed under profiles/ "
-                                     "(r4_pmc_summary.txt); algorithmic bytes and time are measured live",
+                                     "(r5_pmc_summary.txt); algorithmic bytes and time are measured live",
                         avg_launch_ms=dom[1]["avg_ms"], algorithmic_bytes_per_launch=dom[1]["bytes_per_launch"],
                         launches=dom[1]["launches"])
         # the fused y stage is co-limited by FP64 issue: its algorithmic flops per launch (a real transform of N points =

@@ -259,7 +259,7 @@ int launch_c(const FftDev &d, const FusedArgs &f_in, long nlines, hipStream_t st
     const size_t lds = ((size_t)G::TW + (size_t)WAVES * G::LDW) * sizeof(double2);
     const dim3 grid((unsigned)nwg), block(64 * WAVES);
     static const bool twreg = getenv("DDH_GW_TWREG") ? atoi(getenv("DDH_GW_TWREG")) != 0 : false;   // (spills: see below)
-    static const int dma = getenv("DDH_GW_DMA") ? atoi(getenv("DDH_GW_DMA")) : 0;     // 1: LDS-DMA staging + register twiddles, 2: without
+    static const int dma = getenv("DDH_GW_DMA") ? atoi(getenv("DDH_GW_DMA")) : 1;     // 1: LDS-DMA staging + register twiddles, 2: without, 0: register loads
     FusedArgs f = f_in;
     for (int t = 0; t < FUSED_TERMS; ++t) f.coef[t] *= 0.25;     // both factors of a term arrive doubled
     if (dma && d.K + 1 == 64 * NT32) {
@@ -277,19 +277,23 @@ int launch_c(const FftDev &d, const FusedArgs &f_in, long nlines, hipStream_t st
 
 }  // namespace gw2
 
-// Opt-in (DDH_GW_V2=1): measured on MI355X at 768 x 384 lines of 768 points (tools/bench_fused.py, round 5) the second
-// generation runs at 6.95 ms without register twiddles -- the first generation takes 7.46 ms without and 6.82 ms with them --
-// but its 8 C x 8 register map (96 + 32 + 32 registers of operands / accumulator / work values) leaves no room for the 28
-// twiddle registers: with them the kernel spills (256 VGPRs + 44 B of scratch, 8.19 ms).  A third fewer LDS cycles did
-// not move the time: the LDS pipe is ~13 % of a wave's cycles, FP64 issue 30 %, waits 29 %.
+// Default for 3/2-padded lines whose stored pairs fill their 64-pair blocks exactly (K + 1 == 64 NT: 768 / 512, 384 / 256):
+// the LDS-DMA variant with register twiddles.  Measured on MI355X at 768 x 384 lines of 768 points (tools/bench_fused.py,
+// same box, round 5): first generation 6.71 ms; this kernel with register loads 6.83 ms (no room for register twiddles:
+// with them 256 VGPRs + 44 B of scratch, 8.19 ms); LDS-DMA staging, one operand ahead 6.71 ms; two operands ahead 6.42 ms
+// (235 VGPRs), without register twiddles 6.59 ms.  Counters (profiles/r5_fused_sq_counters.txt): 6405 instead of 6897 VALU
+// and 1021 instead of 1135 LDS instructions per line, LDS bank-conflict cycles -64 %, s_waitcnt time -15 %.
+// DDH_GW_V2=0 keeps the first generation; other sizes take it anyway.
 bool gridwave2_supported(const FftDev &d) {
-    static const bool on = getenv("DDH_GW_V2") != nullptr && atoi(getenv("DDH_GW_V2")) != 0;
-    if (!on) return false;
+    static const bool off = getenv("DDH_GW_V2") != nullptr && atoi(getenv("DDH_GW_V2")) == 0;
+    if (off) return false;
     if (d.N % 128 != 0 || (d.M & 1) || d.M < 2 || d.M > d.N) return false;
     const int C = d.N / 128;
     if (!(C == 3 || C == 6)) return false;
     const int NT32 = (2 * C + 2) / 3;
-    return d.K + 1 <= 64 * NT32 && NT32 < C;
+    static const bool any_k = getenv("DDH_GW_V2") != nullptr && atoi(getenv("DDH_GW_V2")) == 2;   // 2: also truncated spectra (register loads)
+    if (any_k) return d.K + 1 <= 64 * NT32 && NT32 < C;
+    return d.K + 1 == 64 * NT32 && NT32 < C;
 }
 
 int launch_gridwave2(const FftDev &d, const FusedArgs &f, long nlines, hipStream_t st) {

@@ -149,18 +149,19 @@ def test_wave_real_fourier_all_paths(dev, N, M, outer, inner):
     assert rel(dev.to_host(cf), npt.rfft_forward(gin, 1, M)) < 1e-12
 
 
-def test_second_generation_fused_grid_stage_opt_in():
-    """DDH_GW_V2=1 selects gw2::gridwave2_bilinear_kernel (csrc/ddh_gridwave2.hip: C x 8 x 8 with mirror loads; its lane
-    code is also checked on the CPU, tests/test_host_emu_gridwave2.py) for 3/2-padded lines of 768 / 384 points: the same
-    oracle comparison as the default kernel, in a subprocess (the switch is read once per process)."""
+def test_fused_grid_stage_generations():
+    """The fused y stage has two kernel generations: gw2::gridwave2_bilinear_kernel (csrc/ddh_gridwave2.hip: C x 8 x 8, LDS-DMA
+    operand staging two operands ahead; its lane code is also checked on the CPU, tests/test_host_emu_gridwave2.py) is the
+    default for full 3/2-padded lines of 768 / 384 points, gw::gridwave_bilinear_kernel for everything else.  The same
+    oracle comparison for every selectable variant, each in a subprocess (the switches are read once per process):
+    DDH_GW_V2=0 first generation; =2 second generation also for truncated spectra; DDH_GW_DMA=0 register loads, =2 LDS-DMA
+    without register twiddles."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sel = "test_fused_grid_stage and (768-512 or 384-256 or 768-40)"
-    # DDH_GW_DMA=1 / 2: operand pairs staged by LDS-DMA loads (with / without register twiddles) where every stored pair is in
-    # range (768-512, 384-256; 768-40 keeps the register loads)
-    for extra in ({}, {"DDH_GW_DMA": "1"}, {"DDH_GW_DMA": "2"}):
-        env = dict(os.environ, DDH_GW_V2="1", **extra)
+    for extra in ({"DDH_GW_V2": "0"}, {"DDH_GW_V2": "2"}, {"DDH_GW_V2": "2", "DDH_GW_DMA": "0"}, {"DDH_GW_DMA": "2"}):
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_transforms.py"), "-q", "-m", "gpu",
                             "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
         assert r.returncode == 0, (extra, r.stdout[-3000:] + r.stderr[-2000:])

@@ -32,14 +32,13 @@ for step in "$@"; do
                 timeout 200 rocprofv3 --kernel-trace -d /tmp/prof_eb -o eb -- python tools/gpu/ellband_time.py > $OUT/ellband_band.log 2>&1
                 grep -E "^(build|plan|solve|factor)" $OUT/ellband_band.log; python tools/gpu/db_stats.py /tmp/prof_eb/eb_results.db 4 | tee $OUT/ellband_kernels.txt
                 DDH_SHELL_DENSE=1 timeout 200 python tools/gpu/ellband_time.py 2>&1 | grep -E "^(build|solve|factor)" | tee $OUT/ellband_dense.log ;;
-    fused)      # the fused y stage alone: first generation, second generation (register loads / LDS-DMA staging, twiddles in registers or LDS)
-                for envs in "DDH_GW_V2=0" "DDH_GW_V2=1" "DDH_GW_V2=1 DDH_GW_DMA=1" "DDH_GW_V2=1 DDH_GW_DMA=2" "DDH_GW_V2=1 DDH_GW_DMA=1 DDH_GW_LPW=4"; do
+    fused)      # the fused y stage alone: first generation, second generation (LDS-DMA staging default / register loads / twiddles in LDS)
+                for envs in "DDH_GW_V2=0" "DDH_GW_V2=1" "DDH_GW_DMA=0" "DDH_GW_DMA=2" "DDH_GW_LPW=4"; do
                   echo "$envs" | tee -a $OUT/fused.txt
                   env $envs FUSED_DERIV=1 python tools/bench_fused.py 2>&1 | tail -1 | tee -a $OUT/fused.txt
                 done ;;
     tests-fused) python -m pytest tests/test_gpu_wave_transforms.py tests/test_gpu_transforms.py -x -q -m gpu -k "fused" > $OUT/pytest_fused.txt 2>&1; tail -3 $OUT/pytest_fused.txt ;;
-    bench-v2dma) DDH_GW_V2=1 DDH_GW_DMA=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cfl > $OUT/bench_v2dma.json 2> $OUT/bench_v2dma.err; bench_line $OUT/bench_v2dma.json ;;
-    bench-v1)   DDH_GW_V1=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cfl > $OUT/bench_v1.json 2> $OUT/bench_v1.err; bench_line $OUT/bench_v1.json ;;
+    bench-v1)   DDH_GW_V2=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cfl > $OUT/bench_v1.json 2> $OUT/bench_v1.err; bench_line $OUT/bench_v1.json ;;
     configs)    python tools/bench_configs.py --json > $OUT/configs.json 2> $OUT/configs.err; tail -5 $OUT/configs.json ;;
     shares)     # per-rank shares of the strong-scaled problem on one GPU, sweep variants A/B (profiles/*_strong_scaling_shares.txt)
                 for sz in 256,512,256 128,512,256 64,512,256; do
