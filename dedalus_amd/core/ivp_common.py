@@ -171,11 +171,21 @@ class IVPLifecycle:
             torch = self.ex.torch
             t0 = self.sim_time
             snap = ts.graph_snapshot() if hasattr(ts, "graph_snapshot") else None
+            # Cyclic garbage must not be collected INSIDE the capture: a finalizer that releases device memory (an old
+            # solver's plans, factorizations: ddh_destroy -> hipFree) is illegal on a capturing stream and aborts the process.
+            import gc
+            gc_was_on = gc.isenabled()
             try:
                 g = torch.cuda.CUDAGraph()
+                gc.collect()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g):
-                    ts.step(dt, wall_time)
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g):
+                        ts.step(dt, wall_time)
+                finally:
+                    if gc_was_on:
+                        gc.enable()
                 st["graphs"][phase[1]] = g
             except Exception as e:                      # something in the step is not capturable: never try again
                 st["failed"] = True

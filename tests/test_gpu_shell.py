@@ -105,6 +105,29 @@ def test_shell_convection_config_size_sampled_ell_systems():
           % (worst_m, worst_r, worst_x))
     b = np.asarray(f["b"]["c"])
     assert np.isfinite(b).all()
+    # ---- the END STATE of those two steps against the unmodified reference's at this size (tests/golden/
+    # config_shell_endstate.npz <- oracle/make_golden_config.py::config_shell_endstate: 25 min of host time to build the
+    # reference's 127 subproblems, 38 s per step): norms of the whole arrays and every 32nd row of the packed azimuthal axis
+    E = np.load(os.path.join(os.path.dirname(__file__), "golden", "config_shell_endstate.npz"))
+    assert tuple(E["shape"]) == (256, 128, 128) and int(E["steps"]) == 2 and float(E["dt"]) == 0.05
+    stride = int(E["sub_stride"])
+    # rel-L2; the tau amplitudes are 1e-5 ... 1e-10 of the fields they correct: measured against 1e-6 where smaller
+    tol = dict(b=1e-9, p=1e-6, u=1e-7, tau_p=1e-6, tau_b1=1e-5, tau_b2=1e-5, tau_u1=1e-5, tau_u2=1e-5)
+    errs = {}
+    for k, fld in f.items():
+        c = np.asarray(fld["c"])
+        ref = E["end__%s_sub" % k]
+        if k == "tau_p":                                        # a constant: one number (~1e-20 here)
+            errs[k] = abs(float(c.reshape(-1)[0]) - float(ref.reshape(-1)[0]))
+            continue
+        sub = c[..., ::stride, :, :] if (c.ndim >= 3 and c.shape[-3] >= 32) else c
+        assert sub.shape == ref.shape, (k, sub.shape, ref.shape)
+        floor = 1e-6 if k.startswith("tau") else 1e-300
+        errs[k] = float(np.linalg.norm(sub - ref) / max(np.linalg.norm(ref), floor))
+        assert abs(np.linalg.norm(c) - float(E["end__%s_norm" % k])) <= 10 * tol[k] * max(float(E["end__%s_norm" % k]), floor), k
+    print("shell 256x128x128 end state vs reference:", {k: "%.1e" % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < tol[k], (k, v)
 
 
 @pytest.mark.gpu
