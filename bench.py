@@ -454,15 +454,15 @@ def main():
                         launches=dom[1]["launches"])
         # the fused y stage is co-limited by FP64 issue: its algorithmic flops per launch (a real transform of N points =
         # 2.5 N log2 N; 15 backward + 4 forward per line; 12 product terms of 3 flops per grid point) against the vector
-        # FP64 peak (MI355X_MICROARCH.md: 78.6 TFLOP/s).  The kernel issues ~1.6 x these flops' worth of instructions
-        # (pre- / post-processing, twiddles, address arithmetic; profiles/r3_sq_counters.txt: 6900 VALU per line).
+        # FP64 peak (MI355X_MICROARCH.md: 78.6 TFLOP/s).  The kernel issues ~1.5 x these flops' worth of instructions
+        # (pre- / post-processing, twiddles, address arithmetic; profiles/r5_fused_sq_counters.txt: 6405 VALU per line).
         if roof and roof["kernel"] == "rfft_bilinear_fused" and world == 1:
             gy, nl = 3 * Ny // 2, (3 * Nz // 2) * (3 * Nx // 2)
             fl = nl * (19 * 2.5 * gy * np.log2(gy) + 12 * 3 * gy)
             tf = fl / (roof["avg_launch_ms"] * 1e-3) / 1e12
             roof["valu"] = dict(bound="fp64-valu", algorithmic_flops_per_launch=fl, achieved=tf, peak=78.6, unit="TFLOP/s",
-                                frac=tf / 78.6, issued_valu_frac_note="6900 wave instructions per line x 4 cycles on 1024 "
-                                "SIMDs = 3.3 ms of pure FP64 issue per launch (profiles/r3_sq_counters.txt)")
+                                frac=tf / 78.6, issued_valu_frac_note="6405 wave instructions per line x 4 cycles on 1024 "
+                                "SIMDs = 3.1 ms of pure VALU issue per launch (profiles/r5_fused_sq_counters.txt)")
         total_kernel_ms = sum(v["total_ms"] for v in summ.values())
         total_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in summ.values())
         out = {
