@@ -53,40 +53,9 @@ constexpr int GV_COLS = 8;     // GEMV path: at most this many right-hand-side c
 // The right-hand-side columns (cos / msin parts, leading and trailing axes) are few, so the kernel is bound
 // by streaming the matrices: every lane keeps GV_ROWS matrix loads in flight per step and the (cached)
 // right-hand-side values are loaded once for all the rows of the wave; all index arithmetic is hoisted.
-// Sums of NV values over the 64 lanes with NV + log2(64 / NV) - 1 lane exchanges instead of 6 NV: at every halving step a
-// lane hands the half of its values it does not keep to its partner (lane ^ offset) and adds what it receives, so that the
-// values spread over the lanes while they are reduced.  Afterwards v[0] of lane l is the total of value gv_owner<NV>(l)
-// (the same in the lanes that differ in the unused low bits).
-template <int NV>
-__device__ __forceinline__ int gv_owner(int lane) {
-    int idx = 0, half = NV / 2;
-#pragma unroll
-    for (int o = 32; half >= 1; o >>= 1, half >>= 1) idx += (lane & o) ? half : 0;
-    return idx;
-}
-template <int NV>
-__device__ __forceinline__ void gv_reduce_scatter(double *v, int lane) {
-    static_assert(NV >= 1 && NV <= 64 && (NV & (NV - 1)) == 0, "power of two");
-    int o = 32;
-#pragma unroll
-    for (int n = NV; n > 1; n >>= 1, o >>= 1) {
-        const int half = n / 2;
-        const bool up = (lane & o) != 0;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const double send = up ? v[i] : v[i + half];
-            const double keep = up ? v[i + half] : v[i];
-            v[i] = keep + __shfl_xor(send, o, 64);
-        }
-    }
-#pragma unroll
-    for (; o > 0; o >>= 1) v[0] += __shfl_xor(v[0], o, 64);
-}
+constexpr int GV_ROWS = 4;
 
-// GV_ROWS output rows per wave: 8 since round 5 (4 before): the contraction is short (<= 256 / 384 entries = 4-6 steps of
-// 64 lanes), so the bytes a wave has in flight are rows x 512 B per step -- with 4 rows the launch ran at 2.0 TB/s of
-// matrix bytes; DDH_GEMV_ROWS=4 keeps the old shape for A/B.
-template <bool FWD, int NCOL, bool PAIRS, int GV_ROWS>
+template <bool FWD, int NCOL, bool PAIRS>
 __global__ void __launch_bounds__(256)
 grouped_gemv_kernel(const GroupDev *__restrict__ groups, const double *__restrict__ mats, const double *__restrict__ in,
                     double *__restrict__ out, GmmtDims d, int ncols) {
@@ -139,7 +108,6 @@ grouped_gemv_kernel(const GroupDev *__restrict__ groups, const double *__restric
     bool rok[GV_ROWS];
 #pragma unroll
     for (int r = 0; r < GV_ROWS; ++r) rok[r] = row0 + r < nrows;
-#pragma unroll 2
     for (int k = lane; k < K; k += 64) {
         double a[GV_ROWS], xv[NCOL], xw[NCOL];
 #pragma unroll
@@ -165,35 +133,25 @@ grouped_gemv_kernel(const GroupDev *__restrict__ groups, const double *__restric
                 if (PAIRS) acc2[r][c] += a[r] * xw[c];
             }
     }
-    // all GV_ROWS x NCOL (x 2 with pairs) sums at once: value index = (pair * GV_ROWS + r) * NCOL + c
-    constexpr int NV = GV_ROWS * NCOL * (PAIRS ? 2 : 1);
-    double vals[NV];
 #pragma unroll
-    for (int r = 0; r < GV_ROWS; ++r)
+    for (int r = 0; r < GV_ROWS; ++r) {
 #pragma unroll
         for (int c = 0; c < NCOL; ++c) {
-            vals[r * NCOL + c] = acc[r][c];
-            if (PAIRS) vals[(GV_ROWS + r) * NCOL + c] = acc2[r][c];
-        }
-    gv_reduce_scatter<NV>(vals, lane);
-    constexpr int LOW = 64 / NV;                        // lanes that end up with the same value
-    if ((lane & (LOW - 1)) == 0) {
-        const int idx = gv_owner<NV>(lane);
-        const int c = idx % NCOL, r = (idx / NCOL) % GV_ROWS, pr = idx / (NCOL * GV_ROWS);
-        long ob = obase[0], ob2 = obase2[0];
-        bool ck = cok[0];
+            double v = acc[r][c], w = acc2[r][c];
 #pragma unroll
-        for (int cc = 1; cc < NCOL; ++cc)
-            if (c == cc) { ob = obase[cc]; ob2 = obase2[cc]; ck = cok[cc]; }
-        const int row = row0 + r;
-        if (row < nrows && ck) {
-            if (pr == 0) {
-                out[ob + (long)row * ostride] = vals[0];
-            } else if (paired) {
-                // forward: sign of the output row l = ell_start + row; backward: reversed output row
-                const double so = (FWD && mirror && ((gr.ell_start + row + gr.parity) & 1)) ? -1.0 : 1.0;
-                const long orow = (!FWD && mirror) ? (long)(nrows - 1 - row) : (long)row;
-                out[ob2 + orow * ostride] = so * vals[0];
+            for (int off = 32; off > 0; off >>= 1) {
+                v += __shfl_down(v, off, 64);
+                if (PAIRS) w += __shfl_down(w, off, 64);
+            }
+            if (lane == 0 && rok[r] && cok[c]) {
+                out[obase[c] + (long)(row0 + r) * ostride] = v;
+                if (paired) {
+                    // forward: sign of the output row l = ell_start + row; backward: reversed output row
+                    const int row = row0 + r;
+                    const double so = (FWD && mirror && ((gr.ell_start + row + gr.parity) & 1)) ? -1.0 : 1.0;
+                    const long orow = (!FWD && mirror) ? (long)(nrows - 1 - row) : (long)row;
+                    out[obase2[c] + orow * ostride] = so * w;
+                }
             }
         }
     }
@@ -362,21 +320,15 @@ static int launch_grouped(GmmtPlan *pl, const double *in, double *out, long n0, 
         return fail("grouped_mmt: paired groups are implemented for the GEMV path (few columns) only");
     static const bool no_mfma = getenv("DDH_SWSH_NO_MFMA") != nullptr;
     if (ncols <= GV_COLS) {
-        static const int rows_env = getenv("DDH_GEMV_ROWS") ? atoi(getenv("DDH_GEMV_ROWS")) : 8;
-        const int gv_rows = (rows_env == 4 || ncols > 4) ? 4 : 8;       // (8 columns x 8 rows x pairs would not fit the registers)
-        dim3 grid((unsigned)((max_rows + 4 * gv_rows - 1) / (4 * gv_rows)), (unsigned)pl->ngroups);
-#define DDH_GEMV(NC, R)                                                                                            \
+        dim3 grid((unsigned)((max_rows + 4 * GV_ROWS - 1) / (4 * GV_ROWS)), (unsigned)pl->ngroups);
+#define DDH_GEMV(NC)                                                                                               \
     {                                                                                                              \
         if (pl->paired)                                                                                            \
-            hipLaunchKernelGGL((grouped_gemv_kernel<FWD, NC, true, R>), grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols); \
+            hipLaunchKernelGGL((grouped_gemv_kernel<FWD, NC, true>), grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols); \
         else                                                                                                       \
-            hipLaunchKernelGGL((grouped_gemv_kernel<FWD, NC, false, R>), grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols); \
+            hipLaunchKernelGGL((grouped_gemv_kernel<FWD, NC, false>), grid, dim3(256), 0, st, pl->d_groups, mats, in, out, d, (int)ncols); \
     }
-        if (gv_rows == 8) {
-            if (ncols <= 2) DDH_GEMV(2, 8) else DDH_GEMV(4, 8)
-        } else {
-            if (ncols <= 2) DDH_GEMV(2, 4) else if (ncols <= 4) DDH_GEMV(4, 4) else DDH_GEMV(8, 4)
-        }
+        if (ncols <= 2) DDH_GEMV(2) else if (ncols <= 4) DDH_GEMV(4) else DDH_GEMV(8)
 #undef DDH_GEMV
     } else if (n3 >= 16 && !no_mfma) {
         const int xtiles = (int)((n3 + GM_N - 1) / GM_N);

@@ -40,7 +40,7 @@ for step in "$@"; do
     tests-fused) python -m pytest tests/test_gpu_wave_transforms.py tests/test_gpu_transforms.py -x -q -m gpu -k "fused" > $OUT/pytest_fused.txt 2>&1; tail -3 $OUT/pytest_fused.txt ;;
     bench-v1)   DDH_GW_V2=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cfl > $OUT/bench_v1.json 2> $OUT/bench_v1.err; bench_line $OUT/bench_v1.json ;;
     sphere)     python -m pytest tests/test_gpu_swsh.py tests/test_gpu_sphere.py tests/test_gpu_shell.py -x -q -m gpu > $OUT/pytest_sphere.txt 2>&1; tail -3 $OUT/pytest_sphere.txt
-                for envs in "DDH_GEMV_ROWS=8" "DDH_GEMV_ROWS=4"; do echo "$envs" | tee -a $OUT/sphere.txt; env $envs python tools/bench_configs.py sphere 2>&1 | grep -v "^\[" | tail -3 | tee -a $OUT/sphere.txt; done ;;
+                python tools/bench_configs.py sphere 2>&1 | grep -v "^\[" | tail -3 | tee -a $OUT/sphere.txt ;;
     configs)    python tools/bench_configs.py --json > $OUT/configs.json 2> $OUT/configs.err; tail -5 $OUT/configs.json ;;
     shares)     # per-rank shares of the strong-scaled problem on one GPU, sweep variants A/B (profiles/*_strong_scaling_shares.txt)
                 for sz in 256,512,256 128,512,256 64,512,256; do
