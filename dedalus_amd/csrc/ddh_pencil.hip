@@ -133,7 +133,6 @@ constexpr int PBW = 12;
 struct LuFactor {
     LuDev dev;
     size_t bytes = 0;
-    bool aw_zeroed = false;         // the band storage was zeroed and has only been written by on-the-fly factorizations since
     void *d_rowperm = nullptr, *d_colperm = nullptr, *d_raxes = nullptr, *d_caxes = nullptr;
     void *d_rcode = nullptr, *d_ccode = nullptr;
     // dense fallback
@@ -1019,39 +1018,6 @@ __device__ __forceinline__ void scatter_row(const PencilDev &P, const LuDev &L, 
     }
 }
 
-// The same walk over the terms of physical row r (logical interior row i < n) without touching the band storage: the
-// norm and the band check only (row == nullptr), or the row's entries accumulated into an LDS row of this lane
-// (row[w * 64], w = column - (i - kl): the layout of the factorization window) -- same terms, same order, same sums as
-// scatter_row, so that a row assembled this way equals the stored one bit for bit.
-template <bool REAL>
-__device__ __forceinline__ void walk_row(const PencilDev &P, const LuDev &L, const MatDev &A, double scale, int r, int i,
-                                         const int *__restrict__ colinv, const CellCtx &c, int s, double &anorm, bool &bad,
-                                         typename El<REAL>::T *row) {
-    typedef typename El<REAL>::T E;
-    if (scale == 0.0 || r >= A.nrows_out) return;
-    const int t1 = A.rowptr[r + 1];
-    for (int t = A.rowptr[r]; t < t1; ++t) {
-        const unsigned e = A.expo[t];
-        double f = term_factor(e, c) * scale;
-        if (s == 1 && (e & 1u)) f = -f;
-        if (f == 0.0) continue;
-        const double2 cf = A.coef[t];
-        const double2 v = make_double2(cf.x * f, cf.y * f);
-        const int cc = colinv[A.col[t]];
-        anorm = fmax(anorm, fabs(v.x) + fabs(v.y));
-        const int d = cc - i + L.kl;
-        if (d < 0 || cc - i > L.ku) {
-            bad = true;
-            continue;
-        }
-        if (row) {
-            E o = row[d * 64];
-            El<REAL>::add(o, v);
-            row[d * 64] = o;
-        }
-    }
-}
-
 template <bool REAL>
 __global__ void __launch_bounds__(64 * FR_NTMAX)
 factor_rows_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, const int *__restrict__ rowinv,
@@ -1244,11 +1210,7 @@ factor_rows_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b
 // ------------------------------------------------------------------------------------------------
 constexpr int FW_WMAX = 36;      // window columns kl + ku + 1 held per thread
 
-// OTF (round 5): the band rows are never materialised before the elimination -- a row is ASSEMBLED from the term lists
-// (walk_row into an LDS row of the lane) at the moment it enters the window, instead of being scattered into the band
-// storage by a first pass (read-modify-write of 8.2 GB that a memset had zeroed) and read back when it enters: the
-// factorization writes its 8.2 GB of factors and reads the term lists, nothing else.  Bit-identical factors.
-template <bool REAL, bool OTF = false>
+template <bool REAL>
 __global__ void __launch_bounds__(64 * FR_NTMAX)
 factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, const int *__restrict__ rowinv,
                      const int *__restrict__ colinv) {
@@ -1265,7 +1227,6 @@ factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double
     extern __shared__ double s_dyn_fw[];
     E *s_piv = (E *)s_dyn_fw;                         // [FW_WMAX][64] the pivot row of the step
     E *s_disp = s_piv + FW_WMAX * 64;                 // [FW_WMAX][64] the row an interchange displaces
-    E *s_new = s_disp + FW_WMAX * 64;                 // [FW_WMAX][64] OTF: the row being assembled (one thread per lane column)
     __shared__ double s_val[FR_NTMAX][64];
     __shared__ int s_flag[FR_NTMAX][64];
     double anorm = 0.0;
@@ -1273,33 +1234,10 @@ factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double
     if (g < L.GL) {
         for (int r = ty; r < N; r += NT) {
             const int i = rowinv[r];
-            if (OTF && i < n) {                        // interior rows: norm and band check only
-                walk_row<REAL>(P, L, M, a, r, i, colinv, c, s, anorm, bad, nullptr);
-                walk_row<REAL>(P, L, Lm, b, r, i, colinv, c, s, anorm, bad, nullptr);
-            } else {
-                scatter_row<REAL>(P, L, M, a, r, i, colinv, c, s, g, anorm, bad);
-                scatter_row<REAL>(P, L, Lm, b, r, i, colinv, c, s, g, anorm, bad);
-            }
+            scatter_row<REAL>(P, L, M, a, r, i, colinv, c, s, g, anorm, bad);
+            scatter_row<REAL>(P, L, Lm, b, r, i, colinv, c, s, g, anorm, bad);
         }
     }
-    // OTF: logical interior row `row` of this lane's system -> reg[w] = entry in column row - kl + ... (band entry w + shift)
-    auto assemble = [&](int row, int shift, E *reg_out) {
-        // band entry d of the row sits at s_new[d * 64 + tx]; reg_out[w] = band entry w + shift
-#pragma unroll
-        for (int w = 0; w < FW_WMAX; ++w) s_new[w * 64 + tx] = El<REAL>::zero();
-        if (g < L.GL) {
-            const int r = L.rowperm[row];
-            double an = 0.0;
-            bool bd = false;
-            walk_row<REAL>(P, L, M, a, r, row, colinv, c, s, an, bd, s_new + tx);
-            walk_row<REAL>(P, L, Lm, b, r, row, colinv, c, s, an, bd, s_new + tx);
-        }
-#pragma unroll
-        for (int w = 0; w < FW_WMAX; ++w) {
-            reg_out[w] = El<REAL>::zero();
-            if (w <= W && w + shift >= 0 && w + shift < FW_WMAX) reg_out[w] = s_new[(w + shift) * 64 + tx];
-        }
-    };
     s_val[ty][tx] = anorm;
     s_flag[ty][tx] = bad ? 1 : 0;
     __syncthreads();
@@ -1330,17 +1268,10 @@ factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double
         reg[w] = El<REAL>::zero();
         if (w <= W) {
             if (interior) {
-                if (!OTF && my_row < n) reg[w] = Aw[lu_aw(L, g, my_row, kl - my_row + w)];     // column w of row r <= kl
+                if (my_row < n) reg[w] = Aw[lu_aw(L, g, my_row, kl - my_row + w)];     // column w of row r <= kl
             } else if (rb < nb && w < N) {
                 reg[w] = Ab[lu_ab(L, g, w, rb)];
             }
-        }
-    }
-    if (OTF) {
-        // rows 0 .. kl, one after the other through the one assembly row (column w of row r is its band entry kl - r + w)
-        for (int t = 0; t <= kl; ++t) {
-            if (ty == t && t < n) assemble(t, kl - t, reg);
-            __syncthreads();
         }
     }
     for (int j = 0; j < n; ++j) {
@@ -1413,15 +1344,7 @@ factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double
         // ---- advance the window
         if (interior && live && i == 0) {
             my_row = j + kl + 1;                       // the row entering the window takes this thread
-            if (OTF) {
-                // its first column is j + 1 = my_row - kl: band entry 0
-                if (my_row < n) {
-                    assemble(my_row, 0, reg);
-                } else {
-#pragma unroll
-                    for (int w = 0; w < FW_WMAX; ++w) reg[w] = El<REAL>::zero();
-                }
-            } else {
+            {
                 const E *rowp = Aw + lu_aw(L, g, my_row < n ? my_row : 0, 0);         // one base, entry offsets added per load
 #pragma unroll
                 for (int w = 0; w < FW_WMAX; ++w) {
@@ -3146,19 +3069,7 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
             }
     }
     LuDev &d = lu->dev;
-    // rows of an elimination step spread over the workgroup (factor_rows_kernel) when kl + 1 + nb row threads fit one;
-    // DDH_FACTOR_ROWS=0: one thread per system (factor_kernel), 1: row-parallel, 2: register window over a materialised
-    // band, 3 (default): register window with the rows assembled on the fly
-    static const bool rows_off = getenv("DDH_FACTOR_ROWS") && atoi(getenv("DDH_FACTOR_ROWS")) == 0;
-    static const int rows_mode = getenv("DDH_FACTOR_ROWS") ? atoi(getenv("DDH_FACTOR_ROWS")) : 3;
-    const int NT = d.kl + 1 + d.nb;
-    const bool window = !rows_off && rows_mode >= 2 && real && NT <= FR_NTMAX && d.GL >= 64 && d.W + 1 <= FW_WMAX;
-    const bool otf = window && rows_mode >= 3;
-    // The band storage is zeroed before the terms are scattered into it.  The on-the-fly variant never reads what it has
-    // not written in this factorization -- except the padding and the slots no factorization ever writes, which must be
-    // zero: once, when the storage is new (the written slots are the same in every factorization of a structure).
-    if (!(otf && reuse && lu->aw_zeroed)) DDH_HIP(hipMemsetAsync(d.Aw, 0, esz * (size_t)d.rows_aw * d.BW * (size_t)d.nblk * 64, s));
-    lu->aw_zeroed = otf;
+    DDH_HIP(hipMemsetAsync(d.Aw, 0, esz * (size_t)d.rows_aw * d.BW * (size_t)d.nblk * 64, s));
     DDH_HIP(hipMemsetAsync(d.Ab, 0, esz * (size_t)N * (nb > 0 ? nb : 1) * (size_t)d.nblk * 64, s));
     // inverse permutations (physical -> logical) on the device
     std::vector<int> rowinv(N), colinv(N);
@@ -3171,15 +3082,16 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
     if (!st) st = upload_vec(&d_colinv, colinv.data(), (size_t)N);
     if (st) { if (!reuse) free_lu(lu); return st; }
     const unsigned blocks = (unsigned)((GL + 63) / 64);
-    if (window) {
+    // rows of an elimination step spread over the workgroup (factor_rows_kernel) when kl + 1 + nb row threads fit one;
+    // DDH_FACTOR_ROWS=0: one thread per system (factor_kernel)
+    static const bool rows_off = getenv("DDH_FACTOR_ROWS") && atoi(getenv("DDH_FACTOR_ROWS")) == 0;
+    const int NT = d.kl + 1 + d.nb;
+    static const int rows_mode = getenv("DDH_FACTOR_ROWS") ? atoi(getenv("DDH_FACTOR_ROWS")) : 2;   // 2: register window
+    if (!rows_off && rows_mode >= 2 && real && NT <= FR_NTMAX && GL >= 64 && d.W + 1 <= FW_WMAX) {
         // (real factors: 72 of the 128 registers a 14-wave workgroup allows; the complex window would spill)
-        const size_t lds = 3 * (size_t)FW_WMAX * 64 * esz;
-        if (otf)
-            hipLaunchKernelGGL((factor_window_kernel<true, true>), dim3(blocks), dim3(64, NT), lds, s, P, d, pp->mats[matM_id]->dev,
-                               pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
-        else
-            hipLaunchKernelGGL((factor_window_kernel<true, false>), dim3(blocks), dim3(64, NT), lds, s, P, d, pp->mats[matM_id]->dev,
-                               pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
+        const size_t lds = 2 * (size_t)FW_WMAX * 64 * esz;
+        hipLaunchKernelGGL(factor_window_kernel<true>, dim3(blocks), dim3(64, NT), lds, s, P, d, pp->mats[matM_id]->dev,
+                           pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
     } else if (!rows_off && NT <= FR_NTMAX && GL >= 64) {
         if (real)
             hipLaunchKernelGGL(factor_rows_kernel<true>, dim3(blocks), dim3(64, NT), 0, s, P, d, pp->mats[matM_id]->dev,
