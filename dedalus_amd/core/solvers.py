@@ -997,7 +997,114 @@ class SolverBase:
         if not hasattr(self, "_lu_params"):
             self._lu_params = {}
         self._lu_params[lu] = (float(a), float(b))
+        self._block_inverses(lu, a, b)
         return lu
+
+    # ---- few systems: explicit inverses of the diagonal blocks ----------------------------------------------------------
+    # A 2-D problem has a few hundred pencils of ~1000 rows: a sweep is a chain of n / nblocks dependent rows that so few
+    # systems cannot hide (2-D Rayleigh-Benard 512 x 256: 2 x 0.39 ms of a 1.05 ms step at 0.02 of the HBM rate).  With
+    # real-graded factors and the band split into independent diagonal blocks the inverse of a block is small (515^2
+    # doubles = 2 MB; 1.1 GB for 256 pencils x 2 blocks) and applying it is a streaming GEMV (blockinv_solve_kernel).  The
+    # inverses are formed on the device like the sphere's (core/sphere.py): the numeric band LU of csrc/ddh_ellband.hip on
+    # the TRANSPOSED blocks, one unit solve per lane, so that slot s holds row s of the inverse contiguously -- the layout
+    # the GEMV streams.  Same systems as the reference's per-subproblem LU (libraries/matsolvers.py:126-149).
+    def _block_inverse_plan(self, any_executor=False):
+        """any_executor: the host analysis alone (tests)"""
+        if getattr(self, "_binv", None) is not None:
+            return self._binv
+        self._binv = False
+        rg, n = self.real_grading, self.n_interior
+        if os.environ.get("DDH_BLOCK_INVERSE", "1") == "0" or self.nf != 1 or rg is None or getattr(self.dist, "size", 1) > 1 or n < 128:
+            return False
+        if not any_executor and (getattr(self.ex, "name", "") != "hip" or not hasattr(self.pack, "set_block_inverse")):
+            return False
+        ns = self.n_blocks if (self.n_blocks > 1 and len(set(self.block_sizes)) == 1 and os.environ.get("DDH_SPLIT_THREADS", "1") != "0") else 1
+        nh = n // ns
+        ncells = self.nx // 2
+        nb = self.R - n
+        # border rows / columns (gauge conditions) must exist for the k = 0 pencil only: that one is flagged (dense path)
+        if nb and (np.any(self.row_axes[self.row_perm[n:]] & 1) or np.any(self.col_axes[self.col_perm[n:]] & 1)):
+            return False
+        ng = ncells * ns
+        if ns * nh != n or nh > 1024 or ng * nh * nh * 8 > 2.5e9 or ng * (nh + 112) * (nh + 63) * 8 > 3e9:
+            return False
+        rinv, cinv = np.empty(self.R, dtype=np.int64), np.empty(self.R, dtype=np.int64)
+        rinv[self.row_perm] = np.arange(self.R)
+        cinv[self.col_perm] = np.arange(self.R)
+        kx = np.asarray(self.pack.kx, dtype=np.float64)[:ncells]
+        gmx = np.arange(ncells) + self.dist._mx_offset
+        sel = []
+        for mid in (rg["matM"], rg["matL"]):
+            tl = self.pack.matrices[mid]
+            i, j = rinv[tl.row], cinv[tl.col]
+            ok = (i < n) & (j < n)
+            if np.any(ok & (i // nh != j // nh)):
+                return False                                  # (an entry couples two blocks: not block diagonal after all)
+            sel.append((tl, i, j, ok))
+        kl_b = max(int((i[ok] - j[ok]).max()) if ok.any() else 0 for (_, i, j, ok) in sel)
+        ku_b = max(int((j[ok] - i[ok]).max()) if ok.any() else 0 for (_, i, j, ok) in sel)
+        klT, kuT = max(ku_b, 0), max(kl_b, 0)                 # the TRANSPOSED blocks
+        if klT > 35 or klT + kuT > 96:
+            return False
+        W = klT + kuT + 1
+        bands = []
+        for (tl, i, j, ok) in sel:
+            B = np.zeros((ng, nh, W))
+            t = np.flatnonzero(ok)
+            val = tl.coef[t].real[None, :] * kx[:, None] ** tl.ex[t].astype(float)[None, :]       # [cell][term]
+            val = np.where((tl.dx[t] != 0)[None, :] & (gmx != 0)[:, None], 0.0, val)
+            blk, ii, jj = i[t] // nh, i[t] % nh, j[t] % nh
+            g = np.arange(ncells)[:, None] * ns + blk[None, :]
+            np.add.at(B, (g, np.broadcast_to(jj, g.shape), np.broadcast_to(ii - jj + klT, g.shape)), val)   # B^T[jj][ii]
+            bands.append(B)
+        plan = type("BlockBandPlan", (), {})()
+        plan.nl, plan.nmax, plan.kl, plan.ku, plan.mp, plan.nbc = ng, nh, klT, kuT, 0, 0
+        plan.n = np.full(ng, nh, dtype=np.int32)
+        plan.nbc_of = np.zeros(ng, dtype=np.int32)
+        plan.T = np.zeros((ng, 1, 1))
+        plan.P = np.zeros((ng, nh, 1))
+        plan.MB, plan.LB = bands
+        plan.row_index = plan.col_index = None
+        self._binv = dict(plan=plan, ns=ns, nh=nh, ng=ng, ncells=ncells, dev=None, rhs=None, x={}, n_set=None)
+        return self._binv
+
+    def _block_inverses(self, lu, a, b):
+        bi = self._block_inverse_plan()
+        if not bi:
+            return
+        ex, plan, ns, nh, ng = self.ex, bi["plan"], bi["ns"], bi["nh"], bi["ng"]
+        info = self.pack.lu_info(lu)                    # (the library's own view of the blocks must be the one planned for)
+        if info["nsplit"] != ns or info["rows_per_block"] != nh or not info["real"] or info["pair"]:
+            self._binv = False
+            return
+        flagged = sorted(getattr(self.pack, "flagged", {}).get(lu, []))
+        if bi["dev"] is None or bi["n_set"] != flagged:
+            # (the flagged pencils' blocks are singular: their groups are skipped -- a plan per set of flagged cells)
+            plan.n = np.full(ng, nh, dtype=np.int32)
+            for cell in flagged:
+                plan.n[cell * ns:(cell + 1) * ns] = 0
+            rowoff = np.broadcast_to(np.arange(nh, dtype=np.int64)[None, :] * nh, (ng, nh))
+            coloff = np.arange(ng, dtype=np.int64)[:, None] * (nh * nh) + np.arange(nh, dtype=np.int64)[None, :] * nh
+            try:
+                bi["dev"] = ex.make_ell_band(plan, 1, nh, ng, nh, [nh] * ng, offsets=(rowoff, coloff, 1))
+            except Exception as e:                       # (band wider than the compiled windows, memory): keep the sweeps
+                logger.info("block inverses not available (%s): the sweeps stay" % (e,))
+                self._binv = False
+                return
+            bi["rhs"] = ex.from_host(np.eye(nh))
+            bi["n_set"] = flagged
+            bi["x"] = {}
+            logger.info("LHS of %d pencils: explicit inverses of %d x %d diagonal blocks (%d rows), %.2f GB per factorization"
+                        % (bi["ncells"], ng, ns, nh, ng * nh * nh * 8 / 1e9))
+        if lu not in bi["x"]:
+            if len(bi["x"]) >= 2:                        # (schemes with many distinct implicit coefficients: keep the sweeps)
+                self.pack.set_block_inverse(lu, None)
+                return
+            bi["x"][lu] = (len(bi["x"]), ex.zeros((ng, nh, nh)))
+        idx, x = bi["x"][lu]
+        bi["dev"].factor(a, b, index=idx)
+        bi["dev"].solve(idx, bi["rhs"], x)
+        self.pack.set_block_inverse(lu, x)
 
 
 def _two_colour(n, row, col, label):

@@ -144,6 +144,9 @@ struct LuFactor {
     std::vector<int> colperm_h;             // logical -> physical columns (host copy)
     std::vector<unsigned char> ccode_h;     // grading codes of the logical columns (real mode)
     void *d_rhs_tmp = nullptr;              // materialised right-hand side for the cooperative forward sweep
+    // few systems, one Fourier axis: explicit inverses of the independent diagonal blocks, applied by blockinv_solve_kernel
+    // instead of the sweeps (ddh_pencil_set_block_inverse; caller-owned memory)
+    const double *d_binv = nullptr;
     void *d_pband = nullptr;                // [n][PBW] band of the recombination, see LuDev::pband
     void *d_vcell = nullptr, *d_vslot = nullptr, *d_rowperm2 = nullptr, *d_colperm2 = nullptr;   // partner pencils
     std::vector<long> slot_cells_h;         // [2 * GL]: the cell of a slot and its partner (-1 = none)
@@ -2378,6 +2381,65 @@ static int upload_vec(void **dptr, const T *src, size_t count) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Few systems (2-D problems: a few hundred pencils of ~1000 rows): a sweep is a chain of n / nblocks dependent rows behind
+// too few wavefronts to hide anything (2-D Rayleigh-Benard 512 x 256: 0.39 ms per solve, 0.02 of the HBM rate).  With
+// real-graded factors and the band split into independent diagonal blocks, the explicit inverse of a block is small
+// (nh^2 doubles: 2 MB at nh = 515) and its application is a streaming GEMV: one workgroup per (pencil, block), thread i
+// forms y_i = sum_k Binv[i][k] r_k from the TRANSPOSED inverse (row k contiguous in i: coalesced, the right-hand side
+// broadcast from LDS), for the real and the imaginary part of the graded right-hand side at once.  The inverses come from
+// unit solves of the band LU (csrc/ddh_ellband.hip), as for the sphere.  Same linear systems as the reference's
+// per-subproblem sparse LU (libraries/matsolvers.py:126-149); flagged pencils keep their dense path.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+blockinv_solve_kernel(PencilDev P, LuDev L, const RhsSrc rhs, const double *__restrict__ binv, double *__restrict__ yout) {
+    extern __shared__ double2 s_rb[];                        // the graded right-hand side of the block
+    const int nh = L.nh, ns = L.nsplit;
+    const long cell = blockIdx.x / ns;
+    const int blk = (int)(blockIdx.x - cell * ns);
+    if (L.flag[cell]) return;                                // (real factors: one stored factorization per cell)
+    const CellCtx c = cell_ctx(P, cell);
+    const long plane = P.nx * P.ny;
+    const int row0 = blk * nh, tid = threadIdx.x, NT = blockDim.x;
+    for (int i = tid; i < nh; i += NT) {
+        const int phys = L.rowperm[row0 + i];
+        double2 v = make_double2(0.0, 0.0);
+        if (!(rhs.zrow && rhs.zrow[phys])) v = load_sys<1>(rhs, plane, phys, P, c, 0);
+        if (L.row_code[row0 + i] & 1) v = make_double2(v.y, -v.x);
+        s_rb[i] = v;
+    }
+    __syncthreads();
+    const double *B = binv + (size_t)blockIdx.x * nh * nh;
+    for (int i = tid; i < nh; i += NT) {
+        double2 acc = make_double2(0.0, 0.0);
+        const double *bi = B + i;
+        int k = 0;
+        for (; k + 8 <= nh; k += 8) {
+            double b[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) b[q] = bi[(size_t)(k + q) * nh];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double2 r = s_rb[k + q];
+                acc.x += b[q] * r.x;
+                acc.y += b[q] * r.y;
+            }
+        }
+        for (; k < nh; ++k) {
+            const double b = bi[(size_t)k * nh];
+            const double2 r = s_rb[k];
+            acc.x += b * r.x;
+            acc.y += b * r.y;
+        }
+        double2 v = acc;
+        if (L.col_code[row0 + i] & 1) v = make_double2(-v.y, v.x);
+        store_sys<1>(yout, plane, L.colperm[row0 + i], P, c, 0, v);
+    }
+    // border unknowns exist for flagged pencils only (checked by the host before it hands the inverses over): zero here
+    if (blk == 0)
+        for (int r = tid; r < L.nb; r += NT) store_sys<1>(yout, plane, L.colperm[L.n + r], P, c, 0, make_double2(0.0, 0.0));
+}
+
 // dense fallback for the flagged pencils (after either sweep variant)
 template <int NF>
 static int finish_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double *x, hipStream_t s, int apply_p) {
@@ -3226,6 +3288,20 @@ int ddh_pencil_set_dense_inverse_dev(ddh_handle pack, int lu_id, int sys, const 
     return 0;
 }
 
+int ddh_pencil_set_block_inverse(ddh_handle pack, int lu_id, const double *binv_d) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (lu_id < 0 || lu_id >= (int)pp->lus.size()) return fail("pencil_set_block_inverse: bad LU id");
+    LuFactor *lu = pp->lus[lu_id];
+    if (binv_d) {
+        const LuDev &d = lu->dev;
+        if (pp->dev.nf != 1 || !d.real || d.pair || d.nsplit < 1 || d.n != d.nsplit * d.nh || d.nh > 8192)
+            return fail("pencil_set_block_inverse: one Fourier axis, real-graded factors, equal diagonal blocks");
+    }
+    lu->d_binv = binv_d;
+    return 0;
+}
+
 int ddh_pencil_solve(ddh_handle pack, int lu_id, const double *rhs, double *x, void *stream) {
     PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
     if (!pp) return -1;
@@ -3366,7 +3442,14 @@ static int solve_recombined_impl(ddh_handle pack, int lu_id, int nterms, const d
         }
     }
     r.skip = nullptr;       // (the unfused path recombines from `work` with a mat-vec: every row of it must be written)
-    if (pp->dev.nf == 2) st = launch_solve<2>(pp, lu, r, work, s);
+    if (pp->dev.nf == 1 && lu->d_binv && lu->dev.real && lu->dev.n == lu->dev.nsplit * lu->dev.nh) {
+        const LuDev &d = lu->dev;
+        const unsigned nt = (unsigned)std::min(1024, (d.nh + 63) / 64 * 64);
+        hipLaunchKernelGGL(blockinv_solve_kernel, dim3((unsigned)(pp->dev.ncells * d.nsplit)), dim3(nt), (size_t)d.nh * sizeof(double2),
+                           s, pp->dev, d, r, lu->d_binv, work);
+        DDH_HIP(hipGetLastError());
+        st = finish_solve<1>(pp, lu, r, work, s, 0);
+    } else if (pp->dev.nf == 2) st = launch_solve<2>(pp, lu, r, work, s);
     else if (pp->dev.nf == 1) st = launch_solve<1>(pp, lu, r, work, s);
     else st = launch_solve<0>(pp, lu, r, work, s);
     if (st) return st;

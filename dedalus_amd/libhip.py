@@ -123,6 +123,7 @@ SIGNATURES = {
     "ddh_pencil_flagged": [_h, _i, _ip, C.POINTER(_l), _i],
     "ddh_pencil_set_dense_inverse": [_h, _i, _dp],
     "ddh_pencil_set_dense_inverse_dev": [_h, _i, _i, _vp, _i, _vp],
+    "ddh_pencil_set_block_inverse": [_h, _i, _vp],
     "ddh_pencil_lu_bytes": [_h, _i, C.POINTER(C.c_size_t)],
     "ddh_pencil_lu_info": [_h, _i, _ip],
     "ddh_pencil_lu_row_widths": [_h, _i, _ip],

@@ -161,6 +161,8 @@ class PencilPack:
         libhip.call("ddh_pencil_flagged", self.handle, lu_id, C.byref(count),
                     cells.ctypes.data_as(C.POINTER(C.c_long)), cells.size)
         nflag = count.value
+        self.flagged = {} if not hasattr(self, "flagged") else self.flagged
+        self.flagged[lu_id] = [int(c) for c in cells[:min(nflag, cells.size)]]
         if nflag > cells.size or nflag * self.S * self.nrows ** 2 * 16 > 8e9:
             raise libhip.DdhError("%d pencils have a singular band block: problem structure unsupported by the "
                                   "bordered-band solver" % nflag)
@@ -259,6 +261,11 @@ class PencilPack:
                 libhip.call("ddh_pencil_set_dense_inverse_dev", self.handle, lu_id, int(t),
                             C.c_void_p(flat.data_ptr() + off * 8), int(cx), self.dev.stream)
             off += n * n * (2 if cx else 1)
+
+    def set_block_inverse(self, lu_id, binv):
+        """explicit transposed inverses [cell][block][k][i] of the diagonal blocks (device array, kept alive by the caller),
+        or None: ddh_pencil_solve_recombined* then applies them instead of running the sweeps"""
+        libhip.call("ddh_pencil_set_block_inverse", self.handle, int(lu_id), ptr(binv) if binv is not None else None)
 
     def solve(self, lu_id, rhs, x):
         t = self._timer()

@@ -454,6 +454,13 @@ int ddh_pencil_set_dense_inverse(ddh_handle pack, int lu_id, const double *inv_h
 /* the same from device memory, one system (index f * S + s) at a time, real or interleaved complex N x N row-major:
  * formed by ddh_dense_inverse_compute, so a timestep change costs no host linear algebra for flagged pencils either */
 int ddh_pencil_set_dense_inverse_dev(ddh_handle pack, int lu_id, int sys, const double *inv_d, int is_complex, void *stream);
+/* Few systems with one Fourier axis (2-D problems): explicit inverses of the independent diagonal blocks of a real-graded
+ * factorization (ddh_pencil_set_row_blocks; nblocks = 1: the whole band block), TRANSPOSED -- binv_d [cell][block][k][i] =
+ * (block^-1)[i][k], caller-owned device memory, formed e.g. by unit solves of ddh_ellband_* -- make ddh_pencil_solve_recombined*
+ * apply them as streaming GEMVs instead of running the sweeps (a chain of n / nblocks dependent rows that a few hundred
+ * systems cannot hide).  The solutions are those of the same systems the reference factors per subproblem
+ * (libraries/matsolvers.py:126-149).  Border unknowns must exist for flagged pencils only.  binv_d = NULL: back to the sweeps. */
+int ddh_pencil_set_block_inverse(ddh_handle pack, int lu_id, const double *binv_d);
 int ddh_pencil_lu_bytes(ddh_handle pack, int lu_id, size_t *bytes);
 /* Shape of a factorization and the sweep kernels ddh_pencil_solve* will launch for it (diagnostics, byte accounting,
  * tests): info_h[12] = { n (band rows), nb (border), kl, ku, W = kl + ku, BW (stored entries per band row), nsplit

@@ -431,3 +431,26 @@ def test_x_blocked_stage_layout_changes_addresses_not_values(monkeypatch):
     for k in a:
         assert np.isfinite(a[k]).all(), k
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("ts", ["RK222", "SBDF2"])
+def test_block_inverses_of_few_pencils_match_the_sweeps(ts, monkeypatch):
+    """2-D problems (a few hundred pencils) apply explicit inverses of the diagonal blocks instead of sweeping them
+    (SolverBase._block_inverses, blockinv_solve_kernel; inverses from unit solves of the band LU): same end state as the
+    sweeps (DDH_BLOCK_INVERSE=0) through timestep changes, and the reference's own end state."""
+    import dedalus_amd.public as d3
+    seq = [1e-3] * 5 + [2e-3] * 3 + [1.5e-3] * 3
+    monkeypatch.setenv("DDH_BLOCK_INVERSE", "0")
+    a, fa = problems.rayleigh_benard_2d(d3, Nx=128, Nz=64, timestepper=ts)
+    assert not a._block_inverse_plan()
+    monkeypatch.delenv("DDH_BLOCK_INVERSE")
+    b, fb = problems.rayleigh_benard_2d(d3, Nx=128, Nz=64, timestepper=ts)
+    for dt in seq:
+        a.step(dt)
+        b.step(dt)
+    bi = b._block_inverse_plan()
+    assert bi and bi["x"], "the block-inverse path must be active by default for this size"
+    for k, tol in (("b", 1e-10), ("u", 1e-9), ("p", 1e-8)):
+        x, y = np.array(fb[k]["c"]), np.array(fa[k]["c"])
+        assert np.isfinite(x).all()
+        assert rel(x, y) < tol, (k, rel(x, y))

@@ -93,3 +93,39 @@ def test_bordered_band_inverse_of_the_mean_mode_pencil():
         inv[j0, n] = 1.0 / d
         ref = np.linalg.inv(A)
         assert np.abs(inv - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
+def test_block_inverse_plan_holds_the_transposed_diagonal_blocks():
+    """Host analysis of the few-system path (SolverBase._block_inverse_plan): for 2-D Rayleigh-Benard the band arrays
+    handed to the numeric band LU are, per (pencil, parity block), the TRANSPOSE of that diagonal block of the graded real
+    matrix a M + b L in the solver's permuted order -- so that unit solve s yields row s of the block's inverse."""
+    import problems
+    import dedalus_amd.public as d3
+    from dedalus_amd.pencilpack import TermList
+    from oracle.np_executor import NumpyExecutor
+    s, _ = problems.rayleigh_benard_2d(d3, Nx=16, Nz=64, dist_kw=dict(executor=NumpyExecutor()))
+    # (the oracle's pack keeps term lists under another name)
+    s.pack.matrices = [TermList(t.nrows, t.ncols, t.row, t.col, t.coef, t.ex, t.ey, t.dx, t.dy) for t in s.pack.mats]
+    bi = s._block_inverse_plan(any_executor=True)
+    assert bi, "2-D Rayleigh-Benard must be eligible"
+    plan, ns, nh = bi["plan"], bi["ns"], bi["nh"]
+    assert ns == 2 and ns * nh == s.n_interior and plan.nl == (s.nx // 2) * ns
+    rg = s.real_grading
+    a, b = 1.0, 0.5e-3
+    for cell in (1, 3, 7):
+        kx = s.pack.kx[cell]
+        A = (a * s.pack.matrices[rg["matM"]].dense(kx, 0.0, cell, 0, 1) + b * s.pack.matrices[rg["matL"]].dense(kx, 0.0, cell, 0, 1))
+        assert np.abs(A.imag).max() == 0.0
+        A = A.real[np.ix_(s.row_perm, s.col_perm)][:s.n_interior, :s.n_interior]
+        for blk in range(ns):
+            Bt = A[blk * nh:(blk + 1) * nh, blk * nh:(blk + 1) * nh].T
+            band = a * plan.MB[cell * ns + blk] + b * plan.LB[cell * ns + blk]
+            dense = np.zeros((nh, nh))
+            for i in range(nh):
+                for d in range(plan.kl + plan.ku + 1):
+                    j = i - plan.kl + d
+                    if 0 <= j < nh:
+                        dense[i, j] = band[i, d]
+            assert np.abs(dense - Bt).max() <= 1e-14 * np.abs(Bt).max()
+        # nothing couples the two blocks
+        assert np.abs(A[:nh, nh:]).max() == 0.0 and np.abs(A[nh:, :nh]).max() == 0.0

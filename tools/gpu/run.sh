@@ -41,6 +41,9 @@ for step in "$@"; do
                 python tools/gpu/fused_stress.py check /tmp/fused_ref.pt 2>&1 | tail -3 | tee -a $OUT/fused_stress.txt
                 STRESS_REPS=40 FUSED_ZDIV=1 python tools/gpu/fused_stress.py check /tmp/fused_ref.pt 2>&1 | tail -1 | tee -a $OUT/fused_stress.txt ;;
     refactor)   python tools/gpu/refactor_time.py 2>&1 | tail -1 | tee -a $OUT/refactor.txt ;;
+    r2)         python -m pytest tests/test_gpu_ivp.py tests/test_gpu_baseline_sizes.py tests/test_gpu_examples.py -x -q -m gpu > $OUT/pytest_r2.txt 2>&1; tail -3 $OUT/pytest_r2.txt
+                python tools/bench_configs.py r2 2>&1 | grep -v "^\[" | tee $OUT/r2.txt
+                DDH_BLOCK_INVERSE=0 python tools/bench_configs.py r2 2>&1 | grep -v "^\[" | head -2 | tee -a $OUT/r2.txt ;;
     tests-fused) python -m pytest tests/test_gpu_wave_transforms.py tests/test_gpu_transforms.py -x -q -m gpu -k "fused" > $OUT/pytest_fused.txt 2>&1; tail -3 $OUT/pytest_fused.txt ;;
     bench-v1)   DDH_GW_V2=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cfl > $OUT/bench_v1.json 2> $OUT/bench_v1.err; bench_line $OUT/bench_v1.json ;;
     sphere)     python -m pytest tests/test_gpu_swsh.py tests/test_gpu_sphere.py tests/test_gpu_shell.py -x -q -m gpu > $OUT/pytest_sphere.txt 2>&1; tail -3 $OUT/pytest_sphere.txt
