@@ -1102,7 +1102,14 @@ class SolverBase:
                 return
             bi["x"][lu] = (len(bi["x"]), ex.zeros((ng, nh, nh)))
         idx, x = bi["x"][lu]
-        bi["dev"].factor(a, b, index=idx)
+        try:
+            bi["dev"].factor(a, b, index=idx)
+        except Exception as e:                           # (a zero pivot in a block the pencil LU handled: keep the sweeps)
+            logger.warning("block inverses switched off (%s)" % (e,))
+            for k in bi["x"]:
+                self.pack.set_block_inverse(k, None)
+            self._binv = False
+            return
         bi["dev"].solve(idx, bi["rhs"], x)
         self.pack.set_block_inverse(lu, x)
 
