@@ -1014,6 +1014,8 @@ class SolverBase:
             return self._binv
         self._binv = False
         rg, n = self.real_grading, self.n_interior
+        if not getattr(self, "allow_block_inverse", False):      # (initial-value solvers: many solves per factorization)
+            return False
         if os.environ.get("DDH_BLOCK_INVERSE", "1") == "0" or self.nf != 1 or rg is None or getattr(self.dist, "size", 1) > 1 or n < 128:
             return False
         if not any_executor and (getattr(self.ex, "name", "") != "hip" or not hasattr(self.pack, "set_block_inverse")):
@@ -1228,6 +1230,7 @@ class InitialValueSolver(IVPLifecycle, SolverBase):
         self._init_lifecycle(enforce_real_cadence, warmup_iterations)
         if isinstance(timestepper, str):
             timestepper = ts_mod.schemes[timestepper]
+        self.allow_block_inverse = True
         self.timestepper = timestepper(self)
         self.setup_time = time.time() - t0
         self.total_modes = self.R * self.nx * self.ny

@@ -106,6 +106,7 @@ def test_block_inverse_plan_holds_the_transposed_diagonal_blocks():
     s, _ = problems.rayleigh_benard_2d(d3, Nx=16, Nz=64, dist_kw=dict(executor=NumpyExecutor()))
     # (the oracle's pack keeps term lists under another name)
     s.pack.matrices = [TermList(t.nrows, t.ncols, t.row, t.col, t.coef, t.ex, t.ey, t.dx, t.dy) for t in s.pack.mats]
+    assert s.allow_block_inverse
     bi = s._block_inverse_plan(any_executor=True)
     assert bi, "2-D Rayleigh-Benard must be eligible"
     plan, ns, nh = bi["plan"], bi["ns"], bi["nh"]
