@@ -266,6 +266,7 @@ class PencilPack:
         """explicit transposed inverses [cell][block][k][i] of the diagonal blocks (device array, kept alive by the caller),
         or None: ddh_pencil_solve_recombined* then applies them instead of running the sweeps"""
         libhip.call("ddh_pencil_set_block_inverse", self.handle, int(lu_id), ptr(binv) if binv is not None else None)
+        self.__dict__.setdefault("_binv_bytes", {})[int(lu_id)] = int(binv.numel()) * 8 if binv is not None else 0
 
     def solve(self, lu_id, rhs, x):
         t = self._timer()
@@ -304,6 +305,9 @@ class PencilPack:
             read = 1.0 - (zero_rows[1] if (zero_rows is not None and info["forward"] == "lean") else 0.0)
             wrote = 1.0 - (skip_rows[1] if (skip_rows is not None and info["backward_lanes"] == 0 and info["real"]) else 0.0)
             nb = self.lu_bytes(lu_id) + (sum(v.numel() for v in xs) * read + x.numel() * wrote) * 8
+            binv = getattr(self, "_binv_bytes", {}).get(lu_id)
+            if binv:                            # explicit block inverses: they are what the solve streams, not the factors
+                nb = binv + (sum(v.numel() for v in xs) + 3 * x.numel()) * 8      # (+ work written, read by the P mat-vec, x written)
             return t.run("pencil_solve", nb, self._solve_recombined, lu_id, xs, alphas, p_mat_id, work, x, zero_rows,
                          skip_rows, tiled)
         return self._solve_recombined(lu_id, xs, alphas, p_mat_id, work, x, zero_rows, skip_rows, tiled)
