@@ -44,6 +44,7 @@ for step in "$@"; do
     r2)         python -m pytest tests/test_gpu_ivp.py tests/test_gpu_baseline_sizes.py tests/test_gpu_examples.py -x -q -m gpu > $OUT/pytest_r2.txt 2>&1; tail -3 $OUT/pytest_r2.txt
                 python tools/bench_configs.py r2 2>&1 | grep -v "^\[" | tee $OUT/r2.txt
                 DDH_BLOCK_INVERSE=0 python tools/bench_configs.py r2 2>&1 | grep -v "^\[" | head -2 | tee -a $OUT/r2.txt ;;
+    shell-sweep) for envs in "X=0" "DDH_FFT_B=4" "DDH_FFT_B=8" "DDH_FFT_B=16" "DDH_FFT_OCC4=1" "DDH_FFT_B=8 DDH_FFT_OCC4=1"; do echo "$envs" | tee -a $OUT/shell_sweep.txt; env $envs python tools/bench_configs.py shell 2>&1 | grep "steps/s" | head -1 | tee -a $OUT/shell_sweep.txt; done ;;
     tests-fused) python -m pytest tests/test_gpu_wave_transforms.py tests/test_gpu_transforms.py -x -q -m gpu -k "fused" > $OUT/pytest_fused.txt 2>&1; tail -3 $OUT/pytest_fused.txt ;;
     bench-v1)   DDH_GW_V2=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cfl > $OUT/bench_v1.json 2> $OUT/bench_v1.err; bench_line $OUT/bench_v1.json ;;
     sphere)     python -m pytest tests/test_gpu_swsh.py tests/test_gpu_sphere.py tests/test_gpu_shell.py -x -q -m gpu > $OUT/pytest_sphere.txt 2>&1; tail -3 $OUT/pytest_sphere.txt
