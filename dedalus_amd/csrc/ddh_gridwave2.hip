@@ -149,7 +149,7 @@ gridwave2_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
     const long line0 = (long)blockIdx.x * WAVES + wave, lstride = (long)gridDim.x * WAVES;
     long pf_line = line0;
     int pf_l = 0, cur_buf = 0;
-    bool pf_newer = false, st_pending = false;
+    bool pf_newer = false;
     auto prefetch = [&](int buf) -> bool {
         const bool live = pf_line < nlines;
         if (live) issue_loads_dma<NT>(st + buf * STGB, s_src[pf_l] + pf_line * (long)M, lane, K);
@@ -178,11 +178,12 @@ gridwave2_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
         const double ds = s_dscale[l];
         if constexpr (DMA) {
             // The loads of this operand were issued two transforms ago, those of the next one a transform ago: wait for
-            // the older set only.  Stores retire out of order with loads (one counter): after a forward transform, and when
-            // no newer set was issued (the last operand of the wave), wait for everything.
-            if (pf_newer && !st_pending) wait_older_loads<NT>();
+            // the older set only -- "at most NT memory operations outstanding".  That is enough whatever the stores of a
+            // forward transform in between do (they share the counter and retire out of order with loads): loads retire
+            // in order among themselves, so while any load of the older set is pending all NT of the newer set are too,
+            // i.e. more than NT operations.  When no newer set was issued (the wave's last operand): wait for everything.
+            if (pf_newer) wait_older_loads<NT>();
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            st_pending = false;
             WF_SYNC();
             const double2 *cur = st + cur_buf * STGB;
             if (ds != 0.0) build_z_staged<C, NT, true>(cur, ds, tw, ln, z);
@@ -239,7 +240,6 @@ gridwave2_bilinear_kernel(FftDev p, FusedArgs f, long nlines) {
             WF_OPAQUE_LANE(lf);
             double *dst = s_out[oc] + off;
             forward_line<C, NT, TWREG>(acc, wb, tw, lf, M, K, t64r, [&](int k, double2 v) { gstore16(dst + 2 * k, v); });
-            st_pending = true;
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = make_double2(0.0, 0.0);
         }
