@@ -761,15 +761,25 @@ class SolverBase:
             info["field"].require_coeff_space()
         self.push_unaliased()
 
-    def rhs_tiling(self, lu):
+    def rhs_tiling(self, lus):
         """Row length ny when the solver-internal right-hand-side vectors (the timestepper's M.X and F buffers) can use
         the TILE-MAJOR layout [kx/8][ky/8][kx%8][ky%8] the sweeps read contiguously (ddh_pencil_solve_recombined_tiled,
         include/dedalus_hip.h), else 0.  Needs: two Fourier axes with sizes that are multiples of 8, right-hand sides
         written by the forward transforms themselves (direct F) through the strided-axis wave kernel, the window-form M.X
-        product, the lean forward sweep for this factorization.  DDH_NO_RHS_TILING=1 switches it off (A/B)."""
-        if getattr(self, "_rhs_tiling", None) is not None:
-            return self._rhs_tiling
-        self._rhs_tiling = 0
+        product -- properties of the problem, decided once -- and the lean forward sweep over real factors for EVERY
+        factorization in `lus` (an id or an iterable of ids), asked again on every call: the sweep variant belongs to a
+        factorization and to PencilPack.set_solve_variant, not to the solver.  DDH_NO_RHS_TILING=1 switches it off (A/B)."""
+        if getattr(self, "_rhs_tiling_problem", None) is None:
+            self._rhs_tiling_problem = self._rhs_tiling_of_problem()
+        if not self._rhs_tiling_problem:
+            return 0
+        for lu in ([lus] if isinstance(lus, (int, np.integer)) else list(lus)):
+            info = self.pack.lu_info(lu)
+            if info["forward"] != "lean" or not info["real"]:
+                return 0
+        return self._rhs_tiling_problem
+
+    def _rhs_tiling_of_problem(self):
         ex = self.ex
         if (os.environ.get("DDH_NO_RHS_TILING") is not None or not getattr(self.pack, "supports_tiled_rhs", False)
                 or self.nf != 2 or self.nx % 8 or self.ny % 8 or self.F_direct is None or self.P_id is None
@@ -783,11 +793,7 @@ class SolverBase:
             pos, b, spec = tr._steps(edom, edom.dealias)[0]
             if pos != 0 or not ex.tiled_forward_ok(spec, b, self.nx * self.ny, self.ny):
                 return 0
-        info = self.pack.lu_info(lu)
-        if info["forward"] != "lean" or not info["real"]:
-            return 0
-        self._rhs_tiling = int(self.ny)
-        return self._rhs_tiling
+        return int(self.ny)
 
     def untile_rows(self, vec):
         """Natural-layout copy [R][nx][ny] of a tile-major system vector (diagnostics / parity probes only)."""

@@ -367,12 +367,20 @@ class RungeKuttaIMEX(_SolveMixin):
         t0 = s.sim_time
         s.sync_state_to_device()
         own = dict(owned=True) if getattr(pack, "supports_zero_rows", False) else {}
-        # the M.X and F buffers of this timestepper in the tile-major layout the sweeps read contiguously (decided once,
-        # after the first factorization, while the buffers still hold zeros; SolverBase.rhs_tiling)
-        if getattr(self, "_tiled", None) is None:
-            self._tiled = 0
+        # the M.X and F buffers of this timestepper in the tile-major layout the sweeps read contiguously
+        # (SolverBase.rhs_tiling).  The answer belongs to the current factorizations and sweep variant: asked again after
+        # every refactorization and every PencilPack.set_solve_variant.  Every buffer is rewritten in every step, so a
+        # change of layout only has to restore the zeros of the rows nothing writes.
+        stamp = (tuple(self._lus.values()), getattr(pack, "variant_epoch", 0))
+        if getattr(self, "_tiled_stamp", None) != stamp:
+            tiled_now = 0
             if own and not self._direct and not any(v is not None for v in self.LX) and hasattr(s, "rhs_tiling"):
-                self._tiled = s.rhs_tiling(next(iter(self._lus.values())))
+                tiled_now = s.rhs_tiling(self._lus.values())
+            if getattr(self, "_tiled", None) is not None and bool(tiled_now) != bool(self._tiled):
+                for buf in [self.MX0] + self.F + [v for v in self.MX if v is not None]:
+                    ex.fill_zero(buf)
+                s._F_zeroed = set(b.data_ptr() if hasattr(b, "data_ptr") else id(b) for b in self.F)
+            self._tiled, self._tiled_stamp = tiled_now, stamp
         tiled = self._tiled
         if tiled:
             own = dict(owned=True, tiled=True)

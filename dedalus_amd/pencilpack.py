@@ -330,6 +330,7 @@ class PencilPack:
         """Sweep variant of solve(): mode 1 by the number of systems (default), 0 one thread per system, 2 cooperative;
         fwd (0 / 1) and backward_lanes (0 / 4 / 16) override the two sweeps individually."""
         libhip.call("ddh_pencil_set_solve_variant", self.handle, int(mode), int(fwd), int(backward_lanes))
+        self.variant_epoch = getattr(self, "variant_epoch", 0) + 1     # (layout decisions that depend on the variant: timesteppers)
 
     def set_pairing(self, row_swap, col_swap, min_systems=0):
         """Partner pencils (ddh_pencil_set_pairing): (my, mx) is solved with the factorization of (mx, my) through the

@@ -405,6 +405,40 @@ def test_tile_major_right_hand_sides_change_addresses_not_values(monkeypatch):
         assert np.array_equal(a[k], b[k]), k
 
 
+def test_tile_major_layout_follows_the_sweep_variant(monkeypatch):
+    """The tile-major decision belongs to the factorizations and the sweep variant of the moment (SolverBase.rhs_tiling is
+    asked again after PencilPack.set_solve_variant and after every refactorization): a solver that starts tiled and is
+    switched to the cooperative sweeps (no tiled form) goes back to the natural layout instead of failing inside
+    ddh_pencil_solve_recombined_tiled, returns to tile-major with the default variant, and reaches bit for bit the end state
+    of a run that never tiled."""
+    import dedalus_amd.public as d3
+
+    def run(tiled):
+        if tiled:
+            monkeypatch.delenv("DDH_NO_RHS_TILING", raising=False)
+        else:
+            monkeypatch.setenv("DDH_NO_RHS_TILING", "1")
+        solver, f = problems.rayleigh_benard_3d(d3, Nx=256, Ny=256, Nz=256, timestepper="RK222")
+        seen = []
+        solver.step(1e-3)
+        seen.append(bool(solver.timestepper._tiled))
+        solver.pack.set_solve_variant(2)
+        solver.step(1e-3)
+        seen.append(bool(solver.timestepper._tiled))
+        solver.pack.set_solve_variant(1)
+        solver.step(5e-4)                                  # (a refactorization on the way back)
+        seen.append(bool(solver.timestepper._tiled))
+        out = {k: np.array(f[k]["c"]) for k in ("p", "b", "u")}
+        del solver, f
+        return out, seen
+
+    (a, sa), (b, sb) = run(True), run(False)
+    assert sa == [True, False, True] and sb == [False, False, False]
+    for k in a:
+        assert np.isfinite(a[k]).all(), k
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_x_blocked_stage_layout_changes_addresses_not_values(monkeypatch):
     """The arrays between the z and the x transforms stored [kx / 64][z][kx % 64][ky] (ddh_fft_set_stage_layout,
     Transformer.stage_xb) against the natural layout (DDH_NO_STAGE_XB): same arithmetic, bit-identical end states; the
