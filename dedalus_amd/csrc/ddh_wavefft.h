@@ -545,11 +545,14 @@ DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, u
     const double s3 = 0.86602540378443864676372317075293618;
     // Register relief: the staging area beyond the FFT's exchange buffer is free from here on, and the last ZL of the
     // lane's Z[N - k'] values are parked there (lane-contiguous slots, read back once per transform).  With everything
-    // in registers the R = 16 kernels spill (plain 16, differentiated 72, dual 160-196 bytes of scratch per lane -- for
-    // the dual kernel 10 % more HBM traffic than the tile's own data).
-    constexpr int XB = WfftBuf<R, 2>::size;
+    // in registers the R = 16 kernels spill (plain 16, differentiated 72, dual 160-196 bytes of scratch per lane).
+    // (the differentiated and the dual transform exchange in four chunks instead of two: half the exchange buffer = four
+    //  more parking slots per lane; with 9 slots the dual kernel still spilled 60 bytes per lane at 256 registers -- 1.16 x
+    //  its algorithmic HBM traffic --, with 13 none: 1.38 -> 1.29 ms at 512^2 x 384)
+    constexpr int CHX = (R >= 16 && BK != 0) ? 4 : 2;
+    constexpr int XB = WfftBuf<R, CHX>::size;
     constexpr int ZLmax = (RfftWaveLds<R>::size - XB) / 64;
-    constexpr int ZLwant = (R >= 16) ? (BK == 2 ? 9 : (BK == 1 ? 6 : 4)) : 0;
+    constexpr int ZLwant = (R >= 16) ? (BK == 2 ? 13 : (BK == 1 ? 12 : 4)) : 0;
     constexpr int ZL = ZLwant < ZLmax ? ZLwant : ZLmax;
     double2 *ZS = S + XB + lane;
     if (ZL > 0) {
@@ -602,7 +605,7 @@ DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, u
                 v[t] = (r == 0) ? u : cmul(u, twid<+1>(tw, r * k));
                 if ((t & 3) == 3) WF_SCHED_FENCE();
             }
-            wfft<R, +1, 2, 3>(v, S, tw, L);
+            wfft<R, +1, CHX, 3>(v, S, tw, L);
             WF_OPAQUE_U32(rsb);
             if (pvalid) {
                 const unsigned o0 = (unsigned)(3 * (R * L.q0 + (R / 4) * L.q1) + r) * rsb + 16u * (unsigned)L.p;
