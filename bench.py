@@ -463,6 +463,10 @@ def main():
             roof["valu"] = dict(bound="fp64-valu", algorithmic_flops_per_launch=fl, achieved=tf, peak=78.6, unit="TFLOP/s",
                                 frac=tf / 78.6, issued_valu_frac_note="6405 wave instructions per line x 4 cycles on 1024 "
                                 "SIMDs = 3.1 ms of pure VALU issue per launch (profiles/r5_fused_sq_counters.txt)")
+            roof["power_note"] = ("this kernel runs at the board's power limit: 1362-1368 W and a shader clock of 2.02-2.05 GHz "
+                                  "on real operands, 1250 W at 2.39 GHz and 5.3 instead of 6.4 ms on all-zero operands "
+                                  "(profiles/r5_fused_clocks.txt, rocm-smi sampled beside tools/bench_fused.py); the peaks above "
+                                  "assume 2.4 GHz")
         total_kernel_ms = sum(v["total_ms"] for v in summ.values())
         total_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in summ.values())
         out = {
