@@ -989,6 +989,8 @@ fused_rfft_bilinear_kernel(FftDev p, FusedArgs f, long nlines, long npairs) {
 int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, long outer, long inner, double *dst2,
                   const double *dvec, double dscale, double dscale2, hipStream_t st);
 // ddh_gridwave.hip: wave-per-line variant of the fused grid stage for N = 128*C
+// ddh_fftwave.hip: the same lane code along a CONTIGUOUS axis (Chebyshev, N = 192: the shell's radial transforms)
+int wave_contig_try(int mode, const FftDev &d, const double *src, double *dst, long outer, double *dst2, hipStream_t st);
 bool gridwave_supported(const FftDev &d);
 int launch_gridwave(const FftDev &d, const FusedArgs &f, long nlines, hipStream_t st);
 
@@ -1190,6 +1192,10 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     if (!is_cfft && inner_mode) {
         // strided axis at an instantiated size: one wavefront per four line pairs (ddh_fftwave.hip)
         const int wst = wave_axis_try(MODE, d, src, dst, outer, inner, dst2, dvec, dscale, dscale2, as_stream(stream));
+        if (wst <= 0) return wst;
+    }
+    if (!is_cfft && !inner_mode) {
+        const int wst = wave_contig_try(MODE, d, src, dst, outer, dst2, as_stream(stream));
         if (wst <= 0) return wst;
     }
     if (d.xb && inner_mode) return fail("x-blocked stage layout (ddh_fft_set_stage_layout): only the strided-axis wave kernels at their "

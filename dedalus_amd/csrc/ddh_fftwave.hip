@@ -159,6 +159,164 @@ static int launch_wave_cheb(const FftDev &d, const WaveArgs &a, unsigned nwg, hi
     return 0;
 }
 
+// ---- Chebyshev along the CONTIGUOUS axis (the shell's radial transforms: [lines][192] <-> [lines][128]) ------------------
+// The same lane code on lines that are contiguous in memory: a wave takes 8 consecutive lines (4 pairs of lines 2 p, 2 p + 1).
+// Its loads follow the lane map directly (sixteen lanes of a row group read 128 contiguous bytes of one line); the grid rows
+// of a backward transform leave the FFT scattered over the line (row 2 n / 2 (N - 1 - n) + 1 of FFT slot n), so they are
+// written into the wave's LDS region -- laid out like the global lines, NP doubles apart -- and copied out with linear
+// 16-byte stores.  The staging area is the region the transform itself has just used for its exchanges: the LDS
+// operations of a wave execute in program order.  Replaces core/transforms.py:715-902 for a contiguous axis (the
+// workgroup-per-tile kernel of ddh_fft.hip ran these short lines at 0.19-0.27 of the HBM rate).
+constexpr int WC_WAVES = 4;
+
+struct ContigArgs {
+    const double *src;
+    double *dst;
+    long nlines;             // even
+    unsigned ntiles, tpw;    // tiles of 8 lines, tiles per wave
+    int kind;                // backward: 0 plain, 2 conversion solve
+};
+
+template <int R, int NL, int CH>
+struct ChebContigLds {
+    static constexpr int NP = 16 * R + 2;                       // doubles between staged lines (16-byte aligned line starts)
+    static constexpr int a = wf::ChebWaveLds<R, NL, CH>::size, b = 4 * NP;
+    static constexpr int size = a > b ? a : b;                  // double2 per wave
+};
+
+template <int KIND, int R, int NL, int CH>      // KIND: 0 backward plain, 2 backward conversion, 3 forward
+__global__ void __launch_bounds__(64 * WC_WAVES, 2)
+wave_cheb_contig_kernel(FftDev p, ContigArgs a) {
+    constexpr bool FWD = (KIND == 3);
+    extern __shared__ double2 lds[];
+    constexpr int N = 16 * R, NP = ChebContigLds<R, NL, CH>::NP;
+    const int M = p.M, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double2 *s_tw = lds, *s_half = lds + N;
+    double *s_d = reinterpret_cast<double *>(lds + 2 * N);
+    const int nd = FWD ? p.nbands * M : 3 * M;
+    double2 *S = reinterpret_cast<double2 *>(s_d + ((nd + 1) & ~1)) + wave * ChebContigLds<R, NL, CH>::size;
+    for (int i = tid; i < N; i += 64 * WC_WAVES) {
+        s_tw[i] = p.tw[i];
+        s_half[i] = p.half[i];
+    }
+    if (FWD) {
+        for (int i = tid; i < p.nbands * M; i += 64 * WC_WAVES) s_d[i] = p.bands[i];
+    } else {
+        for (int i = tid; i < 2 * M; i += 64 * WC_WAVES) s_d[i] = p.bsub ? p.bsub[i] : 0.0;
+        for (int i = tid; i < M; i += 64 * WC_WAVES) s_d[2 * M + i] = 0.0;
+    }
+    __syncthreads();                    // the only workgroup barrier
+    wf::ChebTabs T;
+    T.tw = s_tw;
+    T.half = s_half;
+    T.bands = s_d;
+    T.bsub = s_d;
+    T.dvec = s_d + 2 * M;
+    T.M = M;
+    T.Mk = 16 * NL;
+    T.nbands = p.nbands;
+    T.gcd_off = p.gcd_off;
+    { T.boff1 = p.boff[1]; T.boff2 = p.boff[2]; T.boff3 = p.boff[3]; }
+    const double kSqPi = 1.7724538509055160272981674833411, kSqPi2 = 1.2533141373155002512078826424055;
+    T.fs0 = kSqPi / (2.0 * (double)N);
+    T.fs1 = kSqPi2 / (double)N;
+    T.bs0 = 1.0 / kSqPi;
+    T.bs1 = 0.5 / kSqPi2;
+    const wf::Lane L = wf::make_lane(lane);
+    const unsigned g = xcd_swizzle(blockIdx.x, gridDim.x);
+    const unsigned lsc = (unsigned)(M * 8), lsg = (unsigned)(N * 8);      // bytes between coefficient / grid lines
+    auto tile_of = [&](unsigned i) -> unsigned { return (g * a.tpw + i) * WC_WAVES + wave; };
+    if (FWD) {
+        for (unsigned i = 0; i < a.tpw; ++i) {
+            const unsigned tile = tile_of(i);
+            if (tile >= a.ntiles) break;
+            const long l0 = 8L * tile;
+            const bool valid = l0 + 2 * L.p < a.nlines;
+            wf::cheb_fwd_tile<R, NL, CH, true>(a.src + l0 * N, a.dst + l0 * M, lsg, lsc, valid, S, T, lane);
+        }
+    } else {
+        double2 c[NL];
+        if (tile_of(0) >= a.ntiles) return;
+        {
+            const long l0 = 8L * tile_of(0);
+            wf::cheb_bwd_load_contig<NL>(c, a.src + l0 * M, lsc, l0 + 2 * L.p < a.nlines, L);
+        }
+        double *stage = reinterpret_cast<double *>(S);
+        for (unsigned i = 0; i < a.tpw; ++i) {
+            const unsigned tile = tile_of(i);
+            if (tile >= a.ntiles) break;
+            const long l0 = 8L * tile;
+            const bool valid = l0 + 2 * L.p < a.nlines;
+            const unsigned tn = tile_of(i + 1);
+            const bool more = (i + 1 < a.tpw) && (tn < a.ntiles);
+            const long l0n = more ? 8L * tn : l0;
+            const bool validn = l0n + 2 * L.p < a.nlines;
+            const unsigned lscn = more ? lsc : 0u;
+            if (KIND == 2)
+                wf::cheb_bwd_pass<R, NL, CH, 2, true, true>(c, S, T, stage, (unsigned)(NP * 8), valid, lane, a.src + l0n * M, lscn, validn);
+            else
+                wf::cheb_bwd_pass<R, NL, CH, 0, true, true>(c, S, T, stage, (unsigned)(NP * 8), valid, lane, a.src + l0n * M, lscn, validn);
+            WF_SYNC();
+            // staged lines -> global, 16 bytes per lane and step
+            double *out = a.dst + l0 * N;
+#pragma unroll
+            for (int it = 0; it < (8 * (N / 2) + 63) / 64; ++it) {
+                const int ch = it * 64 + lane;
+                const int l = ch / (N / 2), j = ch - l * (N / 2);
+                if (ch < 8 * (N / 2) && l0 + l < a.nlines)
+                    *reinterpret_cast<double2 *>(out + (long)l * N + 2 * j) = *reinterpret_cast<const double2 *>(stage + l * NP + 2 * j);
+            }
+            WF_SYNC();
+        }
+    }
+}
+
+template <int KIND, int R, int NL, int CH>
+static int launch_wave_cheb_contig(const FftDev &d, const ContigArgs &a, unsigned nwg, hipStream_t st) {
+    const int N = 16 * R;
+    constexpr bool FWD = (KIND == 3);
+    const int nd = FWD ? d.nbands * d.M : 3 * d.M;
+    const size_t lds = (size_t)2 * N * sizeof(double2) + (size_t)((nd + 1) & ~1) * sizeof(double) +
+                       (size_t)WC_WAVES * ChebContigLds<R, NL, CH>::size * sizeof(double2);
+    if (lds > 160 * 1024) return 1;
+    auto kern = wave_cheb_contig_kernel<KIND, R, NL, CH>;
+    if (lds > 64 * 1024)
+        DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WC_WAVES), lds, st, d, a);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+// 0 = launched, 1 = shape not covered
+int wave_contig_try(int mode, const FftDev &d, const double *src, double *dst, long outer, double *dst2, hipStream_t st) {
+    static const int on = getenv("DDH_CHEB_CONTIG_WAVE") ? atoi(getenv("DDH_CHEB_CONTIG_WAVE")) : 1;
+    if (!on || d.dbg || d.prof || d.xb || d.ctile_nseg || dst2) return 1;
+    if (mode != CHEB_FWD && mode != CHEB_BWD) return 1;
+    if (d.N != 192 || d.M != 128 || (outer & 1) || outer < 2) return 1;            // instantiated size (R = 12, 8 rows per lane)
+    if (src == dst) return 1;
+    ContigArgs a;
+    a.src = src;
+    a.dst = dst;
+    a.nlines = outer;
+    const unsigned long ntiles = ((unsigned long)outer + 7) / 8;
+    if (ntiles > 0x7fffffffUL) return 1;
+    a.ntiles = (unsigned)ntiles;
+    a.kind = 0;
+    if (mode == CHEB_BWD && d.nbands > 0) {
+        if (!(d.bsub && d.bsub_order == 1 && (d.gcd_off == 1 || d.gcd_off == 2))) return 1;
+        a.kind = 2;
+    }
+    static const int env_tpw = getenv("DDH_CHEB_CONTIG_TPW") ? atoi(getenv("DDH_CHEB_CONTIG_TPW")) : 0;
+    unsigned tpw = (unsigned)(env_tpw > 0 ? env_tpw : 4);
+    while (tpw > 1 && ntiles / ((unsigned long)tpw * WC_WAVES) < 2048) tpw /= 2;
+    a.tpw = tpw;
+    const unsigned nwg = (unsigned)((ntiles + (unsigned long)tpw * WC_WAVES - 1) / ((unsigned long)tpw * WC_WAVES));
+    if (mode == CHEB_FWD) return launch_wave_cheb_contig<3, 12, 8, 3>(d, a, nwg, st);
+    if (a.kind == 2) return launch_wave_cheb_contig<2, 12, 8, 3>(d, a, nwg, st);
+    return launch_wave_cheb_contig<0, 12, 8, 3>(d, a, nwg, st);
+}
+
 // ---- real Fourier, 3/2 dealiasing (N = 48 R, M = 32 R): RKIND 0 backward, 1 backward differentiated, 2 backward dual
 // (plain + differentiated), 3 forward
 template <int RKIND, int R>

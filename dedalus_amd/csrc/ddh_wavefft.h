@@ -228,6 +228,25 @@ DDH_DEV void gstore(double *base, unsigned off, double2 v) {
     *reinterpret_cast<double2 *>(reinterpret_cast<char *>(base) + off) = v;
 }
 
+// Contiguous axis (CONTIG variants below): the lines of the wave's four pairs are lines 2 p, 2 p + 1 of an array of lines
+// lsb bytes apart (global memory, or the wave's LDS staging area), row k of a line is its k-th double.
+DDH_DEV double2 cload(const double *base, unsigned off, unsigned lsb) {
+    const char *b = reinterpret_cast<const char *>(base) + off;
+    return make_double2(*reinterpret_cast<const double *>(b), *reinterpret_cast<const double *>(b + lsb));
+}
+DDH_DEV void cstore(double *base, unsigned off, unsigned lsb, double2 v) {
+    char *b = reinterpret_cast<char *>(base) + off;
+    *reinterpret_cast<double *>(b) = v.x;
+    *reinterpret_cast<double *>(b + lsb) = v.y;
+}
+template <int NLC>
+DDH_DEV void cheb_bwd_load_contig(double2 (&c)[NLC], const double *src_t, unsigned lsb, bool pvalid, const Lane &L) {
+    WF_OPAQUE_U32(lsb);
+    const unsigned o0 = (pvalid ? (unsigned)(2 * L.p) * lsb : 0u) + 8u * (unsigned)L.q;      // (a missing pair re-reads pair 0)
+#pragma unroll
+    for (int t = 0; t < NLC; ++t) c[t] = cload(src_t, o0 + (unsigned)(128 * t), lsb);
+}
+
 // loads of one backward tile: c[t] = coefficient row q + 16 t of the lane's pair (zero for a pair beyond the array)
 template <int NLC>
 DDH_DEV void cheb_bwd_load(double2 (&c)[NLC], const double *src_t, unsigned rsb, bool pvalid, const Lane &L) {
@@ -324,6 +343,24 @@ DDH_DEV void cheb_bwd_store(const double2 (&v)[R], double *dst_t, unsigned rsb, 
         }
 }
 
+template <int R>
+DDH_DEV void cheb_bwd_store_contig(const double2 (&v)[R], double *dst_t, unsigned lsb, bool pvalid, const Lane &L) {
+    constexpr int N = 16 * R, RQ = R / 4;
+    WF_OPAQUE_U32(lsb);
+    if (!pvalid) return;
+    const int nl = R * L.q0 + RQ * L.q1;                             // n = nl + 4 R a0 + i
+    const unsigned po = (unsigned)(2 * L.p) * lsb;
+    const unsigned lo = po + 8u * (unsigned)(2 * nl);                                    // row 2 n          (n < N / 2)
+    const unsigned hi = po + 8u * (unsigned)(2 * (N - 1 - nl) + 1);                      // row 2 (N - 1 - n) + 1
+#pragma unroll
+    for (int a0 = 0; a0 < 4; ++a0)
+#pragma unroll
+        for (int i = 0; i < RQ; ++i) {
+            const unsigned d = 8u * (unsigned)(2 * (4 * R * a0 + i));
+            cstore(dst_t, (a0 < 2) ? lo + d : hi - d, lsb, v[a0 * RQ + i]);
+        }
+}
+
 // One backward pass on staged data.  mode 0: plain (Z from the coefficients in c); 1: derivative pass of the dual
 // transform (d[j] = dvec[j] c[j + 1], conversion solve, Z from LDS); 2: conversion solve of c itself.
 // S: this wave's LDS region of max(16 NLC * 4, WfftBuf<R, CH>::size) elements.
@@ -331,7 +368,8 @@ DDH_DEV void cheb_bwd_store(const double2 (&v)[R], double *dst_t, unsigned rsb, 
 // same registers; they are in flight during the FFT and the stores of this pass.  The request is unconditional (a
 // conditional one makes the compiler keep both register sets and spill): after its last tile a wave passes
 // next_rsb = 0, i.e. sixteen reads of one 64-byte segment it already has in cache.
-template <int R, int NLC, int CH, int mode, bool PREFETCH>
+// CONTIG: contiguous axis -- rsb / next_rsb are the bytes between LINES of dst_t / next_src_t (cload / cstore addressing).
+template <int R, int NLC, int CH, int mode, bool PREFETCH, bool CONTIG = false>
 DDH_DEV void cheb_bwd_pass(double2 (&c)[NLC], double2 *S, const ChebTabs &T, double *dst_t, unsigned rsb,
                            bool pvalid, int lane, const double *next_src_t, unsigned next_rsb, bool next_valid) {
     constexpr int Mk = 16 * NLC;
@@ -354,25 +392,33 @@ DDH_DEV void cheb_bwd_pass(double2 (&c)[NLC], double2 *S, const ChebTabs &T, dou
     if (mode == 0) {
         cheb_bwd_build<R, NLC, true>(v, c, S, T, L);
         WF_SCHED_FENCE();            // c is dead from here on: its registers take the prefetch
-        if (PREFETCH) cheb_bwd_load<NLC>(c, next_src_t, next_rsb, next_valid, L);
+        if (PREFETCH) {
+            if constexpr (CONTIG) cheb_bwd_load_contig<NLC>(c, next_src_t, next_rsb, next_valid, L);
+            else cheb_bwd_load<NLC>(c, next_src_t, next_rsb, next_valid, L);
+        }
         WF_SCHED_FENCE();
     } else {
         WF_SCHED_FENCE();
-        if (PREFETCH) cheb_bwd_load<NLC>(c, next_src_t, next_rsb, next_valid, L);
+        if (PREFETCH) {
+            if constexpr (CONTIG) cheb_bwd_load_contig<NLC>(c, next_src_t, next_rsb, next_valid, L);
+            else cheb_bwd_load<NLC>(c, next_src_t, next_rsb, next_valid, L);
+        }
         WF_SCHED_FENCE();
         cheb_solve_chains<NLC>(S, T, L);
         WF_SYNC();
         cheb_bwd_build<R, NLC, false>(v, c, S, T, L);
     }
     wfft<R, +1, CH>(v, S, T.tw, L);
-    cheb_bwd_store<R>(v, dst_t, rsb, pvalid, L);
+    if constexpr (CONTIG) cheb_bwd_store_contig<R>(v, dst_t, rsb, pvalid, L);
+    else cheb_bwd_store<R>(v, dst_t, rsb, pvalid, L);
 }
 
 // Forward: grid rows -> coefficients k = q + 16 t, t < NST (Mk = 16 NST), optional conversion bands.
 // S: max(8 R * 4, 16 NST * 4, WfftBuf size) elements.
-template <int R, int NST, int CH>
+template <int R, int NST, int CH, bool CONTIG = false>
 DDH_DEV void cheb_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, unsigned rsbd, bool pvalid, double2 *S,
                            const ChebTabs &T, int lane) {      // rsb: bytes between grid rows (src), rsbd: coefficient rows (dst)
+                                                                // (CONTIG: bytes between the LINES of src / dst)
     constexpr int N = 16 * R, RQ = R / 4, Mk = 16 * NST, H8 = 8 * R;
     WF_OPAQUE_LANE(lane);
     const Lane L = make_lane(lane);
@@ -380,12 +426,21 @@ DDH_DEV void cheb_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, uns
     {
         WF_OPAQUE_U32(rsb);
         // FFT position n = q + 16 t holds grid row 2 n (t < R / 2) or 2 (N - 1 - n) + 1
+        if constexpr (CONTIG) {
+            const unsigned po = pvalid ? (unsigned)(2 * L.p) * rsb : 0u;
+            const unsigned lo = 8u * (unsigned)(2 * L.q) + po;
+            const unsigned hi = 8u * (unsigned)(2 * N - 1 - 2 * L.q) + po;
+#pragma unroll
+            for (int t = 0; t < R; ++t)
+                v[t] = cload(src_t, (2 * t < R) ? lo + 8u * (unsigned)(32 * t) : hi - 8u * (unsigned)(32 * t), rsb);
+        } else {
         const unsigned po = pvalid ? 16u * (unsigned)L.p : 0u;       // a pair beyond the array re-reads pair 0
         const unsigned lo = (unsigned)(2 * L.q) * rsb + po;
         const unsigned hi = (unsigned)(2 * N - 1 - 2 * L.q) * rsb + po;
 #pragma unroll
         for (int t = 0; t < R; ++t)
             v[t] = gload(src_t, (2 * t < R) ? lo + (unsigned)(32 * t) * rsb : hi - (unsigned)(32 * t) * rsb);
+        }
     }
     wfft<R, -1, CH>(v, S, T.tw, L);
     // c~[k] = fs_k (X[k] h_k + X[N - k] conj h_k)  (X[N] = X[0]); natural-order exchange in two halves of N / 2
@@ -455,9 +510,15 @@ DDH_DEV void cheb_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, uns
     }
     WF_OPAQUE_U32(rsbd);
     if (pvalid) {
+        if constexpr (CONTIG) {
+            const unsigned o0 = (unsigned)(2 * L.p) * rsbd + 8u * (unsigned)L.q;
+#pragma unroll
+            for (int t = 0; t < NST; ++t) cstore(dst_t, o0 + (unsigned)(128 * t), rsbd, acc[t]);
+        } else {
         const unsigned o0 = (unsigned)L.q * rsbd + 16u * (unsigned)L.p;
 #pragma unroll
         for (int t = 0; t < NST; ++t) gstore(dst_t, o0 + (unsigned)(16 * t) * rsbd, acc[t]);
+        }
     }
 }
 

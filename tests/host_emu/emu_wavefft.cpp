@@ -126,6 +126,61 @@ static void cheb_fwd(const EmuTabs &e, const double *src, double *dst, long oute
     });
 }
 
+// contiguous axis (wave_cheb_contig_kernel): lines [nlines][M] -> [nlines][N]; the staged grid lines are NP doubles apart
+template <int R, int NL, int CH>
+static void cheb_bwd_contig(const EmuTabs &e, int kind, const double *src, double *dst, long nlines) {
+    constexpr int N = 16 * R, NP = N + 2;
+    const int M = e.M;
+    const ChebTabs T = make_tabs(e, N, 16 * NL);
+    const long ntiles = (nlines + 7) / 8;
+    std::vector<double2> S(ChebWaveLds<R, NL, CH>::size);
+    std::vector<double> stage(8 * NP);
+    run_wave([&](int lane) {
+        const Lane L = make_lane(lane);
+        double2 c[NL];
+        cheb_bwd_load_contig<NL>(c, src, (unsigned)(M * 8), 2 * L.p < nlines, L);
+        for (long tile = 0; tile < ntiles; ++tile) {
+            const long l0 = 8 * tile;
+            const bool valid = l0 + 2 * L.p < nlines;
+            const bool more = tile + 1 < ntiles;
+            const long l0n = more ? l0 + 8 : l0;
+            const bool validn = l0n + 2 * L.p < nlines;
+            const unsigned lscn = more ? (unsigned)(M * 8) : 0u;
+            if (kind == 2)
+                cheb_bwd_pass<R, NL, CH, 2, true, true>(c, S.data(), T, stage.data(), (unsigned)(NP * 8), valid, lane, src + l0n * M, lscn, validn);
+            else
+                cheb_bwd_pass<R, NL, CH, 0, true, true>(c, S.data(), T, stage.data(), (unsigned)(NP * 8), valid, lane, src + l0n * M, lscn, validn);
+            WF_SYNC();
+            for (int it = 0; it < (8 * (N / 2) + 63) / 64; ++it) {
+                const int ch = it * 64 + lane;
+                const int l = ch / (N / 2), j = ch - l * (N / 2);
+                if (ch < 8 * (N / 2) && l0 + l < nlines) {
+                    dst[(l0 + l) * N + 2 * j] = stage[l * NP + 2 * j];
+                    dst[(l0 + l) * N + 2 * j + 1] = stage[l * NP + 2 * j + 1];
+                }
+            }
+            WF_SYNC();
+        }
+    });
+}
+
+template <int R, int NL, int CH>
+static void cheb_fwd_contig(const EmuTabs &e, const double *src, double *dst, long nlines) {
+    constexpr int N = 16 * R;
+    const int M = e.M;
+    const ChebTabs T = make_tabs(e, N, 16 * NL);
+    const long ntiles = (nlines + 7) / 8;
+    std::vector<double2> S(ChebWaveLds<R, NL, CH>::size);
+    run_wave([&](int lane) {
+        const Lane L = make_lane(lane);
+        for (long tile = 0; tile < ntiles; ++tile) {
+            const long l0 = 8 * tile;
+            const bool valid = l0 + 2 * L.p < nlines;
+            cheb_fwd_tile<R, NL, CH, true>(src + l0 * N, dst + l0 * M, (unsigned)(N * 8), (unsigned)(M * 8), valid, S.data(), T, lane);
+        }
+    });
+}
+
 // plain complex FFT of 4 interleaved lines through wfft: x [N][4][2] -> X [N][4][2]
 template <int R, int SIGN, int CH>
 static void fft4(const double *tw, const double *x, double *X) {
@@ -160,6 +215,24 @@ int emu_cheb_bwd(int N, int M, int kind, const double *tw, const double *half, c
     memset(&e, 0, sizeof(e));
     e.tw = tw; e.half = half; e.bsub = bsub; e.dvec = dvec; e.M = M; e.gcd_off = gcd_off;
     if (N == 384 && M == 256) { cheb_bwd<24, 16, 2>(e, kind, src, dst, dst2, outer, inner); return 0; }
+    return 1;
+}
+int emu_cheb_bwd_contig(int N, int M, int kind, const double *tw, const double *half, const double *bsub, int gcd_off,
+                        const double *src, double *dst, long nlines) {
+    EmuTabs e;
+    memset(&e, 0, sizeof(e));
+    std::vector<double> zero(M, 0.0);
+    e.tw = tw; e.half = half; e.bsub = bsub; e.dvec = zero.data(); e.M = M; e.gcd_off = gcd_off;
+    if (N == 192 && M == 128) { cheb_bwd_contig<12, 8, 3>(e, kind, src, dst, nlines); return 0; }
+    return 1;
+}
+int emu_cheb_fwd_contig(int N, int M, const double *tw, const double *half, int nbands, const int *boff, const double *bands,
+                        const double *src, double *dst, long nlines) {
+    EmuTabs e;
+    memset(&e, 0, sizeof(e));
+    e.tw = tw; e.half = half; e.bands = bands; e.M = M; e.nbands = nbands; e.gcd_off = 1;
+    for (int d = 0; d < nbands && d < 4; ++d) e.boff[d] = boff[d];
+    if (N == 192 && M == 128) { cheb_fwd_contig<12, 8, 3>(e, src, dst, nlines); return 0; }
     return 1;
 }
 int emu_cheb_fwd(int N, int M, const double *tw, const double *half, int nbands, const int *boff, const double *bands,

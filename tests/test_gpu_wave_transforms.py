@@ -77,6 +77,44 @@ def test_wave_chebyshev_all_paths(dev, outer, inner):
     assert rel(dev.to_host(gb), npt.cheb_backward(dc, 1, N, plans[1][1])) < 1e-11
 
 
+@pytest.mark.parametrize("nlines", [2, 8, 18, 8 * 4 * 4 * 7 + 6, 3 * 256 * 128])
+def test_wave_chebyshev_along_the_contiguous_axis(dev, nlines):
+    """The shell's radial transforms (contiguous lines, 192 <- 128; wave_cheb_contig_kernel): one pair, one tile, a partial
+    tile, several tiles per wave with a ragged end, and the configuration's own line count; alpha = 0, 1, 2 both ways against
+    the numpy oracle (reference: core/transforms.py:715-902), plus the round trip."""
+    from dedalus_amd import libhip
+    from dedalus_amd.device import ptr
+    from oracle import np_transforms as npt
+    N, M = 192, 128
+    big = nlines > 10000
+    rng = np.random.default_rng(nlines)
+    cin = rng.standard_normal((nlines, M)) / (1.0 + np.arange(M).reshape(1, -1)) ** 2
+    gin = rng.standard_normal((nlines, N))
+    d_c, d_g = dev.from_host(cin), dev.from_host(gin)
+    sub = slice(None) if not big else slice(0, nlines, 997)
+    for alpha in (0, 1, 2):
+        h, conv = _plan(N, M, alpha)
+        out = dev.empty((nlines, M))
+        out.fill_(float("nan"))
+        libhip.call("ddh_cheb_forward", h, ptr(d_g), ptr(out), nlines, 1, dev.stream)
+        dev.sync()
+        o = dev.to_host(out)
+        assert np.isfinite(o).all()
+        assert rel(o[sub], npt.cheb_forward(gin[sub], 1, M, conv)) < 1e-12, ("forward", alpha)
+        g = dev.empty((nlines, N))
+        g.fill_(float("nan"))
+        libhip.call("ddh_cheb_backward", h, ptr(d_c), ptr(g), nlines, 1, dev.stream)
+        dev.sync()
+        gh = dev.to_host(g)
+        assert np.isfinite(gh).all()
+        assert rel(gh[sub], npt.cheb_backward(cin[sub], 1, N, conv)) < 1e-11, ("backward", alpha)
+        assert np.array_equal(dev.to_host(d_c), cin) and np.array_equal(dev.to_host(d_g), gin)
+        c2 = dev.empty((nlines, M))
+        libhip.call("ddh_cheb_forward", h, ptr(g), ptr(c2), nlines, 1, dev.stream)
+        dev.sync()
+        assert rel(dev.to_host(c2), cin) < 1e-12, ("round trip", alpha)
+
+
 def test_wave_chebyshev_round_trip_full_size(dev):
     """512 x 512 x 256 shape (one component): forward(backward(c)) == c, and the dual's derivative output equals the
     backward transform of the differentiated coefficients taken by the plain conversion path."""

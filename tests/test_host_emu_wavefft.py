@@ -25,6 +25,8 @@ def emu(tmp_path_factory):
     lib.emu_fft4.argtypes = [i, i, vp, vp, vp]
     lib.emu_cheb_bwd.argtypes = [i, i, i, vp, vp, vp, vp, i, vp, vp, vp, l, l]
     lib.emu_cheb_fwd.argtypes = [i, i, vp, vp, i, vp, vp, vp, vp, l, l]
+    lib.emu_cheb_bwd_contig.argtypes = [i, i, i, vp, vp, vp, i, vp, vp, l]
+    lib.emu_cheb_fwd_contig.argtypes = [i, i, vp, vp, i, vp, vp, vp, vp, l]
     lib.emu_rfft_bwd.argtypes = [i, i, C.c_double, C.c_double, vp, vp, vp, vp, l, l]
     lib.emu_rfft_fwd.argtypes = [i, vp, vp, vp, l, l]
     return lib
@@ -108,6 +110,42 @@ def test_wave_chebyshev_matches_the_oracle(emu, shape):
         else:
             cv, offs, bands = conv_bands(M, alpha)
             emu.emu_cheb_fwd(N, M, dp(tw), dp(half), len(offs), dp(offs), dp(bands), dp(gin), dp(out), outer, inner)
+        assert rel(out, npt.cheb_forward(gin, 1, M, cv)) < 1e-14
+
+
+@pytest.mark.parametrize("nlines", [8, 18, 2])
+def test_wave_chebyshev_along_the_contiguous_axis(emu, nlines):
+    """wave_cheb_contig_kernel (the shell's radial transforms, 192 <- 128): 8 contiguous lines per wave, grid lines staged
+    line-major in LDS; whole tiles, a partial tile (18 = 2 tiles + one pair), a single pair; plain, conversion solve
+    (ultraspherical alpha = 1, 2), forward with conversion bands"""
+    N, M = 192, 128
+    rng = np.random.default_rng(nlines)
+    tw, half = tables(N)
+    zero = np.zeros(3 * M)
+    cin = rng.standard_normal((nlines, M)) / (1.0 + np.arange(M).reshape(1, -1)) ** 2
+    g = np.full((nlines, N), np.nan)
+    assert emu.emu_cheb_bwd_contig(N, M, 0, dp(tw), dp(half), dp(zero), 1, dp(cin), dp(g), nlines) == 0
+    assert rel(g, npt.cheb_backward(cin, 1, N, None)) < 1e-14
+    for alpha in (1, 2):
+        conv, offs, bands = conv_bands(M, alpha)
+        if len(offs) != 2:
+            continue                                     # (first-order back substitution only, as on the device)
+        go = int(offs[1])
+        bsub = np.zeros((2, M))
+        bsub[0] = 1.0 / bands[0]
+        bsub[1, :M - go] = bands[1, :M - go] / bands[0, :M - go]
+        g2 = np.full((nlines, N), np.nan)
+        assert emu.emu_cheb_bwd_contig(N, M, 2, dp(tw), dp(half), dp(bsub), go, dp(cin), dp(g2), nlines) == 0
+        assert rel(g2, npt.cheb_backward(cin, 1, N, conv)) < 1e-13
+    gin = rng.standard_normal((nlines, N))
+    for alpha in (0, 1, 2):
+        out = np.full((nlines, M), np.nan)
+        if alpha == 0:
+            emu.emu_cheb_fwd_contig(N, M, dp(tw), dp(half), 0, None, None, dp(gin), dp(out), nlines)
+            cv = None
+        else:
+            cv, offs, bands = conv_bands(M, alpha)
+            emu.emu_cheb_fwd_contig(N, M, dp(tw), dp(half), len(offs), dp(offs), dp(bands), dp(gin), dp(out), nlines)
         assert rel(out, npt.cheb_forward(gin, 1, M, cv)) < 1e-14
 
 
