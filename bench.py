@@ -83,8 +83,9 @@ def parse():
     ap.add_argument("--size", type=str, default=os.environ.get("BENCH_SIZE", "512,512,256"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=30.0,
-                    help="seconds of one-core CPU work for the cpu_baseline samples (default 30; >= 240 adds 128x128x64)")
+    ap.add_argument("--cpu-budget", type=float, default=120.0,
+                    help="budget of the one-core cpu_baseline samples; >= 100 (default 120) includes 128x128x64, the sample the value "
+                         "extrapolates from (~1 min of setup + ~7 s per step)")
     ap.add_argument("--cpu-replicas", type=int, default=None,
                     help="one-core replicas of the 64^3 sample run at once (default: min(32, usable cores / 2))")
     ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
@@ -97,6 +98,9 @@ def parse():
                          "loop -- d3.CFL(cadence=10, threshold=0.05) on an O(1) flow, i.e. with LHS refactorizations -- is "
                          "timed and reported as `cfl_mode` beside the fixed-dt value (one GPU only)")
     ap.add_argument("--cfl-steps", type=int, default=40)
+    ap.add_argument("--emulate-rank", type=str, default=None, metavar="r/P",
+                    help="time rank r's share of the P-rank run on ONE GPU with a loop-back exchange (tools/rank_emulation.py); "
+                         "not the metric")
     return ap.parse_args()
 
 
@@ -137,7 +141,7 @@ CPU_CASES = {   # name -> (kind, size kwargs, share of the budget)
     "rb3d 64x64x32": ("rb3d", dict(Nx=64, Ny=64, Nz=32), 0.2),
     "rb3d 64x64x64": ("rb3d", dict(Nx=64, Ny=64, Nz=64), 0.3),
     "rb2d 512x256": ("rb2d", dict(Nx=512, Nz=256), 0.25),
-    "rb3d 128x128x64": ("rb3d", dict(Nx=128, Ny=128, Nz=64), 1.0),       # SURVEY 8(d); only with --cpu-budget >= 240
+    "rb3d 128x128x64": ("rb3d", dict(Nx=128, Ny=128, Nz=64), 1.0),       # the sample `value` extrapolates from
 }
 
 
@@ -195,31 +199,39 @@ def cpu_replicas(name, seconds, n, which="port"):
     return res
 
 
-def cpu_baseline(full_shape, budget_s=30.0, replicas=None):
-    """CPU baseline on this box's host cores (rank 0, N = 1 only), bounded samples of the same problem family -- 3-D RB
-    32^3, 64x64x32, 64^3, the 2-D config 512x256, and 128x128x64 when --cpu-budget allows:
-      * one core, one sample after the other ("port"; plus the unmodified reference on the same samples wherever
-        /root/reference exists: `reference_here`);
-      * `replicas`: n one-core copies of the 64^3 sample at once -> aggregate mode-stages per second of n cores.
-    The metric's size is far beyond host memory for the reference's algorithm, so `value` extrapolates the
-    n-core aggregate of the largest 3-D sample with the reference's own speed figure, mode-stages per cpu-second
-    (core/solvers.py:755-778).  `port_vs_reference` is the calibration of this port against the unmodified reference
-    (profiles/r5_cpu_port_vs_reference.json, tools/cpu_calibration.py: same machine, same samples, one core)."""
+def cpu_baseline(full_shape, budget_s=120.0, replicas=None):
+    """CPU baseline on this box's host cores (rank 0, N = 1 only), bounded samples of the same problem family:
+    3-D RB 32^3, 64x64x32, 64^3, **128x128x64** (the largest the budget allows: ~1 min of setup + three steps of ~7 s) and
+    the 2-D config 512x256:
+      * one core, one sample after the other ("port" = the oracle executor; plus the unmodified reference on small
+        samples wherever /root/reference exists: `reference_here`);
+      * `size_trend`: mode-stages per cpu-second of every 3-D sample -- the port's (and the reference's) rate FALLS with
+        size (SuperLU fill, cache misses), so the extrapolation starts from the LARGEST sample (`extrapolated_from`) and is
+        still an over-estimate of the CPU at the metric's size;
+      * `replicas`: n one-core copies of the 64^3 sample at once -> what n cores deliver together when nothing is
+        communicated (an upper bound for an n-rank MPI run); `per_core_vs_alone` is the memory-contention factor.
+    The metric's size is far beyond host memory for the reference's algorithm, so
+        value = n cores x per_core_vs_alone x (mode-stages per cpu-second of the largest sample) / (2 stages x modes of the metric)
+    with the reference's own speed figure (core/solvers.py:755-778).  `port_vs_reference` is the calibration of this port
+    against the unmodified reference AT THE LARGEST SAMPLE (profiles/r5_cpu_port_vs_reference.json, tools/cpu_calibration.py:
+    same machine, same sample, one core) -- not a mean over small cases."""
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     host = host_info()
     names = ["rb3d 32x32x32", "rb3d 64x64x32", "rb3d 64x64x64", "rb2d 512x256"]
     not_run = None
-    if budget_s >= 240:
+    if budget_s >= 100:
         names.append("rb3d 128x128x64")
     else:
-        not_run = ("rb3d 128x128x64 (SURVEY 8d): ~1 min of setup + ~10 s per step on one core, beyond the default "
-                   "--cpu-budget of %g s; run `python bench.py --cpu-budget 300`; measured on the build container in "
-                   "profiles/r5_cpu_port_vs_reference.json" % budget_s)
+        not_run = ("rb3d 128x128x64 (SURVEY 8d): ~1 min of setup + ~7 s per step on one core, beyond --cpu-budget %g s "
+                   "(default 120)" % budget_s)
     base = min(budget_s, 30.0)
     samples = [cpu_sample(n, CPU_CASES[n][2] * base * 0.5) for n in names]
-    big = [x for x in samples if x["case"].startswith("rb3d")][-1]           # the largest 3-D sample
+    s3 = [x for x in samples if x["case"].startswith("rb3d")]
+    big = max(s3, key=lambda x: x["modes"])                                  # the largest 3-D sample
+    s64 = [x for x in samples if x["case"] == "rb3d 64x64x64"][0]
     full_modes = 5 * int(np.prod(full_shape))
     one_core = big["mode_stages_per_cpu_s"] / (2 * full_modes)
+    size_trend = [dict(case=x["case"], modes=x["modes"], mode_stages_per_cpu_s=round(x["mode_stages_per_cpu_s"], 1)) for x in s3]
     # the reference itself, where it exists (the build container; the GPU box has no /root/reference)
     reference_here = None
     try:
@@ -238,31 +250,38 @@ def cpu_baseline(full_shape, budget_s=30.0, replicas=None):
         rs = cpu_replicas("rb3d 64x64x64", CPU_CASES["rb3d 64x64x64"][2] * base * 0.5, replicas)
         if rs:
             agg = sum(r["mode_stages_per_cpu_s"] for r in rs)
+            eff = (agg / len(rs)) / s64["mode_stages_per_cpu_s"]
             rep = dict(case="rb3d 64x64x64", replicas_started=replicas, replicas_finished=len(rs),
                        per_replica_steps_per_s=[round(r["steps_per_s"], 4) for r in rs],
-                       aggregate_mode_stages_per_s=agg,
-                       per_core_vs_alone=(agg / len(rs)) / samples[2]["mode_stages_per_cpu_s"])
-            cores, value = len(rs), agg / (2 * full_modes)
+                       aggregate_mode_stages_per_s=agg, per_core_vs_alone=eff)
+            cores, value = len(rs), len(rs) * eff * big["mode_stages_per_cpu_s"] / (2 * full_modes)
     calib = None
-    for tag in ("r5", "r2"):
+    for tag in ("r6", "r5"):
         cpath = os.path.join(ROOT, "profiles", "%s_cpu_port_vs_reference.json" % tag)
         if os.path.exists(cpath):
             cj = json.load(open(cpath))
-            calib = dict(geomean=cj["port_vs_reference_geomean"], measured_on=cj["host"]["cpu_model"],
-                         per_case={"%s %s" % (c["case"], "x".join(str(v) for v in c["size"].values())): round(c["port_vs_reference"], 3)
-                                   for c in cj["cases"]},
+            per_case = {"%s %s" % (c["case"], "x".join(str(v) for v in c["size"].values())): round(c["port_vs_reference"], 3)
+                        for c in cj["cases"]}
+            at_big = [v for k, v in per_case.items() if "128x128x64" in k]
+            calib = dict(at_largest_sample=(at_big[0] if at_big else None), geomean_all_cases=cj["port_vs_reference_geomean"],
+                         measured_on=cj["host"]["cpu_model"], per_case=per_case,
                          source="profiles/%s_cpu_port_vs_reference.json" % tag)
             break
+    ratio = (calib or {}).get("at_largest_sample") if big["case"].endswith("128x128x64") else None
     return dict(value=value, unit="timesteps/sec (extrapolated to the metric's size with mode-stages per cpu-second)",
                 cores=cores, kind=kind, host=host, cores_total=os.cpu_count(), one_core_value=one_core,
+                extrapolated_from=big["case"], size_trend=size_trend,
+                size_trend_note="the rate falls with size: extrapolating from the largest sample still overstates the CPU at "
+                                "the metric's size (64 x more modes per pencil system and 16 x more pencils)",
                 replicas=rep, not_run=not_run, reference_here=reference_here,
                 sample="%d bounded samples on 1 core, RK222 dt=1e-3: " % len(samples) + "; ".join(
                     "%s: %d steps in %.1f s = %.3f steps/s" % (x["case"], x["steps"], x["seconds"], x["steps_per_s"]) for x in samples)
-                       + ("; then %d one-core replicas of 64x64x64 at once" % cores if rep else "")
-                       + "; value = aggregate mode-stages/s of the %d core(s) on the %s sample / (2 stages x %d modes)"
-                       % (cores, big["case"] if not rep else "rb3d 64x64x64", full_modes),
+                       + ("; then %d one-core replicas of 64x64x64 at once (contention factor %.2f)" % (cores, rep["per_core_vs_alone"]) if rep else "")
+                       + "; value = %d core(s) x contention factor x mode-stages/s of the %s sample / (2 stages x %d modes)"
+                       % (cores, big["case"], full_modes),
                 samples=samples, port_vs_reference=calib,
-                reference_estimate=(value / calib["geomean"]) if calib else None)
+                reference_estimate=(value / ratio) if ratio else None,
+                reference_estimate_note="value / (port-vs-reference ratio measured at the extrapolation's own sample)")
 
 
 def parity_check(solver, dt):
@@ -326,6 +345,11 @@ def main():
     if args.cpu_worker:                          # one replica of cpu_replicas(): no GPU, no torch
         print(json.dumps(cpu_sample(args.cpu_worker, args.cpu_worker_seconds, args.cpu_worker_which)))
         return
+    if args.emulate_rank:                        # one rank of a sharded run on one GPU: its own tool, its own output
+        r, P = args.emulate_rank.split("/")
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "rank_emulation.py"), "--ranks", P, "--rank", r, "--size", args.size,
+               "--steps", str(args.steps), "--warmup", str(min(args.warmup, 5)), "--dt", str(args.dt)]
+        os.execv(cmd[0], cmd)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)                   # does not return
     import torch

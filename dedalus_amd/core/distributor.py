@@ -332,7 +332,8 @@ class Transformer:
             plan = ex.a2a_plan(pcomm, n0, n1, n2, n3) if hasattr(ex, "a2a_plan") else None
             if plan is not None:
                 (ex.a2a_localize_rows if which == "rows" else ex.a2a_localize_columns)(plan, src, dst)
-                pcomm.note_via("ddh_a2a_localize (library RCCL plan)", nbytes * (P - 1) // P)
+                pcomm.note_via("ddh_a2a_localize (%s plan)" % ("loop-back" if pcomm.backend == "loopback" else "library RCCL"),
+                               nbytes * (P - 1) // P)
                 return
             send = ex.empty((nbytes // 8,))
             recv = ex.empty((nbytes // 8,))

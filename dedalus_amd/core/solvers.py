@@ -783,7 +783,8 @@ class SolverBase:
         ex = self.ex
         if (os.environ.get("DDH_NO_RHS_TILING") is not None or not getattr(self.pack, "supports_tiled_rhs", False)
                 or self.nf != 2 or self.nx % 8 or self.ny % 8 or self.F_direct is None or self.P_id is None
-                or self.real_grading is None or self.nx * self.ny < 4 * 16384 or not hasattr(ex, "tiled_forward_ok")):
+                or self.real_grading is None or self.nx * self.ny < int(os.environ.get("DDH_RHS_TILING_MIN", 4 * 16384))
+                or not hasattr(ex, "tiled_forward_ok")):
             return 0
         if self.F_const is not None and np.any(np.asarray(self._F_const_index) % (self.nx * self.ny) != 0):
             return 0
@@ -1076,18 +1077,39 @@ class SolverBase:
         self._binv = dict(plan=plan, ns=ns, nh=nh, ng=ng, ncells=ncells, dev=None, rhs=None, x={}, n_set=None)
         return self._binv
 
+    def _drop_block_inverses(self, bi=None):
+        """Every registered explicit inverse is withdrawn from the library BEFORE its device memory is released (the
+        pack holds caller-owned pointers): the sweeps of the kept LU take over."""
+        bi = bi if isinstance(bi, dict) else getattr(self, "_binv", None)
+        if isinstance(bi, dict):
+            for k in list(bi["x"]):
+                self.pack.set_block_inverse(k, None)
+            bi["x"] = {}
+
     def _block_inverses(self, lu, a, b):
         bi = self._block_inverse_plan()
         if not bi:
             return
         ex, plan, ns, nh, ng = self.ex, bi["plan"], bi["ns"], bi["nh"], bi["ng"]
+        # a re-factorization (reuse=lu) changes (a, b): whatever inverse this id holds is stale until it has been re-formed
+        self.pack.set_block_inverse(lu, None)
         info = self.pack.lu_info(lu)                    # (the library's own view of the blocks must be the one planned for)
         if info["nsplit"] != ns or info["rows_per_block"] != nh or not info["real"] or info["pair"]:
+            self._drop_block_inverses(bi)
             self._binv = False
             return
         flagged = sorted(getattr(self.pack, "flagged", {}).get(lu, []))
+        nb = self.R - self.n_interior
+        if nb:
+            # Border (gauge) unknowns exist for the k = 0 pencil only (checked by the plan): blockinv_solve_kernel ignores
+            # the border coupling of every pencil it solves, so that pencil must be one of the FLAGGED ones (dense path).
+            # If its band block happens to be numerically regular (not flagged) the sweeps, which carry the Schur part, stay.
+            k0 = np.flatnonzero(np.arange(bi["ncells"]) + self.dist._mx_offset == 0)
+            if any(int(c) not in flagged for c in k0):
+                return
         if bi["dev"] is None or bi["n_set"] != flagged:
             # (the flagged pencils' blocks are singular: their groups are skipped -- a plan per set of flagged cells)
+            self._drop_block_inverses(bi)               # (inverses registered for the other set of cells go with their memory)
             plan.n = np.full(ng, nh, dtype=np.int32)
             for cell in flagged:
                 plan.n[cell * ns:(cell + 1) * ns] = 0
@@ -1101,12 +1123,10 @@ class SolverBase:
                 return
             bi["rhs"] = ex.from_host(np.eye(nh))
             bi["n_set"] = flagged
-            bi["x"] = {}
             logger.info("LHS of %d pencils: explicit inverses of %d x %d diagonal blocks (%d rows), %.2f GB per factorization"
                         % (bi["ncells"], ng, ns, nh, ng * nh * nh * 8 / 1e9))
         if lu not in bi["x"]:
             if len(bi["x"]) >= 2:                        # (schemes with many distinct implicit coefficients: keep the sweeps)
-                self.pack.set_block_inverse(lu, None)
                 return
             bi["x"][lu] = (len(bi["x"]), ex.zeros((ng, nh, nh)))
         idx, x = bi["x"][lu]
@@ -1114,12 +1134,42 @@ class SolverBase:
             bi["dev"].factor(a, b, index=idx)
         except Exception as e:                           # (a zero pivot in a block the pencil LU handled: keep the sweeps)
             logger.warning("block inverses switched off (%s)" % (e,))
-            for k in bi["x"]:
-                self.pack.set_block_inverse(k, None)
+            self._drop_block_inverses(bi)
             self._binv = False
             return
         bi["dev"].solve(idx, bi["rhs"], x)
+        if not self._block_inverse_residual_ok(bi, idx, x, a, b):
+            self._drop_block_inverses(bi)
+            self._binv = False
+            return
         self.pack.set_block_inverse(lu, x)
+
+    def _block_inverse_residual_ok(self, bi, idx, x, a, b, tol=1e-9):
+        """||B^T X^T - I||_max on sampled blocks (first, middle, last un-flagged group), formed on the host from the band
+        arrays the inverses were made of: an explicit inverse replaces a backward-stable LU solve by a multiplication with
+        B^-1 (error ~ cond(B) eps); above `tol` the sweeps stay.  Three blocks of <= 1024^2 doubles cross PCIe per
+        factorization."""
+        if os.environ.get("DDH_BLOCK_INVERSE_CHECK", "1") == "0":
+            return True
+        plan, nh = bi["plan"], bi["nh"]
+        live = np.flatnonzero(plan.n > 0)
+        if live.size == 0:
+            return True
+        worst = 0.0
+        for g in sorted({int(live[0]), int(live[live.size // 2]), int(live[-1])}):
+            band = a * plan.MB[g] + b * plan.LB[g]                      # [row of B^T][kl + (col - row)]
+            Bt = np.zeros((nh, nh))
+            for d in range(band.shape[1]):
+                off = d - plan.kl
+                i = np.arange(max(0, -off), min(nh, nh - off))
+                Bt[i, i + off] = band[i, d]
+            Xg = self.ex.download(x[g])                                 # slot s = row s of B^-1  ->  Xg = B^-1
+            worst = max(worst, float(np.abs(Xg @ Bt.T - np.eye(nh)).max()))
+        bi["residual"] = worst
+        if worst > tol:
+            logger.warning("explicit block inverses: ||X B - I|| = %.1e > %.0e, the sweeps stay" % (worst, tol))
+            return False
+        return True
 
 
 def _two_colour(n, row, col, label):
@@ -1244,11 +1294,16 @@ class InitialValueSolver(IVPLifecycle, SolverBase):
         # when every right-hand side is built from the state alone: a parameter field (a forcing the script may rewrite
         # between steps, the time field `t`) is uploaded by ordinary launches, which a replayed graph would not see
         state_ids = {id(v) for v in self.variables}
-        rhs_fields = set()
+        rhs_fields, opaque = set(), False
         for eq in self.equations:
-            if eq["F"] is not None and hasattr(eq["F"], "leaves"):
-                rhs_fields |= {id(f) for f in eq["F"].leaves() if not getattr(f, "_is_number", False)}
-        if rhs_fields <= state_ids:
+            F = eq["F"]
+            if F is None or isinstance(F, (int, float, complex)):
+                continue
+            if hasattr(F, "leaves"):
+                rhs_fields |= {id(f) for f in F.leaves() if not getattr(f, "_is_number", False)}
+            else:
+                opaque = True                    # (an object whose inputs cannot be listed: not provably state-only)
+        if not opaque and rhs_fields <= state_ids:
             self.step_graph_auto_modes = 1 << 22
         self.handlers = []
         from .output import OutputEvaluator

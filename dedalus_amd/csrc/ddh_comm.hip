@@ -71,6 +71,10 @@ static int check_nccl(ncclResult_t r, const char *what) {
 struct Comm : HandleBase {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    // ddh_comm_create_loopback: rank `rank` of `nranks` on ONE GPU, no peers.  Every block a peer would have sent is the
+    // block this rank sends to that peer (device copies on the caller's stream): sizes, pack / unpack kernels, stream
+    // ordering and the per-rank kernel shapes are those of the real run, the VALUES received are not.
+    bool loopback = false;
     ~Comm() override {
         if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
     }
@@ -97,6 +101,13 @@ static int exchange(A2aPlan *pl, hipStream_t s) {
     DDH_HIP(hipMemcpyAsync(pl->recv + (size_t)c->rank * chunk, pl->send + (size_t)c->rank * chunk, chunk * sizeof(double),
                            hipMemcpyDeviceToDevice, s));
     if (c->nranks == 1) return 0;
+    if (c->loopback) {
+        for (int p = 0; p < c->nranks; ++p)
+            if (p != c->rank)
+                DDH_HIP(hipMemcpyAsync(pl->recv + (size_t)p * chunk, pl->send + (size_t)p * chunk, chunk * sizeof(double),
+                                       hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
     DDH_NCCL(g_rccl.GroupStart());
     for (int p = 0; p < c->nranks; ++p) {
         if (p == c->rank) continue;
@@ -144,6 +155,18 @@ int ddh_comm_create(ddh_handle *comm, int rank, int nranks, const unsigned char 
     return 0;
 }
 
+int ddh_comm_create_loopback(ddh_handle *comm, int rank, int nranks) {
+    if (!comm) return fail("ddh_comm_create_loopback: null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("ddh_comm_create_loopback: rank out of range");
+    Comm *c = new Comm();
+    c->kind = H_COMM;
+    c->rank = rank;
+    c->nranks = nranks;
+    c->loopback = true;
+    *comm = register_handle(c);
+    return 0;
+}
+
 int ddh_comm_info(ddh_handle comm, int *rank, int *nranks) {
     Comm *c = (Comm *)lookup_handle(comm, H_COMM);
     if (!c) return -1;
@@ -156,6 +179,7 @@ int ddh_comm_allreduce(ddh_handle comm, double *buf, long count, int op, void *s
     Comm *c = (Comm *)lookup_handle(comm, H_COMM);
     if (!c) return -1;
     if (op < 0 || op > 2) return fail("ddh_comm_allreduce: op must be 0 (sum), 1 (max) or 2 (min)");
+    if (c->loopback) return 0;          // (this rank's own value stands for the reduction)
     const ncclRedOp_t ops[3] = {ncclSum, ncclMax, ncclMin};
     DDH_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ops[op], c->comm, as_stream(stream)));
     return 0;
@@ -173,6 +197,13 @@ int ddh_comm_alltoall(ddh_handle comm, const double *send, double *recv, long ch
     DDH_HIP(hipMemcpyAsync(recv + (size_t)c->rank * chunk, send + (size_t)c->rank * chunk, (size_t)chunk * sizeof(double),
                            hipMemcpyDeviceToDevice, s));
     if (c->nranks == 1) return 0;
+    if (c->loopback) {
+        for (int p = 0; p < c->nranks; ++p)
+            if (p != c->rank)
+                DDH_HIP(hipMemcpyAsync(recv + (size_t)p * chunk, send + (size_t)p * chunk, (size_t)chunk * sizeof(double),
+                                       hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
     DDH_NCCL(g_rccl.GroupStart());
     for (int p = 0; p < c->nranks; ++p) {
         if (p == c->rank) continue;
@@ -201,6 +232,14 @@ static int exchange_v(A2aPlan *pl, const std::vector<size_t> &cnt_s, const std::
         DDH_HIP(hipMemcpyAsync(pl->recv + disp_r[me], pl->send + disp_s[me], cnt_s[me] * sizeof(double),
                                hipMemcpyDeviceToDevice, s));
     if (c->nranks == 1) return 0;
+    if (c->loopback) {
+        for (int p = 0; p < c->nranks; ++p) {
+            const size_t cnt = cnt_s[p] < cnt_r[p] ? cnt_s[p] : cnt_r[p];
+            if (p != me && cnt)
+                DDH_HIP(hipMemcpyAsync(pl->recv + disp_r[p], pl->send + disp_s[p], cnt * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        return 0;
+    }
     DDH_NCCL(g_rccl.GroupStart());
     for (int p = 0; p < c->nranks; ++p) {
         if (p == me) continue;

@@ -1178,6 +1178,8 @@ static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nba
     return 0;
 }
 
+static long g_wave_launches = 0;      // ddh_fft_wave_launches
+
 template <int MODE>
 static int launch(FftPlan *pl, const double *src, double *dst, long outer, long inner, void *stream,
                   double dscale = 0.0, double *dst2 = nullptr, double dscale2 = 0.0, const double *dvec = nullptr) {
@@ -1192,10 +1194,12 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     if (!is_cfft && inner_mode) {
         // strided axis at an instantiated size: one wavefront per four line pairs (ddh_fftwave.hip)
         const int wst = wave_axis_try(MODE, d, src, dst, outer, inner, dst2, dvec, dscale, dscale2, as_stream(stream));
+        if (wst == 0) ++g_wave_launches;
         if (wst <= 0) return wst;
     }
     if (!is_cfft && !inner_mode) {
         const int wst = wave_contig_try(MODE, d, src, dst, outer, dst2, as_stream(stream));
+        if (wst == 0) ++g_wave_launches;
         if (wst <= 0) return wst;
     }
     if (d.xb && inner_mode) return fail("x-blocked stage layout (ddh_fft_set_stage_layout): only the strided-axis wave kernels at their "
@@ -1448,6 +1452,11 @@ int ddh_cheb_backward_dual(ddh_handle plan, const double *c, double *g, double *
     return launch<CHEB_BWD>(pl, c, g, outer, inner, stream, 0.0, g_deriv, 0.0, dvec);
 }
 DDH_FFT_ENTRY(ddh_cheb_forward, K_CHEB, CHEB_FWD)
+int ddh_fft_wave_launches(long *count) {
+    if (!count) return fail("ddh_fft_wave_launches: null pointer");
+    *count = g_wave_launches;
+    return 0;
+}
 int ddh_fft_set_stage_layout(ddh_handle plan, long value) {
     FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
     if (!pl) return -1;

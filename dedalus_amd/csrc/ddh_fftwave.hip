@@ -159,6 +159,17 @@ static int launch_wave_cheb(const FftDev &d, const WaveArgs &a, unsigned nwg, hi
     return 0;
 }
 
+template <int R, int NL>
+static int launch_wave_cheb_kind(int kind, const FftDev &d, const WaveArgs &a, unsigned nwg, hipStream_t st) {
+    constexpr int CH = wf::WaveCH<R>::ch;
+    switch (kind) {
+        case 3: return launch_wave_cheb<3, R, NL, CH>(d, a, nwg, st);
+        case 2: return launch_wave_cheb<2, R, NL, CH>(d, a, nwg, st);
+        case 1: return launch_wave_cheb<1, R, NL, CH>(d, a, nwg, st);
+        default: return launch_wave_cheb<0, R, NL, CH>(d, a, nwg, st);
+    }
+}
+
 // ---- Chebyshev along the CONTIGUOUS axis (the shell's radial transforms: [lines][192] <-> [lines][128]) ------------------
 // The same lane code on lines that are contiguous in memory: a wave takes 8 consecutive lines (4 pairs of lines 2 p, 2 p + 1).
 // Its loads follow the lane map directly (sixteen lanes of a row group read 128 contiguous bytes of one line); the grid rows
@@ -171,10 +182,10 @@ constexpr int WC_WAVES = 4;
 
 struct ContigArgs {
     const double *src;
-    double *dst;
+    double *dst, *dst2;
     long nlines;             // even
     unsigned ntiles, tpw;    // tiles of 8 lines, tiles per wave
-    int kind;                // backward: 0 plain, 2 conversion solve
+    int kind;                // backward: 0 plain, 1 dual (plain + derivative pass), 2 conversion solve
 };
 
 template <int R, int NL, int CH>
@@ -184,7 +195,7 @@ struct ChebContigLds {
     static constexpr int size = a > b ? a : b;                  // double2 per wave
 };
 
-template <int KIND, int R, int NL, int CH>      // KIND: 0 backward plain, 2 backward conversion, 3 forward
+template <int KIND, int R, int NL, int CH>      // KIND: 0 backward plain, 1 backward dual, 2 backward conversion, 3 forward
 __global__ void __launch_bounds__(64 * WC_WAVES, 2)
 wave_cheb_contig_kernel(FftDev p, ContigArgs a) {
     constexpr bool FWD = (KIND == 3);
@@ -204,7 +215,7 @@ wave_cheb_contig_kernel(FftDev p, ContigArgs a) {
         for (int i = tid; i < p.nbands * M; i += 64 * WC_WAVES) s_d[i] = p.bands[i];
     } else {
         for (int i = tid; i < 2 * M; i += 64 * WC_WAVES) s_d[i] = p.bsub ? p.bsub[i] : 0.0;
-        for (int i = tid; i < M; i += 64 * WC_WAVES) s_d[2 * M + i] = 0.0;
+        for (int i = tid; i < M; i += 64 * WC_WAVES) s_d[2 * M + i] = (KIND == 1 && p.dvec) ? p.dvec[i] : 0.0;
     }
     __syncthreads();                    // the only workgroup barrier
     wf::ChebTabs T;
@@ -243,6 +254,18 @@ wave_cheb_contig_kernel(FftDev p, ContigArgs a) {
             wf::cheb_bwd_load_contig<NL>(c, a.src + l0 * M, lsc, l0 + 2 * L.p < a.nlines, L);
         }
         double *stage = reinterpret_cast<double *>(S);
+        // staged lines -> global, 16 bytes per lane and step
+        auto copy_out = [&](double *out, long l0) {
+            WF_SYNC();
+#pragma unroll
+            for (int it = 0; it < (8 * (N / 2) + 63) / 64; ++it) {
+                const int ch = it * 64 + lane;
+                const int l = ch / (N / 2), j = ch - l * (N / 2);
+                if (ch < 8 * (N / 2) && l0 + l < a.nlines)
+                    *reinterpret_cast<double2 *>(out + (long)l * N + 2 * j) = *reinterpret_cast<const double2 *>(stage + l * NP + 2 * j);
+            }
+            WF_SYNC();
+        };
         for (unsigned i = 0; i < a.tpw; ++i) {
             const unsigned tile = tile_of(i);
             if (tile >= a.ntiles) break;
@@ -253,21 +276,19 @@ wave_cheb_contig_kernel(FftDev p, ContigArgs a) {
             const long l0n = more ? 8L * tn : l0;
             const bool validn = l0n + 2 * L.p < a.nlines;
             const unsigned lscn = more ? lsc : 0u;
-            if (KIND == 2)
-                wf::cheb_bwd_pass<R, NL, CH, 2, true, true>(c, S, T, stage, (unsigned)(NP * 8), valid, lane, a.src + l0n * M, lscn, validn);
-            else
-                wf::cheb_bwd_pass<R, NL, CH, 0, true, true>(c, S, T, stage, (unsigned)(NP * 8), valid, lane, a.src + l0n * M, lscn, validn);
-            WF_SYNC();
-            // staged lines -> global, 16 bytes per lane and step
-            double *out = a.dst + l0 * N;
-#pragma unroll
-            for (int it = 0; it < (8 * (N / 2) + 63) / 64; ++it) {
-                const int ch = it * 64 + lane;
-                const int l = ch / (N / 2), j = ch - l * (N / 2);
-                if (ch < 8 * (N / 2) && l0 + l < a.nlines)
-                    *reinterpret_cast<double2 *>(out + (long)l * N + 2 * j) = *reinterpret_cast<const double2 *>(stage + l * NP + 2 * j);
+            if (KIND == 1) {
+                // the plain pass keeps c for the derivative pass (field and d/dz from one read of the coefficients)
+                wf::cheb_bwd_pass<R, NL, CH, 0, false, true>(c, S, T, stage, (unsigned)(NP * 8), valid, lane, a.src + l0 * M, lsc, valid);
+                copy_out(a.dst + l0 * N, l0);
+                wf::cheb_bwd_pass<R, NL, CH, 1, true, true>(c, S, T, stage, (unsigned)(NP * 8), valid, lane, a.src + l0n * M, lscn, validn);
+                copy_out(a.dst2 + l0 * N, l0);
+            } else {
+                if (KIND == 2)
+                    wf::cheb_bwd_pass<R, NL, CH, 2, true, true>(c, S, T, stage, (unsigned)(NP * 8), valid, lane, a.src + l0n * M, lscn, validn);
+                else
+                    wf::cheb_bwd_pass<R, NL, CH, 0, true, true>(c, S, T, stage, (unsigned)(NP * 8), valid, lane, a.src + l0n * M, lscn, validn);
+                copy_out(a.dst + l0 * N, l0);
             }
-            WF_SYNC();
         }
     }
 }
@@ -288,33 +309,60 @@ static int launch_wave_cheb_contig(const FftDev &d, const ContigArgs &a, unsigne
     return 0;
 }
 
+template <int R, int NL>
+static int launch_wave_cheb_contig_kind(int kind, const FftDev &d, const ContigArgs &a, unsigned nwg, hipStream_t st) {
+    constexpr int CH = wf::WaveCH<R>::ch;
+    switch (kind) {
+        case 3: return launch_wave_cheb_contig<3, R, NL, CH>(d, a, nwg, st);
+        case 2: return launch_wave_cheb_contig<2, R, NL, CH>(d, a, nwg, st);
+        case 1: return launch_wave_cheb_contig<1, R, NL, CH>(d, a, nwg, st);
+        default: return launch_wave_cheb_contig<0, R, NL, CH>(d, a, nwg, st);
+    }
+}
+
+// The (grid, coefficient) sizes the wave Chebyshev kernels are instantiated for: N = 16 R grid points, M = 16 NL modes.
+// 3/2 dealiasing of 128 / 256 modes (the configurations' radial / vertical bases), no dealiasing (N = M = 64 .. 256) and
+// factor-two padding; everything else takes the workgroup-per-tile kernel of ddh_fft.hip.
+#define DDH_CHEB_WAVE_SIZES(X) X(24, 16) X(12, 8) X(16, 16) X(12, 12) X(8, 8) X(4, 4) X(16, 8) X(8, 4)
+
 // 0 = launched, 1 = shape not covered
 int wave_contig_try(int mode, const FftDev &d, const double *src, double *dst, long outer, double *dst2, hipStream_t st) {
     static const int on = getenv("DDH_CHEB_CONTIG_WAVE") ? atoi(getenv("DDH_CHEB_CONTIG_WAVE")) : 1;
-    if (!on || d.dbg || d.prof || d.xb || d.ctile_nseg || dst2) return 1;
+    if (!on || d.dbg || d.prof || d.xb || d.ctile_nseg) return 1;
     if (mode != CHEB_FWD && mode != CHEB_BWD) return 1;
-    if (d.N != 192 || d.M != 128 || (outer & 1) || outer < 2) return 1;            // instantiated size (R = 12, 8 rows per lane)
-    if (src == dst) return 1;
+    if ((outer & 1) || outer < 2) return 1;
+    if (src == dst || src == dst2) return 1;
     ContigArgs a;
     a.src = src;
     a.dst = dst;
+    a.dst2 = dst2;
     a.nlines = outer;
     const unsigned long ntiles = ((unsigned long)outer + 7) / 8;
     if (ntiles > 0x7fffffffUL) return 1;
     a.ntiles = (unsigned)ntiles;
     a.kind = 0;
-    if (mode == CHEB_BWD && d.nbands > 0) {
-        if (!(d.bsub && d.bsub_order == 1 && (d.gcd_off == 1 || d.gcd_off == 2))) return 1;
-        a.kind = 2;
+    if (mode == CHEB_BWD) {
+        if (dst2) {
+            if (!(d.bsub && d.bsub_order == 1 && (d.gcd_off == 1 || d.gcd_off == 2) && d.dvec)) return 1;
+            a.kind = 1;
+        } else if (d.nbands > 0) {
+            if (!(d.bsub && d.bsub_order == 1 && (d.gcd_off == 1 || d.gcd_off == 2))) return 1;
+            a.kind = 2;
+        }
+    } else if (dst2) {
+        return 1;
     }
     static const int env_tpw = getenv("DDH_CHEB_CONTIG_TPW") ? atoi(getenv("DDH_CHEB_CONTIG_TPW")) : 0;
     unsigned tpw = (unsigned)(env_tpw > 0 ? env_tpw : 4);
     while (tpw > 1 && ntiles / ((unsigned long)tpw * WC_WAVES) < 2048) tpw /= 2;
     a.tpw = tpw;
     const unsigned nwg = (unsigned)((ntiles + (unsigned long)tpw * WC_WAVES - 1) / ((unsigned long)tpw * WC_WAVES));
-    if (mode == CHEB_FWD) return launch_wave_cheb_contig<3, 12, 8, 3>(d, a, nwg, st);
-    if (a.kind == 2) return launch_wave_cheb_contig<2, 12, 8, 3>(d, a, nwg, st);
-    return launch_wave_cheb_contig<0, 12, 8, 3>(d, a, nwg, st);
+    const int kind = (mode == CHEB_FWD) ? 3 : a.kind;
+#define DDH_X(RV, NLV) \
+    if (d.N == 16 * RV && d.M == 16 * NLV) return launch_wave_cheb_contig_kind<RV, NLV>(kind, d, a, nwg, st);
+    DDH_CHEB_WAVE_SIZES(DDH_X)
+#undef DDH_X
+    return 1;
 }
 
 // ---- real Fourier, 3/2 dealiasing (N = 48 R, M = 32 R): RKIND 0 backward, 1 backward differentiated, 2 backward dual
@@ -370,6 +418,16 @@ static int launch_wave_rfft(const FftDev &d, const WaveArgs &a, unsigned nwg, hi
     return 0;
 }
 
+template <int R>
+static int launch_wave_rfft_kind(int rk, const FftDev &d, const WaveArgs &a, unsigned nwg, hipStream_t st) {
+    switch (rk) {
+        case 3: return launch_wave_rfft<3, R>(d, a, nwg, st);
+        case 2: return launch_wave_rfft<2, R>(d, a, nwg, st);
+        case 1: return launch_wave_rfft<1, R>(d, a, nwg, st);
+        default: return launch_wave_rfft<0, R>(d, a, nwg, st);
+    }
+}
+
 // Returns 0 when the transform was launched here, 1 when the shape is not covered (the caller then uses the
 // workgroup-per-tile kernel of ddh_fft.hip), < 0 on error.
 int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, long outer, long inner, double *dst2,
@@ -395,8 +453,15 @@ int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, lon
     if (!cheb && !rfft) return 1;
     if ((cheb && !(mask & 1)) || (rfft && !(mask & 2))) return 1;
     if (inner < 2 || (inner & 1)) return 1;
-    if (cheb && (d.N != 384 || d.M != 256)) return 1;           // instantiated sizes (R = 24, 16 rows per lane)
-    if (rfft && !((d.N == 768 && d.M == 512) || (d.N == 384 && d.M == 256))) return 1;     // N = 48 R, M = 32 R
+    if (cheb) {
+        bool have = false;
+#define DDH_X(RV, NLV) have = have || (d.N == 16 * RV && d.M == 16 * NLV);
+        DDH_CHEB_WAVE_SIZES(DDH_X)
+#undef DDH_X
+        if (!have) return 1;
+    }
+    // real FFT with 3/2 padding: N = 48 R, M = 32 R for the instantiated R = 4, 8, 12, 16 (128 .. 512 modes)
+    if (rfft && !(d.N % 48 == 0 && 3 * d.M == 2 * d.N && (d.N == 192 || d.N == 384 || d.N == 576 || d.N == 768))) return 1;
     if (rfft && d.K != d.M / 2 - 1) return 1;
     const long npairs = inner / 2;
     const long tpo = (npairs + 3) / 4;
@@ -442,21 +507,20 @@ int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, lon
     if (rfft) {
         if (dst2 && dscale != 0.0) return 1;                    // the dual entry point transforms plainly into dst
         const int rk = (mode == RFFT_FWD) ? 3 : (dst2 ? 2 : (dscale != 0.0 ? 1 : 0));
-        if (d.N == 768) {
-            if (rk == 3) return launch_wave_rfft<3, 16>(dd, a, nwg, st);
-            if (rk == 2) return launch_wave_rfft<2, 16>(dd, a, nwg, st);
-            if (rk == 1) return launch_wave_rfft<1, 16>(dd, a, nwg, st);
-            return launch_wave_rfft<0, 16>(dd, a, nwg, st);
+        switch (d.N / 48) {
+            case 16: return launch_wave_rfft_kind<16>(rk, dd, a, nwg, st);
+            case 12: return launch_wave_rfft_kind<12>(rk, dd, a, nwg, st);
+            case 8: return launch_wave_rfft_kind<8>(rk, dd, a, nwg, st);
+            case 4: return launch_wave_rfft_kind<4>(rk, dd, a, nwg, st);
         }
-        if (rk == 3) return launch_wave_rfft<3, 8>(dd, a, nwg, st);
-        if (rk == 2) return launch_wave_rfft<2, 8>(dd, a, nwg, st);
-        if (rk == 1) return launch_wave_rfft<1, 8>(dd, a, nwg, st);
-        return launch_wave_rfft<0, 8>(dd, a, nwg, st);
+        return 1;
     }
-    if (mode == CHEB_FWD) return launch_wave_cheb<3, 24, 16, 2>(dd, a, nwg, st);
-    if (a.kind == 1) return launch_wave_cheb<1, 24, 16, 2>(dd, a, nwg, st);
-    if (a.kind == 2) return launch_wave_cheb<2, 24, 16, 2>(dd, a, nwg, st);
-    return launch_wave_cheb<0, 24, 16, 2>(dd, a, nwg, st);
+    const int ck = (mode == CHEB_FWD) ? 3 : a.kind;
+#define DDH_X(RV, NLV) \
+    if (d.N == 16 * RV && d.M == 16 * NLV) return launch_wave_cheb_kind<RV, NLV>(ck, dd, a, nwg, st);
+    DDH_CHEB_WAVE_SIZES(DDH_X)
+#undef DDH_X
+    return 1;
 }
 
 }  // namespace ddh

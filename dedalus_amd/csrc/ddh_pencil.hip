@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace ddh {
 
@@ -375,6 +376,14 @@ __device__ __forceinline__ SysId sys_id(const PencilDev &P, const LuDev &L, long
         id.gl = REAL ? id.cell : g;
     }
     return id;
+}
+
+// wave-uniform: every lane of the wave works and the four lanes of each quad share one stored factorization -- the waves
+// solve_backward_ring_kernel takes; the others (unpaired cells of the axes and the diagonal, a ragged last wave) are left
+// to solve_backward_kernel<..., DBG = 64>
+__device__ __forceinline__ bool ring_wave(const SysId &id, int lane) {
+    const long gl_q = __shfl(id.gl, lane & ~3);
+    return __builtin_amdgcn_readfirstlane((int)(__ballot(id.ok && gl_q == id.gl) == ~0ull)) != 0;
 }
 
 // real factor of a term for the +kx system; the -kx system multiplies by (-1)^ex
@@ -1819,6 +1828,9 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x - (long)blk * L.Gp;
     const int row0 = (REAL && L.nsplit > 1) ? blk * L.nh : 0, row1 = (REAL && L.nsplit > 1) ? row0 + L.nh : n;
     const SysId id = sys_id<REAL>(P, L, g);
+    if constexpr ((DBG & 64) != 0) {                 // only the waves solve_backward_ring_kernel leaves out (ring_wave)
+        if (ring_wave(id, (int)(threadIdx.x & 63))) return;
+    }
     if (!id.ok) return;
     const int s = id.s;
     const CellCtx c = cell_ctx(P, id.cell);
@@ -1988,6 +2000,222 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
             row_even(row0, ua, ya, pa);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward sweep of the real-graded two-axis path with the factor rows and the forward sweep's vector y staged through a
+// per-wave LDS RING filled by LDS-DMA (buffer_load_dwordx4 ... lds), D rows ahead.
+//
+// solve_backward_kernel<2, 17, true, false, true, 0, 4> (the kernel this one replaces at 512^2 pencils) has no prefetch at
+// all: its 128 registers hold the solution window, and a row is "request 9 + 1 loads, wait one HBM round trip, 40 FMAs,
+// store" with only the four waves of a SIMD to hide each other's round trips -- 3.6 TB/s, 0.42 of the wave cycles waiting
+// on memory.  A register prefetch costs the fourth wave (tried: slower).  LDS-DMA loads have NO destination registers, so
+// the rows of the next D steps can be in flight whatever the register file holds:
+//   * the four lanes that share a factorization (P, Q systems of a cell and of its transposed partner: sys_id) used to
+//     request the same 16 bytes four times; here the wave fetches each row ONCE: lane l of DMA instruction i brings entry
+//     pair q = 4 i + l / 16 of the factorization of lane group l % 16 -- 9 x 256 B per row in three instructions -- and every
+//     lane reads its pairs back with broadcast ds_read_b128 (four lanes per address: conflict free);
+//   * y (64 x 16 contiguous bytes per row) comes by one more DMA instruction;
+//   * the loads are hand-issued and waited for with s_waitcnt vmcnt(NV (D - 1)): loads retire in order among themselves,
+//     so "at most the NV (D - 1) operations of the D - 1 younger rows outstanding" means row j has landed whatever the
+//     stores of x in between do (csrc/ddh_gridwave2.hip uses the same argument); past the end of the sweep the wave keeps
+//     requesting its last row so that the count stays uniform.
+// Same arithmetic in the same order as solve_backward_kernel: results are bit-identical (tests/test_gpu_pencil.py).
+// Waves whose lane quads do not share factorizations (the unpaired cells of the axes and the diagonal, a ragged last
+// wave) take the direct-load loop of the old kernel.
+// Replaces the back substitution of the reference's per-pencil SuperLU solve (libraries/matsolvers.py:126-149,
+// core/timesteppers.py:630-643).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void *ddh_ldsptr;
+
+__device__ __forceinline__ void ring_dma16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned lds_dst, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rs), "s"(lds_dst), "s"(soff)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ring_wait() {
+    static_assert(N >= 0 && N <= 32, "vmcnt immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else static_assert(N % 4 == 0 && N <= 20, "instantiated depths");
+}
+
+template <int WT>
+struct BwdRing {
+    static constexpr int NQ = (WT + 2) / 2;           // entry pairs of a row from the diagonal on (WT + 1 entries)
+    static constexpr int NI = (NQ + 3) / 4;           // DMA instructions per factor row (four pairs x 16 factorizations each)
+    static constexpr int FB = NQ * 256;               // factor bytes per row and wave
+    static constexpr int SLOT = FB + 1024;            // + y
+    static constexpr int NV = NI + 1;                 // vector-memory operations per row
+};
+
+template <int WT, int D, int MINW>
+__global__ void __launch_bounds__(256, MINW)
+solve_backward_ring_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const double *__restrict__ pband,
+                           const unsigned char *__restrict__ skip) {
+    constexpr int NF = 2;
+    using RG = BwdRing<WT>;
+    static_assert(RG::NV == 4, "ring_wait immediates are multiples of four");
+    static_assert((WT & 1) == 1, "an even number of entries per row: WT + 1");
+    extern __shared__ int s_lds[];
+    const int n = L.n, nb = L.nb, kl = L.kl;
+    int *s_perm = s_lds;
+    int *s_perm2 = s_lds + (L.pair ? n : 0);
+    unsigned char *s_code = (unsigned char *)(s_perm2 + n);
+    unsigned char *s_skip = s_code + n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        s_perm[i] = L.colperm[i];
+        if (L.pair) s_perm2[i] = L.colperm2[i];
+        s_code[i] = L.col_code[i];
+        s_skip[i] = skip ? (skip[L.colperm[i]] && (!L.pair || skip[L.colperm2[i]])) : 0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // this wave's ring: behind the tables, 1 KiB aligned relative to the start of the dynamic LDS
+    const unsigned tab_bytes = (unsigned)(((size_t)n * (L.pair ? 10 : 6) + 1023) & ~(size_t)1023);
+    char *ring = reinterpret_cast<char *>(s_lds) + tab_bytes + (size_t)wave * (D * RG::SLOT);
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(ddh_ldsptr)ring);
+
+    const int blk = (L.nsplit > 1) ? __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x) / L.Gp)) : 0;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x - (long)blk * L.Gp;
+    const int row0 = (L.nsplit > 1) ? blk * L.nh : 0, row1 = (L.nsplit > 1) ? row0 + L.nh : n;
+    const SysId id = sys_id<true>(P, L, g);
+    if (!ring_wave(id, lane)) return;                // (solve_backward_kernel<..., 64> sweeps this wave's systems)
+    const int s = id.s;
+    const CellCtx c = cell_ctx(P, id.cell);
+    const long G = id.G;
+    const int *my_perm = id.partner ? s_perm2 : s_perm;
+    const bool conjq = id.partner && s == 1;
+    const long plane = P.nx * P.ny;
+
+    double2 win[WT];   // win[d] = x[j+1+d] (graded)
+#pragma unroll
+    for (int d = 0; d < WT; ++d) {
+        win[d] = make_double2(0.0, 0.0);
+        if (d < nb && row1 == n) win[d] = L.scratch[(long)(n + d) * G + g];
+    }
+    unsigned dma_voff, y_lane, ur_row8, y_row16;
+    __amdgpu_buffer_rsrc_t ur_rs, y_rs;
+    {
+        const double *const ur0 = (const double *)L.Aw + lu_aw(L, id.gl, 0, kl);     // row 0, diagonal
+        const double2 *const y0 = L.scratch + g;
+        ur_rs = wave_rsrc(ur0);
+        y_rs = wave_rsrc(y0);
+        y_lane = wave_lane_off(y0);
+        ur_row8 = (unsigned)L.BW << 9;
+        y_row16 = (unsigned)(G * (long)sizeof(double2));
+        // DMA role of this lane: entry pair (lane >> 4) (+ 4 per instruction) of the factorization of lane quad (lane & 15)
+        dma_voff = (unsigned)__shfl((int)wave_lane_off(ur0), 4 * (lane & 15)) + ((unsigned)(lane >> 4) << 10);
+    }
+    // the ring is read through LDS addresses of this lane: pair q of its factorization at q * 256 + (lane / 4) * 16, y behind
+    const unsigned rd_u = (unsigned)(lane >> 2) * 16u, rd_y = (unsigned)RG::FB + (unsigned)lane * 16u;
+
+    auto emit = [&](int j, double2 v) {
+        if (s_skip[j]) return;                           // wave-uniform
+        const unsigned char code = s_code[j];
+        if (code & 1) v = make_double2(-v.y, v.x);
+        if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+        if (conjq) v.y = -v.y;
+        store_sys<NF>(xout, plane, my_perm[j], P, c, s, v);
+    };
+    unsigned slot_issue = 0;                         // byte offset of the slot the next request fills (uniform)
+    auto issue = [&](int j) {
+        const int jj = j < row0 ? row0 : j;          // past the end: the last row again (keeps the operation count uniform)
+        const unsigned dst = ring_lds + slot_issue;
+        const unsigned urow = (unsigned)jj * ur_row8;
+#pragma unroll
+        for (int i = 0; i < RG::NI; ++i) {
+            if (4 * (i + 1) <= RG::NQ) {
+                ring_dma16(dma_voff, ur_rs, dst + 1024u * i, urow + 4096u * i);
+            } else if (4 * i + (lane >> 4) < RG::NQ) {           // the last instruction brings NQ - 4 i pairs
+                ring_dma16(dma_voff, ur_rs, dst + 1024u * i, urow + 4096u * i);
+            }
+        }
+        ring_dma16(y_lane, y_rs, dst + RG::FB, (unsigned)jj * y_row16);
+        slot_issue += RG::SLOT;
+        if (slot_issue == (unsigned)(D * RG::SLOT)) slot_issue = 0;
+    };
+    unsigned slot_read = 0;
+    // One row: x_j = (y_j - sum_d U[j, j + d] x_(j + d)) / U[j, j], emitted as x_j + sum_d P[j, j + d] x_(j + d).
+    // ODD: the row above (j + 1) was solved in this pair and sits in `xprev`, the window still starts at j + 2.
+    // The entry pairs are read from the ring three at a time, between the multiply-adds that consume them (the window
+    // fills the register file: 36 more registers for a whole row would spill).
+    auto row = [&](int j, auto odd_tag, double2 xprev) -> double2 {
+        constexpr bool ODD = decltype(odd_tag)::value;
+        ring_wait<RG::NV * (D - 1)>();               // row j has landed (the D - 1 younger requests may be in flight)
+        const char *rs = ring + slot_read;
+        double2 acc = *reinterpret_cast<const double2 *>(rs + rd_y);
+        double pr[PBW];
+        {
+            const double *prow = pband + (long)j * PBW;
+#pragma unroll
+            for (int d = 0; d < PBW; ++d) pr[d] = prow[d];
+        }
+        double piv = 0.0;
+#pragma unroll
+        for (int q = 0; q < RG::NQ; ++q) {
+            const double2 uu = *reinterpret_cast<const double2 *>(rs + rd_u + 256 * q);
+            // entries 2 q, 2 q + 1 of the row: entry e multiplies x_(j + e)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 2 * q + h;
+                const double ue = h ? uu.y : uu.x;
+                if (e == 0) {
+                    piv = ue;                            // reciprocal pivot
+                } else if (e <= WT) {
+                    if (ODD) {
+                        if (e == 1) El<true>::fms2(acc, ue, xprev);
+                        else El<true>::fms2(acc, ue, win[e - 2]);
+                    } else {
+                        El<true>::fms2(acc, ue, win[e - 1]);
+                    }
+                }
+            }
+            if (q % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        const double2 xj = El<true>::mul2(acc, piv);
+        // the slot has been read by every lane: request row j - D into it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue(j - D);
+        slot_read += RG::SLOT;
+        if (slot_read == (unsigned)(D * RG::SLOT)) slot_read = 0;
+        double2 v = xj;
+        if (ODD) {
+            v.x += pr[0] * xprev.x;
+            v.y += pr[0] * xprev.y;
+#pragma unroll
+            for (int d = 1; d < PBW; ++d)
+                if (d - 1 < WT) { v.x += pr[d] * win[d - 1].x; v.y += pr[d] * win[d - 1].y; }
+        } else {
+#pragma unroll
+            for (int d = 0; d < PBW; ++d)
+                if (d < WT) { v.x += pr[d] * win[d].x; v.y += pr[d] * win[d].y; }
+        }
+        emit(j, v);
+        return xj;
+    };
+    int j = row1 - 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(j - d);
+    while (j >= row0 + 1) {
+        const double2 xe = row(j, std::false_type(), make_double2(0.0, 0.0));
+        const double2 xo = row(j - 1, std::true_type(), xe);
+#pragma unroll
+        for (int d = WT - 1; d > 1; --d) win[d] = win[d - 2];
+        win[1] = xe;
+        win[0] = xo;
+        j -= 2;
+    }
+    if (j == row0) row(row0, std::false_type(), make_double2(0.0, 0.0));
+    ring_wait<0>();                                  // nothing of this wave may land in LDS after it has gone
 }
 
 // Border unknowns of a forward sweep that ran one thread per (system, block) (LuDev::nsplit > 1): the blocks' partial
@@ -2630,7 +2858,26 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     if (fuse_p) {
         if constexpr (NF == 2) {
             static const int occ4 = getenv("DDH_SWEEP_OCC") ? atoi(getenv("DDH_SWEEP_OCC")) == 4 : 1;
-            if (W <= 17 && d.nsplit > 1 && occ4)
+            // DDH_BWD_RING = D: factor rows and y through a per-wave LDS-DMA ring D rows deep (solve_backward_ring_kernel);
+            // 0 = direct loads.  LDS per workgroup: the permutation tables + 4 waves x D x 3.25 KiB.
+            static const int ring = getenv("DDH_BWD_RING") ? atoi(getenv("DDH_BWD_RING")) : 2;
+            const size_t tab = (((size_t)d.n * (d.pair ? 10 : 6)) + 1023) & ~(size_t)1023;
+            if (W <= 17 && d.nsplit > 1 && occ4 && d.pair && ring >= 2 && ring <= 4 && P.G % 4 == 0) {
+                const size_t lds_r = tab + (size_t)4 * ring * BwdRing<17>::SLOT;
+#define DDH_RING(DV, MW)                                                                                                   \
+    {                                                                                                                      \
+        auto kern = solve_backward_ring_kernel<17, DV, MW>;                                                                \
+        if (lds_r > 64 * 1024)                                                                                             \
+            DDH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));      \
+        hipLaunchKernelGGL(kern, dim3(blocks_split), dim3(256), lds_r, s, P, d, x, d.pband, rhs.skip);                     \
+    }
+                if (ring == 2) DDH_RING(2, 4)
+                else if (ring == 3) DDH_RING(3, 3)
+                else DDH_RING(4, 2)
+#undef DDH_RING
+                // the waves whose lane quads do not share a factorization (unpaired cells, a ragged last wave)
+                hipLaunchKernelGGL((solve_backward_kernel<NF, 17, true, false, true, 64, 4>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
+            } else if (W <= 17 && d.nsplit > 1 && occ4)
                 hipLaunchKernelGGL((solve_backward_kernel<NF, 17, true, false, true, 0, 4>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
             else if (W <= 17) DDH_SOLVE_P(17)
             else if (W <= 32) DDH_SOLVE_P(32)
@@ -3050,6 +3297,7 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
     const size_t esz = real ? sizeof(double) : sizeof(double2);
     if (reuse) {
         lu = pp->lus[reuse_lu_id];
+        lu->d_binv = nullptr;       // an explicit block inverse belongs to the OLD (a, b): the caller registers a new one
     } else {
         lu = new LuFactor();
         LuDev &d = lu->dev;
@@ -3295,7 +3543,7 @@ int ddh_pencil_set_block_inverse(ddh_handle pack, int lu_id, const double *binv_
     LuFactor *lu = pp->lus[lu_id];
     if (binv_d) {
         const LuDev &d = lu->dev;
-        if (pp->dev.nf != 1 || !d.real || d.pair || d.nsplit < 1 || d.n != d.nsplit * d.nh || d.nh > 8192)
+        if (pp->dev.nf != 1 || !d.real || d.pair || d.nsplit < 1 || d.n != d.nsplit * d.nh || d.nh > 4096)     // (nh * 16 B of LDS per workgroup)
             return fail("pencil_set_block_inverse: one Fourier axis, real-graded factors, equal diagonal blocks");
     }
     lu->d_binv = binv_d;

@@ -109,6 +109,8 @@ DDH_DEV double2 mul_root(double2 a, int m, int sign) {
 template <int R>
 DDH_DEV void dft_inlane(double2 *v, int sign);
 template <>
+DDH_DEV void dft_inlane<4>(double2 *v, int sign) { butterfly<4>(v, sign); }
+template <>
 DDH_DEV void dft_inlane<8>(double2 *v, int sign) { butterfly<8>(v, sign); }
 template <>
 DDH_DEV void dft_inlane<16>(double2 *v, int sign) { butterfly<16>(v, sign); }
@@ -138,6 +140,13 @@ template <>
 DDH_DEV void dft_inlane<24>(double2 *v, int sign) { dft_inlane_3A<8>(v, sign); }
 template <>
 DDH_DEV void dft_inlane<12>(double2 *v, int sign) { dft_inlane_3A<4>(v, sign); }
+
+// default number of exchange chunks of wfft<R>: two where R / 4 is even, else three (R = 12) or one (R = 4)
+template <int R>
+struct WaveCH {
+    static constexpr int RQ = R / 4;
+    static constexpr int ch = (RQ % 2 == 0) ? 2 : ((RQ % 3 == 0) ? 3 : 1);
+};
 
 // LDS elements (double2) of the exchange buffer wfft<R, ., CH> needs
 template <int R, int CH>
@@ -541,7 +550,7 @@ template <int R>
 struct RfftWaveLds {
     static constexpr int a = 16 * R * 4;                 // natural-order exchange of N/3 values x 4 pairs (forward); half of the
                                                          // coefficient rows (backward staging: 8 R modes x 2 rows x 4 pairs)
-    static constexpr int b = WfftBuf<R, 2>::size;
+    static constexpr int b = WfftBuf<R, WaveCH<R>::ch>::size;
     static constexpr int park = (R >= 16) ? 128 : 0;     // two more parking slots per lane for the backward tile (see there):
                                                          // 8 waves x 18 KiB + the 12 KiB table = 156 of the CU's 160 KiB
     static constexpr int size = (a > b ? a : b) + park;
@@ -610,7 +619,7 @@ DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, u
     // (the differentiated and the dual transform exchange in four chunks instead of two: half the exchange buffer = four
     //  more parking slots per lane; with 9 slots the dual kernel still spilled 60 bytes per lane at 256 registers -- 1.16 x
     //  its algorithmic HBM traffic --, with 13 none: 1.38 -> 1.29 ms at 512^2 x 384)
-    constexpr int CHX = (R >= 16 && BK != 0) ? 4 : 2;
+    constexpr int CHX = (R >= 16 && BK != 0) ? 4 : WaveCH<R>::ch;
     constexpr int XB = WfftBuf<R, CHX>::size;
     constexpr int ZLmax = (RfftWaveLds<R>::size - XB) / 64;
     constexpr int ZLwant = (R >= 16) ? (BK == 2 ? 13 : (BK == 1 ? 12 : 4)) : 0;
@@ -689,7 +698,6 @@ template <int R>
 DDH_DEV void rfft_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, unsigned rsb64, bool pvalid, double2 *S,
                            const double2 *tw, int lane) {      // rsb64: see rfft_bwd_tile (coefficient side = dst here)
     constexpr int H = 16 * R, N = 3 * H, RQ = R / 4;
-    static_assert((H & (H - 1)) == 0, "N / 3 must be a power of two here");
     const double s3 = 0.86602540378443864676372317075293618;
     double2 P[R], Q[R];                                  // X[j], X[N - (H - j)] at the wfft output slots j
 #pragma unroll
@@ -706,7 +714,7 @@ DDH_DEV void rfft_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, uns
             for (int t = 0; t < R; ++t) v[t] = gload(src_t, o0 + (unsigned)(48 * t) * rsb);
         }
         WF_SCHED_FENCE();
-        wfft<R, -1, 2, 3>(v, S, tw, Lr);
+        wfft<R, -1, WaveCH<R>::ch, 3>(v, S, tw, Lr);
         const double2 *twr = tw + r * (R * Lr.q0 + RQ * Lr.q1);       // exp(-2 pi i r j / N), j = R (q0 + 4 a0) + RQ q1 + i
 #pragma unroll
         for (int a0 = 0; a0 < 4; ++a0)
@@ -751,7 +759,7 @@ DDH_DEV void rfft_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, uns
     const double2 *Sm = S + (16 - L.q) * 4 + L.p;
 #pragma unroll
     for (int t = 0; t < R; ++t) {
-        const double2 z2 = (t == 0) ? S[((H - L.q) & (H - 1)) * 4 + L.p] : Sm[16 * (R - 1 - t) * 4];
+        const double2 z2 = (t == 0) ? S[(L.q == 0 ? 0 : H - L.q) * 4 + L.p] : Sm[16 * (R - 1 - t) * 4];
         double2 c = make_double2((z1[t].x + z2.x) * invN, (z1[t].y + z2.y) * invN);
         double2 s = make_double2((z1[t].y - z2.y) * invN, (z2.x - z1[t].x) * invN);
         if (t == 0 && L.q == 0) {                        // k = 0

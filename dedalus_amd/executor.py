@@ -192,15 +192,20 @@ class HipExecutor:
             libhip.call("ddh_fft_set_stage_layout", h, int(value))
             cur[h.value] = int(value)
 
+    # (grid, coefficient) sizes the wave-per-four-line-pairs kernels are instantiated for (csrc/ddh_fftwave.hip:
+    # DDH_CHEB_WAVE_SIZES, launch_wave_rfft_kind)
+    WAVE_CHEB_SIZES = frozenset([(384, 256), (192, 128), (256, 256), (192, 192), (128, 128), (64, 64), (256, 128), (128, 64)])
+    WAVE_RFFT_SIZES = frozenset([(768, 512), (576, 384), (384, 256), (192, 128)])
+
     def stage_layout_ok(self, zspec, xspec, nx, ny):
         """Can the array between the z and the x transforms be x-blocked?  (both run as strided wave kernels)"""
-        return (zspec[0] == "cheb" and (int(zspec[1]), int(zspec[2])) == (384, 256) and xspec[0] == "rfft"
-                and (int(xspec[1]), int(xspec[2])) in ((768, 512), (384, 256)) and nx % 64 == 0 and ny % 8 == 0
+        return (zspec[0] == "cheb" and (int(zspec[1]), int(zspec[2])) in self.WAVE_CHEB_SIZES and xspec[0] == "rfft"
+                and (int(xspec[1]), int(xspec[2])) in self.WAVE_RFFT_SIZES and nx % 64 == 0 and ny % 8 == 0
                 and int(xspec[2]) == nx)
 
     def tiled_forward_ok(self, spec, basis, inner, row_len):
         """Can `transform(..., "forward", tiled_row=row_len)` run?  (the strided-axis wave kernel's sizes)"""
-        return (spec[0] == "cheb" and int(spec[1]) == 384 and int(spec[2]) == 256 and inner > 1
+        return (spec[0] == "cheb" and (int(spec[1]), int(spec[2])) in self.WAVE_CHEB_SIZES and inner > 1
                 and row_len % 8 == 0 and inner % row_len == 0 and (inner // row_len) % 8 == 0)
 
     def _transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0, tiled_row=0, xb=0):
@@ -310,9 +315,15 @@ class HipExecutor:
         libhip.call("ddh_a2a_localize_columns", plan, ptr(rl), ptr(cl), self.dev.stream)
 
     def a2a_pack(self, src, dst, outer, na, nb, inner, P):
+        if self.timer is not None:           # (bytes: one read + one write of the packed buffer)
+            return self.timer.run("a2a_pack", 2 * dst.numel() * 8, libhip.call, "ddh_a2a_pack", ptr(src), ptr(dst), outer, na, nb,
+                                  inner, P, self.dev.stream)
         libhip.call("ddh_a2a_pack", ptr(src), ptr(dst), outer, na, nb, inner, P, self.dev.stream)
 
     def a2a_unpack(self, src, dst, outer, na, nb, inner, P):
+        if self.timer is not None:
+            return self.timer.run("a2a_unpack", 2 * src.numel() * 8, libhip.call, "ddh_a2a_unpack", ptr(src), ptr(dst), outer, na,
+                                  nb, inner, P, self.dev.stream)
         libhip.call("ddh_a2a_unpack", ptr(src), ptr(dst), outer, na, nb, inner, P, self.dev.stream)
 
     def make_recombination(self, slot_map, mats):

@@ -92,6 +92,7 @@ SIGNATURES = {
     "ddh_cheb_forward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_cheb_forward_tiled": [_h, _vp, _vp, _l, _l, _l, _vp],
     "ddh_fft_set_stage_layout": [_h, _l],
+    "ddh_fft_wave_launches": [C.POINTER(_l)],
     "ddh_cheb_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_plan_mmt": [_hp, _i, _i, _dp],
     "ddh_mmt_apply": [_h, _vp, _vp, _l, _l, _vp],
@@ -130,6 +131,7 @@ SIGNATURES = {
     "ddh_comm_probe": [],
     "ddh_comm_unique_id": [C.POINTER(C.c_ubyte)],
     "ddh_comm_create": [_hp, _i, _i, C.POINTER(C.c_ubyte)],
+    "ddh_comm_create_loopback": [_hp, _i, _i],
     "ddh_comm_info": [_h, _ip, _ip],
     "ddh_comm_allreduce": [_h, _vp, _l, _i, _vp],
     "ddh_comm_alltoall": [_h, _vp, _vp, _l, _vp],

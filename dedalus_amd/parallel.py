@@ -37,7 +37,81 @@ class _StreamWork:
         return True
 
 
+def emulated_rank():
+    """(rank, size) when this process emulates ONE rank of a sharded run on one GPU (DDH_EMULATE_RANK="r/P",
+    tools/rank_emulation.py), else None."""
+    v = os.environ.get("DDH_EMULATE_RANK")
+    if not v:
+        return None
+    r, P = (int(x) for x in v.split("/"))
+    if not (0 <= r < P):
+        raise ValueError("DDH_EMULATE_RANK=%s: rank out of range" % v)
+    return r, P
+
+
+class LoopbackComm:
+    """Rank r of P with no peers (DDH_EMULATE_RANK): the problem is decomposed exactly as for P ranks, this process owns
+    rank r's pencils / z planes and runs rank r's kernels -- pack, exchange entry points, unpack, the per-component
+    side-stream pipeline -- while every exchange returns the rank's own send blocks (ddh_comm_create_loopback: device
+    copies in place of the wire).  For TIMING a rank's share of the sharded problem on one GPU; the values are not those
+    of the P-rank run, reductions return this rank's contribution only."""
+
+    backend = "loopback"
+
+    def __init__(self, size):
+        import torch
+        r, P = emulated_rank()
+        if P != size:
+            raise ValueError("mesh size %d does not match DDH_EMULATE_RANK (%d ranks)" % (size, P))
+        self.torch = torch
+        self.size, self.rank = P, r
+        self._lib_comm = None
+        self.stats = dict(exchanges=0, bytes_sent=0)
+        self.via = {}
+        self._side = None
+        self.wire_events = None
+
+    def library_comm(self):
+        if self._lib_comm is None:
+            import ctypes as C
+            from . import libhip
+            h = C.c_uint64(0)
+            libhip.call("ddh_comm_create_loopback", C.byref(h), self.rank, self.size)
+            self._lib_comm = h
+        return self._lib_comm
+
+    note_via = None            # (bound below: shared with Comm)
+    all_to_all_start = None
+
+    def all_to_all(self, recv, send):
+        self.note_via("loopback copy", send.numel() * 8 * (self.size - 1) // self.size)
+        recv.reshape(-1).copy_(send.reshape(-1))
+
+    def all_gather_host(self, a, axis=0):
+        return np.concatenate([np.asarray(a)] * self.size, axis=axis)
+
+    def allreduce_sum(self, value):
+        return float(value)
+
+    def allreduce_max(self, value):
+        return float(value)
+
+    def bcast_float(self, value, src=0):
+        return float(value)
+
+    def bcast_scalar(self, view, ex, src_rank=0):
+        return view.reshape(-1)[:1].clone()
+
+    def barrier(self):
+        pass
+
+
 class Comm:
+    def __new__(cls, size):
+        if emulated_rank() is not None:
+            return LoopbackComm(size)
+        return super().__new__(cls)
+
     def __init__(self, size):
         import torch
         import torch.distributed as dist
@@ -173,7 +247,7 @@ class Comm:
         runs on the communicator's stream while the caller keeps launching kernels; the numpy / host-staged test
         configurations complete immediately."""
         t = self.torch
-        if isinstance(send, np.ndarray) or (send.is_cuda and self.dist.get_backend() == "gloo"):
+        if isinstance(send, np.ndarray) or (send.is_cuda and self.backend == "gloo"):
             self.all_to_all(recv, send)
             return _Done()
         h = self.library_comm()
@@ -200,7 +274,8 @@ class Comm:
             done.record(self._side)
             if timed:
                 self.wire_events.append((e0, done))
-            self.note_via("ddh_comm_alltoall (library RCCL, side stream)", send.numel() * 8 * (self.size - 1) // self.size)
+            self.note_via("ddh_comm_alltoall (%s, side stream)" % ("loop-back communicator" if self.backend == "loopback" else "library RCCL"),
+                          send.numel() * 8 * (self.size - 1) // self.size)
             return _StreamWork(t, done, (send, recv))
         self.note_via("torch.distributed.all_to_all_single (%s, async)" % self.backend,
                       send.numel() * 8 * (self.size - 1) // self.size)
@@ -255,3 +330,7 @@ class Comm:
 
     def barrier(self):
         self.dist.barrier()
+
+
+LoopbackComm.note_via = Comm.note_via
+LoopbackComm.all_to_all_start = Comm.all_to_all_start      # (the production side-stream pipeline around ddh_comm_alltoall)

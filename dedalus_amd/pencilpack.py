@@ -229,24 +229,25 @@ class PencilPack:
             if not cx:
                 Ms, Ls = [m.real.copy() for m in Ms], [m.real.copy() for m in Ls]
             band = None
-            if not cx and os.environ.get("DDH_FLAG_DENSE", "0") != "1" and all(rv.all() and cv.all() for rv, cv in zip(rvs, cvs)):
+            if (not cx and os.environ.get("DDH_FLAG_DENSE", "0") != "1" and not getattr(self, "_flag_dense", False)
+                    and all(rv.all() and cv.all() for rv, cv in zip(rvs, cvs))):
                 band = [self._bordered_band(Md, Ld, n_interior) for Md, Ld in zip(Ms, Ls)]
                 if any(bd is None for bd in band):
                     band = None
+            if len(cache) > 4:                       # (either kind of entry holds O(n^2) doubles on the device)
+                cache.clear()
             if band is not None:
                 cache[key] = ("band", band, slots)
             else:
                 from .executor import DenseInverse, HipExecutor
                 ex = self.executor if self.executor is not None else HipExecutor(self.dev)
-                if len(cache) > 4:
-                    cache.clear()
                 cache[key] = ("dev", DenseInverse(ex, Ms, Ls, rvs, cvs, cx), [m.shape[0] for m in Ms], slots, cx)
         ent = cache[key]
         if ent[0] == "band":
             for bd, sl in zip(ent[1], ent[2]):
                 inv = bd.compute(a, b)
                 if inv is None:                      # (a zero pivot: never seen; the dense path takes over for good)
-                    os.environ["DDH_FLAG_DENSE"] = "1"
+                    self._flag_dense = True          # (this pack only: other solvers of the process keep the band path)
                     cache.pop(key)
                     return self._flagged_inverses(lu_id, matM, matL, a, b, row_perm, col_perm, ra, ca, cells, n_interior)
                 for t in sl:

@@ -122,6 +122,11 @@ int ddh_cheb_forward_tiled(ddh_handle plan, const double *g, double *c, long out
  * using another layout.  Values are
  * those of the plain transforms (core/transforms.py:469-565, 801-902), only addresses differ.                        */
 int ddh_fft_set_stage_layout(ddh_handle plan, long value);
+/* Diagnostic: the number of Chebyshev / real-Fourier launches of this process that ran on the wave-per-four-line-pairs
+ * kernels (csrc/ddh_fftwave.hip; the sizes of its tables) rather than on the workgroup-per-tile kernel every size can
+ * take.  The reference's plans are size-generic (core/transforms.py:537-565, 801-902); here the kernel is chosen per
+ * (grid, coefficient) size, and tests assert which one a size took.                                                   */
+int ddh_fft_wave_launches(long *count);
 int ddh_cheb_backward(ddh_handle plan, const double *c, double *g, long outer, long inner, void *stream);
 
 /* Dense matrix-multiply transform along an axis (JacobiMMT core/transforms.py:114-158 via
@@ -484,6 +489,12 @@ int ddh_comm_probe(void);                                          /* 0 when RCC
                                                                     * ranks agree BEFORE the collective ddh_comm_create */
 int ddh_comm_unique_id(unsigned char *id_h);                       /* DDH_COMM_ID_BYTES bytes */
 int ddh_comm_create(ddh_handle *comm, int rank, int nranks, const unsigned char *id_h);
+/* Rank emulation on ONE GPU (no counterpart in the reference, whose transposes need a real MPI run,
+ * core/transposes.pyx:359-445): a communicator that IS rank `rank` of `nranks` but has no peers -- every exchange hands
+ * back, as the block "received" from peer p, the block this rank sends to p (a device copy on the same stream).  Pack /
+ * unpack kernels, buffer sizes, stream ordering and the rank's kernel shapes are those of the P-rank run; the values
+ * are not.  For timing one rank's share of a sharded problem (tools/rank_emulation.py), never for results.            */
+int ddh_comm_create_loopback(ddh_handle *comm, int rank, int nranks);
 int ddh_comm_info(ddh_handle comm, int *rank, int *nranks);
 /* in-place all-reduce of `count` doubles: op 0 sum, 1 max, 2 min (the MPI Allreduce of GlobalArrayReducer,
  * extras/flow_tools.py:9-47, and of the CFL frequency) */

@@ -280,6 +280,44 @@ def config_shell_explicit(shape=(32, 16, 16)):
     print("wrote", path, os.path.getsize(path) >> 10, "KiB")
 
 
+def config_rb3d_endstate(shape, steps=3, dt=1e-3):
+    """3-D Rayleigh-Benard end state of the UNMODIFIED reference at a size whose transforms and solves take the
+    product's headline code paths (wave transforms, per-thread lean sweeps, tile-major right-hand sides): `steps` RK222
+    steps of the benchmark script from its seeded initial condition.  Stored: the norm of every state array and two
+    strided samples of the ARRAYS themselves (at most 24 rows per Fourier axis starting at 0 -- which keeps the
+    k = 0 rows -- and a second, coarser set starting at (1, 3): `sample_a`, `sample_b` = start, stride per axis), all z modes.  128 x 128 x 64 takes the reference ~9 min to build
+    and ~8 s per step on one core."""
+    import problems
+    d3 = refshim.load_reference()
+    Nx, Ny, Nz = shape
+    t0 = time.time()
+    solver, f = problems.rayleigh_benard_3d(d3, Nx=Nx, Ny=Ny, Nz=Nz, timestepper="RK222")
+    t_build = time.time() - t0
+    out = {"shape": np.array(shape), "steps": np.array(steps), "dt": np.array(dt)}
+    t0 = time.time()
+    for i in range(steps):
+        solver.step(dt)
+        if i == 0:
+            out["first_step_seconds"] = np.array(time.time() - t0)
+        print("step", i, "done after %.1f s" % (time.time() - t0), flush=True)
+    out["build_seconds"] = np.array(t_build)
+    out["step_seconds"] = np.array(time.time() - t0)
+    sx, sy = max(1, -(-Nx // 24)), max(1, -(-Ny // 24))     # at most 24 samples per Fourier axis, all z modes
+    out["sample_a"] = np.array([0, sx, 0, sy])
+    out["sample_b"] = np.array([1, 2 * sx, min(3, Ny - 1), 2 * sy])
+    for k in ("p", "b", "u"):
+        f[k].change_scales(1)
+        c = np.array(f[k]["c"])
+        out["end__%s_norm" % k] = np.array(np.linalg.norm(c))
+        out["end__%s_max" % k] = np.array(np.abs(c).max())
+        out["end__%s_a" % k] = c[..., ::sx, ::sy, :]
+        out["end__%s_b" % k] = c[..., 1::2 * sx, min(3, Ny - 1)::2 * sy, :]
+        print(k, c.shape, repr(float(out["end__%s_norm" % k])), flush=True)
+    path = os.path.join(GOLD, "config_rb3d_endstate_%dx%dx%d.npz" % shape)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) >> 10, "KiB, build %.0f s, steps %.0f s" % (t_build, float(out["step_seconds"])))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sphere", "shell", "cartesian", "explicit", "shell_explicit"]
     if "shell_explicit" in which:
@@ -294,3 +332,6 @@ if __name__ == "__main__":
         config_explicit()
     if "shell_endstate" in which:
         config_shell_endstate()
+    for w in which:
+        if w.startswith("rb3d_"):                      # e.g. rb3d_128x128x64
+            config_rb3d_endstate(tuple(int(v) for v in w[5:].split("x")))

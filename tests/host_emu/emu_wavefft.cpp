@@ -128,7 +128,7 @@ static void cheb_fwd(const EmuTabs &e, const double *src, double *dst, long oute
 
 // contiguous axis (wave_cheb_contig_kernel): lines [nlines][M] -> [nlines][N]; the staged grid lines are NP doubles apart
 template <int R, int NL, int CH>
-static void cheb_bwd_contig(const EmuTabs &e, int kind, const double *src, double *dst, long nlines) {
+static void cheb_bwd_contig(const EmuTabs &e, int kind, const double *src, double *dst, double *dst2, long nlines) {
     constexpr int N = 16 * R, NP = N + 2;
     const int M = e.M;
     const ChebTabs T = make_tabs(e, N, 16 * NL);
@@ -139,27 +139,37 @@ static void cheb_bwd_contig(const EmuTabs &e, int kind, const double *src, doubl
         const Lane L = make_lane(lane);
         double2 c[NL];
         cheb_bwd_load_contig<NL>(c, src, (unsigned)(M * 8), 2 * L.p < nlines, L);
+        auto copy_out = [&](double *out, long l0) {
+            WF_SYNC();
+            for (int it = 0; it < (8 * (N / 2) + 63) / 64; ++it) {
+                const int ch = it * 64 + lane;
+                const int l = ch / (N / 2), j = ch - l * (N / 2);
+                if (ch < 8 * (N / 2) && l0 + l < nlines) {
+                    out[(l0 + l) * N + 2 * j] = stage[l * NP + 2 * j];
+                    out[(l0 + l) * N + 2 * j + 1] = stage[l * NP + 2 * j + 1];
+                }
+            }
+            WF_SYNC();
+        };
         for (long tile = 0; tile < ntiles; ++tile) {
             const long l0 = 8 * tile;
             const bool valid = l0 + 2 * L.p < nlines;
             const bool more = tile + 1 < ntiles;
             const long l0n = more ? l0 + 8 : l0;
             const bool validn = l0n + 2 * L.p < nlines;
-            const unsigned lscn = more ? (unsigned)(M * 8) : 0u;
-            if (kind == 2)
-                cheb_bwd_pass<R, NL, CH, 2, true, true>(c, S.data(), T, stage.data(), (unsigned)(NP * 8), valid, lane, src + l0n * M, lscn, validn);
-            else
-                cheb_bwd_pass<R, NL, CH, 0, true, true>(c, S.data(), T, stage.data(), (unsigned)(NP * 8), valid, lane, src + l0n * M, lscn, validn);
-            WF_SYNC();
-            for (int it = 0; it < (8 * (N / 2) + 63) / 64; ++it) {
-                const int ch = it * 64 + lane;
-                const int l = ch / (N / 2), j = ch - l * (N / 2);
-                if (ch < 8 * (N / 2) && l0 + l < nlines) {
-                    dst[(l0 + l) * N + 2 * j] = stage[l * NP + 2 * j];
-                    dst[(l0 + l) * N + 2 * j + 1] = stage[l * NP + 2 * j + 1];
-                }
+            const unsigned lsc = (unsigned)(M * 8), lscn = more ? lsc : 0u;
+            if (kind == 1) {
+                cheb_bwd_pass<R, NL, CH, 0, false, true>(c, S.data(), T, stage.data(), (unsigned)(NP * 8), valid, lane, src + l0 * M, lsc, valid);
+                copy_out(dst, l0);
+                cheb_bwd_pass<R, NL, CH, 1, true, true>(c, S.data(), T, stage.data(), (unsigned)(NP * 8), valid, lane, src + l0n * M, lscn, validn);
+                copy_out(dst2, l0);
+            } else {
+                if (kind == 2)
+                    cheb_bwd_pass<R, NL, CH, 2, true, true>(c, S.data(), T, stage.data(), (unsigned)(NP * 8), valid, lane, src + l0n * M, lscn, validn);
+                else
+                    cheb_bwd_pass<R, NL, CH, 0, true, true>(c, S.data(), T, stage.data(), (unsigned)(NP * 8), valid, lane, src + l0n * M, lscn, validn);
+                copy_out(dst, l0);
             }
-            WF_SYNC();
         }
     });
 }
@@ -199,6 +209,9 @@ static void fft4(const double *tw, const double *x, double *X) {
     });
 }
 
+// the sizes of csrc/ddh_fftwave.hip (DDH_CHEB_WAVE_SIZES)
+#define EMU_CHEB_SIZES(X) X(24, 16) X(12, 8) X(16, 16) X(12, 12) X(8, 8) X(4, 4) X(16, 8) X(8, 4)
+
 extern "C" {
 int emu_fft4(int N, int sign, const double *tw, const double *x, double *X) {
     if (N == 384 && sign < 0) { fft4<24, -1, 2>(tw, x, X); return 0; }
@@ -207,6 +220,10 @@ int emu_fft4(int N, int sign, const double *tw, const double *x, double *X) {
     if (N == 256 && sign > 0) { fft4<16, +1, 2>(tw, x, X); return 0; }
     if (N == 192 && sign < 0) { fft4<12, -1, 1>(tw, x, X); return 0; }
     if (N == 192 && sign > 0) { fft4<12, +1, 1>(tw, x, X); return 0; }
+    if (N == 128 && sign < 0) { fft4<8, -1, 2>(tw, x, X); return 0; }
+    if (N == 128 && sign > 0) { fft4<8, +1, 2>(tw, x, X); return 0; }
+    if (N == 64 && sign < 0) { fft4<4, -1, 1>(tw, x, X); return 0; }
+    if (N == 64 && sign > 0) { fft4<4, +1, 1>(tw, x, X); return 0; }
     return 1;
 }
 int emu_cheb_bwd(int N, int M, int kind, const double *tw, const double *half, const double *bsub, const double *dvec,
@@ -214,16 +231,22 @@ int emu_cheb_bwd(int N, int M, int kind, const double *tw, const double *half, c
     EmuTabs e;
     memset(&e, 0, sizeof(e));
     e.tw = tw; e.half = half; e.bsub = bsub; e.dvec = dvec; e.M = M; e.gcd_off = gcd_off;
-    if (N == 384 && M == 256) { cheb_bwd<24, 16, 2>(e, kind, src, dst, dst2, outer, inner); return 0; }
+#define EMU_X(RV, NLV) \
+    if (N == 16 * RV && M == 16 * NLV) { cheb_bwd<RV, NLV, WaveCH<RV>::ch>(e, kind, src, dst, dst2, outer, inner); return 0; }
+    EMU_CHEB_SIZES(EMU_X)
+#undef EMU_X
     return 1;
 }
 int emu_cheb_bwd_contig(int N, int M, int kind, const double *tw, const double *half, const double *bsub, int gcd_off,
-                        const double *src, double *dst, long nlines) {
+                        const double *src, double *dst, long nlines, const double *dvec, double *dst2) {
     EmuTabs e;
     memset(&e, 0, sizeof(e));
     std::vector<double> zero(M, 0.0);
-    e.tw = tw; e.half = half; e.bsub = bsub; e.dvec = zero.data(); e.M = M; e.gcd_off = gcd_off;
-    if (N == 192 && M == 128) { cheb_bwd_contig<12, 8, 3>(e, kind, src, dst, nlines); return 0; }
+    e.tw = tw; e.half = half; e.bsub = bsub; e.dvec = dvec ? dvec : zero.data(); e.M = M; e.gcd_off = gcd_off;
+#define EMU_X(RV, NLV) \
+    if (N == 16 * RV && M == 16 * NLV) { cheb_bwd_contig<RV, NLV, WaveCH<RV>::ch>(e, kind, src, dst, dst2, nlines); return 0; }
+    EMU_CHEB_SIZES(EMU_X)
+#undef EMU_X
     return 1;
 }
 int emu_cheb_fwd_contig(int N, int M, const double *tw, const double *half, int nbands, const int *boff, const double *bands,
@@ -232,7 +255,10 @@ int emu_cheb_fwd_contig(int N, int M, const double *tw, const double *half, int 
     memset(&e, 0, sizeof(e));
     e.tw = tw; e.half = half; e.bands = bands; e.M = M; e.nbands = nbands; e.gcd_off = 1;
     for (int d = 0; d < nbands && d < 4; ++d) e.boff[d] = boff[d];
-    if (N == 192 && M == 128) { cheb_fwd_contig<12, 8, 3>(e, src, dst, nlines); return 0; }
+#define EMU_X(RV, NLV) \
+    if (N == 16 * RV && M == 16 * NLV) { cheb_fwd_contig<RV, NLV, WaveCH<RV>::ch>(e, src, dst, nlines); return 0; }
+    EMU_CHEB_SIZES(EMU_X)
+#undef EMU_X
     return 1;
 }
 int emu_cheb_fwd(int N, int M, const double *tw, const double *half, int nbands, const int *boff, const double *bands,
@@ -241,7 +267,10 @@ int emu_cheb_fwd(int N, int M, const double *tw, const double *half, int nbands,
     memset(&e, 0, sizeof(e));
     e.tw = tw; e.half = half; e.bands = bands; e.M = M; e.nbands = nbands; e.gcd_off = 1;
     for (int d = 0; d < nbands && d < 4; ++d) e.boff[d] = boff[d];
-    if (N == 384 && M == 256) { cheb_fwd<24, 16, 2>(e, src, dst, outer, inner); return 0; }
+#define EMU_X(RV, NLV) \
+    if (N == 16 * RV && M == 16 * NLV) { cheb_fwd<RV, NLV, WaveCH<RV>::ch>(e, src, dst, outer, inner); return 0; }
+    EMU_CHEB_SIZES(EMU_X)
+#undef EMU_X
     return 1;
 }
 }
@@ -285,12 +314,16 @@ extern "C" {
 int emu_rfft_bwd(int N, int dual, double dsc, double dsc2, const double *tw, const double *src, double *dst, double *dst2,
                  long outer, long inner) {
     if (N == 768) { rfft_bwd<16>(tw, dual != 0, dsc, dsc2, src, dst, dst2, outer, inner); return 0; }
+    if (N == 576) { rfft_bwd<12>(tw, dual != 0, dsc, dsc2, src, dst, dst2, outer, inner); return 0; }
     if (N == 384) { rfft_bwd<8>(tw, dual != 0, dsc, dsc2, src, dst, dst2, outer, inner); return 0; }
+    if (N == 192) { rfft_bwd<4>(tw, dual != 0, dsc, dsc2, src, dst, dst2, outer, inner); return 0; }
     return 1;
 }
 int emu_rfft_fwd(int N, const double *tw, const double *src, double *dst, long outer, long inner) {
     if (N == 768) { rfft_fwd<16>(tw, src, dst, outer, inner); return 0; }
+    if (N == 576) { rfft_fwd<12>(tw, src, dst, outer, inner); return 0; }
     if (N == 384) { rfft_fwd<8>(tw, src, dst, outer, inner); return 0; }
+    if (N == 192) { rfft_fwd<4>(tw, src, dst, outer, inner); return 0; }
     return 1;
 }
 }

@@ -219,3 +219,64 @@ def test_full_spectrum_transforms_at_the_metric_size_against_the_series():
     err = np.abs(c2 - c).max() / np.abs(c).max()
     print("round trip of the full spectrum:", err)
     assert err < 1e-12, err
+
+
+def _wave_launches():
+    import ctypes as C
+    from dedalus_amd import libhip
+    n = C.c_long(0)
+    libhip.call("ddh_fft_wave_launches", C.byref(n))
+    return n.value
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 8, 256), (16, 512, 256), (512, 16, 256)])
+def test_rb3d_end_state_through_the_headline_kernels(shape, monkeypatch):
+    """End states of the UNMODIFIED reference (oracle/make_golden_config.py::config_rb3d_endstate: three RK222 steps of the
+    benchmark script; strided samples of the ARRAYS, not norms) at sizes whose steps run through the kernels of the
+    headline configuration, composed:
+      128 x 128 x 64   partner pencils (x <-> y symmetric), per-thread lean sweeps, real FFT 192 <- 128 on the wave kernel
+      256 x 8 x 256    Chebyshev 384 <- 256 wave kernels (dual / conversion / forward writing F tile-major), real FFT
+                       384 <- 256 wave kernels, x-blocked stage arrays, per-thread lean sweeps on tile-major terms
+      16 x 512 x 256   the second-generation fused y stage (768-point lines, LDS-DMA operands) + the same z kernels
+      512 x 16 x 256   real FFT 768 <- 512 wave kernels (plain, dual, forward) + x-blocked stage + the same z kernels
+    The per-thread sweeps are forced (`set_solve_variant(0)`: these sizes have few pencils and would take the cooperative
+    sweeps) and the tile-major right-hand sides are allowed below their size threshold, so that what runs is what the
+    512 x 512 x 256 benchmark runs.  Tolerances: rel-L2 1e-10 (b, p), 1e-9 (u) on the sampled arrays."""
+    import os
+    import dedalus_amd.public as d3
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_rb3d_endstate_%dx%dx%d.npz" % shape)
+    if not os.path.exists(path):
+        pytest.skip("golden not generated: " + os.path.basename(path))
+    G = np.load(path)
+    monkeypatch.setenv("DDH_RHS_TILING_MIN", "0")
+    Nx, Ny, Nz = shape
+    solver, f = problems.rayleigh_benard_3d(d3, Nx=Nx, Ny=Ny, Nz=Nz, timestepper="RK222")
+    assert solver.ex.name == "hip"
+    solver.pack.set_solve_variant(0)
+    w0 = _wave_launches()
+    for _ in range(int(G["steps"])):
+        solver.step(float(G["dt"]))
+    nwave = _wave_launches() - w0
+    lus = sorted(solver._lu_params)
+    infos = [solver.pack.lu_info(lu) for lu in lus]
+    assert all(i["forward"] == "lean" and i["real"] for i in infos), infos
+    if shape != (128, 128, 64):
+        assert solver.rhs_tiling(lus) == Ny              # tile-major M.X / F buffers
+    assert nwave > 0
+    sa = G["sample_a"] if "sample_a" in G.files else np.array([0, 4, 0, 4])
+    sb = G["sample_b"] if "sample_b" in G.files else np.array([1, 8, 3, 8])
+    worst = {}
+    for k, tol in (("b", 1e-10), ("p", 1e-10), ("u", 1e-9)):
+        c = np.asarray(f[k]["c"])
+        assert abs(np.linalg.norm(c) - float(G["end__%s_norm" % k])) <= tol * float(G["end__%s_norm" % k])
+        for tag, s in (("a", sa), ("b", sb)):
+            mine = c[..., int(s[0])::int(s[1]), int(s[2])::int(s[3]), :]
+            ref = G["end__%s_%s" % (k, tag)]
+            assert mine.shape == ref.shape, (k, tag, mine.shape, ref.shape)
+            if ref.size == 0:
+                continue
+            err = np.linalg.norm(mine - ref) / np.linalg.norm(ref)
+            worst[k] = max(worst.get(k, 0.0), err)
+            assert err < tol, (shape, k, tag, err)
+    print("rb3d %s end state vs the reference: %s, %d wave-kernel transforms, pairing %s"
+          % (shape, {k: "%.1e" % v for k, v in worst.items()}, nwave, infos[0].get("pair")))

@@ -37,13 +37,32 @@ def _plan(N, M, alpha):
     return h, conv
 
 
+# every (grid, coefficient) size the wave Chebyshev kernels are instantiated for (csrc/ddh_fftwave.hip: DDH_CHEB_WAVE_SIZES)
+WAVE_CHEB_SIZES = [(384, 256), (192, 128), (256, 256), (192, 192), (128, 128), (64, 64), (256, 128), (128, 64)]
+WAVE_RFFT_SIZES = [(768, 512), (576, 384), (384, 256), (192, 128)]
+
+
+def _wave_launch_count(fn):
+    """number of launches the library routed to a wave kernel while fn() ran (ddh_fft_wave_launches: a size that silently
+    fell back to the workgroup-per-tile kernel would pass the numerical comparison too)"""
+    from dedalus_amd import libhip
+    n0 = C.c_long(0)
+    libhip.call("ddh_fft_wave_launches", C.byref(n0))
+    fn()
+    n1 = C.c_long(0)
+    libhip.call("ddh_fft_wave_launches", C.byref(n1))
+    return n1.value - n0.value
+
+
+@pytest.mark.parametrize("N,M", WAVE_CHEB_SIZES)
 @pytest.mark.parametrize("outer,inner", [(1, 2), (2, 10), (3, 64), (1, 8 * 8 * 4 * 2 * 3 + 6), (2, 4096)])
-def test_wave_chebyshev_all_paths(dev, outer, inner):
+def test_wave_chebyshev_all_paths(dev, N, M, outer, inner):
     from dedalus_amd import libhip
     from dedalus_amd.device import ptr
     from dedalus_amd.tools import jacobi
     from oracle import np_transforms as npt
-    N, M = 384, 256
+    if (N, M) != (384, 256) and (outer, inner) not in ((2, 10), (1, 8 * 8 * 4 * 2 * 3 + 6)):
+        pytest.skip("the other tile shapes are checked at the benchmark's size")
     rng = np.random.default_rng(outer * 1000 + inner)
     cs, gs = (outer, M, inner), (outer, N, inner)
     cin = rng.standard_normal(cs) / (1.0 + np.arange(M).reshape(1, -1, 1)) ** 2
@@ -70,22 +89,29 @@ def test_wave_chebyshev_all_paths(dev, outer, inner):
     ga, gb = dev.empty(gs), dev.empty(gs)
     ga.fill_(float("nan"))
     gb.fill_(float("nan"))
-    libhip.call("ddh_cheb_backward_dual", plans[1][0], ptr(d_c), ptr(ga), ptr(gb), ptr(d_v), outer, inner, dev.stream)
+    nw = _wave_launch_count(lambda: libhip.call("ddh_cheb_backward_dual", plans[1][0], ptr(d_c), ptr(ga), ptr(gb), ptr(d_v), outer, inner, dev.stream))
     dev.sync()
+    assert nw == 1, "the dual transform of %d <- %d did not run on the wave kernel" % (N, M)
     assert np.array_equal(dev.to_host(d_c), cin)
     assert rel(dev.to_host(ga), npt.cheb_backward(cin, 1, N, None)) < 1e-12
     assert rel(dev.to_host(gb), npt.cheb_backward(dc, 1, N, plans[1][1])) < 1e-11
 
 
+@pytest.mark.parametrize("N,M", WAVE_CHEB_SIZES)
 @pytest.mark.parametrize("nlines", [2, 8, 18, 8 * 4 * 4 * 7 + 6, 3 * 256 * 128])
-def test_wave_chebyshev_along_the_contiguous_axis(dev, nlines):
-    """The shell's radial transforms (contiguous lines, 192 <- 128; wave_cheb_contig_kernel): one pair, one tile, a partial
-    tile, several tiles per wave with a ragged end, and the configuration's own line count; alpha = 0, 1, 2 both ways against
-    the numpy oracle (reference: core/transforms.py:715-902), plus the round trip."""
+def test_wave_chebyshev_along_the_contiguous_axis(dev, N, M, nlines):
+    """The shell's radial transforms (contiguous lines, 192 <- 128) and the vertical axis of 2-D problems (384 <- 256;
+    wave_cheb_contig_kernel): one pair, one tile, a partial tile, several tiles per wave with a ragged end, and the shell
+    configuration's own line count; alpha = 0, 1, 2 both ways against the numpy oracle (reference:
+    core/transforms.py:715-902), the round trip, and the dual backward transform (field + z derivative)."""
     from dedalus_amd import libhip
     from dedalus_amd.device import ptr
+    from dedalus_amd.tools import jacobi
     from oracle import np_transforms as npt
-    N, M = 192, 128
+    if (N, M) not in ((192, 128), (384, 256)) and nlines != 8 * 4 * 4 * 7 + 6:
+        pytest.skip("the other line counts are checked at the configurations' sizes")
+    if (N, M) == (384, 256) and nlines > 10000:
+        nlines = 2 * 512 * 3                 # (2-D Rayleigh-Benard 512 x 256: 3 components of 512 contiguous lines)
     big = nlines > 10000
     rng = np.random.default_rng(nlines)
     cin = rng.standard_normal((nlines, M)) / (1.0 + np.arange(M).reshape(1, -1)) ** 2
@@ -113,6 +139,23 @@ def test_wave_chebyshev_along_the_contiguous_axis(dev, nlines):
         libhip.call("ddh_cheb_forward", h, ptr(g), ptr(c2), nlines, 1, dev.stream)
         dev.sync()
         assert rel(dev.to_host(c2), cin) < 1e-12, ("round trip", alpha)
+        if alpha == 1:
+            D = jacobi.differentiation_matrix(M, -0.5, -0.5).toarray() * (2.0 / 1.7)
+            dvec = np.zeros(M)
+            dvec[:M - 1] = np.diagonal(D, 1)
+            d_v = dev.from_host(dvec)
+            ga, gb = dev.empty((nlines, N)), dev.empty((nlines, N))
+            ga.fill_(float("nan"))
+            gb.fill_(float("nan"))
+            nw = _wave_launch_count(lambda: libhip.call("ddh_cheb_backward_dual", h, ptr(d_c), ptr(ga), ptr(gb), ptr(d_v), nlines, 1, dev.stream))
+            dev.sync()
+            assert nw == 1, "the contiguous dual transform of %d <- %d did not run on the wave kernel" % (N, M)
+            h0, _ = _plan(N, M, 0)
+            g0 = dev.empty((nlines, N))
+            libhip.call("ddh_cheb_backward", h0, ptr(d_c), ptr(g0), nlines, 1, dev.stream)
+            dev.sync()
+            assert np.array_equal(dev.to_host(ga), dev.to_host(g0))
+            assert rel(dev.to_host(gb)[sub], npt.cheb_backward(cin[sub] @ D.T, 1, N, conv)) < 1e-11
 
 
 def test_wave_chebyshev_round_trip_full_size(dev):
@@ -148,7 +191,7 @@ def test_wave_chebyshev_round_trip_full_size(dev):
     assert float((gb - g2).norm() / g2.norm()) < 1e-13
 
 
-@pytest.mark.parametrize("N,M", [(768, 512), (384, 256)])
+@pytest.mark.parametrize("N,M", WAVE_RFFT_SIZES)
 @pytest.mark.parametrize("outer,inner", [(1, 2), (2, 10), (3, 64), (1, 8 * 8 * 4 * 2 + 6), (2, 1024)])
 def test_wave_real_fourier_all_paths(dev, N, M, outer, inner):
     """wave-per-four-pairs real FFT with 3/2 dealiasing (three length-N/3 transforms): backward, differentiated
@@ -168,12 +211,15 @@ def test_wave_real_fourier_all_paths(dev, N, M, outer, inner):
     outs = [dev.empty(gs) for _ in range(4)]
     for o in outs:
         o.fill_(float("nan"))
-    libhip.call("ddh_rfft_backward_dual", h, ptr(d_c), ptr(outs[0]), ptr(outs[1]), outer, inner, dscale, dev.stream)
-    libhip.call("ddh_rfft_backward", h, ptr(d_c), ptr(outs[2]), outer, inner, dev.stream)
-    libhip.call("ddh_rfft_backward_deriv", h, ptr(d_c), ptr(outs[3]), outer, inner, dscale, dev.stream)
     cf = dev.empty(cs)
     cf.fill_(float("nan"))
-    libhip.call("ddh_rfft_forward", h, ptr(d_g), ptr(cf), outer, inner, dev.stream)
+
+    def run():
+        libhip.call("ddh_rfft_backward_dual", h, ptr(d_c), ptr(outs[0]), ptr(outs[1]), outer, inner, dscale, dev.stream)
+        libhip.call("ddh_rfft_backward", h, ptr(d_c), ptr(outs[2]), outer, inner, dev.stream)
+        libhip.call("ddh_rfft_backward_deriv", h, ptr(d_c), ptr(outs[3]), outer, inner, dscale, dev.stream)
+        libhip.call("ddh_rfft_forward", h, ptr(d_g), ptr(cf), outer, inner, dev.stream)
+    assert _wave_launch_count(run) == 4, "a real-Fourier transform of %d <- %d fell back to the workgroup-per-tile kernel" % (N, M)
     dev.sync()
     g, gd, g1, gd1 = [dev.to_host(o) for o in outs]
     assert np.array_equal(dev.to_host(d_c), cin)

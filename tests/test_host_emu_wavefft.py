@@ -25,7 +25,7 @@ def emu(tmp_path_factory):
     lib.emu_fft4.argtypes = [i, i, vp, vp, vp]
     lib.emu_cheb_bwd.argtypes = [i, i, i, vp, vp, vp, vp, i, vp, vp, vp, l, l]
     lib.emu_cheb_fwd.argtypes = [i, i, vp, vp, i, vp, vp, vp, vp, l, l]
-    lib.emu_cheb_bwd_contig.argtypes = [i, i, i, vp, vp, vp, i, vp, vp, l]
+    lib.emu_cheb_bwd_contig.argtypes = [i, i, i, vp, vp, vp, i, vp, vp, l, vp, vp]
     lib.emu_cheb_fwd_contig.argtypes = [i, i, vp, vp, i, vp, vp, vp, vp, l]
     lib.emu_rfft_bwd.argtypes = [i, i, C.c_double, C.c_double, vp, vp, vp, vp, l, l]
     lib.emu_rfft_fwd.argtypes = [i, vp, vp, vp, l, l]
@@ -59,7 +59,7 @@ def conv_bands(M, alpha):
     return conv, offs, bands
 
 
-@pytest.mark.parametrize("N", [384, 256, 192])
+@pytest.mark.parametrize("N", [384, 256, 192, 128, 64])
 @pytest.mark.parametrize("sign", [-1, 1])
 def test_wave_fft_of_four_interleaved_lines(emu, N, sign):
     rng = np.random.default_rng(N + sign)
@@ -72,11 +72,19 @@ def test_wave_fft_of_four_interleaved_lines(emu, N, sign):
     assert rel(X[..., 0] + 1j * X[..., 1], ref) < 1e-14
 
 
-@pytest.mark.parametrize("shape", [(2, 256, 12), (1, 256, 2), (3, 256, 10)])
-def test_wave_chebyshev_matches_the_oracle(emu, shape):
-    """whole and partial tiles (inner = 10: five pairs = one full tile + one pair), several outer indices"""
-    N, M = 384, 256
-    outer, _, inner = shape
+WAVE_CHEB_SIZES = [(384, 256), (192, 128), (256, 256), (192, 192), (128, 128), (64, 64), (256, 128), (128, 64)]
+
+
+@pytest.mark.parametrize("NM", WAVE_CHEB_SIZES)
+@pytest.mark.parametrize("oi", [(2, 12), (1, 2), (3, 10)])
+def test_wave_chebyshev_matches_the_oracle(emu, NM, oi):
+    """whole and partial tiles (inner = 10: five pairs = one full tile + one pair), several outer indices; every
+    instantiated (grid, coefficient) size of csrc/ddh_fftwave.hip (DDH_CHEB_WAVE_SIZES)"""
+    N, M = NM
+    if NM != (384, 256) and oi != (3, 10):
+        pytest.skip("the other tile shapes are checked at the benchmark's size")
+    outer, inner = oi
+    shape = (outer, M, inner)
     rng = np.random.default_rng(inner)
     tw, half = tables(N)
     zero = np.zeros(3 * M)
@@ -113,18 +121,22 @@ def test_wave_chebyshev_matches_the_oracle(emu, shape):
         assert rel(out, npt.cheb_forward(gin, 1, M, cv)) < 1e-14
 
 
+@pytest.mark.parametrize("NM", WAVE_CHEB_SIZES)
 @pytest.mark.parametrize("nlines", [8, 18, 2])
-def test_wave_chebyshev_along_the_contiguous_axis(emu, nlines):
-    """wave_cheb_contig_kernel (the shell's radial transforms, 192 <- 128): 8 contiguous lines per wave, grid lines staged
-    line-major in LDS; whole tiles, a partial tile (18 = 2 tiles + one pair), a single pair; plain, conversion solve
-    (ultraspherical alpha = 1, 2), forward with conversion bands"""
-    N, M = 192, 128
+def test_wave_chebyshev_along_the_contiguous_axis(emu, NM, nlines):
+    """wave_cheb_contig_kernel (the shell's radial transforms, 192 <- 128; the vertical axis of 2-D Rayleigh-Benard,
+    384 <- 256): 8 contiguous lines per wave, grid lines staged line-major in LDS; whole tiles, a partial tile (18 = 2
+    tiles + one pair), a single pair; plain, conversion solve (ultraspherical alpha = 1, 2), dual (field + z derivative),
+    forward with conversion bands"""
+    N, M = NM
+    if NM not in ((192, 128), (384, 256)) and nlines != 18:
+        pytest.skip("the other line counts are checked at the configurations' sizes")
     rng = np.random.default_rng(nlines)
     tw, half = tables(N)
     zero = np.zeros(3 * M)
     cin = rng.standard_normal((nlines, M)) / (1.0 + np.arange(M).reshape(1, -1)) ** 2
     g = np.full((nlines, N), np.nan)
-    assert emu.emu_cheb_bwd_contig(N, M, 0, dp(tw), dp(half), dp(zero), 1, dp(cin), dp(g), nlines) == 0
+    assert emu.emu_cheb_bwd_contig(N, M, 0, dp(tw), dp(half), dp(zero), 1, dp(cin), dp(g), nlines, None, None) == 0
     assert rel(g, npt.cheb_backward(cin, 1, N, None)) < 1e-14
     for alpha in (1, 2):
         conv, offs, bands = conv_bands(M, alpha)
@@ -135,8 +147,17 @@ def test_wave_chebyshev_along_the_contiguous_axis(emu, nlines):
         bsub[0] = 1.0 / bands[0]
         bsub[1, :M - go] = bands[1, :M - go] / bands[0, :M - go]
         g2 = np.full((nlines, N), np.nan)
-        assert emu.emu_cheb_bwd_contig(N, M, 2, dp(tw), dp(half), dp(bsub), go, dp(cin), dp(g2), nlines) == 0
+        assert emu.emu_cheb_bwd_contig(N, M, 2, dp(tw), dp(half), dp(bsub), go, dp(cin), dp(g2), nlines, None, None) == 0
         assert rel(g2, npt.cheb_backward(cin, 1, N, conv)) < 1e-13
+        if alpha == 1:
+            # dual: the plain transform and the z derivative (one superdiagonal into the alpha = 1 basis) from one read
+            D = jacobi.differentiation_matrix(M, -0.5, -0.5).toarray() * (2.0 / 1.7)
+            dvec = np.zeros(M)
+            dvec[:M - 1] = np.diagonal(D, 1)
+            ga, gb = np.full((nlines, N), np.nan), np.full((nlines, N), np.nan)
+            assert emu.emu_cheb_bwd_contig(N, M, 1, dp(tw), dp(half), dp(bsub), go, dp(cin), dp(ga), nlines, dp(dvec), dp(gb)) == 0
+            assert np.array_equal(ga, g)
+            assert rel(gb, npt.cheb_backward(cin @ D.T, 1, N, conv)) < 1e-13
     gin = rng.standard_normal((nlines, N))
     for alpha in (0, 1, 2):
         out = np.full((nlines, M), np.nan)
@@ -149,7 +170,7 @@ def test_wave_chebyshev_along_the_contiguous_axis(emu, nlines):
         assert rel(out, npt.cheb_forward(gin, 1, M, cv)) < 1e-14
 
 
-@pytest.mark.parametrize("N", [768, 384])
+@pytest.mark.parametrize("N", [768, 576, 384, 192])
 @pytest.mark.parametrize("shape_oi", [(2, 10), (1, 8), (3, 2)])
 def test_wave_real_fourier_matches_the_oracle(emu, N, shape_oi):
     """3/2-dealiased real FFT along a strided axis as three length-N/3 transforms (core/transforms.py:469-565)"""

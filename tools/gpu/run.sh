@@ -2,7 +2,7 @@
 # One parameterised GPU-box script (replaces the per-experiment r3*.sh files):  gpurun -- 'bash tools/gpu/run.sh STEP [STEP ...]'
 # Every step writes under gpurun_out/<tag>/ (tag = $TAG or "r4").
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${TAG:-r5}
+TAG=${TAG:-r6}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 bench_line() { python - "$1" <<'PY'
@@ -67,6 +67,14 @@ except Exception as e:
 PY
                   done
                 done ;;
+    ring-ab)    # backward sweep: direct loads against the LDS-DMA ring, depth 2 / 3 / 4 (DDH_BWD_RING), same box
+                for r in 0 2 3 4; do
+                  DDH_BWD_RING=$r python bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-cfl > $OUT/bench_ring$r.json 2> $OUT/bench_ring$r.err
+                  echo "DDH_BWD_RING=$r"; bench_line $OUT/bench_ring$r.json
+                done ;;
+    emu)        # one rank of the P-rank run on this GPU, loop-back exchange (profiles/r6_rank_emulation.txt)
+                python tools/rank_emulation.py --ranks 2,4,8 --rank 1 --steps 10 --warmup 3 ${ONE_GPU_MS:+--single-gpu-ms $ONE_GPU_MS} > $OUT/rank_emulation.jsonl 2> $OUT/rank_emulation.txt; cat $OUT/rank_emulation.txt ;;
+    tests-new)  python -m pytest tests/test_gpu_wave_transforms.py tests/test_gpu_comm.py tests/test_gpu_pencil.py tests/test_gpu_reference_pencils.py tests/test_gpu_baseline_sizes.py -x -q -m gpu -s > $OUT/pytest_new.txt 2>&1; tail -5 $OUT/pytest_new.txt; grep "end state vs" $OUT/pytest_new.txt ;;
     *)          echo "running: $step"; bash -c "$step" ;;
   esac
 done
