@@ -1144,11 +1144,12 @@ class SolverBase:
             return
         self.pack.set_block_inverse(lu, x)
 
-    def _block_inverse_residual_ok(self, bi, idx, x, a, b, tol=1e-9):
-        """||B^T X^T - I||_max on sampled blocks (first, middle, last un-flagged group), formed on the host from the band
+    def _block_inverse_residual_ok(self, bi, idx, x, a, b, tol=1e-6):
+        """||B^-T B^T - I||_max on sampled blocks (first, middle, last un-flagged group), formed on the host from the band
         arrays the inverses were made of: an explicit inverse replaces a backward-stable LU solve by a multiplication with
-        B^-1 (error ~ cond(B) eps); above `tol` the sweeps stay.  Three blocks of <= 1024^2 doubles cross PCIe per
-        factorization."""
+        B^-1 (error ~ cond(B) eps); above `tol` the sweeps stay (measured: 2-D Rayleigh-Benard 512 x 256, blocks of 515 rows:
+        see `solver._binv["residual"]`, printed by tools/bench_configs.py).  Three blocks of <= 1024^2 doubles cross PCIe
+        per factorization."""
         if os.environ.get("DDH_BLOCK_INVERSE_CHECK", "1") == "0":
             return True
         plan, nh = bi["plan"], bi["nh"]
@@ -1167,7 +1168,7 @@ class SolverBase:
             worst = max(worst, float(np.abs(Xg @ Bt.T - np.eye(nh)).max()))
         bi["residual"] = worst
         if worst > tol:
-            logger.warning("explicit block inverses: ||X B - I|| = %.1e > %.0e, the sweeps stay" % (worst, tol))
+            logger.warning("explicit block inverses: ||B^-T B^T - I|| = %.1e > %.0e, the sweeps stay" % (worst, tol))
             return False
         return True
 

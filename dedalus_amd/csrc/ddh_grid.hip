@@ -150,6 +150,38 @@ cfl_spherical_kernel(double *result, const double *__restrict__ u, long n_ang, i
     if (threadIdx.x == 0) atomic_max_double(result, red[0]);
 }
 
+// Copy of one contiguous segment, shared by the pack / unpack kernels below.  The segments of a transpose are few and
+// large (per-component exchange of the 512^2 x 256 problem on 8 ranks: EIGHT segments of 25 MB) or many and small: the grid
+// is (chunks of a segment) x (segments), every thread moves four 16-byte words per round so that a wave has 4 KiB in
+// flight.  (Round 5 launched one workgroup per segment: 57 - 400 GB/s at the per-rank shapes, profiles/r6_rank_emulation.txt)
+__device__ __forceinline__ void copy_segment(const double *__restrict__ s, double *__restrict__ d, long cnt, bool vec) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+    if (vec) {
+        const double2 *s2 = reinterpret_cast<const double2 *>(s);
+        double2 *d2 = reinterpret_cast<double2 *>(d);
+        const long n2 = cnt >> 1;
+        long i = tid;
+        for (; i + 3 * nth < n2; i += 4 * nth) {
+            const double2 a = s2[i], b = s2[i + nth], c = s2[i + 2 * nth], e = s2[i + 3 * nth];
+            d2[i] = a;
+            d2[i + nth] = b;
+            d2[i + 2 * nth] = c;
+            d2[i + 3 * nth] = e;
+        }
+        for (; i < n2; i += nth) d2[i] = s2[i];
+    } else {
+        for (long i = tid; i < cnt; i += nth) d[i] = s[i];
+    }
+}
+// grid of a segment copy: x = chunks of 1024 16-byte words of one segment (at most 1024), y = segments (at most 65535)
+static inline dim3 seg_grid(long nseg, long seg_doubles) {
+    long cx = (seg_doubles / 2 + 1023) / 1024;
+    if (cx < 1) cx = 1;
+    while (cx > 1 && cx * nseg > 16384) cx = (cx + 1) / 2;       // enough workgroups to fill the chip a few times over
+    if (cx > 1024) cx = 1024;
+    return dim3((unsigned)cx, (unsigned)(nseg < 65535 ? nseg : 65535));
+}
+
 // [outer][na][nb*inner]  ->  [P][outer][na/P][nb*inner]   (split axis a into P blocks)
 __global__ void __launch_bounds__(256)
 a2a_pack_kernel(const double *__restrict__ src, double *__restrict__ dst, long outer, long na, long row, int P) {
@@ -158,16 +190,9 @@ a2a_pack_kernel(const double *__restrict__ src, double *__restrict__ dst, long o
     const long seg = blk * row;
     const long nseg = outer * P;
     const bool vec = (seg & 1) == 0;     // even segments keep every 16-byte access aligned
-    for (long r = blockIdx.x; r < nseg; r += gridDim.x) {
+    for (long r = blockIdx.y; r < nseg; r += gridDim.y) {
         const long o = r / P, p = r % P;
-        const double *s = src + r * seg;
-        double *d = dst + (p * outer + o) * seg;
-        if (vec) {
-            for (long i = threadIdx.x; i < (seg >> 1); i += blockDim.x)
-                reinterpret_cast<double2 *>(d)[i] = reinterpret_cast<const double2 *>(s)[i];
-        } else {
-            for (long i = threadIdx.x; i < seg; i += blockDim.x) d[i] = s[i];
-        }
+        copy_segment(src + r * seg, dst + (p * outer + o) * seg, seg, vec);
     }
 }
 
@@ -177,18 +202,11 @@ a2a_unpack_kernel(const double *__restrict__ src, double *__restrict__ dst, long
     const long blk = nb / P;
     const long seg = blk * inner;  // contiguous doubles per (p, o, ia)
     const long nseg = (long)P * outer * na;
-    const long seg2 = seg >> 1;
-    for (long r = blockIdx.x; r < nseg; r += gridDim.x) {
+    const bool vec = (seg & 1) == 0 && ((nb * inner) & 1) == 0;
+    for (long r = blockIdx.y; r < nseg; r += gridDim.y) {
         const long p = r / (outer * na);
         const long oi = r % (outer * na);
-        const double *s = src + r * seg;
-        double *d = dst + (oi * nb + p * blk) * inner;
-        if ((seg & 1) == 0 && ((nb * inner) & 1) == 0) {
-            for (long i = threadIdx.x; i < seg2; i += blockDim.x)
-                reinterpret_cast<double2 *>(d)[i] = reinterpret_cast<const double2 *>(s)[i];
-        } else {
-            for (long i = threadIdx.x; i < seg; i += blockDim.x) d[i] = s[i];
-        }
+        copy_segment(src + r * seg, dst + (oi * nb + p * blk) * inner, seg, vec);
     }
 }
 
@@ -198,28 +216,26 @@ a2a_unpack_kernel(const double *__restrict__ src, double *__restrict__ dst, long
 __global__ void __launch_bounds__(256)
 a2av_pack_kernel(const double *__restrict__ src, double *__restrict__ dst, long outer, long na, long row, int P, long B) {
     const long nseg = outer * P;
-    for (long r = blockIdx.x; r < nseg; r += gridDim.x) {
+    for (long r = blockIdx.y; r < nseg; r += gridDim.y) {
         const long o = r / P, p = r % P;
         const long lo = (p * B < na) ? p * B : na;
         const long hi = (lo + B < na) ? lo + B : na;
         const long cnt = (hi - lo) * row;
-        const double *s = src + (o * na + lo) * row;
-        double *d = dst + outer * row * lo + o * cnt;
-        for (long i = threadIdx.x; i < cnt; i += blockDim.x) d[i] = s[i];
+        const long so = (o * na + lo) * row, dof = outer * row * lo + o * cnt;
+        copy_segment(src + so, dst + dof, cnt, ((cnt | so | dof) & 1) == 0);
     }
 }
 
 __global__ void __launch_bounds__(256)
 a2av_unpack_kernel(const double *__restrict__ src, double *__restrict__ dst, long outer_na, long nb, long inner, int P, long B) {
     const long nseg = (long)P * outer_na;
-    for (long r = blockIdx.x; r < nseg; r += gridDim.x) {
+    for (long r = blockIdx.y; r < nseg; r += gridDim.y) {
         const long p = r / outer_na, oi = r % outer_na;
         const long lo = (p * B < nb) ? p * B : nb;
         const long hi = (lo + B < nb) ? lo + B : nb;
         const long cnt = (hi - lo) * inner;
-        const double *s = src + outer_na * inner * lo + oi * cnt;
-        double *d = dst + (oi * nb + lo) * inner;
-        for (long i = threadIdx.x; i < cnt; i += blockDim.x) d[i] = s[i];
+        const long so = outer_na * inner * lo + oi * cnt, dof = (oi * nb + lo) * inner;
+        copy_segment(src + so, dst + dof, cnt, ((cnt | so | dof) & 1) == 0);
     }
 }
 
@@ -409,21 +425,20 @@ int ddh_grid_reduce(double *out3_d, const double *x, long n, double *work_d, voi
 int ddh_a2a_pack(const double *src, double *dst, long outer, long na, long nb, long inner, int nparts, void *stream) {
     if (nparts < 1 || na % nparts) return fail("ddh_a2a_pack: axis length must be divisible by nparts");
     const long row = nb * inner;
-    long nrows = outer * nparts;
-    unsigned grid = (unsigned)(nrows < 8192 ? nrows : 8192);
-    if (grid == 0) return 0;
-    hipLaunchKernelGGL(a2a_pack_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, dst, outer, na, row, nparts);
+    const long nrows = outer * nparts;
+    if (nrows <= 0 || na * row == 0) return 0;
+    hipLaunchKernelGGL(a2a_pack_kernel, seg_grid(nrows, (na / nparts) * row), dim3(256), 0, as_stream(stream), src, dst, outer, na,
+                       row, nparts);
     DDH_HIP(hipGetLastError());
     return 0;
 }
 
 int ddh_a2a_unpack(const double *src, double *dst, long outer, long na, long nb, long inner, int nparts, void *stream) {
     if (nparts < 1 || nb % nparts) return fail("ddh_a2a_unpack: axis length must be divisible by nparts");
-    long nseg = (long)nparts * outer * na;
-    unsigned grid = (unsigned)(nseg < 8192 ? nseg : 8192);
-    if (grid == 0) return 0;
-    hipLaunchKernelGGL(a2a_unpack_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, dst, outer, na, nb, inner,
-                       nparts);
+    const long nseg = (long)nparts * outer * na;
+    if (nseg <= 0 || nb * inner == 0) return 0;
+    hipLaunchKernelGGL(a2a_unpack_kernel, seg_grid(nseg, (nb / nparts) * inner), dim3(256), 0, as_stream(stream), src, dst, outer,
+                       na, nb, inner, nparts);
     DDH_HIP(hipGetLastError());
     return 0;
 }
@@ -440,9 +455,8 @@ int ddh_a2av_pack_b(const double *src, double *dst, long outer, long na, long ro
     if (nparts < 1 || na < 1) return fail("ddh_a2av_pack: bad arguments");
     const long B = block ? block : (na + nparts - 1) / nparts;
     const long nseg = outer * nparts;
-    const unsigned grid = (unsigned)(nseg < 8192 ? nseg : 8192);
-    if (grid == 0) return 0;
-    hipLaunchKernelGGL(a2av_pack_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, dst, outer, na, row, nparts, B);
+    if (nseg <= 0) return 0;
+    hipLaunchKernelGGL(a2av_pack_kernel, seg_grid(nseg, B * row), dim3(256), 0, as_stream(stream), src, dst, outer, na, row, nparts, B);
     DDH_HIP(hipGetLastError());
     return 0;
 }
@@ -451,9 +465,8 @@ int ddh_a2av_unpack_b(const double *src, double *dst, long outer_na, long nb, lo
     if (nparts < 1 || nb < 1) return fail("ddh_a2av_unpack: bad arguments");
     const long B = block ? block : (nb + nparts - 1) / nparts;
     const long nseg = (long)nparts * outer_na;
-    const unsigned grid = (unsigned)(nseg < 8192 ? nseg : 8192);
-    if (grid == 0) return 0;
-    hipLaunchKernelGGL(a2av_unpack_kernel, dim3(grid), dim3(256), 0, as_stream(stream), src, dst, outer_na, nb, inner, nparts, B);
+    if (nseg <= 0) return 0;
+    hipLaunchKernelGGL(a2av_unpack_kernel, seg_grid(nseg, B * inner), dim3(256), 0, as_stream(stream), src, dst, outer_na, nb, inner, nparts, B);
     DDH_HIP(hipGetLastError());
     return 0;
 }

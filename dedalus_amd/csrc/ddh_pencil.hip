@@ -1801,6 +1801,246 @@ solve_forward_lean_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__rest
     }
 }
 
+template <int KLT, int NBT, int PD, int NT>       // NT: right-hand-side terms at most (rhs.n <= NT)
+__global__ void __launch_bounds__(256, 1)
+solve_forward_deep_kernel(PencilDev P, LuDev L, const RhsSrc rhs, double *__restrict__ xout) {
+    constexpr int NF = 2;
+    extern __shared__ int s_lds[];
+    const int N = L.N, n = L.n, nb = L.nb;
+    int *s_perm = s_lds;                                    // rowperm, then colperm of the border
+    int *s_perm2 = s_lds + (L.pair ? N + nb : 0);           // the partner's (aliases s_perm when unpaired)
+    unsigned char *s_code = (unsigned char *)(s_perm2 + N + nb);
+    unsigned char *s_zero = s_code + N + nb;                // rows whose right-hand side is zero in every term: not read
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        s_perm[i] = L.rowperm[i];
+        if (L.pair) s_perm2[i] = L.rowperm2[i];
+        s_code[i] = L.row_code[i];
+        s_zero[i] = rhs.zrow ? (rhs.zrow[L.rowperm[i]] && (!L.pair || rhs.zrow[L.rowperm2[i]])) : 0;
+    }
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+        s_perm[N + i] = L.colperm[n + i];
+        if (L.pair) s_perm2[N + i] = L.colperm2[n + i];
+        s_code[N + i] = L.col_code[n + i];
+    }
+    __syncthreads();
+    // independent diagonal blocks (LuDev::nsplit): this thread sweeps rows row0 .. row1 - 1 of system g
+    // (Gp is a multiple of the workgroup size: the block index is uniform over the workgroup -- computed from blockIdx
+    // alone so that the row counters and everything indexed by them stay in scalar registers)
+    const int blk = L.nsplit > 1 ? __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x) / L.Gp)) : 0;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x - (long)blk * L.Gp;
+    const int row0 = blk * L.nh, row1 = row0 + L.nh;
+    const SysId id = sys_id<true>(P, L, g);
+    if (!id.ok) return;
+    const int s = id.s;
+    const CellCtx c = cell_ctx(P, id.cell);
+    const long G = id.G;
+    const int *my_perm = id.partner ? s_perm2 : s_perm;
+    const bool conjq = id.partner && s == 1;
+    const long plane = P.nx * P.ny;
+    // running per-lane pointers, advanced by uniform strides once per row:
+    //   mp[i]: multiplier L(j + i + 1, j) = row j + i + 1, entry KLT - i - 1;  abp: border multipliers of column j (nb entries,
+    //   512 B apart: immediate offsets);  pvp: the interchange of step j;  scr: y_j of this system
+    // (one per-lane base + a running 32-bit byte offset + KLT wave-uniform deltas: 3 vector registers instead of 2 KLT)
+    const char *const awl = (const char *)((const double *)L.Aw + lu_aw(L, id.gl, row0, -L.kpad));   // this lane's block, first row, entry 0
+    unsigned mo = 0;
+    unsigned md[KLT];
+    {
+        const long BW64 = (long)L.BW << 6;
+#pragma unroll
+        for (int i = 0; i < KLT; ++i) md[i] = (unsigned)(((long)(i + 1) * BW64 + lu_eoff(L, KLT - i - 1)) * 8);
+    }
+    const double *abp = (const double *)L.Ab + lu_ab(L, id.gl, row0, 0);
+    const unsigned char *pvp = L.piv + lu_pv(L, id.gl, row0);
+    double2 *scr = L.scratch + (long)row0 * G + g;
+    const unsigned row_step8 = (unsigned)L.BW << 9;              // bytes between band rows of a block (32-bit: a block is < 4 GB)
+    const long ab_step = (long)nb << 6;
+
+    auto load_row = [&](int i) -> double2 {
+        if (s_zero[i]) return make_double2(0.0, 0.0);           // wave-uniform
+#ifdef DDH_SWEEP_ABLATE
+        if (rhs.abl & 1) {                                      // right-hand-side terms from lane-contiguous addresses
+            double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int t = 0; t < RHS_MAX; ++t)
+                if (t < rhs.n) {
+                    const double2 q = *reinterpret_cast<const double2 *>(rhs.p[t] + (long)i * plane + 2 * g);
+                    acc.x += rhs.a[t] * q.x;
+                    acc.y += rhs.a[t] * q.y;
+                }
+            return acc;
+        }
+#endif
+        double2 v = load_sys<NF>(rhs, plane, my_perm[i], P, c, s);
+        if (conjq) v.y = -v.y;
+        const unsigned char code = s_code[i];
+        if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+        if (code & 1) v = make_double2(v.y, -v.x);
+        return v;
+    };
+
+    // the window (rows 0 .. KLT) and the border rows are shifted in by rolled loops: one inlined copy of the row load each
+    double2 w[KLT + 1];
+#pragma unroll
+    for (int d = 0; d <= KLT; ++d) w[d] = make_double2(0.0, 0.0);
+#pragma unroll 1
+    for (int t = 0; t <= KLT; ++t) {
+        const double2 v = (row0 + t < row1) ? load_row(row0 + t) : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int d = 0; d < KLT; ++d) w[d] = w[d + 1];
+        w[KLT] = v;
+    }
+    double2 gb[NBT];
+#pragma unroll
+    for (int rb = 0; rb < NBT; ++rb) gb[rb] = make_double2(0.0, 0.0);
+#pragma unroll 1
+    for (int t = 0; t < NBT; ++t) {
+        const double2 v = (t < nb && blk == 0) ? load_row(n + t) : make_double2(0.0, 0.0);   // (block 0 carries the border's right-hand side)
+#pragma unroll
+        for (int rb = 0; rb + 1 < NBT; ++rb) gb[rb] = gb[rb + 1];
+        gb[NBT - 1] = v;
+    }
+    // PD register sets: the factor data of column j and the raw right-hand-side terms of the row that enters the window
+    // at step j, requested PD steps ahead (set = (j - row0) % PD: the loop below is unrolled PD-fold)
+    double m[PD][KLT], ab[PD][NBT];
+    int pv[PD];
+    double2 raw[PD][NT];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+        pv[d] = 0;
+#pragma unroll
+        for (int i = 0; i < KLT; ++i) m[d][i] = 0.0;
+#pragma unroll
+        for (int rb = 0; rb < NBT; ++rb) ab[d][rb] = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) raw[d][t] = make_double2(0.0, 0.0);
+    }
+    // this thread's offset inside a row of the term vectors (tile-major or natural layout)
+    const long cell_off = rhs.tiled ? tile_offset(2 * c.mx + s, 2 * c.my, P.ny) : (2 * c.mx + s) * P.ny + 2 * c.my;
+    // BRANCH-FREE: a uniform branch around any of these loads makes the number of loads in flight depend on the path, and
+    // the compiler then waits for the smaller count -- i.e. drains the pipeline at every step.  Hence: the border is full
+    // (nb == NBT, checked at the launch), terms beyond rhs.n re-read term 0 (coefficient 0), rows that are structurally
+    // zero or past the end of the block are read anyway (and discarded in `entering`).
+    const double *pt[NT];
+    double at[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        pt[t] = t < rhs.n ? rhs.p[t] : rhs.p[0];
+        at[t] = t < rhs.n ? rhs.a[t] : 0.0;
+    }
+    auto request = [&](int jrow, double *mm, double *aa, int &p, double2 *q) {
+        // (past the end of the block: the last row again -- never used, but the addresses stay inside the block)
+        const unsigned jr = (unsigned)((jrow < row1 ? jrow : row1 - 1) - row0);
+        const unsigned mo_j = jr * row_step8;
+        p = pvp[(long)jr << 6];
+#pragma unroll
+        for (int i = 0; i < KLT; ++i) mm[i] = *reinterpret_cast<const double *>(awl + (mo_j + md[i]));
+        const double *abj = abp + (long)jr * ab_step;
+#pragma unroll
+        for (int rb = 0; rb < NBT; ++rb) aa[rb] = abj[rb << 6];
+        const int nxt = jrow + KLT + 1;
+        const long off = (long)my_perm[nxt < row1 ? nxt : row1 - 1] * plane + cell_off;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) q[t] = *reinterpret_cast<const double2 *>(pt[t] + off);
+        __builtin_amdgcn_sched_barrier(0);      // the requests stay here (see solve_backward_deep_kernel)
+    };
+    // the row that enters the window at step jrow, from its raw terms: the arithmetic of load_sys / load_row, in their order
+    auto entering = [&](int jrow, const double2 *q) -> double2 {
+        const int nxt = jrow + KLT + 1;
+        if (nxt >= row1 || s_zero[nxt]) return make_double2(0.0, 0.0);
+        double2 v;
+        if (rhs.n == 1 && !rhs.tiled) {
+            const double2 mine = q[0];
+            double2 other;
+            other.x = __shfl_xor(mine.x, 1);
+            other.y = __shfl_xor(mine.y, 1);
+            v = s == 0 ? make_double2(mine.x - other.y, mine.y + other.x) : make_double2(other.x + mine.y, other.y - mine.x);
+            if (rhs.a[0] != 1.0) v = make_double2(rhs.a[0] * v.x, rhs.a[0] * v.y);
+        } else {
+            double2 mine = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                mine.x += at[t] * q[t].x;
+                mine.y += at[t] * q[t].y;
+            }
+            double2 other;
+            other.x = __shfl_xor(mine.x, 1);
+            other.y = __shfl_xor(mine.y, 1);
+            v = s == 0 ? make_double2(mine.x - other.y, mine.y + other.x) : make_double2(other.x + mine.y, other.y - mine.x);
+        }
+        if (conjq) v.y = -v.y;
+        const unsigned char code = s_code[nxt];
+        if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+        if (code & 1) v = make_double2(v.y, -v.x);
+        return v;
+    };
+    auto step = [&](const double *mm, const double *aa, int p, double2 rnew) {
+        double2 yj = w[0];
+#pragma unroll
+        for (int d = 1; d <= KLT; ++d) {
+            if (d == p) {
+                yj = w[d];
+                w[d] = w[0];
+            }
+        }
+        *scr = yj;
+        scr += G;
+#pragma unroll
+        for (int i = 1; i <= KLT; ++i) {
+            w[i].x -= mm[i - 1] * yj.x;
+            w[i].y -= mm[i - 1] * yj.y;
+        }
+#pragma unroll
+        for (int rb = 0; rb < NBT; ++rb) {
+            gb[rb].x -= aa[rb] * yj.x;
+            gb[rb].y -= aa[rb] * yj.y;
+        }
+#pragma unroll
+        for (int d = 0; d < KLT; ++d) w[d] = w[d + 1];
+        w[KLT] = rnew;
+    };
+    // (requests are unconditional: the factor rows are padded with KLT zero rows and rows_aw >= n + KLT, the right-hand-side
+    //  row is guarded inside; a branch around them would make the compiler wait for everything, see the backward kernel)
+#pragma unroll
+    for (int d = 0; d < PD; ++d) request(row0 + d, m[d], ab[d], pv[d], raw[d]);
+    int j = row0;
+    for (; j + PD - 1 < row1; j += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const double2 rnew = entering(j + d, raw[d]);
+            step(m[d], ab[d], pv[d], rnew);
+            request(j + d + PD, m[d], ab[d], pv[d], raw[d]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+        if (j + d < row1) step(m[d], ab[d], pv[d], entering(j + d, raw[d]));
+    if (L.nsplit > 1) {
+        // the border rows collect contributions of every block: partial sums, finished by border_finish_kernel
+#pragma unroll
+        for (int r = 0; r < NBT; ++r)
+            if (r < nb) L.scratch[(long)(n + nb + blk * nb + r) * G + g] = gb[r];
+        return;
+    }
+    // ---- Schur block: z = Sinv * gb ; border unknown r is logical column n + r
+    const double *Ab = (const double *)L.Ab;
+#pragma unroll
+    for (int r = 0; r < NBT; ++r) {
+        if (r < nb) {
+            double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int cidx = 0; cidx < NBT; ++cidx)
+                if (cidx < nb) El<true>::fma2(acc, Ab[lu_ab(L, id.gl, n + cidx, r)], gb[cidx]);
+            L.scratch[(long)(n + r) * G + g] = acc;     // graded value for the backward sweep
+            double2 v = acc;
+            const unsigned char code = s_code[N + r];
+            if (code & 1) v = make_double2(-v.y, v.x);
+            if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+            if (conjq) v.y = -v.y;
+            store_sys<NF>(xout, plane, my_perm[N + r], P, c, s, v);
+        }
+    }
+}
+
 #ifdef DDH_SWEEP_ABLATE
 __constant__ int c_abl;          // timing ablations of the backward sweep (DDH_ABL): 2 lane-contiguous stores, 8 one factor load per row
 #endif
@@ -1881,7 +2121,20 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
             for (int d = 0; d < PBW; ++d) pr[d] = prow[d];
         }
         const E *Ur = ur0 + (long)j * ur_stride;
-        if constexpr (REAL) {
+        if constexpr (REAL && (DBG & 128) != 0) {
+            // TIMING ONLY (DDH_BWD_DBG=128, results are not a solve): the factor rows addressed as if the storage were
+            // [row][block of 64][entry][lane] instead of [block][row][entry][lane] -- at any time the whole chip then reads
+            // one contiguous 6 MB region per row instead of 9 KB pieces of a thousand streams 15 MB apart
+            const E *rm = (const E *)L.Aw + ((((long)j * L.nblk + (gl >> 6)) * L.BW) << 6) + lu_eoff(L, kl + L.kpad) + ((gl & 63) << 1);
+            const __amdgpu_buffer_rsrc_t rs_j = wave_rsrc(rm);
+            const unsigned ln_j = wave_lane_off(rm);
+#pragma unroll
+            for (int q = 0; 2 * q <= WT; ++q) {
+                const double2 uu = bload16(rs_j, ln_j, (unsigned)(q << 10));
+                u[2 * q] = uu.x;
+                if (2 * q + 1 <= WT) u[2 * q + 1] = uu.y;
+            }
+        } else if constexpr (REAL) {
             // pair-packed rows (LuDev::pk; the diagonal sits at an even entry): 16-byte loads, two entries each
             const unsigned urow = (unsigned)j * ur_row8;                                 // uniform
 #pragma unroll
@@ -1998,6 +2251,151 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
         if (j == row0) {
             fetch(row0, ua, ya, pa);
             row_even(row0, ua, ya, pa);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward sweep for FEW systems (real-graded two-axis path): the loads of the next PD rows in flight, in registers.
+//
+// With fewer threads than two wavefronts per SIMD -- one rank's share of a sharded run (16 384 pencils at P = 4: one
+// wave per SIMD), a 128^3 problem -- solve_backward_kernel is a chain of n dependent "load a row, wait one HBM round trip,
+// 40 multiply-adds" steps with nothing to hide the round trips behind: ~1.5 us per row whatever the bandwidth
+// (profiles/r6_rank_emulation.txt: 1.97 ms per solve at P = 8 against 0.73 ms for an eighth of the one-GPU solve).  One
+// wave per SIMD owns the whole register file (512 VGPRs), so the rows of the next PD steps are simply requested PD steps
+// ahead into PD register sets (the loop is unrolled PD-fold: every set is a compile-time index).  Same arithmetic in
+// the same order: bit-identical to solve_backward_kernel.  Replaces the back substitution of the reference's per-pencil
+// SuperLU solve (libraries/matsolvers.py:126-149).
+// ------------------------------------------------------------------------------------------------
+#ifndef DDH_BWD_DEEP_PD
+#define DDH_BWD_DEEP_PD 2       // register sets of the deep backward sweep: 2 x 40 + the 68 of the window fit 256 registers, 4 do not
+#endif
+template <int WT, int PD>
+__global__ void __launch_bounds__(256, 1)
+solve_backward_deep_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const double *__restrict__ pband,
+                           const unsigned char *__restrict__ skip) {
+    constexpr int NF = 2;
+    static_assert(PD >= 2 && PD % 2 == 0, "rows are processed in pairs");
+    extern __shared__ int s_lds[];
+    const int n = L.n, nb = L.nb, kl = L.kl;
+    int *s_perm = s_lds;
+    int *s_perm2 = s_lds + (L.pair ? n : 0);
+    unsigned char *s_code = (unsigned char *)(s_perm2 + n);
+    unsigned char *s_skip = s_code + n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        s_perm[i] = L.colperm[i];
+        if (L.pair) s_perm2[i] = L.colperm2[i];
+        s_code[i] = L.col_code[i];
+        s_skip[i] = skip ? (skip[L.colperm[i]] && (!L.pair || skip[L.colperm2[i]])) : 0;
+    }
+    __syncthreads();
+    const int blk = (L.nsplit > 1) ? __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x) / L.Gp)) : 0;
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x - (long)blk * L.Gp;
+    const int row0 = (L.nsplit > 1) ? blk * L.nh : 0, row1 = (L.nsplit > 1) ? row0 + L.nh : n;
+    const SysId id = sys_id<true>(P, L, g);
+    if (!id.ok) return;
+    const int s = id.s;
+    const CellCtx c = cell_ctx(P, id.cell);
+    const long G = id.G;
+    const int *my_perm = id.partner ? s_perm2 : s_perm;
+    const bool conjq = id.partner && s == 1;
+    const long plane = P.nx * P.ny;
+
+    double2 win[WT];   // win[d] = x[j+1+d] (graded)
+#pragma unroll
+    for (int d = 0; d < WT; ++d) {
+        win[d] = make_double2(0.0, 0.0);
+        if (d < nb && row1 == n) win[d] = L.scratch[(long)(n + d) * G + g];
+    }
+    constexpr int NQ = (WT + 2) / 2;
+    // the loaded words stay as the load instructions return them (four dwords): any conversion at the request would be an
+    // instruction that waits for the data right there
+    ddh_u4v u[PD][NQ];
+    double pr[PD][PBW];
+    ddh_u4v yv[PD];
+    const double *const ur0 = (const double *)L.Aw + lu_aw(L, id.gl, 0, kl);
+    const double2 *const y0 = L.scratch + g;
+    const __amdgpu_buffer_rsrc_t ur_rs = wave_rsrc(ur0);
+    const unsigned ur_lane = wave_lane_off(ur0);
+    const __amdgpu_buffer_rsrc_t y_rs = wave_rsrc(y0);
+    const unsigned y_lane = wave_lane_off(y0);
+    const unsigned ur_row8 = (unsigned)L.BW << 9, y_row16 = (unsigned)(G * (long)sizeof(double2));
+    auto lo = [](const ddh_u4v &q) -> double { return __hiloint2double((int)q.y, (int)q.x); };
+    auto hi = [](const ddh_u4v &q) -> double { return __hiloint2double((int)q.w, (int)q.z); };
+    auto fetch = [&](int j, ddh_u4v *uu, ddh_u4v &y, double *p) {
+        y = __builtin_amdgcn_raw_buffer_load_b128(y_rs, y_lane, (unsigned)j * y_row16, 0);
+        const double *prow = pband + (long)j * PBW;
+#pragma unroll
+        for (int d = 0; d < PBW; ++d) p[d] = prow[d];
+        const unsigned urow = (unsigned)j * ur_row8;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) uu[q] = __builtin_amdgcn_raw_buffer_load_b128(ur_rs, ur_lane, urow + (unsigned)(q << 10), 0);
+        // the requests stay HERE: left alone, the scheduler sinks them to their first use (fewer live registers) and the
+        // sweep is a chain of exposed round trips again
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto emit = [&](int j, double2 v) {
+        if (s_skip[j]) return;                           // wave-uniform
+        const unsigned char code = s_code[j];
+        if (code & 1) v = make_double2(-v.y, v.x);
+        if ((code & 2) && s == 1) v = make_double2(-v.x, -v.y);
+        if (conjq) v.y = -v.y;
+        store_sys<NF>(xout, plane, my_perm[j], P, c, s, v);
+    };
+    auto ent = [&](const ddh_u4v *uu, int e) -> double { return (e & 1) ? hi(uu[e >> 1]) : lo(uu[e >> 1]); };
+    auto row_even = [&](int j, const ddh_u4v *uu, const ddh_u4v &yr, const double *p) -> double2 {
+        double2 acc = make_double2(lo(yr), hi(yr));
+#pragma unroll
+        for (int d = 0; d < WT; ++d) El<true>::fms2(acc, ent(uu, d + 1), win[d]);
+        const double2 xj = El<true>::mul2(acc, ent(uu, 0));
+        double2 v = xj;
+#pragma unroll
+        for (int d = 0; d < PBW; ++d)
+            if (d < WT) { v.x += p[d] * win[d].x; v.y += p[d] * win[d].y; }
+        emit(j, v);
+        return xj;
+    };
+    auto row_odd = [&](int j, const ddh_u4v *uu, const ddh_u4v &yr, double2 xprev, const double *p) {
+        double2 acc = make_double2(lo(yr), hi(yr));
+        El<true>::fms2(acc, ent(uu, 1), xprev);
+#pragma unroll
+        for (int d = 1; d < WT; ++d) El<true>::fms2(acc, ent(uu, d + 1), win[d - 1]);
+        const double2 xj = El<true>::mul2(acc, ent(uu, 0));
+        double2 v = xj;
+        v.x += p[0] * xprev.x;
+        v.y += p[0] * xprev.y;
+#pragma unroll
+        for (int d = 1; d < PBW; ++d)
+            if (d - 1 < WT) { v.x += p[d] * win[d - 1].x; v.y += p[d] * win[d - 1].y; }
+        emit(j, v);
+#pragma unroll
+        for (int d = WT - 1; d > 1; --d) win[d] = win[d - 2];
+        win[1] = xprev;
+        win[0] = xj;
+    };
+    int j = row1 - 1;
+    // row (row1 - 1 - k) travels in register set k % PD
+#pragma unroll
+    for (int d = 0; d < PD; ++d) fetch(max(j - d, row0), u[d], yv[d], pr[d]);
+    for (; j - (PD - 1) >= row0; j -= PD) {
+#pragma unroll
+        for (int d = 0; d < PD; d += 2) {
+            // (the requests are unconditional -- past the end the first row again: with a branch around them the number of
+            //  loads in flight would depend on the path and the compiler would wait for the smaller count, i.e. for all)
+            const double2 xe = row_even(j - d, u[d], yv[d], pr[d]);
+            fetch(max(j - d - PD, row0), u[d], yv[d], pr[d]);
+            row_odd(j - d - 1, u[d + 1], yv[d + 1], xe, pr[d + 1]);
+            fetch(max(j - d - 1 - PD, row0), u[d + 1], yv[d + 1], pr[d + 1]);
+        }
+    }
+    // fewer than PD rows are left, requested into sets 0, 1, ... in order
+#pragma unroll
+    for (int d = 0; d < PD; d += 2) {
+        if (j - d - 1 >= row0) {
+            const double2 xe = row_even(j - d, u[d], yv[d], pr[d]);
+            row_odd(j - d - 1, u[d + 1], yv[d + 1], xe, pr[d + 1]);
+        } else if (j - d >= row0) {
+            row_even(j - d, u[d], yv[d], pr[d]);
         }
     }
 }
@@ -2736,6 +3134,15 @@ static bool lean_forward_ok(const LuDev &d) {
            d.rows_aw >= d.n + forward_window(d.kl) && d.kl <= 12 && d.nb <= 2;
 }
 
+// Few systems: the one-thread-per-(system, block) sweeps would run at less than two wavefronts per SIMD (MI355X: 1024
+// SIMDs): the deep-prefetch variants (solve_*_deep_kernel) take over.  DDH_SWEEP_DEEP=0 / 1 forces the choice.
+static bool sweep_deep(const LuDev &d) {
+    static const int env = getenv("DDH_SWEEP_DEEP") ? atoi(getenv("DDH_SWEEP_DEEP")) : -1;
+    if (!d.real || d.n <= 0) return false;
+    if (env >= 0) return env != 0;
+    return (long)d.nsplit * d.Gp < 2L * 1024 * 64;
+}
+
 // want_p: the caller asks for x = P y (recombination fused into the backward sweep); *did_p tells whether this launch
 // could do it (one-thread-per-system backward kernel of the real-graded 2-axis path with a band table on file).
 template <int NF>
@@ -2807,7 +3214,9 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     { hipLaunchKernelGGL((solve_forward_lean_kernel<KLTV, NBTV>), dim3(blocks_split), dim3(256), lds_f, s, P, d, rhs, x); }
             // (block-parallel sweeps double the thread count: 4 waves per SIMD keep every thread resident, DDH_SWEEP_OCC=4)
             static const int occ4 = getenv("DDH_SWEEP_OCC") ? atoi(getenv("DDH_SWEEP_OCC")) == 4 : 1;
-            if (forward_window(d.kl) == 6 && d.nsplit > 1 && occ4 && d.nb <= 1)
+            if (forward_window(d.kl) == 6 && d.nb == 1 && rhs.n >= 1 && rhs.n <= 4 && sweep_deep(d))     // few systems: PD rows of loads in flight
+                hipLaunchKernelGGL((solve_forward_deep_kernel<6, 1, 4, 4>), dim3(blocks_split), dim3(256), lds_f, s, P, d, rhs, x);
+            else if (forward_window(d.kl) == 6 && d.nsplit > 1 && occ4 && d.nb <= 1)
                 hipLaunchKernelGGL((solve_forward_lean_kernel<6, 1, 4>), dim3(blocks_split), dim3(256), lds_f, s, P, d, rhs, x);
             else if (forward_window(d.kl) == 6 && d.nb <= 1) DDH_LFWD(6, 1)
             else if (forward_window(d.kl) == 6) DDH_LFWD(6, 2) else DDH_LFWD(12, 2)
@@ -2860,7 +3269,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
             static const int occ4 = getenv("DDH_SWEEP_OCC") ? atoi(getenv("DDH_SWEEP_OCC")) == 4 : 1;
             // DDH_BWD_RING = D: factor rows and y through a per-wave LDS-DMA ring D rows deep (solve_backward_ring_kernel);
             // 0 = direct loads.  LDS per workgroup: the permutation tables + 4 waves x D x 3.25 KiB.
-            static const int ring = getenv("DDH_BWD_RING") ? atoi(getenv("DDH_BWD_RING")) : 2;
+            static const int ring = getenv("DDH_BWD_RING") ? atoi(getenv("DDH_BWD_RING")) : 0;
             const size_t tab = (((size_t)d.n * (d.pair ? 10 : 6)) + 1023) & ~(size_t)1023;
             if (W <= 17 && d.nsplit > 1 && occ4 && d.pair && ring >= 2 && ring <= 4 && P.G % 4 == 0) {
                 const size_t lds_r = tab + (size_t)4 * ring * BwdRing<17>::SLOT;
@@ -2877,7 +3286,16 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
 #undef DDH_RING
                 // the waves whose lane quads do not share a factorization (unpaired cells, a ragged last wave)
                 hipLaunchKernelGGL((solve_backward_kernel<NF, 17, true, false, true, 64, 4>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
-            } else if (W <= 17 && d.nsplit > 1 && occ4)
+            } else if (W <= 17 && sweep_deep(d)) {
+                // few systems (less than two waves per SIMD): PD rows of loads in flight in registers
+                static const int pd = getenv("DDH_BWD_DEEP_PD") ? atoi(getenv("DDH_BWD_DEEP_PD")) : DDH_BWD_DEEP_PD;
+                if (pd == 4)
+                    hipLaunchKernelGGL((solve_backward_deep_kernel<17, 4>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
+                else
+                    hipLaunchKernelGGL((solve_backward_deep_kernel<17, 2>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
+            } else if (W <= 17 && d.nsplit > 1 && occ4 && getenv("DDH_BWD_DBG") && atoi(getenv("DDH_BWD_DBG")) == 128)
+                hipLaunchKernelGGL((solve_backward_kernel<NF, 17, true, false, true, 128, 4>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
+            else if (W <= 17 && d.nsplit > 1 && occ4)
                 hipLaunchKernelGGL((solve_backward_kernel<NF, 17, true, false, true, 0, 4>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
             else if (W <= 17) DDH_SOLVE_P(17)
             else if (W <= 32) DDH_SOLVE_P(32)
@@ -3149,11 +3567,11 @@ static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y,
     const unsigned chunks = (unsigned)((A.nrows_out + rpc - 1) / rpc);
     if (chunks > 65535) return fail("pencil_matvec: too many row chunks");
     const dim3 grid(blocks, chunks ? chunks : 1);
-    if (P.nf == 2 && A.band && ps.nz == 0 && !A.order && blocks >= 64)
+    if (P.nf == 2 && A.band && ps.nz == 0 && !A.order && (blocks >= 64 || out_tiled))
         hipLaunchKernelGGL(band_matvec_kernel, grid, dim3(256), 0, s, P, A, x, y, rpc, keep_empty, out_tiled);
     else if (out_tiled)
         return fail("pencil_matvec_update_tiled: only the window-form mat-vec (real, wavenumber-independent bands; two Fourier "
-                    "axes, >= 16384 cells) writes the tile-major layout");
+                    "axes) writes the tile-major layout");
     else if (P.nf == 2)
         hipLaunchKernelGGL(matvec_kernel<2>, grid, dim3(256), 0, s, P, A, x, y, ps, rpc);
     else if (P.nf == 1)

@@ -140,6 +140,9 @@ def measure_json(tag, make, step, warm, steps, repeats=3):
         solver.ex.sync()
         rates.append(steps / (time.time() - t0))
     prof, costs = EventProfiler(torch), {}
+    import ctypes as C
+    w0 = C.c_long(0)
+    libhip.call("ddh_fft_wave_launches", C.byref(w0))
 
     def cost_log(name, flops, nbytes):
         c = costs.setdefault(name, [0.0, 0.0])
@@ -175,6 +178,12 @@ def measure_json(tag, make, step, warm, steps, repeats=3):
     out = dict(config=tag, steps_per_s=float(np.median(rates)), ms_per_step=1e3 / float(np.median(rates)),
                repeats=rates, steps=steps, launches_per_step=sum(n for n, _ in ents.values()) / steps,
                entry_point_ms_per_step=sum(ms for _, ms in ents.values()) / steps, entry_points=table)
+    w1 = C.c_long(0)
+    libhip.call("ddh_fft_wave_launches", C.byref(w1))
+    out["wave_kernel_transforms_per_step"] = (w1.value - w0.value) / steps     # (of the Chebyshev / real-Fourier launches)
+    bi = getattr(solver, "_binv", None)
+    if isinstance(bi, dict) and "residual" in bi:
+        out["block_inverse_residual_max"] = bi["residual"]                    # ||B^-T B^T - I||_max of the sampled blocks
     if fam:
         out["kernel_families"] = {k: dict(launches_per_step=v["launches"] / steps, ms_per_launch=v["avg_ms"],
                                           algorithmic_GB_per_launch=v["bytes_per_launch"] / 1e9, GBps=v["gbps"],
@@ -212,7 +221,20 @@ def all_json():
     measure_json("H shell_convection ShellBasis(256,128,128) SBDF2", h_make, lambda s: s.step(0.05), 3, 10)
 
 
+def offsize_json():
+    """3-D Rayleigh-Benard at sizes OTHER than the benchmark's: which transform families run on the wave kernels and at what
+    fraction of the HBM rate (`kernel_families`: algorithmic bytes / HIP-event time)."""
+    for (nx, ny, nz), warm, steps in (((128, 128, 128), 3, 20), ((256, 256, 256), 3, 10), ((384, 384, 192), 3, 10),
+                                      ((1024, 1024, 128), 2, 5)):
+        def make(nx=nx, ny=ny, nz=nz):
+            return problems.rayleigh_benard_3d(d3, Nx=nx, Ny=ny, Nz=nz, timestepper="RK222")[0]
+        measure_json("3-D rayleigh_benard %dx%dx%d RK222" % (nx, ny, nz), make, lambda s: s.step(1e-3), warm, steps)
+
+
 if __name__ == "__main__":
+    if "--offsize" in sys.argv[1:]:
+        offsize_json()
+        sys.exit(0)
     if "--json" in sys.argv[1:]:
         all_json()
         sys.exit(0)

@@ -50,6 +50,7 @@ for step in "$@"; do
     sphere)     python -m pytest tests/test_gpu_swsh.py tests/test_gpu_sphere.py tests/test_gpu_shell.py -x -q -m gpu > $OUT/pytest_sphere.txt 2>&1; tail -3 $OUT/pytest_sphere.txt
                 python tools/bench_configs.py sphere 2>&1 | grep -v "^\[" | tail -3 | tee -a $OUT/sphere.txt ;;
     configs)    python tools/bench_configs.py --json > $OUT/configs.json 2> $OUT/configs.err; tail -5 $OUT/configs.json ;;
+    offsize)    python tools/bench_configs.py --offsize > $OUT/offsize.json 2> $OUT/offsize.err; python tools/show_offsize.py $OUT/offsize.json ;;
     shares)     # per-rank shares of the strong-scaled problem on one GPU, sweep variants A/B (profiles/*_strong_scaling_shares.txt)
                 for sz in 256,512,256 128,512,256 64,512,256; do
                   for var in "default:" "per-thread:DDH_SOLVE_COOP=0" "per-thread-unsplit:DDH_SOLVE_COOP=0 DDH_SPLIT_THREADS=0" "coop-fwd+cb4:DDH_COOP_FWD=1 DDH_COOP_CB=4" "cb4:DDH_COOP_FWD=0 DDH_COOP_CB=4"; do
@@ -74,6 +75,21 @@ PY
                 done ;;
     emu)        # one rank of the P-rank run on this GPU, loop-back exchange (profiles/r6_rank_emulation.txt)
                 python tools/rank_emulation.py --ranks 2,4,8 --rank 1 --steps 10 --warmup 3 ${ONE_GPU_MS:+--single-gpu-ms $ONE_GPU_MS} > $OUT/rank_emulation.jsonl 2> $OUT/rank_emulation.txt; cat $OUT/rank_emulation.txt ;;
+    bwd-rowmajor) # timing experiment: the backward sweep reading the factor rows as if stored row-major over the blocks
+                for v in 0 128; do DDH_BWD_DBG=$v python bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-cfl --no-parity > $OUT/bench_bwddbg$v.json 2> $OUT/bench_bwddbg$v.err
+                  echo "DDH_BWD_DBG=$v"; bench_line $OUT/bench_bwddbg$v.json; done ;;
+    deep-ab)    # few-system sweeps: deep register prefetch (solve_*_deep_kernel) against the plain kernels, bit identity + time
+                for sz in 64,512,256 128,512,256; do for v in 0 1 "1 DDH_BWD_DEEP_PD=4"; do
+                  env DDH_SWEEP_DEEP=$v python bench.py --size $sz --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-cfl --no-parity > $OUT/bench_deep.json 2> $OUT/bench_deep.err
+                  echo "size $sz DDH_SWEEP_DEEP=$v"; bench_line $OUT/bench_deep.json; done; done
+                DDH_SWEEP_DEEP=1 python -m pytest tests/test_gpu_pencil.py tests/test_gpu_reference_pencils.py -x -q -m gpu > $OUT/pytest_deep.txt 2>&1; tail -3 $OUT/pytest_deep.txt ;;
+    deep-big)   # the deep sweeps beyond their default range: 2 and 4 waves per SIMD worth of threads
+                for sz in 256,512,256 512,512,256; do for v in 0 1 "1 DDH_BWD_DEEP_PD=4"; do
+                  env DDH_SWEEP_DEEP=$v python bench.py --size $sz --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-cfl --no-parity > $OUT/bench_deep.json 2> $OUT/bench_deep.err
+                  echo "size $sz DDH_SWEEP_DEEP=$v"; bench_line $OUT/bench_deep.json; done; done ;;
+    emu-ring)   # the P = 4 / 8 shares with the backward sweep's LDS-DMA ring, depth 2 / 3 / 4
+                for r in 2 3 4; do echo "DDH_BWD_RING=$r" | tee -a $OUT/rank_emulation_ring.txt
+                  DDH_BWD_RING=$r python tools/rank_emulation.py --ranks 4,8 --rank 1 --steps 10 --warmup 3 2>&1 >/dev/null | tee -a $OUT/rank_emulation_ring.txt; done ;;
     tests-new)  python -m pytest tests/test_gpu_wave_transforms.py tests/test_gpu_comm.py tests/test_gpu_pencil.py tests/test_gpu_reference_pencils.py tests/test_gpu_baseline_sizes.py -x -q -m gpu -s > $OUT/pytest_new.txt 2>&1; tail -5 $OUT/pytest_new.txt; grep "end state vs" $OUT/pytest_new.txt ;;
     *)          echo "running: $step"; bash -c "$step" ;;
   esac
