@@ -45,13 +45,16 @@ PMC_FAMILY = {   # kernel family in this file -> device kernel name prefixes in 
 
 def pmc_traffic(family):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC passes
-    (profiles/r5_pmc_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes,
+    (profiles/r6_pmc_summary.txt, else the newest older one: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes,
     full-size run; a family made of several kernels per call sums their per-launch means).
     Returns None when no measurement is on file."""
-    path = os.path.join(ROOT, "profiles", "r5_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")
-    if not os.path.exists(path) or family not in PMC_FAMILY:
+    path = None
+    for tag in ("r6", "r5", "r4"):
+        cand = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
+        if os.path.exists(cand):
+            path = cand
+            break
+    if path is None or family not in PMC_FAMILY:
         return None
     data = json.load(open(path))
     tot = 0.0
@@ -473,7 +476,7 @@ def main():
                         frac=dom[1]["gbps"] / HBM_PEAK_GBS,
                         traffic=(pmc_traffic(dom[0]) if (Nx, Ny, Nz) == (512, 512, 256) and world == 1 else None),
                         traffic_note="bytes per launch from rocprofv3 PMC passes committed under profiles/ "
-                                     "(r5_pmc_summary.txt); algorithmic bytes and time are measured live",
+                                     "(r6_pmc_summary.txt); algorithmic bytes and time are measured live",
                         avg_launch_ms=dom[1]["avg_ms"], algorithmic_bytes_per_launch=dom[1]["bytes_per_launch"],
                         launches=dom[1]["launches"])
         # the fused y stage is co-limited by FP64 issue: its algorithmic flops per launch (a real transform of N points =

@@ -311,7 +311,21 @@ __global__ void scatter_add_kernel(double *__restrict__ y, const long *__restric
     if (i < n) y[idx[i]] += vals[i];
 }
 
+__global__ void scatter_set_kernel(double *__restrict__ y, const long *__restrict__ idx,
+                                   const double *__restrict__ vals, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[idx[i]] = vals[i];
+}
+
 extern "C" {
+
+int ddh_scatter_set(double *y, const long *idx_d, const double *vals_d, long n, void *stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(scatter_set_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), y,
+                       idx_d, vals_d, n);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
 
 int ddh_scatter_add(double *y, const long *idx_d, const double *vals_d, long n, void *stream) {
     if (n <= 0) return 0;

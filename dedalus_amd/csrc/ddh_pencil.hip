@@ -3140,7 +3140,7 @@ static bool sweep_deep(const LuDev &d) {
     static const int env = getenv("DDH_SWEEP_DEEP") ? atoi(getenv("DDH_SWEEP_DEEP")) : -1;
     if (!d.real || d.n <= 0) return false;
     if (env >= 0) return env != 0;
-    return (long)d.nsplit * d.Gp < 2L * 1024 * 64;
+    return (long)d.nsplit * d.Gp <= 2L * 1024 * 64;
 }
 
 // want_p: the caller asks for x = P y (recombination fused into the backward sweep); *did_p tells whether this launch

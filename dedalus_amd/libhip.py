@@ -51,6 +51,7 @@ SIGNATURES = {
     "ddh_destroy": [_h],
     "ddh_plan_rfft": [_hp, _i, _i],
     "ddh_scatter_add": [_vp, _vp, _vp, _l, _vp],
+    "ddh_scatter_set": [_vp, _vp, _vp, _l, _vp],
     "ddh_plan_grouped_mmt": [_hp, _i, _i, _vp, _i, _ip, C.POINTER(_vp), C.POINTER(_vp)],
     "ddh_grouped_mmt_set_pairs": [_h, _i, _ip, _ip, _ip, _ip],
     "ddh_grouped_mmt_forward": [_h, _vp, _vp, _l, _l, _l, _l, _l, _vp],

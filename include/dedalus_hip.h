@@ -278,6 +278,9 @@ int ddh_ellband_bordered_inverse(const double *X_d, int n, int j0, const double 
  * (e.g. "b(z=0) = Lz", gathered into F by gather_outputs core/timesteppers.py:611-614) touch a handful of
  * rows of the k = 0 pencil only. */
 int ddh_scatter_add(double *y, const long *idx_d, const double *vals_d, long n, void *stream);
+/* y[idx[i]] = vals[i]: the same entries when the right-hand-side rows are written directly by the forward transforms
+ * (the constant rows of F are then set, not accumulated; core/timesteppers.py:611-614). */
+int ddh_scatter_set(double *y, const long *idx_d, const double *vals_d, long n, void *stream);
 
 /* y = sum_t alpha[t] * x_t  (RHS assembly timesteppers.py:617-623 / :156-166; BLAS axpy chain).
  * xs_h: host array of nterms device pointers; y may alias one of them only if it is xs_h[0].   */

@@ -183,7 +183,8 @@ def measure_json(tag, make, step, warm, steps, repeats=3):
     out["wave_kernel_transforms_per_step"] = (w1.value - w0.value) / steps     # (of the Chebyshev / real-Fourier launches)
     bi = getattr(solver, "_binv", None)
     if isinstance(bi, dict) and "residual" in bi:
-        out["block_inverse_residual_max"] = bi["residual"]                    # ||B^-T B^T - I||_max of the sampled blocks
+        out["block_inverse_residual_max"] = bi["residual"]                    # ||B^T X - I||_max of the sampled blocks
+        out["block_inverse_left_residual_max"] = bi.get("left_residual")      # ||X B^T - I||_max ~ cond(B) eps
     if fam:
         out["kernel_families"] = {k: dict(launches_per_step=v["launches"] / steps, ms_per_launch=v["avg_ms"],
                                           algorithmic_GB_per_launch=v["bytes_per_launch"] / 1e9, GBps=v["gbps"],
