@@ -137,6 +137,7 @@ __device__ __forceinline__ void lds_fft(double2 *buf, const FftDev &p, const dou
             case 3: fft_pass<3>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
             case 4: fft_pass<4>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
             case 5: fft_pass<5>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
+            case 6: fft_pass<6>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
             case 8: fft_pass<8>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
             case 16: fft_pass<16>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
             default: fft_pass<7>(buf, p.ld, B, p.N, Ns, p.fd_nb[i], p.fd_ns[i], tw_lo, tw_hi, sign, tid, T, p.dbg); break;
@@ -1007,7 +1008,15 @@ static bool factorize(int n, int *radix, int &nradix) {
     while (n % 5 == 0) { radix[nradix++] = 5; n /= 5; }
     while (n % 7 == 0) { radix[nradix++] = 7; n /= 7; }
     if (nradix == 0 && n == 1) return true;  // N == 1
-    return n == 1 && nradix <= MAX_RADIX_PASSES;
+    if (n != 1 || nradix > MAX_RADIX_PASSES) return false;
+    // radix 6 (round 6): 2 x 3 -> 6 and 4 x 3 x 3 -> 6 x 6 -- one LDS pass (two workgroup barriers) fewer for the 3/2-padded
+    // sizes 96, 576, 1536, ... (16 16 2 3 -> 16 16 6; 16 4 3 3 -> 16 6 6).  DDH_FFT_NO_R6=1 keeps the old schedules (A/B).
+    static const bool no6 = getenv("DDH_FFT_NO_R6") != nullptr;
+    auto count = [&](int r) { int c = 0; for (int i = 0; i < nradix; ++i) c += radix[i] == r; return c; };
+    auto drop = [&](int r) { for (int i = 0; i < nradix; ++i) if (radix[i] == r) { for (int j = i; j + 1 < nradix; ++j) radix[j] = radix[j + 1]; --nradix; return; } };
+    while (!no6 && count(2) >= 1 && count(3) >= 1) { drop(2); drop(3); radix[nradix++] = 6; }
+    while (!no6 && count(4) >= 1 && count(3) >= 2) { drop(4); drop(3); drop(3); radix[nradix++] = 6; radix[nradix++] = 6; }
+    return true;
 }
 
 template <typename T>
@@ -1148,7 +1157,7 @@ static int make_plan(ddh_handle *out, int kind, int n_grid, int n_coeff, int nba
         }
         bool ok = prod == N;
         for (int i = 0; i < n; ++i)
-            ok = ok && (r[i] == 2 || r[i] == 3 || r[i] == 4 || r[i] == 5 || r[i] == 7 || r[i] == 8 || r[i] == 16);
+            ok = ok && (r[i] == 2 || r[i] == 3 || r[i] == 4 || r[i] == 5 || r[i] == 6 || r[i] == 7 || r[i] == 8 || r[i] == 16);
         if (ok) {
             d.nradix = n;
             for (int i = 0; i < n; ++i) d.radix[i] = r[i];
@@ -1497,6 +1506,33 @@ int ddh_rfft_bilinear_fused(ddh_handle plan, int na, const double *const *a_h, c
     if (nlines <= 0) return 0;
     FftDev d = pl->dev;
     const int T = FUSED_T;
+    // A WIDER INTERNAL GRID where this grid size has no wave kernel (round 6).  The stage maps coefficient lines to
+    // coefficient lines; its grid never reaches memory.  Bilinear products of lines with modes <= K are free of aliasing in
+    // the retained modes on ANY grid of N' > 3 K points, so the stage may run on the smallest N' >= N the wave kernels are
+    // instantiated for (N' = 128 C) and returns the same coefficients up to round-off -- e.g. 192-point lines (128 modes) on
+    // 256 points, 576-point lines (384 modes) on 768 -- instead of the workgroup-per-line-pair kernel below (0.05-0.12 of the
+    // HBM rate, profiles/r6_offsize_configs.txt).  DDH_FUSED_WIDER=0 keeps the plan's own size.
+    static const bool wider = !(getenv("DDH_FUSED_WIDER") && atoi(getenv("DDH_FUSED_WIDER")) == 0);
+    if (wider && !gridwave_supported(d)) {
+        if (!pl->fused_alt) {
+            static const int sizes[] = {256, 384, 512, 768, 1024};
+            for (int Np : sizes) {
+                FftDev t = d;
+                t.N = Np;
+                if (Np >= d.N && Np > 3 * d.K && gridwave_supported(t)) {
+                    ddh_handle h = 0;
+                    if (int st = make_plan(&h, K_RFFT, Np, d.M, 0, nullptr, nullptr)) return st;
+                    pl->fused_alt = h;
+                    break;
+                }
+            }
+        }
+        if (pl->fused_alt) {
+            FftPlan *alt = (FftPlan *)lookup_handle(pl->fused_alt, H_FFT);
+            if (!alt) return -1;
+            d = alt->dev;
+        }
+    }
     if ((long)d.N > 6L * T) return fail("rfft_bilinear_fused: axis too long for the fused kernel");
     // operands transformed together: 3 when the points fit 3 per thread and 12 staged values per thread
     static const int envG = getenv("DDH_FUSED_G") ? atoi(getenv("DDH_FUSED_G")) : 0;
@@ -1567,6 +1603,8 @@ int ddh_rfft_bilinear_fused(ddh_handle plan, int na, const double *const *a_h, c
     const size_t lds = ((size_t)d.ld * G + (size_t)tw_entries(d.N, d.twdirect)) * sizeof(double2);
     const dim3 grid((unsigned)npairs), block(T);
     hipStream_t st = as_stream(stream);
+    // (four workgroups per CU instead of two were tried in round 6: 128 registers spill 350-550 bytes per lane and the
+    //  kernel runs 1.6-2.9 x slower)
     if ((long)d.N <= 3L * T) {
         if (G == 3) hipLaunchKernelGGL((fused_rfft_bilinear_kernel<3, 3>), grid, block, lds, st, d, f, nlines, npairs);
         else hipLaunchKernelGGL((fused_rfft_bilinear_kernel<3, 1>), grid, block, lds, st, d, f, nlines, npairs);

@@ -70,7 +70,11 @@ struct FftPlan : HandleBase {
     FftDev dev;
     int tkind;
     void *d_tw = nullptr, *d_half = nullptr, *d_fscale = nullptr, *d_bscale = nullptr, *d_bands = nullptr;
+    // ddh_rfft_bilinear_fused: the plan of the wider grid the fused stage works on when this plan's grid size has no
+    // wave kernel (see there); 0 = none yet, owned by this plan
+    ddh_handle fused_alt = 0;
     ~FftPlan() override {
+        if (fused_alt) (void)ddh_destroy(fused_alt);
         (void)hipFree(d_tw);
         (void)hipFree(d_half);
         (void)hipFree(d_fscale);
