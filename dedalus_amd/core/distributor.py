@@ -367,8 +367,9 @@ class Transformer:
             n1 = int(Gz * nxl * rest)
             pend = None
             for c in range(nc):
-                send = ex.empty((n1,))
-                ex.a2a_pack(src[c:c + 1], send, 1, Gz, nxl, rest, P)
+                # one component [Gz][nx_loc][rest] split along z into P blocks IS the packed order [p][Gz / P][nx_loc][rest]:
+                # it is sent as it lies (round 5 ran a pack kernel here that copied the component onto itself)
+                send = src[c:c + 1].reshape(-1)
                 recv = ex.empty((n1,))
                 work = self.dist.pcomm.all_to_all_start(recv, send)
                 if pend is not None:
@@ -461,14 +462,14 @@ class Transformer:
                     for cc in range(nc):
                         send = ex.empty((n1,))
                         ex.a2a_pack(src[cc:cc + 1], send, Gzl, nx, 1, rest, P)
-                        recv = ex.empty((n1,))
+                        # the received order [p][Gz / P][nx_loc][rest] IS the component [Gz][nx_loc][rest]: received in
+                        # place (round 5 unpacked with a kernel that copied the buffer onto the component unchanged)
+                        recv = tmp[cc:cc + 1].reshape(-1)
                         work = self.dist.pcomm.all_to_all_start(recv, send)
                         if pend is not None:
                             pend[0].wait()
-                            ex.a2a_unpack(pend[1], tmp[pend[2]:pend[2] + 1], 1, 1, Gzl * P, (nx // P) * rest, P)
                         pend = (work, recv, cc, send)
                     pend[0].wait()
-                    ex.a2a_unpack(pend[1], tmp[pend[2]:pend[2] + 1], 1, 1, Gzl * P, (nx // P) * rest, P)
                 else:
                     self._exchange(ex, "columns", src, tmp, nc, Gzl * P, nx, rest)
                 src = tmp

@@ -94,25 +94,26 @@ struct A2aPlan : HandleBase {
 };
 
 // equal-split all-to-all of `local` doubles: block p of `send` goes to rank p, block q of `recv` comes from rank q
-static int exchange(A2aPlan *pl, hipStream_t s) {
+// (send / recv: the plan's staging buffers, or the caller's arrays where a pack / unpack pass would be the identity)
+static int exchange(A2aPlan *pl, const double *send, double *recv, hipStream_t s) {
     const Comm *c = pl->comm;
     const size_t chunk = pl->local / (size_t)c->nranks;
     // the block a rank keeps is a device copy, not a trip through RCCL (1/P of the data never touches the fabric queue)
-    DDH_HIP(hipMemcpyAsync(pl->recv + (size_t)c->rank * chunk, pl->send + (size_t)c->rank * chunk, chunk * sizeof(double),
+    DDH_HIP(hipMemcpyAsync(recv + (size_t)c->rank * chunk, send + (size_t)c->rank * chunk, chunk * sizeof(double),
                            hipMemcpyDeviceToDevice, s));
     if (c->nranks == 1) return 0;
     if (c->loopback) {
         for (int p = 0; p < c->nranks; ++p)
             if (p != c->rank)
-                DDH_HIP(hipMemcpyAsync(pl->recv + (size_t)p * chunk, pl->send + (size_t)p * chunk, chunk * sizeof(double),
+                DDH_HIP(hipMemcpyAsync(recv + (size_t)p * chunk, send + (size_t)p * chunk, chunk * sizeof(double),
                                        hipMemcpyDeviceToDevice, s));
         return 0;
     }
     DDH_NCCL(g_rccl.GroupStart());
     for (int p = 0; p < c->nranks; ++p) {
         if (p == c->rank) continue;
-        DDH_NCCL(g_rccl.Send(pl->send + (size_t)p * chunk, chunk, ncclDouble, p, c->comm, s));
-        DDH_NCCL(g_rccl.Recv(pl->recv + (size_t)p * chunk, chunk, ncclDouble, p, c->comm, s));
+        DDH_NCCL(g_rccl.Send(send + (size_t)p * chunk, chunk, ncclDouble, p, c->comm, s));
+        DDH_NCCL(g_rccl.Recv(recv + (size_t)p * chunk, chunk, ncclDouble, p, c->comm, s));
     }
     DDH_NCCL(g_rccl.GroupEnd());
     return 0;
@@ -309,8 +310,13 @@ int ddh_a2a_localize_rows(ddh_handle plan, const double *cl, double *rl, void *s
         return 0;
     }
     // split N1 into P row blocks, exchange, gather the P column blocks along N2
-    if (int s = ddh_a2a_pack(cl, pl->send, pl->n0, pl->n1, pl->n2 / P, pl->n3, P, stream)) return s;
-    if (int s = exchange(pl, as_stream(stream))) return s;
+    // (N0 == 1: the packed order [p][n1 / P][n2 / P][n3] IS the column-local array -- it is sent as it lies, no pack pass)
+    const double *send = cl;
+    if (pl->n0 > 1) {
+        if (int s = ddh_a2a_pack(cl, pl->send, pl->n0, pl->n1, pl->n2 / P, pl->n3, P, stream)) return s;
+        send = pl->send;
+    }
+    if (int s = exchange(pl, send, pl->recv, as_stream(stream))) return s;
     return ddh_a2a_unpack(pl->recv, rl, pl->n0, pl->n1 / P, pl->n2, pl->n3, P, stream);
 }
 
@@ -338,7 +344,9 @@ int ddh_a2a_localize_columns(ddh_handle plan, const double *rl, double *cl, void
     }
     // split N2 into P column blocks ([N0 N1/P][N2][1][N3] view), exchange, gather the P row blocks along N1
     if (int s = ddh_a2a_pack(rl, pl->send, pl->n0 * (pl->n1 / P), pl->n2, 1, pl->n3, P, stream)) return s;
-    if (int s = exchange(pl, as_stream(stream))) return s;
+    // (N0 == 1: the received order [p][n1 / P][n2 / P][n3] IS the column-local array -- received in place, no unpack pass)
+    if (pl->n0 == 1) return exchange(pl, pl->send, cl, as_stream(stream));
+    if (int s = exchange(pl, pl->send, pl->recv, as_stream(stream))) return s;
     return ddh_a2a_unpack(pl->recv, cl, pl->n0, 1, pl->n1, (pl->n2 / P) * pl->n3, P, stream);
 }
 
