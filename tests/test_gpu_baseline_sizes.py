@@ -249,6 +249,7 @@ def test_rb3d_end_state_through_the_headline_kernels(shape, monkeypatch):
         pytest.skip("golden not generated: " + os.path.basename(path))
     G = np.load(path)
     monkeypatch.setenv("DDH_RHS_TILING_MIN", "0")
+    monkeypatch.setenv("DDH_PAIR_MIN", "0")              # partner pencils below their default size threshold (65 536 systems)
     Nx, Ny, Nz = shape
     solver, f = problems.rayleigh_benard_3d(d3, Nx=Nx, Ny=Ny, Nz=Nz, timestepper="RK222")
     assert solver.ex.name == "hip"
@@ -263,6 +264,7 @@ def test_rb3d_end_state_through_the_headline_kernels(shape, monkeypatch):
     if shape != (128, 128, 64):
         assert solver.rhs_tiling(lus) == Ny              # tile-major M.X / F buffers
     assert nwave > 0
+    assert bool(infos[0]["pair"]) == (Nx == Ny)          # x <-> y symmetric problems share factorizations between (kx, ky) and (ky, kx)
     sa = G["sample_a"] if "sample_a" in G.files else np.array([0, 4, 0, 4])
     sb = G["sample_b"] if "sample_b" in G.files else np.array([1, 8, 3, 8])
     worst = {}
