@@ -123,6 +123,11 @@ struct LuDev {
     int nsplit, nh;
     long Gp;
     int pair;
+    // Per-row fill of U, measured after every factorization (lu_width_kernel): wrow[j] = the last non-zero super-diagonal
+    // of row j over ALL stored factorizations.  Partial pivoting may fill kl + ku super-diagonals, most rows use fewer
+    // (512^2 x 256 Rayleigh-Benard: 15 of 17 for 486 of the 1288 rows, mean 13.5): the backward sweep loads only the
+    // entry pairs that can hold data (-17 % of its factor bytes).  null = not measured (every pair is loaded).
+    const int *wrow;
     const long *vcell;             // [ncells]
     const int *vslot;              // [ncells]
     const long *slot_cell;         // [GL] the cell whose matrix a slot holds
@@ -150,6 +155,7 @@ struct LuFactor {
     const double *d_binv = nullptr;
     void *d_pband = nullptr;                // [n][PBW] band of the recombination, see LuDev::pband
     void *d_vcell = nullptr, *d_vslot = nullptr, *d_rowperm2 = nullptr, *d_colperm2 = nullptr;   // partner pencils
+    void *d_wrow = nullptr;                 // [n] int, see LuDev::wrow
     std::vector<long> slot_cells_h;         // [2 * GL]: the cell of a slot and its partner (-1 = none)
     void *d_slot_cell = nullptr;
     int pband_mat = -1;                     // matrix id it was built from
@@ -199,6 +205,7 @@ static void free_lu(LuFactor *lu) {
     (void)hipFree(lu->d_slot_cell);
     (void)hipFree(lu->d_rowperm2);
     (void)hipFree(lu->d_colperm2);
+    (void)hipFree(lu->d_wrow);
     delete lu;
 }
 
@@ -2055,11 +2062,17 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
     int *s_perm2 = s_lds + (L.pair ? n : 0);
     unsigned char *s_code = (unsigned char *)(s_perm2 + n);
     unsigned char *s_skip = s_code + n;                 // unknowns the caller does not need: not stored
+    unsigned char *s_nq = s_skip + n;                   // entry pairs of U row j that can hold data (LuDev::wrow)
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         s_perm[i] = L.colperm[i];
         if (L.pair) s_perm2[i] = L.colperm2[i];
         s_code[i] = REAL ? L.col_code[i] : 0;
         s_skip[i] = skip ? (skip[L.colperm[i]] && (!L.pair || skip[L.colperm2[i]])) : 0;
+        if (REAL) {
+            const int full = (WT + 2) / 2;
+            const int need = L.wrow ? (L.wrow[i] + 2) >> 1 : full;
+            s_nq[i] = (unsigned char)(need < full ? need : full);
+        }
     }
     __syncthreads();
     // independent diagonal blocks (LuDev::nsplit; only launched that way for REAL): rows row1 - 1 .. row0 of system g
@@ -2137,6 +2150,10 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
         } else if constexpr (REAL) {
             // pair-packed rows (LuDev::pk; the diagonal sits at an even entry): 16-byte loads, two entries each
             const unsigned urow = (unsigned)j * ur_row8;                                 // uniform
+            // pairs beyond the measured fill of this row are exact zeros in every factorization: not loaded (wave-uniform;
+            // the first NQMIN pairs are loaded unconditionally -- nearly every row needs them, and every branch costs)
+            constexpr int NQMIN = (WT >= 13) ? 6 : (WT + 2) / 2;
+            const int nq = __builtin_amdgcn_readfirstlane((int)s_nq[j]);
 #pragma unroll
             for (int q = 0; 2 * q <= WT; ++q) {
 #ifdef DDH_SWEEP_ABLATE
@@ -2144,8 +2161,9 @@ solve_backward_kernel(PencilDev P, LuDev L, double *__restrict__ xout, const dou
 #else
                 constexpr bool one = false;
 #endif
-                const double2 uu = (((DBG & 1) && q > 0) || one) ? make_double2(u[0] * 0.5, u[0] * 0.25)
-                                                                 : bload16(ur_rs, ur_lane, urow + (unsigned)(q << 10));
+                double2 uu = make_double2(0.0, 0.0);
+                if (((DBG & 1) && q > 0) || one) uu = make_double2(u[0] * 0.5, u[0] * 0.25);
+                else if (q < NQMIN || q < nq) uu = bload16(ur_rs, ur_lane, urow + (unsigned)(q << 10));
                 u[2 * q] = uu.x;
                 if (2 * q + 1 <= WT) u[2 * q + 1] = uu.y;
             }
@@ -3155,7 +3173,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
     const int W = d.W;
     const size_t per_entry = d.pair ? 9 : 5;    // one (two when paired) int permutations + a code byte per row
     const size_t lds_f = (size_t)(d.N + d.nb) * (per_entry + 1) + 16,     // (+ the zero-row flags of the lean sweep)
- lds_b = (size_t)(d.n > 0 ? d.n : 1) * (per_entry + 1) + 16;
+ lds_b = (size_t)(d.n > 0 ? d.n : 1) * (per_entry + 2) + 16;   // (+ the skip flags and the row-fill table of the backward sweep)
     if (lds_f > 64 * 1024) return fail("pencil_solve: system too large for the LDS permutation cache");
     int use_fwd, cb;
     choose_variant<NF>(pp, d, use_fwd, cb);
@@ -3863,6 +3881,17 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
     if (lu->nflag) {
         st = upload_vec(&lu->d_flag_cells, lu->flag_cells.data(), lu->flag_cells.size());
         if (st) return st;
+    }
+    // the fill of U, row by row, for the backward sweep (LuDev::wrow); DDH_BWD_ROW_FILL=0: every pair is loaded
+    static const bool row_fill = !(getenv("DDH_BWD_ROW_FILL") && atoi(getenv("DDH_BWD_ROW_FILL")) == 0);
+    lu->dev.wrow = nullptr;
+    if (row_fill && real && n > 0) {
+        if (!lu->d_wrow) DDH_HIP(hipMalloc(&lu->d_wrow, (size_t)n * sizeof(int)));
+        DDH_HIP(hipMemsetAsync(lu->d_wrow, 0, (size_t)n * sizeof(int), s));
+        hipLaunchKernelGGL(lu_width_kernel<true>, dim3((unsigned)((lu->dev.GL + 255) / 256)), dim3(256), 0, s, lu->dev,
+                           (int *)lu->d_wrow);
+        DDH_HIP(hipGetLastError());
+        lu->dev.wrow = (const int *)lu->d_wrow;
     }
     if (reuse) {
         *lu_id = reuse_lu_id;
