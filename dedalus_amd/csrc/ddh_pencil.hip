@@ -3354,10 +3354,10 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
 // actually interchanged keep the original ku: the backward sweep then skips the all-zero tail entries.
 template <bool REAL>
 __global__ void __launch_bounds__(256)
-lu_width_kernel(LuDev L, int *__restrict__ wrow) {
+lu_width_kernel(LuDev L, int *__restrict__ wrow, long only_blk = -1) {     // only_blk >= 0: that block of 64 factorizations alone (diagnostic)
     typedef typename El<REAL>::T E;
     const long gl = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool act = gl < L.GL;
+    const bool act = gl < L.GL && (only_blk < 0 || (gl >> 6) == only_blk);
     const E *Aw = (const E *)L.Aw;
     for (int j = 0; j < L.n; ++j) {
         int w = 0;
@@ -3889,7 +3889,7 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
         if (!lu->d_wrow) DDH_HIP(hipMalloc(&lu->d_wrow, (size_t)n * sizeof(int)));
         DDH_HIP(hipMemsetAsync(lu->d_wrow, 0, (size_t)n * sizeof(int), s));
         hipLaunchKernelGGL(lu_width_kernel<true>, dim3((unsigned)((lu->dev.GL + 255) / 256)), dim3(256), 0, s, lu->dev,
-                           (int *)lu->d_wrow);
+                           (int *)lu->d_wrow, -1L);
         DDH_HIP(hipGetLastError());
         lu->dev.wrow = (const int *)lu->d_wrow;
     }
@@ -4163,8 +4163,9 @@ int ddh_pencil_lu_row_widths(ddh_handle pack, int lu_id, int *wrow_h) {
     DDH_HIP(hipMalloc((void **)&dw, d.n * sizeof(int)));
     DDH_HIP(hipMemset(dw, 0, d.n * sizeof(int)));
     const unsigned blocks = (unsigned)((d.GL + 255) / 256);
-    if (d.real) hipLaunchKernelGGL(lu_width_kernel<true>, dim3(blocks), dim3(256), 0, 0, d, dw);
-    else hipLaunchKernelGGL(lu_width_kernel<false>, dim3(blocks), dim3(256), 0, 0, d, dw);
+    const long only = getenv("DDH_LUW_BLOCK") ? atol(getenv("DDH_LUW_BLOCK")) : -1;      // (diagnostic: one block of 64)
+    if (d.real) hipLaunchKernelGGL(lu_width_kernel<true>, dim3(blocks), dim3(256), 0, 0, d, dw, only);
+    else hipLaunchKernelGGL(lu_width_kernel<false>, dim3(blocks), dim3(256), 0, 0, d, dw, only);
     DDH_HIP(hipGetLastError());
     DDH_HIP(hipMemcpy(wrow_h, dw, d.n * sizeof(int), hipMemcpyDeviceToHost));
     (void)hipFree(dw);

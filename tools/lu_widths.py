@@ -22,6 +22,15 @@ lu = list(ts._lus.values())[0]
 nint = solver.n_interior
 w = np.zeros(nint, dtype=np.int32)
 libhip.call("ddh_pencil_lu_row_widths", solver.pack.handle, lu, libhip.as_ip(w))
+if os.environ.get("LUW_BLOCKS"):
+    # fill per block of 64 stored factorizations (DDH_LUW_BLOCK is read per call): how much tighter than the global maximum?
+    pairs_all = np.minimum(9, (w + 2) // 2).mean()
+    for b in [int(x) for x in os.environ["LUW_BLOCKS"].split(",")]:
+        os.environ["DDH_LUW_BLOCK"] = str(b)
+        wb = np.zeros(nint, dtype=np.int32)
+        libhip.call("ddh_pencil_lu_row_widths", solver.pack.handle, lu, libhip.as_ip(wb))
+        print("block %5d: mean width %.2f, entry pairs per row %.2f (global maximum: %.2f)" % (b, wb.mean(), np.minimum(9, (wb + 2) // 2).mean(), pairs_all))
+    os.environ.pop("DDH_LUW_BLOCK")
 print("n_interior", nint, "kl", solver.kl, "ku", solver.ku, "allocated width", solver.kl + solver.ku)
 print("row width histogram:", dict(zip(*np.unique(w, return_counts=True))))
 print("mean width %.2f of %d -> U bytes read could drop to %.0f%%" % (w.mean(), solver.kl + solver.ku,
