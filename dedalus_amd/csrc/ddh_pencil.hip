@@ -1227,10 +1227,14 @@ factor_rows_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b
 // from global memory every step: 7.5 MB per system against ~0.9 MB here.  Same operations per entry in the same order:
 // bit-identical factors.
 // ------------------------------------------------------------------------------------------------
-constexpr int FW_WMAX = 36;      // window columns kl + ku + 1 held per thread
+constexpr int FW_WMAX = 36;      // window columns kl + ku + 1 held per thread (the general instantiation)
+// The narrow instantiation (FW_WMAX_T_T = 20 columns, 8 row threads, at most 84 registers): THREE workgroups per CU.  The
+// Rayleigh-Benard factorization at 512^2 is 514 workgroups of 8 waves; at 124 registers two of them fit a CU -- 512 slots
+// for 514 workgroups, i.e. the last two ran alone after everyone else and the kernel took two rounds (16.9 ms, rounds 3-5).
+constexpr int FW_WNARROW = 20, FW_NT_NARROW = 8;
 
-template <bool REAL>
-__global__ void __launch_bounds__(64 * FR_NTMAX)
+template <bool REAL, int FW_WMAX_T = FW_WMAX, int NTB = FR_NTMAX, int MINB = 1>     // MINB: waves per SIMD the register budget is sized for
+__global__ void __launch_bounds__(64 * NTB, MINB)
 factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double b, const int *__restrict__ rowinv,
                      const int *__restrict__ colinv) {
     typedef typename El<REAL>::T E;
@@ -1244,8 +1248,8 @@ factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double
     E *Aw = (E *)L.Aw, *Ab = (E *)L.Ab;
     const int n = L.n, nb = L.nb, N = L.N, kl = L.kl, W = L.W, KL1 = L.kl + 1;
     extern __shared__ double s_dyn_fw[];
-    E *s_piv = (E *)s_dyn_fw;                         // [FW_WMAX][64] the pivot row of the step
-    E *s_disp = s_piv + FW_WMAX * 64;                 // [FW_WMAX][64] the row an interchange displaces
+    E *s_piv = (E *)s_dyn_fw;                         // [FW_WMAX_T][64] the pivot row of the step
+    E *s_disp = s_piv + FW_WMAX_T * 64;                 // [FW_WMAX_T][64] the row an interchange displaces
     __shared__ double s_val[FR_NTMAX][64];
     __shared__ int s_flag[FR_NTMAX][64];
     double anorm = 0.0;
@@ -1281,9 +1285,9 @@ factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double
     const bool interior = ty <= kl;
     const int rb = ty - kl - 1;                        // border row of a border thread
     int my_row = ty;                                   // interior: the row this thread holds
-    E reg[FW_WMAX];                                    // reg[w]: the entry of my row in column j + w
+    E reg[FW_WMAX_T];                                    // reg[w]: the entry of my row in column j + w
 #pragma unroll
-    for (int w = 0; w < FW_WMAX; ++w) {
+    for (int w = 0; w < FW_WMAX_T; ++w) {
         reg[w] = El<REAL>::zero();
         if (w <= W) {
             if (interior) {
@@ -1318,14 +1322,14 @@ factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double
         // ---- (B) the pivot row (slot p) and the row it displaces (slot 0) go through LDS
         if (live && i == p) {
 #pragma unroll
-            for (int w = 0; w < FW_WMAX; ++w) {
+            for (int w = 0; w < FW_WMAX_T; ++w) {
                 if (w <= W) s_piv[w * 64 + tx] = reg[w];
                 if ((w & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (live && i == 0) {
 #pragma unroll
-            for (int w = 0; w < FW_WMAX; ++w) {
+            for (int w = 0; w < FW_WMAX_T; ++w) {
                 if (w <= W) s_disp[w * 64 + tx] = reg[w];
                 if ((w & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
@@ -1339,7 +1343,7 @@ factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double
         const E ip = El<REAL>::inv(piv);
         if (live && i == p && p != 0) {                // the old row j lives on in slot p
 #pragma unroll
-            for (int w = 0; w < FW_WMAX; ++w) {
+            for (int w = 0; w < FW_WMAX_T; ++w) {
                 if (w <= W) reg[w] = s_disp[w * 64 + tx];
                 if ((w & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
@@ -1352,7 +1356,7 @@ factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double
             else Ab[lu_ab(L, g, j, rb)] = m;
             if (!El<REAL>::is_zero(m)) {
 #pragma unroll
-                for (int w = 1; w < FW_WMAX; ++w) {
+                for (int w = 1; w < FW_WMAX_T; ++w) {
                     if (w <= wmax) El<REAL>::fms(reg[w], m, s_piv[w * 64 + tx]);
                     if ((w & 7) == 7) __builtin_amdgcn_sched_barrier(0);       // at most 8 LDS reads in flight (registers)
                 }
@@ -1366,7 +1370,7 @@ factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double
             {
                 const E *rowp = Aw + lu_aw(L, g, my_row < n ? my_row : 0, 0);         // one base, entry offsets added per load
 #pragma unroll
-                for (int w = 0; w < FW_WMAX; ++w) {
+                for (int w = 0; w < FW_WMAX_T; ++w) {
                     reg[w] = El<REAL>::zero();
                     if (w <= W && my_row < n) reg[w] = rowp[lu_eoff(L, w + L.kpad) - lu_eoff(L, L.kpad)];
                     if ((w & 7) == 7) __builtin_amdgcn_sched_barrier(0);
@@ -1374,13 +1378,13 @@ factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double
             }
         } else {
 #pragma unroll
-            for (int w = 0; w + 1 < FW_WMAX; ++w) reg[w] = reg[w + 1];
-            reg[FW_WMAX - 1] = El<REAL>::zero();
+            for (int w = 0; w + 1 < FW_WMAX_T; ++w) reg[w] = reg[w + 1];
+            reg[FW_WMAX_T - 1] = El<REAL>::zero();
             if (!interior && rb < nb) {
                 // the column entering a border row's window
                 const int cn = j + 1 + W;
 #pragma unroll
-                for (int w = 0; w < FW_WMAX; ++w)
+                for (int w = 0; w < FW_WMAX_T; ++w)
                     if (w == W) reg[w] = (cn < N) ? Ab[lu_ab(L, g, cn, rb)] : El<REAL>::zero();
             }
         }
@@ -1389,7 +1393,7 @@ factor_window_kernel(PencilDev P, LuDev L, MatDev M, MatDev Lm, double a, double
     // border rows: what is left of their window are the columns n .. N - 1
     if (!interior && rb < nb) {
 #pragma unroll
-        for (int w = 0; w < FW_WMAX; ++w)
+        for (int w = 0; w < FW_WMAX_T; ++w)
             if (w < N - n) Ab[lu_ab(L, g, n + w, rb)] = reg[w];
     }
     __syncthreads();
@@ -3352,6 +3356,8 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
 // Per-row upper width of the factors: wrow[j] = max over all factorizations of the last non-zero offset d of
 // U(j, j + d).  Partial pivoting can fill up to kl extra super-diagonals, but rows where no factorization
 // actually interchanged keep the original ku: the backward sweep then skips the all-zero tail entries.
+constexpr int LUW_ROWS = 32;      // rows per workgroup of lu_width_kernel
+
 template <bool REAL>
 __global__ void __launch_bounds__(256)
 lu_width_kernel(LuDev L, int *__restrict__ wrow, long only_blk = -1) {     // only_blk >= 0: that block of 64 factorizations alone (diagnostic)
@@ -3359,7 +3365,9 @@ lu_width_kernel(LuDev L, int *__restrict__ wrow, long only_blk = -1) {     // on
     const long gl = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool act = gl < L.GL && (only_blk < 0 || (gl >> 6) == only_blk);
     const E *Aw = (const E *)L.Aw;
-    for (int j = 0; j < L.n; ++j) {
+    // blockIdx.y: a chunk of LUW_ROWS rows (a thread's scan of a row is a chain of dependent loads: the chunks run side by side)
+    const int j0 = (int)blockIdx.y * LUW_ROWS, j1 = min(L.n, j0 + LUW_ROWS);
+    for (int j = j0; j < j1; ++j) {
         int w = 0;
         if (act) {
             for (int d = L.W; d > 0; --d)
@@ -3835,9 +3843,17 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
     static const int rows_mode = getenv("DDH_FACTOR_ROWS") ? atoi(getenv("DDH_FACTOR_ROWS")) : 2;   // 2: register window
     if (!rows_off && rows_mode >= 2 && real && NT <= FR_NTMAX && GL >= 64 && d.W + 1 <= FW_WMAX) {
         // (real factors: 72 of the 128 registers a 14-wave workgroup allows; the complex window would spill)
-        const size_t lds = 2 * (size_t)FW_WMAX * 64 * esz;
-        hipLaunchKernelGGL(factor_window_kernel<true>, dim3(blocks), dim3(64, NT), lds, s, P, d, pp->mats[matM_id]->dev,
-                           pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
+        static const bool narrow_ok = !(getenv("DDH_FACTOR_NARROW") && atoi(getenv("DDH_FACTOR_NARROW")) == 0);
+        if (narrow_ok && d.W + 1 <= FW_WNARROW && NT <= FW_NT_NARROW) {
+            // three workgroups per CU instead of two: the 514 workgroups of 512^2 pencils run in ONE round (see FW_WNARROW)
+            const size_t lds = 2 * (size_t)FW_WNARROW * 64 * esz;
+            hipLaunchKernelGGL((factor_window_kernel<true, FW_WNARROW, FW_NT_NARROW, 6>), dim3(blocks), dim3(64, NT), lds, s, P, d,
+                               pp->mats[matM_id]->dev, pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
+        } else {
+            const size_t lds = 2 * (size_t)FW_WMAX * 64 * esz;
+            hipLaunchKernelGGL(factor_window_kernel<true>, dim3(blocks), dim3(64, NT), lds, s, P, d, pp->mats[matM_id]->dev,
+                               pp->mats[matL_id]->dev, a, b, (const int *)d_rowinv, (const int *)d_colinv);
+        }
     } else if (!rows_off && NT <= FR_NTMAX && GL >= 64) {
         if (real)
             hipLaunchKernelGGL(factor_rows_kernel<true>, dim3(blocks), dim3(64, NT), 0, s, P, d, pp->mats[matM_id]->dev,
@@ -3888,8 +3904,8 @@ static int factor_impl(ddh_handle pack, int matM_id, int matL_id, double a, doub
     if (row_fill && real && n > 0) {
         if (!lu->d_wrow) DDH_HIP(hipMalloc(&lu->d_wrow, (size_t)n * sizeof(int)));
         DDH_HIP(hipMemsetAsync(lu->d_wrow, 0, (size_t)n * sizeof(int), s));
-        hipLaunchKernelGGL(lu_width_kernel<true>, dim3((unsigned)((lu->dev.GL + 255) / 256)), dim3(256), 0, s, lu->dev,
-                           (int *)lu->d_wrow, -1L);
+        hipLaunchKernelGGL(lu_width_kernel<true>, dim3((unsigned)((lu->dev.GL + 255) / 256), (unsigned)((n + LUW_ROWS - 1) / LUW_ROWS)),
+                           dim3(256), 0, s, lu->dev, (int *)lu->d_wrow, -1L);
         DDH_HIP(hipGetLastError());
         lu->dev.wrow = (const int *)lu->d_wrow;
     }
@@ -4164,8 +4180,9 @@ int ddh_pencil_lu_row_widths(ddh_handle pack, int lu_id, int *wrow_h) {
     DDH_HIP(hipMemset(dw, 0, d.n * sizeof(int)));
     const unsigned blocks = (unsigned)((d.GL + 255) / 256);
     const long only = getenv("DDH_LUW_BLOCK") ? atol(getenv("DDH_LUW_BLOCK")) : -1;      // (diagnostic: one block of 64)
-    if (d.real) hipLaunchKernelGGL(lu_width_kernel<true>, dim3(blocks), dim3(256), 0, 0, d, dw, only);
-    else hipLaunchKernelGGL(lu_width_kernel<false>, dim3(blocks), dim3(256), 0, 0, d, dw, only);
+    const dim3 wgrid(blocks, (unsigned)((d.n + LUW_ROWS - 1) / LUW_ROWS));
+    if (d.real) hipLaunchKernelGGL(lu_width_kernel<true>, wgrid, dim3(256), 0, 0, d, dw, only);
+    else hipLaunchKernelGGL(lu_width_kernel<false>, wgrid, dim3(256), 0, 0, d, dw, only);
     DDH_HIP(hipGetLastError());
     DDH_HIP(hipMemcpy(wrow_h, dw, d.n * sizeof(int), hipMemcpyDeviceToHost));
     (void)hipFree(dw);
