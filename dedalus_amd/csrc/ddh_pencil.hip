@@ -3165,6 +3165,16 @@ static bool sweep_deep(const LuDev &d) {
     return (long)d.nsplit * d.Gp <= 2L * 1024 * 64;
 }
 
+// workgroup size of the deep sweeps: the largest of 256 / 128 / 64 threads that still gives every CU a workgroup (measured at the
+// P = 8 share, 32 768 threads: 2.02 / 1.76 / 1.83 ms per step with 256 / 128 / 64; at 65 536 threads 256 wins: 3.04 / 3.38 / 3.47).
+// DDH_DEEP_BLOCK forces one.
+static unsigned deep_block(long threads) {
+    static const int v = getenv("DDH_DEEP_BLOCK") ? atoi(getenv("DDH_DEEP_BLOCK")) : 0;
+    if (v == 64 || v == 128 || v == 256) return (unsigned)v;
+    if (threads / 256 >= 256) return 256u;
+    return threads / 128 >= 256 ? 128u : 64u;
+}
+
 // want_p: the caller asks for x = P y (recombination fused into the backward sweep); *did_p tells whether this launch
 // could do it (one-thread-per-system backward kernel of the real-graded 2-axis path with a band table on file).
 template <int NF>
@@ -3237,7 +3247,7 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
             // (block-parallel sweeps double the thread count: 4 waves per SIMD keep every thread resident, DDH_SWEEP_OCC=4)
             static const int occ4 = getenv("DDH_SWEEP_OCC") ? atoi(getenv("DDH_SWEEP_OCC")) == 4 : 1;
             if (forward_window(d.kl) == 6 && d.nb == 1 && rhs.n >= 1 && rhs.n <= 4 && sweep_deep(d))     // few systems: PD rows of loads in flight
-                hipLaunchKernelGGL((solve_forward_deep_kernel<6, 1, 4, 4>), dim3(blocks_split), dim3(256), lds_f, s, P, d, rhs, x);
+                hipLaunchKernelGGL((solve_forward_deep_kernel<6, 1, 4, 4>), dim3(blocks_split * (256 / deep_block((long)d.nsplit * d.Gp))), dim3(deep_block((long)d.nsplit * d.Gp)), lds_f, s, P, d, rhs, x);
             else if (forward_window(d.kl) == 6 && d.nsplit > 1 && occ4 && d.nb <= 1)
                 hipLaunchKernelGGL((solve_forward_lean_kernel<6, 1, 4>), dim3(blocks_split), dim3(256), lds_f, s, P, d, rhs, x);
             else if (forward_window(d.kl) == 6 && d.nb <= 1) DDH_LFWD(6, 1)
@@ -3312,9 +3322,9 @@ static int launch_solve(PencilPack *pp, LuFactor *lu, const RhsSrc &rhs, double 
                 // few systems (less than two waves per SIMD): PD rows of loads in flight in registers
                 static const int pd = getenv("DDH_BWD_DEEP_PD") ? atoi(getenv("DDH_BWD_DEEP_PD")) : DDH_BWD_DEEP_PD;
                 if (pd == 4)
-                    hipLaunchKernelGGL((solve_backward_deep_kernel<17, 4>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
+                    hipLaunchKernelGGL((solve_backward_deep_kernel<17, 4>), dim3(blocks_split * (256 / deep_block((long)d.nsplit * d.Gp))), dim3(deep_block((long)d.nsplit * d.Gp)), lds_b, s, P, d, x, d.pband, rhs.skip);
                 else
-                    hipLaunchKernelGGL((solve_backward_deep_kernel<17, 2>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
+                    hipLaunchKernelGGL((solve_backward_deep_kernel<17, 2>), dim3(blocks_split * (256 / deep_block((long)d.nsplit * d.Gp))), dim3(deep_block((long)d.nsplit * d.Gp)), lds_b, s, P, d, x, d.pband, rhs.skip);
             } else if (W <= 17 && d.nsplit > 1 && occ4 && getenv("DDH_BWD_DBG") && atoi(getenv("DDH_BWD_DBG")) == 128)
                 hipLaunchKernelGGL((solve_backward_kernel<NF, 17, true, false, true, 128, 4>), dim3(blocks_split), dim3(256), lds_b, s, P, d, x, d.pband, rhs.skip);
             else if (W <= 17 && d.nsplit > 1 && occ4)

@@ -90,6 +90,8 @@ PY
     rowfill-ab) # backward sweep: entry pairs beyond the measured fill of a U row not loaded (LuDev::wrow), against all pairs
                 for v in 0 1 0 1; do DDH_BWD_ROW_FILL=$v python bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-cfl > $OUT/bench_rowfill$v.json 2> $OUT/bench_rowfill$v.err
                   echo "DDH_BWD_ROW_FILL=$v"; bench_line $OUT/bench_rowfill$v.json; done ;;
+    emu-block)  # the deep sweeps' workgroup size at the P = 4 / 8 shares
+                for b in 256 128 64; do echo "DDH_DEEP_BLOCK=$b"; DDH_DEEP_BLOCK=$b python tools/rank_emulation.py --ranks 4,8 --rank 1 --steps 10 --warmup 3 2>&1 >/dev/null | cut -c1-150; done ;;
     emu-ring)   # the P = 4 / 8 shares with the backward sweep's LDS-DMA ring, depth 2 / 3 / 4
                 for r in 2 3 4; do echo "DDH_BWD_RING=$r" | tee -a $OUT/rank_emulation_ring.txt
                   DDH_BWD_RING=$r python tools/rank_emulation.py --ranks 4,8 --rank 1 --steps 10 --warmup 3 2>&1 >/dev/null | tee -a $OUT/rank_emulation_ring.txt; done ;;
