@@ -262,12 +262,17 @@ class Transformer:
         return tuple(shape)
 
     def stage_xb(self, domain, scales):
-        """(ny, gz) when the array between the z and the x transforms of `domain` at `scales` -- "stage 1": after backward
-        step 0, before forward step 0 -- is stored x-blocked, [comp][kx / 64][z][kx % 64][ky] (include/dedalus_hip.h,
-        ddh_fft_set_stage_layout), else None.  A RULE, not a property of an array: every producer and consumer of a stage-1
-        array asks it with the same arguments.  One rank (the exchange between the two transforms reads the natural
-        layout), a domain with bases on all three axes, both transforms on the strided wave kernels.  DDH_NO_STAGE_XB=1
-        switches it off."""
+        """(z-side value, x-side value) when the array between the z and the x transforms of `domain` at `scales` -- "stage
+        1": after backward step 0, before forward step 0 -- is stored blocked, else None.  A RULE, not a property of an
+        array: every producer and consumer of a stage-1 array asks it with the same arguments.
+          * one rank: [comp][kx / 64][z][kx % 64][ky] (include/dedalus_hip.h, ddh_fft_set_stage_layout) -> (ny, gz): the z
+            transforms write / read it on their grid side, the x transforms on their coefficient side;
+          * several ranks (round 6): the all-to-all delivers a component as [p][z_loc][nx / P][ky]; with blocks of nx / P rows
+            that IS the blocked layout on the x side -> (0, (gz_loc, nx / P)): the z side stays natural (it is what is sent
+            as it lies), the x transforms read what arrived and write what leaves, and the unpack / pack passes around the
+            exchange disappear (ddh_fft_set_stage_block).  DDH_A2A_BLOCKED=0 keeps the natural layout + unpack / pack.
+        A domain with bases on all three axes, both transforms on the strided wave kernels.  DDH_NO_STAGE_XB=1 switches the
+        one-rank layout off."""
         cache = self.__dict__.setdefault("_xb_cache", {})
         key = (id(domain), tuple(scales))
         hit = cache.get(key)
@@ -276,13 +281,18 @@ class Transformer:
         res = None
         ex = self.dist.executor
         steps = self._steps(domain, scales)
-        if (os.environ.get("DDH_NO_STAGE_XB") is None and self.dist.size == 1 and len(steps) == 3
-                and hasattr(ex, "stage_layout_ok") and [p for p, _, _ in steps] == [0, 1, 2]):
+        if len(steps) == 3 and hasattr(ex, "stage_layout_ok") and [p for p, _, _ in steps] == [0, 1, 2]:
             (_, bz, zspec), (_, bx, xspec), (_, by, _) = steps
             shape = domain.storage_coeff_shape()
             nx, ny = int(shape[1]), int(shape[2])
-            if ex.stage_layout_ok(zspec, xspec, nx, ny):
-                res = (ny, int(bz.grid_size(scales[self.dist.storage_order[0]])))
+            gz = int(bz.grid_size(scales[self.dist.storage_order[0]]))
+            P = self.dist.size
+            if P == 1:
+                if os.environ.get("DDH_NO_STAGE_XB") is None and ex.stage_layout_ok(zspec, xspec, nx, ny):
+                    res = (ny, gz)
+            elif (os.environ.get("DDH_A2A_BLOCKED", "1") != "0" and _overlap() and self._needs_exchange(domain)
+                  and hasattr(ex, "stage_block_ok") and gz % P == 0 and ex.stage_block_ok(xspec, nx * P, nx, ny)):
+                res = (0, (gz // P, nx))                 # (nx: this rank's rows = nx_global / P)
         cache[key] = (domain, res)
         return res
 
@@ -305,7 +315,7 @@ class Transformer:
             last = (i == i1 - 1)
             out = dst if (last and dst is not None and not (exchange and pos == 0)) else ex.empty(tuple(shape))
             xb = self.stage_xb(domain, scales) if i <= 1 else None
-            xbv = dict(xb=xb[i]) if xb is not None else {}      # step 0 writes, step 1 reads the stage-1 array
+            xbv = dict(xb=xb[i]) if (xb is not None and xb[i]) else {}      # step 0 writes, step 1 reads the stage-1 array
             if deriv is not None and deriv[0] == i:
                 if spec[0] != "rfft":
                     raise NotImplementedError("derivative at load along a non-Fourier axis")
@@ -314,7 +324,8 @@ class Transformer:
                 ex.transform(spec, b, "backward", src, out, outer, inner, **xbv)
             src = out
             if exchange and pos == 0:
-                src = self._rows_after_z(ex, src, shape, dst if last else None)
+                src = self._rows_after_z(ex, src, shape, dst if last else None,
+                                         blocked=self.stage_xb(domain, scales) is not None)
         return src
 
     def _exchange(self, ex, which, src, dst, n0, n1, n2, n3):
@@ -353,7 +364,7 @@ class Transformer:
         else:
             run()
 
-    def _rows_after_z(self, ex, src, shape, dst=None):
+    def _rows_after_z(self, ex, src, shape, dst=None, blocked=False):
         """The pencil transpose that follows the backward z transform: [comp, Gz, nx_loc, ny] -> [comp, Gz/P, nx, ny]
         (`shape` is updated in place)."""
         P = self.dist.size
@@ -361,6 +372,16 @@ class Transformer:
         rest = int(np.prod(shape[3:]))
         shape[1], shape[2] = Gz // P, nxl * P
         out2 = dst if dst is not None else ex.empty(tuple(shape))
+        if blocked:
+            # blocked x side (stage_xb, several ranks): a component is sent as it lies and received as [p][Gz / P][nx_loc][..]
+            # straight into its slice of the result -- which the x transforms read in that layout: no kernel at all
+            works = []
+            for c in range(nc):
+                works.append(self.dist.pcomm.all_to_all_start(out2[c:c + 1].reshape(-1), src[c:c + 1].reshape(-1)))
+            for w in works:
+                w.wait()
+            self.dist.pcomm.stats["exchanges"] += nc
+            return out2
         if nc > 1 and _overlap():
             # per-component pipeline: the exchange of component c runs (on the communicator's stream) while
             # component c + 1 is packed and component c - 1 is unpacked
@@ -397,10 +418,10 @@ class Transformer:
         xb = self.stage_xb(ldomain, scales)
         if xb is not None and self.stage_xb(xdomain, scales) != xb:
             raise RuntimeError("dual z transform: the two domains disagree about the stage layout")
-        ex.transform_dual_z(spec, b, src, out, out_d, dvec, outer, inner, **(dict(xb=xb[0]) if xb is not None else {}))
+        ex.transform_dual_z(spec, b, src, out, out_d, dvec, outer, inner, **(dict(xb=xb[0]) if (xb is not None and xb[0]) else {}))
         if self._needs_exchange(ldomain) and pos == 0:
-            out = self._rows_after_z(ex, out, list(shape))
-            out_d = self._rows_after_z(ex, out_d, list(shape))
+            out = self._rows_after_z(ex, out, list(shape), blocked=xb is not None)
+            out_d = self._rows_after_z(ex, out_d, list(shape), blocked=xb is not None)
         return out, out_d
 
     def backward_dual_step(self, domain, ncomp, src, scales, step, dscale):
@@ -456,7 +477,15 @@ class Transformer:
                 n_el = nc * Gzl * nx * rest
                 shape[1], shape[2] = Gzl * P, nx // P
                 tmp = ex.empty(tuple(shape))
-                if nc > 1 and _overlap():
+                if self.stage_xb(domain, scales) is not None:
+                    # blocked x side: the x transform has written [comp][p][Gz / P][nx_loc][..] -- a component is sent as it
+                    # lies and received as the component [Gz][nx_loc][..]: no kernel at all
+                    works = [self.dist.pcomm.all_to_all_start(tmp[cc:cc + 1].reshape(-1), src[cc:cc + 1].reshape(-1))
+                             for cc in range(nc)]
+                    for w in works:
+                        w.wait()
+                    self.dist.pcomm.stats["exchanges"] += nc
+                elif nc > 1 and _overlap():
                     n1 = Gzl * nx * rest
                     pend = None
                     for cc in range(nc):
@@ -479,7 +508,7 @@ class Transformer:
             last = i == len(rsteps) - 1
             dst = c if last else ex.empty(tuple(shape))
             xb = self.stage_xb(domain, scales) if pos <= 1 else None
-            kw = dict(xb=xb[pos]) if xb is not None else {}      # step 1 (x) writes, step 0 (z) reads the stage-1 array
+            kw = dict(xb=xb[pos]) if (xb is not None and xb[pos]) else {}      # step 1 (x) writes, step 0 (z) reads the stage-1 array
             if last and tiled_row:
                 kw["tiled_row"] = tiled_row
             ex.transform(spec, b, "forward", src, dst, outer, inner, **kw)

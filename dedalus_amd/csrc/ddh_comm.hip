@@ -10,6 +10,7 @@
 // so the library itself has no link-time dependency and loads on boxes without a GPU.
 #include "ddh_common.h"
 #include <vector>
+#include <cstdlib>
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -75,10 +76,26 @@ struct Comm : HandleBase {
     // block this rank sends to that peer (device copies on the caller's stream): sizes, pack / unpack kernels, stream
     // ordering and the per-rank kernel shapes are those of the real run, the VALUES received are not.
     bool loopback = false;
+    double link_gbps = 0.0;     // loop-back only (DDH_LOOPBACK_LINK_GBPS): > 0 = every exchange is followed, on its stream, by a
+                                // wait of (bytes to one peer) / link_gbps -- the time the P - 1 concurrent xGMI transfers would take
     ~Comm() override {
         if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
     }
 };
+
+// holds a stream for `ns` nanoseconds (one lane spins on the 100 MHz wall clock): the wire time of an emulated exchange
+__global__ void wire_delay_kernel(long long ns) {
+    const long long t0 = wall_clock64();
+    const long long ticks = ns / 10;                     // wall_clock64: 100 MHz
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+static int loopback_wire(const Comm *c, size_t bytes_to_one_peer, hipStream_t s) {
+    if (c->link_gbps <= 0.0 || c->nranks < 2 || bytes_to_one_peer == 0) return 0;
+    const long long ns = (long long)((double)bytes_to_one_peer / c->link_gbps);       // bytes / (GB/s) = ns
+    hipLaunchKernelGGL(wire_delay_kernel, dim3(1), dim3(1), 0, s, ns);
+    DDH_HIP(hipGetLastError());
+    return 0;
+}
 
 struct A2aPlan : HandleBase {
     Comm *comm = nullptr;
@@ -107,7 +124,7 @@ static int exchange(A2aPlan *pl, const double *send, double *recv, hipStream_t s
             if (p != c->rank)
                 DDH_HIP(hipMemcpyAsync(recv + (size_t)p * chunk, send + (size_t)p * chunk, chunk * sizeof(double),
                                        hipMemcpyDeviceToDevice, s));
-        return 0;
+        return loopback_wire(c, chunk * sizeof(double), s);
     }
     DDH_NCCL(g_rccl.GroupStart());
     for (int p = 0; p < c->nranks; ++p) {
@@ -164,6 +181,7 @@ int ddh_comm_create_loopback(ddh_handle *comm, int rank, int nranks) {
     c->rank = rank;
     c->nranks = nranks;
     c->loopback = true;
+    if (const char *g = getenv("DDH_LOOPBACK_LINK_GBPS")) c->link_gbps = atof(g);
     *comm = register_handle(c);
     return 0;
 }
@@ -203,7 +221,7 @@ int ddh_comm_alltoall(ddh_handle comm, const double *send, double *recv, long ch
             if (p != c->rank)
                 DDH_HIP(hipMemcpyAsync(recv + (size_t)p * chunk, send + (size_t)p * chunk, (size_t)chunk * sizeof(double),
                                        hipMemcpyDeviceToDevice, s));
-        return 0;
+        return loopback_wire(c, (size_t)chunk * sizeof(double), s);
     }
     DDH_NCCL(g_rccl.GroupStart());
     for (int p = 0; p < c->nranks; ++p) {

@@ -1475,6 +1475,15 @@ int ddh_fft_set_stage_layout(ddh_handle plan, long value) {
     return 0;
 }
 
+int ddh_fft_set_stage_block(ddh_handle plan, int rows) {
+    FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
+    if (!pl) return -1;
+    if (pl->tkind != K_RFFT) return fail("ddh_fft_set_stage_block: real-Fourier plans");
+    if (!(rows == 0 || rows == 64 || rows == 128 || rows == 256)) return fail("ddh_fft_set_stage_block: 64, 128 or 256 rows (0 = 64)");
+    pl->dev.xbB = (unsigned)rows;
+    return 0;
+}
+
 int ddh_cheb_forward_tiled(ddh_handle plan, const double *g, double *c, long outer, long inner, long row_len, void *stream) {
     FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
     if (!pl) return -1;

@@ -61,6 +61,7 @@ struct FftDev {
     int ld;                // LDS leading dimension of the FFT buffer (>= N)
     unsigned long long *prof;   // optional phase timing (debug): [load, fft, store, count]
     unsigned xb;                // != 0: x-blocked stage layout on the INTERMEDIATE side of a strided wave transform
+    unsigned xbB;               // rows per block of that layout on the coefficient side of a real-Fourier transform (0 = 64)
                                 // (ddh_fft_set_stage_layout): Chebyshev plans: row length ny; real-FFT plans: z planes gz
     unsigned ctile_nseg;        // != 0: the coefficient rows [nx][ny] are written tile-major, ctile_nseg = ny / 8 64-byte
                                 // segments per storage row (ddh_cheb_forward_tiled; wave kernel only)

@@ -393,16 +393,20 @@ wave_rfft_kernel(FftDev p, WaveArgs a) {
         long oc = ((long)o * M) * inner + 2 * pair0;
         const long og = ((long)o * N) * inner + 2 * pair0;
         unsigned rsb64 = 64u * rsb;
+        int bsh = 1;
         if (p.xb) {
-            // coefficient side = the stage array [comp][kx / 64][z][kx % 64][ky], o = comp * gz + z (p.xb = gz)
+            // coefficient side = the stage array [comp][kx / B][z][kx % B][ky], o = comp * gz + z (p.xb = gz; B = 64 on one
+            // rank, nx / P in a sharded run: the layout [p][z][nx / P][ky] the exchange delivers / takes)
+            const unsigned B = p.xbB ? p.xbB : 64u;
             const unsigned comp = o / p.xb, z = o - comp * p.xb;
-            oc = ((long)comp * M * p.xb + 64L * z) * inner + 2 * pair0;
-            rsb64 = (unsigned)(64u * p.xb) * rsb;
+            oc = ((long)comp * M * p.xb + (long)B * z) * inner + 2 * pair0;
+            rsb64 = (unsigned)(B * p.xb) * rsb;
+            bsh = (B == 64u) ? 1 : ((B == 128u) ? 2 : 3);
         }
         const bool valid = pair0 + p4 < a.npairs;
-        if (RKIND == 3) wf::rfft_fwd_tile<R>(a.src + og, a.dst + oc, rsb, rsb64, valid, S, s_tw, lane);
+        if (RKIND == 3) wf::rfft_fwd_tile<R>(a.src + og, a.dst + oc, rsb, rsb64, valid, S, s_tw, lane, bsh);
         else wf::rfft_bwd_tile<R, (RKIND == 3 ? 0 : RKIND)>(a.src + oc, a.dst + og, (RKIND == 2) ? a.dst2 + og : nullptr, rsb, rsb64, valid,
-                                                            (RKIND == 2) ? p.dscale2 : p.dscale, S, s_tw, lane);
+                                                            (RKIND == 2) ? p.dscale2 : p.dscale, S, s_tw, lane, bsh);
     }
 }
 
@@ -443,7 +447,9 @@ int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, lon
         if (mode == CHEB_FWD || mode == CHEB_BWD) {
             if ((d.xb & 7) || inner % d.xb || (inner / d.xb) % 64) return 1;
         } else if (mode == RFFT_FWD || mode == RFFT_BWD) {
-            if (outer % d.xb || d.M % 64 || (unsigned long)d.xb * 64UL * (unsigned long)inner * 8UL * (unsigned long)(d.M / 64) >= 0xffffffffUL) return 1;
+            const unsigned long B = d.xbB ? d.xbB : 64UL;
+            if (!(B == 64 || B == 128 || B == 256)) return 1;
+            if (outer % d.xb || d.M % B || (unsigned long)d.xb * B * (unsigned long)inner * 8UL * (unsigned long)(d.M / B) >= 0xffffffffUL) return 1;
         } else {
             return 1;
         }

@@ -563,7 +563,9 @@ template <int R, int BK>
 // [kx][ky]; the x-blocked stage layout [kx / 64][z][kx % 64][ky] (ddh_fft_set_stage_layout) has the z planes of a block
 // of 64 rows in between.  The lane's rows are 2 q + 32 t (+ 1), q < 16: block t / 2, row 32 (t % 2) + 2 q (+ 1) inside it.
 DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, unsigned rsb, unsigned rsb64, bool pvalid,
-                           double dsc, double2 *S, const double2 *tw, int lane) {
+                           double dsc, double2 *S, const double2 *tw, int lane, int bsh = 1) {
+    // bsh: the blocks of the blocked coefficient layout hold 32 << bsh rows (rsb64 = bytes between blocks): 64 (bsh = 1) on
+    // one rank, nx / P in a sharded run where the received layout [p][z][nx / P][ky] is read as it arrives
     constexpr int H = 16 * R;                            // N / 3 = modes per pair incl. k = 0
     WF_OPAQUE_LANE(lane);
     const Lane L = make_lane(lane);
@@ -575,7 +577,7 @@ DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, u
         const unsigned o0 = (unsigned)(2 * L.q) * rsb + (pvalid ? 16u * (unsigned)L.p : 0u);
 #pragma unroll
         for (int t = 0; t < R; ++t) {
-            const unsigned ob = (unsigned)(t >> 1) * rsb64 + (unsigned)(32 * (t & 1)) * rsb;
+            const unsigned ob = (unsigned)(t >> bsh) * rsb64 + (unsigned)(32 * (t & ((1 << bsh) - 1))) * rsb;
             c[t] = gload(src_t, o0 + ob);
             s[t] = gload(src_t, o0 + ob + rsb);
         }
@@ -696,7 +698,7 @@ DDH_DEV void rfft_bwd_tile(const double *src_t, double *dst_t, double *dst2_t, u
 // exchange at the end hands X[k], X[N - k] to the lane that stores mode k.
 template <int R>
 DDH_DEV void rfft_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, unsigned rsb64, bool pvalid, double2 *S,
-                           const double2 *tw, int lane) {      // rsb64: see rfft_bwd_tile (coefficient side = dst here)
+                           const double2 *tw, int lane, int bsh = 1) {      // rsb64, bsh: see rfft_bwd_tile (coefficient side = dst here)
     constexpr int H = 16 * R, N = 3 * H, RQ = R / 4;
     const double s3 = 0.86602540378443864676372317075293618;
     double2 P[R], Q[R];                                  // X[j], X[N - (H - j)] at the wfft output slots j
@@ -767,7 +769,7 @@ DDH_DEV void rfft_fwd_tile(const double *src_t, double *dst_t, unsigned rsb, uns
             s = make_double2(0.0, 0.0);
         }
         if (pvalid) {
-            const unsigned ob = (unsigned)(t >> 1) * rsb64 + (unsigned)(32 * (t & 1)) * rsb;
+            const unsigned ob = (unsigned)(t >> bsh) * rsb64 + (unsigned)(32 * (t & ((1 << bsh) - 1))) * rsb;
             gstore(dst_t, o0 + ob, c);
             gstore(dst_t, o0 + ob + rsb, s);
         }

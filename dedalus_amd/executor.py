@@ -186,11 +186,19 @@ class HipExecutor:
         return self._transform(spec, basis, direction, src, dst, outer, inner, deriv, tiled_row, xb)
 
     def _stage_layout(self, h, value):
-        """x-blocked stage layout of a plan (ddh_fft_set_stage_layout); the library call only when the value changes."""
+        """x-blocked stage layout of a plan (ddh_fft_set_stage_layout); the library call only when the value changes.
+        value: 0 natural; an int (row length ny for a Chebyshev plan, z planes gz for a real-Fourier plan, blocks of 64
+        rows); or (gz, rows) for a real-Fourier plan with blocks of `rows` = nx / P rows (ddh_fft_set_stage_block: the layout
+        the all-to-all of a sharded run delivers)."""
+        block = 0
+        if isinstance(value, tuple):
+            value, block = value
         cur = self.__dict__.setdefault("_layouts", {})
-        if cur.get(h.value, 0) != int(value):
+        if cur.get(h.value, (0, 0)) != (int(value), int(block)):
             libhip.call("ddh_fft_set_stage_layout", h, int(value))
-            cur[h.value] = int(value)
+            if int(block) != cur.get(h.value, (0, 0))[1]:
+                libhip.call("ddh_fft_set_stage_block", h, int(block))
+            cur[h.value] = (int(value), int(block))
 
     # (grid, coefficient) sizes the wave-per-four-line-pairs kernels are instantiated for (csrc/ddh_fftwave.hip:
     # DDH_CHEB_WAVE_SIZES, launch_wave_rfft_kind)
@@ -202,6 +210,12 @@ class HipExecutor:
         return (zspec[0] == "cheb" and (int(zspec[1]), int(zspec[2])) in self.WAVE_CHEB_SIZES and xspec[0] == "rfft"
                 and (int(xspec[1]), int(xspec[2])) in self.WAVE_RFFT_SIZES and nx % 64 == 0 and ny % 8 == 0
                 and int(xspec[2]) == nx)
+
+    def stage_block_ok(self, xspec, nx, nx_local, ny):
+        """Sharded run: can the x transforms read / write the exchanged layout [p][z][nx / P][ky] in place?  (real-Fourier
+        wave kernels, blocks of 64 / 128 / 256 rows)"""
+        return (xspec[0] == "rfft" and (int(xspec[1]), int(xspec[2])) in self.WAVE_RFFT_SIZES and int(xspec[2]) == nx
+                and nx_local in (64, 128, 256) and nx % nx_local == 0 and ny % 2 == 0)
 
     def tiled_forward_ok(self, spec, basis, inner, row_len):
         """Can `transform(..., "forward", tiled_row=row_len)` run?  (the strided-axis wave kernel's sizes)"""

@@ -93,6 +93,7 @@ SIGNATURES = {
     "ddh_cheb_forward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_cheb_forward_tiled": [_h, _vp, _vp, _l, _l, _l, _vp],
     "ddh_fft_set_stage_layout": [_h, _l],
+    "ddh_fft_set_stage_block": [_h, _i],
     "ddh_fft_wave_launches": [C.POINTER(_l)],
     "ddh_cheb_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_plan_mmt": [_hp, _i, _i, _dp],

@@ -122,6 +122,11 @@ int ddh_cheb_forward_tiled(ddh_handle plan, const double *g, double *c, long out
  * using another layout.  Values are
  * those of the plain transforms (core/transforms.py:469-565, 801-902), only addresses differ.                        */
 int ddh_fft_set_stage_layout(ddh_handle plan, long value);
+/* Rows per block of the blocked layout on the coefficient side of a real-Fourier plan: 64 (default, 0), 128 or 256.  In a
+ * sharded run the all-to-all delivers a component as [p][z][nx / P][ky] (core/transposes.pyx:359-445 would now unpack it to
+ * [z][nx][ky]): with rows = nx / P that IS this layout, so the x transforms read what arrived and write what leaves -- no
+ * unpack / pack pass (ddh_a2a_unpack / ddh_a2a_pack) around the exchange. */
+int ddh_fft_set_stage_block(ddh_handle plan, int rows);
 /* Diagnostic: the number of Chebyshev / real-Fourier launches of this process that ran on the wave-per-four-line-pairs
  * kernels (csrc/ddh_fftwave.hip; the sizes of its tables) rather than on the workgroup-per-tile kernel every size can
  * take.  The reference's plans are size-generic (core/transforms.py:537-565, 801-902); here the kernel is chosen per

@@ -310,7 +310,34 @@ static void rfft_fwd(const double *tw, const double *src, double *dst, long oute
     });
 }
 
+// blocked coefficient layout [kx / B][z][kx % B][ky] (one component, gz planes): backward into the natural grid array
+// [z][N][inner], forward back into the blocked layout
+template <int R>
+static void rfft_blocked(const double *tw, int B, long gz, const double *src, double *grid, double *back, long inner) {
+    constexpr int H = 16 * R, N = 3 * H, M = 2 * H;
+    const long npairs = inner / 2, tpo = (npairs + 3) / 4, ntiles = tpo * gz;
+    const int bsh = (B == 64) ? 1 : (B == 128 ? 2 : 3);
+    std::vector<double2> S(RfftWaveLds<R>::size);
+    const double2 *twp = reinterpret_cast<const double2 *>(tw);
+    run_wave([&](int lane) {
+        for (long tile = 0; tile < ntiles; ++tile) {
+            const long z = tile / tpo, tb = tile % tpo;
+            const bool valid = 4 * tb + (lane & 3) < npairs;
+            const long oc = ((long)B * z) * inner + 8 * tb, og = (z * N) * inner + 8 * tb;
+            const unsigned rsb = (unsigned)(inner * 8), rsbB = (unsigned)((long)B * gz * inner * 8);
+            rfft_bwd_tile<R, 0>(src + oc, grid + og, nullptr, rsb, rsbB, valid, 0.0, S.data(), twp, lane, bsh);
+            rfft_fwd_tile<R>(grid + og, back + oc, rsb, rsbB, valid, S.data(), twp, lane, bsh);
+        }
+        (void)M;
+    });
+}
+
 extern "C" {
+int emu_rfft_blocked(int N, int B, long gz, const double *tw, const double *src, double *grid, double *back, long inner) {
+    if (N == 768) { rfft_blocked<16>(tw, B, gz, src, grid, back, inner); return 0; }
+    if (N == 384) { rfft_blocked<8>(tw, B, gz, src, grid, back, inner); return 0; }
+    return 1;
+}
 int emu_rfft_bwd(int N, int dual, double dsc, double dsc2, const double *tw, const double *src, double *dst, double *dst2,
                  long outer, long inner) {
     if (N == 768) { rfft_bwd<16>(tw, dual != 0, dsc, dsc2, src, dst, dst2, outer, inner); return 0; }

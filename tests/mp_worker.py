@@ -58,6 +58,19 @@ def main():
         out = pencil_check.check_records(ref, solver.solve_probe["records"], mine)
         res = dict(npencils=np.array(len(mine)), residual=np.array([r["residual"] for r in out]),
                    solution=np.array([r["solution"] for r in out]), dropped=np.array([r["dropped_max"] for r in out]))
+    elif case.startswith("rb3dsize_"):
+        # 3-D Rayleigh-Benard at a given size, three RK222 steps: the local coefficient blocks + what the transformer's
+        # stage rule says about the exchanged layout (tests/test_gpu_multirank.py: blocked x side of the sharded run)
+        nx, ny, nz = (int(v) for v in case.split("_")[1].split("x"))
+        solver, f = problems.rayleigh_benard_3d(d3, Nx=nx, Ny=ny, Nz=nz, timestepper="RK222", dist_kw=dist_kw)
+        for _ in range(3):
+            solver.step(1e-3)
+        res = {k: np.array(f[k]['c']) for k in ("p", "b", "u")}
+        dom = f["b"].domain
+        xb = solver.dist.transformer.stage_xb(dom, dom.dealias)
+        res["stage_xb"] = np.array([-1, -1, -1] if xb is None else [int(xb[0]), int(xb[1][0]), int(xb[1][1])] if isinstance(xb[1], tuple)
+                                   else [int(xb[0]), int(xb[1]), 64])
+        res["via"] = np.array(sorted(solver.dist.pcomm.via)) if solver.dist.pcomm is not None else np.array([])
     elif case == "shell_cfl":
         solver, dts, speeds, res = problems.run_shell_cfl_case(d3, dist_kw=dist_kw)
         res = dict(res, dts=np.array(dts), speeds=np.array(speeds))

@@ -39,6 +39,50 @@ def test_sharded_hip_run_matches_reference(golden_dir, case, world):
             assert rel(full, ref) < tol, (key, rel(full, ref))
 
 
+def _run_sharded(case, world, env_extra):
+    with tempfile.TemporaryDirectory() as tmp:
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "tests", "mp_worker.py"), case, tmp, "hip"]
+        env = dict(os.environ, OMP_NUM_THREADS="1", DDH_DIST_BACKEND="gloo", **env_extra)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return [dict(np.load(os.path.join(tmp, "rank%d.npz" % k))) for k in range(world)]
+
+
+def test_sharded_run_with_the_blocked_exchange_layout_matches_the_reference():
+    """3-D RB 128 x 128 x 64 on 2 ranks (64 kx rows each: blocks of 64): the x transforms read the exchanged layout
+    [p][z_loc][nx / P][ky] in place and write what leaves -- no unpack / pack kernel (Transformer.stage_xb, round 6) -- and
+    the end state is the UNMODIFIED reference's (tests/golden/config_rb3d_endstate_128x128x64.npz, three RK222 steps)."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "config_rb3d_endstate_128x128x64.npz"))
+    parts = _run_sharded("rb3dsize_128x128x64", 2, {})
+    assert list(parts[0]["stage_xb"]) == [0, 96 // 2, 64], parts[0]["stage_xb"]      # z side natural, x side (gz_loc, rows)
+    sa = G["sample_a"] if "sample_a" in G else np.array([0, 4, 0, 4])
+    for key, tol in (("b", 1e-10), ("p", 1e-10), ("u", 1e-9)):
+        full = np.concatenate([p[key] for p in parts], axis=parts[0][key].ndim - 3)
+        mine = full[..., int(sa[0])::int(sa[1]), int(sa[2])::int(sa[3]), :]
+        ref = G["end__%s_a" % key]
+        assert mine.shape == ref.shape
+        assert rel(mine, ref) < tol, (key, rel(mine, ref))
+
+
+@pytest.mark.parametrize("shape,rows", [((256, 16, 32), 128), ((512, 16, 32), 256), ((512, 16, 32), 64)])
+def test_blocked_and_unpacked_exchanges_take_the_same_steps(shape, rows):
+    """Blocks of 128 and 256 rows (2 ranks at Nx = 256 / 512) and of 64 rows (8 ranks' share emulated by 2 ranks is not
+    possible: 64 = 512 / 8 needs 8 processes -- here 4 ranks x 128... so the 64-row case runs 4 ranks at Nx = 256): the
+    blocked exchange (DDH_A2A_BLOCKED default) and the round-5 pack / exchange / unpack path (=0) give bit-identical states."""
+    world = {128: 2, 256: 2, 64: 4}[rows]
+    nx = {128: 256, 256: 512, 64: 256}[rows]
+    case = "rb3dsize_%dx%dx%d" % (nx, shape[1], shape[2])
+    a = _run_sharded(case, world, {})
+    b = _run_sharded(case, world, {"DDH_A2A_BLOCKED": "0"})
+    assert int(a[0]["stage_xb"][2]) == rows and int(b[0]["stage_xb"][0]) == -1
+    for ra, rb in zip(a, b):
+        for key in ("p", "b", "u"):
+            assert np.array_equal(ra[key], rb[key]), (rows, key)
+
+
 @pytest.mark.parametrize("ts", ["SBDF2"])
 def test_m_sharded_shell_hip_run_matches_reference(golden_dir, ts):
     """Shell convection, azimuthal wavenumbers sharded over 2 processes that share the GPU: local SWSH / regularity /

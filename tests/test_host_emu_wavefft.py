@@ -29,6 +29,7 @@ def emu(tmp_path_factory):
     lib.emu_cheb_fwd_contig.argtypes = [i, i, vp, vp, i, vp, vp, vp, vp, l]
     lib.emu_rfft_bwd.argtypes = [i, i, C.c_double, C.c_double, vp, vp, vp, vp, l, l]
     lib.emu_rfft_fwd.argtypes = [i, vp, vp, vp, l, l]
+    lib.emu_rfft_blocked.argtypes = [i, i, l, vp, vp, vp, vp, l]
     return lib
 
 
@@ -196,3 +197,24 @@ def test_wave_real_fourier_matches_the_oracle(emu, N, shape_oi):
     out = np.full(cs, np.nan)
     emu.emu_rfft_fwd(N, dp(tw), dp(gin), dp(out), outer, inner)
     assert rel(out, npt.rfft_forward(gin, 1, M)) < 1e-14
+
+
+@pytest.mark.parametrize("N,B", [(768, 64), (768, 128), (768, 256), (384, 64), (384, 128)])
+def test_wave_real_fourier_reads_and_writes_the_blocked_coefficient_layout(emu, N, B):
+    """[kx / B][z][kx % B][ky]: B = 64 is the x-blocked stage layout of one rank, B = nx / P the layout the all-to-all of a
+    sharded run delivers ([p][z][nx / P][ky], core/transposes.pyx:359-445 would unpack it): the x transforms read and write it
+    in place of the natural [z][kx][ky]"""
+    M = 2 * N // 3
+    gz, inner = 3, 10
+    rng = np.random.default_rng(N + B)
+    tw, _ = tables(N)
+    nat = rng.standard_normal((gz, M, inner))                                  # [z][kx][ky]
+    blocked = np.ascontiguousarray(nat.reshape(gz, M // B, B, inner).transpose(1, 0, 2, 3))
+    grid = np.full((gz, N, inner), np.nan)
+    back = np.full_like(blocked, np.nan)
+    assert emu.emu_rfft_blocked(N, B, gz, dp(tw), dp(blocked), dp(grid), dp(back), inner) == 0
+    assert rel(grid, npt.rfft_backward(nat, 1, N)) < 1e-14
+    want = nat.copy()
+    want[:, 1, :] = 0.0                                                        # the msin row of k = 0 is no mode
+    want_b = np.ascontiguousarray(want.reshape(gz, M // B, B, inner).transpose(1, 0, 2, 3))
+    assert rel(back, want_b) < 1e-13

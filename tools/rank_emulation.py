@@ -89,10 +89,16 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--link-gbps", type=float, default=0.0,
+                    help="> 0: the loop-back communicator holds the exchange stream for (bytes to one peer) / this rate after "
+                         "every exchange (DDH_LOOPBACK_LINK_GBPS): the step time then INCLUDES an emulated wire and shows how "
+                         "much of it the pipeline hides")
     ap.add_argument("--single-gpu-ms", type=float, default=None, help="ms per step of the 1-GPU run (ideal share = that / P)")
     ap.add_argument("--worker", type=str, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     size = tuple(int(v) for v in args.size.split(","))
+    if args.link_gbps > 0:
+        os.environ["DDH_LOOPBACK_LINK_GBPS"] = str(args.link_gbps)
     if args.worker:                       # one (rank, P) per process: the decomposition is read once per process
         r, P = (int(v) for v in args.worker.split("/"))
         print(json.dumps(one(r, P, size, args.steps, args.warmup, args.dt)))
@@ -115,10 +121,11 @@ def main():
 
         def ms(k):
             return f.get(k, {}).get("ms_per_step", 0.0)
-        print("P=%d rank %d: %.2f ms/step with loop-back exchange (kernels %.2f)%s | solve %.2f fused-y %.2f x %.2f z %.2f "
+        print("P=%d rank %d: %.2f ms/step with loop-back exchange%s (kernels %.2f)%s | solve %.2f fused-y %.2f x %.2f z %.2f "
               "matvec %.2f | pack %.2f ms (%.0f GB/s) unpack %.2f ms (%.0f GB/s) plan-exchanges %.2f | side stream %.2f ms | wire "
               "%.1f MB -> %.2f ms at %.0f GB/s per link | predicted %.1f (no overlap) .. %.1f (full overlap) steps/s"
-              % (P, r, d["ms_per_step_loopback"], d["kernel_ms_per_step"],
+              % (P, r, d["ms_per_step_loopback"], (" + emulated wire at %.0f GB/s per link" % d["emulated_link_GBps"]) if d["emulated_link_GBps"] else "",
+                 d["kernel_ms_per_step"],
                  (" ideal share %.2f" % d["ideal_share_ms"]) if d["ideal_share_ms"] else "",
                  ms("pencil_solve"), ms("rfft_bilinear_fused"),
                  sum(ms(k) for k in f if k.startswith("rfft_") and k != "rfft_bilinear_fused"),
