@@ -296,6 +296,55 @@ class Transformer:
         cache[key] = (domain, res)
         return res
 
+    # ---- exchanges in flight (blocked stage layout, several ranks) ------------------------------------------------------
+    # The z step starts one exchange per component on the communicator's stream and returns; the first x-side consumer of
+    # a component waits for it (a stream-side wait: the host never blocks).  With the evaluator issuing every field's z
+    # step first (Evaluator.prefetch_stage1) the wire of a later field runs under the x transforms of an earlier one.
+    def _defer(self, arr, works):
+        self.__dict__.setdefault("_inflight", []).append([arr.data_ptr(), arr[0:1].numel() * 8, list(works), arr])
+
+    def in_flight(self, arr):
+        """True when an exchange into (part of) arr has not been waited for."""
+        fl = self.__dict__.get("_inflight")
+        if not fl:
+            return False
+        lo = arr.data_ptr()
+        hi = lo + arr.numel() * 8
+        return any(w is not None and base + c * cb < hi and lo < base + (c + 1) * cb
+                   for base, cb, works, _ in fl for c, w in enumerate(works))
+
+    def wait_for(self, arr):
+        """Make the current stream wait for the exchanges that deliver (part of) arr."""
+        fl = self.__dict__.get("_inflight")
+        if not fl:
+            return
+        lo = arr.data_ptr()
+        hi = lo + arr.numel() * 8
+        keep = []
+        for ent in fl:
+            base, cb, works, _ = ent
+            for c, w in enumerate(works):
+                if w is not None and base + c * cb < hi and lo < base + (c + 1) * cb:
+                    w.wait()
+                    works[c] = None
+            if any(w is not None for w in works):
+                keep.append(ent)
+        self._inflight = keep
+
+    def settle(self):
+        """Wait for every exchange still in flight (end of an evaluation pass)."""
+        for _, _, works, _ in self.__dict__.get("_inflight", ()):
+            for w in works:
+                if w is not None:
+                    w.wait()
+        self._inflight = []
+
+    def _x_step_by_component(self, src, ncomp):
+        """DDH_A2A_SPLIT_X=1: the x step runs component by component when its input is still arriving (component c is
+        transformed while component c + 1 is on the wire).  Off by default: under an emulated 75 GB/s wire the smaller
+        launches cost what the overlap wins (P = 4: 30.1 ms per step without, 31.0 with; profiles/r6_rank_emulation.txt)."""
+        return ncomp > 1 and os.environ.get("DDH_A2A_SPLIT_X", "0") == "1" and self.in_flight(src)
+
     def backward_steps(self, domain, ncomp, src, scales, i0, i1, dst=None, deriv=None):
         """Apply backward steps i0 .. i1-1 to data that has seen steps < i0 (z transform first, then the
         all-to-all (-> z-sharded, kx local), then the Fourier transforms).  deriv = (step, 2 pi / L)
@@ -319,8 +368,14 @@ class Transformer:
             if deriv is not None and deriv[0] == i:
                 if spec[0] != "rfft":
                     raise NotImplementedError("derivative at load along a non-Fourier axis")
-                ex.transform(spec, b, "backward", src, out, outer, inner, deriv=deriv[1], **xbv)
+                xbv["deriv"] = deriv[1]
+            if exchange and i >= 1 and self._x_step_by_component(src, ncomp):
+                for c in range(ncomp):
+                    self.wait_for(src[c:c + 1])
+                    ex.transform(spec, b, "backward", src[c:c + 1], out[c:c + 1], outer // ncomp, inner, **xbv)
             else:
+                if exchange and i >= 1:
+                    self.wait_for(src)
                 ex.transform(spec, b, "backward", src, out, outer, inner, **xbv)
             src = out
             if exchange and pos == 0:
@@ -378,9 +433,12 @@ class Transformer:
             works = []
             for c in range(nc):
                 works.append(self.dist.pcomm.all_to_all_start(out2[c:c + 1].reshape(-1), src[c:c + 1].reshape(-1)))
-            for w in works:
-                w.wait()
             self.dist.pcomm.stats["exchanges"] += nc
+            if os.environ.get("DDH_A2A_DEFER", "1") != "0" and hasattr(out2, "data_ptr"):
+                self._defer(out2, works)                 # waited for by the x step that reads it (wait_for)
+            else:
+                for w in works:
+                    w.wait()
             return out2
         if nc > 1 and _overlap():
             # per-component pipeline: the exchange of component c runs (on the communicator's stream) while
@@ -442,7 +500,14 @@ class Transformer:
         shape[pos + 1] = b.grid_size(scales[ax])
         out, out_d = ex.empty(tuple(shape)), ex.empty(tuple(shape))
         xb = self.stage_xb(domain, scales) if step == 1 else None
-        ex.transform_dual(spec, b, src, out, out_d, outer, inner, dscale, **(dict(xb=xb[1]) if xb is not None else {}))
+        kw = dict(xb=xb[1]) if xb is not None else {}
+        if self._x_step_by_component(src, ncomp):
+            for c in range(ncomp):
+                self.wait_for(src[c:c + 1])
+                ex.transform_dual(spec, b, src[c:c + 1], out[c:c + 1], out_d[c:c + 1], outer // ncomp, inner, dscale, **kw)
+        else:
+            self.wait_for(src)
+            ex.transform_dual(spec, b, src, out, out_d, outer, inner, dscale, **kw)
         return out, out_d
 
     def backward_data(self, domain, ncomp, c, g, scales, skip_last=False):
@@ -456,6 +521,14 @@ class Transformer:
     def forward_data(self, domain, ncomp, g, scales, c, skip_last=False, tiled_row=0):
         """tiled_row: the coefficient rows (the last transform's output, `c`) are written tile-major, rows of
         nx * tiled_row doubles (Executor.transform; only where `tiled_forward_ok` said so)."""
+        self.forward_begin(domain, ncomp, g, scales, c, skip_last=skip_last, tiled_row=tiled_row)()
+
+    def forward_begin(self, domain, ncomp, g, scales, c, skip_last=False, tiled_row=0):
+        """forward_data in two halves: runs the transforms up to the pencil transpose and STARTS it (blocked stage layout on
+        several ranks: component by component, each exchange starting as soon as its x transform is issued), and returns
+        the function that waits for the arrivals and runs the remaining transforms.  A caller with several fields begins
+        them all before it finishes the first (Solver.evaluate_F): the wire of one field runs under the x transforms of the
+        next.  Without an exchange in flight everything happens in the first half and the returned function does nothing."""
         ex = self.dist.executor
         steps = self._steps(domain, scales)
         shape = [ncomp] + list(domain.storage_grid_shape(scales))
@@ -464,52 +537,88 @@ class Transformer:
             shape = list(self.pregrid_shape(domain, ncomp, scales))
         if not steps:
             ex.copy(c, g)
-            return
+            return lambda: None
         exchange = self._needs_exchange(domain)
-        src = g
         rsteps = list(reversed(steps))
-        for i, (pos, b, spec) in enumerate(rsteps):
-            if exchange and pos == 0:
-                # [comp, Gz/P, nx, ny] -> [comp, Gz, nx_loc, ny]
-                P = self.dist.size
-                nc, Gzl, nx = shape[0], shape[1], shape[2]
-                rest = int(np.prod(shape[3:]))
-                n_el = nc * Gzl * nx * rest
-                shape[1], shape[2] = Gzl * P, nx // P
-                tmp = ex.empty(tuple(shape))
-                if self.stage_xb(domain, scales) is not None:
-                    # blocked x side: the x transform has written [comp][p][Gz / P][nx_loc][..] -- a component is sent as it
-                    # lies and received as the component [Gz][nx_loc][..]: no kernel at all
-                    works = [self.dist.pcomm.all_to_all_start(tmp[cc:cc + 1].reshape(-1), src[cc:cc + 1].reshape(-1))
-                             for cc in range(nc)]
+        blocked = exchange and self.stage_xb(domain, scales) is not None
+        defer = blocked and os.environ.get("DDH_A2A_DEFER", "1") != "0"
+        split_x = os.environ.get("DDH_A2A_SPLIT_X", "0") == "1"
+        state = dict(src=g, works=None, second_half=False)
+
+        def run(i_from, i_to):
+            src = state["src"]
+            for i in range(i_from, i_to):
+                pos, b, spec = rsteps[i]
+                if exchange and pos == 0:
+                    # [comp, Gz/P, nx, ny] -> [comp, Gz, nx_loc, ny]
+                    P = self.dist.size
+                    nc, Gzl, nx = shape[0], shape[1], shape[2]
+                    rest = int(np.prod(shape[3:]))
+                    if state["works"] is None:          # (else: started by the component-wise x step below)
+                        tmp = ex.empty((nc, Gzl * P, nx // P) + tuple(shape[3:]))
+                        works = []
+                        if blocked:
+                            # blocked x side: the x transform has written [comp][p][Gz / P][nx_loc][..] -- a component is sent
+                            # as it lies and received as the component [Gz][nx_loc][..]: no kernel at all
+                            works = [self.dist.pcomm.all_to_all_start(tmp[cc:cc + 1].reshape(-1), src[cc:cc + 1].reshape(-1))
+                                     for cc in range(nc)]
+                            self.dist.pcomm.stats["exchanges"] += nc
+                        elif nc > 1 and _overlap():
+                            n1 = Gzl * nx * rest
+                            pend = None
+                            for cc in range(nc):
+                                send = ex.empty((n1,))
+                                ex.a2a_pack(src[cc:cc + 1], send, Gzl, nx, 1, rest, P)
+                                # the received order [p][Gz / P][nx_loc][rest] IS the component [Gz][nx_loc][rest]: received in
+                                # place (round 5 unpacked with a kernel that copied the buffer onto the component unchanged)
+                                recv = tmp[cc:cc + 1].reshape(-1)
+                                work = self.dist.pcomm.all_to_all_start(recv, send)
+                                if pend is not None:
+                                    pend[0].wait()
+                                pend = (work, recv, cc, send)
+                            pend[0].wait()
+                        else:
+                            self._exchange(ex, "columns", src, tmp, nc, Gzl * P, nx, rest)
+                        state["works"] = (tmp, works)
+                    if defer and not state["second_half"]:
+                        state["src"] = src              # the exchanges are in flight: the second half re-enters here
+                        return i
+                    tmp, works = state["works"]
+                    state["works"] = None
                     for w in works:
                         w.wait()
-                    self.dist.pcomm.stats["exchanges"] += nc
-                elif nc > 1 and _overlap():
-                    n1 = Gzl * nx * rest
-                    pend = None
+                    shape[1], shape[2] = Gzl * P, nx // P
+                    src = tmp
+                outer = int(np.prod(shape[:pos + 1]))
+                inner = int(np.prod(shape[pos + 2:]))
+                shape[pos + 1] = b.coeff_size
+                last = i == len(rsteps) - 1
+                dst = c if last else ex.empty(tuple(shape))
+                xb = self.stage_xb(domain, scales) if pos <= 1 else None
+                kw = dict(xb=xb[pos]) if (xb is not None and xb[pos]) else {}  # step 1 (x) writes, step 0 (z) reads the stage-1 array
+                if last and tiled_row:
+                    kw["tiled_row"] = tiled_row
+                if defer and split_x and pos == 1 and i + 1 < len(rsteps) and rsteps[i + 1][0] == 0:
+                    # the x step before a deferred blocked exchange: component by component, each one's exchange started
+                    # behind its transform -- component c is on the wire while component c + 1 is transformed
+                    P = self.dist.size
+                    nc = shape[0]
+                    tmp = ex.empty((nc, shape[1] * P, shape[2] // P) + tuple(shape[3:]))
+                    works = []
                     for cc in range(nc):
-                        send = ex.empty((n1,))
-                        ex.a2a_pack(src[cc:cc + 1], send, Gzl, nx, 1, rest, P)
-                        # the received order [p][Gz / P][nx_loc][rest] IS the component [Gz][nx_loc][rest]: received in
-                        # place (round 5 unpacked with a kernel that copied the buffer onto the component unchanged)
-                        recv = tmp[cc:cc + 1].reshape(-1)
-                        work = self.dist.pcomm.all_to_all_start(recv, send)
-                        if pend is not None:
-                            pend[0].wait()
-                        pend = (work, recv, cc, send)
-                    pend[0].wait()
+                        ex.transform(spec, b, "forward", src[cc:cc + 1], dst[cc:cc + 1], outer // nc, inner, **kw)
+                        works.append(self.dist.pcomm.all_to_all_start(tmp[cc:cc + 1].reshape(-1), dst[cc:cc + 1].reshape(-1)))
+                    self.dist.pcomm.stats["exchanges"] += nc
+                    state["works"] = (tmp, works)
                 else:
-                    self._exchange(ex, "columns", src, tmp, nc, Gzl * P, nx, rest)
-                src = tmp
-            outer = int(np.prod(shape[:pos + 1]))
-            inner = int(np.prod(shape[pos + 2:]))
-            shape[pos + 1] = b.coeff_size
-            last = i == len(rsteps) - 1
-            dst = c if last else ex.empty(tuple(shape))
-            xb = self.stage_xb(domain, scales) if pos <= 1 else None
-            kw = dict(xb=xb[pos]) if (xb is not None and xb[pos]) else {}      # step 1 (x) writes, step 0 (z) reads the stage-1 array
-            if last and tiled_row:
-                kw["tiled_row"] = tiled_row
-            ex.transform(spec, b, "forward", src, dst, outer, inner, **kw)
-            src = dst
+                    ex.transform(spec, b, "forward", src, dst, outer, inner, **kw)
+                src = dst
+            state["src"] = src
+            return i_to
+
+        split = run(0, len(rsteps))             # returns early, at the exchange step, when that one was only started
+
+        def finish():
+            state["second_half"] = True
+            run(split, len(rsteps))
+        return finish

@@ -304,6 +304,10 @@ class Evaluator:
         else:
             prev = self.eval_stage(leaf, k - 1)
             res = None
+            if k == 1 and self.dist.size > 1:
+                order = self.__dict__.setdefault("_stage1_order", [])
+                if all(x is not leaf for x in order):
+                    order.append(leaf)              # prefetch_stage1
             wz = getattr(self, "_dualz_want", {}).get(id(leaf)) if k == 1 else None
             if wz is not None:
                 self._z_dual(leaf, *wz)                 # the z-derivative is an operand too: both from one read
@@ -731,6 +735,23 @@ class Evaluator:
 
     def new_pass(self):
         self.cache = {}
+        settle = getattr(self.dist.transformer, "settle", None)
+        if settle is not None:
+            settle()                            # no exchange outlives the pass that started it
+
+    def prefetch_stage1(self):
+        """Several ranks: issue the z step (and with it the pencil transposes, which return without waiting:
+        Transformer._defer) of every field the previous pass transformed, in that pass's order, before anything consumes
+        one -- the exchanges queue up on the communicator's stream and the wire of a later field runs under the x transforms
+        of an earlier one.  The expression graph is static, so the previous pass's list is this pass's list; a field that
+        turns out not to be needed costs one transform, a new one is simply evaluated on demand.  DDH_A2A_PREFETCH=1 switches
+        it on: under an emulated wire it measured neutral (the grid stage needs every operand, so only the x transforms
+        are there to hide the wire behind: profiles/r6_rank_emulation.txt) and it is off by default."""
+        order = self.__dict__.get("_stage1_order")
+        if not order or self.dist.size == 1 or os.environ.get("DDH_A2A_PREFETCH", "0") != "1":
+            return
+        for leaf in order:
+            self.eval_stage(leaf, 1)
 
 
 def evaluate_expression(expr):

@@ -664,6 +664,7 @@ class SolverBase:
         whose address the allocator may hand out again after unrelated data lived there -- is zeroed on every call."""
         ev, ex = self.evaluator_core, self.ex
         ev.new_pass()
+        ev.prefetch_stage1()                    # several ranks: every field's z step + exchange start before the first x step
         if tiled_row and self.F_direct is None:
             raise RuntimeError("tile-major right-hand sides need the direct-F plan")
         if self.F_direct is not None:
@@ -678,12 +679,17 @@ class SolverBase:
                         for (leaf, row0, rows), fp in grp]
                 ev.eval_fused_products([(item[0], fp) for item, fp in grp], outs,
                                        scales=[self.F_direct[id(item[0])][1] for item, fp in grp])
+                finish = []
                 for ((leaf, row0, rows), fp), pg in zip(grp, outs):
                     einfo = self.F_direct[id(leaf)][0]
                     edom = einfo["eq"]["domain"]
                     dst = out[einfo["row0"]:einfo["row0"] + einfo["rows"]].reshape(
                         (leaf.ncomp,) + tuple(edom.storage_coeff_shape()))
-                    tr.forward_data(edom, leaf.ncomp, pg, edom.dealias, dst, skip_last=True, tiled_row=tiled_row)
+                    # every product's transforms up to its pencil transpose first, then the rest: on several ranks the
+                    # exchange of one product runs under the x transforms of the next (Transformer.forward_begin)
+                    finish.append(tr.forward_begin(edom, leaf.ncomp, pg, edom.dealias, dst, skip_last=True, tiled_row=tiled_row))
+                for f in finish:
+                    f()
             ev.new_pass()
             if self.F_const is not None:
                 ex.scatter_set(out, self.F_const)       # (entries of the kx = ky = 0 cos-cos mode: offset 0 of a row in

@@ -334,3 +334,26 @@ def test_rank_emulation_tool_runs_a_rank_of_a_sharded_problem():
     assert any("loop-back" in k for k in d["exchange_via"]), d["exchange_via"]
     assert "pencil_solve" in d["families"] and "a2a_pack" in d["families"] and "a2a_unpack" in d["families"]
     assert d["wire_MB_per_rank_per_step"] > 0 and d["predicted_wire_ms_per_step"] > 0
+
+
+def test_deferred_exchange_schedules_compute_the_same_state_under_an_emulated_wire():
+    """Rank 1 of 2 of 3-D RB 128 x 16 x 32 (blocks of 64 rows: the blocked exchange) on the loop-back communicator with
+    every exchange followed by an emulated wire time on its stream (DDH_LOOPBACK_LINK_GBPS, slow enough that a consumer
+    that did not wait would read stale data): the schedules of the exchange -- waits at the exchange, waits deferred to the
+    consumer (default), x steps component by component, all z steps first -- end in bit-identical states."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shas = {}
+    for name, env in (("eager", {"DDH_A2A_DEFER": "0"}), ("deferred", {}), ("split", {"DDH_A2A_SPLIT_X": "1"}),
+                      ("prefetch+split", {"DDH_A2A_PREFETCH": "1", "DDH_A2A_SPLIT_X": "1"})):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "rank_emulation.py"), "--ranks", "2", "--rank", "1",
+                            "--size", "128,16,32", "--steps", "3", "--warmup", "1", "--link-gbps", "0.5"],
+                           capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["state_finite"] is True and d["emulated_link_GBps"] == 0.5
+        assert "a2a_pack" not in d["families"] and "a2a_unpack" not in d["families"], sorted(d["families"])
+        shas[name] = d["state_sha256"]
+    assert len(set(shas.values())) == 1, shas

@@ -67,20 +67,24 @@ def test_sharded_run_with_the_blocked_exchange_layout_matches_the_reference():
         assert rel(mine, ref) < tol, (key, rel(mine, ref))
 
 
-@pytest.mark.parametrize("shape,rows", [((256, 16, 32), 128), ((512, 16, 32), 256), ((512, 16, 32), 64)])
-def test_blocked_and_unpacked_exchanges_take_the_same_steps(shape, rows):
-    """Blocks of 128 and 256 rows (2 ranks at Nx = 256 / 512) and of 64 rows (8 ranks' share emulated by 2 ranks is not
-    possible: 64 = 512 / 8 needs 8 processes -- here 4 ranks x 128... so the 64-row case runs 4 ranks at Nx = 256): the
-    blocked exchange (DDH_A2A_BLOCKED default) and the round-5 pack / exchange / unpack path (=0) give bit-identical states."""
-    world = {128: 2, 256: 2, 64: 4}[rows]
-    nx = {128: 256, 256: 512, 64: 256}[rows]
-    case = "rb3dsize_%dx%dx%d" % (nx, shape[1], shape[2])
+@pytest.mark.parametrize("nx,world,rows", [(256, 2, 128), (512, 2, 256), (256, 4, 64)])
+def test_blocked_and_unpacked_exchanges_take_the_same_steps(nx, world, rows):
+    """Blocks of nx / world = 128, 256 and 64 rows: the blocked exchange (x transforms on the exchanged layout, no pack /
+    unpack kernels: the default) and the round-5 pack / exchange / unpack path (DDH_A2A_BLOCKED=0) give bit-identical
+    states -- and so do the blocked exchange's schedules: waits deferred to the consumer (default) or not, the x steps
+    component by component behind the arrivals, every field's z step issued first."""
+    case = "rb3dsize_%dx16x32" % nx
     a = _run_sharded(case, world, {})
     b = _run_sharded(case, world, {"DDH_A2A_BLOCKED": "0"})
     assert int(a[0]["stage_xb"][2]) == rows and int(b[0]["stage_xb"][0]) == -1
-    for ra, rb in zip(a, b):
-        for key in ("p", "b", "u"):
-            assert np.array_equal(ra[key], rb[key]), (rows, key)
+    others = [b]
+    if rows == 128:
+        others += [_run_sharded(case, world, env) for env in ({"DDH_A2A_DEFER": "0"}, {"DDH_A2A_SPLIT_X": "1"},
+                                                              {"DDH_A2A_PREFETCH": "1", "DDH_A2A_SPLIT_X": "1"})]
+    for other in others:
+        for ra, rb in zip(a, other):
+            for key in ("p", "b", "u"):
+                assert np.array_equal(ra[key], rb[key]), (rows, key)
 
 
 @pytest.mark.parametrize("ts", ["SBDF2"])

@@ -75,6 +75,13 @@ PY
                 done ;;
     emu)        # one rank of the P-rank run on this GPU, loop-back exchange (profiles/r6_rank_emulation.txt)
                 python tools/rank_emulation.py --ranks 2,4,8 --rank 1 --steps 10 --warmup 3 ${ONE_GPU_MS:+--single-gpu-ms $ONE_GPU_MS} > $OUT/rank_emulation.jsonl 2> $OUT/rank_emulation.txt; cat $OUT/rank_emulation.txt ;;
+    emu-wire)   # the same with the loop-back exchanges followed by an emulated wire time at 75 GB/s per link: how much of it is hidden
+                python tools/rank_emulation.py --ranks 2,4,8 --rank 1 --steps 10 --warmup 8 --link-gbps 75 > $OUT/rank_emulation_wire.jsonl 2> $OUT/rank_emulation_wire.txt; cat $OUT/rank_emulation_wire.txt
+                python tools/rank_emulation.py --ranks 2,4,8 --rank 1 --steps 10 --warmup 8 > $OUT/rank_emulation.jsonl 2> $OUT/rank_emulation.txt; cat $OUT/rank_emulation.txt ;;
+    emu-defer)  # deferred waits / component-split x steps / z-step prefetch around the blocked exchange, under an emulated wire
+                python -m pytest tests/test_gpu_multirank.py -x -q -m gpu > $OUT/pytest_multirank.txt 2>&1; tail -3 $OUT/pytest_multirank.txt
+                for P in 8 4; do for v in "DDH_A2A_DEFER=0" "DDH_X=1" "DDH_A2A_SPLIT_X=1" "DDH_A2A_PREFETCH=1" "DDH_A2A_PREFETCH=1 DDH_A2A_SPLIT_X=1"; do
+                  echo "P=$P $v"; env $v python tools/rank_emulation.py --ranks $P --rank 1 --steps 10 --warmup 8 --link-gbps 75 2>&1 >/dev/null | cut -c1-120; done; done 2>&1 | tee $OUT/emu_defer_ab.txt ;;
     bwd-rowmajor) # timing experiment: the backward sweep reading the factor rows as if stored row-major over the blocks
                 for v in 0 128; do DDH_BWD_DBG=$v python bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-cfl --no-parity > $OUT/bench_bwddbg$v.json 2> $OUT/bench_bwddbg$v.err
                   echo "DDH_BWD_DBG=$v"; bench_line $OUT/bench_bwddbg$v.json; done ;;

@@ -71,13 +71,17 @@ def one(rank, P, size, steps, warmup, dt):
     side_ms = sum(a.elapsed_time(b) for a, b in wire_events) / steps if wire_events else 0.0
     wire_ms = (wire_bytes / max(P - 1, 1) / 1e9) / LINK_GBPS * 1e3               # every peer over its own link, concurrently
     kern_ms = sum(v["total_ms"] for v in summ.values()) / steps
-    finite = bool(np.isfinite(np.asarray(ex.download(solver.X))).all()) if hasattr(solver, "X") else None
+    import hashlib
+    Xh = np.ascontiguousarray(np.asarray(ex.download(solver.X))) if hasattr(solver, "X") else None
+    finite = bool(np.isfinite(Xh).all()) if Xh is not None else None
+    sha = hashlib.sha256(Xh.tobytes()).hexdigest() if Xh is not None else None
     return dict(P=P, rank=rank, size=list(size), steps=steps, ms_per_step_loopback=step_ms, kernel_ms_per_step=kern_ms,
                 families=fam, exchange_via=via, wire_MB_per_rank_per_step=wire_bytes / 1e6,
                 side_stream_copy_ms_per_step=side_ms, predicted_wire_ms_per_step=wire_ms, link_GBps_assumed=LINK_GBPS,
                 predicted_ms_per_step_no_overlap=step_ms + wire_ms, predicted_ms_per_step_full_overlap=max(step_ms, wire_ms),
                 predicted_steps_per_s=dict(no_overlap=1e3 / (step_ms + wire_ms), full_overlap=1e3 / max(step_ms, wire_ms)),
-                ideal_share_ms=None, build_s=build_s, state_finite=finite,
+                ideal_share_ms=None, build_s=build_s, state_finite=finite, state_sha256=sha,
+                emulated_link_GBps=float(os.environ.get("DDH_LOOPBACK_LINK_GBPS", 0) or 0),
                 pencils_local=(Nx // 2 // P) * (Ny // 2), z_planes_local=(3 * Nz // 2) // P)
 
 
