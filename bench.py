@@ -505,6 +505,8 @@ def main():
             "config": {"workload": "3-D Rayleigh-Benard IVP %dx%dx%d, dealias 3/2, RK222, fixed dt=%g, Ra=2e6 Pr=1, "
                                    "example-script initial condition (fill_random seed 42)" % (Nx, Ny, Nz, args.dt),
                        "pencils": (Nx // 2) * (Ny // 2), "rows_per_pencil_real": 4 * solver.R,
+                       "layouts": {"state_vector": "tile-major" if getattr(solver, "x_tiled", 0) else "natural",
+                                   "right_hand_sides": "tile-major" if getattr(solver.timestepper, "_tiled", 0) else "natural"},
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs, pencils sharded on kx, RCCL all-to-all" % world},
             "roofline": roof,
             "whole_step": {"algorithmic_GB_per_step": total_bytes / (args.steps * nrep) / 1e9,

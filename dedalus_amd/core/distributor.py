@@ -345,10 +345,23 @@ class Transformer:
         launches cost what the overlap wins (P = 4: 30.1 ms per step without, 31.0 with; profiles/r6_rank_emulation.txt)."""
         return ncomp > 1 and os.environ.get("DDH_A2A_SPLIT_X", "0") == "1" and self.in_flight(src)
 
-    def backward_steps(self, domain, ncomp, src, scales, i0, i1, dst=None, deriv=None):
+    def coeff_tiled_ok(self, domain, scales, row_len):
+        """Can the first backward step of `domain` read coefficient rows [nx][row_len] stored tile-major?  (a strided
+        Chebyshev step on the wave kernels, one rank: Executor.tiled_forward_ok states the sizes)"""
+        ex = self.dist.executor
+        steps = self._steps(domain, scales)
+        if self.dist.size > 1 or not steps or not hasattr(ex, "tiled_forward_ok") or not hasattr(ex, "tile_rows"):
+            return False
+        pos, b, spec = steps[0]
+        shape = domain.storage_coeff_shape()
+        inner = int(np.prod(shape[pos + 1:]))
+        return pos == 0 and len(shape) == 3 and int(shape[2]) == row_len and ex.tiled_forward_ok(spec, b, inner, row_len)
+
+    def backward_steps(self, domain, ncomp, src, scales, i0, i1, dst=None, deriv=None, ctile=0):
         """Apply backward steps i0 .. i1-1 to data that has seen steps < i0 (z transform first, then the
         all-to-all (-> z-sharded, kx local), then the Fourier transforms).  deriv = (step, 2 pi / L)
-        differentiates along that RealFourier step's axis while its coefficients are loaded.
+        differentiates along that RealFourier step's axis while its coefficients are loaded.  ctile (with i0 = 0): the
+        coefficient rows of src are tile-major, rows of that length (coeff_tiled_ok).
         Returns the result (dst when given)."""
         ex = self.dist.executor
         steps = self._steps(domain, scales)
@@ -369,6 +382,8 @@ class Transformer:
                 if spec[0] != "rfft":
                     raise NotImplementedError("derivative at load along a non-Fourier axis")
                 xbv["deriv"] = deriv[1]
+            if ctile and i == 0:
+                xbv["tiled_row"] = ctile
             if exchange and i >= 1 and self._x_step_by_component(src, ncomp):
                 for c in range(ncomp):
                     self.wait_for(src[c:c + 1])
@@ -461,7 +476,7 @@ class Transformer:
             self._exchange(ex, "rows", src, out2, nc, Gz, nxl * P, rest)
         return out2
 
-    def backward_dual_z(self, ldomain, xdomain, ncomp, src, scales, dvec):
+    def backward_dual_z(self, ldomain, xdomain, ncomp, src, scales, dvec, ctile=0):
         """The backward Jacobi-axis step (step 0) of a field's coefficients twice from one read: -> (the field's transform,
         the transform of the one-superdiagonal operator `dvec` (device array) applied to the coefficients, taken in
         xdomain's basis), each followed by the pencil transpose on several ranks."""
@@ -476,7 +491,10 @@ class Transformer:
         xb = self.stage_xb(ldomain, scales)
         if xb is not None and self.stage_xb(xdomain, scales) != xb:
             raise RuntimeError("dual z transform: the two domains disagree about the stage layout")
-        ex.transform_dual_z(spec, b, src, out, out_d, dvec, outer, inner, **(dict(xb=xb[0]) if (xb is not None and xb[0]) else {}))
+        kw = dict(xb=xb[0]) if (xb is not None and xb[0]) else {}
+        if ctile:
+            kw["tiled_row"] = ctile             # (src: a state field's rows as the solver keeps them)
+        ex.transform_dual_z(spec, b, src, out, out_d, dvec, outer, inner, **kw)
         if self._needs_exchange(ldomain) and pos == 0:
             out = self._rows_after_z(ex, out, list(shape), blocked=xb is not None)
             out_d = self._rows_after_z(ex, out_d, list(shape), blocked=xb is not None)

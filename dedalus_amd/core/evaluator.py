@@ -26,10 +26,51 @@ from .problems import LinCtx
 
 
 class SystemBuffer:
-    """A [rows][nx][ny] device array together with the leaves that are views into it."""
+    """A [rows][nx][ny] device array together with the leaves that are views into it.
+
+    tiled = ny: the rows of `array` are stored tile-major ([kx / 8][ky / 8][kx % 8][ky % 8]; the solver's choice,
+    SolverBase._enable_state_tiling): the kernels of the step read and write that layout, everything else -- user access to
+    a state field, output, generic operators -- sees a NATURAL shadow of the rows it asks for, converted on demand
+    (ddh_tile_rows) and valid until the solver writes the state again."""
 
     def __init__(self, array, nrows):
         self.array, self.nrows = array, nrows
+        self.tiled = 0
+        self.ranges = []            # (row0, rows) of the variables
+        self.valid = {}             # row0 -> the natural shadow of that variable's rows is current
+        self._nat = None
+
+    def _shadow(self, ex):
+        if self._nat is None:
+            self._nat = ex.empty(tuple(self.array.shape))
+        return self._nat
+
+    def invalidate(self):
+        for k in self.valid:
+            self.valid[k] = False
+
+    def natural_rows(self, ex, row0, rows, current=True):
+        """The natural shadow of rows row0 .. row0 + rows (a view); current: brought up to date from the tiled state."""
+        nat = self._shadow(ex)
+        if current and not self.valid.get(row0, False):
+            _, nx, ny = self.array.shape
+            ex.tile_rows(self.array[row0:row0 + rows], nat[row0:row0 + rows], rows, nx, ny, False)
+            self.valid[row0] = True
+        return nat[row0:row0 + rows]
+
+    def commit_rows(self, ex, row0, rows):
+        """The natural shadow of these rows was written: into the tiled state with it."""
+        _, nx, ny = self.array.shape
+        ex.tile_rows(self._shadow(ex)[row0:row0 + rows], self.array[row0:row0 + rows], rows, nx, ny, True)
+        self.valid[row0] = True
+
+    def natural(self, ex):
+        """The whole state in the natural layout (the array itself when it is not tiled)."""
+        if not self.tiled:
+            return self.array
+        for row0, rows in self.ranges:
+            self.natural_rows(ex, row0, rows)
+        return self._nat
 
 
 def _pencil_geom(dist):
@@ -172,7 +213,7 @@ class Evaluator:
             if cached is None:
                 cached = le._tl_cache = {}
             if sb is not None:
-                x = sb.array
+                x = sb.natural(self.ex)         # (a tile-major state: its natural shadow)
                 nrows_in = sb.nrows
             else:
                 leaf = items[0][0]
@@ -302,7 +343,7 @@ class Evaluator:
         if k == 0:
             res = leaf.coeff_data().reshape((leaf.ncomp,) + tuple(dom.storage_coeff_shape()))
         else:
-            prev = self.eval_stage(leaf, k - 1)
+            prev = self.eval_stage(leaf, k - 1) if k > 1 else None          # (k == 1: _stage0, below / in _z_dual)
             res = None
             if k == 1 and self.dist.size > 1:
                 order = self.__dict__.setdefault("_stage1_order", [])
@@ -315,13 +356,30 @@ class Evaluator:
             want = getattr(self, "_dual_want", {}).get((id(leaf), k - 1))
             if res is None and want is not None and os.environ.get("DDH_NO_DUAL_FFT") is None:
                 # this field AND its derivative along the axis of step k - 1 are operands: one kernel, one read
+                if prev is None:
+                    prev = self.eval_stage(leaf, 0)
                 pair = self.dist.transformer.backward_dual_step(dom, leaf.ncomp, prev, dom.dealias, k - 1, want)
                 if pair is not None:
                     res, self.cache[("sd", id(leaf), k - 1, want)] = pair
             if res is None:
-                res = self.dist.transformer.backward_steps(dom, leaf.ncomp, prev, dom.dealias, k - 1, k)
+                ctile = 0
+                if k == 1:
+                    prev, ctile = self._stage0(leaf)
+                res = self.dist.transformer.backward_steps(dom, leaf.ncomp, prev, dom.dealias, k - 1, k,
+                                                           **(dict(ctile=ctile) if ctile else {}))
         self.cache[key] = res
         return res
+
+    def _stage0(self, leaf):
+        """(coefficient data of a field for its first backward step, row length of tile-major rows or 0): a state field
+        kept tile-major by its solver is handed to the z transform as it lies when that transform reads the layout
+        (Transformer.coeff_tiled_ok), otherwise its natural data."""
+        tr = self.dist.transformer
+        if getattr(leaf, "_tiled", None) is not None and hasattr(tr, "coeff_tiled_ok") \
+                and tr.coeff_tiled_ok(leaf.domain, leaf.domain.dealias, int(leaf._tiled.tiled)):
+            c, ctile = leaf.coeff_tiled()
+            return c.reshape((leaf.ncomp,) + tuple(leaf.domain.storage_coeff_shape())), ctile
+        return self.eval_stage(leaf, 0), 0
 
     def eval_pregrid(self, expr):
         """Data of a field / linear expression with every axis but the last storage axis in (dealiased)
@@ -426,8 +484,9 @@ class Evaluator:
         dv = store.get(dvec.tobytes())
         if dv is None:
             dv = store[dvec.tobytes()] = self.dist.executor.from_host(dvec)
-        coeff = self.eval_stage(leaf, 0)
-        plain, der = self.dist.transformer.backward_dual_z(leaf.domain, xdomain, leaf.ncomp, coeff, leaf.domain.dealias, dv)
+        coeff, ctile = self._stage0(leaf)
+        plain, der = self.dist.transformer.backward_dual_z(leaf.domain, xdomain, leaf.ncomp, coeff, leaf.domain.dealias, dv,
+                                                           **(dict(ctile=ctile) if ctile else {}))
         self.cache.setdefault(("s", id(leaf), 1), plain)
         self.cache[key] = der
         return der

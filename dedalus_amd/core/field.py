@@ -154,6 +154,8 @@ class Field(Operand):
         self._host_scales = None
         self._authority = "device"      # 'device' | 'host'
         self._adopted = False           # coefficient array is a view into a solver's state vector
+        self._tiled = None              # the SystemBuffer whose tile-major rows _c is a view of (SolverBase._enable_state_tiling)
+        self._nrows = 0
 
     def __repr__(self):
         return self.name or "<Field %d>" % id(self)
@@ -201,9 +203,18 @@ class Field(Operand):
         return self.dist.executor
 
     def _alloc_c(self):
+        """The coefficient array to WRITE natural-layout data into (followed by _coeff_written)."""
+        if self._tiled is not None:
+            return self._tiled.natural_rows(self.ex, self._row0, self._nrows, current=False).reshape(
+                self._storage_shape("c", None))
         if self._c is None:
             self._c = self.ex.zeros(self._storage_shape("c", None))
         return self._c
+
+    def _coeff_written(self):
+        """Natural coefficient data was written into _alloc_c(): a state field kept tile-major takes it over."""
+        if self._tiled is not None:
+            self._tiled.commit_rows(self.ex, self._row0, self._nrows)
 
     def _alloc_g(self, scales):
         shape = self._storage_shape("g", scales)
@@ -221,19 +232,36 @@ class Field(Operand):
         st = self._to_storage(self._host, lay, sc)
         if lay == "c":
             self.ex.upload(self._alloc_c(), st)
+            self._coeff_written()
         else:
             self.ex.upload(self._alloc_g(sc), st)
             self.scales = sc
         self.layout = lay
 
     def require_coeff_space(self):
+        """Device coefficient array in the NATURAL layout, current (for a state field kept tile-major by its solver: the
+        natural shadow of its rows, refreshed from the state when stale -- read-only for the caller)."""
         self._sync_to_device()
         if self.layout == "g":
             self.dist.transformer.forward(self, self._g, self._g_scales, self._alloc_c())
+            self._coeff_written()
             self.layout = "c"
         elif self._c is None:
             self._alloc_c()
+        if self._tiled is not None:
+            return self._tiled.natural_rows(self.ex, self._row0, self._nrows).reshape(self._storage_shape("c", None))
         return self._c
+
+    def coeff_tiled(self):
+        """(device coefficient array as the solver stores it, row length of its tile-major rows or 0 for natural)."""
+        if self._tiled is None:
+            return self.require_coeff_space(), 0
+        self._sync_to_device()
+        if self.layout == "g":
+            self.dist.transformer.forward(self, self._g, self._g_scales, self._alloc_c())
+            self._coeff_written()
+            self.layout = "c"
+        return self._c, int(self._tiled.tiled)
 
     def require_grid_space(self, scales=None):
         self._sync_to_device()

@@ -71,6 +71,7 @@ class SolverBase:
                              "may still differ, this is the global count)" % (row, self.R))
         # ---- state vector; state fields become views into it
         self.X = self.ex.zeros((self.R, nx, ny))
+        self.x_tiled = 0                    # row length when X is kept tile-major (_enable_state_tiling: IVPs)
         self.sysbuf = SystemBuffer(self.X, self.R)
         for info in self.var_info:
             v = info["field"]
@@ -757,6 +758,7 @@ class SolverBase:
             self.ex.assign(cs, xs)
 
     def mark_state_current(self):
+        self.sysbuf.invalidate()                # (a tile-major state: the natural shadows of its rows are stale)
         for info in self.var_info:
             if info["aliased"]:
                 info["field"].mark_device_coeff_current()
@@ -764,8 +766,61 @@ class SolverBase:
 
     def sync_state_to_device(self):
         for info in self.var_info:
-            info["field"].require_coeff_space()
+            info["field"].coeff_tiled()         # (host edits uploaded; a tile-major field is NOT converted for this)
         self.push_unaliased()
+
+    # ---- tile-major state vector ---------------------------------------------------------------------------
+    def _state_tiling_ok(self):
+        ex = self.ex
+        if os.environ.get("DDH_X_TILED", "1") == "0" or not hasattr(ex, "tile_rows") or not hasattr(self.pack, "set_state_tiled"):
+            return False
+        if self.nf != 2 or self.nx % 8 or self.ny % 8 or self.dist.size > 1:
+            return False
+        if self.nx * self.ny < int(os.environ.get("DDH_X_TILED_MIN", 4 * 16384)):
+            return False
+        sep = self.dist.separable_axes
+        for info in self.var_info:
+            v = info["field"]
+            if info["aliased"]:
+                if tuple(v._storage_shape("c", None))[-2:] != (self.nx, self.ny):
+                    return False
+            elif any(v.domain.by_axis[ax] is not None for ax in sep):
+                return False                    # (plane copies of a field with one Fourier axis address X naturally)
+        return True
+
+    def _enable_state_tiling(self):
+        """Keep the state vector X tile-major ([kx / 8][ky / 8][kx % 8][ky % 8] within a row, like the right-hand-side
+        vectors): a wavefront of the backward sweep stores a solution row as two 512-byte runs instead of sixteen 64-byte
+        runs over eight storage rows (solve -0.5 ms per launch pair at 512^2 pencils).  The kernels of the step follow --
+        every solve of the pack writes, every mat-vec reads that layout (ddh_pencil_set_state_tiled), the backward z
+        transforms read it (ddh_fft_set_coeff_tiled; Evaluator._stage0) -- and everything else sees natural shadows of the
+        rows it asks for (SystemBuffer, Field.require_coeff_space).  One rank, two Fourier axes with sizes that are
+        multiples of 8; DDH_X_TILED=0 keeps the natural layout.  Replaces nothing in the reference, whose state lives in
+        the fields (core/subsystems.py:497-596 gathers / scatters per solve)."""
+        self.x_tiled = 0
+        if not self._state_tiling_ok():
+            return
+        ex = self.ex
+        self.sync_state_to_device()
+        tmp = ex.empty((self.R, self.nx, self.ny))
+        ex.tile_rows(self.X, tmp, self.R, self.nx, self.ny, True)
+        ex.copy(self.X, tmp)
+        del tmp
+        sb = self.sysbuf
+        sb.tiled = int(self.ny)
+        for info in self.var_info:
+            sb.ranges.append((info["row0"], info["rows"]))
+            sb.valid[info["row0"]] = False
+            if info["aliased"]:
+                v = info["field"]
+                v._tiled, v._nrows = sb, info["rows"]
+        self.pack.set_state_tiled(True)
+        self.x_tiled = int(self.ny)
+
+    def state_natural(self):
+        """The state vector [R][nx][ny] in the natural layout (tests, tools): X itself, or the natural shadow of a
+        tile-major state brought up to date."""
+        return self.sysbuf.natural(self.ex)
 
     def rhs_tiling(self, lus):
         """Row length ny when the solver-internal right-hand-side vectors (the timestepper's M.X and F buffers) can use
@@ -830,6 +885,8 @@ class SolverBase:
         not store -- their entries of `x` are stale by design and the record says which."""
         probe = self.solve_probe
         a, b = self._lu_params[lu]
+        if getattr(self, "x_tiled", 0):
+            out = self.untile_rows(out)         # (every solution vector of a pack with a tile-major state is tile-major)
         rec = dict(a=a, b=b, path=path, terms=int(terms), zero_rows=bool(zero_rows), skip_rows=skip_rows is not None,
                    rhs=[self.gather_pencil(rhs, "equations", gx, gy) for gx, gy in probe["groups"]],
                    x=[self.gather_pencil(out, "variables", gx, gy) for gx, gy in probe["groups"]])
@@ -1292,6 +1349,7 @@ class InitialValueSolver(IVPLifecycle, SolverBase):
     def __init__(self, problem, timestepper, enforce_real_cadence=100, warmup_iterations=10, **kw):
         t0 = time.time()
         SolverBase.__init__(self, problem, **kw)
+        self._enable_state_tiling()
         self.sim_time_field = problem.time
         self._sim_time = 0.0
         self._init_lifecycle(enforce_real_cadence, warmup_iterations)

@@ -1213,8 +1213,8 @@ static int launch(FftPlan *pl, const double *src, double *dst, long outer, long 
     }
     if (d.xb && inner_mode) return fail("x-blocked stage layout (ddh_fft_set_stage_layout): only the strided-axis wave kernels at their "
                           "instantiated sizes read / write it -- this transform would have used another kernel");
-    if (d.ctile_nseg) return fail("cheb_forward_tiled: only the wave-per-four-pairs kernel (N = 384, M = 256, strided axis) "
-                                  "writes the tile-major coefficient layout");
+    if (d.ctile_nseg) return fail("tile-major coefficient rows (ddh_cheb_forward_tiled, ddh_fft_set_coeff_tiled): only the strided-axis "
+                                  "Chebyshev wave kernels at their instantiated sizes read / write that layout");
     long npairs;
     if (is_cfft)
         npairs = inner_mode ? inner : outer;
@@ -1481,6 +1481,19 @@ int ddh_fft_set_stage_block(ddh_handle plan, int rows) {
     if (pl->tkind != K_RFFT) return fail("ddh_fft_set_stage_block: real-Fourier plans");
     if (!(rows == 0 || rows == 64 || rows == 128 || rows == 256)) return fail("ddh_fft_set_stage_block: 64, 128 or 256 rows (0 = 64)");
     pl->dev.xbB = (unsigned)rows;
+    return 0;
+}
+
+/* The coefficient-side array of this Chebyshev plan's following STRIDED-axis transforms (both directions) has rows
+ * [nx][ny = row_len] stored tile-major ([kx / 8][ky / 8][kx % 8][ky % 8]: the state vector of a pack with
+ * ddh_pencil_set_state_tiled); row_len = 0: natural again.  Like the stage layout it is a property of the next launches, set
+ * by the caller before each of them; transforms that cannot take the wave kernels fail instead of reading another layout. */
+int ddh_fft_set_coeff_tiled(ddh_handle plan, long row_len) {
+    FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
+    if (!pl) return -1;
+    if (pl->tkind != K_CHEB) return fail("ddh_fft_set_coeff_tiled: Chebyshev plans");
+    if (row_len < 0 || (row_len & 7) || row_len > 0x7fffffffL) return fail("ddh_fft_set_coeff_tiled: row_len a multiple of 8");
+    pl->dev.ctile_nseg = (unsigned)(row_len / 8);
     return 0;
 }
 

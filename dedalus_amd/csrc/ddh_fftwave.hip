@@ -80,12 +80,12 @@ wave_cheb_kernel(FftDev p, WaveArgs a) {
     auto locate = [&](unsigned tile, long &off_c, long &off_g, bool &valid) {
         unsigned o, tb;
         a.fd_tpo.divmod(tile, o, tb);
-        const long pair0 = 4L * tb;
         long seg = tb;                       // 64-byte segment of the coefficient row [nx][ny] ...
-        if (FWD && p.ctile_nseg) {           // ... tile-major: [kx / 8][ky / 8][kx % 8] (ddh_cheb_forward_tiled, tile_offset)
+        if (p.ctile_nseg) {           // ... tile-major: [kx / 8][ky / 8][kx % 8] (ddh_cheb_forward_tiled, ddh_fft_set_coeff_tiled)
             const unsigned kxrow = tb / p.ctile_nseg, sg = tb - kxrow * p.ctile_nseg;
             seg = ((long)(kxrow >> 3) * p.ctile_nseg + sg) * 8 + (kxrow & 7);
         }
+        const long pair0 = 4L * tb;
         off_c = ((long)o * M) * inner + 8 * seg;
         off_g = ((long)o * N) * inner + 2 * pair0;
         if (p.xb) {
@@ -454,7 +454,7 @@ int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, lon
             return 1;
         }
     }
-    if (d.ctile_nseg && (mode != CHEB_FWD || inner % (8L * d.ctile_nseg) || (inner / (8L * d.ctile_nseg)) % 8)) return 1;
+    if (d.ctile_nseg && ((mode != CHEB_FWD && mode != CHEB_BWD) || inner % (8L * d.ctile_nseg) || (inner / (8L * d.ctile_nseg)) % 8)) return 1;
     const bool cheb = (mode == CHEB_FWD || mode == CHEB_BWD), rfft = (mode == RFFT_FWD || mode == RFFT_BWD);
     if (!cheb && !rfft) return 1;
     if ((cheb && !(mask & 1)) || (rfft && !(mask & 2))) return 1;

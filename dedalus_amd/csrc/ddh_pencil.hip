@@ -48,6 +48,8 @@ struct PencilDev {
     long G;         // systems = ncells * S
     long mx_offset; // global x mode index of the first local cell (pencils sharded over ranks)
     const double *kx, *ky;
+    int xtile;      // 1: the STATE vector X -- the solution every solve writes, the input of every mat-vec -- is stored
+                    // tile-major (tile_offset) like the right-hand-side vectors: ddh_pencil_set_state_tiled
 };
 
 struct MatDev {
@@ -430,13 +432,16 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
     const CellCtx c = cell_ctx(P, cell);
     const long plane = P.nx * P.ny;
     long off0, off1 = 0;
+    long xoff0, xoff1 = 0;           // x: natural or tile-major (PencilDev::xtile); y: natural
     if (NF == 2) {
         off0 = (2 * c.mx) * P.ny + 2 * c.my;
         off1 = off0 + P.ny;
+        xoff0 = P.xtile ? tile_offset(2 * c.mx, 2 * c.my, P.ny) : off0;
+        xoff1 = P.xtile ? tile_offset(2 * c.mx + 1, 2 * c.my, P.ny) : off1;
     } else if (NF == 1) {
-        off0 = 2 * c.mx;
+        off0 = xoff0 = 2 * c.mx;
     } else {
-        off0 = 0;
+        off0 = xoff0 = 0;
     }
     double2 h0[4], h1[4];
 #pragma unroll
@@ -463,15 +468,15 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
             const double2 v = make_double2(cf.x * f, cf.y * f);
             const double *xr = x + (long)A.col[t] * plane;
             if (NF == 2) {
-                const double2 a = *reinterpret_cast<const double2 *>(xr + off0);   // cc, cs
-                const double2 b = *reinterpret_cast<const double2 *>(xr + off1);   // sc, ss
+                const double2 a = *reinterpret_cast<const double2 *>(xr + xoff0);   // cc, cs
+                const double2 b = *reinterpret_cast<const double2 *>(xr + xoff1);   // sc, ss
                 const double2 xP = make_double2(a.x - b.y, a.y + b.x);
                 const double2 xQ = make_double2(a.x + b.y, a.y - b.x);
                 cfma(accP, v, xP);
                 const double sg = (e & 1u) ? -1.0 : 1.0;
                 cfma(accQ, make_double2(v.x * sg, v.y * sg), xQ);
             } else if (NF == 1) {
-                const double2 xP = *reinterpret_cast<const double2 *>(xr + off0);
+                const double2 xP = *reinterpret_cast<const double2 *>(xr + xoff0);
                 cfma(accP, v, xP);
             } else {
                 accP.x += v.x * xr[0];
@@ -534,14 +539,22 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
 __global__ void __launch_bounds__(256)
 band_matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, int rows_per_chunk, int keep_empty,
                    int out_tiled) {
-    const long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long cell = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= P.ncells) return;
+    if (P.xtile && out_tiled) {
+        // x and y both tile-major: threads follow the tiles (16 consecutive threads = the 4 x 4 cells of one 512-byte tile, a
+        // wavefront = four neighbouring tiles: every row access of a wave is one 2 KiB run).  Which thread computes a cell
+        // does not change its value.
+        const long tile = cell >> 4, tpr = P.ncy >> 2;
+        cell = ((tile / tpr) * 4 + ((cell >> 2) & 3)) * P.ncy + (tile % tpr) * 4 + (cell & 3);
+    }
     const CellCtx c = cell_ctx(P, cell);
     const long plane = P.nx * P.ny;
-    const long off0 = (2 * c.mx) * P.ny + 2 * c.my, off1 = off0 + P.ny;
+    const long off0 = P.xtile ? tile_offset(2 * c.mx, 2 * c.my, P.ny) : (2 * c.mx) * P.ny + 2 * c.my;
+    const long off1 = P.xtile ? tile_offset(2 * c.mx + 1, 2 * c.my, P.ny) : off0 + P.ny;
     // (y tile-major: ddh_pencil_matvec_update_tiled)
-    const long yoff0 = out_tiled ? tile_offset(2 * c.mx, 2 * c.my, P.ny) : off0;
-    const long yoff1 = out_tiled ? tile_offset(2 * c.mx + 1, 2 * c.my, P.ny) : off1;
+    const long yoff0 = out_tiled ? tile_offset(2 * c.mx, 2 * c.my, P.ny) : (2 * c.mx) * P.ny + 2 * c.my;
+    const long yoff1 = out_tiled ? tile_offset(2 * c.mx + 1, 2 * c.my, P.ny) : (2 * c.mx + 1) * P.ny + 2 * c.my;
     const int rr0 = blockIdx.y * rows_per_chunk;
     const int rr1 = (rr0 + rows_per_chunk < A.nrows_out) ? rr0 + rows_per_chunk : A.nrows_out;
     double2 wa[MV_W], wb[MV_W];                  // x rows wbase .. wbase + MV_W - 1: (cc, cs) and (sc, ss)
@@ -782,7 +795,8 @@ __device__ __forceinline__ void store_sys(double *__restrict__ v, long plane, in
         // independently, which would leave round-off there: write exact zeros.
         if (c.my == 0) out.y = 0.0;
         if (c.gmx == 0 && s == 1) out = make_double2(0.0, 0.0);
-        if (writer) *reinterpret_cast<double2 *>(vr + (2 * c.mx + s) * P.ny + 2 * c.my) = out;
+        if (writer) *reinterpret_cast<double2 *>(vr + (P.xtile ? tile_offset(2 * c.mx + s, 2 * c.my, P.ny)
+                                                                : (2 * c.mx + s) * P.ny + 2 * c.my)) = out;
     } else if (NF == 1) {
         if (c.gmx == 0) val.y = 0.0;
         if (writer) *reinterpret_cast<double2 *>(vr + 2 * c.mx) = val;
@@ -3420,6 +3434,7 @@ int ddh_pencil_create(ddh_handle *pack, const ddh_pencil_geom *geom) {
     d.ncells = d.ncx * d.ncy;
     d.G = d.ncells * d.S;
     d.mx_offset = geom->mx_offset;
+    d.xtile = 0;
     int st = 0;
     if (d.nf >= 1) st = upload_vec(&pp->d_kx, geom->kx_h, (size_t)d.ncx);
     if (!st && d.nf == 2) st = upload_vec(&pp->d_ky, geom->ky_h, (size_t)d.ncy);
@@ -3574,6 +3589,7 @@ static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y,
     if (ps.nz > 0 && A.nrows_out % ps.nz) return fail("pencil_matvec_solve: rows are not a multiple of nz");
     const unsigned blocks = (unsigned)((P.ncells + 255) / 256);
     hipStream_t s = as_stream(stream);
+    if (P.xtile && (P.nf != 2 || ps.nz > 0)) return fail("pencil_matvec: a tile-major state vector needs two Fourier axes and no fused back-substitution");
     if (ps.nz > 0 && blocks < 64 && !getenv("DDH_MV_FUSED_POST")) {
         // few cells: all rows in parallel first, then the light sequential recurrence (see postsolve_kernel)
         PostSolve none;
@@ -3615,6 +3631,19 @@ static int launch_matvec(PencilPack *pp, int mat_id, const double *x, double *y,
     else
         hipLaunchKernelGGL(matvec_kernel<0>, grid, dim3(256), 0, s, P, A, x, y, ps, rpc);
     DDH_HIP(hipGetLastError());
+    return 0;
+}
+
+/* The state vector X -- the solution vector of every solve and the input vector of every mat-vec of this pack from now on --
+ * is stored tile-major ([kx / 8][ky / 8][kx % 8][ky % 8] within a row, like the right-hand-side vectors of
+ * ddh_pencil_solve_recombined_tiled): a wavefront's stores of a solution row are two 512-byte runs instead of sixteen 64-byte
+ * runs.  Two Fourier axes with storage sizes that are multiples of 8; on = 0 returns to the natural layout. */
+int ddh_pencil_set_state_tiled(ddh_handle pack, int on) {
+    PencilPack *pp = (PencilPack *)lookup_handle(pack, H_PENCIL);
+    if (!pp) return -1;
+    if (on && (pp->dev.nf != 2 || (pp->dev.nx & 7) || (pp->dev.ny & 7)))
+        return fail("pencil_set_state_tiled: two Fourier axes with storage sizes that are multiples of 8");
+    pp->dev.xtile = on ? 1 : 0;
     return 0;
 }
 
@@ -4176,7 +4205,8 @@ static int solve_recombined_impl(ddh_handle pack, int lu_id, int nterms, const d
     if (st) return st;
     PostSolve none;
     memset(&none, 0, sizeof(none));
-    return launch_matvec(pp, p_mat_id, work, x, none, stream);
+    // (a tile-major state, ddh_pencil_set_state_tiled: `work` was written tile-major by the sweeps, and x must be too)
+    return launch_matvec(pp, p_mat_id, work, x, none, stream, 0, pp->dev.xtile);
 }
 
 int ddh_pencil_lu_row_widths(ddh_handle pack, int lu_id, int *wrow_h) {

@@ -176,8 +176,8 @@ class HipExecutor:
         return self._plans[spec]
 
     def transform(self, spec, basis, direction, src, dst, outer, inner, deriv=0.0, tiled_row=0, xb=0):
-        """tiled_row (forward Chebyshev only): dst rows of `inner` = nx * tiled_row doubles are written tile-major
-        (ddh_cheb_forward_tiled).  xb: the stage array of this transform (grid side of a Chebyshev, coefficient side of a
+        """tiled_row (strided Chebyshev only): the coefficient rows of `inner` = nx * tiled_row doubles -- dst of a forward,
+        src of a backward transform -- are tile-major (ddh_cheb_forward_tiled / ddh_fft_set_coeff_tiled).  xb: the stage array of this transform (grid side of a Chebyshev, coefficient side of a
         real-Fourier transform) is x-blocked: row length ny / z planes gz (ddh_fft_set_stage_layout), 0 = natural."""
         if self.timer is not None:
             name = "%s_%s_%s" % (spec[0], direction, "strided" if inner > 1 else "contig")
@@ -229,9 +229,16 @@ class HipExecutor:
         elif xb:
             raise NotImplementedError("x-blocked stage layout: strided Chebyshev / real-Fourier transforms only")
         if tiled_row:
-            if kind != "cheb" or direction != "forward":
-                raise NotImplementedError("tile-major output: forward Chebyshev transforms only")
-            libhip.call("ddh_cheb_forward_tiled", h, ptr(src), ptr(dst), outer, inner, int(tiled_row), self.dev.stream)
+            if kind != "cheb" or deriv:
+                raise NotImplementedError("tile-major coefficient rows: Chebyshev transforms only")
+            if direction == "forward":
+                libhip.call("ddh_cheb_forward_tiled", h, ptr(src), ptr(dst), outer, inner, int(tiled_row), self.dev.stream)
+                return
+            libhip.call("ddh_fft_set_coeff_tiled", h, int(tiled_row))
+            try:
+                libhip.call("ddh_cheb_backward", h, ptr(src), ptr(dst), outer, inner, self.dev.stream)
+            finally:
+                libhip.call("ddh_fft_set_coeff_tiled", h, 0)
             return
         if deriv:
             if kind != "rfft" or direction != "backward":
@@ -261,23 +268,34 @@ class HipExecutor:
         libhip.call("ddh_rfft_backward_dual", h, ptr(src), ptr(dst), ptr(dst_deriv), outer, inner, float(dscale),
                     self.dev.stream)
 
-    def transform_dual_z(self, spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb=0):
+    def transform_dual_z(self, spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb=0, tiled_row=0):
         """dst = backward Chebyshev transform of src (the family's own basis), dst_deriv = backward transform, in `basis`
-        (the derivative's basis), of the one-superdiagonal operator dvec applied to src (ddh_cheb_backward_dual)."""
+        (the derivative's basis), of the one-superdiagonal operator dvec applied to src (ddh_cheb_backward_dual).
+        tiled_row: the rows of src ([nx][tiled_row]) are tile-major (a state field of a solver with a tile-major state)."""
         if self.timer is not None:
             nb = (src.numel() + dst.numel() + dst_deriv.numel()) * 8
             return self.timer.run("cheb_backward_%s_dual" % ("strided" if inner > 1 else "contig"), nb,
-                                  self._transform_dual_z, spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb)
-        return self._transform_dual_z(spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb)
+                                  self._transform_dual_z, spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb, tiled_row)
+        return self._transform_dual_z(spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb, tiled_row)
 
-    def _transform_dual_z(self, spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb=0):
+    def _transform_dual_z(self, spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb=0, tiled_row=0):
         kind, h, _ = self._plan(spec, basis)
         if kind != "cheb":
             raise NotImplementedError("dual z transform: Chebyshev-family axes only")
         if inner > 1:
             self._stage_layout(h, xb)
-        libhip.call("ddh_cheb_backward_dual", h, ptr(src), ptr(dst), ptr(dst_deriv), ptr(dvec), outer, inner,
-                    self.dev.stream)
+        if tiled_row:
+            libhip.call("ddh_fft_set_coeff_tiled", h, int(tiled_row))
+        try:
+            libhip.call("ddh_cheb_backward_dual", h, ptr(src), ptr(dst), ptr(dst_deriv), ptr(dvec), outer, inner,
+                        self.dev.stream)
+        finally:
+            if tiled_row:
+                libhip.call("ddh_fft_set_coeff_tiled", h, 0)
+
+    def tile_rows(self, src, dst, nrows, nx, ny, to_tiled):
+        """nrows rows of [nx][ny] doubles: natural -> tile-major (to_tiled) or back (ddh_tile_rows), out of place."""
+        libhip.call("ddh_tile_rows", ptr(src), ptr(dst), int(nrows), int(nx), int(ny), 1 if to_tiled else 0, self.dev.stream)
 
     def cfl_max(self, u, ncomp, shape, inv_spacings, comp_axis):
         """max over the grid of sum_c |u_c| / dx_c; inv_spacings: device arrays per component."""

@@ -114,6 +114,12 @@ class PencilPack:
 
     supports_tiled_rhs = True
 
+    def set_state_tiled(self, on):
+        """The vector every solve of this pack writes and every mat-vec of it reads (the solver's state X) is tile-major
+        from now on (ddh_pencil_set_state_tiled)."""
+        libhip.call("ddh_pencil_set_state_tiled", self.handle, 1 if on else 0)
+        self.state_tiled = bool(on)
+
     def add_upper_bands(self, nz, offsets, bands):
         offs = np.ascontiguousarray(offsets, dtype=np.int32)
         b = np.ascontiguousarray(bands, dtype=np.float64)

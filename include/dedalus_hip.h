@@ -287,6 +287,17 @@ int ddh_scatter_add(double *y, const long *idx_d, const double *vals_d, long n, 
  * (the constant rows of F are then set, not accumulated; core/timesteppers.py:611-614). */
 int ddh_scatter_set(double *y, const long *idx_d, const double *vals_d, long n, void *stream);
 
+/* Round 6: the STATE vector of a pack kept tile-major.  The reference keeps one layout for every system vector
+ * (core/subsystems.py:497-596 gather / scatter into per-pencil vectors; core/timesteppers.py:588-643); here the state X --
+ * written by every solve, read by every mat-vec and by the backward z transforms -- may be stored like the right-hand-side
+ * vectors, [kx / 8][ky / 8][kx % 8][ky % 8] within a row, so that a wavefront's stores of a solution row are two 512-byte
+ * runs.  ddh_pencil_set_state_tiled switches the solves' output / the mat-vecs' input of a pack, ddh_fft_set_coeff_tiled
+ * the coefficient side of a Chebyshev plan's next strided transforms, ddh_tile_rows converts rows between the layouts
+ * (user access to a state field, output, generic operators). */
+int ddh_pencil_set_state_tiled(ddh_handle pack, int on);
+int ddh_fft_set_coeff_tiled(ddh_handle plan, long row_len);
+int ddh_tile_rows(const double *src, double *dst, long nrows, long nx, long ny, int to_tiled, void *stream);
+
 /* y = sum_t alpha[t] * x_t  (RHS assembly timesteppers.py:617-623 / :156-166; BLAS axpy chain).
  * xs_h: host array of nterms device pointers; y may alias one of them only if it is xs_h[0].   */
 int ddh_lincomb(double *y, int nterms, const double *const *xs_h, const double *alpha_h,

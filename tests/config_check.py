@@ -43,7 +43,7 @@ def internal_tags(solver, make_eq_field, place):
         saved.append(c)
         v['c'] = _tags(i, c.shape)
     solver.sync_state_to_device()
-    Tin = np.array(ex.download(solver.X))
+    Tin = np.array(ex.download(solver.state_natural() if hasattr(solver, "state_natural") else solver.X))
     for v, c in zip(solver.variables, saved):
         v['c'] = c
     solver.sync_state_to_device()

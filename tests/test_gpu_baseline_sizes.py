@@ -240,8 +240,8 @@ def test_rb3d_end_state_through_the_headline_kernels(shape, monkeypatch):
       16 x 512 x 256   the second-generation fused y stage (768-point lines, LDS-DMA operands) + the same z kernels
       512 x 16 x 256   real FFT 768 <- 512 wave kernels (plain, dual, forward) + x-blocked stage + the same z kernels
     The per-thread sweeps are forced (`set_solve_variant(0)`: these sizes have few pencils and would take the cooperative
-    sweeps) and the tile-major right-hand sides are allowed below their size threshold, so that what runs is what the
-    512 x 512 x 256 benchmark runs.  Tolerances: rel-L2 1e-10 (b, p), 1e-9 (u) on the sampled arrays."""
+    sweeps) and the tile-major right-hand sides and state vector are allowed below their size threshold, so that what runs
+    is what the 512 x 512 x 256 benchmark runs.  Tolerances: rel-L2 1e-10 (b, p), 1e-9 (u) on the sampled arrays."""
     import os
     import dedalus_amd.public as d3
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_rb3d_endstate_%dx%dx%d.npz" % shape)
@@ -250,9 +250,10 @@ def test_rb3d_end_state_through_the_headline_kernels(shape, monkeypatch):
     G = np.load(path)
     monkeypatch.setenv("DDH_RHS_TILING_MIN", "0")
     monkeypatch.setenv("DDH_PAIR_MIN", "0")              # partner pencils below their default size threshold (65 536 systems)
+    monkeypatch.setenv("DDH_X_TILED_MIN", "0")           # the state vector tile-major, as at the benchmark's size
     Nx, Ny, Nz = shape
     solver, f = problems.rayleigh_benard_3d(d3, Nx=Nx, Ny=Ny, Nz=Nz, timestepper="RK222")
-    assert solver.ex.name == "hip"
+    assert solver.ex.name == "hip" and solver.x_tiled == Ny
     solver.pack.set_solve_variant(0)
     w0 = _wave_launches()
     for _ in range(int(G["steps"])):
