@@ -36,6 +36,7 @@ class SystemBuffer:
     def __init__(self, array, nrows):
         self.array, self.nrows = array, nrows
         self.tiled = 0
+        self.banded = 0             # rows of the whole vector when it is kx-band-major: [kx / 8][rows][ky / 8][8][8]
         self.ranges = []            # (row0, rows) of the variables
         self.valid = {}             # row0 -> the natural shadow of that variable's rows is current
         self._nat = None
@@ -54,14 +55,23 @@ class SystemBuffer:
         nat = self._shadow(ex)
         if current and not self.valid.get(row0, False):
             _, nx, ny = self.array.shape
-            ex.tile_rows(self.array[row0:row0 + rows], nat[row0:row0 + rows], rows, nx, ny, False)
+            ex.tile_rows(self.state_rows(row0, rows), nat[row0:row0 + rows], rows, nx, ny, False, self.banded)
             self.valid[row0] = True
         return nat[row0:row0 + rows]
+
+    def state_rows(self, row0, rows):
+        """Rows row0 .. row0 + rows of the state as it is stored: a view whose first element is the block's first (for a
+        kx-band-major state a strided one, [rows][kx / 8][8 ny]: kernels take its address, nothing reshapes it)."""
+        if not self.banded:
+            return self.array[row0:row0 + rows]
+        R, nx, ny = self.array.shape
+        return self.array.as_strided((rows, nx // 8, 8 * ny), (8 * ny, R * 8 * ny, 1),
+                                     self.array.storage_offset() + row0 * 8 * ny)
 
     def commit_rows(self, ex, row0, rows):
         """The natural shadow of these rows was written: into the tiled state with it."""
         _, nx, ny = self.array.shape
-        ex.tile_rows(self._shadow(ex)[row0:row0 + rows], self.array[row0:row0 + rows], rows, nx, ny, True)
+        ex.tile_rows(self._shadow(ex)[row0:row0 + rows], self.state_rows(row0, rows), rows, nx, ny, True, self.banded)
         self.valid[row0] = True
 
     def natural(self, ex):
@@ -377,8 +387,8 @@ class Evaluator:
         tr = self.dist.transformer
         if getattr(leaf, "_tiled", None) is not None and hasattr(tr, "coeff_tiled_ok") \
                 and tr.coeff_tiled_ok(leaf.domain, leaf.domain.dealias, int(leaf._tiled.tiled)):
-            c, ctile = leaf.coeff_tiled()
-            return c.reshape((leaf.ncomp,) + tuple(leaf.domain.storage_coeff_shape())), ctile
+            c, ctile = leaf.coeff_tiled()              # (handed on as it lies: the transforms take its address)
+            return c, ((ctile, int(leaf._tiled.banded)) if leaf._tiled.banded else ctile)
         return self.eval_stage(leaf, 0), 0
 
     def eval_pregrid(self, expr):

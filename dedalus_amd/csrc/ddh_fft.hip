@@ -1486,14 +1486,18 @@ int ddh_fft_set_stage_block(ddh_handle plan, int rows) {
 
 /* The coefficient-side array of this Chebyshev plan's following STRIDED-axis transforms (both directions) has rows
  * [nx][ny = row_len] stored tile-major ([kx / 8][ky / 8][kx % 8][ky % 8]: the state vector of a pack with
- * ddh_pencil_set_state_tiled); row_len = 0: natural again.  Like the stage layout it is a property of the next launches, set
+ * ddh_pencil_set_state_tiled); row_len = 0: natural again.  band_rows != 0: the array is a block of rows of a kx-band-major
+ * state vector of band_rows rows, [kx / 8][band_rows][ky / 8][8][8], and the pointer handed to the transform is that of the
+ * block's first row in band 0 (state + row0 * 8 * row_len).  Like the stage layout it is a property of the next launches, set
  * by the caller before each of them; transforms that cannot take the wave kernels fail instead of reading another layout. */
-int ddh_fft_set_coeff_tiled(ddh_handle plan, long row_len) {
+int ddh_fft_set_coeff_tiled(ddh_handle plan, long row_len, long band_rows) {
     FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
     if (!pl) return -1;
     if (pl->tkind != K_CHEB) return fail("ddh_fft_set_coeff_tiled: Chebyshev plans");
     if (row_len < 0 || (row_len & 7) || row_len > 0x7fffffffL) return fail("ddh_fft_set_coeff_tiled: row_len a multiple of 8");
+    if (band_rows < 0 || (band_rows && !row_len)) return fail("ddh_fft_set_coeff_tiled: band_rows needs row_len");
     pl->dev.ctile_nseg = (unsigned)(row_len / 8);
+    pl->dev.cband = (unsigned long)band_rows * 8UL * (unsigned long)row_len;
     return 0;
 }
 
@@ -1506,9 +1510,12 @@ int ddh_cheb_forward_tiled(ddh_handle plan, const double *g, double *c, long out
     if (g == c) return fail("ddh_cheb_forward_tiled: in-place unsupported");
     if (outer <= 0 || inner <= 0) return 0;
     const unsigned saved = pl->dev.ctile_nseg;
+    const unsigned long saved_band = pl->dev.cband;
     pl->dev.ctile_nseg = (unsigned)(row_len / 8);
+    pl->dev.cband = 0;
     const int st = launch<CHEB_FWD>(pl, g, c, outer, inner, stream);
     pl->dev.ctile_nseg = saved;
+    pl->dev.cband = saved_band;
     return st;
 }
 DDH_FFT_ENTRY(ddh_cheb_backward, K_CHEB, CHEB_BWD)

@@ -63,6 +63,9 @@ struct FftDev {
     unsigned xb;                // != 0: x-blocked stage layout on the INTERMEDIATE side of a strided wave transform
     unsigned xbB;               // rows per block of that layout on the coefficient side of a real-Fourier transform (0 = 64)
                                 // (ddh_fft_set_stage_layout): Chebyshev plans: row length ny; real-FFT plans: z planes gz
+    unsigned long cband;        // != 0 (with ctile_nseg): the tile-major coefficient rows are kx-band-major, [kx / 8][row][ky / 8][8][8]:
+                                // cband = doubles between the bands of 8 storage rows (all rows of the state vector x 8 ny);
+                                // the rows of a line are then 8 ny doubles apart (ddh_fft_set_coeff_tiled)
     unsigned ctile_nseg;        // != 0: the coefficient rows [nx][ny] are written tile-major, ctile_nseg = ny / 8 64-byte
                                 // segments per storage row (ddh_cheb_forward_tiled; wave kernel only)
 };

@@ -71,7 +71,8 @@ wave_cheb_kernel(FftDev p, WaveArgs a) {
     const wf::Lane L = wf::make_lane(lane);
     const unsigned g = xcd_swizzle(blockIdx.x, gridDim.x);
     const long inner = a.inner;
-    const unsigned rsb = (unsigned)(inner * 8);                       // bytes between coefficient rows
+    // bytes between coefficient rows (kx-band-major state vector: 8 ny doubles)
+    const unsigned rsb = (p.ctile_nseg && p.cband) ? (unsigned)(p.ctile_nseg * 512u) : (unsigned)(inner * 8);
     // grid side (the stage array between the z and the x transforms): natural [z][kx][ky], or x-blocked
     // [kx / 64][z][kx % 64][ky] (p.xb = ny): rows 64 ny doubles apart (256 KiB at ny = 512, not one 2 MiB page per row)
     const unsigned rsg = p.xb ? (unsigned)(64u * p.xb * 8u) : rsb;
@@ -87,6 +88,10 @@ wave_cheb_kernel(FftDev p, WaveArgs a) {
         }
         const long pair0 = 4L * tb;
         off_c = ((long)o * M) * inner + 8 * seg;
+        if (p.ctile_nseg && p.cband) {       // ... kx-band-major: [kx / 8][row][ky / 8][kx % 8]
+            const unsigned kxrow = tb / p.ctile_nseg, sg = tb - kxrow * p.ctile_nseg;
+            off_c = ((long)o * M) * (64L * p.ctile_nseg) + (long)(kxrow >> 3) * (long)p.cband + 64L * sg + 8L * (kxrow & 7);
+        }
         off_g = ((long)o * N) * inner + 2 * pair0;
         if (p.xb) {
             const unsigned nsg = p.xb >> 3, kxrow = tb / nsg, sg = tb - kxrow * nsg;

@@ -320,32 +320,36 @@ __global__ void scatter_set_kernel(double *__restrict__ y, const long *__restric
 // rows of [nx][ny] doubles <-> the tile-major layout [nx / 8][ny / 8][8][8] of the solver's system vectors (ddh_pencil.hip:
 // tile_offset); one 16-byte word per thread, the tiled side accessed linearly
 __global__ void __launch_bounds__(256)
-tile_rows_kernel(const double *__restrict__ src, double *__restrict__ dst, long nrows, long nx, long ny, int to_tiled) {
+tile_rows_kernel(const double *__restrict__ src, double *__restrict__ dst, long nrows, long nx, long ny, int to_tiled,
+                 long band_rows) {
     const long plane2 = nx * ny / 2;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrows * plane2) return;
     const long row = i / plane2, o = 2 * (i - row * plane2);
     const long tile = o >> 6, in = o & 63, tpr = ny >> 3;
-    const long nat = ((tile / tpr) * 8 + (in >> 3)) * ny + (tile % tpr) * 8 + (in & 7);
-    const double *s = src + row * nx * ny;
-    double *d = dst + row * nx * ny;
-    if (to_tiled) *reinterpret_cast<double2 *>(d + o) = *reinterpret_cast<const double2 *>(s + nat);
-    else *reinterpret_cast<double2 *>(d + nat) = *reinterpret_cast<const double2 *>(s + o);
+    const long nat = row * nx * ny + ((tile / tpr) * 8 + (in >> 3)) * ny + (tile % tpr) * 8 + (in & 7);
+    // tiled side: rows one after the other, or (band_rows) the rows of a kx band together: [kx / 8][band_rows][ky / 8][8][8]
+    const long til = band_rows ? ((tile / tpr) * band_rows + row) * (8 * ny) + ((tile % tpr) << 6) + in : row * nx * ny + o;
+    if (to_tiled) *reinterpret_cast<double2 *>(dst + til) = *reinterpret_cast<const double2 *>(src + nat);
+    else *reinterpret_cast<double2 *>(dst + nat) = *reinterpret_cast<const double2 *>(src + til);
 }
 
 extern "C" {
 
 /* nrows rows of [nx][ny] doubles between the natural layout and the tile-major layout of the solver's system vectors
  * ([kx / 8][ky / 8][kx % 8][ky % 8] within a row; ddh_pencil_set_state_tiled, ddh_pencil_solve_recombined_tiled): to_tiled = 1
- * natural -> tiled, 0 tiled -> natural.  Out of place; nx and ny multiples of 8.  The host layer uses it where a state
+ * natural -> tiled, 0 tiled -> natural.  Out of place; nx and ny multiples of 8.  band_rows != 0: the tiled side is a block
+ * of nrows rows of a kx-band-major vector of band_rows rows ([kx / 8][band_rows][ky / 8][8][8]; its pointer = that of the
+ * block's first row in band 0), the natural side the nrows rows [nrows][nx][ny].  The host layer uses it where a state
  * field kept tile-major by the solver is read or written in the natural order (user access, output, generic operators). */
-int ddh_tile_rows(const double *src, double *dst, long nrows, long nx, long ny, int to_tiled, void *stream) {
+int ddh_tile_rows(const double *src, double *dst, long nrows, long nx, long ny, int to_tiled, long band_rows, void *stream) {
     if (nrows <= 0) return 0;
+    if (band_rows < 0) return fail("ddh_tile_rows: band_rows >= 0");
     if (nx < 8 || ny < 8 || (nx & 7) || (ny & 7)) return fail("ddh_tile_rows: nx and ny multiples of 8");
     if (src == dst) return fail("ddh_tile_rows: in-place unsupported");
     const long n = nrows * nx * ny / 2;
     hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), src, dst, nrows,
-                       nx, ny, to_tiled);
+                       nx, ny, to_tiled, band_rows);
     DDH_HIP(hipGetLastError());
     return 0;
 }

@@ -48,8 +48,10 @@ struct PencilDev {
     long G;         // systems = ncells * S
     long mx_offset; // global x mode index of the first local cell (pencils sharded over ranks)
     const double *kx, *ky;
-    int xtile;      // 1: the STATE vector X -- the solution every solve writes, the input of every mat-vec -- is stored
-                    // tile-major (tile_offset) like the right-hand-side vectors: ddh_pencil_set_state_tiled
+    int xtile;      // the STATE vector X -- the solution every solve writes, the input of every mat-vec -- (state_cell,
+                    // state_row_stride; ddh_pencil_set_state_tiled): 0 natural [row][kx][ky]; 1 rows tile-major
+                    // [row][kx/8][ky/8][8][8] like the right-hand-side vectors; 2 kx-band-major [kx/8][row][ky/8][8][8]
+                    // (rows of a pencil 8 ny doubles apart instead of one nx ny plane)
 };
 
 struct MatDev {
@@ -421,6 +423,15 @@ __device__ __forceinline__ long tile_offset(long kxrow, long ky, long ny) {
     return (((kxrow >> 3) * (ny >> 3) + (ky >> 3)) << 6) + ((kxrow & 7) << 3) + (ky & 7);
 }
 
+// Element (row, storage row kxrow, ky) of a STATE vector (PencilDev::xtile) lies at row * state_row_stride + state_cell.
+__device__ __forceinline__ long state_row_stride(const PencilDev &P) {
+    return P.xtile == 2 ? 8 * P.ny : P.nx * P.ny;
+}
+__device__ __forceinline__ long state_cell(const PencilDev &P, long kxrow, long ky) {
+    if (P.xtile == 2) return (kxrow >> 3) * ((long)P.nrows * 8 * P.ny) + ((ky >> 3) << 6) + ((kxrow & 7) << 3) + (ky & 7);
+    return P.xtile ? tile_offset(kxrow, ky, P.ny) : kxrow * P.ny + ky;
+}
+
 // ------------------------------------------------------------------------------------------------
 // y = A x for every cell (apply_sparse over all pencils; M.X and L.X of timesteppers.py:588-604)
 // ------------------------------------------------------------------------------------------------
@@ -436,8 +447,8 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
     if (NF == 2) {
         off0 = (2 * c.mx) * P.ny + 2 * c.my;
         off1 = off0 + P.ny;
-        xoff0 = P.xtile ? tile_offset(2 * c.mx, 2 * c.my, P.ny) : off0;
-        xoff1 = P.xtile ? tile_offset(2 * c.mx + 1, 2 * c.my, P.ny) : off1;
+        xoff0 = state_cell(P, 2 * c.mx, 2 * c.my);
+        xoff1 = state_cell(P, 2 * c.mx + 1, 2 * c.my);
     } else if (NF == 1) {
         off0 = xoff0 = 2 * c.mx;
     } else {
@@ -466,7 +477,7 @@ matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *y, Po
             const double f = term_factor(e, c);
             const double2 cf = A.coef[t];
             const double2 v = make_double2(cf.x * f, cf.y * f);
-            const double *xr = x + (long)A.col[t] * plane;
+            const double *xr = x + (long)A.col[t] * (NF == 2 ? state_row_stride(P) : plane);
             if (NF == 2) {
                 const double2 a = *reinterpret_cast<const double2 *>(xr + xoff0);   // cc, cs
                 const double2 b = *reinterpret_cast<const double2 *>(xr + xoff1);   // sc, ss
@@ -550,8 +561,8 @@ band_matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *
     }
     const CellCtx c = cell_ctx(P, cell);
     const long plane = P.nx * P.ny;
-    const long off0 = P.xtile ? tile_offset(2 * c.mx, 2 * c.my, P.ny) : (2 * c.mx) * P.ny + 2 * c.my;
-    const long off1 = P.xtile ? tile_offset(2 * c.mx + 1, 2 * c.my, P.ny) : off0 + P.ny;
+    const long off0 = state_cell(P, 2 * c.mx, 2 * c.my), off1 = state_cell(P, 2 * c.mx + 1, 2 * c.my);
+    const long xrs = state_row_stride(P);
     // (y tile-major: ddh_pencil_matvec_update_tiled)
     const long yoff0 = out_tiled ? tile_offset(2 * c.mx, 2 * c.my, P.ny) : (2 * c.mx) * P.ny + 2 * c.my;
     const long yoff1 = out_tiled ? tile_offset(2 * c.mx + 1, 2 * c.my, P.ny) : (2 * c.mx + 1) * P.ny + 2 * c.my;
@@ -563,7 +574,7 @@ band_matvec_kernel(PencilDev P, MatDev A, const double *__restrict__ x, double *
     int wbase = -(1 << 30);
     const int ncol = P.nrows;
     auto load_row = [&](int col, double2 &a, double2 &b) {
-        const double *xr = x + (long)(col < ncol ? col : ncol - 1) * plane;      // (slots beyond the last row: zero coefficient)
+        const double *xr = x + (long)(col < ncol ? col : ncol - 1) * xrs;        // (slots beyond the last row: zero coefficient)
         a = *reinterpret_cast<const double2 *>(xr + off0);
         b = *reinterpret_cast<const double2 *>(xr + off1);
     };
@@ -783,7 +794,7 @@ __device__ __forceinline__ double2 load_sys(const RhsSrc &r, long plane, int row
 template <int NF, int XD = 1>
 __device__ __forceinline__ void store_sys(double *__restrict__ v, long plane, int row, const PencilDev &P,
                                           const CellCtx &c, int s, double2 val, bool writer = true) {
-    double *vr = v + (long)row * plane;
+    double *vr = v + (long)row * (NF == 2 ? state_row_stride(P) : plane);
     if (NF == 2) {
         double2 other;
         other.x = __shfl_xor(val.x, XD);
@@ -795,8 +806,7 @@ __device__ __forceinline__ void store_sys(double *__restrict__ v, long plane, in
         // independently, which would leave round-off there: write exact zeros.
         if (c.my == 0) out.y = 0.0;
         if (c.gmx == 0 && s == 1) out = make_double2(0.0, 0.0);
-        if (writer) *reinterpret_cast<double2 *>(vr + (P.xtile ? tile_offset(2 * c.mx + s, 2 * c.my, P.ny)
-                                                                : (2 * c.mx + s) * P.ny + 2 * c.my)) = out;
+        if (writer) *reinterpret_cast<double2 *>(vr + state_cell(P, 2 * c.mx + s, 2 * c.my)) = out;
     } else if (NF == 1) {
         if (c.gmx == 0) val.y = 0.0;
         if (writer) *reinterpret_cast<double2 *>(vr + 2 * c.mx) = val;
@@ -3643,7 +3653,8 @@ int ddh_pencil_set_state_tiled(ddh_handle pack, int on) {
     if (!pp) return -1;
     if (on && (pp->dev.nf != 2 || (pp->dev.nx & 7) || (pp->dev.ny & 7)))
         return fail("pencil_set_state_tiled: two Fourier axes with storage sizes that are multiples of 8");
-    pp->dev.xtile = on ? 1 : 0;
+    if (on < 0 || on > 2) return fail("pencil_set_state_tiled: 0 natural, 1 tile-major rows, 2 kx-band-major");
+    pp->dev.xtile = on;
     return 0;
 }
 
@@ -4206,6 +4217,7 @@ static int solve_recombined_impl(ddh_handle pack, int lu_id, int nterms, const d
     PostSolve none;
     memset(&none, 0, sizeof(none));
     // (a tile-major state, ddh_pencil_set_state_tiled: `work` was written tile-major by the sweeps, and x must be too)
+    if (pp->dev.xtile == 2) return fail("pencil_solve_recombined: a kx-band-major state needs the fused recombination");
     return launch_matvec(pp, p_mat_id, work, x, none, stream, 0, pp->dev.xtile);
 }
 

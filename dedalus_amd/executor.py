@@ -232,13 +232,16 @@ class HipExecutor:
             if kind != "cheb" or deriv:
                 raise NotImplementedError("tile-major coefficient rows: Chebyshev transforms only")
             if direction == "forward":
+                if isinstance(tiled_row, tuple):
+                    raise NotImplementedError("kx-band-major rows: backward transforms of the state only")
                 libhip.call("ddh_cheb_forward_tiled", h, ptr(src), ptr(dst), outer, inner, int(tiled_row), self.dev.stream)
                 return
-            libhip.call("ddh_fft_set_coeff_tiled", h, int(tiled_row))
+            row_len, band = tiled_row if isinstance(tiled_row, tuple) else (tiled_row, 0)
+            libhip.call("ddh_fft_set_coeff_tiled", h, int(row_len), int(band))
             try:
                 libhip.call("ddh_cheb_backward", h, ptr(src), ptr(dst), outer, inner, self.dev.stream)
             finally:
-                libhip.call("ddh_fft_set_coeff_tiled", h, 0)
+                libhip.call("ddh_fft_set_coeff_tiled", h, 0, 0)
             return
         if deriv:
             if kind != "rfft" or direction != "backward":
@@ -271,7 +274,8 @@ class HipExecutor:
     def transform_dual_z(self, spec, basis, src, dst, dst_deriv, dvec, outer, inner, xb=0, tiled_row=0):
         """dst = backward Chebyshev transform of src (the family's own basis), dst_deriv = backward transform, in `basis`
         (the derivative's basis), of the one-superdiagonal operator dvec applied to src (ddh_cheb_backward_dual).
-        tiled_row: the rows of src ([nx][tiled_row]) are tile-major (a state field of a solver with a tile-major state)."""
+        tiled_row: the rows of src ([nx][tiled_row]) are tile-major (a state field of a solver with a tile-major state);
+        (row length, rows of the state vector): kx-band-major."""
         if self.timer is not None:
             nb = (src.numel() + dst.numel() + dst_deriv.numel()) * 8
             return self.timer.run("cheb_backward_%s_dual" % ("strided" if inner > 1 else "contig"), nb,
@@ -285,17 +289,20 @@ class HipExecutor:
         if inner > 1:
             self._stage_layout(h, xb)
         if tiled_row:
-            libhip.call("ddh_fft_set_coeff_tiled", h, int(tiled_row))
+            row_len, band = tiled_row if isinstance(tiled_row, tuple) else (tiled_row, 0)
+            libhip.call("ddh_fft_set_coeff_tiled", h, int(row_len), int(band))
         try:
             libhip.call("ddh_cheb_backward_dual", h, ptr(src), ptr(dst), ptr(dst_deriv), ptr(dvec), outer, inner,
                         self.dev.stream)
         finally:
             if tiled_row:
-                libhip.call("ddh_fft_set_coeff_tiled", h, 0)
+                libhip.call("ddh_fft_set_coeff_tiled", h, 0, 0)
 
-    def tile_rows(self, src, dst, nrows, nx, ny, to_tiled):
-        """nrows rows of [nx][ny] doubles: natural -> tile-major (to_tiled) or back (ddh_tile_rows), out of place."""
-        libhip.call("ddh_tile_rows", ptr(src), ptr(dst), int(nrows), int(nx), int(ny), 1 if to_tiled else 0, self.dev.stream)
+    def tile_rows(self, src, dst, nrows, nx, ny, to_tiled, band_rows=0):
+        """nrows rows of [nx][ny] doubles: natural -> tile-major (to_tiled) or back (ddh_tile_rows), out of place.
+        band_rows: the tiled side is a block of rows of a kx-band-major vector of that many rows (its first row in band 0)."""
+        libhip.call("ddh_tile_rows", ptr(src), ptr(dst), int(nrows), int(nx), int(ny), 1 if to_tiled else 0, int(band_rows),
+                    self.dev.stream)
 
     def cfl_max(self, u, ncomp, shape, inv_spacings, comp_axis):
         """max over the grid of sum_c |u_c| / dx_c; inv_spacings: device arrays per component."""

@@ -53,8 +53,8 @@ SIGNATURES = {
     "ddh_scatter_add": [_vp, _vp, _vp, _l, _vp],
     "ddh_scatter_set": [_vp, _vp, _vp, _l, _vp],
     "ddh_pencil_set_state_tiled": [_h, _i],
-    "ddh_fft_set_coeff_tiled": [_h, _l],
-    "ddh_tile_rows": [_vp, _vp, _l, _l, _l, _i, _vp],
+    "ddh_fft_set_coeff_tiled": [_h, _l, _l],
+    "ddh_tile_rows": [_vp, _vp, _l, _l, _l, _i, _l, _vp],
     "ddh_plan_grouped_mmt": [_hp, _i, _i, _vp, _i, _ip, C.POINTER(_vp), C.POINTER(_vp)],
     "ddh_grouped_mmt_set_pairs": [_h, _i, _ip, _ip, _ip, _ip],
     "ddh_grouped_mmt_forward": [_h, _vp, _vp, _l, _l, _l, _l, _l, _vp],

@@ -117,8 +117,8 @@ class PencilPack:
     def set_state_tiled(self, on):
         """The vector every solve of this pack writes and every mat-vec of it reads (the solver's state X) is tile-major
         from now on (ddh_pencil_set_state_tiled)."""
-        libhip.call("ddh_pencil_set_state_tiled", self.handle, 1 if on else 0)
-        self.state_tiled = bool(on)
+        libhip.call("ddh_pencil_set_state_tiled", self.handle, int(on))      # 0 natural, 1 tile-major rows, 2 kx-band-major
+        self.state_tiled = int(on)
 
     def add_upper_bands(self, nz, offsets, bands):
         offs = np.ascontiguousarray(offsets, dtype=np.int32)

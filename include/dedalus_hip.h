@@ -293,10 +293,12 @@ int ddh_scatter_set(double *y, const long *idx_d, const double *vals_d, long n, 
  * vectors, [kx / 8][ky / 8][kx % 8][ky % 8] within a row, so that a wavefront's stores of a solution row are two 512-byte
  * runs.  ddh_pencil_set_state_tiled switches the solves' output / the mat-vecs' input of a pack, ddh_fft_set_coeff_tiled
  * the coefficient side of a Chebyshev plan's next strided transforms, ddh_tile_rows converts rows between the layouts
- * (user access to a state field, output, generic operators). */
-int ddh_pencil_set_state_tiled(ddh_handle pack, int on);
-int ddh_fft_set_coeff_tiled(ddh_handle plan, long row_len);
-int ddh_tile_rows(const double *src, double *dst, long nrows, long nx, long ny, int to_tiled, void *stream);
+ * (user access to a state field, output, generic operators).  Mode 2 / band_rows = R goes one step further: the rows of
+ * a band of 8 storage rows together, [kx / 8][R][ky / 8][kx % 8][ky % 8] -- the rows of a pencil are 8 ny doubles apart
+ * instead of one nx x ny plane (32 KiB instead of 2 MiB at 512 x 512), for the sweeps' stores and the z transforms' loads. */
+int ddh_pencil_set_state_tiled(ddh_handle pack, int on);     /* 0 natural, 1 tile-major rows, 2 kx-band-major (below) */
+int ddh_fft_set_coeff_tiled(ddh_handle plan, long row_len, long band_rows);
+int ddh_tile_rows(const double *src, double *dst, long nrows, long nx, long ny, int to_tiled, long band_rows, void *stream);
 
 /* y = sum_t alpha[t] * x_t  (RHS assembly timesteppers.py:617-623 / :156-166; BLAS axpy chain).
  * xs_h: host array of nterms device pointers; y may alias one of them only if it is xs_h[0].   */

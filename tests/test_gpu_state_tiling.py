@@ -20,6 +20,12 @@ def _tile(a):
     return np.ascontiguousarray(a.reshape(R, nx // 8, 8, ny // 8, 8).transpose(0, 1, 3, 2, 4)).reshape(R, nx, ny)
 
 
+def _band(a):
+    """natural [R][nx][ny] -> kx-band-major [nx/8][R][ny/8][8][8] (flattened back to [R][nx][ny])"""
+    R, nx, ny = a.shape
+    return np.ascontiguousarray(a.reshape(R, nx // 8, 8, ny // 8, 8).transpose(1, 0, 3, 2, 4)).reshape(R, nx, ny)
+
+
 @pytest.mark.parametrize("shape", [(3, 8, 8), (5, 64, 40), (2, 256, 512)])
 def test_tile_rows_is_the_documented_permutation_both_ways(shape):
     from dedalus_amd.device import Device
@@ -34,10 +40,22 @@ def test_tile_rows_is_the_documented_permutation_both_ways(shape):
     assert np.array_equal(td.cpu().numpy(), _tile(a))
     ex.tile_rows(td, bd, R, nx, ny, False)
     assert np.array_equal(bd.cpu().numpy(), a)
+    # kx-band-major: a block of rows of a vector of R + 3 rows, starting at row 2
+    Rt = R + 3
+    full = np.random.default_rng(2).standard_normal((Rt, nx, ny))
+    fd = dev.from_host(_band(full))
+    base = fd.reshape(-1)[2 * 8 * ny:]
+    ex.tile_rows(ad, base, R, nx, ny, True, Rt)
+    full[2:2 + R] = a
+    assert np.array_equal(fd.cpu().numpy(), _band(full))
+    bd.zero_()
+    ex.tile_rows(base, bd, R, nx, ny, False, Rt)
+    assert np.array_equal(bd.cpu().numpy(), a)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("noband", [False, True])
-def test_mat_vec_reads_a_tile_major_state_bit_for_bit(monkeypatch, noband):
+def test_mat_vec_reads_a_tile_major_state_bit_for_bit(monkeypatch, noband, mode):
     """x tile-major (ddh_pencil_set_state_tiled) with y natural / y tile-major (threads following the tiles), window-form and
     term-list kernels: the values of the natural run, at the tiled addresses."""
     from dedalus_amd.device import Device
@@ -59,11 +77,11 @@ def test_mat_vec_reads_a_tile_major_state_bit_for_bit(monkeypatch, noband):
         monkeypatch.setenv("DDH_MV_NOBAND", "1")
     mid = pack.add_matrix(M)
     x = rng.standard_normal((N, nx, ny))
-    xn, xt = dev.from_host(x), dev.from_host(_tile(x))
+    xn, xt = dev.from_host(x), dev.from_host(_tile(x) if mode == 1 else _band(x))
     y_nat = dev.zeros((N, nx, ny))
     pack.matvec(mid, xn, y_nat)
     want = y_nat.cpu().numpy()
-    pack.set_state_tiled(True)
+    pack.set_state_tiled(mode)
     try:
         y1 = dev.zeros((N, nx, ny))
         pack.matvec(mid, xt, y1)                                    # x tiled, y natural
@@ -113,15 +131,16 @@ def _run(size, ts, env):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("size,ts", [((256, 256, 64), "RK222"), ((64, 48, 32), "RK443"), ((128, 128, 64), "SBDF2")])
-def test_tile_major_state_changes_addresses_not_values(size, ts):
-    """3-D Rayleigh-Benard stepped with the state vector tile-major (the default from 65 536 storage entries per row on;
-    forced here) and natural (DDH_X_TILED=0), with a grid-space read and a coefficient-space rewrite of state fields between
+@pytest.mark.parametrize("size,ts,mode", [((256, 256, 64), "RK222", "1"), ((64, 48, 32), "RK443", "1"), ((128, 128, 64), "SBDF2", "1"),
+                                          ((256, 256, 64), "RK222", "2")])
+def test_tile_major_state_changes_addresses_not_values(size, ts, mode):
+    """3-D Rayleigh-Benard stepped with the state vector stored with tile-major rows (mode 1: the default from 65 536 storage
+    entries per row on; forced here) or kx-band-major (mode 2, opt-in) and natural (DDH_X_TILED=0), with a grid-space read and a coefficient-space rewrite of state fields between
     the steps: the same end state bit for bit -- fields, the un-aliased tau variable, the whole state vector -- also with the
     right-hand sides natural (DDH_NO_RHS_TILING: tile-major x, natural y in the mat-vec)."""
-    a = _run(size, ts, {})
+    a = _run(size, ts, {"DDH_X_TILED": mode})
     b = _run(size, ts, {"DDH_X_TILED": "0"})
-    c = _run(size, ts, {"DDH_NO_RHS_TILING": "1"})
+    c = _run(size, ts, {"DDH_X_TILED": mode, "DDH_NO_RHS_TILING": "1"})
     assert a["x_tiled"] == size[1] and b["x_tiled"] == 0 and c["x_tiled"] == size[1]
     for k in a:
         if k != "x_tiled":

@@ -84,11 +84,11 @@ PY
                   echo "P=$P $v"; env $v python tools/rank_emulation.py --ranks $P --rank 1 --steps 10 --warmup 8 --link-gbps 75 2>&1 >/dev/null | cut -c1-120; done; done 2>&1 | tee $OUT/emu_defer_ab.txt ;;
     xtiled)     # tile-major state vector: bench A/B with the parity probe, then the suites that step problems with it forced on
                 python tools/gpu/xtile_diag.py
-                for v in "0" "1" "1 DDH_CTILE_PERM=1" "0" "1" "1 DDH_CTILE_PERM=1"; do env DDH_X_TILED=$v python bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-cfl > $OUT/bench_xtiled.json 2> $OUT/bench_xtiled.err
+                for v in "0" "1" "2" "0" "1" "2"; do env DDH_X_TILED=$v python bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-cfl > $OUT/bench_xtiled.json 2> $OUT/bench_xtiled.err
                   echo "DDH_X_TILED=$v"; bench_line $OUT/bench_xtiled.json | cut -c1-400
                   python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print('   parity', {k: d['parity'][k] for k in ('max_residual', 'max_solution_error')})" $OUT/bench_xtiled.json
                 done
-                DDH_X_TILED_MIN=0 DDH_RHS_TILING_MIN=0 python -m pytest tests/test_gpu_ivp.py tests/test_gpu_baseline_sizes.py tests/test_gpu_reference_pencils.py tests/test_gpu_examples.py -x -q -m gpu > $OUT/pytest_xtiled.txt 2>&1; tail -5 $OUT/pytest_xtiled.txt ;;
+                DDH_X_TILED_MIN=0 DDH_RHS_TILING_MIN=0 python -m pytest tests/test_gpu_ivp.py tests/test_gpu_baseline_sizes.py tests/test_gpu_reference_pencils.py tests/test_gpu_examples.py tests/test_gpu_state_tiling.py -x -q -m gpu > $OUT/pytest_xtiled.txt 2>&1; tail -5 $OUT/pytest_xtiled.txt ;;
     bwd-rowmajor) # timing experiment: the backward sweep reading the factor rows as if stored row-major over the blocks
                 for v in 0 128; do DDH_BWD_DBG=$v python bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-cfl --no-parity > $OUT/bench_bwddbg$v.json 2> $OUT/bench_bwddbg$v.err
                   echo "DDH_BWD_DBG=$v"; bench_line $OUT/bench_bwddbg$v.json; done ;;

@@ -25,7 +25,7 @@ if __name__ == "__main__":
         worker(sys.argv[1])
         sys.exit(0)
     res = {}
-    for xt in (0, 1):
+    for xt in (0, 1, 2):
         for rt in (0, 1):
             for perm in (0,):
                 env = dict(os.environ, DDH_X_TILED=str(xt))
