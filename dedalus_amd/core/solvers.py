@@ -81,6 +81,7 @@ class SolverBase:
                 view = self.X[info["row0"]:info["row0"] + info["rows"]].reshape(v._storage_shape("c", None))
                 self.ex.copy(view, old)
                 v._c = view
+                v._tiled, v._nrows = None, 0    # (a field another solver kept tile-major: its data is this solver's now)
                 v._adopted = True
                 v._sysbuf = self.sysbuf
                 v._row0 = info["row0"]
@@ -783,10 +784,16 @@ class SolverBase:
         if self.nx * self.ny < int(os.environ.get("DDH_X_TILED_MIN", 4 * 16384)):
             return False
         sep = self.dist.separable_axes
+        tr = self.dist.transformer
         for info in self.var_info:
             v = info["field"]
             if info["aliased"]:
                 if tuple(v._storage_shape("c", None))[-2:] != (self.nx, self.ny):
+                    return False
+                # a field with a Jacobi axis is an operand of the right-hand side: its backward z transform must read the
+                # tile-major rows in place (the strided wave kernels' sizes), or every evaluation would convert it first
+                has_jacobi = any(v.domain.by_axis[ax] is not None for ax in self.dist._jacobi_axes)
+                if has_jacobi and not tr.coeff_tiled_ok(v.domain, v.domain.dealias, self.ny):
                     return False
             elif any(v.domain.by_axis[ax] is not None for ax in sep):
                 return False                    # (plane copies of a field with one Fourier axis address X naturally)

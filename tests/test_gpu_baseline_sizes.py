@@ -253,7 +253,8 @@ def test_rb3d_end_state_through_the_headline_kernels(shape, monkeypatch):
     monkeypatch.setenv("DDH_X_TILED_MIN", "0")           # the state vector tile-major, as at the benchmark's size
     Nx, Ny, Nz = shape
     solver, f = problems.rayleigh_benard_3d(d3, Nx=Nx, Ny=Ny, Nz=Nz, timestepper="RK222")
-    assert solver.ex.name == "hip" and solver.x_tiled == Ny
+    assert solver.ex.name == "hip"
+    assert solver.x_tiled == (Ny if Nz == 256 else 0)    # (tile-major where the backward z transforms read it in place: 384 <- 256)
     solver.pack.set_solve_variant(0)
     w0 = _wave_launches()
     for _ in range(int(G["steps"])):
