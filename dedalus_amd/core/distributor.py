@@ -237,13 +237,59 @@ class Transformer:
             return None
         return b, spec
 
-    def pregrid_shape(self, domain, ncomp, scales):
-        """[comp][grid...][last axis coefficients]: every axis but the last in grid space (local shape)."""
+    def pregrid_shape(self, domain, ncomp, scales, window=True):
+        """[comp][grid...][last axis coefficients]: every axis but the last in grid space (local shape; window: of the
+        window of z planes being evaluated, when there is one)."""
         shape = [ncomp] + list(domain.storage_grid_shape(scales))
         b = domain.by_axis[self.dist.storage_order[-1]]
         if b is not None:
             shape[-1] = b.coeff_size            # full size: this layout sits on the grid side of the exchange
+        win = self.__dict__.get("_win")
+        if window and win is not None and win["k"] is not None and len(shape) == 4:
+            shape[1] = shape[1] // win["K"]     # a window of this rank's z planes (windows, below)
         return tuple(shape)
+
+    # ---- the grid stage in windows of z planes (several ranks, blocked stage layout) -------------------------------------
+    # Everything between the two pencil transposes -- x backward, fused y stage, x forward: two thirds of a rank's kernels --
+    # is independent from z plane to z plane, and a window of planes of the exchanged layout [p][z_loc][B][ky] is one
+    # contiguous range per peer.  Solver.evaluate_F therefore runs that stage K times on 1 / K of the planes: the z steps of
+    # every field first (their exchanges are REGISTERED here, not started), then all parts of window 0, 1, .. queued on the
+    # communicator's stream (ddh_comm_alltoall_part), then per window the x steps -- each waits for its own parts only --,
+    # the fused launch, and the x forward step, whose window is on the wire while the next window computes.  Exposed wire:
+    # the first window's arrivals and the last window's departures instead of everything (profiles/r6_rank_emulation.txt).
+    def windows_begin(self, K):
+        self._win = dict(K=int(K), k=None, pending=[], works={}, arrays={})
+
+    def windows_end(self):
+        win = self.__dict__.get("_win")
+        if win is not None:
+            for w in win["works"].values():
+                w.wait()
+        self._win = None
+
+    def windows_start_exchanges(self):
+        """Queue the registered backward exchanges window by window (all components of all fields of window 0 first)."""
+        win = self._win
+        P = self.dist.size
+        pc = self.dist.pcomm
+        for k in range(win["K"]):
+            for src, out2, nc, gz, per_plane in win["pending"]:
+                cw = gz // win["K"]
+                # the components of a field as ONE group of sends / receives
+                win["works"][(out2.data_ptr(), k)] = pc.all_to_all_start(
+                    out2.reshape(-1), src.reshape(-1), part=(k * cw * per_plane, cw * per_plane), batch=nc)
+                pc.stats["exchanges"] += nc
+        win["pending"] = []
+
+    def window_set(self, k):
+        self._win["k"] = k
+
+    def _window_of(self, src):
+        """(k, K, works) when src is a stage-1 array exchanged in windows and a window is being evaluated."""
+        win = self.__dict__.get("_win")
+        if win is None or win["k"] is None or src.data_ptr() not in win["arrays"]:
+            return None
+        return win
 
     def nsteps(self, domain, scales):
         return len(self._steps(domain, scales))
@@ -384,7 +430,23 @@ class Transformer:
                 xbv["deriv"] = deriv[1]
             if ctile and i == 0:
                 xbv["tiled_row"] = ctile
-            if exchange and i >= 1 and self._x_step_by_component(src, ncomp):
+            win = self._window_of(src) if (exchange and pos == 1) else None
+            if win is not None:
+                # the x step on ONE window of this rank's planes: component by component (a window of a component is what
+                # a launch can address), each waiting for its own part of the exchange; the result has cw planes
+                _, gz, rows, rest = win["arrays"][src.data_ptr()]
+                cw = gz // win["K"]
+                z0 = win["k"] * cw
+                shape[1] = cw
+                out = ex.empty(tuple(shape))
+                w = win["works"].pop((src.data_ptr(), win["k"]), None)
+                if w is not None:
+                    w.wait()
+                xbv["xb"] = tuple(xbv["xb"]) + (z0, cw)
+                ex.transform(spec, b, "backward", src, out, ncomp * cw, inner, **xbv)
+            elif exchange and pos == 1 and self.__dict__.get("_win") is not None and self._win["k"] is not None:
+                raise RuntimeError("windowed evaluation: an x step on a stage array that was not exchanged in windows")
+            elif exchange and i >= 1 and self._x_step_by_component(src, ncomp):
                 for c in range(ncomp):
                     self.wait_for(src[c:c + 1])
                     ex.transform(spec, b, "backward", src[c:c + 1], out[c:c + 1], outer // ncomp, inner, **xbv)
@@ -445,9 +507,15 @@ class Transformer:
         if blocked:
             # blocked x side (stage_xb, several ranks): a component is sent as it lies and received as [p][Gz / P][nx_loc][..]
             # straight into its slice of the result -- which the x transforms read in that layout: no kernel at all
-            works = []
-            for c in range(nc):
-                works.append(self.dist.pcomm.all_to_all_start(out2[c:c + 1].reshape(-1), src[c:c + 1].reshape(-1)))
+            win = self.__dict__.get("_win")
+            if win is not None and win["k"] is None and dst is None and (Gz // P) % win["K"] == 0:
+                # windows: registered, started window by window once every field's z step is issued
+                win["pending"].append((src, out2, nc, Gz // P, nxl * rest))
+                win["arrays"][out2.data_ptr()] = (out2, Gz // P, nxl, rest)
+                return out2
+            # (the components of a field as ONE group of sends / receives: ddh_comm_alltoall_part with the whole block as part)
+            w = self.dist.pcomm.all_to_all_start(out2.reshape(-1), src.reshape(-1), part=(0, (Gz // P) * nxl * rest), batch=nc)
+            works = [w] * nc
             self.dist.pcomm.stats["exchanges"] += nc
             if os.environ.get("DDH_A2A_DEFER", "1") != "0" and hasattr(out2, "data_ptr"):
                 self._defer(out2, works)                 # waited for by the x step that reads it (wait_for)
@@ -519,6 +587,18 @@ class Transformer:
         out, out_d = ex.empty(tuple(shape)), ex.empty(tuple(shape))
         xb = self.stage_xb(domain, scales) if step == 1 else None
         kw = dict(xb=xb[1]) if xb is not None else {}
+        win = self._window_of(src) if step == 1 else None
+        if win is not None:
+            _, gz, rows, rest = win["arrays"][src.data_ptr()]
+            cw = gz // win["K"]
+            z0 = win["k"] * cw
+            shape[1] = cw
+            out, out_d = ex.empty(tuple(shape)), ex.empty(tuple(shape))
+            w = win["works"].pop((src.data_ptr(), win["k"]), None)
+            if w is not None:
+                w.wait()
+            ex.transform_dual(spec, b, src, out, out_d, ncomp * cw, inner, dscale, xb=tuple(kw["xb"]) + (z0, cw))
+            return out, out_d
         if self._x_step_by_component(src, ncomp):
             for c in range(ncomp):
                 self.wait_for(src[c:c + 1])
@@ -540,6 +620,47 @@ class Transformer:
         """tiled_row: the coefficient rows (the last transform's output, `c`) are written tile-major, rows of
         nx * tiled_row doubles (Executor.transform; only where `tiled_forward_ok` said so)."""
         self.forward_begin(domain, ncomp, g, scales, c, skip_last=skip_last, tiled_row=tiled_row)()
+
+    def forward_windows(self, domain, ncomp, scales, c, tiled_row=0):
+        """The forward transform of a product evaluated in windows of z planes (windows_begin): an object whose
+        push(k, pg_k) runs the x step of window k ([ncomp][cw][Gx][..] pre-grid data) into the window's place of the
+        exchanged layout and starts that window's parts of the pencil transpose, and whose finish() waits for all parts and
+        runs the z step into `c`.  Pre-grid layout only (the last axis is the fused stage's): steps z, x."""
+        ex = self.dist.executor
+        steps = self._steps(domain, scales)[:-1]
+        if [p for p, _, _ in steps] != [0, 1] or not self._needs_exchange(domain) or self.stage_xb(domain, scales) is None:
+            raise RuntimeError("forward_windows: z / x steps around a blocked pencil transpose only")
+        (_, bz, zspec), (_, bx, xspec) = steps
+        xb = self.stage_xb(domain, scales)
+        P = self.dist.size
+        K = self._win["K"]
+        full = list(self.pregrid_shape(domain, ncomp, scales, window=False))     # [ncomp][gz][Gx][rest..]
+        gz, rest = full[1], int(np.prod(full[3:]))
+        cw = gz // K
+        nx = bx.coeff_size
+        rows = nx // P
+        send = ex.empty((ncomp, gz, nx) + tuple(full[3:]))          # blocked: [comp][p][gz][rows][rest]
+        recv = ex.empty((ncomp, gz * P, rows) + tuple(full[3:]))    # [comp][Gz][nx_loc][rest]
+        works = []
+        tr = self
+
+        class _Fwd:
+            def push(self_, k, pg):
+                z0 = k * cw
+                ex.transform(xspec, bx, "forward", pg, send, ncomp * cw, rest, xb=tuple(xb[1]) + (z0, cw))
+                works.append(tr.dist.pcomm.all_to_all_start(recv.reshape(-1), send.reshape(-1),
+                                                            part=(z0 * rows * rest, cw * rows * rest), batch=ncomp))
+                tr.dist.pcomm.stats["exchanges"] += ncomp
+
+            def finish(self_):
+                for w in works:
+                    w.wait()
+                del works[:]
+                kw = dict(xb=xb[0]) if xb[0] else {}
+                if tiled_row:
+                    kw["tiled_row"] = tiled_row
+                ex.transform(zspec, bz, "forward", recv, c, ncomp, rows * rest, **kw)
+        return _Fwd()
 
     def forward_begin(self, domain, ncomp, g, scales, c, skip_last=False, tiled_row=0):
         """forward_data in two halves: runs the transforms up to the pencil transpose and STARTS it (blocked stage layout on
@@ -578,8 +699,8 @@ class Transformer:
                         if blocked:
                             # blocked x side: the x transform has written [comp][p][Gz / P][nx_loc][..] -- a component is sent
                             # as it lies and received as the component [Gz][nx_loc][..]: no kernel at all
-                            works = [self.dist.pcomm.all_to_all_start(tmp[cc:cc + 1].reshape(-1), src[cc:cc + 1].reshape(-1))
-                                     for cc in range(nc)]
+                            works = [self.dist.pcomm.all_to_all_start(tmp.reshape(-1), src.reshape(-1),
+                                                                      part=(0, Gzl * (nx // P) * rest), batch=nc)]
                             self.dist.pcomm.stats["exchanges"] += nc
                         elif nc > 1 and _overlap():
                             n1 = Gzl * nx * rest

@@ -494,6 +494,10 @@ class Evaluator:
         dv = store.get(dvec.tobytes())
         if dv is None:
             dv = store[dvec.tobytes()] = self.dist.executor.from_host(dvec)
+        if self.dist.size > 1:
+            order = self.__dict__.setdefault("_stage1_order", [])
+            if all(x is not leaf for x in order):
+                order.append(leaf)                  # prefetch_stage1 (reached here before eval_stage(leaf, 1) ever ran)
         coeff, ctile = self._stage0(leaf)
         plain, der = self.dist.transformer.backward_dual_z(leaf.domain, xdomain, leaf.ncomp, coeff, leaf.domain.dealias, dv,
                                                            **(dict(ctile=ctile) if ctile else {}))
@@ -702,6 +706,10 @@ class Evaluator:
     def _le_to_grid(self, le, domain, ncomp, scales, skip_last=False):
         """Grid (or pre-grid) data of a linear expression given as a LinExpr on `domain`."""
         tr = self.dist.transformer
+        if skip_last:
+            self._generic_pregrid = True            # (a whole-array operand of the grid stage: no windows, windows_possible)
+            if getattr(tr, "_win", None) is not None and tr._win["k"] is not None:
+                raise RuntimeError("windowed evaluation met a generic pre-grid operand")
         if not _full_sep(self.dist, domain):
             raise NotImplementedError("evaluating expressions without all Fourier bases")
         jac = [ax for ax in self.dist._jacobi_axes if domain.by_axis[ax] is not None]
@@ -808,7 +816,18 @@ class Evaluator:
         if settle is not None:
             settle()                            # no exchange outlives the pass that started it
 
-    def prefetch_stage1(self):
+    def window_cache_reset(self):
+        """Between two windows of z planes (Transformer windows): everything computed from a window is dropped, the fields'
+        coefficient data and their z-step results (whole arrays, exchanged in windows) stay."""
+        self.cache = {k: v for k, v in self.cache.items()
+                      if (k[0] == "s" and k[2] <= 1) or k[0] == "sz"}
+
+    def windows_possible(self):
+        """The previous pass evaluated every pre-grid operand through the stage cache (eval_stage / _z_dual): only then
+        can the grid stage run in windows (a generic operand is a whole array)."""
+        return bool(self.__dict__.get("_stage1_order")) and not self.__dict__.get("_generic_pregrid", False)
+
+    def prefetch_stage1(self, force=False):
         """Several ranks: issue the z step (and with it the pencil transposes, which return without waiting:
         Transformer._defer) of every field the previous pass transformed, in that pass's order, before anything consumes
         one -- the exchanges queue up on the communicator's stream and the wire of a later field runs under the x transforms
@@ -817,7 +836,7 @@ class Evaluator:
         it on: under an emulated wire it measured neutral (the grid stage needs every operand, so only the x transforms
         are there to hide the wire behind: profiles/r6_rank_emulation.txt) and it is off by default."""
         order = self.__dict__.get("_stage1_order")
-        if not order or self.dist.size == 1 or os.environ.get("DDH_A2A_PREFETCH", "0") != "1":
+        if not order or self.dist.size == 1 or (not force and os.environ.get("DDH_A2A_PREFETCH", "0") != "1"):
             return
         for leaf in order:
             self.eval_stage(leaf, 1)

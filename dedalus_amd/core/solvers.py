@@ -667,7 +667,8 @@ class SolverBase:
         whose address the allocator may hand out again after unrelated data lived there -- is zeroed on every call."""
         ev, ex = self.evaluator_core, self.ex
         ev.new_pass()
-        ev.prefetch_stage1()                    # several ranks: every field's z step + exchange start before the first x step
+        if self._grid_windows() == 1:
+            ev.prefetch_stage1()                # several ranks (DDH_A2A_PREFETCH): every field's z step + exchange start first
         if tiled_row and self.F_direct is None:
             raise RuntimeError("tile-major right-hand sides need the direct-F plan")
         if self.F_direct is not None:
@@ -677,6 +678,13 @@ class SolverBase:
                 ex.fill_zero(out)
                 if persistent:
                     self._F_zeroed.add(key)
+            K = self._grid_windows()
+            if K > 1:
+                self._evaluate_F_windows(out, K, tiled_row)
+                ev.new_pass()
+                if self.F_const is not None:
+                    ex.scatter_set(out, self.F_const)
+                return
             for grp in self.nl_fused:
                 outs = [ex.empty(tr.pregrid_shape(leaf.domain, leaf.ncomp, leaf.domain.dealias))
                         for (leaf, row0, rows), fp in grp]
@@ -730,6 +738,61 @@ class SolverBase:
             ex.lincomb(out, parts, [1.0] * len(parts))      # parts[0] is out itself
         if self.F_const is not None:
             ex.scatter_add(out, self.F_const)               # a handful of entries of the k = 0 pencil
+
+    def _grid_windows(self):
+        """Number of windows of z planes the grid stage of a sharded evaluation runs in (Transformer windows): several
+        ranks with the blocked stage layout, every product through the fused stage, every operand through the stage
+        cache (known after the first, un-windowed pass), DDH_A2A_WINDOWS = K dividing this rank's planes (default 2: under
+        an emulated 75 GB/s wire a P = 8 rank steps in 10.0 instead of 12.6 ms, 4 windows in 10.4; 1 = off)."""
+        K = int(os.environ.get("DDH_A2A_WINDOWS", "2"))
+        if K <= 1 or self.dist.size == 1 or self.F_direct is None or not self.nl_fused:
+            return 1
+        ev, tr = self.evaluator_core, self.dist.transformer
+        if not ev.windows_possible() or not hasattr(tr, "windows_begin") or os.environ.get("DDH_A2A_DEFER", "1") == "0":
+            return 1
+        for grp in self.nl_fused:
+            for (leaf, row0, rows), fp in grp:
+                edom = self.F_direct[id(leaf)][0]["eq"]["domain"]
+                if tr.stage_xb(edom, edom.dealias) is None or tr.stage_xb(leaf.domain, leaf.domain.dealias) is None:
+                    return 1
+                gz = tr.pregrid_shape(leaf.domain, leaf.ncomp, leaf.domain.dealias, window=False)[1]
+                if gz % K:
+                    return 1
+        return K
+
+    def _evaluate_F_windows(self, out, K, tiled_row):
+        """evaluate_F (direct branch) with the grid stage in K windows of z planes: z steps of every operand field, their
+        exchanges queued window by window, then per window the x steps, the fused launches and the x forward steps -- whose
+        parts of the forward exchange are on the wire while the next window computes -- and at the end the z forward steps."""
+        ev, ex, tr = self.evaluator_core, self.ex, self.dist.transformer
+        tr.windows_begin(K)
+        try:
+            ev.prefetch_stage1(force=True)              # every field's z step; the transposes are registered, not started
+            tr.windows_start_exchanges()
+            fwd = {}
+            for k in range(K):
+                tr.window_set(k)
+                ev.window_cache_reset()
+                for gi, grp in enumerate(self.nl_fused):
+                    outs = [ex.empty(tr.pregrid_shape(leaf.domain, leaf.ncomp, leaf.domain.dealias))
+                            for (leaf, row0, rows), fp in grp]
+                    ev.eval_fused_products([(item[0], fp) for item, fp in grp], outs,
+                                           scales=[self.F_direct[id(item[0])][1] for item, fp in grp])
+                    for pi, (((leaf, row0, rows), fp), pg) in enumerate(zip(grp, outs)):
+                        if (gi, pi) not in fwd:
+                            einfo = self.F_direct[id(leaf)][0]
+                            edom = einfo["eq"]["domain"]
+                            dst = out[einfo["row0"]:einfo["row0"] + einfo["rows"]].reshape(
+                                (leaf.ncomp,) + tuple(edom.storage_coeff_shape()))
+                            tr.window_set(None)
+                            fwd[(gi, pi)] = tr.forward_windows(edom, leaf.ncomp, edom.dealias, dst, tiled_row=tiled_row)
+                            tr.window_set(k)
+                        fwd[(gi, pi)].push(k, pg)
+            tr.window_set(None)
+            for f in fwd.values():
+                f.finish()
+        finally:
+            tr.windows_end()
 
     # ---- un-aliased variables (no separable bases): tiny copies around each solve ---------------------------
     def push_unaliased(self):

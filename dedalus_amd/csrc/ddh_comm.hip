@@ -233,6 +233,41 @@ int ddh_comm_alltoall(ddh_handle comm, const double *send, double *recv, long ch
     return 0;
 }
 
+// A PART of such an all-to-all: `count` doubles per peer, the blocks `peer_stride` doubles apart (send / recv point at the
+// part of block 0).  A component exchanged in windows of its planes: window k of [p][z][rows][ky] is one contiguous range
+// per peer, and the grid stage of window k runs while window k + 1 is on the wire (Transformer windows, core/distributor.py).
+// `nbatch` such exchanges `batch_stride` doubles apart (the components of a field) go out as ONE group of sends / receives.
+int ddh_comm_alltoall_part(ddh_handle comm, const double *send, double *recv, long count, long peer_stride, int nbatch,
+                           long batch_stride, void *stream) {
+    Comm *c = (Comm *)lookup_handle(comm, H_COMM);
+    if (!c) return -1;
+    if (!send || !recv || count < 0 || peer_stride < count || nbatch < 1 || (nbatch > 1 && batch_stride < 1))
+        return fail("ddh_comm_alltoall_part: bad argument");
+    if (send == recv) return fail("ddh_comm_alltoall_part: send and receive buffers must differ");
+    hipStream_t s = as_stream(stream);
+    if (count == 0) return 0;
+    const size_t st = (size_t)peer_stride, bs = (size_t)batch_stride;
+    if (c->loopback || c->nranks == 1) {
+        // every block -- the rank's own and, in place of the wire, the ones it would have received -- as one strided copy
+        for (int b = 0; b < nbatch; ++b)
+            DDH_HIP(hipMemcpy2DAsync(recv + b * bs, st * sizeof(double), send + b * bs, st * sizeof(double),
+                                     (size_t)count * sizeof(double), (size_t)c->nranks, hipMemcpyDeviceToDevice, s));
+        return c->nranks == 1 ? 0 : loopback_wire(c, (size_t)nbatch * (size_t)count * sizeof(double), s);
+    }
+    for (int b = 0; b < nbatch; ++b)
+        DDH_HIP(hipMemcpyAsync(recv + b * bs + (size_t)c->rank * st, send + b * bs + (size_t)c->rank * st,
+                               (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, s));
+    DDH_NCCL(g_rccl.GroupStart());
+    for (int b = 0; b < nbatch; ++b)
+        for (int p = 0; p < c->nranks; ++p) {
+            if (p == c->rank) continue;
+            DDH_NCCL(g_rccl.Send(send + b * bs + (size_t)p * st, (size_t)count, ncclDouble, p, c->comm, s));
+            DDH_NCCL(g_rccl.Recv(recv + b * bs + (size_t)p * st, (size_t)count, ncclDouble, p, c->comm, s));
+        }
+    DDH_NCCL(g_rccl.GroupEnd());
+    return 0;
+}
+
 // uneven blocks: rank p owns [p B, min((p + 1) B, n)) of an axis of length n, B = ceil(n / P) (Layout.local_chunks,
 // core/distributor.py; Alltoallv transposes core/transposes.pyx:287-445)
 static inline long blk_lo(long n, long B, int p) { return (p * B < n) ? p * B : n; }

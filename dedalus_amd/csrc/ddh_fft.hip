@@ -1501,6 +1501,20 @@ int ddh_fft_set_coeff_tiled(ddh_handle plan, long row_len, long band_rows) {
     return 0;
 }
 
+/* Real-Fourier plan with the blocked stage layout (ddh_fft_set_stage_layout / _block): the next strided transforms cover
+ * planes z0 .. z0 + nplanes of every component only -- the array on the other side holds nplanes planes per component,
+ * outer = components x nplanes.  nplanes = 0: all planes again.  The grid stage of a sharded run in windows of z planes,
+ * pipelined against windowed exchanges (ddh_comm_alltoall_part). */
+int ddh_fft_set_stage_window(ddh_handle plan, int z0, int nplanes) {
+    FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
+    if (!pl) return -1;
+    if (pl->tkind != K_RFFT) return fail("ddh_fft_set_stage_window: real-Fourier plans");
+    if (z0 < 0 || nplanes < 0) return fail("ddh_fft_set_stage_window: bad window");
+    pl->dev.xbw0 = (unsigned)z0;
+    pl->dev.xbwn = (unsigned)nplanes;
+    return 0;
+}
+
 int ddh_cheb_forward_tiled(ddh_handle plan, const double *g, double *c, long outer, long inner, long row_len, void *stream) {
     FftPlan *pl = (FftPlan *)lookup_handle(plan, H_FFT);
     if (!pl) return -1;

@@ -61,6 +61,8 @@ struct FftDev {
     int ld;                // LDS leading dimension of the FFT buffer (>= N)
     unsigned long long *prof;   // optional phase timing (debug): [load, fft, store, count]
     unsigned xb;                // != 0: x-blocked stage layout on the INTERMEDIATE side of a strided wave transform
+    unsigned xbw0, xbwn;        // xbwn != 0: the launch covers planes xbw0 .. xbw0 + xbwn of EVERY component (a window of this
+                                // rank's z planes: outer = components x xbwn), the other side holding xbwn planes per component
     unsigned xbB;               // rows per block of that layout on the coefficient side of a real-Fourier transform (0 = 64)
                                 // (ddh_fft_set_stage_layout): Chebyshev plans: row length ny; real-FFT plans: z planes gz
     unsigned long cband;        // != 0 (with ctile_nseg): the tile-major coefficient rows are kx-band-major, [kx / 8][row][ky / 8][8][8]:

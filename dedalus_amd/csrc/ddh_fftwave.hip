@@ -403,7 +403,14 @@ wave_rfft_kernel(FftDev p, WaveArgs a) {
             // coefficient side = the stage array [comp][kx / B][z][kx % B][ky], o = comp * gz + z (p.xb = gz; B = 64 on one
             // rank, nx / P in a sharded run: the layout [p][z][nx / P][ky] the exchange delivers / takes)
             const unsigned B = p.xbB ? p.xbB : 64u;
-            const unsigned comp = o / p.xb, z = o - comp * p.xb;
+            unsigned comp, z;
+            if (p.xbwn) {                                // a window of every component's planes (ddh_fft_set_stage_window)
+                comp = o / p.xbwn;
+                z = p.xbw0 + (o - comp * p.xbwn);
+            } else {
+                comp = o / p.xb;
+                z = o - comp * p.xb;
+            }
             oc = ((long)comp * M * p.xb + (long)B * z) * inner + 2 * pair0;
             rsb64 = (unsigned)(B * p.xb) * rsb;
             bsh = (B == 64u) ? 1 : ((B == 128u) ? 2 : 3);
@@ -454,7 +461,9 @@ int wave_axis_try(int mode, const FftDev &d, const double *src, double *dst, lon
         } else if (mode == RFFT_FWD || mode == RFFT_BWD) {
             const unsigned long B = d.xbB ? d.xbB : 64UL;
             if (!(B == 64 || B == 128 || B == 256)) return 1;
-            if (outer % d.xb || d.M % B || (unsigned long)d.xb * B * (unsigned long)inner * 8UL * (unsigned long)(d.M / B) >= 0xffffffffUL) return 1;
+            // (outer: whole components of gz planes each, or of the xbwn planes of a window)
+            if (d.xbwn && (d.xbw0 + d.xbwn > d.xb)) return 1;
+            if (outer % (d.xbwn ? d.xbwn : d.xb) || d.M % B || (unsigned long)d.xb * B * (unsigned long)inner * 8UL * (unsigned long)(d.M / B) >= 0xffffffffUL) return 1;
         } else {
             return 1;
         }

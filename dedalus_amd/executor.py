@@ -190,15 +190,22 @@ class HipExecutor:
         value: 0 natural; an int (row length ny for a Chebyshev plan, z planes gz for a real-Fourier plan, blocks of 64
         rows); or (gz, rows) for a real-Fourier plan with blocks of `rows` = nx / P rows (ddh_fft_set_stage_block: the layout
         the all-to-all of a sharded run delivers)."""
-        block = 0
+        block, z0, cw = 0, 0, 0
         if isinstance(value, tuple):
-            value, block = value
+            if len(value) == 4:                 # (gz, rows, z0, planes): a window of every component's planes
+                value, block, z0, cw = value
+            else:
+                value, block = value
         cur = self.__dict__.setdefault("_layouts", {})
         if cur.get(h.value, (0, 0)) != (int(value), int(block)):
             libhip.call("ddh_fft_set_stage_layout", h, int(value))
             if int(block) != cur.get(h.value, (0, 0))[1]:
                 libhip.call("ddh_fft_set_stage_block", h, int(block))
             cur[h.value] = (int(value), int(block))
+        wcur = self.__dict__.setdefault("_windows", {})
+        if wcur.get(h.value, (0, 0)) != (int(z0), int(cw)):
+            libhip.call("ddh_fft_set_stage_window", h, int(z0), int(cw))
+            wcur[h.value] = (int(z0), int(cw))
 
     # (grid, coefficient) sizes the wave-per-four-line-pairs kernels are instantiated for (csrc/ddh_fftwave.hip:
     # DDH_CHEB_WAVE_SIZES, launch_wave_rfft_kind)

@@ -97,6 +97,7 @@ SIGNATURES = {
     "ddh_cheb_forward_tiled": [_h, _vp, _vp, _l, _l, _l, _vp],
     "ddh_fft_set_stage_layout": [_h, _l],
     "ddh_fft_set_stage_block": [_h, _i],
+    "ddh_fft_set_stage_window": [_h, _i, _i],
     "ddh_fft_wave_launches": [C.POINTER(_l)],
     "ddh_cheb_backward": [_h, _vp, _vp, _l, _l, _vp],
     "ddh_plan_mmt": [_hp, _i, _i, _dp],
@@ -140,6 +141,7 @@ SIGNATURES = {
     "ddh_comm_info": [_h, _ip, _ip],
     "ddh_comm_allreduce": [_h, _vp, _l, _i, _vp],
     "ddh_comm_alltoall": [_h, _vp, _vp, _l, _vp],
+    "ddh_comm_alltoall_part": [_h, _vp, _vp, _l, _l, _i, _l, _vp],
     "ddh_a2a_plan": [_hp, _h, _l, _l, _l, _l],
     "ddh_a2a_plan_blocks": [_hp, _h, _l, _l, _l, _l, _l, _l],
     "ddh_a2a_localize_rows": [_h, _vp, _vp, _vp],

@@ -242,11 +242,30 @@ class Comm:
         else:
             self.dist.all_to_all_single(recv.reshape(-1), send.reshape(-1))
 
-    def all_to_all_start(self, recv, send):
+    def all_to_all_start(self, recv, send, part=None, batch=1):
         """Start an equal-split all-to-all and return a handle with .wait(): on device buffers with RCCL the exchange
         runs on the communicator's stream while the caller keeps launching kernels; the numpy / host-staged test
-        configurations complete immediately."""
+        configurations complete immediately.  part = (offset, count): only `count` elements at `offset` of every peer's
+        block are exchanged (ddh_comm_alltoall_part: one window of a component's planes); batch = n: send / recv hold n
+        such components one after the other, exchanged as one group."""
         t = self.torch
+        if part is not None and (isinstance(send, np.ndarray) or self.library_comm() is None or
+                                 (send.is_cuda and self.backend == "gloo")):
+            # test configurations: the parts gathered into contiguous buffers around the whole-buffer exchange
+            off, cnt = part
+            P = self.size
+            for bi in range(batch):
+                s2 = send.reshape(batch, P, -1)[bi, :, off:off + cnt]
+                r2 = recv.reshape(batch, P, -1)[bi]
+                if isinstance(send, np.ndarray):
+                    tmp = np.empty((P, cnt))
+                    self.all_to_all(tmp, np.ascontiguousarray(s2))
+                    r2[:, off:off + cnt] = tmp
+                else:
+                    tmp = t.empty((P, cnt), dtype=send.dtype, device=send.device)
+                    self.all_to_all(tmp, s2.contiguous())
+                    r2[:, off:off + cnt] = tmp
+            return _Done()
         if isinstance(send, np.ndarray) or (send.is_cuda and self.backend == "gloo"):
             self.all_to_all(recv, send)
             return _Done()
@@ -268,14 +287,24 @@ class Comm:
             if timed:
                 e0 = t.cuda.Event(enable_timing=True)
                 e0.record(self._side)
-            libhip.call("ddh_comm_alltoall", h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
-                        send.numel() // self.size, C.c_void_p(self._side.cuda_stream))
+            if part is None:
+                libhip.call("ddh_comm_alltoall", h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
+                            send.numel() // self.size, C.c_void_p(self._side.cuda_stream))
+                sent = send.numel() * 8 * (self.size - 1) // self.size
+            else:
+                off, cnt = part
+                per = send.numel() // batch
+                libhip.call("ddh_comm_alltoall_part", h, C.c_void_p(send.data_ptr() + 8 * off),
+                            C.c_void_p(recv.data_ptr() + 8 * off), int(cnt), per // self.size, int(batch), per,
+                            C.c_void_p(self._side.cuda_stream))
+                sent = batch * cnt * 8 * (self.size - 1)
             done = t.cuda.Event(enable_timing=timed)
             done.record(self._side)
             if timed:
                 self.wire_events.append((e0, done))
-            self.note_via("ddh_comm_alltoall (%s, side stream)" % ("loop-back communicator" if self.backend == "loopback" else "library RCCL"),
-                          send.numel() * 8 * (self.size - 1) // self.size)
+            self.note_via("ddh_comm_alltoall%s (%s, side stream)" % ("_part" if part is not None else "",
+                                                                     "loop-back communicator" if self.backend == "loopback" else "library RCCL"),
+                          sent)
             return _StreamWork(t, done, (send, recv))
         self.note_via("torch.distributed.all_to_all_single (%s, async)" % self.backend,
                       send.numel() * 8 * (self.size - 1) // self.size)

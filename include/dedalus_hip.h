@@ -525,6 +525,14 @@ int ddh_comm_allreduce(ddh_handle comm, double *buf, long count, int op, void *s
  * block p (`chunk` doubles) of `send` goes to rank p, block q of `recv` comes from rank q; grouped ncclSend / ncclRecv,
  * the rank's own block as a device copy; asynchronous on `stream` */
 int ddh_comm_alltoall(ddh_handle comm, const double *send, double *recv, long chunk, void *stream);
+/* a PART of such an exchange: `count` doubles per peer, the peers' blocks `peer_stride` doubles apart; send / recv point at
+ * the part inside block 0.  One window of the planes of a component stored [p][z][rows][ky] (the reference exchanges whole
+ * fields, core/transposes.pyx:329-358; windows let the grid stage of one window run while the next is on the wire). */
+int ddh_comm_alltoall_part(ddh_handle comm, const double *send, double *recv, long count, long peer_stride, int nbatch,
+                           long batch_stride, void *stream);      /* nbatch such exchanges batch_stride apart (the components of a field) as ONE group */
+/* ... and the x transforms of one window: planes z0 .. z0 + nplanes of every component of the blocked stage array
+ * (ddh_fft_set_stage_layout / _block), the other side holding nplanes planes per component; nplanes = 0: all planes */
+int ddh_fft_set_stage_window(ddh_handle plan, int z0, int nplanes);
 
 /* Transpose plan = FFTWTranspose / AlltoallvTranspose (core/transposes.pyx:22-445, planner interface
  * core/distributor.py:696-768): (n0, n1, n2, n3) is the reference's reduced GLOBAL shape (N0, N1, N2, N3) around the

@@ -71,6 +71,7 @@ def main():
         res["stage_xb"] = np.array([-1, -1, -1] if xb is None else [int(xb[0]), int(xb[1][0]), int(xb[1][1])] if isinstance(xb[1], tuple)
                                    else [int(xb[0]), int(xb[1]), 64])
         res["via"] = np.array(sorted(solver.dist.pcomm.via)) if solver.dist.pcomm is not None else np.array([])
+        res["windows"] = np.array(solver._grid_windows() if hasattr(solver, "_grid_windows") else 1)
     elif case == "shell_cfl":
         solver, dts, speeds, res = problems.run_shell_cfl_case(d3, dist_kw=dist_kw)
         res = dict(res, dts=np.array(dts), speeds=np.array(speeds))

@@ -340,14 +340,17 @@ def test_deferred_exchange_schedules_compute_the_same_state_under_an_emulated_wi
     """Rank 1 of 2 of 3-D RB 128 x 16 x 32 (blocks of 64 rows: the blocked exchange) on the loop-back communicator with
     every exchange followed by an emulated wire time on its stream (DDH_LOOPBACK_LINK_GBPS, slow enough that a consumer
     that did not wait would read stale data): the schedules of the exchange -- waits at the exchange, waits deferred to the
-    consumer (default), x steps component by component, all z steps first -- end in bit-identical states."""
+    consumer, x steps component by component, all z steps first, the grid stage in 2 (default) / 4 windows of z planes
+    pipelined against windowed exchanges -- end in bit-identical states."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     shas = {}
-    for name, env in (("eager", {"DDH_A2A_DEFER": "0"}), ("deferred", {}), ("split", {"DDH_A2A_SPLIT_X": "1"}),
-                      ("prefetch+split", {"DDH_A2A_PREFETCH": "1", "DDH_A2A_SPLIT_X": "1"})):
+    for name, env in (("eager", {"DDH_A2A_DEFER": "0"}), ("deferred", {"DDH_A2A_WINDOWS": "1"}),
+                      ("split", {"DDH_A2A_SPLIT_X": "1", "DDH_A2A_WINDOWS": "1"}),
+                      ("prefetch+split", {"DDH_A2A_PREFETCH": "1", "DDH_A2A_SPLIT_X": "1", "DDH_A2A_WINDOWS": "1"}),
+                      ("2 windows (default)", {}), ("4 windows", {"DDH_A2A_WINDOWS": "4"})):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "rank_emulation.py"), "--ranks", "2", "--rank", "1",
                             "--size", "128,16,32", "--steps", "3", "--warmup", "1", "--link-gbps", "0.5"],
                            capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, **env))

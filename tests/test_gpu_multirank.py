@@ -72,7 +72,7 @@ def test_blocked_and_unpacked_exchanges_take_the_same_steps(nx, world, rows):
     """Blocks of nx / world = 128, 256 and 64 rows: the blocked exchange (x transforms on the exchanged layout, no pack /
     unpack kernels: the default) and the round-5 pack / exchange / unpack path (DDH_A2A_BLOCKED=0) give bit-identical
     states -- and so do the blocked exchange's schedules: waits deferred to the consumer (default) or not, the x steps
-    component by component behind the arrivals, every field's z step issued first."""
+    component by component behind the arrivals, every field's z step issued first, the grid stage in windows of z planes."""
     case = "rb3dsize_%dx16x32" % nx
     a = _run_sharded(case, world, {})
     b = _run_sharded(case, world, {"DDH_A2A_BLOCKED": "0"})
@@ -81,6 +81,12 @@ def test_blocked_and_unpacked_exchanges_take_the_same_steps(nx, world, rows):
     if rows == 128:
         others += [_run_sharded(case, world, env) for env in ({"DDH_A2A_DEFER": "0"}, {"DDH_A2A_SPLIT_X": "1"},
                                                               {"DDH_A2A_PREFETCH": "1", "DDH_A2A_SPLIT_X": "1"})]
+    # the grid stage in 2 / 4 windows of this rank's z planes, the exchanges in parts (Transformer windows)
+    assert int(a[0]["windows"]) == 2                     # (the default)
+    for K in ("1", "4"):
+        w = _run_sharded(case, world, {"DDH_A2A_WINDOWS": K})
+        assert int(w[0]["windows"]) == int(K), w[0]["windows"]
+        others.append(w)
     for other in others:
         for ra, rb in zip(a, other):
             for key in ("p", "b", "u"):

@@ -75,6 +75,10 @@ PY
                 done ;;
     emu)        # one rank of the P-rank run on this GPU, loop-back exchange (profiles/r6_rank_emulation.txt)
                 python tools/rank_emulation.py --ranks 2,4,8 --rank 1 --steps 10 --warmup 3 ${ONE_GPU_MS:+--single-gpu-ms $ONE_GPU_MS} > $OUT/rank_emulation.jsonl 2> $OUT/rank_emulation.txt; cat $OUT/rank_emulation.txt ;;
+    emu-final)  # final table: windows 1 / 2 with and without the emulated wire, P = 2, 4, 8
+                for w in 1 2; do for link in 75 0; do
+                  echo "DDH_A2A_WINDOWS=$w link $link"; DDH_A2A_WINDOWS=$w python tools/rank_emulation.py --ranks 2,4,8 --rank 1 --steps 10 --warmup 8 --link-gbps $link 2>&1 >> $OUT/rank_emulation_final.jsonl | cut -c1-330
+                done; done 2>&1 | tee $OUT/rank_emulation_final.txt ;;
     emu-wire)   # the same with the loop-back exchanges followed by an emulated wire time at 75 GB/s per link: how much of it is hidden
                 python tools/rank_emulation.py --ranks 2,4,8 --rank 1 --steps 10 --warmup 8 --link-gbps 75 > $OUT/rank_emulation_wire.jsonl 2> $OUT/rank_emulation_wire.txt; cat $OUT/rank_emulation_wire.txt
                 python tools/rank_emulation.py --ranks 2,4,8 --rank 1 --steps 10 --warmup 8 > $OUT/rank_emulation.jsonl 2> $OUT/rank_emulation.txt; cat $OUT/rank_emulation.txt ;;
@@ -89,6 +93,10 @@ PY
                   python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print('   parity', {k: d['parity'][k] for k in ('max_residual', 'max_solution_error')})" $OUT/bench_xtiled.json
                 done
                 DDH_X_TILED_MIN=0 DDH_RHS_TILING_MIN=0 python -m pytest tests/test_gpu_ivp.py tests/test_gpu_baseline_sizes.py tests/test_gpu_reference_pencils.py tests/test_gpu_examples.py tests/test_gpu_state_tiling.py -x -q -m gpu > $OUT/pytest_xtiled.txt 2>&1; tail -5 $OUT/pytest_xtiled.txt ;;
+    emu-windows) # the grid stage in windows of z planes pipelined against windowed exchanges, under an emulated wire
+                python -m pytest tests/test_gpu_multirank.py -x -q -m gpu > $OUT/pytest_multirank.txt 2>&1; tail -3 $OUT/pytest_multirank.txt
+                for P in 8 4; do for v in 1 2 4; do
+                  echo "P=$P DDH_A2A_WINDOWS=$v"; env DDH_A2A_WINDOWS=$v python tools/rank_emulation.py --ranks $P --rank 1 --steps 10 --warmup 8 --link-gbps 75 2>&1 >/dev/null | cut -c1-220; done; done 2>&1 | tee $OUT/emu_windows_ab.txt ;;
     bwd-rowmajor) # timing experiment: the backward sweep reading the factor rows as if stored row-major over the blocks
                 for v in 0 128; do DDH_BWD_DBG=$v python bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-cfl --no-parity > $OUT/bench_bwddbg$v.json 2> $OUT/bench_bwddbg$v.err
                   echo "DDH_BWD_DBG=$v"; bench_line $OUT/bench_bwddbg$v.json; done ;;
