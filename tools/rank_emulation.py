@@ -6,8 +6,9 @@ core/transposes.pyx:359-445, core/distributor.py:770-924).
 
 The problem is decomposed exactly as for P ranks (Distributor(mesh=(P,)): this process owns rank r's kx block of the
 pencils and rank r's z planes of the grid) and runs rank r's REAL work through the production code path -- z transforms,
-pack kernels, the per-component side-stream pipeline around ddh_comm_alltoall / the transpose plans ddh_a2a_localize_*,
-unpack kernels, x transforms, fused y stage, sharded factor + solve.  The communicator is the library's loop-back one
+the side-stream exchanges (ddh_comm_alltoall_part: a field's components as one group, in windows of z planes; for sizes
+without the blocked stage layout pack kernels, ddh_comm_alltoall / the transpose plans ddh_a2a_localize_*, unpack kernels),
+x transforms, fused y stage, sharded factor + solve.  The communicator is the library's loop-back one
 (ddh_comm_create_loopback): what a peer would have sent is the block this rank sends to it, copied on the device, so every
 buffer size, kernel shape and stream dependency is that of the P-GPU run and only the wire is missing.  The wire is
 priced separately: bytes per peer / 75 GB/s (one xGMI link per peer and direction, MI355X_MICROARCH.md: 7 links x ~153
@@ -81,6 +82,7 @@ def one(rank, P, size, steps, warmup, dt):
                 predicted_ms_per_step_no_overlap=step_ms + wire_ms, predicted_ms_per_step_full_overlap=max(step_ms, wire_ms),
                 predicted_steps_per_s=dict(no_overlap=1e3 / (step_ms + wire_ms), full_overlap=1e3 / max(step_ms, wire_ms)),
                 ideal_share_ms=None, build_s=build_s, state_finite=finite, state_sha256=sha,
+                grid_stage_windows=int(solver._grid_windows()) if hasattr(solver, "_grid_windows") else 1,
                 emulated_link_GBps=float(os.environ.get("DDH_LOOPBACK_LINK_GBPS", 0) or 0),
                 pencils_local=(Nx // 2 // P) * (Ny // 2), z_planes_local=(3 * Nz // 2) // P)
 
