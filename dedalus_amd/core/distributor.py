@@ -664,7 +664,7 @@ class Transformer:
 
     def forward_begin(self, domain, ncomp, g, scales, c, skip_last=False, tiled_row=0):
         """forward_data in two halves: runs the transforms up to the pencil transpose and STARTS it (blocked stage layout on
-        several ranks: component by component, each exchange starting as soon as its x transform is issued), and returns
+        several ranks: the components of the field as one group of sends / receives), and returns
         the function that waits for the arrivals and runs the remaining transforms.  A caller with several fields begins
         them all before it finishes the first (Solver.evaluate_F): the wire of one field runs under the x transforms of the
         next.  Without an exchange in flight everything happens in the first half and the returned function does nothing."""
