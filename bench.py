@@ -438,8 +438,12 @@ def main():
         exch = dict(via=via, per_rank_wire_bytes_per_step=wire_bytes, exchanges_per_step=sum(v[0] for v in via_counts.values()) / nst,
                     wire_ms_per_step_side_stream_rank0=wire_ms, timed_kernel_ms_per_step_rank0=kern_ms,
                     overlap_fraction=overlap,
+                    grid_stage_windows=int(solver._grid_windows()) if hasattr(solver, "_grid_windows") else 1,
+                    grid_stage_windows_note="the grid stage (x backward, fused y, x forward) runs in this many windows of the "
+                                            "rank's z planes, each window's exchange parts on the wire while another "
+                                            "window computes (DDH_A2A_WINDOWS; DESIGN.md section 6)",
                     overlap_note="(timed kernels + side-stream exchange time - step time) / exchange time on rank 0, clamped to "
-                                 "[0, 1]; the exchange time is HIP events around ddh_comm_alltoall on the side stream",
+                                 "[0, 1]; the exchange time is HIP events around ddh_comm_alltoall(_part) on the side stream",
                     per_link_GBps=(wire_bytes / max(world - 1, 1) / 1e9) / (wire_ms / 1e3) if wire_ms else None)
     chk2 = float(np.sum(np.asarray(fields["b"]["c"]) ** 2))
     if world > 1:
