@@ -33,6 +33,24 @@ def main():
     else:
         from oracle.np_executor import NumpyExecutor
         dist_kw = dict(executor=NumpyExecutor(), mesh=(world,))
+    if case == "a2a_part":
+        # a PART of every peer's block, several components as one group (parallel.Comm.all_to_all_start(part=, batch=)): the
+        # windowed exchanges of the sharded grid stage, here through the gloo stand-in on numpy and torch buffers
+        from dedalus_amd.parallel import Comm
+        pc = Comm(world)
+        nb, blk, off, cnt = 3, 10, 4, 5
+        send = np.empty((nb, world, blk))
+        for b_ in range(nb):
+            for p in range(world):
+                send[b_, p] = 1000 * rank + 100 * p + 10 * b_ + np.arange(blk) / 16.0     # (from rank, to p, component b_)
+        recv = np.full((nb, world, blk), -7.0)
+        pc.all_to_all_start(recv, send, part=(off, cnt), batch=nb).wait()
+        import torch
+        recv_t = torch.full((nb, world, blk), -7.0, dtype=torch.float64)
+        pc.all_to_all_start(recv_t, torch.from_numpy(send.copy()), part=(off, cnt), batch=nb).wait()
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), recv=recv, recv_t=recv_t.numpy(), send=send)
+        dist.destroy_process_group()
+        return
     if case.startswith("shell_conv_"):
         # m-sharded shell convection: local blocks of the packed coefficient arrays (+ tau_p, replicated)
         solver, res = problems.run_shell_convection(d3, steps=4, timestepper=case.split("_")[-1], dist_kw=dist_kw)

@@ -114,3 +114,20 @@ def test_sharded_solve_against_the_references_pencil_matrices(tmp_path):
     assert sum(int(p["npencils"]) for p in parts) == 16 and all(int(p["npencils"]) == 8 for p in parts)
     for p in parts:
         assert p["residual"].max() < 1e-13 and p["solution"].max() < 1e-11 and p["dropped"].max() == 0.0
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_partial_all_to_all_of_several_components(world):
+    """all_to_all_start(part=(offset, count), batch=n) -- the exchange of one window of z planes of a field's n components
+    (ddh_comm_alltoall_part on the GPUs) -- through its gloo stand-in: rank r receives from every peer q exactly the
+    elements [offset, offset + count) of q's block r of every component, and nothing else of its buffer changes."""
+    with tempfile.TemporaryDirectory() as tmp:
+        parts = _run_worker("a2a_part", world, tmp)
+    nb, blk, off, cnt = 3, 10, 4, 5
+    for r, me in enumerate(parts):
+        for key in ("recv", "recv_t"):
+            got = me[key]
+            want = np.full((nb, world, blk), -7.0)
+            for q in range(world):
+                want[:, q, off:off + cnt] = parts[q]["send"][:, r, off:off + cnt]
+            assert np.array_equal(got, want), (world, r, key)
