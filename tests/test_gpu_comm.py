@@ -317,6 +317,30 @@ def test_loopback_communicator_returns_the_rank_own_blocks(P, rank):
     libhip.call("ddh_destroy", h)
 
 
+@pytest.mark.parametrize("P,rank", [(2, 0), (8, 3)])
+def test_partial_exchange_on_the_loopback_communicator(P, rank):
+    """ddh_comm_alltoall_part (the windowed exchanges of the sharded grid stage): `count` doubles of every peer's block, the
+    blocks peer_stride apart, nbatch components batch_stride apart as one group -- on the loop-back communicator the parts
+    come back as they were sent and nothing else of the receive buffer is written."""
+    import ctypes as C
+    import torch
+    from dedalus_amd import libhip
+    from dedalus_amd.device import Device
+    dev = Device.get()
+    h = C.c_uint64(0)
+    libhip.call("ddh_comm_create_loopback", C.byref(h), rank, P)
+    nb, blk, off, cnt = 3, 500, 120, 250
+    send = torch.randn(nb, P, blk, dtype=torch.float64, device="cuda")
+    recv = torch.full_like(send, -7.0)
+    libhip.call("ddh_comm_alltoall_part", h, C.c_void_p(send.data_ptr() + 8 * off), C.c_void_p(recv.data_ptr() + 8 * off), cnt,
+                blk, nb, P * blk, dev.stream)
+    dev.sync()
+    want = torch.full_like(send, -7.0)
+    want[:, :, off:off + cnt] = send[:, :, off:off + cnt]
+    assert torch.equal(recv, want)
+    libhip.call("ddh_destroy", h)
+
+
 def test_rank_emulation_tool_runs_a_rank_of_a_sharded_problem():
     """tools/rank_emulation.py at a small size: rank 1 of 4 of 3-D Rayleigh-Benard 64 x 32 x 32 runs through the production
     pipeline (per-component side-stream exchanges + transpose plans) on the loop-back communicator and reports a finite

@@ -250,3 +250,38 @@ def test_fused_grid_stage_generations():
                             "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
         assert r.returncode == 0, (extra, r.stdout[-3000:] + r.stderr[-2000:])
         assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("N,M,B", [(384, 256, 64), (768, 512, 128), (192, 128, 64)])
+def test_windows_of_the_blocked_stage_layout_equal_the_whole_transform(dev, N, M, B):
+    """ddh_fft_set_stage_window (round 6: the grid stage of a sharded run in windows of z planes): planes z0 .. z0 + cw of
+    every component of the blocked stage array [comp][p][gz][B][ky], transformed into / out of an array that holds cw planes
+    per component, are bit for bit the planes of the transform over all gz planes -- backward, dual and forward."""
+    from dedalus_amd import libhip
+    from dedalus_amd.device import ptr
+    ncomp, gz, ky, cw = 2, 6, 16, 2
+    rng = np.random.default_rng(N + B)
+    h = C.c_uint64(0)
+    libhip.call("ddh_plan_rfft", C.byref(h), N, M)
+    libhip.call("ddh_fft_set_stage_layout", h, gz)
+    libhip.call("ddh_fft_set_stage_block", h, B)
+    stage = dev.from_host(rng.standard_normal((ncomp, M // B, gz, B, ky)))         # [comp][p][gz][B][ky]
+    full, full_d = dev.empty((ncomp, gz, N, ky)), dev.empty((ncomp, gz, N, ky))
+    libhip.call("ddh_rfft_backward_dual", h, ptr(stage), ptr(full), ptr(full_d), ncomp * gz, ky, 1.7, dev.stream)
+    grid = dev.from_host(rng.standard_normal((ncomp, gz, N, ky)))
+    back = dev.empty((ncomp, M // B, gz, B, ky))
+    libhip.call("ddh_rfft_forward", h, ptr(grid), ptr(back), ncomp * gz, ky, dev.stream)
+    win_back = dev.empty((ncomp, M // B, gz, B, ky))
+    win_back.fill_(float("nan"))
+    for z0 in range(0, gz, cw):
+        libhip.call("ddh_fft_set_stage_window", h, z0, cw)
+        w, wd, w1 = dev.empty((ncomp, cw, N, ky)), dev.empty((ncomp, cw, N, ky)), dev.empty((ncomp, cw, N, ky))
+        libhip.call("ddh_rfft_backward_dual", h, ptr(stage), ptr(w), ptr(wd), ncomp * cw, ky, 1.7, dev.stream)
+        libhip.call("ddh_rfft_backward", h, ptr(stage), ptr(w1), ncomp * cw, ky, dev.stream)
+        assert (w == full[:, z0:z0 + cw]).all() and (wd == full_d[:, z0:z0 + cw]).all() and (w1 == w).all()
+        gw = grid[:, z0:z0 + cw].contiguous()
+        libhip.call("ddh_rfft_forward", h, ptr(gw), ptr(win_back), ncomp * cw, ky, dev.stream)
+    libhip.call("ddh_fft_set_stage_window", h, 0, 0)
+    dev.sync()
+    assert (win_back == back).all()
+    libhip.call("ddh_destroy", h)
