@@ -667,7 +667,11 @@ class SolverBase:
         whose address the allocator may hand out again after unrelated data lived there -- is zeroed on every call."""
         ev, ex = self.evaluator_core, self.ex
         ev.new_pass()
+        work = self.__dict__.pop("_overlap_work", None) or []    # (state-only work of the caller: overlaps_rhs_work)
         if self._grid_windows() == 1:
+            for f in work:
+                f()
+            work = []
             ev.prefetch_stage1()                # several ranks (DDH_A2A_PREFETCH): every field's z step + exchange start first
         if tiled_row and self.F_direct is None:
             raise RuntimeError("tile-major right-hand sides need the direct-F plan")
@@ -680,7 +684,7 @@ class SolverBase:
                     self._F_zeroed.add(key)
             K = self._grid_windows()
             if K > 1:
-                self._evaluate_F_windows(out, K, tiled_row)
+                self._evaluate_F_windows(out, K, tiled_row, work)
                 ev.new_pass()
                 if self.F_const is not None:
                     ex.scatter_set(out, self.F_const)
@@ -760,7 +764,12 @@ class SolverBase:
                     return 1
         return K
 
-    def _evaluate_F_windows(self, out, K, tiled_row):
+    def overlaps_rhs_work(self):
+        """True when evaluate_F has a wait for the wire in it (the grid stage in windows on several ranks): the caller may
+        hand it state-only work (`_overlap_work`: the stage's mat-vecs) to issue under that wait instead of in front of it."""
+        return self._grid_windows() > 1
+
+    def _evaluate_F_windows(self, out, K, tiled_row, work=()):
         """evaluate_F (direct branch) with the grid stage in K windows of z planes: z steps of every operand field, their
         exchanges queued window by window, then per window the x steps, the fused launches and the x forward steps -- whose
         parts of the forward exchange are on the wire while the next window computes -- and at the end the z forward steps."""
@@ -789,6 +798,8 @@ class SolverBase:
                             tr.window_set(k)
                         fwd[(gi, pi)].push(k, pg)
             tr.window_set(None)
+            for f in work:                              # the caller's state-only kernels: under the last window's departure
+                f()
             for f in fwd.values():
                 f.finish()
         finally:

@@ -384,15 +384,23 @@ class RungeKuttaIMEX(_SolveMixin):
         tiled = self._tiled
         if tiled:
             own = dict(owned=True, tiled=True)
-        pack.matvec(s.M_id, s.X, self.MX0, **own)
+        # The mat-vecs of a stage read the state only: a solver whose right-hand-side evaluation has a wait in it (several
+        # ranks: the last window's forward exchange, SolverBase.evaluate_F) takes them as work to issue at that point.
+        later = []
+        defer_mv = bool(getattr(s, "overlaps_rhs_work", lambda: False)())
+        (later.append if defer_mv else (lambda f: f()))(lambda: pack.matvec(s.M_id, s.X, self.MX0, **own))
         combs = {}
         for i in range(1, self.stages + 1):
             j = i - 1                                   # s.X holds X_j
             if self._need_lx[j]:
                 if self._direct or j == 0:
-                    pack.matvec(s.L_id, s.X, self.LX[j])
+                    mv = (lambda j=j: pack.matvec(s.L_id, s.X, self.LX[j]))
                 else:
-                    pack.matvec(s.M_id, s.X, self.MX[j], **own)
+                    mv = (lambda j=j: pack.matvec(s.M_id, s.X, self.MX[j], **own))
+                (later.append if defer_mv else (lambda f: f()))(mv)
+            if later:
+                s._overlap_work = list(later)
+                del later[:]
             if tiled:
                 s.evaluate_F(self.F[i - 1], persistent=True, tiled_row=tiled)
             else:
